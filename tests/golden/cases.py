@@ -1,0 +1,101 @@
+"""Case table shared by make_golden.py (reference side, build container only) and
+the parity tests (oracle / HIP side).  Inputs are regenerated from seeds."""
+import hashlib
+
+import numpy as np
+
+
+def sha(a):
+    return hashlib.sha256(np.ascontiguousarray(a).tobytes()).hexdigest()
+
+
+def synth(n, sr, seed, tone_hz=1000.0, tone_amp=0.5, noise_sigma=0.1):
+    """float32-valued white noise + tone, returned as float64 copies (the dtype
+    the reference is fed)."""
+    rng = np.random.default_rng(seed)
+    t = np.arange(n, dtype=np.float64) / sr
+    y = noise_sigma * rng.standard_normal(n) + tone_amp * np.sin(2 * np.pi * tone_hz * t)
+    return y.astype(np.float32).astype(np.float64)
+
+
+# ---- variant S: reduce_noise(use_torch=False) -----------------------------
+S_CASES = {
+    # single chunk, defaults (per-stage taps stored)
+    "stat_1chunk": dict(sr=48000, n=40000, seed=11, kwargs=dict(stationary=True), stages=True),
+    "nonstat_1chunk": dict(sr=48000, n=40000, seed=12, kwargs=dict(stationary=False)),
+    # chunk grid: 4 chunks, last one partial
+    "stat_chunked": dict(sr=48000, n=90000, seed=13,
+                         kwargs=dict(stationary=True, chunk_size=25000, padding=4000)),
+    "nonstat_chunked": dict(sr=48000, n=90000, seed=14,
+                            kwargs=dict(stationary=False, chunk_size=25000, padding=4000)),
+    # 2 channels, explicit 2-D noise clip, partial reduction
+    "stat_2ch_noise": dict(sr=48000, n=30000, seed=15, channels=2, noise_len=20000,
+                           kwargs=dict(stationary=True, prop_decrease=0.8)),
+    "nonstat_2ch_prop": dict(sr=48000, n=30000, seed=16, channels=2,
+                             kwargs=dict(stationary=False, prop_decrease=0.6,
+                                         thresh_n_mult_nonstationary=1.5,
+                                         sigmoid_slope_nonstationary=7,
+                                         time_constant_s=0.5)),
+    # other FFT sizes / sample rates
+    "stat_nfft512": dict(sr=16000, n=30000, seed=17, tone_hz=440.0,
+                         kwargs=dict(stationary=True, n_fft=512)),
+    "stat_nfft2048": dict(sr=44100, n=50000, seed=18,
+                          kwargs=dict(stationary=True, n_fft=2048, n_std_thresh_stationary=2.0)),
+    "nonstat_nfft256": dict(sr=8000, n=20000, seed=19, tone_hz=300.0,
+                            kwargs=dict(stationary=False, n_fft=256)),
+    # no smoothing / one-axis smoothing
+    "stat_nosmooth": dict(sr=48000, n=30000, seed=20,
+                          kwargs=dict(stationary=True, freq_mask_smooth_hz=None,
+                                      time_mask_smooth_ms=None)),
+    "stat_freqsmooth_only": dict(sr=48000, n=30000, seed=21,
+                                 kwargs=dict(stationary=True, time_mask_smooth_ms=None)),
+    # general STFT geometry (win_length < n_fft, hop not win/4)
+    "stat_geom": dict(sr=48000, n=30000, seed=22,
+                      kwargs=dict(stationary=True, n_fft=2048, win_length=1500, hop_length=300)),
+    "nonstat_geom": dict(sr=48000, n=30000, seed=23,
+                         kwargs=dict(stationary=False, n_fft=1024, win_length=800, hop_length=160)),
+}
+
+
+def make_input_S(case):
+    n, sr = case["n"], case["sr"]
+    C = case.get("channels", 1)
+    chans = [synth(n, sr, case["seed"] + 100 * c, tone_hz=case.get("tone_hz", 1000.0) * (c + 1))
+             for c in range(C)]
+    y = chans[0] if C == 1 else np.stack(chans)
+    y_noise = None
+    if case.get("noise_len"):
+        nl = case["noise_len"]
+        y_noise = np.stack([0.1 * np.random.default_rng(case["seed"] + 7 + c).standard_normal(nl)
+                            for c in range(C)]).astype(np.float32).astype(np.float64)
+    return y, y_noise
+
+
+# ---- variant T: TorchGate.forward (float64) ------------------------------------
+T_CASES = {
+    "stat": dict(sr=16000, B=3, L=9000, seed=31, kwargs=dict()),
+    "stat_xn": dict(sr=16000, B=3, L=9000, seed=32, xn=(1, 5000), kwargs=dict()),
+    "stat_xn_rows": dict(sr=16000, B=3, L=9000, seed=33, xn=(3, 6000), kwargs=dict(prop_decrease=0.5)),
+    "nonstat": dict(sr=16000, B=3, L=9000, seed=34, kwargs=dict(nonstationary=True)),
+    "nonstat_odd": dict(sr=16000, B=2, L=9001, seed=35,
+                        kwargs=dict(nonstationary=True, n_movemean_nonstationary=7,
+                                    n_thresh_nonstationary=1.0, temp_coeff_nonstationary=0.2,
+                                    prop_decrease=0.9)),
+    "stat_geom": dict(sr=16000, B=2, L=9000, seed=36,
+                      kwargs=dict(n_fft=512, win_length=400, hop_length=100)),
+    "stat_nosmooth": dict(sr=16000, B=2, L=6000, seed=37,
+                          kwargs=dict(freq_mask_smooth_hz=None, time_mask_smooth_ms=None)),
+    "stat_sr8k": dict(sr=8000, B=3, L=32000, seed=38, kwargs=dict(nonstationary=True)),
+}
+
+
+def make_input_T(case):
+    rng = np.random.default_rng(case["seed"])
+    B, L, sr = case["B"], case["L"], case["sr"]
+    t = np.arange(L, dtype=np.float64) / sr
+    x = 0.1 * rng.standard_normal((B, L)) + 0.5 * np.sin(2 * np.pi * 440.0 * t)[None, :]
+    x = x.astype(np.float32).astype(np.float64)
+    xn = None
+    if case.get("xn"):
+        xn = (0.1 * rng.standard_normal(case["xn"])).astype(np.float32).astype(np.float64)
+    return x, xn

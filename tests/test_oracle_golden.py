@@ -1,0 +1,84 @@
+"""Pins oracle/spectralgate_oracle.py against the golden vectors generated from the
+live reference (tests/golden/make_golden.py).  CPU only."""
+import os
+
+import numpy as np
+import pytest
+
+from oracle import spectralgate_oracle as O
+from tests.golden.cases import S_CASES, T_CASES, make_input_S, make_input_T, sha
+
+TOL_S = 1e-11   # oracle and reference are both float64; differences are rounding only
+TOL_T = 2e-6    # the reference builds its Hann window / OLA envelope in float32
+
+
+def _load(golden_dir, name):
+    return np.load(os.path.join(golden_dir, name + ".npz"))
+
+
+@pytest.mark.parametrize("name", sorted(S_CASES))
+def test_reduce_noise_S_matches_reference(golden_dir, name):
+    case = S_CASES[name]
+    g = _load(golden_dir, "S_" + name)
+    y, y_noise = make_input_S(case)
+    assert sha(y) == str(g["in_sha"]), "seeded input drifted from the one the golden was made with"
+    out = O.reduce_noise_S(y, case["sr"], y_noise=y_noise, **case["kwargs"])
+    assert out.shape == g["out"].shape and out.dtype == g["out"].dtype
+    assert O.rel_err(out, g["out"]) < TOL_S
+
+
+def test_stage_taps_match_reference(golden_dir):
+    case = S_CASES["stat_1chunk"]
+    g = _load(golden_dir, "S_stat_1chunk")
+    y, _ = make_input_S(case)
+    thresh, _, _ = O.noise_threshold_S(y[None, :], 1024, 1024, 256, 1.5, 600000)
+    assert np.max(np.abs(thresh - g["thresh"])) < 1e-10
+    chunk = O.read_chunk(y[None, :], -30000, len(y) + 30000)
+    nf, nt, smooth = O.mask_smoothing_widths(48000, 1024, 256, 500, 50)
+    assert (nf, nt, smooth) == (5, 9, True)
+    filt = O.smoothing_filter(nf, nt)
+    _, stages = O.gate_stationary_S(chunk, g["thresh"], 1024, 1024, 256, 1.0, filt,
+                                    return_stages=True)
+    raw = stages[0]["raw"]
+    assert tuple(g["raw_shape"]) == raw.shape
+    assert np.array_equal(np.packbits(raw, axis=1), g["raw_bits"])       # bit-exact mask
+    assert np.max(np.abs(stages[0]["mask"][[0, 3, 100, 511, 512], :] - g["smooth_rows"])) < 1e-12
+    cols = [0, 1, 2, 117, 200, raw.shape[1] - 1]
+    assert np.max(np.abs(stages[0]["Z"][:, cols] - g["Z_cols"])) < 1e-15
+
+
+def test_fish_wav_config0(golden_dir):
+    """BASELINE.json configs[0]: assets/fish.wav, mono, stationary, reference CPU path."""
+    g = _load(golden_dir, "S_fish")
+    data, rate = g["data"], int(g["rate"])
+    out = O.reduce_noise_S(data, rate, stationary=True)
+    assert out.dtype == np.int16
+    assert np.array_equal(out, g["out_i16"])                              # int16: bit-exact
+    out64 = O.reduce_noise_S(data.astype(np.float64), rate, stationary=True)
+    assert O.rel_err(out64, g["out_f64"]) < 1e-6                          # golden stored as f32
+    out_ns = O.reduce_noise_S(data.astype(np.float64), rate, stationary=False)
+    assert O.rel_err(out_ns, g["out_ns"]) < 1e-6
+
+
+@pytest.mark.parametrize("name", sorted(T_CASES))
+def test_torchgate_T_matches_reference(golden_dir, name):
+    case = T_CASES[name]
+    g = _load(golden_dir, "T_" + name)
+    x, xn = make_input_T(case)
+    assert sha(x) == str(g["in_sha"])
+    out = O.torchgate_T(x, case["sr"], xn=xn, window=g["window"], **case["kwargs"])
+    assert out.shape == g["out"].shape
+    assert O.rel_err(out, g["out"]) < TOL_T
+
+
+def test_conv_variants_agree():
+    rng = np.random.default_rng(0)
+    m = (rng.random((40, 60)) > 0.5) * 1.0
+    K = O.smoothing_filter(5, 9)
+    assert np.max(np.abs(O.conv2_same(m, K) - O.conv2_same_direct(m, K))) < 1e-13
+
+
+def test_smoothing_filter_shape_and_sum():
+    K = O.smoothing_filter(5, 9)
+    assert K.shape == (11, 19) and abs(K.sum() - 1) < 1e-15
+    assert np.allclose(O.triangle(3), np.array([1, 2, 3, 4, 3, 2, 1]) / 4)
