@@ -1,0 +1,156 @@
+/*
+ * mi355gate.h -- C ABI of libmi355gate.so, the MI355X (gfx950) spectral-gating engine.
+ *
+ * This is the drop-in boundary for ONE hot path of timsainb/noisereduce: the chunk
+ * filter  STFT -> per-band noise statistics -> threshold/sigmoid mask -> 2-D mask
+ * smoothing -> masked complex multiply -> overlap-add ISTFT.  Nothing like this ABI
+ * exists in the reference (it is pure Python); each entry point states which reference
+ * interface it replaces (paths relative to /root/reference/noisereduce/).
+ *
+ * Conventions
+ *   - plain C: pointers + sizes, no torch / C++ types.  All `*_dev` pointers are DEVICE
+ *     pointers (e.g. torch.Tensor.data_ptr() of a ROCm tensor); `*_host` are host pointers.
+ *   - `stream` is a hipStream_t passed as void* (0 = default stream).  Every call only
+ *     ENQUEUES work on that stream unless documented as synchronising.
+ *   - return value: 0 = success, negative = error (SG_E_*); text via sg_last_error().
+ *     Nothing throws across the boundary.
+ *   - a handle is not thread-safe; use one handle per (device, stream).
+ *   - caller owns input/output buffers; the library owns its workspace (grown on demand,
+ *     bounded by sg_params.max_workspace_bytes; large jobs are processed in unit batches).
+ */
+#ifndef MI355GATE_H
+#define MI355GATE_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define SG_VERSION 100 /* 0.1.0 */
+
+/* error codes */
+#define SG_OK 0
+#define SG_E_INVALID (-1)     /* bad argument (maps to ValueError)            */
+#define SG_E_UNSUPPORTED (-2) /* geometry outside the kernels' range          */
+#define SG_E_HIP (-3)         /* HIP runtime error                            */
+#define SG_E_NOMEM (-4)       /* workspace allocation failed                  */
+#define SG_E_STATE (-5)       /* call order (e.g. no noise threshold yet)     */
+
+/* sample dtypes of caller buffers */
+#define SG_F32 0
+#define SG_F64 1
+#define SG_I16 2
+#define SG_I32 3
+
+/* algorithm variant: the reference holds two different algorithms behind one API
+ *  */
+#define SG_VARIANT_S 0 /* numpy/scipy "spectralgate": spectralgate/{base,stationary,nonstationary}.py */
+#define SG_VARIANT_T 1 /* torch "torchgate": torchgate/torchgate.py                                   */
+
+typedef struct sg_params {
+  int32_t variant;    /* SG_VARIANT_S | SG_VARIANT_T                                        */
+  int32_t stationary; /* 1: stationary (threshold) mask, 0: non-stationary (sigmoid) mask   */
+  int32_t n_fft;      /* power of two, 64..4096 (base.py:77; torchgate.py:55)               */
+  int32_t win_length; /* <= n_fft (base.py:79-82)                                           */
+  int32_t hop_length; /* >= 1    (base.py:83-86)                                            */
+  int32_t n_grad_freq; /* mask-smoothing half width in bins  (base.py:104), >= 1            */
+  int32_t n_grad_time; /* mask-smoothing half width in frames (base.py:115), >= 1           */
+  int32_t smooth_mask; /* 0: no smoothing (base.py:90-91,124-125)                           */
+  int64_t chunk_size;  /* S only: base.py:66 (reduce_noise default 600000)                  */
+  int64_t padding;     /* S only: base.py:67 (default 30000)                                */
+  double prop_decrease;     /* base.py:88; torchgate.py:53                                  */
+  double n_std_thresh;      /* stationary.py:45,79-81; torchgate.py:160                     */
+  double top_db;            /* 80 (spectralgate/utils.py:11) or 40 (torchgate/utils.py:6)   */
+  int32_t ddof;             /* 0: np.std (stationary.py:77); 1: torch.std_mean (torchgate.py:158) */
+  int32_t n_movemean;       /* T non-stationary: boxcar length (torchgate.py:179-190)       */
+  double nonstat_thresh;    /* S: thresh_n_mult_nonstationary; T: n_thresh_nonstationary     */
+  double nonstat_slope;     /* S: sigmoid_slope_nonstationary; T: 1 / temp_coeff_nonstationary */
+  double iir_b;             /* S non-stationary: one-pole coefficient (nonstationary.py:109-114) */
+  int64_t max_workspace_bytes; /* 0 = default (8 GiB) */
+} sg_params;
+
+typedef struct sg_handle sg_handle;
+
+int sg_version(void);
+
+/* Last error text of a handle (or of the last failed sg_create when h == NULL). */
+const char* sg_last_error(const sg_handle* h);
+
+/* Replaces SpectralGate.__init__ parameter resolution (base.py:33-97) and
+ * TorchGate.__init__ (torchgate.py:31-71): builds twiddle/window/smoothing tables on the
+ * current HIP device.  `window_host`: win_length doubles, or NULL for the periodic Hann
+ * window both references use (scipy get_window('hann'), torch.hann_window). */
+int sg_create(const sg_params* p, const double* window_host, sg_handle** out);
+int sg_destroy(sg_handle* h);
+
+/* Geometry helpers: number of STFT frames and ISTFT output length for a length-L signal
+ * (scipy/_spectral_py.py:2185-2189,1715; torch.stft/istft center=True). */
+int sg_n_frames(const sg_handle* h, int64_t L, int64_t* n_frames);
+int sg_output_length(const sg_handle* h, int64_t L, int64_t* out_len);
+
+/* ---- variant S -------------------------------------------------------------------- */
+
+/* Replaces the noise-statistics block of SpectralGateStationary.__init__
+ * (stationary.py:47-81): channel mean of the (C, n) noise clip, STFT, dB with -top_db
+ * floor, per-band mean/std over time, thresh = mean + n_std*std.  The caller applies
+ * clip_noise_stationary (n = min(n, chunk_size)).  Result stays on the device. */
+int sg_noise_stats(sg_handle* h, const void* noise_dev, int dtype, int64_t C, int64_t n,
+                   int64_t row_stride, void* stream);
+/* Read back / override the per-band threshold in dB (n_fft/2+1 doubles).
+ * sg_get_noise_threshold synchronises the stream. */
+int sg_get_noise_threshold(sg_handle* h, double* thresh_host, int32_t n_bins, void* stream);
+int sg_set_noise_threshold(sg_handle* h, const double* thresh_host, int32_t n_bins, void* stream);
+
+/* Replaces SpectralGate.get_traces + filter_chunk + _read_chunk + _do_filter for a whole
+ * (C, N) planar recording that already lives in HBM (base.py:130-226): the reference's
+ * chunk grid (chunk i = samples [i*cs, (i+1)*cs), filtered on a zero-padded window of
+ * `padding` extra samples per side, padding discarded) is evaluated on the device, all
+ * (channel, chunk) units in one set of launches.  Writes out[c][g - start_frame] for
+ * g in [start_frame, end_frame); pass 0, N for everything.  `chunked` = 0 reproduces the
+ * single-window branch (base.py:222), 1 the chunk grid (base.py:175-216). */
+int sg_process_chunks(sg_handle* h, const void* in_dev, int in_dtype, void* out_dev,
+                      int out_dtype, int64_t C, int64_t N, int64_t in_stride,
+                      int64_t out_stride, int64_t start_frame, int64_t end_frame,
+                      int32_t chunked, void* stream);
+
+/* Replaces SpectralGate._do_filter(chunk) (base.py:158-160; stationary.py:129-133;
+ * nonstationary.py:99-103): (C, Lp) padded chunk in, (C, Lp) filtered chunk out, the
+ * last Lp - sg_output_length(Lp) samples are zero like the reference's. */
+int sg_filter_padded(sg_handle* h, const void* chunk_dev, int in_dtype, void* out_dev,
+                     int out_dtype, int64_t C, int64_t Lp, int64_t in_stride,
+                     int64_t out_stride, void* stream);
+
+/* ---- variant T -------------------------------------------------------------------- */
+
+/* Replaces TorchGate.forward(x, xn) (torchgate.py:200-264): x (B, L) -> out
+ * (B, hop*(L//hop)).  xn_dev may be NULL (statistics from x itself, per row) or a
+ * (Bn, Ln) noise batch with Bn in {1, B}. */
+int sg_process_batch(sg_handle* h, const void* x_dev, int dtype, int64_t B, int64_t L,
+                     int64_t x_stride, const void* xn_dev, int64_t Bn, int64_t Ln,
+                     int64_t xn_stride, void* out_dev, int out_dtype, int64_t out_stride,
+                     void* stream);
+
+/* Adjoint of sg_process_batch with the mask of the LAST forward call held fixed
+ * (TorchGate.forward is differentiable w.r.t. x with the mask detached,
+ * torchgate.py:126,167): grad_out (B, Lout) -> grad_x (B, L). */
+int sg_process_batch_backward(sg_handle* h, const void* grad_out_dev, int dtype, int64_t B,
+                              int64_t L, int64_t go_stride, void* grad_x_dev,
+                              int64_t gx_stride, void* stream);
+
+/* ---- stage taps (used by the parity tests; also plain STFT/ISTFT operators) ------ */
+
+/* Forward STFT of (B, L) rows -> complex float64 Z[B][T][F] (interleaved re,im), same
+ * scaling as the variant's reference call (S: 1/sum(w), scipy stft; T: unscaled). */
+int sg_stft(sg_handle* h, const void* x_dev, int dtype, int64_t B, int64_t L, int64_t stride,
+            double* z_dev, void* stream);
+/* Fields of the last processed unit batch, copied to the host (synchronises):
+ * what = 0: raw mask  float[units][T][FS];  1: final mask float[units][T][FS];
+ *        2: power     double[units][T][FS] (stationary only).  FS = sg_debug_dims()[2]. */
+int sg_debug_dims(const sg_handle* h, int64_t dims[3]); /* units, T, FS */
+int sg_debug_fetch(sg_handle* h, int32_t what, void* host, int64_t bytes, void* stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* MI355GATE_H */

@@ -1,0 +1,293 @@
+"""ctypes binding of libmi355gate.so (C ABI: include/mi355gate.h).
+
+PyTorch-ROCm tensors are only the I/O container: this module passes
+``tensor.data_ptr()`` and the current HIP stream to the library.  There is no CPU
+fallback: if the shared library is missing, or no MI355X/HIP device is visible, the
+calls raise.
+"""
+import ctypes
+import os
+from ctypes import (POINTER, Structure, byref, c_char_p, c_double, c_int, c_int32,
+                    c_int64, c_void_p)
+
+import numpy as np
+import torch
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "libmi355gate.so")
+
+SG_F32, SG_F64, SG_I16, SG_I32 = 0, 1, 2, 3
+SG_VARIANT_S, SG_VARIANT_T = 0, 1
+SG_E_INVALID, SG_E_UNSUPPORTED, SG_E_HIP, SG_E_NOMEM, SG_E_STATE = -1, -2, -3, -4, -5
+
+_TORCH_DTYPES = {torch.float32: SG_F32, torch.float64: SG_F64, torch.int16: SG_I16,
+                 torch.int32: SG_I32}
+
+
+class SgParams(Structure):
+    """struct sg_params (include/mi355gate.h)."""
+    _fields_ = [
+        ("variant", c_int32), ("stationary", c_int32), ("n_fft", c_int32),
+        ("win_length", c_int32), ("hop_length", c_int32), ("n_grad_freq", c_int32),
+        ("n_grad_time", c_int32), ("smooth_mask", c_int32), ("chunk_size", c_int64),
+        ("padding", c_int64), ("prop_decrease", c_double), ("n_std_thresh", c_double),
+        ("top_db", c_double), ("ddof", c_int32), ("n_movemean", c_int32),
+        ("nonstat_thresh", c_double), ("nonstat_slope", c_double), ("iir_b", c_double),
+        ("max_workspace_bytes", c_int64),
+    ]
+
+
+# every symbol include/mi355gate.h declares: name -> (restype, argtypes)
+_PROTOTYPES = {
+    "sg_version": (c_int, []),
+    "sg_last_error": (c_char_p, [c_void_p]),
+    "sg_create": (c_int, [POINTER(SgParams), POINTER(c_double), POINTER(c_void_p)]),
+    "sg_destroy": (c_int, [c_void_p]),
+    "sg_n_frames": (c_int, [c_void_p, c_int64, POINTER(c_int64)]),
+    "sg_output_length": (c_int, [c_void_p, c_int64, POINTER(c_int64)]),
+    "sg_noise_stats": (c_int, [c_void_p, c_void_p, c_int, c_int64, c_int64, c_int64, c_void_p]),
+    "sg_get_noise_threshold": (c_int, [c_void_p, POINTER(c_double), c_int32, c_void_p]),
+    "sg_set_noise_threshold": (c_int, [c_void_p, POINTER(c_double), c_int32, c_void_p]),
+    "sg_process_chunks": (c_int, [c_void_p, c_void_p, c_int, c_void_p, c_int, c_int64, c_int64,
+                                  c_int64, c_int64, c_int64, c_int64, c_int32, c_void_p]),
+    "sg_filter_padded": (c_int, [c_void_p, c_void_p, c_int, c_void_p, c_int, c_int64, c_int64,
+                                 c_int64, c_int64, c_void_p]),
+    "sg_process_batch": (c_int, [c_void_p, c_void_p, c_int, c_int64, c_int64, c_int64, c_void_p,
+                                 c_int64, c_int64, c_int64, c_void_p, c_int, c_int64, c_void_p]),
+    "sg_process_batch_backward": (c_int, [c_void_p, c_void_p, c_int, c_int64, c_int64, c_int64,
+                                          c_void_p, c_int64, c_void_p]),
+    "sg_stft": (c_int, [c_void_p, c_void_p, c_int, c_int64, c_int64, c_int64, c_void_p, c_void_p]),
+    "sg_debug_dims": (c_int, [c_void_p, POINTER(c_int64)]),
+    "sg_debug_fetch": (c_int, [c_void_p, c_int32, c_void_p, c_int64, c_void_p]),
+}
+
+_lib = None
+
+
+def load_library():
+    """dlopen libmi355gate.so and bind every declared symbol.  Loading needs the HIP
+    runtime but no GPU; calling compute entry points does."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.exists(LIB_PATH):
+        raise ImportError(
+            f"{LIB_PATH} not found: build it with `python -c 'import __graft_entry__ as g; "
+            "g.build()'` (hipcc --offload-arch=gfx950).  noisereduce_amd has no CPU fallback.")
+    lib = ctypes.CDLL(LIB_PATH)
+    for name, (res, args) in _PROTOTYPES.items():
+        fn = getattr(lib, name)  # AttributeError if the .so is stale
+        fn.restype = res
+        fn.argtypes = args
+    _lib = lib
+    return lib
+
+
+def exported_symbols():
+    return sorted(_PROTOTYPES)
+
+
+def resolve_device(device="cuda"):
+    """Return a torch.device on an AMD GPU or raise -- never falls back to CPU."""
+    if not torch.cuda.is_available():
+        raise RuntimeError(
+            "noisereduce_amd needs a HIP device (MI355X / gfx950): torch.cuda.is_available() is "
+            "False and there is no CPU fallback.")
+    dev = torch.device(device)
+    if dev.type != "cuda":
+        raise RuntimeError(f"noisereduce_amd only runs on the GPU (got device={device!r})")
+    if dev.index is None:
+        dev = torch.device("cuda", torch.cuda.current_device())
+    return dev
+
+
+def _sg_dtype(t):
+    try:
+        return _TORCH_DTYPES[t.dtype]
+    except KeyError:
+        raise TypeError(f"unsupported device sample dtype {t.dtype}") from None
+
+
+def _rows(t):
+    """(data_ptr, row_stride) of a 2-D tensor whose last dim is contiguous."""
+    assert t.dim() == 2
+    if t.shape[1] > 1 and t.stride(1) != 1:
+        t = t.contiguous()
+    return t, t.stride(0) if t.shape[0] > 1 else t.shape[1]
+
+
+class Gate:
+    """One sg_handle bound to one device (and used on that device's current stream)."""
+
+    def __init__(self, device, *, variant, stationary, n_fft, win_length, hop_length,
+                 n_grad_freq=1, n_grad_time=1, smooth_mask=False, chunk_size=600000,
+                 padding=30000, prop_decrease=1.0, n_std_thresh=1.5, top_db=80.0, ddof=0,
+                 n_movemean=20, nonstat_thresh=2.0, nonstat_slope=10.0, iir_b=0.0,
+                 window=None, max_workspace_bytes=0):
+        self.lib = load_library()
+        self.device = resolve_device(device)
+        p = SgParams(variant=variant, stationary=int(bool(stationary)), n_fft=int(n_fft),
+                     win_length=int(win_length), hop_length=int(hop_length),
+                     n_grad_freq=int(n_grad_freq), n_grad_time=int(n_grad_time),
+                     smooth_mask=int(bool(smooth_mask)), chunk_size=int(chunk_size or 1),
+                     padding=int(padding or 0), prop_decrease=float(prop_decrease),
+                     n_std_thresh=float(n_std_thresh), top_db=float(top_db), ddof=int(ddof),
+                     n_movemean=int(n_movemean), nonstat_thresh=float(nonstat_thresh),
+                     nonstat_slope=float(nonstat_slope), iir_b=float(iir_b),
+                     max_workspace_bytes=int(max_workspace_bytes))
+        self.params = p
+        self.n_bins = int(n_fft) // 2 + 1
+        wptr = None
+        if window is not None:
+            w = np.ascontiguousarray(np.asarray(window, dtype=np.float64))
+            if w.shape != (int(win_length),):
+                raise ValueError("window must have win_length entries")
+            wptr = w.ctypes.data_as(POINTER(c_double))
+        self._h = c_void_p()
+        with torch.cuda.device(self.device):
+            rc = self.lib.sg_create(byref(p), wptr, byref(self._h))
+        if rc != 0:
+            msg = self.lib.sg_last_error(None).decode()
+            self._h = c_void_p()
+            self._raise(rc, msg)
+
+    # -- plumbing --------------------------------------------------------------------
+    @staticmethod
+    def _raise(rc, msg):
+        if rc == SG_E_INVALID:
+            raise ValueError(msg)
+        if rc == SG_E_UNSUPPORTED:
+            raise NotImplementedError(msg)
+        if rc == SG_E_NOMEM:
+            raise MemoryError(msg)
+        raise RuntimeError(f"libmi355gate error {rc}: {msg}")
+
+    def _check(self, rc):
+        if rc != 0:
+            self._raise(rc, self.lib.sg_last_error(self._h).decode())
+
+    def _stream(self):
+        return c_void_p(torch.cuda.current_stream(self.device).cuda_stream)
+
+    def close(self):
+        if getattr(self, "_h", None) is not None and self._h.value:
+            with torch.cuda.device(self.device):
+                self.lib.sg_destroy(self._h)
+            self._h = c_void_p()
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def _on_device(self, t):
+        if not isinstance(t, torch.Tensor) or t.device != self.device:
+            raise ValueError(f"expected a tensor on {self.device}")
+
+    # -- geometry --------------------------------------------------------------------
+    def n_frames(self, L):
+        out = c_int64()
+        self._check(self.lib.sg_n_frames(self._h, int(L), byref(out)))
+        return out.value
+
+    def output_length(self, L):
+        out = c_int64()
+        self._check(self.lib.sg_output_length(self._h, int(L), byref(out)))
+        return out.value
+
+    # -- variant S -------------------------------------------------------------------
+    def noise_stats(self, noise):
+        self._on_device(noise)
+        noise, stride = _rows(noise)
+        with torch.cuda.device(self.device):
+            self._check(self.lib.sg_noise_stats(self._h, noise.data_ptr(), _sg_dtype(noise),
+                                                noise.shape[0], noise.shape[1], stride,
+                                                self._stream()))
+
+    def get_noise_threshold(self):
+        out = np.empty(self.n_bins, dtype=np.float64)
+        with torch.cuda.device(self.device):
+            self._check(self.lib.sg_get_noise_threshold(
+                self._h, out.ctypes.data_as(POINTER(c_double)), self.n_bins, self._stream()))
+        return out
+
+    def set_noise_threshold(self, thresh):
+        t = np.ascontiguousarray(np.asarray(thresh, dtype=np.float64))
+        with torch.cuda.device(self.device):
+            self._check(self.lib.sg_set_noise_threshold(
+                self._h, t.ctypes.data_as(POINTER(c_double)), int(t.shape[0]), self._stream()))
+
+    def process_chunks(self, x, out_dtype=None, start_frame=0, end_frame=None, chunked=True,
+                       out=None):
+        self._on_device(x)
+        x, stride = _rows(x)
+        C, N = x.shape
+        end_frame = N if end_frame is None else int(end_frame)
+        n_out = end_frame if not chunked else end_frame - int(start_frame)
+        if out is None:
+            out = torch.empty((C, n_out), dtype=out_dtype or x.dtype, device=self.device)
+        with torch.cuda.device(self.device):
+            self._check(self.lib.sg_process_chunks(
+                self._h, x.data_ptr(), _sg_dtype(x), out.data_ptr(), _sg_dtype(out), C, N, stride,
+                out.stride(0) if C > 1 else n_out, int(start_frame), end_frame, int(bool(chunked)),
+                self._stream()))
+        return out
+
+    def filter_padded(self, chunk, out_dtype=None):
+        self._on_device(chunk)
+        chunk, stride = _rows(chunk)
+        C, Lp = chunk.shape
+        out = torch.empty((C, Lp), dtype=out_dtype or chunk.dtype, device=self.device)
+        with torch.cuda.device(self.device):
+            self._check(self.lib.sg_filter_padded(self._h, chunk.data_ptr(), _sg_dtype(chunk),
+                                                  out.data_ptr(), _sg_dtype(out), C, Lp, stride, Lp,
+                                                  self._stream()))
+        return out
+
+    # -- variant T -------------------------------------------------------------------
+    def process_batch(self, x, xn=None, out_dtype=None):
+        self._on_device(x)
+        x, xs = _rows(x)
+        B, L = x.shape
+        Lout = self.output_length(L)
+        out = torch.empty((B, Lout), dtype=out_dtype or x.dtype, device=self.device)
+        if xn is not None:
+            self._on_device(xn)
+            if xn.dtype != x.dtype:
+                xn = xn.to(x.dtype)
+            xn, xns = _rows(xn)
+            xn_ptr, Bn, Ln = xn.data_ptr(), xn.shape[0], xn.shape[1]
+        else:
+            xn_ptr, Bn, Ln, xns = None, 0, 0, 0
+        with torch.cuda.device(self.device):
+            self._check(self.lib.sg_process_batch(
+                self._h, x.data_ptr(), _sg_dtype(x), B, L, xs, xn_ptr, Bn, Ln, xns, out.data_ptr(),
+                _sg_dtype(out), Lout, self._stream()))
+        return out
+
+    # -- stage taps ------------------------------------------------------------------
+    def stft(self, x):
+        """(B, L) -> complex128 (B, T, F), scaled like the variant's reference STFT."""
+        self._on_device(x)
+        x, xs = _rows(x)
+        B, L = x.shape
+        T = self.n_frames(L)
+        z = torch.empty((B, T, self.n_bins, 2), dtype=torch.float64, device=self.device)
+        with torch.cuda.device(self.device):
+            self._check(self.lib.sg_stft(self._h, x.data_ptr(), _sg_dtype(x), B, L, xs, z.data_ptr(),
+                                         self._stream()))
+        return torch.view_as_complex(z)
+
+    def debug_field(self, what):
+        """0: raw mask, 1: final mask (float32); 2: power (float64) of the last unit batch,
+        as (units, T, F) numpy arrays."""
+        dims = (c_int64 * 3)()
+        self._check(self.lib.sg_debug_dims(self._h, dims))
+        units, T, FS = dims[0], dims[1], dims[2]
+        dt = np.float64 if what == 2 else np.float32
+        host = np.empty((units, T, FS), dtype=dt)
+        with torch.cuda.device(self.device):
+            self._check(self.lib.sg_debug_fetch(self._h, int(what), host.ctypes.data_as(c_void_p),
+                                                host.nbytes, self._stream()))
+        return host[:, :, :self.n_bins]

@@ -1,0 +1,674 @@
+// libmi355gate.so -- host side of the C ABI declared in include/mi355gate.h.
+// Builds tables, owns the workspace, batches (channel, chunk) units and enqueues the
+// kernels of kernels.hpp on the caller's HIP stream.  gfx950 only.
+#include <hip/hip_runtime.h>
+
+#include <algorithm>
+#include <cmath>
+#include <cstdarg>
+#include <cstdio>
+#include <cstring>
+#include <string>
+#include <vector>
+
+#include "../../include/mi355gate.h"
+#include "kernels.hpp"
+
+using namespace sg;
+
+namespace {
+thread_local std::string g_create_error;
+
+struct DevBuf {
+  void* p = nullptr;
+  size_t bytes = 0;
+};
+
+std::string fmt(const char* f, ...) {
+  char buf[512];
+  va_list ap;
+  va_start(ap, f);
+  vsnprintf(buf, sizeof buf, f, ap);
+  va_end(ap);
+  return buf;
+}
+}  // namespace
+
+struct sg_handle {
+  sg_params p{};
+  int n = 0, N = 0, W = 0, H = 0, F = 0, FS = 0, padL = 0;
+  double sum_w = 0.0;   // sum of the analysis window (scipy 'spectrum' scaling)
+  double mag_scale = 1; // |Z| = sqrt(P) * mag_scale  (S: 1/sum_w, T: 1)
+  // device tables
+  DevBuf tw64, tw32, wfull64, wa32, ws32, wsq32, kf, kt;
+  // per-band threshold (S stationary): double[FS]
+  DevBuf thresh;
+  bool has_thresh = false;
+  // workspace
+  DevBuf P, pmax, thr_rows, raw, M, seg, yn;
+  int64_t dbg_units = 0, dbg_T = 0;
+  bool dbg_has_P = false;
+  std::string err;
+};
+
+#define HIPCHK(h, call)                                                                      \
+  do {                                                                                       \
+    hipError_t e_ = (call);                                                                  \
+    if (e_ != hipSuccess) {                                                                  \
+      (h)->err = fmt("%s failed: %s (%s:%d)", #call, hipGetErrorString(e_), __FILE__, __LINE__); \
+      return SG_E_HIP;                                                                       \
+    }                                                                                        \
+  } while (0)
+
+#define FAIL(h, code, ...)      \
+  do {                          \
+    (h)->err = fmt(__VA_ARGS__); \
+    return (code);              \
+  } while (0)
+
+static int ensure(sg_handle* h, DevBuf& b, size_t bytes) {
+  if (b.bytes >= bytes) return SG_OK;
+  if (b.p) {
+    HIPCHK(h, hipDeviceSynchronize());  // buffer may still be in use by enqueued work
+    HIPCHK(h, hipFree(b.p));
+    b.p = nullptr;
+    b.bytes = 0;
+  }
+  hipError_t e = hipMalloc(&b.p, bytes);
+  if (e != hipSuccess) {
+    b.p = nullptr;
+    FAIL(h, SG_E_NOMEM, "workspace allocation of %zu bytes failed: %s", bytes, hipGetErrorString(e));
+  }
+  b.bytes = bytes;
+  return SG_OK;
+}
+
+static int upload(sg_handle* h, DevBuf& b, const void* src, size_t bytes) {
+  int rc = ensure(h, b, bytes);
+  if (rc) return rc;
+  HIPCHK(h, hipMemcpy(b.p, src, bytes, hipMemcpyHostToDevice));
+  return SG_OK;
+}
+
+static void free_buf(DevBuf& b) {
+  if (b.p) (void)hipFree(b.p);
+  b.p = nullptr;
+  b.bytes = 0;
+}
+
+static int64_t frames_for(const sg_handle* h, int64_t L) {
+  // S: zero extension W//2 per side, padded=False (scipy/_spectral_py.py:2052,2185-2189).
+  // T: torch.stft(center=True): 1 + L // hop.
+  if (h->p.variant == SG_VARIANT_S) return (L + 2 * (int64_t)(h->W / 2) - h->W) / h->H + 1;
+  return 1 + L / h->H;
+}
+static int64_t outlen_for(const sg_handle* h, int64_t L) {
+  int64_t T = frames_for(h, L);
+  if (h->p.variant == SG_VARIANT_S) return (T - 1) * h->H + h->W - 2 * (int64_t)(h->W / 2);
+  return (T - 1) * (int64_t)h->H;
+}
+
+static Geom make_geom(const sg_handle* h, int64_t Lp) {
+  Geom g;
+  g.n = h->n; g.W = h->W; g.H = h->H; g.F = h->F; g.FS = h->FS; g.padL = h->padL;
+  g.T = frames_for(h, Lp);
+  g.Lout = outlen_for(h, Lp);
+  return g;
+}
+
+// ------------------------------------------------------------------------------------------
+// kernel dispatch on the FFT size
+// ------------------------------------------------------------------------------------------
+template <typename TC, int N>
+static hipError_t launch_stft_n(const View& v, const Geom& g, int64_t units, const void* tw, const void* wfull,
+                                double* P, float* mag, double* z, double zscale, hipStream_t st) {
+  constexpr int WAVES = (N * sizeof(cx<TC>) > 16384) ? 2 : 4;
+  constexpr int FPW = 4;
+  size_t lds = (size_t)(N + WAVES * N) * sizeof(cx<TC>);
+  auto kern = k_stft<TC, N, WAVES, FPW>;
+  if (lds > 65536) {
+    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern),
+                                       hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    if (e != hipSuccess) return e;
+  }
+  dim3 grid((unsigned)((g.T + WAVES * FPW - 1) / (WAVES * FPW)), (unsigned)units);
+  hipLaunchKernelGGL(kern, grid, dim3(WAVES * 64), lds, st, v, g, (const cx<TC>*)tw, (const TC*)wfull, P, mag, z,
+                     zscale);
+  return hipGetLastError();
+}
+
+template <typename TC>
+static hipError_t launch_stft(int N, const View& v, const Geom& g, int64_t units, const void* tw,
+                              const void* wfull, double* P, float* mag, double* z, double zscale,
+                              hipStream_t st) {
+  switch (N) {
+    case 32: return launch_stft_n<TC, 32>(v, g, units, tw, wfull, P, mag, z, zscale, st);
+    case 64: return launch_stft_n<TC, 64>(v, g, units, tw, wfull, P, mag, z, zscale, st);
+    case 128: return launch_stft_n<TC, 128>(v, g, units, tw, wfull, P, mag, z, zscale, st);
+    case 256: return launch_stft_n<TC, 256>(v, g, units, tw, wfull, P, mag, z, zscale, st);
+    case 512: return launch_stft_n<TC, 512>(v, g, units, tw, wfull, P, mag, z, zscale, st);
+    case 1024: return launch_stft_n<TC, 1024>(v, g, units, tw, wfull, P, mag, z, zscale, st);
+    case 2048: return launch_stft_n<TC, 2048>(v, g, units, tw, wfull, P, mag, z, zscale, st);
+  }
+  return hipErrorInvalidValue;
+}
+
+template <int N>
+static hipError_t launch_apply_n(const View& v, const Geom& g, int64_t units, const void* tw, const float* wa,
+                                 const float* ws, const float* M, float* seg, hipStream_t st) {
+  constexpr int WAVES = (N * sizeof(cx<float>) > 16384) ? 2 : 4;
+  constexpr int FPW = 4;
+  size_t lds = (size_t)(N + WAVES * N) * sizeof(cx<float>);
+  auto kern = k_apply_istft<N, WAVES, FPW>;
+  if (lds > 65536) {
+    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern),
+                                       hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    if (e != hipSuccess) return e;
+  }
+  dim3 grid((unsigned)((g.T + WAVES * FPW - 1) / (WAVES * FPW)), (unsigned)units);
+  hipLaunchKernelGGL(kern, grid, dim3(WAVES * 64), lds, st, v, g, (const cx<float>*)tw, wa, ws, M, seg);
+  return hipGetLastError();
+}
+
+static hipError_t launch_apply(int N, const View& v, const Geom& g, int64_t units, const void* tw,
+                               const float* wa, const float* ws, const float* M, float* seg, hipStream_t st) {
+  switch (N) {
+    case 32: return launch_apply_n<32>(v, g, units, tw, wa, ws, M, seg, st);
+    case 64: return launch_apply_n<64>(v, g, units, tw, wa, ws, M, seg, st);
+    case 128: return launch_apply_n<128>(v, g, units, tw, wa, ws, M, seg, st);
+    case 256: return launch_apply_n<256>(v, g, units, tw, wa, ws, M, seg, st);
+    case 512: return launch_apply_n<512>(v, g, units, tw, wa, ws, M, seg, st);
+    case 1024: return launch_apply_n<1024>(v, g, units, tw, wa, ws, M, seg, st);
+    case 2048: return launch_apply_n<2048>(v, g, units, tw, wa, ws, M, seg, st);
+  }
+  return hipErrorInvalidValue;
+}
+
+static unsigned grid_1d(int64_t work, int block) {
+  int64_t b = (work + block - 1) / block;
+  return (unsigned)std::min<int64_t>(std::max<int64_t>(b, 1), 256 * 32);
+}
+
+// ------------------------------------------------------------------------------------------
+// create / destroy
+// ------------------------------------------------------------------------------------------
+extern "C" int sg_version(void) { return SG_VERSION; }
+
+extern "C" const char* sg_last_error(const sg_handle* h) { return h ? h->err.c_str() : g_create_error.c_str(); }
+
+static std::vector<double> triangle(int m) {
+  // base.py:7-29 one axis: [1..m, m+1, m..1] / (m+1)
+  std::vector<double> v(2 * m + 1);
+  for (int i = 0; i <= 2 * m; ++i) v[i] = (double)(i <= m ? i + 1 : 2 * m + 1 - i) / (double)(m + 1);
+  return v;
+}
+
+extern "C" int sg_create(const sg_params* p, const double* window_host, sg_handle** out) {
+  if (!p || !out) {
+    g_create_error = "sg_create: null argument";
+    return SG_E_INVALID;
+  }
+  auto bad = [&](int code, const std::string& m) {
+    g_create_error = m;
+    return code;
+  };
+  int n = p->n_fft;
+  if (n < 64 || n > 4096 || (n & (n - 1)))
+    return bad(SG_E_UNSUPPORTED, fmt("n_fft=%d unsupported: must be a power of two in [64, 4096]", n));
+  if (p->win_length < 2 || p->win_length > n)
+    return bad(SG_E_INVALID, fmt("win_length=%d must be in [2, n_fft=%d]", p->win_length, n));
+  if (p->hop_length < 1 || p->hop_length > p->win_length)
+    return bad(SG_E_INVALID, fmt("hop_length=%d must be in [1, win_length]", p->hop_length));
+  if (p->variant != SG_VARIANT_S && p->variant != SG_VARIANT_T) return bad(SG_E_INVALID, "bad variant");
+  if (p->smooth_mask && (p->n_grad_freq < 1 || p->n_grad_time < 1))
+    return bad(SG_E_INVALID, "n_grad_freq / n_grad_time must be >= 1");
+  if (p->variant == SG_VARIANT_S && (p->padding < 0 || p->chunk_size < 1))
+    return bad(SG_E_INVALID, "chunk_size must be >= 1 and padding >= 0");
+  if (!p->stationary && p->variant == SG_VARIANT_T && p->n_movemean < 1)
+    return bad(SG_E_INVALID, "n_movemean must be >= 1");
+
+  sg_handle* h = new sg_handle();
+  h->p = *p;
+  h->n = n;
+  h->N = n / 2;
+  h->W = p->win_length;
+  h->H = p->hop_length;
+  h->F = n / 2 + 1;
+  h->FS = (h->F + 15) / 16 * 16;
+  const int W = h->W;
+  std::vector<double> w(W);
+  if (window_host) {
+    for (int k = 0; k < W; ++k) w[k] = window_host[k];
+  } else {
+    for (int k = 0; k < W; ++k) w[k] = 0.5 - 0.5 * std::cos(2.0 * M_PI * (double)k / (double)W);
+  }
+  h->sum_w = 0.0;
+  for (int k = 0; k < W; ++k) h->sum_w += w[k];
+  // window embedded in an n_fft frame: scipy zero-pads the windowed frame at the END
+  // (scipy/_spectral_py.py:2202) and extends the signal by W//2; torch centres the window
+  // inside n_fft and pads the signal by n_fft//2.
+  std::vector<double> wfull(n, 0.0);
+  int left = (p->variant == SG_VARIANT_S) ? 0 : (n - W) / 2;
+  for (int k = 0; k < W; ++k) wfull[left + k] = w[k];
+  h->padL = (p->variant == SG_VARIANT_S) ? W / 2 : n / 2;
+  h->mag_scale = (p->variant == SG_VARIANT_S) ? 1.0 / h->sum_w : 1.0;
+
+  std::vector<cx<double>> tw64(h->N);
+  std::vector<cx<float>> tw32(h->N);
+  for (int k = 0; k < h->N; ++k) {
+    long double a = -2.0L * 3.14159265358979323846264338327950288L * (long double)k / (long double)n;
+    tw64[k] = {(double)cosl(a), (double)sinl(a)};
+    tw32[k] = {(float)cosl(a), (float)sinl(a)};
+  }
+  std::vector<float> wa32(n), ws32(n), wsq32(n);
+  for (int k = 0; k < n; ++k) {
+    wa32[k] = (float)wfull[k];
+    ws32[k] = (float)(wfull[k] / (double)h->N);
+    wsq32[k] = (float)(wfull[k] * wfull[k]);
+  }
+  int rc = SG_OK;
+  if (!rc) rc = upload(h, h->tw64, tw64.data(), tw64.size() * sizeof(cx<double>));
+  if (!rc) rc = upload(h, h->tw32, tw32.data(), tw32.size() * sizeof(cx<float>));
+  if (!rc) rc = upload(h, h->wfull64, wfull.data(), wfull.size() * sizeof(double));
+  if (!rc) rc = upload(h, h->wa32, wa32.data(), wa32.size() * sizeof(float));
+  if (!rc) rc = upload(h, h->ws32, ws32.data(), ws32.size() * sizeof(float));
+  if (!rc) rc = upload(h, h->wsq32, wsq32.data(), wsq32.size() * sizeof(float));
+  if (!rc && p->smooth_mask) {
+    auto vf = triangle(p->n_grad_freq), vt = triangle(p->n_grad_time);
+    double sf = 0, stt = 0;
+    for (double x : vf) sf += x;
+    for (double x : vt) stt += x;
+    std::vector<float> kf(vf.size()), kt(vt.size());
+    for (size_t i = 0; i < vf.size(); ++i) kf[i] = (float)(vf[i] / sf);
+    for (size_t i = 0; i < vt.size(); ++i) kt[i] = (float)(vt[i] / stt);
+    if (!rc) rc = upload(h, h->kf, kf.data(), kf.size() * sizeof(float));
+    if (!rc) rc = upload(h, h->kt, kt.data(), kt.size() * sizeof(float));
+  }
+  if (!rc) rc = ensure(h, h->thresh, (size_t)h->FS * sizeof(double));
+  if (rc) {
+    g_create_error = h->err;
+    sg_destroy(h);
+    return rc;
+  }
+  *out = h;
+  return SG_OK;
+}
+
+extern "C" int sg_destroy(sg_handle* h) {
+  if (!h) return SG_OK;
+  (void)hipDeviceSynchronize();
+  for (DevBuf* b : {&h->tw64, &h->tw32, &h->wfull64, &h->wa32, &h->ws32, &h->wsq32, &h->kf, &h->kt, &h->thresh,
+                    &h->P, &h->pmax, &h->thr_rows, &h->raw, &h->M, &h->seg, &h->yn})
+    free_buf(*b);
+  delete h;
+  return SG_OK;
+}
+
+extern "C" int sg_n_frames(const sg_handle* h, int64_t L, int64_t* n_frames) {
+  if (!h || !n_frames) return SG_E_INVALID;
+  *n_frames = frames_for(h, L);
+  return SG_OK;
+}
+extern "C" int sg_output_length(const sg_handle* h, int64_t L, int64_t* out_len) {
+  if (!h || !out_len) return SG_E_INVALID;
+  *out_len = outlen_for(h, L);
+  return SG_OK;
+}
+
+// ------------------------------------------------------------------------------------------
+// workspace
+// ------------------------------------------------------------------------------------------
+static int64_t ws_budget(const sg_handle* h) {
+  return h->p.max_workspace_bytes > 0 ? h->p.max_workspace_bytes : (int64_t)8 << 30;
+}
+
+static size_t unit_bytes(const sg_handle* h, const Geom& g) {
+  size_t cells = (size_t)g.T * g.FS;
+  return cells * (8 + 4 + 4) + (size_t)g.T * g.n * 4 + (size_t)g.FS * 16;
+}
+
+static int64_t units_per_batch(const sg_handle* h, const Geom& g, int64_t total) {
+  int64_t ub = ws_budget(h) / (int64_t)unit_bytes(h, g);
+  ub = std::max<int64_t>(1, std::min<int64_t>(ub, 32768));
+  return std::min(ub, total);
+}
+
+static int ensure_ws(sg_handle* h, const Geom& g, int64_t ub) {
+  size_t cells = (size_t)ub * g.T * g.FS;
+  int rc;
+  if ((rc = ensure(h, h->P, cells * 8))) return rc;  // power (f64) or magnitude (f32)
+  if ((rc = ensure(h, h->raw, cells * 4))) return rc;
+  if ((rc = ensure(h, h->M, cells * 4))) return rc;
+  if ((rc = ensure(h, h->seg, std::max((size_t)ub * g.T * g.n * 4, cells * 4)))) return rc;
+  if ((rc = ensure(h, h->pmax, (size_t)ub * g.FS * 8))) return rc;
+  if ((rc = ensure(h, h->thr_rows, (size_t)ub * g.FS * 8))) return rc;
+  return SG_OK;
+}
+
+// ------------------------------------------------------------------------------------------
+// pipeline pieces (all enqueue on `st`)
+// ------------------------------------------------------------------------------------------
+// power field + column max of a batch of units
+static int stage_power(sg_handle* h, const View& v, const Geom& g, int64_t ub, hipStream_t st) {
+  HIPCHK(h, launch_stft<double>(h->N, v, g, ub, h->tw64.p, h->wfull64.p, (double*)h->P.p, nullptr, nullptr, 1.0,
+                                st));
+  dim3 grid((g.F + 63) / 64, (unsigned)ub);
+  hipLaunchKernelGGL(k_colmax, grid, dim3(64 * STAT_TG), 0, st, (const double*)h->P.p, g, (double*)h->pmax.p);
+  HIPCHK(h, hipGetLastError());
+  return SG_OK;
+}
+
+static int stage_colstats(sg_handle* h, const Geom& g, int64_t ub, double* thresh_out, hipStream_t st) {
+  dim3 grid((g.F + 63) / 64, (unsigned)ub);
+  hipLaunchKernelGGL(k_colstats, grid, dim3(64 * STAT_TG), 0, st, (const double*)h->P.p, g,
+                     (const double*)h->pmax.p, h->mag_scale, h->p.top_db, h->p.n_std_thresh, h->p.ddof,
+                     thresh_out);
+  HIPCHK(h, hipGetLastError());
+  return SG_OK;
+}
+
+static int stage_decide(sg_handle* h, const Geom& g, int64_t ub, const double* thresh, int64_t ustride,
+                        hipStream_t st) {
+  int64_t cells = ub * g.T * g.FS;
+  hipLaunchKernelGGL(k_decide, dim3(grid_1d(cells, 256)), dim3(256), 0, st, (const double*)h->P.p, g,
+                     (const double*)h->pmax.p, thresh, ustride, h->mag_scale, h->p.top_db, (float*)h->raw.p, ub);
+  HIPCHK(h, hipGetLastError());
+  return SG_OK;
+}
+
+static int stage_nonstat_raw(sg_handle* h, const View& v, const Geom& g, int64_t ub, hipStream_t st) {
+  float* mag = (float*)h->P.p;
+  HIPCHK(h, launch_stft<float>(h->N, v, g, ub, h->tw32.p, h->wa32.p, nullptr, mag, nullptr, 1.0, st));
+  dim3 grid((g.F + 63) / 64, (unsigned)ub);
+  if (h->p.variant == SG_VARIANT_S) {
+    // |Z| scale (1/sum_w) cancels in (A-S)/S: work on the unscaled magnitude.
+    hipLaunchKernelGGL(k_iir_sigmoid, grid, dim3(64), 0, st, (const float*)mag, g, h->p.iir_b,
+                       h->p.nonstat_thresh, h->p.nonstat_slope, (float*)h->raw.p);
+  } else {
+    hipLaunchKernelGGL(k_boxcar_sigmoid, grid, dim3(64), 0, st, (const float*)mag, g, h->p.n_movemean,
+                       h->p.nonstat_thresh, h->p.nonstat_slope, (float*)h->raw.p);
+  }
+  HIPCHK(h, hipGetLastError());
+  return SG_OK;
+}
+
+static int stage_smooth(sg_handle* h, const Geom& g, int64_t ub, hipStream_t st) {
+  int64_t cells = ub * g.T * g.FS;
+  float p = (float)h->p.prop_decrease;
+  if (!h->p.smooth_mask) {
+    hipLaunchKernelGGL(k_prop_only, dim3(grid_1d(cells, 256)), dim3(256), 0, st, (const float*)h->raw.p, g, p,
+                       (float*)h->M.p, ub);
+    HIPCHK(h, hipGetLastError());
+    return SG_OK;
+  }
+  float* tmp = (float*)h->seg.p;  // seg is not live yet
+  hipLaunchKernelGGL(k_smooth_f, dim3(grid_1d(cells, 256)), dim3(256), 0, st, (const float*)h->raw.p, g,
+                     (const float*)h->kf.p, h->p.n_grad_freq, tmp, ub);
+  HIPCHK(h, hipGetLastError());
+  // prop_decrease is applied before smoothing by stationary.py:108-114 and torchgate.py:241-249,
+  // after smoothing by nonstationary.py:78-84.
+  int prop_before = (h->p.variant == SG_VARIANT_T || h->p.stationary) ? 1 : 0;
+  hipLaunchKernelGGL(k_smooth_t, dim3(grid_1d(cells, 256)), dim3(256), 0, st, (const float*)tmp, g,
+                     (const float*)h->kt.p, h->p.n_grad_time, (const float*)h->kf.p, h->p.n_grad_freq, p,
+                     prop_before, (float*)h->M.p, ub);
+  HIPCHK(h, hipGetLastError());
+  return SG_OK;
+}
+
+static int stage_apply_ola(sg_handle* h, const View& v, const Geom& g, int64_t ub, const float* M,
+                           const OutMap& om, int normalize, hipStream_t st) {
+  HIPCHK(h, launch_apply(h->N, v, g, ub, h->tw32.p, (const float*)h->wa32.p, (const float*)h->ws32.p, M,
+                         (float*)h->seg.p, st));
+  int64_t np = om.p1 - om.p0;
+  if (np > 0) {
+    dim3 grid((unsigned)((np + 255) / 256), (unsigned)ub);
+    hipLaunchKernelGGL(k_ola, grid, dim3(256), 0, st, v, g, om, (const float*)h->seg.p, (const float*)h->wsq32.p,
+                       normalize);
+    HIPCHK(h, hipGetLastError());
+  }
+  return SG_OK;
+}
+
+// Variant S over a set of units described by `v` (unit0 filled per batch).
+static int run_S(sg_handle* h, View v, int64_t total_units, const OutMap& om, hipStream_t st) {
+  Geom g = make_geom(h, v.Lp);
+  if (v.Lp < h->W) FAIL(h, SG_E_INVALID, "signal window of %lld samples is shorter than win_length=%d",
+                        (long long)v.Lp, h->W);
+  if (h->p.stationary && !h->has_thresh)
+    FAIL(h, SG_E_STATE, "stationary gate: call sg_noise_stats or sg_set_noise_threshold first");
+  int64_t ub = units_per_batch(h, g, total_units);
+  int rc = ensure_ws(h, g, ub);
+  if (rc) return rc;
+  for (int64_t u0 = 0; u0 < total_units; u0 += ub) {
+    int64_t nb = std::min(ub, total_units - u0);
+    v.unit0 = u0;
+    if (h->p.stationary) {
+      if ((rc = stage_power(h, v, g, nb, st))) return rc;
+      if ((rc = stage_decide(h, g, nb, (const double*)h->thresh.p, 0, st))) return rc;
+    } else {
+      if ((rc = stage_nonstat_raw(h, v, g, nb, st))) return rc;
+    }
+    if ((rc = stage_smooth(h, g, nb, st))) return rc;
+    if ((rc = stage_apply_ola(h, v, g, nb, (const float*)h->M.p, om, 1, st))) return rc;
+    h->dbg_units = nb;
+    h->dbg_T = g.T;
+    h->dbg_has_P = h->p.stationary != 0;
+  }
+  return SG_OK;
+}
+
+static bool dtype_ok(int d) { return d >= SG_F32 && d <= SG_I32; }
+
+// ------------------------------------------------------------------------------------------
+// variant S entry points
+// ------------------------------------------------------------------------------------------
+extern "C" int sg_noise_stats(sg_handle* h, const void* noise_dev, int dtype, int64_t C, int64_t n,
+                              int64_t row_stride, void* stream) {
+  if (!h) return SG_E_INVALID;
+  if (!noise_dev || !dtype_ok(dtype) || C < 1 || n < 1) FAIL(h, SG_E_INVALID, "sg_noise_stats: bad argument");
+  if (h->p.variant != SG_VARIANT_S) FAIL(h, SG_E_INVALID, "sg_noise_stats is a variant-S entry point");
+  if (n < h->W) FAIL(h, SG_E_INVALID, "noise clip of %lld samples is shorter than win_length=%d", (long long)n, h->W);
+  hipStream_t st = (hipStream_t)stream;
+  int rc = ensure(h, h->yn, (size_t)n * sizeof(double));
+  if (rc) return rc;
+  hipLaunchKernelGGL(k_channel_mean, dim3(grid_1d(n, 256)), dim3(256), 0, st, noise_dev, dtype, C, n, row_stride,
+                     (double*)h->yn.p);
+  HIPCHK(h, hipGetLastError());
+  View v{};
+  v.x = h->yn.p; v.dtype = SG_F64; v.stride = n; v.N = n; v.cs = 0; v.pad = 0; v.Lp = n; v.n_chunks = 1; v.unit0 = 0;
+  Geom g = make_geom(h, n);
+  if ((rc = ensure_ws(h, g, 1))) return rc;
+  if ((rc = stage_power(h, v, g, 1, st))) return rc;
+  if ((rc = stage_colstats(h, g, 1, (double*)h->thresh.p, st))) return rc;
+  h->has_thresh = true;
+  return SG_OK;
+}
+
+extern "C" int sg_get_noise_threshold(sg_handle* h, double* thresh_host, int32_t n_bins, void* stream) {
+  if (!h) return SG_E_INVALID;
+  if (!thresh_host || n_bins != h->F) FAIL(h, SG_E_INVALID, "sg_get_noise_threshold: n_bins must be %d", h->F);
+  if (!h->has_thresh) FAIL(h, SG_E_STATE, "no noise threshold set");
+  HIPCHK(h, hipMemcpyAsync(thresh_host, h->thresh.p, (size_t)h->F * sizeof(double), hipMemcpyDeviceToHost,
+                           (hipStream_t)stream));
+  HIPCHK(h, hipStreamSynchronize((hipStream_t)stream));
+  return SG_OK;
+}
+
+extern "C" int sg_set_noise_threshold(sg_handle* h, const double* thresh_host, int32_t n_bins, void* stream) {
+  if (!h) return SG_E_INVALID;
+  if (!thresh_host || n_bins != h->F) FAIL(h, SG_E_INVALID, "sg_set_noise_threshold: n_bins must be %d", h->F);
+  HIPCHK(h, hipMemcpyAsync(h->thresh.p, thresh_host, (size_t)h->F * sizeof(double), hipMemcpyHostToDevice,
+                           (hipStream_t)stream));
+  HIPCHK(h, hipStreamSynchronize((hipStream_t)stream));
+  h->has_thresh = true;
+  return SG_OK;
+}
+
+extern "C" int sg_process_chunks(sg_handle* h, const void* in_dev, int in_dtype, void* out_dev, int out_dtype,
+                                 int64_t C, int64_t N, int64_t in_stride, int64_t out_stride,
+                                 int64_t start_frame, int64_t end_frame, int32_t chunked, void* stream) {
+  if (!h) return SG_E_INVALID;
+  if (h->p.variant != SG_VARIANT_S) FAIL(h, SG_E_INVALID, "sg_process_chunks is a variant-S entry point");
+  if (!in_dev || !out_dev || !dtype_ok(in_dtype) || !dtype_ok(out_dtype) || C < 1 || N < 1)
+    FAIL(h, SG_E_INVALID, "sg_process_chunks: bad argument");
+  if (start_frame < 0 || end_frame > N || start_frame >= end_frame)
+    FAIL(h, SG_E_INVALID, "sg_process_chunks: bad frame range [%lld, %lld)", (long long)start_frame,
+         (long long)end_frame);
+  const int64_t cs = h->p.chunk_size, pad = h->p.padding;
+  View v{};
+  v.x = in_dev; v.dtype = in_dtype; v.stride = in_stride; v.N = N; v.pad = pad;
+  OutMap om{};
+  om.out = out_dev; om.dtype = out_dtype; om.stride = out_stride; om.g0 = start_frame;
+  om.g_lo = start_frame; om.g_hi = end_frame;
+  int64_t units;
+  if (chunked) {
+    // base.py:175-216: chunks ich1..ich2, each filtered over [i*cs - pad, (i+1)*cs + pad)
+    int64_t ich1 = start_frame / cs, ich2 = (end_frame - 1) / cs;
+    int64_t n_chunks = ich2 + 1;  // chunk index == unit % n_chunks; chunks < ich1 are skipped below
+    v.cs = cs; v.Lp = cs + 2 * pad; v.n_chunks = (int32_t)n_chunks;
+    om.p0 = pad; om.p1 = pad + cs; om.g_step = cs;
+    units = C * n_chunks;
+    (void)ich1;  // units of chunks before ich1 write nothing (g_lo clips them); cheap enough for v1
+  } else {
+    // base.py:222: one window [-pad, end_frame + pad) -- start_frame is ignored by the reference
+    v.cs = 0; v.Lp = end_frame + 2 * pad; v.n_chunks = 1;  // _read_chunk may read past end_frame (base.py:136-141)
+    om.p0 = pad; om.p1 = pad + end_frame; om.g_step = 0;
+    om.g_lo = 0; om.g0 = 0;
+    units = C;
+  }
+  return run_S(h, v, units, om, (hipStream_t)stream);
+}
+
+extern "C" int sg_filter_padded(sg_handle* h, const void* chunk_dev, int in_dtype, void* out_dev, int out_dtype,
+                                int64_t C, int64_t Lp, int64_t in_stride, int64_t out_stride, void* stream) {
+  if (!h) return SG_E_INVALID;
+  if (h->p.variant != SG_VARIANT_S) FAIL(h, SG_E_INVALID, "sg_filter_padded is a variant-S entry point");
+  if (!chunk_dev || !out_dev || !dtype_ok(in_dtype) || !dtype_ok(out_dtype) || C < 1 || Lp < 1)
+    FAIL(h, SG_E_INVALID, "sg_filter_padded: bad argument");
+  View v{};
+  v.x = chunk_dev; v.dtype = in_dtype; v.stride = in_stride; v.N = Lp; v.cs = 0; v.pad = 0; v.Lp = Lp; v.n_chunks = 1;
+  OutMap om{};
+  om.out = out_dev; om.dtype = out_dtype; om.stride = out_stride;
+  om.p0 = 0; om.p1 = Lp; om.g_step = 0; om.g0 = 0; om.g_lo = 0; om.g_hi = Lp;
+  return run_S(h, v, C, om, (hipStream_t)stream);
+}
+
+// ------------------------------------------------------------------------------------------
+// variant T
+// ------------------------------------------------------------------------------------------
+extern "C" int sg_process_batch(sg_handle* h, const void* x_dev, int dtype, int64_t B, int64_t L, int64_t x_stride,
+                                const void* xn_dev, int64_t Bn, int64_t Ln, int64_t xn_stride, void* out_dev,
+                                int out_dtype, int64_t out_stride, void* stream) {
+  if (!h) return SG_E_INVALID;
+  if (h->p.variant != SG_VARIANT_T) FAIL(h, SG_E_INVALID, "sg_process_batch is a variant-T entry point");
+  if (!x_dev || !out_dev || !dtype_ok(dtype) || !dtype_ok(out_dtype) || B < 1)
+    FAIL(h, SG_E_INVALID, "sg_process_batch: bad argument");
+  if (L < 2 * (int64_t)h->W) FAIL(h, SG_E_INVALID, "x must be bigger than %d", 2 * h->W);  // torchgate.py:215-216
+  if (xn_dev) {
+    if (Ln < 2 * (int64_t)h->W) FAIL(h, SG_E_INVALID, "xn must be bigger than %d", 2 * h->W);  // :219-220
+    if (Bn != 1 && Bn != B) FAIL(h, SG_E_INVALID, "xn rows (%lld) must be 1 or the batch size", (long long)Bn);
+  }
+  hipStream_t st = (hipStream_t)stream;
+  View v{};
+  v.x = x_dev; v.dtype = dtype; v.stride = x_stride; v.N = L; v.cs = 0; v.pad = 0; v.Lp = L; v.n_chunks = 1;
+  Geom g = make_geom(h, L);
+  OutMap om{};
+  om.out = out_dev; om.dtype = out_dtype; om.stride = out_stride;
+  om.p0 = 0; om.p1 = g.Lout; om.g_step = 0; om.g0 = 0; om.g_lo = 0; om.g_hi = g.Lout;
+  View vn{};
+  Geom gn{};
+  if (xn_dev && h->p.stationary) {
+    vn.x = xn_dev; vn.dtype = dtype; vn.stride = xn_stride; vn.N = Ln; vn.cs = 0; vn.pad = 0; vn.Lp = Ln; vn.n_chunks = 1;
+    gn = make_geom(h, Ln);
+  }
+  // size the workspace for the larger of the two geometries
+  Geom gbig = (xn_dev && h->p.stationary && gn.T > g.T) ? gn : g;
+  int64_t ub = units_per_batch(h, gbig, B);
+  int rc = ensure_ws(h, gbig, ub);
+  if (rc) return rc;
+  double* thr = (double*)h->thr_rows.p;
+  if (xn_dev && h->p.stationary && Bn == 1) {
+    vn.unit0 = 0;
+    if ((rc = stage_power(h, vn, gn, 1, st))) return rc;
+    if ((rc = stage_colstats(h, gn, 1, (double*)h->thresh.p, st))) return rc;
+  }
+  for (int64_t u0 = 0; u0 < B; u0 += ub) {
+    int64_t nb = std::min(ub, B - u0);
+    v.unit0 = u0;
+    if (h->p.stationary) {
+      const double* th;
+      int64_t ustride;
+      if (xn_dev && Bn == 1) {
+        th = (const double*)h->thresh.p; ustride = 0;
+      } else if (xn_dev) {
+        vn.unit0 = u0;
+        if ((rc = stage_power(h, vn, gn, nb, st))) return rc;
+        if ((rc = stage_colstats(h, gn, nb, thr, st))) return rc;
+        th = thr; ustride = g.FS;
+      } else {
+        th = nullptr; ustride = g.FS;
+      }
+      if ((rc = stage_power(h, v, g, nb, st))) return rc;
+      if (!th) {
+        if ((rc = stage_colstats(h, g, nb, thr, st))) return rc;
+        th = thr;
+      }
+      if ((rc = stage_decide(h, g, nb, th, ustride, st))) return rc;
+    } else {
+      if ((rc = stage_nonstat_raw(h, v, g, nb, st))) return rc;
+    }
+    if ((rc = stage_smooth(h, g, nb, st))) return rc;
+    if ((rc = stage_apply_ola(h, v, g, nb, (const float*)h->M.p, om, 1, st))) return rc;
+    h->dbg_units = nb;
+    h->dbg_T = g.T;
+    h->dbg_has_P = h->p.stationary != 0;
+  }
+  return SG_OK;
+}
+
+extern "C" int sg_process_batch_backward(sg_handle* h, const void*, int, int64_t, int64_t, int64_t, void*, int64_t,
+                                         void*) {
+  if (!h) return SG_E_INVALID;
+  FAIL(h, SG_E_UNSUPPORTED, "sg_process_batch_backward: not implemented yet");
+}
+
+// ------------------------------------------------------------------------------------------
+// stage taps
+// ------------------------------------------------------------------------------------------
+extern "C" int sg_stft(sg_handle* h, const void* x_dev, int dtype, int64_t B, int64_t L, int64_t stride,
+                       double* z_dev, void* stream) {
+  if (!h) return SG_E_INVALID;
+  if (!x_dev || !z_dev || !dtype_ok(dtype) || B < 1 || L < h->W) FAIL(h, SG_E_INVALID, "sg_stft: bad argument");
+  View v{};
+  v.x = x_dev; v.dtype = dtype; v.stride = stride; v.N = L; v.cs = 0; v.pad = 0; v.Lp = L; v.n_chunks = 1; v.unit0 = 0;
+  Geom g = make_geom(h, L);
+  HIPCHK(h, launch_stft<double>(h->N, v, g, B, h->tw64.p, h->wfull64.p, nullptr, nullptr, z_dev, h->mag_scale,
+                                (hipStream_t)stream));
+  return SG_OK;
+}
+
+extern "C" int sg_debug_dims(const sg_handle* h, int64_t dims[3]) {
+  if (!h || !dims) return SG_E_INVALID;
+  dims[0] = h->dbg_units; dims[1] = h->dbg_T; dims[2] = h->FS;
+  return SG_OK;
+}
+
+extern "C" int sg_debug_fetch(sg_handle* h, int32_t what, void* host, int64_t bytes, void* stream) {
+  if (!h) return SG_E_INVALID;
+  if (!host || h->dbg_units == 0) FAIL(h, SG_E_STATE, "sg_debug_fetch: nothing processed yet");
+  size_t cells = (size_t)h->dbg_units * h->dbg_T * h->FS;
+  const void* src;
+  size_t need;
+  switch (what) {
+    case 0: src = h->raw.p; need = cells * 4; break;
+    case 1: src = h->M.p; need = cells * 4; break;
+    case 2:
+      if (!h->dbg_has_P) FAIL(h, SG_E_STATE, "power field only exists for stationary gates");
+      src = h->P.p; need = cells * 8; break;
+    default: FAIL(h, SG_E_INVALID, "sg_debug_fetch: unknown field %d", what);
+  }
+  if ((size_t)bytes != need) FAIL(h, SG_E_INVALID, "sg_debug_fetch: need %zu bytes, got %lld", need, (long long)bytes);
+  HIPCHK(h, hipStreamSynchronize((hipStream_t)stream));
+  HIPCHK(h, hipMemcpy(host, src, need, hipMemcpyDeviceToHost));
+  return SG_OK;
+}

@@ -1,0 +1,162 @@
+// Per-wavefront Stockham FFT for gfx950 (wave64).
+//
+// One 64-lane wavefront transforms one complex sequence of length N (N = n_fft/2, the
+// real frame packed as even/odd pairs) that lives in that wave's private LDS slice.
+// Constant-geometry Stockham autosort passes of radix 8/4/2: in every pass lane l owns
+// butterflies i = l, l+64, ... ; it reads x[i + j*N/R] (conflict-free, lane-contiguous),
+// does the R-point DFT in registers, applies the twiddle w^(p*k) and writes
+// y[(i-q)*R + q + s*k].  Reads of a pass complete before its writes start (WAVE_SYNC),
+// so the transform is in place; the result comes out in natural order.
+//
+// Twiddles come from one master table tw[k] = exp(-2*pi*i*k/(2N)), k in [0, N), shared
+// by the whole workgroup in LDS: it serves both the complex passes (w_N^t = tw[2t], with
+// tw[k+N] = -tw[k]) and the real-FFT split/merge step (w_2N^k).
+#pragma once
+#include <hip/hip_runtime.h>
+
+namespace sg {
+
+template <typename T>
+struct cx {
+  T x, y;
+};
+
+template <typename T>
+__device__ __forceinline__ cx<T> cadd(cx<T> a, cx<T> b) { return {a.x + b.x, a.y + b.y}; }
+template <typename T>
+__device__ __forceinline__ cx<T> csub(cx<T> a, cx<T> b) { return {a.x - b.x, a.y - b.y}; }
+template <typename T>
+__device__ __forceinline__ cx<T> cmul(cx<T> a, cx<T> b) {
+  return {a.x * b.x - a.y * b.y, a.x * b.y + a.y * b.x};
+}
+// multiply by -i (forward) or +i (inverse)
+template <bool INV, typename T>
+__device__ __forceinline__ cx<T> rot90(cx<T> a) {
+  if (INV) return {-a.y, a.x};
+  return {a.y, -a.x};
+}
+
+// Workgroup-level sync between FFT passes.  All waves of a block run the same pass
+// sequence, so a block barrier is always legal here.
+#define SG_PASS_SYNC() __syncthreads()
+
+template <bool INV, typename T>
+__device__ __forceinline__ void dft2(cx<T>* v) {
+  cx<T> a = v[0], b = v[1];
+  v[0] = cadd(a, b);
+  v[1] = csub(a, b);
+}
+
+template <bool INV, typename T>
+__device__ __forceinline__ void dft4(cx<T>* v) {
+  cx<T> s02 = cadd(v[0], v[2]), d02 = csub(v[0], v[2]);
+  cx<T> s13 = cadd(v[1], v[3]), d13 = rot90<INV>(csub(v[1], v[3]));
+  v[0] = cadd(s02, s13);
+  v[2] = csub(s02, s13);
+  v[1] = cadd(d02, d13);
+  v[3] = csub(d02, d13);
+}
+
+template <bool INV, typename T>
+__device__ __forceinline__ void dft8(cx<T>* v) {
+  cx<T> e[4] = {v[0], v[2], v[4], v[6]};
+  cx<T> o[4] = {v[1], v[3], v[5], v[7]};
+  dft4<INV>(e);
+  dft4<INV>(o);
+  const T h = (T)0.70710678118654752440;
+  // o[k] *= w8^k,  w8 = exp(-+ i pi/4)
+  {
+    cx<T> t = o[1];
+    if (INV) o[1] = {(t.x - t.y) * h, (t.x + t.y) * h};
+    else     o[1] = {(t.x + t.y) * h, (t.y - t.x) * h};
+    o[2] = rot90<INV>(o[2]);
+    t = o[3];
+    if (INV) o[3] = {(-t.x - t.y) * h, (t.x - t.y) * h};
+    else     o[3] = {(t.y - t.x) * h, (-t.x - t.y) * h};
+  }
+#pragma unroll
+  for (int k = 0; k < 4; ++k) {
+    v[k] = cadd(e[k], o[k]);
+    v[k + 4] = csub(e[k], o[k]);
+  }
+}
+
+template <int R, bool INV, typename T>
+__device__ __forceinline__ void dftR(cx<T>* v) {
+  if (R == 8) dft8<INV>(v);
+  else if (R == 4) dft4<INV>(v);
+  else dft2<INV>(v);
+}
+
+// w_N^t from the master table (w_2N^k, k < N);  conjugated for the inverse transform.
+template <int N, bool INV, typename T>
+__device__ __forceinline__ cx<T> twN(const cx<T>* tw, int t) {
+  int k = 2 * t;
+  cx<T> w;
+  if (k < N) {
+    w = tw[k];
+  } else {
+    w = tw[k - N];
+    w.x = -w.x;
+    w.y = -w.y;
+  }
+  if (INV) w.y = -w.y;
+  return w;
+}
+
+template <typename T, int N, int S, bool INV>
+struct FftPass {
+  static __device__ __forceinline__ void run(cx<T>* buf, const cx<T>* tw, int lane) {
+    constexpr int NR = N / S;  // current sub-transform length
+    constexpr int R = (NR % 8 == 0) ? 8 : ((NR % 4 == 0) ? 4 : 2);
+    constexpr int NB = N / R;  // butterflies in this pass
+    constexpr int PER = (NB + 63) / 64;
+    cx<T> v[PER][R];
+#pragma unroll
+    for (int c = 0; c < PER; ++c) {
+      int i = lane + 64 * c;
+      if (NB >= 64 || i < NB) {
+#pragma unroll
+        for (int j = 0; j < R; ++j) v[c][j] = buf[i + j * NB];
+      }
+    }
+    SG_PASS_SYNC();
+#pragma unroll
+    for (int c = 0; c < PER; ++c) {
+      int i = lane + 64 * c;
+      if (NB >= 64 || i < NB) {
+        int q = i & (S - 1);
+        int base = i - q;  // = p * S
+        dftR<R, INV>(v[c]);
+        if (NR != R) {  // the last pass has p == 0: all twiddles are 1
+#pragma unroll
+          for (int k = 1; k < R; ++k) v[c][k] = cmul(v[c][k], twN<N, INV>(tw, base * k));
+        }
+        int o = base * R + q;
+#pragma unroll
+        for (int k = 0; k < R; ++k) buf[o + S * k] = v[c][k];
+      }
+    }
+    SG_PASS_SYNC();
+    if constexpr (NR / R > 1) FftPass<T, N, S * R, INV>::run(buf, tw, lane);
+  }
+};
+
+// In-place complex FFT of buf[0..N) (unnormalised; INV uses exp(+i...)).
+template <typename T, int N, bool INV>
+__device__ __forceinline__ void wave_fft(cx<T>* buf, const cx<T>* tw, int lane) {
+  FftPass<T, N, 1, INV>::run(buf, tw, lane);
+}
+
+// Real-FFT split: from Zc = FFT_N(x_even + i x_odd) compute bin k of the length-2N real
+// transform, k in [0, N].  a = Zc[k], b = Zc[N-k] (a = b = Zc[0] for k = 0 and k = N).
+template <typename T>
+__device__ __forceinline__ cx<T> rfft_bin(cx<T> a, cx<T> b, cx<T> w, int k, int N) {
+  if (k == 0) return {a.x + a.y, (T)0};
+  if (k == N) return {a.x - a.y, (T)0};
+  cx<T> E = {(a.x + b.x) * (T)0.5, (a.y - b.y) * (T)0.5};
+  cx<T> O = {(a.y + b.y) * (T)0.5, (b.x - a.x) * (T)0.5};  // (a - conj b) / (2i)
+  return cadd(E, cmul(w, O));
+}
+
+}  // namespace sg

@@ -1,0 +1,462 @@
+// Device kernels of the spectral-gating path (v1: every field materialised in HBM).
+//
+// Layout of all time-frequency fields: [unit][frame t][FS] with FS = round_up(F, 16),
+// bin index contiguous -- one STFT frame is one contiguous row, so the FFT kernels
+// store/load rows with lane-contiguous (coalesced) accesses and the time recurrences
+// walk rows with lanes = bins.
+//
+// A "unit" is one independently filtered signal window: a (channel, chunk) pair of the
+// reference's chunk grid (base.py:144-156) or one batch row of TorchGate.forward.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#include "fft_wave.hpp"
+
+namespace sg {
+
+// How a unit's samples map onto the caller's planar (rows, N) buffer.  Sample s of unit
+// u = (row r, chunk i) is x[r*stride + i*cs - pad + s] when that index is inside [0, N),
+// else 0 (SpectralGate._read_chunk, base.py:130-142).
+struct View {
+  const void* x;
+  int dtype;        // SG_F32 ...
+  int64_t stride;   // elements between rows
+  int64_t N;        // valid samples per row
+  int64_t cs;       // chunk step (0 when n_chunks == 1)
+  int64_t pad;      // zero/neighbour padding before the chunk start
+  int64_t Lp;       // samples per unit window
+  int32_t n_chunks; // units per row
+  int64_t unit0;    // global index of this batch's first unit (unit = row*n_chunks + chunk)
+};
+
+struct Geom {
+  int32_t n, W, H, F, FS, padL;  // padL: zero extension before sample 0 (W/2 scipy, n/2 torch)
+  int64_t T;                     // frames per unit
+  int64_t Lout;                  // valid ISTFT samples per unit
+};
+
+__device__ __forceinline__ double load_sample(const void* p, int dtype, int64_t idx) {
+  switch (dtype) {
+    case 0: return (double)((const float*)p)[idx];
+    case 1: return ((const double*)p)[idx];
+    case 2: return (double)((const int16_t*)p)[idx];
+    default: return (double)((const int32_t*)p)[idx];
+  }
+}
+
+__device__ __forceinline__ double view_sample(const View& v, int64_t row, int64_t chunk, int64_t s) {
+  if (s < 0 || s >= v.Lp) return 0.0;
+  int64_t g = chunk * v.cs - v.pad + s;
+  if (g < 0 || g >= v.N) return 0.0;
+  return load_sample(v.x, v.dtype, row * v.stride + g);
+}
+
+__device__ __forceinline__ void store_sample(void* p, int dtype, int64_t idx, float val) {
+  switch (dtype) {
+    case 0: ((float*)p)[idx] = val; break;
+    case 1: ((double*)p)[idx] = (double)val; break;
+    case 2: ((int16_t*)p)[idx] = (int16_t)val; break;  // truncation, like ndarray.astype
+    default: ((int32_t*)p)[idx] = (int32_t)val; break;
+  }
+}
+
+// ---------------------------------------------------------------------------------------
+// Forward STFT.  One wavefront per frame, FPW frames per wave, WAVES waves per block.
+//   TC = double: stores the power |X|^2 (float64) -- the decision-critical quantity
+//                (the stationary mask is a hard compare).
+//   TC = float : stores the magnitude |X| (float32) for the non-stationary masks.
+// X is the UNSCALED transform of window * frame (scipy's 1/sum(w) is applied by consumers).
+// Optionally dumps X itself (float64 pairs, [u][t][F]) for the stage tap sg_stft.
+// ---------------------------------------------------------------------------------------
+template <typename TC, int N, int WAVES, int FPW>
+__global__ __launch_bounds__(WAVES * 64) void k_stft(View view, Geom g, const cx<TC>* __restrict__ tw_g,
+                                                     const TC* __restrict__ wfull,
+                                                     double* __restrict__ P_out, float* __restrict__ mag_out,
+                                                     double* __restrict__ z_out, double z_scale) {
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  cx<TC>* tw = reinterpret_cast<cx<TC>*>(smem);
+  cx<TC>* bufs = tw + N;
+  const int lane = threadIdx.x & 63;
+  const int wave = threadIdx.x >> 6;
+  cx<TC>* buf = bufs + wave * N;
+  for (int i = threadIdx.x; i < N; i += WAVES * 64) tw[i] = tw_g[i];
+  const int64_t u = blockIdx.y;
+  const int64_t row = (view.unit0 + u) / view.n_chunks;
+  const int64_t chunk = (view.unit0 + u) % view.n_chunks;
+  __syncthreads();
+  for (int fi = 0; fi < FPW; ++fi) {
+    const int64_t t = ((int64_t)blockIdx.x * FPW + fi) * WAVES + wave;
+    const bool valid = t < g.T;
+    // gather window * frame as complex pairs (x[2j], x[2j+1])
+    const int64_t s0 = t * g.H - g.padL;
+    for (int j = lane; j < N; j += 64) {
+      cx<TC> z = {(TC)0, (TC)0};
+      if (valid) {
+        z.x = (TC)view_sample(view, row, chunk, s0 + 2 * j) * wfull[2 * j];
+        z.y = (TC)view_sample(view, row, chunk, s0 + 2 * j + 1) * wfull[2 * j + 1];
+      }
+      buf[j] = z;
+    }
+    SG_PASS_SYNC();
+    wave_fft<TC, N, false>(buf, tw, lane);
+    if (valid) {
+      const int64_t rowoff = (u * g.T + t) * g.FS;
+      for (int k = lane; k <= N; k += 64) {
+        cx<TC> a = buf[k == N ? 0 : k];
+        cx<TC> b = buf[(k == 0 || k == N) ? 0 : N - k];
+        cx<TC> w = tw[k == N ? 0 : k];
+        cx<TC> X = rfft_bin(a, b, w, k, N);
+        if (P_out) P_out[rowoff + k] = (double)X.x * (double)X.x + (double)X.y * (double)X.y;
+        if (mag_out) mag_out[rowoff + k] = sqrtf((float)(X.x * X.x + X.y * X.y));
+        if (z_out) {
+          int64_t zo = ((u * g.T + t) * g.F + k) * 2;
+          z_out[zo] = (double)X.x * z_scale;
+          z_out[zo + 1] = (double)X.y * z_scale;
+        }
+      }
+    }
+    SG_PASS_SYNC();
+  }
+}
+
+// ---------------------------------------------------------------------------------------
+// Apply + inverse: frame -> FFT (fp32) -> X * M[t][k] -> inverse FFT -> * window / N
+// -> windowed segment seg[u][t][0..n) ready for overlap-add.  `adjoint` swaps nothing here:
+// the backward pass of TorchGate uses the same kernel on grad_out frames (the operator
+// frame -> window -> rfft -> mask -> irfft -> window is symmetric up to the Hermitian weights,
+// handled by the caller through the window/normalisation tables).
+// ---------------------------------------------------------------------------------------
+template <int N, int WAVES, int FPW>
+__global__ __launch_bounds__(WAVES * 64) void k_apply_istft(View view, Geom g, const cx<float>* __restrict__ tw_g,
+                                                            const float* __restrict__ win_a,  // analysis window (n)
+                                                            const float* __restrict__ win_s,  // synthesis window (n), incl. 1/N
+                                                            const float* __restrict__ M, float* __restrict__ seg) {
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  cx<float>* tw = reinterpret_cast<cx<float>*>(smem);
+  cx<float>* bufs = tw + N;
+  const int lane = threadIdx.x & 63;
+  const int wave = threadIdx.x >> 6;
+  cx<float>* buf = bufs + wave * N;
+  for (int i = threadIdx.x; i < N; i += WAVES * 64) tw[i] = tw_g[i];
+  const int64_t u = blockIdx.y;
+  const int64_t row = (view.unit0 + u) / view.n_chunks;
+  const int64_t chunk = (view.unit0 + u) % view.n_chunks;
+  __syncthreads();
+  for (int fi = 0; fi < FPW; ++fi) {
+    const int64_t t = ((int64_t)blockIdx.x * FPW + fi) * WAVES + wave;
+    const bool valid = t < g.T;
+    const int64_t s0 = t * g.H - g.padL;
+    for (int j = lane; j < N; j += 64) {
+      cx<float> z = {0.f, 0.f};
+      if (valid) {
+        z.x = (float)view_sample(view, row, chunk, s0 + 2 * j) * win_a[2 * j];
+        z.y = (float)view_sample(view, row, chunk, s0 + 2 * j + 1) * win_a[2 * j + 1];
+      }
+      buf[j] = z;
+    }
+    SG_PASS_SYNC();
+    wave_fft<float, N, false>(buf, tw, lane);
+    // split -> mask -> merge, pairwise in place: task k handles bins k and N-k.
+    if (valid) {
+      const float* Mrow = M + (u * g.T + t) * g.FS;
+      for (int k = lane; k <= N / 2; k += 64) {
+        if (k == 0) {
+          cx<float> a = buf[0];
+          float y0 = (a.x + a.y) * Mrow[0];
+          float yN = (a.x - a.y) * Mrow[N];
+          buf[0] = {0.5f * (y0 + yN), 0.5f * (y0 - yN)};
+        } else {
+          cx<float> a = buf[k], b = buf[N - k];
+          cx<float> w = tw[k];
+          // X[k] = E + w O ; X[N-k] = conj(E) - conj(w) conj(O)
+          cx<float> E = {(a.x + b.x) * 0.5f, (a.y - b.y) * 0.5f};
+          cx<float> O = {(a.y + b.y) * 0.5f, (b.x - a.x) * 0.5f};
+          cx<float> wO = cmul(w, O);
+          float mk = Mrow[k], mn = Mrow[N - k];
+          cx<float> Yk = {(E.x + wO.x) * mk, (E.y + wO.y) * mk};
+          cx<float> Yn = {(E.x - wO.x) * mn, (-E.y + wO.y) * mn};  // X[N-k] * mn
+          // merge: E' = (Yk + conj Yn)/2 ; O' = (Yk - conj Yn)/2 * conj(w) ; Zc'[k] = E' + i O'
+          cx<float> Ep = {(Yk.x + Yn.x) * 0.5f, (Yk.y - Yn.y) * 0.5f};
+          cx<float> D = {(Yk.x - Yn.x) * 0.5f, (Yk.y + Yn.y) * 0.5f};
+          cx<float> wc = {w.x, -w.y};
+          cx<float> Op = cmul(D, wc);
+          buf[k] = {Ep.x - Op.y, Ep.y + Op.x};
+          if (k != N - k) {
+            // Zc'[N-k] = conj(E') + i conj(O')  (E', O' are spectra of real sequences)
+            buf[N - k] = {Ep.x + Op.y, -Ep.y + Op.x};
+          }
+        }
+      }
+    }
+    SG_PASS_SYNC();
+    wave_fft<float, N, true>(buf, tw, lane);
+    if (valid) {
+      float2* srow = reinterpret_cast<float2*>(seg + (u * g.T + t) * (int64_t)g.n);
+      for (int j = lane; j < N; j += 64) {
+        cx<float> z = buf[j];
+        srow[j] = make_float2(z.x * win_s[2 * j], z.y * win_s[2 * j + 1]);
+      }
+    }
+    SG_PASS_SYNC();
+  }
+}
+
+// ---------------------------------------------------------------------------------------
+// Overlap-add gather (scipy/_spectral_py.py:1708-1725; torch.istft): one thread per kept
+// output sample.  out[p] = sum_t seg[t][e - tH] / sum_t w^2[e - tH],  e = p + padL.
+// ---------------------------------------------------------------------------------------
+struct OutMap {
+  void* out;
+  int dtype;
+  int64_t stride;   // elements between rows
+  int64_t p0, p1;   // kept range of unit-local sample positions [p0, p1)
+  int64_t g_step;   // destination index of position p of chunk i: i*g_step + (p - p0) - g0
+  int64_t g0;       // destination offset subtracted (start_frame)
+  int64_t g_lo, g_hi;  // keep only destination indices (before -g0) in [g_lo, g_hi)
+};
+
+__global__ void k_ola(View view, Geom g, OutMap om, const float* __restrict__ seg,
+                      const float* __restrict__ wsq /* analysis*synthesis window product (n) */,
+                      int normalize) {
+  const int64_t u = blockIdx.y;
+  const int64_t row = (view.unit0 + u) / view.n_chunks;
+  const int64_t chunk = (view.unit0 + u) % view.n_chunks;
+  const int64_t p = om.p0 + (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (p >= om.p1) return;
+  const int64_t gi = chunk * om.g_step + (p - om.p0);
+  if (gi < om.g_lo || gi >= om.g_hi) return;
+  float val = 0.f;
+  if (p < g.Lout) {
+    const int64_t e = p + g.padL;
+    int64_t t_hi = e / g.H;
+    if (t_hi > g.T - 1) t_hi = g.T - 1;
+    int64_t t_lo = (e - g.n + g.H) / g.H;  // ceil((e - n + 1) / H)
+    if (e - g.n + 1 <= 0) t_lo = 0;
+    float acc = 0.f, norm = 0.f;
+    for (int64_t t = t_lo; t <= t_hi; ++t) {
+      int m = (int)(e - t * g.H);
+      acc += seg[(u * g.T + t) * (int64_t)g.n + m];
+      norm += wsq[m];
+    }
+    val = normalize ? acc / (norm > 1e-10f ? norm : 1.0f) : acc;
+  }
+  store_sample(om.out, om.dtype, row * om.stride + gi - om.g0, val);
+}
+
+// ---------------------------------------------------------------------------------------
+// Per-band statistics over time (lanes = bins).  block = 64 bins x TG time groups.
+// ---------------------------------------------------------------------------------------
+constexpr int STAT_TG = 4;
+
+// dB of one cell exactly as the reference writes it: 20*log10(|Z| + eps)
+// (spectralgate/utils.py:15; torchgate/utils.py:22), |Z| = sqrt(P) * mag_scale.
+__device__ __forceinline__ double cell_db(double P, double mag_scale) {
+  return 20.0 * log10(sqrt(P) * mag_scale + 2.220446049250313e-16);
+}
+
+__global__ __launch_bounds__(64 * STAT_TG) void k_colmax(const double* __restrict__ P, Geom g,
+                                                         double* __restrict__ pmax) {
+  __shared__ double red[STAT_TG][64];
+  const int f = blockIdx.x * 64 + (threadIdx.x & 63);
+  const int tg = threadIdx.x >> 6;
+  const int64_t u = blockIdx.y;
+  double m = 0.0;
+  if (f < g.F)
+    for (int64_t t = tg; t < g.T; t += STAT_TG) m = fmax(m, P[(u * g.T + t) * g.FS + f]);
+  red[tg][threadIdx.x & 63] = m;
+  __syncthreads();
+  if (tg == 0 && f < g.F) {
+    for (int i = 1; i < STAT_TG; ++i) m = fmax(m, red[i][threadIdx.x & 63]);
+    pmax[u * g.FS + f] = m;
+  }
+}
+
+// thresh[u][f] = mean_t(dBfl) + n_std * std_t(dBfl), dBfl = max(dB, rowmax_dB - top_db)
+// (stationary.py:75-81; torchgate.py:158-160).
+__global__ __launch_bounds__(64 * STAT_TG) void k_colstats(const double* __restrict__ P, Geom g,
+                                                           const double* __restrict__ pmax, double mag_scale,
+                                                           double top_db, double n_std, int ddof,
+                                                           double* __restrict__ thresh) {
+  __shared__ double r1[STAT_TG][64], r2[STAT_TG][64];
+  const int l = threadIdx.x & 63;
+  const int f = blockIdx.x * 64 + l;
+  const int tg = threadIdx.x >> 6;
+  const int64_t u = blockIdx.y;
+  double s1 = 0.0, s2 = 0.0, mdb = 0.0;
+  if (f < g.F) {
+    mdb = cell_db(pmax[u * g.FS + f], mag_scale);
+    for (int64_t t = tg; t < g.T; t += STAT_TG) {
+      double d = cell_db(P[(u * g.T + t) * g.FS + f], mag_scale) - mdb;  // <= 0
+      d = fmax(d, -top_db);
+      s1 += d;
+      s2 += d * d;
+    }
+  }
+  r1[tg][l] = s1;
+  r2[tg][l] = s2;
+  __syncthreads();
+  if (tg == 0 && f < g.F) {
+    for (int i = 1; i < STAT_TG; ++i) {
+      s1 += r1[i][l];
+      s2 += r2[i][l];
+    }
+    double Tn = (double)g.T;
+    double mean_d = s1 / Tn;
+    double var = (s2 - s1 * s1 / Tn) / (Tn - (double)ddof);
+    if (var < 0.0) var = 0.0;
+    thresh[u * g.FS + f] = (mdb + mean_d) + sqrt(var) * n_std;
+  }
+}
+
+// raw[u][t][f] = (max(dB, rowmax_dB - top_db) > thresh[f])   (stationary.py:96-106;
+// torchgate.py:161-164 with amp_to_db's floor, torchgate/utils.py:23).
+__global__ void k_decide(const double* __restrict__ P, Geom g, const double* __restrict__ pmax,
+                         const double* __restrict__ thresh, int64_t thresh_ustride, double mag_scale,
+                         double top_db, float* __restrict__ raw, int64_t n_units) {
+  const int64_t cells = n_units * g.T * g.FS;
+  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < cells;
+       i += (int64_t)gridDim.x * blockDim.x) {
+    const int f = (int)(i % g.FS);
+    if (f >= g.F) continue;
+    const int64_t u = i / (g.T * g.FS);
+    double db = cell_db(P[i], mag_scale);
+    double fl = cell_db(pmax[u * g.FS + f], mag_scale) - top_db;
+    db = fmax(db, fl);
+    raw[i] = db > thresh[u * thresh_ustride + f] ? 1.0f : 0.0f;
+  }
+}
+
+// ---------------------------------------------------------------------------------------
+// Non-stationary raw masks.
+// ---------------------------------------------------------------------------------------
+// S: forward-backward one-pole smoother == scipy filtfilt([b],[1,b-1],padtype=None)
+// (nonstationary.py:106-115), then sigmoid((A-S)/S - thresh) * slope) (nonstationary.py:70-76).
+// One thread per (unit, bin); lanes = bins (coalesced row walk).  raw is used as scratch for
+// the forward pass.
+__global__ void k_iir_sigmoid(const float* __restrict__ A, Geom g, double b, double nthresh, double slope,
+                              float* __restrict__ raw) {
+  const int f = blockIdx.x * blockDim.x + threadIdx.x;
+  const int64_t u = blockIdx.y;
+  if (f >= g.F) return;
+  const float* a = A + u * g.T * g.FS + f;
+  float* r = raw + u * g.T * g.FS + f;
+  const double c = 1.0 - b;
+  double s = (double)a[0];
+  for (int64_t t = 0; t < g.T; ++t) {
+    s = b * (double)a[t * g.FS] + c * s;
+    r[t * g.FS] = (float)s;
+  }
+  // backward pass on the forward output, seeded with its last value
+  double fprev = s;
+  for (int64_t t = g.T - 1; t >= 0; --t) {
+    double fw = (double)r[t * g.FS];
+    if (t == g.T - 1) fw = fprev;  // exact (unrounded) last forward value
+    s = b * fw + c * s;
+    double av = (double)a[t * g.FS];
+    double ratio = (av - s) / s;
+    r[t * g.FS] = (float)(1.0 / (1.0 + exp(-(ratio - nthresh) * slope)));
+  }
+}
+
+// T: boxcar moving mean conv1d(ones(k), padding="same")/k, left pad (k-1)//2
+// (torchgate.py:179-190), then sigmoid((ratio - x0)/temp) (torchgate.py:193-196).
+__global__ void k_boxcar_sigmoid(const float* __restrict__ A, Geom g, int kbox, double nthresh, double slope,
+                                 float* __restrict__ raw) {
+  const int f = blockIdx.x * blockDim.x + threadIdx.x;
+  const int64_t u = blockIdx.y;
+  if (f >= g.F) return;
+  const float* a = A + u * g.T * g.FS + f;
+  float* r = raw + u * g.T * g.FS + f;
+  const int left = (kbox - 1) / 2;
+  // sliding window sum over [t-left, t-left+kbox)
+  double sum = 0.0;
+  for (int64_t j = 0; j < kbox - left && j < g.T; ++j) sum += (double)a[j * g.FS];
+  for (int64_t t = 0; t < g.T; ++t) {
+    double S = sum / (double)kbox;
+    double av = (double)a[t * g.FS];
+    double ratio = (av - S) / S;
+    r[t * g.FS] = (float)(1.0 / (1.0 + exp(-(ratio - nthresh) * slope)));
+    // slide: drop t-left, add t-left+kbox
+    int64_t drop = t - left, add = t - left + kbox;
+    if (drop >= 0) sum -= (double)a[drop * g.FS];
+    if (add < g.T) sum += (double)a[add * g.FS];
+  }
+}
+
+// ---------------------------------------------------------------------------------------
+// Mask smoothing: separable triangular FIR, zero padded ("same"), two passes.
+// final = p * conv(raw) + (1-p) * edge   where edge = conv(1) (zero-padded) when the reference
+// applies prop_decrease BEFORE smoothing (stationary.py:108-114; torchgate.py:241-249) and
+// 1 when it applies it AFTER (nonstationary.py:78-84).
+// ---------------------------------------------------------------------------------------
+__global__ void k_smooth_f(const float* __restrict__ raw, Geom g, const float* __restrict__ kf, int nf,
+                           float* __restrict__ tmp, int64_t n_units) {
+  const int64_t cells = n_units * g.T * g.FS;
+  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < cells;
+       i += (int64_t)gridDim.x * blockDim.x) {
+    const int f = (int)(i % g.FS);
+    if (f >= g.F) continue;
+    float acc = 0.f;
+    for (int a = -nf; a <= nf; ++a) {
+      int ff = f + a;
+      if (ff >= 0 && ff < g.F) acc += kf[a + nf] * raw[i + a];
+    }
+    tmp[i] = acc;
+  }
+}
+
+__global__ void k_smooth_t(const float* __restrict__ tmp, Geom g, const float* __restrict__ kt, int nt,
+                           const float* __restrict__ kf, int nf, float p, int prop_before,
+                           float* __restrict__ M, int64_t n_units) {
+  const int64_t cells = n_units * g.T * g.FS;
+  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < cells;
+       i += (int64_t)gridDim.x * blockDim.x) {
+    const int f = (int)(i % g.FS);
+    if (f >= g.F) continue;
+    const int64_t t = (i / g.FS) % g.T;
+    float acc = 0.f, et = 0.f;
+    for (int b = -nt; b <= nt; ++b) {
+      int64_t tt = t + b;
+      if (tt >= 0 && tt < g.T) {
+        acc += kt[b + nt] * tmp[i + (int64_t)b * g.FS];
+        et += kt[b + nt];
+      }
+    }
+    float edge = 1.0f;
+    if (prop_before) {  // conv(1) with zero padding = (valid freq taps) * (valid time taps)
+      float ef = 0.f;
+      for (int a = -nf; a <= nf; ++a)
+        if (f + a >= 0 && f + a < g.F) ef += kf[a + nf];
+      edge = ef * et;
+    }
+    M[i] = p * acc + (1.0f - p) * edge;
+  }
+}
+
+// no smoothing: M = p*raw + (1-p)
+__global__ void k_prop_only(const float* __restrict__ raw, Geom g, float p, float* __restrict__ M,
+                            int64_t n_units) {
+  const int64_t cells = n_units * g.T * g.FS;
+  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < cells;
+       i += (int64_t)gridDim.x * blockDim.x)
+    M[i] = p * raw[i] + (1.0f - p);
+}
+
+// yn[s] = mean over channels (np.mean(axis=0), stationary.py:61): sequential fp64 sum / C.
+__global__ void k_channel_mean(const void* __restrict__ x, int dtype, int64_t C, int64_t n, int64_t stride,
+                               double* __restrict__ out) {
+  for (int64_t s = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; s < n;
+       s += (int64_t)gridDim.x * blockDim.x) {
+    double acc = 0.0;
+    for (int64_t c = 0; c < C; ++c) acc += load_sample(x, dtype, c * stride + s);
+    out[s] = acc / (double)C;
+  }
+}
+
+__global__ void k_copy_thresh(const double* __restrict__ src, double* __restrict__ dst, int F) {
+  int f = blockIdx.x * blockDim.x + threadIdx.x;
+  if (f < F) dst[f] = src[f];
+}
+
+}  // namespace sg

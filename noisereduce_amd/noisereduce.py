@@ -1,0 +1,53 @@
+"""``reduce_noise`` -- same signature as /root/reference/noisereduce/noisereduce.py:13-36.
+
+All work runs on the GPU named by ``device`` (default ``"cuda"``, i.e. the MI355X the
+process sees); there is no CPU path.  ``y`` may be array-like (result: numpy array of the
+input dtype and shape, like the reference) or a torch tensor (result: tensor on the GPU;
+use this to keep long recordings resident in HBM).
+"""
+from noisereduce_amd.spectralgate.nonstationary import SpectralGateNonStationary
+from noisereduce_amd.spectralgate.stationary import SpectralGateStationary
+
+
+def reduce_noise(y, sr, stationary=False, y_noise=None, prop_decrease=1.0, time_constant_s=2.0,
+                 freq_mask_smooth_hz=500, time_mask_smooth_ms=50, thresh_n_mult_nonstationary=2,
+                 sigmoid_slope_nonstationary=10, n_std_thresh_stationary=1.5, tmp_folder=None,
+                 chunk_size=600000, padding=30000, n_fft=1024, win_length=None, hop_length=None,
+                 clip_noise_stationary=True, use_tqdm=False, n_jobs=1, use_torch=False,
+                 device="cuda"):
+    """Reduce noise via spectral gating (see the reference docstring,
+    noisereduce.py:37-109, for the meaning of every argument).
+
+    ``use_torch=False`` evaluates the numpy/scipy "spectralgate" algorithm,
+    ``use_torch=True`` the "torchgate" algorithm (the two differ)."""
+    if use_torch:
+        if n_jobs != 1:
+            raise ValueError("n_jobs must be 1 when using torch version of spectral gating.")
+        from noisereduce_amd.spectralgate.streamed_torch_gate import StreamedTorchGate
+        sg = StreamedTorchGate(
+            y=y, sr=sr, stationary=stationary, y_noise=y_noise, prop_decrease=prop_decrease,
+            time_constant_s=time_constant_s, freq_mask_smooth_hz=freq_mask_smooth_hz,
+            time_mask_smooth_ms=time_mask_smooth_ms,
+            thresh_n_mult_nonstationary=thresh_n_mult_nonstationary,
+            sigmoid_slope_nonstationary=sigmoid_slope_nonstationary, tmp_folder=tmp_folder,
+            chunk_size=chunk_size, padding=padding, n_fft=n_fft, win_length=win_length,
+            hop_length=hop_length, clip_noise_stationary=clip_noise_stationary,
+            use_tqdm=use_tqdm, n_jobs=n_jobs, device=device)
+    elif stationary:
+        sg = SpectralGateStationary(
+            y=y, sr=sr, y_noise=y_noise, prop_decrease=prop_decrease,
+            n_std_thresh_stationary=n_std_thresh_stationary, chunk_size=chunk_size,
+            clip_noise_stationary=clip_noise_stationary, padding=padding, n_fft=n_fft,
+            win_length=win_length, hop_length=hop_length, time_constant_s=time_constant_s,
+            freq_mask_smooth_hz=freq_mask_smooth_hz, time_mask_smooth_ms=time_mask_smooth_ms,
+            tmp_folder=tmp_folder, use_tqdm=use_tqdm, n_jobs=n_jobs, device=device)
+    else:
+        sg = SpectralGateNonStationary(
+            y=y, sr=sr, chunk_size=chunk_size, padding=padding, prop_decrease=prop_decrease,
+            n_fft=n_fft, win_length=win_length, hop_length=hop_length,
+            time_constant_s=time_constant_s, freq_mask_smooth_hz=freq_mask_smooth_hz,
+            time_mask_smooth_ms=time_mask_smooth_ms,
+            thresh_n_mult_nonstationary=thresh_n_mult_nonstationary,
+            sigmoid_slope_nonstationary=sigmoid_slope_nonstationary, tmp_folder=tmp_folder,
+            use_tqdm=use_tqdm, n_jobs=n_jobs, device=device)
+    return sg.get_traces()

@@ -1,0 +1,186 @@
+"""Host-side mirror of the reference chunk streamer
+(/root/reference/noisereduce/spectralgate/base.py).
+
+Same constructor arguments, attributes and method names as the reference's
+``SpectralGate``; the difference is where the work happens: the recording is uploaded
+once and the whole chunk grid of ``get_traces`` (base.py:167-226) -- every
+(channel, chunk) unit -- is evaluated on the GPU by ``sg_process_chunks``; there is no
+joblib pool and no memmap tempfile (``n_jobs``, ``tmp_folder`` and ``use_tqdm`` are
+accepted and ignored).  ``_do_filter`` stays the operator seam (base.py:158-160).
+"""
+import numpy as np
+import torch
+
+from noisereduce_amd import _ffi
+
+
+def _triangle(m):
+    # base.py:17-27 one axis: [1..m, m+1, m..1] / (m+1)
+    up = np.arange(1, m + 2, dtype=np.float64)
+    return np.concatenate([up, up[-2::-1]]) / (m + 1)
+
+
+def _smoothing_filter(n_grad_freq, n_grad_time):
+    """Mask smoothing filter (base.py:7-29): outer product of two triangles, unit sum."""
+    f = np.outer(_triangle(n_grad_freq), _triangle(n_grad_time))
+    return f / np.sum(f)
+
+
+_DEVICE_DTYPES = {
+    np.dtype(np.float32): torch.float32, np.dtype(np.float64): torch.float64,
+    np.dtype(np.int16): torch.int16, np.dtype(np.int32): torch.int32,
+}
+
+
+class SpectralGate:
+    def __init__(self, y, sr, prop_decrease, chunk_size, padding, n_fft, win_length,
+                 hop_length, time_constant_s, freq_mask_smooth_hz, time_mask_smooth_ms,
+                 tmp_folder, use_tqdm, n_jobs, device="cuda"):
+        self.sr = sr
+        self.flat = False
+        self._tensor_io = isinstance(y, torch.Tensor)
+        if not self._tensor_io:
+            y = np.array(y)
+        # reshape data to (#channels, #frames)  (base.py:54-62)
+        if len(y.shape) == 1:
+            self.y = y[None, :]
+            self.flat = True
+        elif len(y.shape) > 2:
+            raise ValueError("Waveform must be in shape (# frames, # channels)")
+        else:
+            self.y = y
+        self._dtype = y.dtype
+        self.n_channels, self.n_frames = self.y.shape
+        self._chunk_size = chunk_size
+        self.padding = padding
+        self.n_jobs = n_jobs
+        self.use_tqdm = use_tqdm
+        self._tmp_folder = tmp_folder
+
+        # STFT parameters (base.py:77-86)
+        self._n_fft = n_fft
+        self._win_length = self._n_fft if win_length is None else win_length
+        self._hop_length = self._win_length // 4 if hop_length is None else hop_length
+        self._time_constant_s = time_constant_s
+        self._prop_decrease = prop_decrease
+
+        self._n_grad_freq = 1
+        self._n_grad_time = 1
+        if (freq_mask_smooth_hz is None) & (time_mask_smooth_ms is None):
+            self.smooth_mask = False
+        else:
+            self._generate_mask_smoothing_filter(freq_mask_smooth_hz, time_mask_smooth_ms)
+
+        self.device = _ffi.resolve_device(device)
+        self._y_dev = None
+        self._gate = None
+
+    # -- filter design (base.py:99-128) ---------------------------------------------------
+    def _generate_mask_smoothing_filter(self, freq_mask_smooth_hz, time_mask_smooth_ms):
+        if freq_mask_smooth_hz is None:
+            n_grad_freq = 1
+        else:
+            n_grad_freq = int(freq_mask_smooth_hz / (self.sr / (self._n_fft / 2)))
+            if n_grad_freq < 1:
+                raise ValueError("freq_mask_smooth_hz needs to be at least {}Hz".format(
+                    int((self.sr / (self._n_fft / 2)))))
+        if time_mask_smooth_ms is None:
+            n_grad_time = 1
+        else:
+            n_grad_time = int(time_mask_smooth_ms / ((self._hop_length / self.sr) * 1000))
+            if n_grad_time < 1:
+                raise ValueError("time_mask_smooth_ms needs to be at least {}ms".format(
+                    int((self._hop_length / self.sr) * 1000)))
+        if (n_grad_time == 1) & (n_grad_freq == 1):
+            self.smooth_mask = False
+        else:
+            self.smooth_mask = True
+            self._n_grad_freq, self._n_grad_time = n_grad_freq, n_grad_time
+            self._smoothing_filter = _smoothing_filter(n_grad_freq, n_grad_time)
+
+    # -- device plumbing ---------------------------------------------------------------------
+    def _gate_kwargs(self):
+        return dict(variant=_ffi.SG_VARIANT_S, n_fft=self._n_fft, win_length=self._win_length,
+                    hop_length=self._hop_length, n_grad_freq=self._n_grad_freq,
+                    n_grad_time=self._n_grad_time, smooth_mask=self.smooth_mask,
+                    chunk_size=self._chunk_size, padding=self.padding,
+                    prop_decrease=self._prop_decrease)
+
+    def _to_device(self, a):
+        """Upload a host array (or pass a tensor) as one of the dtypes the kernels read
+        natively; anything else goes through float64 like the reference's chunk copy
+        (base.py:140)."""
+        if isinstance(a, torch.Tensor):
+            t = a.to(self.device)
+            if t.dtype not in _ffi._TORCH_DTYPES:
+                t = t.to(torch.float64)
+            return t
+        a = np.asarray(a)
+        if a.dtype not in _DEVICE_DTYPES:
+            a = a.astype(np.float64)
+        return torch.from_numpy(np.ascontiguousarray(a)).to(self.device)
+
+    def _device_y(self):
+        if self._y_dev is None:
+            self._y_dev = self._to_device(self.y)
+        return self._y_dev
+
+    def _finish(self, out_dev):
+        """Device result -> what the reference returns: input dtype, 1-D if the input was
+        (base.py:217-226)."""
+        if self._tensor_io:
+            out = out_dev if out_dev.dtype == self._dtype else out_dev.to(self._dtype)
+            return out.flatten() if self.flat else out
+        out = out_dev.cpu().numpy().astype(self._dtype, copy=False)
+        return out.flatten() if self.flat else out
+
+    # -- the reference's host-side chunk helpers (kept for API compatibility) -----------------
+    def _host_y(self):
+        return self.y.cpu().numpy() if self._tensor_io else self.y
+
+    def _read_chunk(self, i1, i2):
+        """read chunk and pad with zeros (base.py:130-142)"""
+        i1b = max(i1, 0)
+        i2b = min(i2, self.n_frames)
+        chunk = np.zeros((self.n_channels, i2 - i1))
+        chunk[:, i1b - i1: i2b - i1] = self._host_y()[:, i1b:i2b]
+        return chunk
+
+    def filter_chunk(self, start_frame, end_frame):
+        """Pad and perform filtering (base.py:144-150)"""
+        i1 = start_frame - self.padding
+        i2 = end_frame + self.padding
+        padded_chunk = self._read_chunk(i1, i2)
+        filtered_padded_chunk = self._do_filter(padded_chunk)
+        return filtered_padded_chunk[:, start_frame - i1: end_frame - i1]
+
+    def _get_filtered_chunk(self, ind):
+        """Grabs a single chunk (base.py:152-156)"""
+        start0 = ind * self._chunk_size
+        end0 = (ind + 1) * self._chunk_size
+        return self.filter_chunk(start_frame=start0, end_frame=end0)
+
+    def _do_filter(self, chunk):
+        """The operator seam (base.py:158-160): float64 (C, Lp) padded chunk in, filtered
+        chunk of the same shape out -- computed by sg_filter_padded on the GPU."""
+        if self._gate is None:
+            raise NotImplementedError
+        is_np = isinstance(chunk, np.ndarray)
+        dev = self._to_device(chunk)
+        out = self._gate.filter_padded(dev, out_dtype=dev.dtype if dev.dtype.is_floating_point
+                                       else torch.float64)
+        return out.cpu().numpy() if is_np else out
+
+    def get_traces(self, start_frame=None, end_frame=None):
+        """Grab filtered data iterating over chunks (base.py:167-226) -- on the device."""
+        if self._gate is None:
+            raise NotImplementedError
+        if start_frame is None:
+            start_frame = 0
+        if end_frame is None:
+            end_frame = self.n_frames
+        ydev = self._device_y()
+        chunked = self._chunk_size is not None and end_frame - start_frame > self._chunk_size
+        out = self._gate.process_chunks(ydev, out_dtype=ydev.dtype, start_frame=start_frame,
+                                        end_frame=end_frame, chunked=chunked)
+        return self._finish(out)

@@ -1,0 +1,54 @@
+"""Stationary spectral gate, mirror of
+/root/reference/noisereduce/spectralgate/stationary.py."""
+import numpy as np
+import torch
+
+from noisereduce_amd import _ffi
+from noisereduce_amd.spectralgate.base import SpectralGate
+
+
+class SpectralGateStationary(SpectralGate):
+    def __init__(self, y, sr, y_noise, n_std_thresh_stationary, chunk_size,
+                 clip_noise_stationary, padding, n_fft, win_length, hop_length, time_constant_s,
+                 freq_mask_smooth_hz, time_mask_smooth_ms, tmp_folder, prop_decrease, use_tqdm,
+                 n_jobs, device="cuda"):
+        super().__init__(y=y, sr=sr, chunk_size=chunk_size, padding=padding, n_fft=n_fft,
+                         win_length=win_length, hop_length=hop_length,
+                         time_constant_s=time_constant_s,
+                         freq_mask_smooth_hz=freq_mask_smooth_hz,
+                         time_mask_smooth_ms=time_mask_smooth_ms, tmp_folder=tmp_folder,
+                         prop_decrease=prop_decrease, use_tqdm=use_tqdm, n_jobs=n_jobs,
+                         device=device)
+        self.n_std_thresh_stationary = n_std_thresh_stationary
+
+        # noise clip, (channels, frames)  (stationary.py:47-58)
+        if y_noise is None:
+            noise_dev = self._device_y()
+        else:
+            if not isinstance(y_noise, torch.Tensor):
+                y_noise = np.array(y_noise)
+            if len(y_noise.shape) == 1:
+                y_noise = y_noise[None, :]
+            elif len(y_noise.shape) > 2:
+                raise ValueError("Waveform must be in shape (# frames, # channels)")
+            noise_dev = self._to_device(y_noise)
+        if clip_noise_stationary and chunk_size is not None:
+            noise_dev = noise_dev[:, :chunk_size]          # stationary.py:63-64
+
+        self._gate = _ffi.Gate(self.device, stationary=True, n_std_thresh=n_std_thresh_stationary,
+                               top_db=80.0, ddof=0, **self._gate_kwargs())
+        # channel mean -> STFT -> dB -> per-band mean/std -> threshold (stationary.py:61-81),
+        # all on the device; the result stays there.
+        self._gate.noise_stats(noise_dev)
+        self._noise_thresh = None
+
+    @property
+    def noise_thresh(self):
+        """Per-band threshold in dB (stationary.py:79-81), fetched from the device on demand."""
+        if self._noise_thresh is None:
+            self._noise_thresh = self._gate.get_noise_threshold()
+        return self._noise_thresh
+
+    def spectral_gating_stationary(self, chunk):
+        """(stationary.py:83-127)"""
+        return self._do_filter(chunk)

@@ -1,0 +1,89 @@
+"""``reduce_noise(use_torch=True)`` adapter, mirror of
+/root/reference/noisereduce/spectralgate/streamed_torch_gate.py: the reference's chunk
+streamer feeding each (C, chunk+2*padding) float64 window to ``TorchGate`` as a batch
+(streamed_torch_gate.py:81-87).  Here the recording stays in HBM: each padded chunk is a
+strided view of the uploaded signal (zero-extended once), so there is no per-chunk
+host<->device copy."""
+import numpy as np
+import torch
+
+from noisereduce_amd.spectralgate.base import SpectralGate
+from noisereduce_amd.torchgate import TorchGate as TG
+
+
+class StreamedTorchGate(SpectralGate):
+    def __init__(self, y, sr, stationary=False, y_noise=None, prop_decrease=1.0,
+                 time_constant_s=2.0, freq_mask_smooth_hz=500, time_mask_smooth_ms=50,
+                 thresh_n_mult_nonstationary=2, sigmoid_slope_nonstationary=10,
+                 n_std_thresh_stationary=1.5, tmp_folder=None, chunk_size=600000, padding=30000,
+                 n_fft=1024, win_length=None, hop_length=None, clip_noise_stationary=True,
+                 use_tqdm=False, n_jobs=1, device="cuda"):
+        super().__init__(y=y, sr=sr, chunk_size=chunk_size, padding=padding, n_fft=n_fft,
+                         win_length=win_length, hop_length=hop_length,
+                         time_constant_s=time_constant_s,
+                         freq_mask_smooth_hz=freq_mask_smooth_hz,
+                         time_mask_smooth_ms=time_mask_smooth_ms, tmp_folder=tmp_folder,
+                         prop_decrease=prop_decrease, use_tqdm=use_tqdm, n_jobs=n_jobs,
+                         device=device)
+        # noise clip (streamed_torch_gate.py:55-63): trimmed to len(y), kept 2-D
+        if y_noise is not None:
+            if not isinstance(y_noise, torch.Tensor):
+                y_noise = torch.from_numpy(np.asarray(y_noise))
+            if y_noise.shape[-1] > self.n_frames and clip_noise_stationary:
+                y_noise = y_noise[..., : self.n_frames]
+            y_noise = y_noise.to(self.device)
+            if y_noise.ndim == 1:
+                y_noise = y_noise.unsqueeze(0)
+            y_noise = y_noise.to(torch.float64)
+        self.y_noise = y_noise
+        # parameter mapping of streamed_torch_gate.py:66-79
+        self.tg = TG(sr=sr, nonstationary=not stationary,
+                     n_std_thresh_stationary=n_std_thresh_stationary,
+                     n_thresh_nonstationary=thresh_n_mult_nonstationary,
+                     temp_coeff_nonstationary=1 / sigmoid_slope_nonstationary,
+                     n_movemean_nonstationary=int(time_constant_s / self._hop_length * sr),
+                     prop_decrease=prop_decrease, n_fft=self._n_fft, win_length=self._win_length,
+                     hop_length=self._hop_length, freq_mask_smooth_hz=freq_mask_smooth_hz,
+                     time_mask_smooth_ms=time_mask_smooth_ms).to(self.device)
+
+    def _do_filter(self, chunk):
+        """float64 (C, Lp) chunk -> TorchGate batch (streamed_torch_gate.py:81-87).  The
+        result is hop*(Lp//hop) samples long, like the reference's."""
+        is_np = isinstance(chunk, np.ndarray)
+        if is_np:
+            chunk = torch.from_numpy(chunk)
+        chunk = chunk.to(self.device, torch.float64)
+        out = self.tg(x=chunk, xn=self.y_noise)
+        return out.cpu().detach().numpy() if is_np else out
+
+    def get_traces(self, start_frame=None, end_frame=None):
+        """The reference's chunk loop (base.py:167-226) with device-resident chunks."""
+        if start_frame is None:
+            start_frame = 0
+        if end_frame is None:
+            end_frame = self.n_frames
+        ydev = self._device_y().to(torch.float64)
+        pad, cs = self.padding, self._chunk_size
+
+        def filt(s, e):  # filter_chunk (base.py:144-150) on the device
+            i1, i2 = s - pad, e + pad
+            chunk = torch.zeros((self.n_channels, i2 - i1), dtype=torch.float64, device=self.device)
+            i1b, i2b = max(i1, 0), min(i2, self.n_frames)
+            chunk[:, i1b - i1:i2b - i1] = ydev[:, i1b:i2b]
+            res = self._do_filter(chunk)
+            return res[:, s - i1:e - i1]
+
+        if cs is not None and end_frame - start_frame > cs:
+            out = torch.zeros((self.n_channels, end_frame - start_frame), dtype=torch.float64,
+                              device=self.device)
+            ich1, ich2 = int(start_frame / cs), int((end_frame - 1) / cs)
+            pos = 0
+            for ich in range(ich1, ich2 + 1):
+                s0 = start_frame - ich * cs if ich == ich1 else 0
+                e0 = end_frame - ich * cs if ich == ich2 else cs
+                full = filt(ich * cs, (ich + 1) * cs)
+                out[:, pos:pos + e0 - s0] = full[:, s0:e0]
+                pos += e0 - s0
+        else:
+            out = filt(0, end_frame)
+        return self._finish(out)

@@ -1,0 +1,166 @@
+"""GPU parity tests: the HIP path (through the C ABI) against the golden vectors from the
+live reference and against the CPU oracle.  Tolerance: max|y - y_ref| / max|y_ref| <= 1e-4
+(BASELINE.json north_star); the stationary masks must match bit-for-bit on these cases."""
+import os
+
+import numpy as np
+import pytest
+import torch
+
+from oracle import spectralgate_oracle as O
+from tests.golden.cases import S_CASES, T_CASES, make_input_S, make_input_T
+
+pytestmark = pytest.mark.gpu
+
+TOL = 1e-4
+
+
+def _load(golden_dir, name):
+    return np.load(os.path.join(golden_dir, name + ".npz"))
+
+
+@pytest.fixture(scope="module")
+def nr():
+    import noisereduce_amd
+    return noisereduce_amd
+
+
+@pytest.mark.parametrize("name", sorted(S_CASES))
+def test_reduce_noise_golden(nr, golden_dir, name):
+    case = S_CASES[name]
+    g = _load(golden_dir, "S_" + name)
+    y, y_noise = make_input_S(case)
+    out = nr.reduce_noise(y=y, sr=case["sr"], y_noise=y_noise, **case["kwargs"])
+    assert out.shape == g["out"].shape and out.dtype == g["out"].dtype
+    assert O.rel_err(out, g["out"]) < TOL
+
+
+@pytest.mark.parametrize("name", sorted(S_CASES))
+def test_reduce_noise_float32_input(nr, golden_dir, name):
+    """float32 in -> float32 out (the BASELINE workload dtype); compared with the reference fed
+    float64 copies of the same values."""
+    case = S_CASES[name]
+    g = _load(golden_dir, "S_" + name)
+    y, y_noise = make_input_S(case)
+    out = nr.reduce_noise(y=y.astype(np.float32), sr=case["sr"],
+                          y_noise=None if y_noise is None else y_noise.astype(np.float32),
+                          **case["kwargs"])
+    assert out.dtype == np.float32 and out.shape == g["out"].shape
+    assert O.rel_err(out, g["out"]) < TOL
+
+
+def test_stage_taps(nr, golden_dir):
+    """STFT values, per-band threshold, raw mask bits and smoothed mask of the single-chunk
+    stationary case, each against the reference's own intermediate."""
+    from noisereduce_amd.spectralgate.stationary import SpectralGateStationary
+    case = S_CASES["stat_1chunk"]
+    g = _load(golden_dir, "S_stat_1chunk")
+    y, _ = make_input_S(case)
+    sg = SpectralGateStationary(
+        y=y, sr=48000, y_noise=None, prop_decrease=1.0, n_std_thresh_stationary=1.5,
+        chunk_size=600000, clip_noise_stationary=True, padding=30000, n_fft=1024, win_length=None,
+        hop_length=None, time_constant_s=2.0, freq_mask_smooth_hz=500, time_mask_smooth_ms=50,
+        tmp_folder=None, use_tqdm=False, n_jobs=1)
+    thr = sg.noise_thresh
+    assert np.max(np.abs(thr - g["thresh"])) < 1e-9
+    # STFT tap on the padded chunk
+    chunk = O.read_chunk(y[None, :], -30000, len(y) + 30000)
+    Z = sg._gate.stft(torch.from_numpy(chunk).cuda()).cpu().numpy()[0].T   # (F, T)
+    cols = [0, 1, 2, 117, 200, Z.shape[1] - 1]
+    assert np.max(np.abs(Z[:, cols] - g["Z_cols"])) < 1e-13
+    out = sg.get_traces()
+    assert O.rel_err(out, g["out"]) < TOL
+    raw = sg._gate.debug_field(0)[0].T > 0.5                                # (F, T)
+    assert raw.shape == tuple(g["raw_shape"])
+    ref_raw = np.unpackbits(g["raw_bits"], axis=1)[:, :raw.shape[1]].astype(bool)
+    assert np.count_nonzero(raw != ref_raw) == 0, "mask flips vs the reference"
+    M = sg._gate.debug_field(1)[0].T
+    assert np.max(np.abs(M[[0, 3, 100, 511, 512], :] - g["smooth_rows"])) < 1e-5
+
+
+def test_fish_wav_config0(nr, golden_dir):
+    """BASELINE.json configs[0] on the GPU: int16 in/out (<= 1 LSB from the reference, which
+    truncates a float64 result), float64 stationary and non-stationary."""
+    g = _load(golden_dir, "S_fish")
+    data, rate = g["data"], int(g["rate"])
+    out = nr.reduce_noise(y=data, sr=rate, stationary=True)
+    assert out.dtype == np.int16 and out.shape == data.shape
+    d = np.abs(out.astype(np.int32) - g["out_i16"].astype(np.int32))
+    assert d.max() <= 1 and np.mean(d > 0) < 0.02
+    out64 = nr.reduce_noise(y=data.astype(np.float64), sr=rate, stationary=True)
+    assert out64.dtype == np.float64
+    assert O.rel_err(out64, g["out_f64"]) < TOL
+    out_ns = nr.reduce_noise(y=data.astype(np.float64), sr=rate, stationary=False)
+    assert O.rel_err(out_ns, g["out_ns"]) < TOL
+
+
+def test_do_filter_seam(nr):
+    """SpectralGate._do_filter(chunk): float64 (C, Lp) in, same shape out, zero tail."""
+    from noisereduce_amd.spectralgate.nonstationary import SpectralGateNonStationary
+    y = np.stack([O.synth_signal(30000, seed=3).astype(np.float64),
+                  O.synth_signal(30000, seed=4, tone_hz=333.0).astype(np.float64)])
+    sg = SpectralGateNonStationary(
+        y=y, sr=48000, chunk_size=600000, padding=30000, n_fft=1024, win_length=None,
+        hop_length=None, time_constant_s=2.0, freq_mask_smooth_hz=500, time_mask_smooth_ms=50,
+        thresh_n_mult_nonstationary=2, sigmoid_slope_nonstationary=10, tmp_folder=None,
+        prop_decrease=1.0, use_tqdm=False, n_jobs=1)
+    chunk = sg._read_chunk(-1000, 30000 + 1234)
+    got = sg._do_filter(chunk)
+    want = O.gate_nonstationary_S(chunk, 1024, 1024, 256, 1.0, O.smoothing_filter(5, 9),
+                                  O.iir_coefficient(2.0, 48000, 256), 2, 10)
+    assert got.shape == chunk.shape and got.dtype == np.float64
+    assert O.rel_err(got, want) < TOL
+    Lout = (chunk.shape[1] // 256) * 256
+    assert np.all(got[:, Lout:] == 0)
+
+
+def test_get_traces_subrange(nr):
+    """get_traces(start_frame, end_frame) on a persistent object (base.py:167-172)."""
+    from noisereduce_amd.spectralgate.nonstationary import SpectralGateNonStationary
+    y = O.synth_signal(100000, seed=9).astype(np.float64)
+    kw = dict(sr=48000, chunk_size=20000, padding=3000, n_fft=1024, win_length=None, hop_length=None,
+              time_constant_s=2.0, freq_mask_smooth_hz=500, time_mask_smooth_ms=50,
+              thresh_n_mult_nonstationary=2, sigmoid_slope_nonstationary=10, tmp_folder=None,
+              prop_decrease=1.0, use_tqdm=False, n_jobs=1)
+    sg = SpectralGateNonStationary(y=y, **kw)
+    full = O.reduce_noise_S(y, 48000, stationary=False, chunk_size=20000, padding=3000)
+    got = sg.get_traces(start_frame=25000, end_frame=77000)
+    assert got.shape == (52000,)
+    assert O.rel_err(got, full[25000:77000]) < TOL
+
+
+def test_tensor_io_stays_on_device(nr):
+    y = torch.from_numpy(O.synth_signal(70000, seed=2)).cuda()
+    out = nr.reduce_noise(y=y, sr=48000, stationary=True, chunk_size=30000, padding=4000)
+    assert isinstance(out, torch.Tensor) and out.is_cuda and out.dtype == torch.float32
+    want = O.reduce_noise_S(y.cpu().numpy().astype(np.float64), 48000, stationary=True,
+                            chunk_size=30000, padding=4000)
+    assert O.rel_err(out.cpu().numpy(), want) < TOL
+
+
+@pytest.mark.parametrize("name", sorted(T_CASES))
+@pytest.mark.parametrize("dtype", [torch.float64, torch.float32])
+def test_torchgate_golden(golden_dir, name, dtype):
+    from noisereduce_amd.torchgate import TorchGate
+    case = T_CASES[name]
+    g = _load(golden_dir, "T_" + name)
+    x, xn = make_input_T(case)
+    tg = TorchGate(sr=case["sr"], **case["kwargs"]).cuda()
+    xt = torch.from_numpy(x).to(dtype).cuda()
+    xnt = None if xn is None else torch.from_numpy(xn).to(dtype).cuda()
+    out = tg(xt, xnt)
+    assert out.dtype == dtype and tuple(out.shape) == g["out"].shape
+    assert O.rel_err(out.cpu().numpy(), g["out"]) < TOL
+
+
+def test_torchgate_state_dict_and_errors():
+    from noisereduce_amd.torchgate import TorchGate
+    tg = TorchGate(sr=16000)
+    sd = tg.state_dict()
+    assert list(sd) == ["smoothing_filter"] and tuple(sd["smoothing_filter"].shape) == (1, 1, 33, 7)
+    assert abs(float(sd["smoothing_filter"].sum()) - 1) < 1e-6
+    assert sum(p.numel() for p in tg.parameters()) == 0
+    with pytest.raises(Exception):
+        tg(torch.zeros(2, 1000).cuda())
+    with pytest.raises(AssertionError):
+        tg(torch.zeros(4000).cuda())
