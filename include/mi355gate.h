@@ -108,11 +108,15 @@ int sg_set_noise_threshold(sg_handle* h, const double* thresh_host, int32_t n_bi
  * `padding` extra samples per side, padding discarded) is evaluated on the device, all
  * (channel, chunk) units in one set of launches.  Writes out[c][g - start_frame] for
  * g in [start_frame, end_frame); pass 0, N for everything.  `chunked` = 0 reproduces the
- * single-window branch (base.py:222), 1 the chunk grid (base.py:175-216). */
+ * single-window branch (base.py:222), 1 the chunk grid (base.py:175-216).
+ * `halo_left` / `halo_right`: number of valid samples stored BEFORE index 0 / AFTER index N-1
+ * of every row (0 for a plain recording).  A rank that holds one time shard of a longer
+ * recording passes its neighbours' seam samples this way so that chunk windows read real
+ * data instead of zeros across the shard boundary. */
 int sg_process_chunks(sg_handle* h, const void* in_dev, int in_dtype, void* out_dev,
                       int out_dtype, int64_t C, int64_t N, int64_t in_stride,
                       int64_t out_stride, int64_t start_frame, int64_t end_frame,
-                      int32_t chunked, void* stream);
+                      int32_t chunked, int64_t halo_left, int64_t halo_right, void* stream);
 
 /* Replaces SpectralGate._do_filter(chunk) (base.py:158-160; stationary.py:129-133;
  * nonstationary.py:99-103): (C, Lp) padded chunk in, (C, Lp) filtered chunk out, the
@@ -149,6 +153,26 @@ int sg_stft(sg_handle* h, const void* x_dev, int dtype, int64_t B, int64_t L, in
  *        2: power     double[units][T][FS] (stationary only).  FS = sg_debug_dims()[2]. */
 int sg_debug_dims(const sg_handle* h, int64_t dims[3]); /* units, T, FS */
 int sg_debug_fetch(sg_handle* h, int32_t what, void* host, int64_t bytes, void* stream);
+
+/* ---- per-kernel timing (bench.py's roofline leg) ------------------------------------- */
+#define SG_STAGE_CHANNEL_MEAN 0
+#define SG_STAGE_STFT_POWER 1
+#define SG_STAGE_COLMAX 2
+#define SG_STAGE_COLSTATS 3
+#define SG_STAGE_DECIDE 4
+#define SG_STAGE_STFT_MAG 5
+#define SG_STAGE_NONSTAT_MASK 6
+#define SG_STAGE_SMOOTH 7
+#define SG_STAGE_APPLY_ISTFT 8
+#define SG_STAGE_OLA 9
+#define SG_STAGE_NOISE_STATS 10 /* every launch of sg_noise_stats */
+#define SG_N_STAGES 11
+/* When enabled, every kernel launch is bracketed by a hipEvent pair recorded on the launch
+ * stream.  sg_profile_read synchronises those events and returns accumulated milliseconds
+ * and launch counts per stage (arrays of SG_N_STAGES); reset != 0 clears the accumulators. */
+int sg_profile_enable(sg_handle* h, int32_t on);
+int sg_profile_read(sg_handle* h, double* ms, int64_t* counts, int32_t n_stages, int32_t reset);
+const char* sg_stage_name(int32_t stage);
 
 #ifdef __cplusplus
 }

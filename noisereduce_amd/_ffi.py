@@ -19,6 +19,7 @@ LIB_PATH = os.path.join(_HERE, "libmi355gate.so")
 SG_F32, SG_F64, SG_I16, SG_I32 = 0, 1, 2, 3
 SG_VARIANT_S, SG_VARIANT_T = 0, 1
 SG_E_INVALID, SG_E_UNSUPPORTED, SG_E_HIP, SG_E_NOMEM, SG_E_STATE = -1, -2, -3, -4, -5
+SG_N_STAGES = 11
 
 _TORCH_DTYPES = {torch.float32: SG_F32, torch.float64: SG_F64, torch.int16: SG_I16,
                  torch.int32: SG_I32}
@@ -49,7 +50,8 @@ _PROTOTYPES = {
     "sg_get_noise_threshold": (c_int, [c_void_p, POINTER(c_double), c_int32, c_void_p]),
     "sg_set_noise_threshold": (c_int, [c_void_p, POINTER(c_double), c_int32, c_void_p]),
     "sg_process_chunks": (c_int, [c_void_p, c_void_p, c_int, c_void_p, c_int, c_int64, c_int64,
-                                  c_int64, c_int64, c_int64, c_int64, c_int32, c_void_p]),
+                                  c_int64, c_int64, c_int64, c_int64, c_int32, c_int64, c_int64,
+                                  c_void_p]),
     "sg_filter_padded": (c_int, [c_void_p, c_void_p, c_int, c_void_p, c_int, c_int64, c_int64,
                                  c_int64, c_int64, c_void_p]),
     "sg_process_batch": (c_int, [c_void_p, c_void_p, c_int, c_int64, c_int64, c_int64, c_void_p,
@@ -57,6 +59,9 @@ _PROTOTYPES = {
     "sg_process_batch_backward": (c_int, [c_void_p, c_void_p, c_int, c_int64, c_int64, c_int64,
                                           c_void_p, c_int64, c_void_p]),
     "sg_stft": (c_int, [c_void_p, c_void_p, c_int, c_int64, c_int64, c_int64, c_void_p, c_void_p]),
+    "sg_profile_enable": (c_int, [c_void_p, c_int32]),
+    "sg_profile_read": (c_int, [c_void_p, POINTER(c_double), POINTER(c_int64), c_int32, c_int32]),
+    "sg_stage_name": (c_char_p, [c_int32]),
     "sg_debug_dims": (c_int, [c_void_p, POINTER(c_int64)]),
     "sg_debug_fetch": (c_int, [c_void_p, c_int32, c_void_p, c_int64, c_void_p]),
 }
@@ -219,19 +224,23 @@ class Gate:
                 self._h, t.ctypes.data_as(POINTER(c_double)), int(t.shape[0]), self._stream()))
 
     def process_chunks(self, x, out_dtype=None, start_frame=0, end_frame=None, chunked=True,
-                       out=None):
+                       out=None, halo_left=0, halo_right=0):
+        """x: (C, N) tensor, or -- with halos -- a (C, halo_left + N + halo_right) tensor whose
+        columns [halo_left, halo_left + N) are this shard's samples."""
         self._on_device(x)
         x, stride = _rows(x)
-        C, N = x.shape
+        C = x.shape[0]
+        N = x.shape[1] - halo_left - halo_right
+        x_ptr = x.data_ptr() + halo_left * x.element_size()
         end_frame = N if end_frame is None else int(end_frame)
         n_out = end_frame if not chunked else end_frame - int(start_frame)
         if out is None:
             out = torch.empty((C, n_out), dtype=out_dtype or x.dtype, device=self.device)
         with torch.cuda.device(self.device):
             self._check(self.lib.sg_process_chunks(
-                self._h, x.data_ptr(), _sg_dtype(x), out.data_ptr(), _sg_dtype(out), C, N, stride,
+                self._h, x_ptr, _sg_dtype(x), out.data_ptr(), _sg_dtype(out), C, N, stride,
                 out.stride(0) if C > 1 else n_out, int(start_frame), end_frame, int(bool(chunked)),
-                self._stream()))
+                int(halo_left), int(halo_right), self._stream()))
         return out
 
     def filter_padded(self, chunk, out_dtype=None):
@@ -266,6 +275,19 @@ class Gate:
                 _sg_dtype(out), Lout, self._stream()))
         return out
 
+    # -- per-kernel timing -----------------------------------------------------------
+    def profile_enable(self, on=True):
+        self._check(self.lib.sg_profile_enable(self._h, int(bool(on))))
+
+    def profile_read(self, reset=True):
+        """{stage name: (total ms, launches)} accumulated since the last reset (synchronises)."""
+        ms = (c_double * SG_N_STAGES)()
+        cnt = (c_int64 * SG_N_STAGES)()
+        with torch.cuda.device(self.device):
+            self._check(self.lib.sg_profile_read(self._h, ms, cnt, SG_N_STAGES, int(bool(reset))))
+        return {self.lib.sg_stage_name(i).decode(): (ms[i], cnt[i]) for i in range(SG_N_STAGES)
+                if cnt[i]}
+
     # -- stage taps ------------------------------------------------------------------
     def stft(self, x):
         """(B, L) -> complex128 (B, T, F), scaled like the variant's reference STFT."""
@@ -291,3 +313,37 @@ class Gate:
             self._check(self.lib.sg_debug_fetch(self._h, int(what), host.ctypes.data_as(c_void_p),
                                                 host.nbytes, self._stream()))
         return host[:, :, :self.n_bins]
+
+
+# Handles are cached per (device, parameters): a handle owns its twiddle/window tables and a
+# grown-on-demand workspace, so repeated reduce_noise()/TorchGate calls with the same settings
+# reuse them instead of paying hipMalloc/hipFree per call.  Not thread-safe (like the handle).
+_GATE_CACHE = {}
+
+
+def cached_gate(device, **kw):
+    dev = resolve_device(device)
+
+    def norm(v):
+        if isinstance(v, np.ndarray):
+            return ("nd", v.shape, v.tobytes())
+        if isinstance(v, (bool, np.bool_)):
+            return bool(v)
+        if isinstance(v, (int, np.integer)):
+            return int(v)
+        if isinstance(v, (float, np.floating)):
+            return float(v)
+        return v
+    key = (dev.index,) + tuple(sorted((k, norm(v)) for k, v in kw.items()))
+    g = _GATE_CACHE.get(key)
+    if g is None:
+        if len(_GATE_CACHE) >= 8:  # bound the number of live workspaces
+            _GATE_CACHE.pop(next(iter(_GATE_CACHE))).close()
+        g = Gate(dev, **kw)
+        _GATE_CACHE[key] = g
+    return g
+
+
+def clear_gate_cache():
+    while _GATE_CACHE:
+        _GATE_CACHE.popitem()[1].close()

@@ -48,8 +48,45 @@ struct sg_handle {
   DevBuf P, pmax, thr_rows, raw, M, seg, yn;
   int64_t dbg_units = 0, dbg_T = 0;
   bool dbg_has_P = false;
+  // per-kernel timing with HIP events on the launch stream (sg_profile_*)
+  bool prof_on = false;
+  int prof_override = -1;  // >= 0: book every launch under this stage (noise statistics)
+  struct ProfRec { int stage; hipEvent_t a, b; };
+  std::vector<ProfRec> prof_live;
+  std::vector<hipEvent_t> prof_pool;
+  double prof_ms[SG_N_STAGES] = {0};
+  int64_t prof_cnt[SG_N_STAGES] = {0};
   std::string err;
 };
+
+namespace {
+// RAII: records an event pair around one kernel launch when profiling is enabled.
+struct ProfScope {
+  sg_handle* h;
+  hipStream_t st;
+  int idx = -1;
+  static hipEvent_t get(sg_handle* h) {
+    if (!h->prof_pool.empty()) {
+      hipEvent_t e = h->prof_pool.back();
+      h->prof_pool.pop_back();
+      return e;
+    }
+    hipEvent_t e = nullptr;
+    (void)hipEventCreate(&e);
+    return e;
+  }
+  ProfScope(sg_handle* h_, int stage, hipStream_t st_) : h(h_), st(st_) {
+    if (!h->prof_on) return;
+    sg_handle::ProfRec r{h->prof_override >= 0 ? h->prof_override : stage, get(h), get(h)};
+    (void)hipEventRecord(r.a, st);
+    h->prof_live.push_back(r);
+    idx = (int)h->prof_live.size() - 1;
+  }
+  ~ProfScope() {
+    if (idx >= 0) (void)hipEventRecord(h->prof_live[idx].b, st);
+  }
+};
+}  // namespace
 
 #define HIPCHK(h, call)                                                                      \
   do {                                                                                       \
@@ -297,6 +334,8 @@ extern "C" int sg_create(const sg_params* p, const double* window_host, sg_handl
 extern "C" int sg_destroy(sg_handle* h) {
   if (!h) return SG_OK;
   (void)hipDeviceSynchronize();
+  for (auto& r : h->prof_live) { (void)hipEventDestroy(r.a); (void)hipEventDestroy(r.b); }
+  for (auto e : h->prof_pool) (void)hipEventDestroy(e);
   for (DevBuf* b : {&h->tw64, &h->tw32, &h->wfull64, &h->wa32, &h->ws32, &h->wsq32, &h->kf, &h->kt, &h->thresh,
                     &h->P, &h->pmax, &h->thr_rows, &h->raw, &h->M, &h->seg, &h->yn})
     free_buf(*b);
@@ -350,8 +389,12 @@ static int ensure_ws(sg_handle* h, const Geom& g, int64_t ub) {
 // ------------------------------------------------------------------------------------------
 // power field + column max of a batch of units
 static int stage_power(sg_handle* h, const View& v, const Geom& g, int64_t ub, hipStream_t st) {
-  HIPCHK(h, launch_stft<double>(h->N, v, g, ub, h->tw64.p, h->wfull64.p, (double*)h->P.p, nullptr, nullptr, 1.0,
-                                st));
+  {
+    ProfScope ps(h, SG_STAGE_STFT_POWER, st);
+    HIPCHK(h, launch_stft<double>(h->N, v, g, ub, h->tw64.p, h->wfull64.p, (double*)h->P.p, nullptr, nullptr,
+                                  1.0, st));
+  }
+  ProfScope ps(h, SG_STAGE_COLMAX, st);
   dim3 grid((g.F + 63) / 64, (unsigned)ub);
   hipLaunchKernelGGL(k_colmax, grid, dim3(64 * STAT_TG), 0, st, (const double*)h->P.p, g, (double*)h->pmax.p);
   HIPCHK(h, hipGetLastError());
@@ -359,6 +402,7 @@ static int stage_power(sg_handle* h, const View& v, const Geom& g, int64_t ub, h
 }
 
 static int stage_colstats(sg_handle* h, const Geom& g, int64_t ub, double* thresh_out, hipStream_t st) {
+  ProfScope ps(h, SG_STAGE_COLSTATS, st);
   dim3 grid((g.F + 63) / 64, (unsigned)ub);
   hipLaunchKernelGGL(k_colstats, grid, dim3(64 * STAT_TG), 0, st, (const double*)h->P.p, g,
                      (const double*)h->pmax.p, h->mag_scale, h->p.top_db, h->p.n_std_thresh, h->p.ddof,
@@ -369,6 +413,7 @@ static int stage_colstats(sg_handle* h, const Geom& g, int64_t ub, double* thres
 
 static int stage_decide(sg_handle* h, const Geom& g, int64_t ub, const double* thresh, int64_t ustride,
                         hipStream_t st) {
+  ProfScope ps(h, SG_STAGE_DECIDE, st);
   int64_t cells = ub * g.T * g.FS;
   hipLaunchKernelGGL(k_decide, dim3(grid_1d(cells, 256)), dim3(256), 0, st, (const double*)h->P.p, g,
                      (const double*)h->pmax.p, thresh, ustride, h->mag_scale, h->p.top_db, (float*)h->raw.p, ub);
@@ -378,7 +423,11 @@ static int stage_decide(sg_handle* h, const Geom& g, int64_t ub, const double* t
 
 static int stage_nonstat_raw(sg_handle* h, const View& v, const Geom& g, int64_t ub, hipStream_t st) {
   float* mag = (float*)h->P.p;
-  HIPCHK(h, launch_stft<float>(h->N, v, g, ub, h->tw32.p, h->wa32.p, nullptr, mag, nullptr, 1.0, st));
+  {
+    ProfScope ps(h, SG_STAGE_STFT_MAG, st);
+    HIPCHK(h, launch_stft<float>(h->N, v, g, ub, h->tw32.p, h->wa32.p, nullptr, mag, nullptr, 1.0, st));
+  }
+  ProfScope ps(h, SG_STAGE_NONSTAT_MASK, st);
   dim3 grid((g.F + 63) / 64, (unsigned)ub);
   if (h->p.variant == SG_VARIANT_S) {
     // |Z| scale (1/sum_w) cancels in (A-S)/S: work on the unscaled magnitude.
@@ -393,6 +442,7 @@ static int stage_nonstat_raw(sg_handle* h, const View& v, const Geom& g, int64_t
 }
 
 static int stage_smooth(sg_handle* h, const Geom& g, int64_t ub, hipStream_t st) {
+  ProfScope ps(h, SG_STAGE_SMOOTH, st);
   int64_t cells = ub * g.T * g.FS;
   float p = (float)h->p.prop_decrease;
   if (!h->p.smooth_mask) {
@@ -417,10 +467,14 @@ static int stage_smooth(sg_handle* h, const Geom& g, int64_t ub, hipStream_t st)
 
 static int stage_apply_ola(sg_handle* h, const View& v, const Geom& g, int64_t ub, const float* M,
                            const OutMap& om, int normalize, hipStream_t st) {
-  HIPCHK(h, launch_apply(h->N, v, g, ub, h->tw32.p, (const float*)h->wa32.p, (const float*)h->ws32.p, M,
-                         (float*)h->seg.p, st));
+  {
+    ProfScope ps(h, SG_STAGE_APPLY_ISTFT, st);
+    HIPCHK(h, launch_apply(h->N, v, g, ub, h->tw32.p, (const float*)h->wa32.p, (const float*)h->ws32.p, M,
+                           (float*)h->seg.p, st));
+  }
   int64_t np = om.p1 - om.p0;
   if (np > 0) {
+    ProfScope ps(h, SG_STAGE_OLA, st);
     dim3 grid((unsigned)((np + 255) / 256), (unsigned)ub);
     hipLaunchKernelGGL(k_ola, grid, dim3(256), 0, st, v, g, om, (const float*)h->seg.p, (const float*)h->wsq32.p,
                        normalize);
@@ -469,13 +523,21 @@ extern "C" int sg_noise_stats(sg_handle* h, const void* noise_dev, int dtype, in
   if (h->p.variant != SG_VARIANT_S) FAIL(h, SG_E_INVALID, "sg_noise_stats is a variant-S entry point");
   if (n < h->W) FAIL(h, SG_E_INVALID, "noise clip of %lld samples is shorter than win_length=%d", (long long)n, h->W);
   hipStream_t st = (hipStream_t)stream;
+  struct Tag {
+    sg_handle* h;
+    explicit Tag(sg_handle* h_) : h(h_) { h->prof_override = SG_STAGE_NOISE_STATS; }
+    ~Tag() { h->prof_override = -1; }
+  } tag(h);
   int rc = ensure(h, h->yn, (size_t)n * sizeof(double));
   if (rc) return rc;
-  hipLaunchKernelGGL(k_channel_mean, dim3(grid_1d(n, 256)), dim3(256), 0, st, noise_dev, dtype, C, n, row_stride,
-                     (double*)h->yn.p);
-  HIPCHK(h, hipGetLastError());
+  {
+    ProfScope ps(h, SG_STAGE_CHANNEL_MEAN, st);
+    hipLaunchKernelGGL(k_channel_mean, dim3(grid_1d(n, 256)), dim3(256), 0, st, noise_dev, dtype, C, n,
+                       row_stride, (double*)h->yn.p);
+    HIPCHK(h, hipGetLastError());
+  }
   View v{};
-  v.x = h->yn.p; v.dtype = SG_F64; v.stride = n; v.N = n; v.cs = 0; v.pad = 0; v.Lp = n; v.n_chunks = 1; v.unit0 = 0;
+  v.x = h->yn.p; v.dtype = SG_F64; v.stride = n; v.N = n; v.lo = 0; v.hi = n; v.cs = 0; v.pad = 0; v.Lp = n; v.n_chunks = 1; v.unit0 = 0;
   Geom g = make_geom(h, n);
   if ((rc = ensure_ws(h, g, 1))) return rc;
   if ((rc = stage_power(h, v, g, 1, st))) return rc;
@@ -506,7 +568,8 @@ extern "C" int sg_set_noise_threshold(sg_handle* h, const double* thresh_host, i
 
 extern "C" int sg_process_chunks(sg_handle* h, const void* in_dev, int in_dtype, void* out_dev, int out_dtype,
                                  int64_t C, int64_t N, int64_t in_stride, int64_t out_stride,
-                                 int64_t start_frame, int64_t end_frame, int32_t chunked, void* stream) {
+                                 int64_t start_frame, int64_t end_frame, int32_t chunked, int64_t halo_left,
+                                 int64_t halo_right, void* stream) {
   if (!h) return SG_E_INVALID;
   if (h->p.variant != SG_VARIANT_S) FAIL(h, SG_E_INVALID, "sg_process_chunks is a variant-S entry point");
   if (!in_dev || !out_dev || !dtype_ok(in_dtype) || !dtype_ok(out_dtype) || C < 1 || N < 1)
@@ -515,8 +578,10 @@ extern "C" int sg_process_chunks(sg_handle* h, const void* in_dev, int in_dtype,
     FAIL(h, SG_E_INVALID, "sg_process_chunks: bad frame range [%lld, %lld)", (long long)start_frame,
          (long long)end_frame);
   const int64_t cs = h->p.chunk_size, pad = h->p.padding;
+  if (halo_left < 0 || halo_right < 0) FAIL(h, SG_E_INVALID, "sg_process_chunks: negative halo");
   View v{};
   v.x = in_dev; v.dtype = in_dtype; v.stride = in_stride; v.N = N; v.pad = pad;
+  v.lo = -halo_left; v.hi = N + halo_right;
   OutMap om{};
   om.out = out_dev; om.dtype = out_dtype; om.stride = out_stride; om.g0 = start_frame;
   om.g_lo = start_frame; om.g_hi = end_frame;
@@ -546,7 +611,7 @@ extern "C" int sg_filter_padded(sg_handle* h, const void* chunk_dev, int in_dtyp
   if (!chunk_dev || !out_dev || !dtype_ok(in_dtype) || !dtype_ok(out_dtype) || C < 1 || Lp < 1)
     FAIL(h, SG_E_INVALID, "sg_filter_padded: bad argument");
   View v{};
-  v.x = chunk_dev; v.dtype = in_dtype; v.stride = in_stride; v.N = Lp; v.cs = 0; v.pad = 0; v.Lp = Lp; v.n_chunks = 1;
+  v.x = chunk_dev; v.dtype = in_dtype; v.stride = in_stride; v.N = Lp; v.lo = 0; v.hi = Lp; v.cs = 0; v.pad = 0; v.Lp = Lp; v.n_chunks = 1;
   OutMap om{};
   om.out = out_dev; om.dtype = out_dtype; om.stride = out_stride;
   om.p0 = 0; om.p1 = Lp; om.g_step = 0; om.g0 = 0; om.g_lo = 0; om.g_hi = Lp;
@@ -570,7 +635,7 @@ extern "C" int sg_process_batch(sg_handle* h, const void* x_dev, int dtype, int6
   }
   hipStream_t st = (hipStream_t)stream;
   View v{};
-  v.x = x_dev; v.dtype = dtype; v.stride = x_stride; v.N = L; v.cs = 0; v.pad = 0; v.Lp = L; v.n_chunks = 1;
+  v.x = x_dev; v.dtype = dtype; v.stride = x_stride; v.N = L; v.lo = 0; v.hi = L; v.cs = 0; v.pad = 0; v.Lp = L; v.n_chunks = 1;
   Geom g = make_geom(h, L);
   OutMap om{};
   om.out = out_dev; om.dtype = out_dtype; om.stride = out_stride;
@@ -578,7 +643,7 @@ extern "C" int sg_process_batch(sg_handle* h, const void* x_dev, int dtype, int6
   View vn{};
   Geom gn{};
   if (xn_dev && h->p.stationary) {
-    vn.x = xn_dev; vn.dtype = dtype; vn.stride = xn_stride; vn.N = Ln; vn.cs = 0; vn.pad = 0; vn.Lp = Ln; vn.n_chunks = 1;
+    vn.x = xn_dev; vn.dtype = dtype; vn.stride = xn_stride; vn.N = Ln; vn.lo = 0; vn.hi = Ln; vn.cs = 0; vn.pad = 0; vn.Lp = Ln; vn.n_chunks = 1;
     gn = make_geom(h, Ln);
   }
   // size the workspace for the larger of the two geometries
@@ -640,11 +705,46 @@ extern "C" int sg_stft(sg_handle* h, const void* x_dev, int dtype, int64_t B, in
   if (!h) return SG_E_INVALID;
   if (!x_dev || !z_dev || !dtype_ok(dtype) || B < 1 || L < h->W) FAIL(h, SG_E_INVALID, "sg_stft: bad argument");
   View v{};
-  v.x = x_dev; v.dtype = dtype; v.stride = stride; v.N = L; v.cs = 0; v.pad = 0; v.Lp = L; v.n_chunks = 1; v.unit0 = 0;
+  v.x = x_dev; v.dtype = dtype; v.stride = stride; v.N = L; v.lo = 0; v.hi = L; v.cs = 0; v.pad = 0; v.Lp = L; v.n_chunks = 1; v.unit0 = 0;
   Geom g = make_geom(h, L);
   HIPCHK(h, launch_stft<double>(h->N, v, g, B, h->tw64.p, h->wfull64.p, nullptr, nullptr, z_dev, h->mag_scale,
                                 (hipStream_t)stream));
   return SG_OK;
+}
+
+extern "C" int sg_profile_enable(sg_handle* h, int32_t on) {
+  if (!h) return SG_E_INVALID;
+  h->prof_on = on != 0;
+  return SG_OK;
+}
+
+extern "C" int sg_profile_read(sg_handle* h, double* ms, int64_t* counts, int32_t n_stages, int32_t reset) {
+  if (!h) return SG_E_INVALID;
+  if (n_stages != SG_N_STAGES) FAIL(h, SG_E_INVALID, "sg_profile_read: n_stages must be %d", SG_N_STAGES);
+  for (auto& r : h->prof_live) {
+    HIPCHK(h, hipEventSynchronize(r.b));
+    float t = 0.f;
+    HIPCHK(h, hipEventElapsedTime(&t, r.a, r.b));
+    h->prof_ms[r.stage] += (double)t;
+    h->prof_cnt[r.stage] += 1;
+    h->prof_pool.push_back(r.a);
+    h->prof_pool.push_back(r.b);
+  }
+  h->prof_live.clear();
+  for (int i = 0; i < SG_N_STAGES; ++i) {
+    if (ms) ms[i] = h->prof_ms[i];
+    if (counts) counts[i] = h->prof_cnt[i];
+    if (reset) { h->prof_ms[i] = 0; h->prof_cnt[i] = 0; }
+  }
+  return SG_OK;
+}
+
+extern "C" const char* sg_stage_name(int32_t stage) {
+  static const char* names[SG_N_STAGES] = {"k_channel_mean", "k_stft<double> (power)", "k_colmax", "k_colstats",
+                                           "k_decide", "k_stft<float> (magnitude)", "nonstat mask (iir/boxcar)",
+                                           "k_smooth_f+k_smooth_t", "k_apply_istft", "k_ola",
+                                           "noise statistics (all kernels)"};
+  return (stage >= 0 && stage < SG_N_STAGES) ? names[stage] : "?";
 }
 
 extern "C" int sg_debug_dims(const sg_handle* h, int64_t dims[3]) {

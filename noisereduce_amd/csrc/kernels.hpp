@@ -22,7 +22,8 @@ struct View {
   const void* x;
   int dtype;        // SG_F32 ...
   int64_t stride;   // elements between rows
-  int64_t N;        // valid samples per row
+  int64_t N;        // samples per row
+  int64_t lo, hi;   // readable index range [lo, hi) of a row (0, N unless the caller holds halos)
   int64_t cs;       // chunk step (0 when n_chunks == 1)
   int64_t pad;      // zero/neighbour padding before the chunk start
   int64_t Lp;       // samples per unit window
@@ -48,7 +49,7 @@ __device__ __forceinline__ double load_sample(const void* p, int dtype, int64_t 
 __device__ __forceinline__ double view_sample(const View& v, int64_t row, int64_t chunk, int64_t s) {
   if (s < 0 || s >= v.Lp) return 0.0;
   int64_t g = chunk * v.cs - v.pad + s;
-  if (g < 0 || g >= v.N) return 0.0;
+  if (g < v.lo || g >= v.hi) return 0.0;
   return load_sample(v.x, v.dtype, row * v.stride + g);
 }
 

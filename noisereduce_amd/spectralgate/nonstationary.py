@@ -27,7 +27,7 @@ class SpectralGateNonStationary(SpectralGate):
                          prop_decrease=prop_decrease, use_tqdm=use_tqdm, n_jobs=n_jobs,
                          device=device)
         b = iir_coefficient(self._time_constant_s, self.sr, self._hop_length)
-        self._gate = _ffi.Gate(self.device, stationary=False, iir_b=b,
+        self._gate = _ffi.cached_gate(self.device, stationary=False, iir_b=b,
                                nonstat_thresh=thresh_n_mult_nonstationary,
                                nonstat_slope=sigmoid_slope_nonstationary, **self._gate_kwargs())
 

@@ -35,7 +35,7 @@ class SpectralGateStationary(SpectralGate):
         if clip_noise_stationary and chunk_size is not None:
             noise_dev = noise_dev[:, :chunk_size]          # stationary.py:63-64
 
-        self._gate = _ffi.Gate(self.device, stationary=True, n_std_thresh=n_std_thresh_stationary,
+        self._gate = _ffi.cached_gate(self.device, stationary=True, n_std_thresh=n_std_thresh_stationary,
                                top_db=80.0, ddof=0, **self._gate_kwargs())
         # channel mean -> STFT -> dB -> per-band mean/std -> threshold (stationary.py:61-81),
         # all on the device; the result stays there.

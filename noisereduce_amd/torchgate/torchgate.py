@@ -93,7 +93,7 @@ class TorchGate(torch.nn.Module):
             # (torchgate.py:150,231,261); hand the engine the same table.
             window = torch.hann_window(self.win_length).double().numpy()
             nf, nt = self._n_grad
-            g = _ffi.Gate(device, variant=_ffi.SG_VARIANT_T, stationary=not self.nonstationary,
+            g = _ffi.cached_gate(device, variant=_ffi.SG_VARIANT_T, stationary=not self.nonstationary,
                           n_fft=self.n_fft, win_length=self.win_length, hop_length=self.hop_length,
                           n_grad_freq=nf, n_grad_time=nt,
                           smooth_mask=self.smoothing_filter is not None,
