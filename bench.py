@@ -88,7 +88,7 @@ def main():
         __graft_entry__.build()
     if world > 1:
         dist.barrier()
-    from noisereduce_amd.sharded import ShardedStationaryGate, with_halos
+    from noisereduce_amd.sharded import HipStationaryBackend, TimeShardedStationary, with_halos
     from noisereduce_amd.spectralgate.nonstationary import SpectralGateNonStationary
 
     # this rank's time shard of the (world x 10 min) recording
@@ -97,7 +97,8 @@ def main():
 
     def make_gate():
         if stationary:
-            return ShardedStationaryGate(y, SR, chunk_size=CHUNK, padding=PAD, n_fft=NFFT, device=device)
+            backend = HipStationaryBackend(SR, device, chunk_size=CHUNK, padding=PAD, n_fft=NFFT)
+            return TimeShardedStationary(backend, NFFT // 2 + 1)
         return SpectralGateNonStationary(
             y=y, sr=SR, chunk_size=CHUNK, padding=PAD, n_fft=NFFT, win_length=None, hop_length=None,
             time_constant_s=2.0, freq_mask_smooth_hz=500, time_mask_smooth_ms=50,
@@ -105,16 +106,16 @@ def main():
             prop_decrease=1.0, use_tqdm=False, n_jobs=1, device=device)
 
     def gate_of(sg):
-        return sg.sg._gate if stationary else sg._gate
+        return sg.backend._gate(y[None, :], False) if stationary else sg._gate
 
     def step():
         # one whole reduce_noise: (statistics + threshold broadcast) + seam exchange + chunk grid.
         # The engine handle (tables + workspace) is cached across calls by noisereduce_amd._ffi.
         sg = make_gate()
-        gate = gate_of(sg)
         if stationary:
-            out = sg.run()
+            out = sg.run(y)
         else:
+            gate = sg._gate
             ext = with_halos(y[None, :], PAD) if world > 1 else None
             if ext is None:
                 out = gate.process_chunks(y[None, :], chunked=True)

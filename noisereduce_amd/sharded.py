@@ -61,55 +61,96 @@ def with_halos(y_local, padding, group=None):
     return torch.cat([left, y_local, right], dim=1)
 
 
-class ShardedStationaryGate:
-    """reduce_noise(stationary=True) of a time-sharded (C, n_total) recording.  Each rank
-    constructs this with ITS shard (already on its GPU) and calls run()."""
+class HipStationaryBackend:
+    """Compute steps of the sharded stationary gate on this rank's MI355X."""
 
-    def __init__(self, y_local, sr, n_total=None, group=None, device=None, **kw):
+    def __init__(self, sr, device, **kw):
+        self.sr, self.device = sr, device
+        self.kw = dict(y_noise=None, n_std_thresh_stationary=1.5, chunk_size=600000,
+                       clip_noise_stationary=True, padding=30000, n_fft=1024, win_length=None,
+                       hop_length=None, time_constant_s=2.0, freq_mask_smooth_hz=500,
+                       time_mask_smooth_ms=50, tmp_folder=None, prop_decrease=1.0,
+                       use_tqdm=False, n_jobs=1)
+        self.kw.update(kw)
+        self.chunk_size, self.padding = self.kw["chunk_size"], self.kw["padding"]
+        self.sg = None
+
+    def _gate(self, y_local, with_stats):
+        from noisereduce_amd import _ffi
         from noisereduce_amd.spectralgate.stationary import SpectralGateStationary
+        if with_stats:
+            # statistics from the clip this rank holds (stationary.py:47-81)
+            self.sg = SpectralGateStationary(y=y_local, sr=self.sr, device=self.device, **self.kw)
+            return self.sg._gate
+        k = self.kw
+        W = k["n_fft"] if k["win_length"] is None else k["win_length"]
+        H = W // 4 if k["hop_length"] is None else k["hop_length"]
+        from noisereduce_amd.spectralgate.base import SpectralGate
+        probe = SpectralGate.__new__(SpectralGate)  # only to reuse the filter-design arithmetic
+        probe.sr, probe._n_fft, probe._hop_length = self.sr, k["n_fft"], H
+        probe._n_grad_freq = probe._n_grad_time = 1
+        probe.smooth_mask = False
+        if not (k["freq_mask_smooth_hz"] is None and k["time_mask_smooth_ms"] is None):
+            probe._generate_mask_smoothing_filter(k["freq_mask_smooth_hz"], k["time_mask_smooth_ms"])
+        return _ffi.cached_gate(self.device, variant=_ffi.SG_VARIANT_S, stationary=True,
+                                n_fft=k["n_fft"], win_length=W, hop_length=H,
+                                n_grad_freq=probe._n_grad_freq, n_grad_time=probe._n_grad_time,
+                                smooth_mask=probe.smooth_mask, chunk_size=k["chunk_size"],
+                                padding=k["padding"], prop_decrease=k["prop_decrease"],
+                                n_std_thresh=k["n_std_thresh_stationary"], top_db=80.0, ddof=0)
+
+    def stats(self, y_local):
+        """Noise statistics from this rank's data, left on the device (owning rank only)."""
+        return self._gate(y_local, True)
+
+    def threshold(self, y_local):
+        """Per-band threshold (dB) as a device tensor, for the broadcast."""
+        return torch.from_numpy(self.stats(y_local).get_noise_threshold()).to(y_local.device)
+
+    def filter(self, y_local, ext, halo, thresh, owner):
+        """Filter the shard.  `ext` is the halo-extended buffer (or y_local when halo == 0)."""
+        g = self._gate(y_local, False)
+        if not owner:
+            g.set_noise_threshold(thresh.cpu().numpy())
+        S = y_local.shape[1]
+        if halo == 0 and ext is y_local:
+            return g.process_chunks(y_local, chunked=S > self.chunk_size)
+        return g.process_chunks(ext, out_dtype=y_local.dtype, chunked=True, halo_left=halo,
+                                halo_right=halo)
+
+
+class TimeShardedStationary:
+    """reduce_noise(stationary=True, y_noise=None) of a recording that is time-sharded over the
+    ranks of `group` (rank r holds the r-th chunk-aligned slice, already on its device).
+    `backend` supplies the two compute steps (HipStationaryBackend in production)."""
+
+    def __init__(self, backend, n_bins, group=None):
+        self.backend = backend
+        self.n_bins = n_bins
         self.group = group
         self.ws = dist.get_world_size(group) if dist.is_initialized() else 1
         self.rank = dist.get_rank(group) if dist.is_initialized() else 0
+
+    def run(self, y_local):
         if y_local.dim() == 1:
             y_local = y_local[None, :]
-        self.y_local = y_local
-        self.chunk_size = kw.get("chunk_size", 600000)
-        self.padding = kw.get("padding", 30000)
+        pad, cs = self.backend.padding, self.backend.chunk_size
         S = y_local.shape[1]
-        if self.ws > 1 and S % self.chunk_size != 0 and self.rank != self.ws - 1:
+        if self.ws > 1 and self.rank != self.ws - 1 and S % cs != 0:
             raise ValueError("time shards must be chunk-aligned")
-        # The gate object of this rank: statistics from the local data on rank 0 (y_noise=None
-        # means "the first chunk_size samples of the recording", stationary.py:47-64, which
-        # live on rank 0); other ranks build theirs on a stand-in clip and get the threshold
-        # by broadcast.
-        defaults = dict(y_noise=None, n_std_thresh_stationary=1.5, chunk_size=600000,
-                        clip_noise_stationary=True, padding=30000, n_fft=1024, win_length=None,
-                        hop_length=None, time_constant_s=2.0, freq_mask_smooth_hz=500,
-                        time_mask_smooth_ms=50, tmp_folder=None, prop_decrease=1.0,
-                        use_tqdm=False, n_jobs=1)
-        defaults.update(kw)
-        self.sg = SpectralGateStationary(y=y_local, sr=sr,
-                                         device=device or y_local.device, **defaults)
-        if self.ws > 1:
-            thr = torch.from_numpy(self.sg.noise_thresh).to(y_local.device)
-            dist.broadcast(thr, src=0, group=group)
-            if self.rank != 0:
-                self.sg._gate.set_noise_threshold(thr.cpu().numpy())
-
-    def run(self):
-        """Filter this rank's shard; returns (C, S) on the rank's device."""
-        S = self.y_local.shape[1]
-        pad = self.padding
+        # threshold: y_noise=None means "the first chunk_size samples of the recording"
+        # (stationary.py:47-64); they live on rank 0, which broadcasts n_bins doubles.
+        thr = None
         if self.ws == 1:
-            return self.sg._gate.process_chunks(self.y_local, chunked=S > self.chunk_size)
-        ext = with_halos(self.y_local, pad, self.group)
-        # the sharded recording is always "chunked" (it is longer than one chunk)
-        return self.sg._gate.process_chunks(ext, out_dtype=self.y_local.dtype, chunked=True,
-                                            halo_left=pad, halo_right=pad)
-
-
-def reduce_noise_time_sharded(y_local, sr, filter_fn, chunk_size=600000, padding=30000, group=None):
-    """Backend-agnostic form used by the CPU tests: `filter_fn(ext, halo)` filters the chunks
-    of a shard given its halo-extended buffer and returns (C, S)."""
-    ext = with_halos(y_local, padding, group)
-    return filter_fn(ext, padding)
+            self.backend.stats(y_local)
+        elif self.rank == 0:
+            thr = self.backend.threshold(y_local)
+        else:
+            thr = torch.zeros(self.n_bins, dtype=torch.float64, device=y_local.device)
+        if self.ws > 1:
+            dist.broadcast(thr, src=0, group=self.group)
+            ext = with_halos(y_local, pad, self.group)
+            halo = pad
+        else:
+            ext, halo = y_local, 0
+        return self.backend.filter(y_local, ext, halo, thr, owner=self.rank == 0)

@@ -1,0 +1,88 @@
+"""CPU-only checks of the host side: the C-ABI library loads and exports every symbol the
+header declares, the Python mirror resolves parameters like the reference, and the product
+path refuses to run without a GPU (no silent CPU fallback)."""
+import os
+import re
+
+import numpy as np
+import pytest
+import torch
+
+from oracle import spectralgate_oracle as O
+
+ROOT = os.path.abspath(os.path.join(os.path.dirname(__file__), ".."))
+HAS_GPU = torch.cuda.is_available()
+
+
+def test_cabi_library_exports_every_declared_symbol():
+    import __graft_entry__
+    __graft_entry__.build()
+    from noisereduce_amd import _ffi
+    header = open(os.path.join(ROOT, "include", "mi355gate.h")).read()
+    declared = set(re.findall(r"\b(sg_[a-z_0-9]+)\s*\(", header))
+    declared.discard("sg_debug_dims()")
+    lib = _ffi.load_library()
+    assert declared == set(_ffi.exported_symbols()), declared ^ set(_ffi.exported_symbols())
+    for name in declared:
+        assert hasattr(lib, name), name
+    assert lib.sg_version() == 100
+    assert lib.sg_stage_name(8) == b"k_apply_istft"
+
+
+def test_sg_params_struct_layout_matches_header():
+    """ctypes mirror of struct sg_params: same field order as the header."""
+    from noisereduce_amd import _ffi
+    header = open(os.path.join(ROOT, "include", "mi355gate.h")).read()
+    body = header[header.index("typedef struct sg_params {"):header.index("} sg_params;")]
+    names = re.findall(r"^\s*(?:int32_t|int64_t|double)\s+(\w+);", body, flags=re.M)
+    assert names == [f[0] for f in _ffi.SgParams._fields_]
+
+
+def test_filter_design_matches_oracle():
+    from noisereduce_amd.spectralgate.base import _smoothing_filter, _triangle
+    for nf, nt in [(5, 9), (16, 3), (1, 4), (7, 1)]:
+        assert np.allclose(_smoothing_filter(nf, nt), O.smoothing_filter(nf, nt), rtol=0, atol=1e-16)
+    assert np.allclose(_triangle(3), O.triangle(3))
+
+
+def test_iir_coefficient():
+    from noisereduce_amd.spectralgate.nonstationary import iir_coefficient
+    assert iir_coefficient(2.0, 48000, 256) == O.iir_coefficient(2.0, 48000, 256)
+    assert abs(iir_coefficient(2.0, 48000, 256) - 0.0026631) < 1e-7
+
+
+def test_input_validation_happens_before_any_device_work():
+    """The reference's ValueErrors (base.py:60,105-123) are raised by the mirror too."""
+    from noisereduce_amd import reduce_noise
+    with pytest.raises(ValueError):
+        reduce_noise(np.zeros((2, 2, 100)), 48000)
+    with pytest.raises(ValueError):
+        reduce_noise(np.zeros(5000), 48000, freq_mask_smooth_hz=10)
+    with pytest.raises(ValueError):
+        reduce_noise(np.zeros(5000), 48000, time_mask_smooth_ms=1)
+    with pytest.raises(ValueError):
+        reduce_noise(np.zeros(5000), 48000, use_torch=True, n_jobs=2)
+
+
+@pytest.mark.skipif(HAS_GPU, reason="checks the no-GPU failure mode")
+def test_no_cpu_fallback():
+    from noisereduce_amd import reduce_noise
+    from noisereduce_amd.torchgate import TorchGate
+    with pytest.raises(RuntimeError, match="no CPU fallback"):
+        reduce_noise(np.zeros(5000), 48000, stationary=True)
+    with pytest.raises(RuntimeError, match="no CPU fallback"):
+        TorchGate(sr=16000)(torch.zeros(2, 4000))
+
+
+def test_torchgate_module_surface():
+    from noisereduce_amd.torchgate import TorchGate
+    tg = TorchGate(sr=16000)
+    assert (tg.n_fft, tg.win_length, tg.hop_length) == (1024, 1024, 256)
+    assert tuple(tg.smoothing_filter.shape) == (1, 1, 33, 7)
+    K = O.smoothing_filter(16, 3)
+    assert np.allclose(tg.smoothing_filter[0, 0].numpy(), K, atol=1e-7)
+    assert TorchGate(sr=16000, freq_mask_smooth_hz=None, time_mask_smooth_ms=None).smoothing_filter is None
+    with pytest.raises(ValueError):
+        TorchGate(sr=48000, freq_mask_smooth_hz=10)
+    with pytest.raises(AssertionError):
+        TorchGate(sr=16000, prop_decrease=1.5)

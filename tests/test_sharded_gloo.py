@@ -1,0 +1,96 @@
+"""world_size-2 test of the time-sharded gate's partition + exchange logic on CPU (gloo).
+The compute steps are supplied by the oracle here (the product backend is the HIP engine);
+the result of the two ranks, concatenated, must equal the single-process result."""
+import os
+import socket
+
+import numpy as np
+import pytest
+import torch
+import torch.distributed as dist
+import torch.multiprocessing as mp
+
+from oracle import spectralgate_oracle as O
+
+SR, CS, PAD, NFFT = 48000, 20000, 3000, 1024
+
+
+class OracleBackend:
+    """Same interface as noisereduce_amd.sharded.HipStationaryBackend, computed by the oracle."""
+    chunk_size, padding = CS, PAD
+
+    def stats(self, y_local):
+        return self
+
+    def threshold(self, y_local):
+        thr, _, _ = O.noise_threshold_S(y_local.numpy().astype(np.float64), NFFT, NFFT, NFFT // 4,
+                                        1.5, CS)
+        return torch.from_numpy(thr)
+
+    def filter(self, y_local, ext, halo, thresh, owner):
+        filt = O.smoothing_filter(5, 9)
+        C, S = y_local.shape
+        e = ext.numpy().astype(np.float64)
+        if halo == 0:
+            e = np.pad(e, ((0, 0), (PAD, PAD)))
+        out = np.zeros((C, S))
+        for i in range(-(-S // CS)):
+            win = np.zeros((C, CS + 2 * PAD))
+            seg = e[:, i * CS:i * CS + CS + 2 * PAD]
+            win[:, :seg.shape[1]] = seg
+            res = O.gate_stationary_S(win, thresh.numpy(), NFFT, NFFT, NFFT // 4, 1.0, filt)
+            n = min(CS, S - i * CS)
+            out[:, i * CS:i * CS + n] = res[:, PAD:PAD + n]
+        return torch.from_numpy(out)
+
+
+def _free_port():
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    p = s.getsockname()[1]
+    s.close()
+    return p
+
+
+def _worker(rank, world, port, y, want, ret):
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    from noisereduce_amd.sharded import TimeShardedStationary, exchange_seams, shard_bounds
+    s0, s1 = shard_bounds(y.shape[1], CS, world, rank)
+    y_local = y[:, s0:s1].contiguous()
+    left, right = exchange_seams(y_local, PAD)
+    ok = True
+    ok &= bool(torch.equal(left, y[:, s0 - PAD:s0]) if rank > 0 else torch.all(left == 0))
+    ok &= bool(torch.equal(right, y[:, s1:s1 + PAD]) if rank < world - 1 else torch.all(right == 0))
+    out = TimeShardedStationary(OracleBackend(), NFFT // 2 + 1).run(y_local)
+    err = float((out - want[:, s0:s1]).abs().max() / want.abs().max())
+    ret[rank] = (ok, err, (s0, s1))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_time_sharded_two_ranks_matches_single_process():
+    n = 7 * CS + 1234          # 8 chunks, the last one partial: rank 0 gets 4, rank 1 gets 4
+    y = np.stack([O.synth_signal(n, seed=5).astype(np.float64),
+                  O.synth_signal(n, seed=6, tone_hz=300.0).astype(np.float64)])
+    want = O.reduce_noise_S(y, SR, stationary=True, chunk_size=CS, padding=PAD, n_fft=NFFT)
+    mgr = mp.Manager()
+    ret = mgr.dict()
+    mp.spawn(_worker, args=(2, _free_port(), torch.from_numpy(y), torch.from_numpy(want), ret),
+             nprocs=2, join=True)
+    assert ret[0][2] == (0, 4 * CS) and ret[1][2] == (4 * CS, n)
+    for r in (0, 1):
+        ok, err, _ = ret[r]
+        assert ok, "seam exchange returned wrong halos"
+        assert err < 1e-12, err
+
+
+def test_shard_bounds_cover_and_align():
+    from noisereduce_amd.sharded import shard_bounds
+    for n, cs, ws in [(28_800_000, 600_000, 8), (1_000_001, 600_000, 2), (90_000, 25_000, 3),
+                      (600_000, 600_000, 4)]:
+        edges = [shard_bounds(n, cs, ws, r) for r in range(ws)]
+        assert edges[0][0] == 0 and edges[-1][1] == n
+        for (a0, a1), (b0, b1) in zip(edges, edges[1:]):
+            assert a1 == b0 and (a1 % cs == 0 or a1 == n)
