@@ -150,9 +150,15 @@ int sg_stft(sg_handle* h, const void* x_dev, int dtype, int64_t B, int64_t L, in
             double* z_dev, void* stream);
 /* Fields of the last processed unit batch, copied to the host (synchronises):
  * what = 0: raw mask  float[units][T][FS];  1: final mask float[units][T][FS];
- *        2: power     double[units][T][FS] (stationary only).  FS = sg_debug_dims()[2]. */
+ *        2: power     double[units][T][FS] (stationary, materialised path only);
+ *        3: raw mask as bits uint64[units][T][ceil(F/64)] (fused stationary path only).
+ * FS = third entry of sg_debug_dims. */
 int sg_debug_dims(const sg_handle* h, int64_t dims[3]); /* units, T, FS */
 int sg_debug_fetch(sg_handle* h, int32_t what, void* host, int64_t bytes, void* stream);
+
+/* ---- options ------------------------------------------------------------------------- */
+#define SG_OPT_FORCE_UNFUSED 1 /* value != 0: use the materialised (v1) kernels everywhere */
+int sg_set_option(sg_handle* h, int32_t option, int64_t value);
 
 /* ---- per-kernel timing (bench.py's roofline leg) ------------------------------------- */
 #define SG_STAGE_CHANNEL_MEAN 0
@@ -166,7 +172,10 @@ int sg_debug_fetch(sg_handle* h, int32_t what, void* host, int64_t bytes, void* 
 #define SG_STAGE_APPLY_ISTFT 8
 #define SG_STAGE_OLA 9
 #define SG_STAGE_NOISE_STATS 10 /* every launch of sg_noise_stats */
-#define SG_N_STAGES 11
+#define SG_STAGE_PREP 11
+#define SG_STAGE_STFT_MAX 12
+#define SG_STAGE_STFT_BITS 13
+#define SG_N_STAGES 14
 /* When enabled, every kernel launch is bracketed by a hipEvent pair recorded on the launch
  * stream.  sg_profile_read synchronises those events and returns accumulated milliseconds
  * and launch counts per stage (arrays of SG_N_STAGES); reset != 0 clears the accumulators. */

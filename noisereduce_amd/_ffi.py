@@ -19,7 +19,8 @@ LIB_PATH = os.path.join(_HERE, "libmi355gate.so")
 SG_F32, SG_F64, SG_I16, SG_I32 = 0, 1, 2, 3
 SG_VARIANT_S, SG_VARIANT_T = 0, 1
 SG_E_INVALID, SG_E_UNSUPPORTED, SG_E_HIP, SG_E_NOMEM, SG_E_STATE = -1, -2, -3, -4, -5
-SG_N_STAGES = 11
+SG_N_STAGES = 14
+SG_OPT_FORCE_UNFUSED = 1
 
 _TORCH_DTYPES = {torch.float32: SG_F32, torch.float64: SG_F64, torch.int16: SG_I16,
                  torch.int32: SG_I32}
@@ -59,6 +60,7 @@ _PROTOTYPES = {
     "sg_process_batch_backward": (c_int, [c_void_p, c_void_p, c_int, c_int64, c_int64, c_int64,
                                           c_void_p, c_int64, c_void_p]),
     "sg_stft": (c_int, [c_void_p, c_void_p, c_int, c_int64, c_int64, c_int64, c_void_p, c_void_p]),
+    "sg_set_option": (c_int, [c_void_p, c_int32, c_int64]),
     "sg_profile_enable": (c_int, [c_void_p, c_int32]),
     "sg_profile_read": (c_int, [c_void_p, POINTER(c_double), POINTER(c_int64), c_int32, c_int32]),
     "sg_stage_name": (c_char_p, [c_int32]),
@@ -275,6 +277,9 @@ class Gate:
                 _sg_dtype(out), Lout, self._stream()))
         return out
 
+    def set_option(self, option, value):
+        self._check(self.lib.sg_set_option(self._h, int(option), int(value)))
+
     # -- per-kernel timing -----------------------------------------------------------
     def profile_enable(self, on=True):
         self._check(self.lib.sg_profile_enable(self._h, int(bool(on))))
@@ -307,6 +312,14 @@ class Gate:
         dims = (c_int64 * 3)()
         self._check(self.lib.sg_debug_dims(self._h, dims))
         units, T, FS = dims[0], dims[1], dims[2]
+        if what == 3:  # bit field -> boolean (units, T, F)
+            wpr = (self.n_bins + 63) // 64
+            words = np.empty((units, T, wpr), dtype=np.uint64)
+            with torch.cuda.device(self.device):
+                self._check(self.lib.sg_debug_fetch(self._h, 3, words.ctypes.data_as(c_void_p),
+                                                    words.nbytes, self._stream()))
+            b = np.unpackbits(words.view(np.uint8), axis=-1, bitorder="little")
+            return b[:, :, :self.n_bins].astype(bool)
         dt = np.float64 if what == 2 else np.float32
         host = np.empty((units, T, FS), dtype=dt)
         with torch.cuda.device(self.device):

@@ -13,6 +13,7 @@
 
 #include "../../include/mi355gate.h"
 #include "kernels.hpp"
+#include "fused.hpp"
 
 using namespace sg;
 
@@ -46,8 +47,14 @@ struct sg_handle {
   bool has_thresh = false;
   // workspace
   DevBuf P, pmax, thr_rows, raw, M, seg, yn;
+  DevBuf bits, K16, umax, need, T2;  // fused stationary path
+  int64_t ktot = 1;                  // (nf+1)^2 (nt+1)^2: integer weight total of the smoothing filter
+  bool fused_ok = false;
+  double sum_abs_w = 0.0;
   int64_t dbg_units = 0, dbg_T = 0;
   bool dbg_has_P = false;
+  bool dbg_fused = false;
+  bool force_unfused = false;  // sg_set_option(SG_OPT_FORCE_UNFUSED): materialised v1 path
   // per-kernel timing with HIP events on the launch stream (sg_profile_*)
   bool prof_on = false;
   int prof_override = -1;  // >= 0: book every launch under this stage (noise statistics)
@@ -190,6 +197,42 @@ static hipError_t launch_stft(int N, const View& v, const Geom& g, int64_t units
   return hipErrorInvalidValue;
 }
 
+template <int N, int MODE>
+static hipError_t launch_bits_n(const View& v, const Geom& g, int64_t units, const void* tw, const void* wfull,
+                                const ThreshConsts& tc, double mag_scale, double top_db,
+                                unsigned long long* pmax_bits, unsigned long long* bits, int wpr,
+                                hipStream_t st) {
+  constexpr int WAVES = (N * sizeof(cx<double>) > 16384) ? 2 : 4;
+  constexpr int FPW = 4;
+  size_t lds = (size_t)(N + WAVES * N) * sizeof(cx<double>) + (size_t)(N + 1) * sizeof(double);
+  auto kern = k_stft_bits<N, WAVES, FPW, MODE>;
+  if (lds > 65536) {
+    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern),
+                                       hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    if (e != hipSuccess) return e;
+  }
+  dim3 grid((unsigned)((g.T + WAVES * FPW - 1) / (WAVES * FPW)), (unsigned)units);
+  hipLaunchKernelGGL(kern, grid, dim3(WAVES * 64), lds, st, v, g, (const cx<double>*)tw, (const double*)wfull, tc,
+                     mag_scale, top_db, pmax_bits, bits, wpr);
+  return hipGetLastError();
+}
+
+template <int MODE>
+static hipError_t launch_bits(int N, const View& v, const Geom& g, int64_t units, const void* tw,
+                              const void* wfull, const ThreshConsts& tc, double mag_scale, double top_db,
+                              unsigned long long* pmax_bits, unsigned long long* bits, int wpr, hipStream_t st) {
+  switch (N) {
+    case 32: return launch_bits_n<32, MODE>(v, g, units, tw, wfull, tc, mag_scale, top_db, pmax_bits, bits, wpr, st);
+    case 64: return launch_bits_n<64, MODE>(v, g, units, tw, wfull, tc, mag_scale, top_db, pmax_bits, bits, wpr, st);
+    case 128: return launch_bits_n<128, MODE>(v, g, units, tw, wfull, tc, mag_scale, top_db, pmax_bits, bits, wpr, st);
+    case 256: return launch_bits_n<256, MODE>(v, g, units, tw, wfull, tc, mag_scale, top_db, pmax_bits, bits, wpr, st);
+    case 512: return launch_bits_n<512, MODE>(v, g, units, tw, wfull, tc, mag_scale, top_db, pmax_bits, bits, wpr, st);
+    case 1024: return launch_bits_n<1024, MODE>(v, g, units, tw, wfull, tc, mag_scale, top_db, pmax_bits, bits, wpr, st);
+    case 2048: return launch_bits_n<2048, MODE>(v, g, units, tw, wfull, tc, mag_scale, top_db, pmax_bits, bits, wpr, st);
+  }
+  return hipErrorInvalidValue;
+}
+
 template <int N>
 static hipError_t launch_apply_n(const View& v, const Geom& g, int64_t units, const void* tw, const float* wa,
                                  const float* ws, const float* M, float* seg, hipStream_t st) {
@@ -281,6 +324,15 @@ extern "C" int sg_create(const sg_params* p, const double* window_host, sg_handl
   }
   h->sum_w = 0.0;
   for (int k = 0; k < W; ++k) h->sum_w += w[k];
+  for (int k = 0; k < W; ++k) h->sum_abs_w += std::fabs(w[k]);
+  {
+    int64_t a = p->smooth_mask ? (int64_t)(p->n_grad_freq + 1) * (p->n_grad_freq + 1) : 1;
+    int64_t b = p->smooth_mask ? (int64_t)(p->n_grad_time + 1) * (p->n_grad_time + 1) : 1;
+    h->ktot = a * b;
+    // fused (bit-mask) path: variant-S stationary gate whose integer smoothing sums fit uint16
+    h->fused_ok = p->variant == SG_VARIANT_S && p->stationary && h->ktot <= 65535 &&
+                  (!p->smooth_mask || p->n_grad_time <= 96);
+  }
   // window embedded in an n_fft frame: scipy zero-pads the windowed frame at the END
   // (scipy/_spectral_py.py:2202) and extends the signal by W//2; torch centres the window
   // inside n_fft and pads the signal by n_fft//2.
@@ -337,7 +389,8 @@ extern "C" int sg_destroy(sg_handle* h) {
   for (auto& r : h->prof_live) { (void)hipEventDestroy(r.a); (void)hipEventDestroy(r.b); }
   for (auto e : h->prof_pool) (void)hipEventDestroy(e);
   for (DevBuf* b : {&h->tw64, &h->tw32, &h->wfull64, &h->wa32, &h->ws32, &h->wsq32, &h->kf, &h->kt, &h->thresh,
-                    &h->P, &h->pmax, &h->thr_rows, &h->raw, &h->M, &h->seg, &h->yn})
+                    &h->P, &h->pmax, &h->thr_rows, &h->raw, &h->M, &h->seg, &h->yn, &h->bits, &h->K16, &h->umax,
+                    &h->need, &h->T2})
     free_buf(*b);
   delete h;
   return SG_OK;
@@ -483,6 +536,73 @@ static int stage_apply_ola(sg_handle* h, const View& v, const Geom& g, int64_t u
   return SG_OK;
 }
 
+// Fused stationary mask (variant S): STFT(f64) -> bits -> integer smoothing -> K16 -> float mask.
+static int stage_fused_mask(sg_handle* h, const View& v, const Geom& g, int64_t ub, hipStream_t st) {
+  const int wpr = (g.F + 63) / 64;
+  int rc;
+  if ((rc = ensure(h, h->bits, (size_t)ub * g.T * wpr * 8))) return rc;
+  if ((rc = ensure(h, h->K16, (size_t)ub * g.T * g.FS * 2))) return rc;
+  if ((rc = ensure(h, h->umax, (size_t)ub * 4))) return rc;
+  if ((rc = ensure(h, h->need, (size_t)ub * 4))) return rc;
+  if ((rc = ensure(h, h->T2, (size_t)g.FS * 8))) return rc;
+  HIPCHK(h, hipMemsetAsync(h->umax.p, 0, (size_t)ub * 4, st));
+  HIPCHK(h, hipMemsetAsync(h->pmax.p, 0, (size_t)ub * g.FS * 8, st));
+  {
+    ProfScope ps(h, SG_STAGE_PREP, st);
+    hipLaunchKernelGGL(k_unit_absmax, dim3(32, (unsigned)ub), dim3(256), 0, st, v, ub, (unsigned*)h->umax.p);
+    HIPCHK(h, hipGetLastError());
+    hipLaunchKernelGGL(k_prep_thresh, dim3((unsigned)((ub + 255) / 256)), dim3(256), 0, st,
+                       (const double*)h->thresh.p, g.F, h->mag_scale, h->sum_abs_w, h->p.top_db,
+                       (const unsigned*)h->umax.p, ub, (double*)h->T2.p, (int*)h->need.p);
+    HIPCHK(h, hipGetLastError());
+  }
+  ThreshConsts tc{(const double*)h->T2.p, (const double*)h->thresh.p, (const double*)h->pmax.p,
+                  (const int*)h->need.p};
+  {
+    ProfScope ps(h, SG_STAGE_STFT_MAX, st);
+    HIPCHK(h, launch_bits<0>(h->N, v, g, ub, h->tw64.p, h->wfull64.p, tc, h->mag_scale, h->p.top_db,
+                             (unsigned long long*)h->pmax.p, (unsigned long long*)h->bits.p, wpr, st));
+  }
+  {
+    ProfScope ps(h, SG_STAGE_STFT_BITS, st);
+    HIPCHK(h, launch_bits<1>(h->N, v, g, ub, h->tw64.p, h->wfull64.p, tc, h->mag_scale, h->p.top_db,
+                             (unsigned long long*)h->pmax.p, (unsigned long long*)h->bits.p, wpr, st));
+  }
+  ProfScope ps(h, SG_STAGE_SMOOTH, st);
+  const int nf = h->p.n_grad_freq, nt = h->p.n_grad_time;
+  int64_t cells = ub * g.T * g.FS;
+  if (h->p.smooth_mask) {
+    const int rows = SM_TT + 2 * nt;
+    const bool small = (nf + 1) * (nf + 1) <= 255;
+    size_t lds = smooth_cf_bytes(rows, g.F, small ? 1 : 2) + (size_t)rows * wpr * 8;
+    dim3 grid((unsigned)((g.T + SM_TT - 1) / SM_TT), (unsigned)ub);
+    if (small) {
+      auto kern = k_smooth_bits<uint8_t>;
+      if (lds > 65536)
+        HIPCHK(h, hipFuncSetAttribute(reinterpret_cast<const void*>(kern),
+                                      hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+      hipLaunchKernelGGL(kern, grid, dim3(256), lds, st, (const unsigned long long*)h->bits.p, g, wpr, nf, nt,
+                         (unsigned short*)h->K16.p);
+    } else {
+      auto kern = k_smooth_bits<uint16_t>;
+      if (lds > 65536)
+        HIPCHK(h, hipFuncSetAttribute(reinterpret_cast<const void*>(kern),
+                                      hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+      hipLaunchKernelGGL(kern, grid, dim3(256), lds, st, (const unsigned long long*)h->bits.p, g, wpr, nf, nt,
+                         (unsigned short*)h->K16.p);
+    }
+  } else {
+    hipLaunchKernelGGL(k_bits_to_k16, dim3(grid_1d(cells, 256)), dim3(256), 0, st,
+                       (const unsigned long long*)h->bits.p, g, wpr, (unsigned short*)h->K16.p, ub);
+  }
+  HIPCHK(h, hipGetLastError());
+  hipLaunchKernelGGL(k_k16_to_mask, dim3(grid_1d(cells, 256)), dim3(256), 0, st, (const unsigned short*)h->K16.p,
+                     g, nf, nt, 1.0f / (float)h->ktot, (float)h->p.prop_decrease, 1, h->p.smooth_mask ? 1 : 0,
+                     (float*)h->M.p, ub);
+  HIPCHK(h, hipGetLastError());
+  return SG_OK;
+}
+
 // Variant S over a set of units described by `v` (unit0 filled per batch).
 static int run_S(sg_handle* h, View v, int64_t total_units, const OutMap& om, hipStream_t st) {
   Geom g = make_geom(h, v.Lp);
@@ -496,17 +616,23 @@ static int run_S(sg_handle* h, View v, int64_t total_units, const OutMap& om, hi
   for (int64_t u0 = 0; u0 < total_units; u0 += ub) {
     int64_t nb = std::min(ub, total_units - u0);
     v.unit0 = u0;
-    if (h->p.stationary) {
-      if ((rc = stage_power(h, v, g, nb, st))) return rc;
-      if ((rc = stage_decide(h, g, nb, (const double*)h->thresh.p, 0, st))) return rc;
+    const bool fused = h->fused_ok && !h->force_unfused;
+    if (fused) {
+      if ((rc = stage_fused_mask(h, v, g, nb, st))) return rc;
     } else {
-      if ((rc = stage_nonstat_raw(h, v, g, nb, st))) return rc;
+      if (h->p.stationary) {
+        if ((rc = stage_power(h, v, g, nb, st))) return rc;
+        if ((rc = stage_decide(h, g, nb, (const double*)h->thresh.p, 0, st))) return rc;
+      } else {
+        if ((rc = stage_nonstat_raw(h, v, g, nb, st))) return rc;
+      }
+      if ((rc = stage_smooth(h, g, nb, st))) return rc;
     }
-    if ((rc = stage_smooth(h, g, nb, st))) return rc;
     if ((rc = stage_apply_ola(h, v, g, nb, (const float*)h->M.p, om, 1, st))) return rc;
     h->dbg_units = nb;
     h->dbg_T = g.T;
-    h->dbg_has_P = h->p.stationary != 0;
+    h->dbg_has_P = h->p.stationary != 0 && !fused;
+    h->dbg_fused = fused;
   }
   return SG_OK;
 }
@@ -712,6 +838,14 @@ extern "C" int sg_stft(sg_handle* h, const void* x_dev, int dtype, int64_t B, in
   return SG_OK;
 }
 
+extern "C" int sg_set_option(sg_handle* h, int32_t option, int64_t value) {
+  if (!h) return SG_E_INVALID;
+  switch (option) {
+    case SG_OPT_FORCE_UNFUSED: h->force_unfused = value != 0; return SG_OK;
+  }
+  FAIL(h, SG_E_INVALID, "sg_set_option: unknown option %d", option);
+}
+
 extern "C" int sg_profile_enable(sg_handle* h, int32_t on) {
   if (!h) return SG_E_INVALID;
   h->prof_on = on != 0;
@@ -743,7 +877,8 @@ extern "C" const char* sg_stage_name(int32_t stage) {
   static const char* names[SG_N_STAGES] = {"k_channel_mean", "k_stft<double> (power)", "k_colmax", "k_colstats",
                                            "k_decide", "k_stft<float> (magnitude)", "nonstat mask (iir/boxcar)",
                                            "k_smooth_f+k_smooth_t", "k_apply_istft", "k_ola",
-                                           "noise statistics (all kernels)"};
+                                           "noise statistics (all kernels)", "k_unit_absmax+k_prep_thresh",
+                                           "k_stft_bits<max> (floor pre-pass)", "k_stft_bits<decide>"};
   return (stage >= 0 && stage < SG_N_STAGES) ? names[stage] : "?";
 }
 
@@ -760,7 +895,12 @@ extern "C" int sg_debug_fetch(sg_handle* h, int32_t what, void* host, int64_t by
   const void* src;
   size_t need;
   switch (what) {
-    case 0: src = h->raw.p; need = cells * 4; break;
+    case 0:
+      if (h->dbg_fused) FAIL(h, SG_E_STATE, "fused path keeps the raw mask as bits: fetch field 3");
+      src = h->raw.p; need = cells * 4; break;
+    case 3:
+      if (!h->dbg_fused) FAIL(h, SG_E_STATE, "bit field only exists on the fused path");
+      src = h->bits.p; need = (size_t)h->dbg_units * h->dbg_T * ((h->F + 63) / 64) * 8; break;
     case 1: src = h->M.p; need = cells * 4; break;
     case 2:
       if (!h->dbg_has_P) FAIL(h, SG_E_STATE, "power field only exists for stationary gates");

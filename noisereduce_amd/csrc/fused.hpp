@@ -1,0 +1,287 @@
+// Fused stationary path (variant S): no time-frequency field wider than one BIT per cell
+// is written by the decision stage.
+//
+//   k_unit_absmax   max|x| per unit (upper bound of every |X[k]| -> is the -top_db floor live?)
+//   k_prep_thresh   per-band compare constants from the dB threshold (monotone transform of
+//                   20*log10(|Z|+eps) > thresh  <=>  |X|^2 > T2[f]) + per-unit floor flags
+//   k_stft_bits     float64 STFT of every frame; MODE_MAX: per-(unit,band) max power (only for
+//                   units whose floor may be live), MODE_DECIDE: mask bits via wave ballot
+//   k_smooth_bits   separable triangular smoothing on the bit field in exact integer
+//                   arithmetic -> uint16 weight sums K (mask = K / ktot)
+// The apply kernel (k_apply_istft_k16 in this file) reads K instead of a float mask.
+#pragma once
+#include "kernels.hpp"
+
+namespace sg {
+
+constexpr int BITS_WPR_MAX = 33;  // 64-bit words per bit row: ceil(F/64), F <= 2049
+
+struct ThreshConsts {
+  // all device pointers
+  const double* T2;        // [F]  compare constant on the RAW power |X|^2 (see k_prep_thresh)
+  const double* thresh;    // [F]  dB threshold (for the floor test)
+  const double* pmax;      // [units][FS] per-(unit, band) max raw power, 0 where not computed
+  const int* need_floor;   // [units] 1: this unit's -top_db floor may be live -> pmax is valid
+};
+
+// ---------------------------------------------------------------------------------------
+__global__ void k_unit_absmax(View view, int64_t n_units, unsigned* __restrict__ umax_bits) {
+  // grid: (splits, units).  Non-negative floats order like their bit patterns.
+  const int64_t u = blockIdx.y;
+  const int64_t row = (view.unit0 + u) / view.n_chunks;
+  const int64_t chunk = (view.unit0 + u) % view.n_chunks;
+  float m = 0.f;
+  for (int64_t s = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; s < view.Lp;
+       s += (int64_t)gridDim.x * blockDim.x)
+    m = fmaxf(m, fabsf((float)view_sample(view, row, chunk, s)));
+  // float(double) rounds to nearest: inflate by one ulp so the bound stays an upper bound
+  m = m * 1.0000002f;
+  for (int off = 32; off > 0; off >>= 1) m = fmaxf(m, __shfl_xor(m, off));
+  if ((threadIdx.x & 63) == 0) atomicMax(&umax_bits[u], __float_as_uint(m));
+}
+
+// T2[f]: 20*log10(|X|*mag_scale + eps) > thresh[f]   <=>   |X|^2 > T2[f]   with
+//   Tm = (10^(thresh/20) - eps) / mag_scale ;  T2 = Tm^2  (Tm > 0)
+// and the two degenerate cases pinned to what the reference's formula gives for |X| = 0:
+//   zero cell passes (20*log10(eps) > thresh)  -> T2 = -1  (everything passes)
+//   zero cell fails                            -> T2 = max(T2, 0)  (0 > 0 is false)
+// need_floor[u]: the floor max(dB, rowmax - top_db) can only lift a cell above thresh[f] if
+// rowmax_dB - top_db > thresh[f]; |X[k]| <= sum|x w| <= max|x| * sum|w| bounds rowmax.
+__global__ void k_prep_thresh(const double* __restrict__ thresh, int F, double mag_scale, double sum_abs_w,
+                              double top_db, const unsigned* __restrict__ umax_bits, int64_t n_units,
+                              double* __restrict__ T2, int* __restrict__ need_floor) {
+  const double eps = 2.220446049250313e-16;
+  __shared__ double s_min[256];
+  double mn = 1e300;
+  for (int f = threadIdx.x; f < F; f += blockDim.x) {
+    double th = thresh[f];
+    mn = fmin(mn, th);
+    if (blockIdx.x == 0) {
+      double zero_db = 20.0 * log10(eps);
+      double t2;
+      if (zero_db > th) {
+        t2 = -1.0;
+      } else {
+        double tm = (exp10(th / 20.0) - eps) / mag_scale;
+        t2 = tm > 0.0 ? tm * tm : 0.0;
+      }
+      T2[f] = t2;
+    }
+  }
+  s_min[threadIdx.x] = mn;
+  __syncthreads();
+  for (int o = blockDim.x / 2; o > 0; o >>= 1) {
+    if ((int)threadIdx.x < o) s_min[threadIdx.x] = fmin(s_min[threadIdx.x], s_min[threadIdx.x + o]);
+    __syncthreads();
+  }
+  const double min_thresh = s_min[0];
+  for (int64_t u = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; u < n_units;
+       u += (int64_t)gridDim.x * blockDim.x) {
+    double ub = (double)__uint_as_float(umax_bits[u]) * sum_abs_w * mag_scale;
+    double ub_db = 20.0 * log10(ub + eps) + 1e-6;  // margin covers log10/rounding slack
+    need_floor[u] = (ub_db - top_db > min_thresh) ? 1 : 0;
+  }
+}
+
+// ---------------------------------------------------------------------------------------
+// float64 STFT + decision.  One wavefront per frame (LDS Stockham core of fft_wave.hpp).
+// MODE 0 (max): only for units with need_floor: atomic max of the raw power per band.
+// MODE 1 (decide): bits[u][t][w] (64 bins per word) = |X|^2 > T2[f]  ||  floor lifts the band.
+// ---------------------------------------------------------------------------------------
+template <int N, int WAVES, int FPW, int MODE>
+__global__ __launch_bounds__(WAVES * 64) void k_stft_bits(View view, Geom g, const cx<double>* __restrict__ tw_g,
+                                                          const double* __restrict__ wfull, ThreshConsts tc,
+                                                          double mag_scale, double top_db,
+                                                          unsigned long long* __restrict__ pmax_bits,
+                                                          unsigned long long* __restrict__ bits, int wpr) {
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  cx<double>* tw = reinterpret_cast<cx<double>*>(smem);
+  cx<double>* bufs = tw + N;
+  double* sT2 = reinterpret_cast<double*>(bufs + WAVES * N);  // [N+1] compare constants
+  const int lane = threadIdx.x & 63;
+  const int wave = threadIdx.x >> 6;
+  cx<double>* buf = bufs + wave * N;
+  const int64_t u = blockIdx.y;
+  const bool floor_live = tc.need_floor[u] != 0;
+  if (MODE == 0 && !floor_live) return;  // whole block: uniform
+  for (int i = threadIdx.x; i < N; i += WAVES * 64) tw[i] = tw_g[i];
+  if (MODE == 1) {
+    for (int i = threadIdx.x; i <= N; i += WAVES * 64) {
+      double t2 = tc.T2[i];
+      if (floor_live) {
+        // band lifted by the floor: rowmax_dB - top_db > thresh  =>  every cell passes
+        double fl = cell_db(tc.pmax[u * g.FS + i], mag_scale) - top_db;
+        if (fl > tc.thresh[i]) t2 = -1.0;
+      }
+      sT2[i] = t2;
+    }
+  }
+  const int64_t row = (view.unit0 + u) / view.n_chunks;
+  const int64_t chunk = (view.unit0 + u) % view.n_chunks;
+  __syncthreads();
+  double vmax[N / 64 + 1];
+#pragma unroll
+  for (int m = 0; m <= N / 64; ++m) vmax[m] = 0.0;
+  for (int fi = 0; fi < FPW; ++fi) {
+    const int64_t t = ((int64_t)blockIdx.x * FPW + fi) * WAVES + wave;
+    const bool valid = t < g.T;
+    const int64_t s0 = t * g.H - g.padL;
+    for (int j = lane; j < N; j += 64) {
+      cx<double> z = {0.0, 0.0};
+      if (valid) {
+        z.x = view_sample(view, row, chunk, s0 + 2 * j) * wfull[2 * j];
+        z.y = view_sample(view, row, chunk, s0 + 2 * j + 1) * wfull[2 * j + 1];
+      }
+      buf[j] = z;
+    }
+    SG_PASS_SYNC();
+    wave_fft<double, N, false>(buf, tw, lane);
+    unsigned long long* brow = bits + ((u * g.T + t) * (int64_t)wpr);
+#pragma unroll
+    for (int m = 0; m <= N / 64; ++m) {
+      const int k = lane + 64 * m;
+      bool pred = false;
+      if (k <= N) {
+        cx<double> a = buf[k == N ? 0 : k];
+        cx<double> b = buf[(k == 0 || k == N) ? 0 : N - k];
+        cx<double> w = tw[k == N ? 0 : k];
+        cx<double> X = rfft_bin(a, b, w, k, N);
+        double P = X.x * X.x + X.y * X.y;
+        if (MODE == 0) vmax[m] = fmax(vmax[m], valid ? P : 0.0);
+        else pred = P > sT2[k];
+      }
+      if (MODE == 1) {
+        unsigned long long word = __ballot(pred);
+        if (valid && lane == 0) brow[m] = word;
+      }
+    }
+    SG_PASS_SYNC();
+  }
+  if (MODE == 0) {
+#pragma unroll
+    for (int m = 0; m <= N / 64; ++m) {
+      const int k = lane + 64 * m;
+      if (k <= N) atomicMax(&pmax_bits[u * g.FS + k], (unsigned long long)__double_as_longlong(vmax[m]));
+    }
+  }
+}
+
+// ---------------------------------------------------------------------------------------
+// Integer mask smoothing.  K[t][f] = sum_{a,b} vf[a] vt[b] bit[t+b][f+a], vf/vt the integer
+// triangles [1..m+1..1] (base.py:7-29 times (m+1)), zero outside the unit's (F, T) field
+// (fftconvolve mode="same", stationary.py:114).  Exact: K <= (nf+1)^2 (nt+1)^2 <= 65535.
+// Block = one tile of TT frames of one unit.  Phase 1: along f, from the bit words, with the
+// two-boxcar recurrence  c[f+1]-c[f] = sum(x[f+1..f+m+1]) - sum(x[f-m..f]) ; phase 2: the same
+// recurrence along t on the phase-1 counts held in LDS.
+// ---------------------------------------------------------------------------------------
+constexpr int SM_TT = 64;   // output frames per block
+constexpr int SM_SEG = 64;  // recurrence segment length (both phases)
+
+__device__ __forceinline__ int bit_at(const unsigned long long* __restrict__ rowbits, int f, int F) {
+  if (f < 0 || f >= F) return 0;
+  return (int)((rowbits[f >> 6] >> (f & 63)) & 1ull);
+}
+
+// CT: uint8_t when (nf+1)^2 <= 255, else uint16_t (phase-1 counts held in LDS).
+__host__ __device__ inline size_t smooth_cf_bytes(int rows, int F, int ct_size) {
+  size_t b = (size_t)rows * ((F + 3) & ~3) * ct_size;
+  return (b + 15) & ~(size_t)15;
+}
+
+template <typename CT>
+__global__ __launch_bounds__(256) void k_smooth_bits(const unsigned long long* __restrict__ bits, Geom g, int wpr,
+                                                     int nf, int nt, unsigned short* __restrict__ K) {
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  const int rows = SM_TT + 2 * nt;     // halo rows on both sides
+  const int FP = (g.F + 3) & ~3;       // LDS row pitch
+  CT* cf = reinterpret_cast<CT*>(smem);                                               // [rows][FP]
+  unsigned long long* wb = reinterpret_cast<unsigned long long*>(smem + smooth_cf_bytes(rows, g.F, sizeof(CT)));
+  const int64_t u = blockIdx.y;
+  const int64_t t0 = (int64_t)blockIdx.x * SM_TT;  // first output frame of the tile
+  // stage the bit rows (zero rows outside [0, T))
+  for (int i = threadIdx.x; i < rows * wpr; i += blockDim.x) {
+    int r = i / wpr, w = i % wpr;
+    int64_t t = t0 - nt + r;
+    wb[i] = (t >= 0 && t < g.T) ? bits[(u * g.T + t) * (int64_t)wpr + w] : 0ull;
+  }
+  __syncthreads();
+  // phase 1: along f.  task = (row r, segment s)
+  const int nseg = (g.F + SM_SEG - 1) / SM_SEG;
+  for (int task = threadIdx.x; task < rows * nseg; task += blockDim.x) {
+    const int r = task / nseg, f0 = (task % nseg) * SM_SEG;
+    const unsigned long long* rb = wb + (size_t)r * wpr;
+    int c = 0, R = 0, L = 0;
+    for (int a = -nf; a <= nf; ++a) c += (nf + 1 - (a < 0 ? -a : a)) * bit_at(rb, f0 + a, g.F);
+    for (int j = 1; j <= nf + 1; ++j) R += bit_at(rb, f0 + j, g.F);
+    for (int j = 0; j <= nf; ++j) L += bit_at(rb, f0 - j, g.F);
+    const int f1 = min(f0 + SM_SEG, g.F);
+    for (int f = f0; f < f1; ++f) {
+      cf[(size_t)r * FP + f] = (CT)c;
+      c += R - L;
+      R += bit_at(rb, f + nf + 2, g.F) - bit_at(rb, f + 1, g.F);
+      L += bit_at(rb, f + 1, g.F) - bit_at(rb, f - nf, g.F);
+    }
+  }
+  __syncthreads();
+  // phase 2: along t on cf.  task = (bin f, time segment)
+  const int tsegs = 4, tlen = SM_TT / tsegs;
+  for (int task = threadIdx.x; task < g.F * tsegs; task += blockDim.x) {
+    const int f = task % g.F, ts = task / g.F;
+    const int r0 = nt + ts * tlen;  // LDS row of the first output frame of this segment
+    auto at = [&](int r) -> int { return (r >= 0 && r < rows) ? (int)cf[(size_t)r * FP + f] : 0; };
+    int c = 0, R = 0, L = 0;
+    for (int b = -nt; b <= nt; ++b) c += (nt + 1 - (b < 0 ? -b : b)) * at(r0 + b);
+    for (int j = 1; j <= nt + 1; ++j) R += at(r0 + j);
+    for (int j = 0; j <= nt; ++j) L += at(r0 - j);
+    for (int i = 0; i < tlen; ++i) {
+      const int r = r0 + i;
+      const int64_t t = t0 + ts * tlen + i;
+      if (t < g.T) K[(u * g.T + t) * (int64_t)g.FS + f] = (unsigned short)c;
+      c += R - L;
+      R += at(r + nt + 2) - at(r + 1);
+      L += at(r + 1) - at(r - nt);
+    }
+  }
+}
+
+// no smoothing: K = bit (ktot = 1)
+__global__ void k_bits_to_k16(const unsigned long long* __restrict__ bits, Geom g, int wpr,
+                              unsigned short* __restrict__ K, int64_t n_units) {
+  const int64_t cells = n_units * g.T * g.FS;
+  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < cells;
+       i += (int64_t)gridDim.x * blockDim.x) {
+    const int f = (int)(i % g.FS);
+    if (f >= g.F) continue;
+    const int64_t ut = i / g.FS;
+    K[i] = (unsigned short)((bits[ut * wpr + (f >> 6)] >> (f & 63)) & 1ull);
+  }
+}
+
+// M[t][f] from K:  p * K/ktot + (1-p) * edge(f, t)  (edge = valid-tap weight fraction when the
+// reference applies prop_decrease before smoothing, else 1).  Written as float for the v1
+// apply kernel (general geometries); the fast apply kernel evaluates this on the fly.
+__global__ void k_k16_to_mask(const unsigned short* __restrict__ K, Geom g, int nf, int nt, float inv_ktot,
+                              float p, int prop_before, int smooth, float* __restrict__ M, int64_t n_units) {
+  const int64_t cells = n_units * g.T * g.FS;
+  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < cells;
+       i += (int64_t)gridDim.x * blockDim.x) {
+    const int f = (int)(i % g.FS);
+    if (f >= g.F) continue;
+    const int64_t t = (i / g.FS) % g.T;
+    float edge = 1.0f;
+    if (prop_before && smooth) {
+      // integer triangle sums over the valid taps
+      auto tri = [](int m, int lo, int hi) {  // sum_{a=lo..hi} (m+1-|a|), -m <= lo <= hi <= m
+        int s = 0;
+        for (int a = lo; a <= hi; ++a) s += m + 1 - (a < 0 ? -a : a);
+        return s;
+      };
+      int flo = max(-nf, -f), fhi = min(nf, g.F - 1 - f);
+      int64_t tlo = max<int64_t>(-nt, -t), thi = min<int64_t>(nt, g.T - 1 - t);
+      edge = (float)tri(nf, flo, fhi) * (float)tri(nt, (int)tlo, (int)thi) * inv_ktot;
+    }
+    M[i] = p * ((float)K[i] * inv_ktot) + (1.0f - p) * edge;
+  }
+}
+
+}  // namespace sg

@@ -70,7 +70,7 @@ def test_stage_taps(nr, golden_dir):
     assert np.max(np.abs(Z[:, cols] - g["Z_cols"])) < 1e-13
     out = sg.get_traces()
     assert O.rel_err(out, g["out"]) < TOL
-    raw = sg._gate.debug_field(0)[0].T > 0.5                                # (F, T)
+    raw = sg._gate.debug_field(3)[0].T                                      # (F, T) bits
     assert raw.shape == tuple(g["raw_shape"])
     ref_raw = np.unpackbits(g["raw_bits"], axis=1)[:, :raw.shape[1]].astype(bool)
     assert np.count_nonzero(raw != ref_raw) == 0, "mask flips vs the reference"
@@ -164,3 +164,58 @@ def test_torchgate_state_dict_and_errors():
         tg(torch.zeros(2, 1000).cuda())
     with pytest.raises(AssertionError):
         tg(torch.zeros(4000).cuda())
+
+
+def test_unfused_path_still_matches(nr, golden_dir):
+    """The materialised (v1) kernels stay available behind SG_OPT_FORCE_UNFUSED and must
+    give the same answer as the fused bit-mask path."""
+    from noisereduce_amd import _ffi
+    from noisereduce_amd.spectralgate.stationary import SpectralGateStationary
+    case = S_CASES["stat_chunked"]
+    g = _load(golden_dir, "S_stat_chunked")
+    y, _ = make_input_S(case)
+    kw = dict(sr=48000, y_noise=None, prop_decrease=1.0, n_std_thresh_stationary=1.5,
+              chunk_size=25000, clip_noise_stationary=True, padding=4000, n_fft=1024, win_length=None,
+              hop_length=None, time_constant_s=2.0, freq_mask_smooth_hz=500, time_mask_smooth_ms=50,
+              tmp_folder=None, use_tqdm=False, n_jobs=1)
+    sg = SpectralGateStationary(y=y, **kw)
+    fused = sg.get_traces()
+    try:
+        sg._gate.set_option(_ffi.SG_OPT_FORCE_UNFUSED, 1)
+        unfused = sg.get_traces()
+        raw = sg._gate.debug_field(0)
+    finally:
+        sg._gate.set_option(_ffi.SG_OPT_FORCE_UNFUSED, 0)
+    assert raw.dtype == np.float32
+    assert O.rel_err(fused, g["out"]) < TOL and O.rel_err(unfused, g["out"]) < TOL
+    assert O.rel_err(fused, unfused) < 1e-6
+
+
+@pytest.mark.parametrize("prop", [1.0, 0.7])
+def test_db_floor_live(nr, prop):
+    """A band whose peak sits more than 80 dB above the noise threshold has its whole row lifted
+    by _amp_to_db's floor (spectralgate/utils.py:16): digital silence next to loud noise, with a
+    very quiet noise clip.  Exercises the floor pre-pass of the fused path."""
+    rng = np.random.default_rng(77)
+    n = 60000
+    y = np.zeros(n)
+    y[n // 2:] = 0.5 * rng.standard_normal(n // 2)
+    y = y.astype(np.float32).astype(np.float64)
+    y_noise = (1e-7 * rng.standard_normal(20000)).astype(np.float32).astype(np.float64)
+    kw = dict(stationary=True, y_noise=y_noise, prop_decrease=prop, chunk_size=25000, padding=4000)
+    want = O.reduce_noise_S(y, 48000, **kw)
+    got = nr.reduce_noise(y=y, sr=48000, **kw)
+    assert O.rel_err(got, want) < TOL
+    # the same input with the floor out of reach (loud noise clip) for contrast
+    y_noise2 = (0.3 * rng.standard_normal(20000)).astype(np.float32).astype(np.float64)
+    kw["y_noise"] = y_noise2
+    assert O.rel_err(nr.reduce_noise(y=y, sr=48000, **kw), O.reduce_noise_S(y, 48000, **kw)) < TOL
+
+
+def test_silence_and_constant_inputs(nr):
+    """Degenerate inputs: all-zero signal (every dB equals the threshold) and a short burst."""
+    z = np.zeros(30000)
+    out = nr.reduce_noise(y=z, sr=48000, stationary=True)
+    assert np.all(out == 0)
+    out = nr.reduce_noise(y=z, sr=48000, stationary=False)
+    assert out.shape == z.shape
