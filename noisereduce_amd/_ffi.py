@@ -19,8 +19,9 @@ LIB_PATH = os.path.join(_HERE, "libmi355gate.so")
 SG_F32, SG_F64, SG_I16, SG_I32 = 0, 1, 2, 3
 SG_VARIANT_S, SG_VARIANT_T = 0, 1
 SG_E_INVALID, SG_E_UNSUPPORTED, SG_E_HIP, SG_E_NOMEM, SG_E_STATE = -1, -2, -3, -4, -5
-SG_N_STAGES = 14
+SG_N_STAGES = 15
 SG_OPT_FORCE_UNFUSED = 1
+SG_OPT_FORCE_NOFAST = 2
 
 _TORCH_DTYPES = {torch.float32: SG_F32, torch.float64: SG_F64, torch.int16: SG_I16,
                  torch.int32: SG_I32}

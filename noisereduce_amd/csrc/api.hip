@@ -48,12 +48,17 @@ struct sg_handle {
   // workspace
   DevBuf P, pmax, thr_rows, raw, M, seg, yn;
   DevBuf bits, K16, umax, need, T2;  // fused stationary path
+  DevBuf part;                       // partial reductions of the column statistics
+  DevBuf tw512, invn;                // fast path tables (n_fft = 1024, hop = 256)
+  bool fast_ok = false;              // default geometry: fused apply kernel available
+  bool force_nofast = false;
   int64_t ktot = 1;                  // (nf+1)^2 (nt+1)^2: integer weight total of the smoothing filter
   bool fused_ok = false;
   double sum_abs_w = 0.0;
   int64_t dbg_units = 0, dbg_T = 0;
   bool dbg_has_P = false;
   bool dbg_fused = false;
+  bool dbg_fast = false;
   bool force_unfused = false;  // sg_set_option(SG_OPT_FORCE_UNFUSED): materialised v1 path
   // per-kernel timing with HIP events on the launch stream (sg_profile_*)
   bool prof_on = false;
@@ -373,6 +378,22 @@ extern "C" int sg_create(const sg_params* p, const double* window_host, sg_handl
     if (!rc) rc = upload(h, h->kf, kf.data(), kf.size() * sizeof(float));
     if (!rc) rc = upload(h, h->kt, kt.data(), kt.size() * sizeof(float));
   }
+  if (!rc && n == 1024 && W == 1024 && h->H == 256) {
+    std::vector<cx<float>> t512(512);
+    for (int j = 0; j < 512; ++j) {
+      long double a = -2.0L * 3.14159265358979323846264338327950288L * (long double)j / 512.0L;
+      t512[j] = {(float)cosl(a), (float)sinl(a)};
+    }
+    std::vector<float> invn(256);
+    for (int s2 = 0; s2 < 256; ++s2) {
+      double acc = 0.0;
+      for (int q = 0; q < 4; ++q) acc += wfull[256 * q + s2] * wfull[256 * q + s2];
+      invn[s2] = (float)(acc > 1e-10 ? 1.0 / acc : 1.0);
+    }
+    rc = upload(h, h->tw512, t512.data(), t512.size() * sizeof(cx<float>));
+    if (!rc) rc = upload(h, h->invn, invn.data(), invn.size() * sizeof(float));
+    h->fast_ok = true;
+  }
   if (!rc) rc = ensure(h, h->thresh, (size_t)h->FS * sizeof(double));
   if (rc) {
     g_create_error = h->err;
@@ -390,7 +411,7 @@ extern "C" int sg_destroy(sg_handle* h) {
   for (auto e : h->prof_pool) (void)hipEventDestroy(e);
   for (DevBuf* b : {&h->tw64, &h->tw32, &h->wfull64, &h->wa32, &h->ws32, &h->wsq32, &h->kf, &h->kt, &h->thresh,
                     &h->P, &h->pmax, &h->thr_rows, &h->raw, &h->M, &h->seg, &h->yn, &h->bits, &h->K16, &h->umax,
-                    &h->need, &h->T2})
+                    &h->need, &h->T2, &h->part, &h->tw512, &h->invn})
     free_buf(*b);
   delete h;
   return SG_OK;
@@ -440,6 +461,14 @@ static int ensure_ws(sg_handle* h, const Geom& g, int64_t ub) {
 // ------------------------------------------------------------------------------------------
 // pipeline pieces (all enqueue on `st`)
 // ------------------------------------------------------------------------------------------
+// time slices for the column statistics: enough blocks to fill 256 CUs even for one unit
+static int stat_slices(const Geom& g, int64_t ub) {
+  int64_t blocks = (int64_t)((g.F + 63) / 64) * ub;
+  int64_t nts = (2048 + blocks - 1) / blocks;
+  nts = std::max<int64_t>(1, std::min<int64_t>(nts, std::min<int64_t>(64, std::max<int64_t>(1, g.T / 16))));
+  return (int)nts;
+}
+
 // power field + column max of a batch of units
 static int stage_power(sg_handle* h, const View& v, const Geom& g, int64_t ub, hipStream_t st) {
   {
@@ -448,18 +477,30 @@ static int stage_power(sg_handle* h, const View& v, const Geom& g, int64_t ub, h
                                   1.0, st));
   }
   ProfScope ps(h, SG_STAGE_COLMAX, st);
-  dim3 grid((g.F + 63) / 64, (unsigned)ub);
-  hipLaunchKernelGGL(k_colmax, grid, dim3(64 * STAT_TG), 0, st, (const double*)h->P.p, g, (double*)h->pmax.p);
+  const int nts = stat_slices(g, ub);
+  int rc = ensure(h, h->part, (size_t)ub * nts * 2 * g.FS * 8);
+  if (rc) return rc;
+  dim3 grid((g.F + 63) / 64, (unsigned)ub, nts);
+  hipLaunchKernelGGL(k_colmax, grid, dim3(64 * STAT_TG), 0, st, (const double*)h->P.p, g, (double*)h->part.p);
+  HIPCHK(h, hipGetLastError());
+  hipLaunchKernelGGL(k_colmax_final, dim3(grid_1d(ub * g.FS, 256)), dim3(256), 0, st, (const double*)h->part.p, g,
+                     nts, (double*)h->pmax.p, ub);
   HIPCHK(h, hipGetLastError());
   return SG_OK;
 }
 
 static int stage_colstats(sg_handle* h, const Geom& g, int64_t ub, double* thresh_out, hipStream_t st) {
   ProfScope ps(h, SG_STAGE_COLSTATS, st);
-  dim3 grid((g.F + 63) / 64, (unsigned)ub);
+  const int nts = stat_slices(g, ub);
+  int rc = ensure(h, h->part, (size_t)ub * nts * 2 * g.FS * 8);
+  if (rc) return rc;
+  dim3 grid((g.F + 63) / 64, (unsigned)ub, nts);
   hipLaunchKernelGGL(k_colstats, grid, dim3(64 * STAT_TG), 0, st, (const double*)h->P.p, g,
-                     (const double*)h->pmax.p, h->mag_scale, h->p.top_db, h->p.n_std_thresh, h->p.ddof,
-                     thresh_out);
+                     (const double*)h->pmax.p, h->mag_scale, h->p.top_db, (double*)h->part.p);
+  HIPCHK(h, hipGetLastError());
+  hipLaunchKernelGGL(k_colstats_final, dim3(grid_1d(ub * g.FS, 256)), dim3(256), 0, st,
+                     (const double*)h->part.p, g, nts, (const double*)h->pmax.p, h->mag_scale,
+                     h->p.n_std_thresh, h->p.ddof, thresh_out, ub);
   HIPCHK(h, hipGetLastError());
   return SG_OK;
 }
@@ -537,7 +578,7 @@ static int stage_apply_ola(sg_handle* h, const View& v, const Geom& g, int64_t u
 }
 
 // Fused stationary mask (variant S): STFT(f64) -> bits -> integer smoothing -> K16 -> float mask.
-static int stage_fused_mask(sg_handle* h, const View& v, const Geom& g, int64_t ub, hipStream_t st) {
+static int stage_fused_mask(sg_handle* h, const View& v, const Geom& g, int64_t ub, bool fast, hipStream_t st) {
   const int wpr = (g.F + 63) / 64;
   int rc;
   if ((rc = ensure(h, h->bits, (size_t)ub * g.T * wpr * 8))) return rc;
@@ -582,23 +623,53 @@ static int stage_fused_mask(sg_handle* h, const View& v, const Geom& g, int64_t 
         HIPCHK(h, hipFuncSetAttribute(reinterpret_cast<const void*>(kern),
                                       hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
       hipLaunchKernelGGL(kern, grid, dim3(256), lds, st, (const unsigned long long*)h->bits.p, g, wpr, nf, nt,
-                         (unsigned short*)h->K16.p);
+                         (unsigned short*)h->K16.p, fast ? 1 : 0);
     } else {
       auto kern = k_smooth_bits<uint16_t>;
       if (lds > 65536)
         HIPCHK(h, hipFuncSetAttribute(reinterpret_cast<const void*>(kern),
                                       hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
       hipLaunchKernelGGL(kern, grid, dim3(256), lds, st, (const unsigned long long*)h->bits.p, g, wpr, nf, nt,
-                         (unsigned short*)h->K16.p);
+                         (unsigned short*)h->K16.p, fast ? 1 : 0);
     }
   } else {
     hipLaunchKernelGGL(k_bits_to_k16, dim3(grid_1d(cells, 256)), dim3(256), 0, st,
-                       (const unsigned long long*)h->bits.p, g, wpr, (unsigned short*)h->K16.p, ub);
+                       (const unsigned long long*)h->bits.p, g, wpr, (unsigned short*)h->K16.p, ub, fast ? 1 : 0);
   }
   HIPCHK(h, hipGetLastError());
+  if (fast) return SG_OK;  // the fused apply kernel reads K directly
   hipLaunchKernelGGL(k_k16_to_mask, dim3(grid_1d(cells, 256)), dim3(256), 0, st, (const unsigned short*)h->K16.p,
                      g, nf, nt, 1.0f / (float)h->ktot, (float)h->p.prop_decrease, 1, h->p.smooth_mask ? 1 : 0,
                      (float*)h->M.p, ub);
+  HIPCHK(h, hipGetLastError());
+  return SG_OK;
+}
+
+// Fused apply (default geometry): FFT -> mask(K) -> IFFT -> overlap-add -> output, one kernel.
+static int stage_apply_fast(sg_handle* h, const View& v, const Geom& g, int64_t ub, const OutMap& om,
+                            hipStream_t st) {
+  ProfScope ps(h, SG_STAGE_APPLY_FAST, st);
+  constexpr int WAVES = 4;
+  fast::ApplyArgs A;
+  A.view = v; A.g = g; A.om = om;
+  A.K = (const unsigned short*)h->K16.p;
+  A.win = (const float*)h->wa32.p;
+  A.wsq = (const float*)h->wsq32.p;
+  A.invn = (const float*)h->invn.p;
+  A.tw512 = (const fast::cf*)h->tw512.p;
+  A.tw1024 = (const fast::cf*)h->tw32.p;
+  A.kscale = (float)(1.0 / ((double)h->ktot * 512.0));
+  A.h_begin = (om.p0 + g.padL) / 256;
+  A.h_end = (om.p1 - 1 + g.padL) / 256 + 1;
+  const int64_t nh = A.h_end - A.h_begin;
+  if (nh <= 0) return SG_OK;
+  constexpr int NH = 4 * WAVES - 3;
+  size_t lds = (size_t)(fast::FN + WAVES * fast::WAVE_CX) * sizeof(fast::cf);
+  auto kern = fast::k_apply_fast<WAVES>;
+  HIPCHK(h, hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize,
+                                (int)lds));
+  dim3 grid((unsigned)((nh + NH - 1) / NH), (unsigned)ub);
+  hipLaunchKernelGGL(kern, grid, dim3(WAVES * 64), lds, st, A);
   HIPCHK(h, hipGetLastError());
   return SG_OK;
 }
@@ -617,8 +688,16 @@ static int run_S(sg_handle* h, View v, int64_t total_units, const OutMap& om, hi
     int64_t nb = std::min(ub, total_units - u0);
     v.unit0 = u0;
     const bool fused = h->fused_ok && !h->force_unfused;
+    const bool fast = fused && h->fast_ok && !h->force_nofast && h->p.prop_decrease == 1.0;
+    if (fast) {
+      if ((rc = stage_fused_mask(h, v, g, nb, true, st))) return rc;
+      if ((rc = stage_apply_fast(h, v, g, nb, om, st))) return rc;
+      h->dbg_units = nb; h->dbg_T = g.T; h->dbg_has_P = false; h->dbg_fused = true; h->dbg_fast = true;
+      continue;
+    }
+    h->dbg_fast = false;
     if (fused) {
-      if ((rc = stage_fused_mask(h, v, g, nb, st))) return rc;
+      if ((rc = stage_fused_mask(h, v, g, nb, false, st))) return rc;
     } else {
       if (h->p.stationary) {
         if ((rc = stage_power(h, v, g, nb, st))) return rc;
@@ -842,6 +921,7 @@ extern "C" int sg_set_option(sg_handle* h, int32_t option, int64_t value) {
   if (!h) return SG_E_INVALID;
   switch (option) {
     case SG_OPT_FORCE_UNFUSED: h->force_unfused = value != 0; return SG_OK;
+    case SG_OPT_FORCE_NOFAST: h->force_nofast = value != 0; return SG_OK;
   }
   FAIL(h, SG_E_INVALID, "sg_set_option: unknown option %d", option);
 }
@@ -878,7 +958,8 @@ extern "C" const char* sg_stage_name(int32_t stage) {
                                            "k_decide", "k_stft<float> (magnitude)", "nonstat mask (iir/boxcar)",
                                            "k_smooth_f+k_smooth_t", "k_apply_istft", "k_ola",
                                            "noise statistics (all kernels)", "k_unit_absmax+k_prep_thresh",
-                                           "k_stft_bits<max> (floor pre-pass)", "k_stft_bits<decide>"};
+                                           "k_stft_bits<max> (floor pre-pass)", "k_stft_bits<decide>",
+                                           "k_apply_fast (fft+mask+ifft+ola)"};
   return (stage >= 0 && stage < SG_N_STAGES) ? names[stage] : "?";
 }
 
@@ -901,7 +982,9 @@ extern "C" int sg_debug_fetch(sg_handle* h, int32_t what, void* host, int64_t by
     case 3:
       if (!h->dbg_fused) FAIL(h, SG_E_STATE, "bit field only exists on the fused path");
       src = h->bits.p; need = (size_t)h->dbg_units * h->dbg_T * ((h->F + 63) / 64) * 8; break;
-    case 1: src = h->M.p; need = cells * 4; break;
+    case 1:
+      if (h->dbg_fast) FAIL(h, SG_E_STATE, "fast path keeps the smoothed mask as permuted uint16 counts");
+      src = h->M.p; need = cells * 4; break;
     case 2:
       if (!h->dbg_has_P) FAIL(h, SG_E_STATE, "power field only exists for stationary gates");
       src = h->P.p; need = cells * 8; break;

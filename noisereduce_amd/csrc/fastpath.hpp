@@ -1,0 +1,392 @@
+// Fast path for the default STFT geometry (n_fft = win_length = 1024, hop = 256), float32.
+//
+// FFT core: one wavefront transforms FOUR frames at once.  A 1024-sample real frame is packed
+// as 512 complex points z[m] = x[2m] + i x[2m+1]; lane (g, c) = (lane >> 4, lane & 15) holds the 32
+// points z[c + 16 r], r = 0..31, of frame g in registers.  512 = 32 x 16:
+//
+//   forward:  DFT32 over r (registers)  ->  twiddle w512^(c k1)  ->  ONE exchange through LDS
+//             ->  DFT16 over c (registers)   =>  lane c' holds rows k1 = c' and k1 = 32 - c'
+//             (lane 0: rows 0 and 16) of Zc[k1 + 32 k2], k2 = 0..15.
+//   inverse:  the mirror image (DFT16 over k2 -> exchange -> twiddle -> DFT32 over k1).
+//
+// Rows are dealt so that the two bins k and 512-k that the real-FFT split/merge couples
+// always sit in the SAME lane: the mask multiply needs no cross-lane traffic and no LDS.
+// The exchange layout is XOR-swizzled (16-byte chunk index ^ ((row >> 1) & 7)) and odd frames
+// are skewed by 128 B so that every ds_write_b64 / ds_read_b128 is bank-conflict free.
+#pragma once
+#include "kernels.hpp"
+
+namespace sg {
+namespace fast {
+
+constexpr int FN = 512;           // complex points per frame
+constexpr int FPITCH = FN + 16;    // LDS complex slots per frame slice: 512 + a 128-byte skew
+constexpr int WAVE_CX = 4 * FPITCH;  // LDS complex slots per wave
+constexpr int FSK = 528;          // mask row pitch (entries) of the permuted K layout
+
+typedef cx<float> cf;
+
+// cos(2 pi k / 32), k = 0..8
+__device__ constexpr float C32[9] = {1.0f,
+                                     0.98078528040323044913f,
+                                     0.92387953251128675613f,
+                                     0.83146961230254523708f,
+                                     0.70710678118654752440f,
+                                     0.55557023301960222474f,
+                                     0.38268343236508977173f,
+                                     0.19509032201612826785f,
+                                     0.0f};
+
+// w_R^k = exp(-2 pi i k / R) for R in {8, 16, 32}, 0 <= k < R/2  (compile-time after unrolling)
+template <int R>
+__device__ __forceinline__ constexpr float twc(int k) {
+  int j = k * (32 / R);  // index in 32nds of a turn, 0..15
+  return j <= 8 ? C32[j] : -C32[16 - j];
+}
+template <int R>
+__device__ __forceinline__ constexpr float tws(int k) {  // sin(2 pi k / R) >= 0 for k < R/2
+  int j = k * (32 / R);
+  return j <= 8 ? C32[8 - j] : C32[j - 8];
+}
+
+template <bool INV>
+__device__ __forceinline__ cf mul_tw(cf a, float c, float s) {
+  // a * (c - i s) forward, a * (c + i s) inverse
+  if (INV) return {a.x * c - a.y * s, a.y * c + a.x * s};
+  return {a.x * c + a.y * s, a.y * c - a.x * s};
+}
+
+// In-register DFT of R points, natural order in and out (decimation in time).
+template <int R, bool INV>
+__device__ __forceinline__ void dft_reg(cf* v) {
+  if constexpr (R == 2) {
+    cf a = v[0], b = v[1];
+    v[0] = cadd(a, b);
+    v[1] = csub(a, b);
+  } else if constexpr (R == 4) {
+    dft4<INV>(v);
+  } else {
+    cf e[R / 2], o[R / 2];
+#pragma unroll
+    for (int k = 0; k < R / 2; ++k) {
+      e[k] = v[2 * k];
+      o[k] = v[2 * k + 1];
+    }
+    dft_reg<R / 2, INV>(e);
+    dft_reg<R / 2, INV>(o);
+#pragma unroll
+    for (int k = 0; k < R / 2; ++k) {
+      cf t;
+      if (k == 0) t = o[k];
+      else if (k == R / 4) t = rot90<INV>(o[k]);
+      else t = mul_tw<INV>(o[k], twc<R>(k), tws<R>(k));
+      v[k] = cadd(e[k], t);
+      v[k + R / 2] = csub(e[k], t);
+    }
+  }
+}
+
+__device__ __forceinline__ void wave_lds_sync() {
+  // LDS operations of one wavefront execute in order; this only pins the compiler.
+  __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+  __builtin_amdgcn_wave_barrier();
+  __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+}
+
+// LDS complex-slot offset of frame g inside a wave's region: a pitch of 512+16 slots shifts odd
+// frames by 128 B relative to the 256-byte bank row (conflict-free 32-lane b64 column reads).
+__device__ __forceinline__ int frame_base(int g) { return g * FPITCH; }
+
+// the two rows of Zc[k1 + 32 k2] owned by lane c
+__device__ __forceinline__ int row1(int c) { return c; }
+__device__ __forceinline__ int row2(int c) { return c == 0 ? 16 : 32 - c; }
+
+// exchange, "column" side: element (row k1, column c) for all 32 rows, one b64 access each
+__device__ __forceinline__ void xchg_write_cols(cf* fb, int c, const cf* A) {
+#pragma unroll
+  for (int k1 = 0; k1 < 32; ++k1) fb[k1 * 16 + (c ^ (2 * ((k1 >> 1) & 7)))] = A[k1];
+}
+__device__ __forceinline__ void xchg_read_cols(const cf* fb, int c, cf* A) {
+#pragma unroll
+  for (int k1 = 0; k1 < 32; ++k1) A[k1] = fb[k1 * 16 + (c ^ (2 * ((k1 >> 1) & 7)))];
+}
+// exchange, "row" side: one whole row (16 columns) as eight b128 accesses
+__device__ __forceinline__ void xchg_read_row(const cf* fb, int row, cf* B) {
+  const int s = (row >> 1) & 7;
+#pragma unroll
+  for (int h = 0; h < 8; ++h) {
+    float4 q = *reinterpret_cast<const float4*>(&fb[row * 16 + ((h ^ s) << 1)]);
+    B[2 * h] = {q.x, q.y};
+    B[2 * h + 1] = {q.z, q.w};
+  }
+}
+__device__ __forceinline__ void xchg_write_row(cf* fb, int row, const cf* B) {
+  const int s = (row >> 1) & 7;
+#pragma unroll
+  for (int h = 0; h < 8; ++h)
+    *reinterpret_cast<float4*>(&fb[row * 16 + ((h ^ s) << 1)]) =
+        make_float4(B[2 * h].x, B[2 * h].y, B[2 * h + 1].x, B[2 * h + 1].y);
+}
+
+// Forward: v[r] = z[c + 16 r]  ->  v[k2] = Zc[row1 + 32 k2], v[16 + k2] = Zc[row2 + 32 k2].
+// fb: this frame's LDS slice; tw512: LDS table w_512^j, j < 512.
+__device__ __forceinline__ void fft512_fwd(cf* v, cf* fb, const cf* tw512, int c) {
+  dft_reg<32, false>(v);
+#pragma unroll
+  for (int k1 = 1; k1 < 32; ++k1) v[k1] = cmul(v[k1], tw512[k1 * c]);
+  xchg_write_cols(fb, c, v);
+  wave_lds_sync();
+  xchg_read_row(fb, row1(c), v);
+  xchg_read_row(fb, row2(c), v + 16);
+  wave_lds_sync();
+  dft_reg<16, false>(v);
+  dft_reg<16, false>(v + 16);
+}
+
+// Inverse (unnormalised): v[k2], v[16 + k2] as above  ->  v[r] = 512 * z[c + 16 r].
+__device__ __forceinline__ void fft512_inv(cf* v, cf* fb, const cf* tw512, int c) {
+  dft_reg<16, true>(v);
+  dft_reg<16, true>(v + 16);
+  xchg_write_row(fb, row1(c), v);
+  xchg_write_row(fb, row2(c), v + 16);
+  wave_lds_sync();
+  xchg_read_cols(fb, c, v);
+  wave_lds_sync();
+#pragma unroll
+  for (int k1 = 1; k1 < 32; ++k1) {
+    cf w = tw512[k1 * c];
+    w.y = -w.y;
+    v[k1] = cmul(v[k1], w);
+  }
+  dft_reg<32, true>(v);
+}
+
+// One conjugate pair of the real-FFT split -> mask -> merge (see k_apply_istft in kernels.hpp):
+// a = Zc[k], b = Zc[N-k], w = w_1024^k, mk / mn = mask of bin k / N-k.  Returns Zc'[k], Zc'[N-k].
+__device__ __forceinline__ void pair_mask(cf& a, cf& b, cf w, float mk, float mn) {
+  cf E = {(a.x + b.x) * 0.5f, (a.y - b.y) * 0.5f};
+  cf O = {(a.y + b.y) * 0.5f, (b.x - a.x) * 0.5f};
+  cf wO = cmul(w, O);
+  cf Yk = {(E.x + wO.x) * mk, (E.y + wO.y) * mk};
+  cf Yn = {(E.x - wO.x) * mn, (wO.y - E.y) * mn};
+  cf Ep = {(Yk.x + Yn.x) * 0.5f, (Yk.y - Yn.y) * 0.5f};
+  cf D = {(Yk.x - Yn.x) * 0.5f, (Yk.y + Yn.y) * 0.5f};
+  cf Op = cmul(D, cf{w.x, -w.y});
+  a = {Ep.x - Op.y, Ep.y + Op.x};
+  b = {Ep.x + Op.y, Op.x - Ep.y};
+}
+
+// Position of bin f in the permuted mask row: lane c owns 32 consecutive entries,
+// [0,16): row1(c) bins c + 32 k2 ; [16,32): row2(c) bins row2 + 32 k2 ; entry 512 = bin 512.
+__host__ __device__ inline int perm_pos(int f) {
+  if (f >= 512) return 512;
+  int rho = f & 31, k2 = f >> 5;
+  if (rho <= 15) return rho * 32 + k2;
+  if (rho == 16) return 16 + k2;
+  return (32 - rho) * 32 + 16 + k2;
+}
+__host__ __device__ inline int perm_inv(int pos) {
+  if (pos >= 512) return 512;
+  int lane = pos >> 5, slot = pos & 31;
+  if (slot < 16) return lane + 32 * slot;
+  int rho = lane == 0 ? 16 : 32 - lane;
+  return rho + 32 * (slot - 16);
+}
+
+struct ApplyArgs {
+  View view;
+  Geom g;
+  OutMap om;
+  const unsigned short* K;  // permuted mask counts [units][T][FSK]
+  const float* win;         // analysis == synthesis window (1024)
+  const float* wsq;         // window squared (1024)
+  const float* invn;        // 1 / sum_q wsq[256 q + s], s < 256 (interior hops)
+  const cf* tw512;          // w_512^j (512)
+  const cf* tw1024;         // w_1024^j (512)
+  float kscale;             // prop_decrease-free mask scale: 1 / (ktot * 512)
+  int64_t h_begin;          // first ext hop (256-sample block, ext = unit sample + 512) to produce
+  int64_t h_end;
+};
+
+// ---------------------------------------------------------------------------------------
+// Fused apply: frames -> FFT -> x mask -> IFFT -> window -> overlap-add -> output samples.
+// One workgroup = WAVES wavefronts = 4*WAVES consecutive frames of one unit -> 4*WAVES-3 hops.
+// ---------------------------------------------------------------------------------------
+template <int WAVES>
+__global__ __launch_bounds__(WAVES * 64) void k_apply_fast(ApplyArgs A) {
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  cf* tw512 = reinterpret_cast<cf*>(smem);
+  cf* regions = tw512 + FN;
+  constexpr int NF = 4 * WAVES;   // frames per tile
+  constexpr int NH = NF - 3;      // hops per tile
+  const int tid = threadIdx.x;
+  const int lane = tid & 63, wave = tid >> 6;
+  const int g = lane >> 4, c = lane & 15;
+  for (int i = tid; i < FN; i += WAVES * 64) tw512[i] = A.tw512[i];
+  const Geom& G = A.g;
+  const int64_t u = blockIdx.y;
+  const int64_t row = (A.view.unit0 + u) / A.view.n_chunks;
+  const int64_t chunk = (A.view.unit0 + u) % A.view.n_chunks;
+  const int64_t hs = A.h_begin + (int64_t)blockIdx.x * NH;  // first hop of this tile
+  const int64_t t = hs - 3 + 4 * wave + g;                   // this lane group's frame
+  const bool fvalid = t >= 0 && t < G.T;
+
+  // window values of this lane's 64 samples m = 2c + 32 r + e
+  float wr[32][2];
+#pragma unroll
+  for (int r = 0; r < 32; ++r) {
+    float2 w2 = *reinterpret_cast<const float2*>(&A.win[2 * c + 32 * r]);
+    wr[r][0] = w2.x;
+    wr[r][1] = w2.y;
+  }
+  // mask counts of this lane's 32 bins (+ bin 512 for lane c == 0)
+  unsigned short kk[32];
+  float k512 = 0.f;
+  {
+    const unsigned short* Krow = A.K + ((u * G.T + (fvalid ? t : 0)) * (int64_t)FSK);
+    const uint4* p4 = reinterpret_cast<const uint4*>(Krow + c * 32);
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+      uint4 w4 = p4[q];
+      unsigned ws[4] = {w4.x, w4.y, w4.z, w4.w};
+#pragma unroll
+      for (int j = 0; j < 4; ++j) {
+        kk[q * 8 + 2 * j] = (unsigned short)(ws[j] & 0xffffu);
+        kk[q * 8 + 2 * j + 1] = (unsigned short)(ws[j] >> 16);
+      }
+    }
+    k512 = (float)Krow[512] * A.kscale;
+  }
+  // gather window * frame
+  cf v[32];
+  {
+    const int64_t s0 = t * 256 - G.padL;  // unit-local index of frame sample 0
+    const int64_t gbase = chunk * A.view.cs - A.view.pad + s0;
+    const bool inside = fvalid && s0 >= 0 && s0 + 1024 <= A.view.Lp && gbase >= A.view.lo &&
+                        gbase + 1024 <= A.view.hi && A.view.dtype == 0;
+    if (inside) {
+      const float* src = (const float*)A.view.x + row * A.view.stride + gbase + 2 * c;
+      if ((reinterpret_cast<uintptr_t>(src) & 7) == 0) {
+#pragma unroll
+        for (int r = 0; r < 32; ++r) {
+          float2 x2 = *reinterpret_cast<const float2*>(src + 32 * r);
+          v[r].x = x2.x * wr[r][0];
+          v[r].y = x2.y * wr[r][1];
+        }
+      } else {
+#pragma unroll
+        for (int r = 0; r < 32; ++r) {
+          v[r].x = src[32 * r] * wr[r][0];
+          v[r].y = src[32 * r + 1] * wr[r][1];
+        }
+      }
+    } else {
+#pragma unroll
+      for (int r = 0; r < 32; ++r) {
+        float a = 0.f, b = 0.f;
+        if (fvalid) {
+          a = (float)view_sample(A.view, row, chunk, s0 + 2 * c + 32 * r);
+          b = (float)view_sample(A.view, row, chunk, s0 + 2 * c + 32 * r + 1);
+        }
+        v[r].x = a * wr[r][0];
+        v[r].y = b * wr[r][1];
+      }
+    }
+  }
+  cf* fb = regions + wave * WAVE_CX + frame_base(g);
+  __syncthreads();  // twiddle table staged
+  fft512_fwd(v, fb, tw512, c);
+
+  // split -> mask -> merge on conjugate pairs, all in this lane
+  {
+    const float ks = A.kscale;
+    if (c != 0) {
+      const cf wl = A.tw1024[c];  // w_1024^row1
+#pragma unroll
+      for (int k2 = 0; k2 < 16; ++k2) {
+        // bins k = c + 32 k2 (v[k2]) and 512 - k = row2 + 32 (15 - k2) (v[16 + 15 - k2])
+        cf w = k2 == 0 ? wl : mul_tw<false>(wl, twc<32>(k2), tws<32>(k2));
+        pair_mask(v[k2], v[31 - k2], w, (float)kk[k2] * ks, (float)kk[31 - k2] * ks);
+      }
+    } else {
+      // row 0: bins 32 k2; pairs (k2, 16 - k2), k2 = 1..7; specials k2 = 0 (bins 0, 512), 8 (bin 256)
+      {
+        cf a = v[0];
+        float y0 = (a.x + a.y) * ((float)kk[0] * ks);
+        float yN = (a.x - a.y) * k512;
+        v[0] = {0.5f * (y0 + yN), 0.5f * (y0 - yN)};
+        float m8 = (float)kk[8] * ks;
+        v[8] = {v[8].x * m8, v[8].y * m8};
+      }
+#pragma unroll
+      for (int k2 = 1; k2 < 8; ++k2) {
+        cf w = {twc<32>(k2), -tws<32>(k2)};  // w_1024^(32 k2) = w_32^k2
+        pair_mask(v[k2], v[16 - k2], w, (float)kk[k2] * ks, (float)kk[16 - k2] * ks);
+      }
+      // row 16: bins 16 + 32 j; pairs (j, 15 - j), j = 0..7
+      const cf w16 = A.tw1024[16];
+#pragma unroll
+      for (int j = 0; j < 8; ++j) {
+        cf w = j == 0 ? w16 : mul_tw<false>(w16, twc<32>(j), tws<32>(j));
+        pair_mask(v[16 + j], v[31 - j], w, (float)kk[16 + j] * ks, (float)kk[31 - j] * ks);
+      }
+    }
+  }
+  fft512_inv(v, fb, tw512, c);
+  // synthesis window, store the time-domain frame (natural order) into this frame's LDS slice
+#pragma unroll
+  for (int r = 0; r < 32; ++r) fb[c + 16 * r] = {v[r].x * wr[r][0], v[r].y * wr[r][1]};
+  __syncthreads();
+
+  // overlap-add: tile hop j (ext hop hs + j) = sum over tile frames i = j..j+3 of quarter j+3-i
+  const float* fr = reinterpret_cast<const float*>(regions);
+  const int s4 = (tid & 63) * 4;
+  for (int j = tid >> 6; j < NH; j += WAVES) {
+    const int64_t h = hs + j;
+    if (h >= A.h_end) break;
+    float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
+    float4 nrm = make_float4(0.f, 0.f, 0.f, 0.f);
+    bool all_valid = true;
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+      const int i = j + 3 - q;                 // tile frame contributing quarter q
+      const int64_t ti = hs - 3 + i;
+      if (ti >= 0 && ti < G.T) {
+        const int off = ((i >> 2) * WAVE_CX + frame_base(i & 3)) * 2 + 256 * q + s4;  // float index
+        float4 f4 = *reinterpret_cast<const float4*>(&fr[off]);
+        acc.x += f4.x; acc.y += f4.y; acc.z += f4.z; acc.w += f4.w;
+      } else {
+        all_valid = false;
+      }
+    }
+    if (all_valid) {
+      float4 n4 = *reinterpret_cast<const float4*>(&A.invn[s4]);
+      acc.x *= n4.x; acc.y *= n4.y; acc.z *= n4.z; acc.w *= n4.w;
+    } else {
+#pragma unroll
+      for (int q = 0; q < 4; ++q) {
+        const int64_t ti = h - q;
+        if (ti >= 0 && ti < G.T) {
+          float4 w4 = *reinterpret_cast<const float4*>(&A.wsq[256 * q + s4]);
+          nrm.x += w4.x; nrm.y += w4.y; nrm.z += w4.z; nrm.w += w4.w;
+        }
+      }
+      acc.x /= (nrm.x > 1e-10f ? nrm.x : 1.f);
+      acc.y /= (nrm.y > 1e-10f ? nrm.y : 1.f);
+      acc.z /= (nrm.z > 1e-10f ? nrm.z : 1.f);
+      acc.w /= (nrm.w > 1e-10f ? nrm.w : 1.f);
+    }
+    const float vals[4] = {acc.x, acc.y, acc.z, acc.w};
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {
+      const int64_t p = h * 256 + s4 + e - G.padL;  // unit-local output position
+      if (p < A.om.p0 || p >= A.om.p1) continue;
+      const int64_t gi = chunk * A.om.g_step + (p - A.om.p0);
+      if (gi < A.om.g_lo || gi >= A.om.g_hi) continue;
+      store_sample(A.om.out, A.om.dtype, row * A.om.stride + gi - A.om.g0, p < G.Lout ? vals[e] : 0.f);
+    }
+  }
+}
+
+}  // namespace fast
+}  // namespace sg

@@ -11,6 +11,7 @@
 // The apply kernel (k_apply_istft_k16 in this file) reads K instead of a float mask.
 #pragma once
 #include "kernels.hpp"
+#include "fastpath.hpp"
 
 namespace sg {
 
@@ -190,7 +191,8 @@ __host__ __device__ inline size_t smooth_cf_bytes(int rows, int F, int ct_size) 
 
 template <typename CT>
 __global__ __launch_bounds__(256) void k_smooth_bits(const unsigned long long* __restrict__ bits, Geom g, int wpr,
-                                                     int nf, int nt, unsigned short* __restrict__ K) {
+                                                     int nf, int nt, unsigned short* __restrict__ K,
+                                                     int perm) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
   const int rows = SM_TT + 2 * nt;     // halo rows on both sides
   const int FP = (g.F + 3) & ~3;       // LDS row pitch
@@ -225,8 +227,11 @@ __global__ __launch_bounds__(256) void k_smooth_bits(const unsigned long long* _
   __syncthreads();
   // phase 2: along t on cf.  task = (bin f, time segment)
   const int tsegs = 4, tlen = SM_TT / tsegs;
+  // tasks are ordered by OUTPUT position so that the uint16 stores of a wavefront are contiguous
+  // even in the permuted layout of the fast apply kernel (fast::perm_pos).
   for (int task = threadIdx.x; task < g.F * tsegs; task += blockDim.x) {
-    const int f = task % g.F, ts = task / g.F;
+    const int pos = task % g.F, ts = task / g.F;
+    const int f = perm ? fast::perm_inv(pos) : pos;
     const int r0 = nt + ts * tlen;  // LDS row of the first output frame of this segment
     auto at = [&](int r) -> int { return (r >= 0 && r < rows) ? (int)cf[(size_t)r * FP + f] : 0; };
     int c = 0, R = 0, L = 0;
@@ -236,7 +241,7 @@ __global__ __launch_bounds__(256) void k_smooth_bits(const unsigned long long* _
     for (int i = 0; i < tlen; ++i) {
       const int r = r0 + i;
       const int64_t t = t0 + ts * tlen + i;
-      if (t < g.T) K[(u * g.T + t) * (int64_t)g.FS + f] = (unsigned short)c;
+      if (t < g.T) K[(u * g.T + t) * (int64_t)g.FS + pos] = (unsigned short)c;
       c += R - L;
       R += at(r + nt + 2) - at(r + 1);
       L += at(r + 1) - at(r - nt);
@@ -246,12 +251,13 @@ __global__ __launch_bounds__(256) void k_smooth_bits(const unsigned long long* _
 
 // no smoothing: K = bit (ktot = 1)
 __global__ void k_bits_to_k16(const unsigned long long* __restrict__ bits, Geom g, int wpr,
-                              unsigned short* __restrict__ K, int64_t n_units) {
+                              unsigned short* __restrict__ K, int64_t n_units, int perm) {
   const int64_t cells = n_units * g.T * g.FS;
   for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < cells;
        i += (int64_t)gridDim.x * blockDim.x) {
-    const int f = (int)(i % g.FS);
-    if (f >= g.F) continue;
+    const int pos = (int)(i % g.FS);
+    if (pos >= g.F) continue;
+    const int f = perm ? fast::perm_inv(pos) : pos;
     const int64_t ut = i / g.FS;
     K[i] = (unsigned short)((bits[ut * wpr + (f >> 6)] >> (f & 63)) & 1ull);
   }

@@ -256,38 +256,56 @@ __device__ __forceinline__ double cell_db(double P, double mag_scale) {
   return 20.0 * log10(sqrt(P) * mag_scale + 2.220446049250313e-16);
 }
 
+// Time is split into gridDim.z slices (deterministic two-stage reduction: partials, then a
+// fixed-order final sum) so that a single unit (the noise clip) still fills the chip.
 __global__ __launch_bounds__(64 * STAT_TG) void k_colmax(const double* __restrict__ P, Geom g,
-                                                         double* __restrict__ pmax) {
+                                                         double* __restrict__ pmax_part) {
   __shared__ double red[STAT_TG][64];
   const int f = blockIdx.x * 64 + (threadIdx.x & 63);
   const int tg = threadIdx.x >> 6;
   const int64_t u = blockIdx.y;
+  const int ts = blockIdx.z, nts = gridDim.z;
+  const int64_t tb = g.T * ts / nts, te = g.T * (ts + 1) / nts;
   double m = 0.0;
   if (f < g.F)
-    for (int64_t t = tg; t < g.T; t += STAT_TG) m = fmax(m, P[(u * g.T + t) * g.FS + f]);
+    for (int64_t t = tb + tg; t < te; t += STAT_TG) m = fmax(m, P[(u * g.T + t) * g.FS + f]);
   red[tg][threadIdx.x & 63] = m;
   __syncthreads();
   if (tg == 0 && f < g.F) {
     for (int i = 1; i < STAT_TG; ++i) m = fmax(m, red[i][threadIdx.x & 63]);
-    pmax[u * g.FS + f] = m;
+    pmax_part[(u * nts + ts) * g.FS + f] = m;
   }
 }
 
-// thresh[u][f] = mean_t(dBfl) + n_std * std_t(dBfl), dBfl = max(dB, rowmax_dB - top_db)
-// (stationary.py:75-81; torchgate.py:158-160).
+// pmax[u][f] = max over the slices (also the input of k_decide)
+__global__ void k_colmax_final(const double* __restrict__ pmax_part, Geom g, int nts, double* __restrict__ pmax,
+                               int64_t n_units) {
+  const int64_t n = n_units * g.FS;
+  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x) {
+    const int64_t u = i / g.FS;
+    const int f = (int)(i % g.FS);
+    double m = 0.0;
+    if (f < g.F)
+      for (int ts = 0; ts < nts; ++ts) m = fmax(m, pmax_part[(u * nts + ts) * g.FS + f]);
+    pmax[i] = m;
+  }
+}
+
+// partial sums of dBfl - rowmax_dB and its square, dBfl = max(dB, rowmax_dB - top_db)
 __global__ __launch_bounds__(64 * STAT_TG) void k_colstats(const double* __restrict__ P, Geom g,
                                                            const double* __restrict__ pmax, double mag_scale,
-                                                           double top_db, double n_std, int ddof,
-                                                           double* __restrict__ thresh) {
+                                                           double top_db, double* __restrict__ s_part) {
   __shared__ double r1[STAT_TG][64], r2[STAT_TG][64];
   const int l = threadIdx.x & 63;
   const int f = blockIdx.x * 64 + l;
   const int tg = threadIdx.x >> 6;
   const int64_t u = blockIdx.y;
-  double s1 = 0.0, s2 = 0.0, mdb = 0.0;
+  const int ts = blockIdx.z, nts = gridDim.z;
+  const int64_t tb = g.T * ts / nts, te = g.T * (ts + 1) / nts;
+  double s1 = 0.0, s2 = 0.0;
   if (f < g.F) {
-    mdb = cell_db(pmax[u * g.FS + f], mag_scale);
-    for (int64_t t = tg; t < g.T; t += STAT_TG) {
+    const double mdb = cell_db(pmax[u * g.FS + f], mag_scale);
+    for (int64_t t = tb + tg; t < te; t += STAT_TG) {
       double d = cell_db(P[(u * g.T + t) * g.FS + f], mag_scale) - mdb;  // <= 0
       d = fmax(d, -top_db);
       s1 += d;
@@ -302,11 +320,30 @@ __global__ __launch_bounds__(64 * STAT_TG) void k_colstats(const double* __restr
       s1 += r1[i][l];
       s2 += r2[i][l];
     }
-    double Tn = (double)g.T;
-    double mean_d = s1 / Tn;
+    s_part[((u * nts + ts) * 2 + 0) * g.FS + f] = s1;
+    s_part[((u * nts + ts) * 2 + 1) * g.FS + f] = s2;
+  }
+}
+
+// thresh[u][f] = mean_t(dBfl) + n_std * std_t(dBfl)   (stationary.py:75-81; torchgate.py:158-160)
+__global__ void k_colstats_final(const double* __restrict__ s_part, Geom g, int nts,
+                                 const double* __restrict__ pmax, double mag_scale, double n_std, int ddof,
+                                 double* __restrict__ thresh, int64_t n_units) {
+  const int64_t n = n_units * g.FS;
+  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x) {
+    const int64_t u = i / g.FS;
+    const int f = (int)(i % g.FS);
+    if (f >= g.F) continue;
+    double s1 = 0.0, s2 = 0.0;
+    for (int ts = 0; ts < nts; ++ts) {
+      s1 += s_part[((u * nts + ts) * 2 + 0) * g.FS + f];
+      s2 += s_part[((u * nts + ts) * 2 + 1) * g.FS + f];
+    }
+    const double Tn = (double)g.T;
+    const double mean_d = s1 / Tn;
     double var = (s2 - s1 * s1 / Tn) / (Tn - (double)ddof);
     if (var < 0.0) var = 0.0;
-    thresh[u * g.FS + f] = (mdb + mean_d) + sqrt(var) * n_std;
+    thresh[i] = (cell_db(pmax[i], mag_scale) + mean_d) + sqrt(var) * n_std;
   }
 }
 

@@ -74,8 +74,15 @@ def test_stage_taps(nr, golden_dir):
     assert raw.shape == tuple(g["raw_shape"])
     ref_raw = np.unpackbits(g["raw_bits"], axis=1)[:, :raw.shape[1]].astype(bool)
     assert np.count_nonzero(raw != ref_raw) == 0, "mask flips vs the reference"
-    M = sg._gate.debug_field(1)[0].T
+    from noisereduce_amd import _ffi
+    try:  # the smoothed mask as floats only exists on the general apply path
+        sg._gate.set_option(_ffi.SG_OPT_FORCE_NOFAST, 1)
+        out2 = sg.get_traces()
+        M = sg._gate.debug_field(1)[0].T
+    finally:
+        sg._gate.set_option(_ffi.SG_OPT_FORCE_NOFAST, 0)
     assert np.max(np.abs(M[[0, 3, 100, 511, 512], :] - g["smooth_rows"])) < 1e-5
+    assert O.rel_err(out2, g["out"]) < TOL
 
 
 def test_fish_wav_config0(nr, golden_dir):
@@ -179,16 +186,20 @@ def test_unfused_path_still_matches(nr, golden_dir):
               hop_length=None, time_constant_s=2.0, freq_mask_smooth_hz=500, time_mask_smooth_ms=50,
               tmp_folder=None, use_tqdm=False, n_jobs=1)
     sg = SpectralGateStationary(y=y, **kw)
-    fused = sg.get_traces()
+    fast = sg.get_traces()
     try:
+        sg._gate.set_option(_ffi.SG_OPT_FORCE_NOFAST, 1)
+        fused = sg.get_traces()
         sg._gate.set_option(_ffi.SG_OPT_FORCE_UNFUSED, 1)
         unfused = sg.get_traces()
         raw = sg._gate.debug_field(0)
     finally:
         sg._gate.set_option(_ffi.SG_OPT_FORCE_UNFUSED, 0)
+        sg._gate.set_option(_ffi.SG_OPT_FORCE_NOFAST, 0)
     assert raw.dtype == np.float32
-    assert O.rel_err(fused, g["out"]) < TOL and O.rel_err(unfused, g["out"]) < TOL
-    assert O.rel_err(fused, unfused) < 1e-6
+    for o in (fast, fused, unfused):
+        assert O.rel_err(o, g["out"]) < TOL
+    assert O.rel_err(fused, unfused) < 1e-6 and O.rel_err(fast, unfused) < 1e-5
 
 
 @pytest.mark.parametrize("prop", [1.0, 0.7])
