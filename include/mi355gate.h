@@ -158,6 +158,7 @@ int sg_debug_fetch(sg_handle* h, int32_t what, void* host, int64_t bytes, void* 
 
 /* ---- options ------------------------------------------------------------------------- */
 #define SG_OPT_FORCE_UNFUSED 1 /* value != 0: use the materialised (v1) kernels everywhere */
+#define SG_OPT_FORCE_F64_DECIDE 3 /* value != 0: decide every mask cell from a float64 STFT */
 #define SG_OPT_FORCE_NOFAST 2  /* value != 0: keep the bit-mask stages but use the general apply kernels */
 int sg_set_option(sg_handle* h, int32_t option, int64_t value);
 
@@ -177,7 +178,8 @@ int sg_set_option(sg_handle* h, int32_t option, int64_t value);
 #define SG_STAGE_STFT_MAX 12
 #define SG_STAGE_STFT_BITS 13
 #define SG_STAGE_APPLY_FAST 14
-#define SG_N_STAGES 15
+#define SG_STAGE_DECIDE_FAST 15
+#define SG_N_STAGES 16
 /* When enabled, every kernel launch is bracketed by a hipEvent pair recorded on the launch
  * stream.  sg_profile_read synchronises those events and returns accumulated milliseconds
  * and launch counts per stage (arrays of SG_N_STAGES); reset != 0 clears the accumulators. */

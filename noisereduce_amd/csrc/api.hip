@@ -52,6 +52,7 @@ struct sg_handle {
   DevBuf tw512, invn;                // fast path tables (n_fft = 1024, hop = 256)
   bool fast_ok = false;              // default geometry: fused apply kernel available
   bool force_nofast = false;
+  bool force_f64_decide = false;     // SG_OPT_FORCE_F64_DECIDE: float64 STFT for every mask decision
   int64_t ktot = 1;                  // (nf+1)^2 (nt+1)^2: integer weight total of the smoothing filter
   bool fused_ok = false;
   double sum_abs_w = 0.0;
@@ -604,7 +605,32 @@ static int stage_fused_mask(sg_handle* h, const View& v, const Geom& g, int64_t 
     HIPCHK(h, launch_bits<0>(h->N, v, g, ub, h->tw64.p, h->wfull64.p, tc, h->mag_scale, h->p.top_db,
                              (unsigned long long*)h->pmax.p, (unsigned long long*)h->bits.p, wpr, st));
   }
-  {
+  if (fast && !h->force_f64_decide) {
+    ProfScope ps(h, SG_STAGE_DECIDE_FAST, st);
+    constexpr int WAVES = 4;
+    fast::DecideArgs D;
+    D.view = v; D.g = g;
+    D.win = (const float*)h->wa32.p;
+    D.win64 = (const double*)h->wfull64.p;
+    D.tw512 = (const fast::cf*)h->tw512.p;
+    D.tw1024 = (const fast::cf*)h->tw32.p;
+    D.tw64 = (const cx<double>*)h->tw64.p;
+    D.tc = tc;
+    D.mag_scale = h->mag_scale; D.top_db = h->p.top_db;
+    D.bits = (unsigned long long*)h->bits.p;
+    D.wpr = wpr;
+    D.t_begin = 0; D.t_end = g.T;
+    D.quads_per_wave = 1;
+    const int64_t quads = (D.t_end - D.t_begin + 3) / 4;
+    const int64_t per_block = (int64_t)WAVES * D.quads_per_wave;
+    size_t lds = (size_t)(fast::FN + WAVES * fast::WAVE_CX) * sizeof(fast::cf) + 528 * sizeof(float);
+    auto kern = fast::k_decide_fast<WAVES>;
+    HIPCHK(h, hipFuncSetAttribute(reinterpret_cast<const void*>(kern),
+                                  hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+    dim3 grid((unsigned)((quads + per_block - 1) / per_block), (unsigned)ub);
+    hipLaunchKernelGGL(kern, grid, dim3(WAVES * 64), lds, st, D);
+    HIPCHK(h, hipGetLastError());
+  } else {
     ProfScope ps(h, SG_STAGE_STFT_BITS, st);
     HIPCHK(h, launch_bits<1>(h->N, v, g, ub, h->tw64.p, h->wfull64.p, tc, h->mag_scale, h->p.top_db,
                              (unsigned long long*)h->pmax.p, (unsigned long long*)h->bits.p, wpr, st));
@@ -922,6 +948,7 @@ extern "C" int sg_set_option(sg_handle* h, int32_t option, int64_t value) {
   switch (option) {
     case SG_OPT_FORCE_UNFUSED: h->force_unfused = value != 0; return SG_OK;
     case SG_OPT_FORCE_NOFAST: h->force_nofast = value != 0; return SG_OK;
+    case SG_OPT_FORCE_F64_DECIDE: h->force_f64_decide = value != 0; return SG_OK;
   }
   FAIL(h, SG_E_INVALID, "sg_set_option: unknown option %d", option);
 }
@@ -959,7 +986,8 @@ extern "C" const char* sg_stage_name(int32_t stage) {
                                            "k_smooth_f+k_smooth_t", "k_apply_istft", "k_ola",
                                            "noise statistics (all kernels)", "k_unit_absmax+k_prep_thresh",
                                            "k_stft_bits<max> (floor pre-pass)", "k_stft_bits<decide>",
-                                           "k_apply_fast (fft+mask+ifft+ola)"};
+                                           "k_apply_fast (fft+mask+ifft+ola)",
+                                           "k_decide_fast (f32 stft + exact f64 refine)"};
   return (stage >= 0 && stage < SG_N_STAGES) ? names[stage] : "?";
 }
 

@@ -17,6 +17,15 @@
 #include "kernels.hpp"
 
 namespace sg {
+
+struct ThreshConsts {
+  // all device pointers
+  const double* T2;        // [F]  compare constant on the RAW power |X|^2 (see k_prep_thresh)
+  const double* thresh;    // [F]  dB threshold (for the floor test)
+  const double* pmax;      // [units][FS] per-(unit, band) max raw power, 0 where not computed
+  const int* need_floor;   // [units] 1: this unit's -top_db floor may be live -> pmax is valid
+};
+
 namespace fast {
 
 constexpr int FN = 512;           // complex points per frame
@@ -131,25 +140,33 @@ __device__ __forceinline__ void xchg_write_row(cf* fb, int row, const cf* B) {
 // Forward: v[r] = z[c + 16 r]  ->  v[k2] = Zc[row1 + 32 k2], v[16 + k2] = Zc[row2 + 32 k2].
 // fb: this frame's LDS slice; tw512: LDS table w_512^j, j < 512.
 __device__ __forceinline__ void fft512_fwd(cf* v, cf* fb, const cf* tw512, int c) {
+  // sched_barriers keep the phases apart: left alone, the scheduler overlaps the loads of one
+  // phase with the arithmetic of the previous one and the live range balloons past 256 VGPRs.
+  __builtin_amdgcn_sched_barrier(0);
   dft_reg<32, false>(v);
+  __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
   for (int k1 = 1; k1 < 32; ++k1) v[k1] = cmul(v[k1], tw512[k1 * c]);
   xchg_write_cols(fb, c, v);
   wave_lds_sync();
+  __builtin_amdgcn_sched_barrier(0);
   xchg_read_row(fb, row1(c), v);
   xchg_read_row(fb, row2(c), v + 16);
   wave_lds_sync();
   dft_reg<16, false>(v);
   dft_reg<16, false>(v + 16);
+  __builtin_amdgcn_sched_barrier(0);
 }
 
 // Inverse (unnormalised): v[k2], v[16 + k2] as above  ->  v[r] = 512 * z[c + 16 r].
 __device__ __forceinline__ void fft512_inv(cf* v, cf* fb, const cf* tw512, int c) {
+  __builtin_amdgcn_sched_barrier(0);
   dft_reg<16, true>(v);
   dft_reg<16, true>(v + 16);
   xchg_write_row(fb, row1(c), v);
   xchg_write_row(fb, row2(c), v + 16);
   wave_lds_sync();
+  __builtin_amdgcn_sched_barrier(0);
   xchg_read_cols(fb, c, v);
   wave_lds_sync();
 #pragma unroll
@@ -158,7 +175,9 @@ __device__ __forceinline__ void fft512_inv(cf* v, cf* fb, const cf* tw512, int c
     w.y = -w.y;
     v[k1] = cmul(v[k1], w);
   }
+  __builtin_amdgcn_sched_barrier(0);
   dft_reg<32, true>(v);
+  __builtin_amdgcn_sched_barrier(0);
 }
 
 // One conjugate pair of the real-FFT split -> mask -> merge (see k_apply_istft in kernels.hpp):
@@ -213,7 +232,7 @@ struct ApplyArgs {
 // One workgroup = WAVES wavefronts = 4*WAVES consecutive frames of one unit -> 4*WAVES-3 hops.
 // ---------------------------------------------------------------------------------------
 template <int WAVES>
-__global__ __launch_bounds__(WAVES * 64) void k_apply_fast(ApplyArgs A) {
+__global__ __launch_bounds__(WAVES * 64, 2) void k_apply_fast(ApplyArgs A) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
   cf* tw512 = reinterpret_cast<cf*>(smem);
   cf* regions = tw512 + FN;
@@ -231,15 +250,52 @@ __global__ __launch_bounds__(WAVES * 64) void k_apply_fast(ApplyArgs A) {
   const int64_t t = hs - 3 + 4 * wave + g;                   // this lane group's frame
   const bool fvalid = t >= 0 && t < G.T;
 
-  // window values of this lane's 64 samples m = 2c + 32 r + e
-  float wr[32][2];
+  cf* fb = regions + wave * WAVE_CX + frame_base(g);
+  // gather the frame: v[r] = (x[2c + 32r], x[2c + 32r + 1]) * window
+  cf v[32];
+  {
+    const int64_t s0 = t * 256 - G.padL;  // unit-local index of frame sample 0
+    const int64_t gbase = chunk * A.view.cs - A.view.pad + s0;
+    const bool inside = fvalid && s0 >= 0 && s0 + 1024 <= A.view.Lp && gbase >= A.view.lo &&
+                        gbase + 1024 <= A.view.hi && A.view.dtype == 0;
+    const float* src = (const float*)A.view.x + row * A.view.stride + gbase + 2 * c;
+    const bool aligned = (reinterpret_cast<uintptr_t>(src) & 7) == 0;
+    const float2* wsrc = reinterpret_cast<const float2*>(A.win + 2 * c);
+    if (inside && aligned) {
+      const float2* s2 = reinterpret_cast<const float2*>(src);
 #pragma unroll
-  for (int r = 0; r < 32; ++r) {
-    float2 w2 = *reinterpret_cast<const float2*>(&A.win[2 * c + 32 * r]);
-    wr[r][0] = w2.x;
-    wr[r][1] = w2.y;
+      for (int r = 0; r < 32; ++r) {
+        float2 x2 = s2[16 * r];
+        float2 w2 = wsrc[16 * r];
+        v[r] = {x2.x * w2.x, x2.y * w2.y};
+      }
+    } else {
+      // edge / non-float32 / unaligned frames: rolled gather staged through this frame's LDS slice
+      float* fl = reinterpret_cast<float*>(fb);
+#pragma unroll 1
+      for (int r = 0; r < 32; ++r) {
+        float a = 0.f, b = 0.f;
+        if (fvalid) {
+          a = (float)view_sample(A.view, row, chunk, s0 + 2 * c + 32 * r);
+          b = (float)view_sample(A.view, row, chunk, s0 + 2 * c + 32 * r + 1);
+        }
+        fl[2 * c + 32 * r] = a;
+        fl[2 * c + 32 * r + 1] = b;
+      }
+      wave_lds_sync();
+#pragma unroll
+      for (int r = 0; r < 32; ++r) {
+        float2 w2 = wsrc[16 * r];
+        cf x2 = fb[c + 16 * r];
+        v[r] = {x2.x * w2.x, x2.y * w2.y};
+      }
+      wave_lds_sync();
+    }
   }
-  // mask counts of this lane's 32 bins (+ bin 512 for lane c == 0)
+  __syncthreads();  // twiddle table staged
+  fft512_fwd(v, fb, tw512, c);
+
+  // mask counts of this lane's 32 bins (+ bin 512 for lane c == 0), permuted layout
   unsigned short kk[32];
   float k512 = 0.f;
   {
@@ -257,45 +313,6 @@ __global__ __launch_bounds__(WAVES * 64) void k_apply_fast(ApplyArgs A) {
     }
     k512 = (float)Krow[512] * A.kscale;
   }
-  // gather window * frame
-  cf v[32];
-  {
-    const int64_t s0 = t * 256 - G.padL;  // unit-local index of frame sample 0
-    const int64_t gbase = chunk * A.view.cs - A.view.pad + s0;
-    const bool inside = fvalid && s0 >= 0 && s0 + 1024 <= A.view.Lp && gbase >= A.view.lo &&
-                        gbase + 1024 <= A.view.hi && A.view.dtype == 0;
-    if (inside) {
-      const float* src = (const float*)A.view.x + row * A.view.stride + gbase + 2 * c;
-      if ((reinterpret_cast<uintptr_t>(src) & 7) == 0) {
-#pragma unroll
-        for (int r = 0; r < 32; ++r) {
-          float2 x2 = *reinterpret_cast<const float2*>(src + 32 * r);
-          v[r].x = x2.x * wr[r][0];
-          v[r].y = x2.y * wr[r][1];
-        }
-      } else {
-#pragma unroll
-        for (int r = 0; r < 32; ++r) {
-          v[r].x = src[32 * r] * wr[r][0];
-          v[r].y = src[32 * r + 1] * wr[r][1];
-        }
-      }
-    } else {
-#pragma unroll
-      for (int r = 0; r < 32; ++r) {
-        float a = 0.f, b = 0.f;
-        if (fvalid) {
-          a = (float)view_sample(A.view, row, chunk, s0 + 2 * c + 32 * r);
-          b = (float)view_sample(A.view, row, chunk, s0 + 2 * c + 32 * r + 1);
-        }
-        v[r].x = a * wr[r][0];
-        v[r].y = b * wr[r][1];
-      }
-    }
-  }
-  cf* fb = regions + wave * WAVE_CX + frame_base(g);
-  __syncthreads();  // twiddle table staged
-  fft512_fwd(v, fb, tw512, c);
 
   // split -> mask -> merge on conjugate pairs, all in this lane
   {
@@ -333,9 +350,17 @@ __global__ __launch_bounds__(WAVES * 64) void k_apply_fast(ApplyArgs A) {
     }
   }
   fft512_inv(v, fb, tw512, c);
-  // synthesis window, store the time-domain frame (natural order) into this frame's LDS slice
+  // synthesis window (re-read: keeping 64 window registers live across both FFTs would cost a
+  // wave of occupancy), store the time-domain frame (natural order) into this frame's LDS slice
+  {
+    const float2* wsrc2 = reinterpret_cast<const float2*>(A.win + 2 * c);
+    asm volatile("" : "+v"(wsrc2));  // opaque: do not CSE with the analysis-window loads
 #pragma unroll
-  for (int r = 0; r < 32; ++r) fb[c + 16 * r] = {v[r].x * wr[r][0], v[r].y * wr[r][1]};
+    for (int r = 0; r < 32; ++r) {
+      float2 w2 = wsrc2[16 * r];
+      fb[c + 16 * r] = {v[r].x * w2.x, v[r].y * w2.y};
+    }
+  }
   __syncthreads();
 
   // overlap-add: tile hop j (ext hop hs + j) = sum over tile frames i = j..j+3 of quarter j+3-i
@@ -385,6 +410,291 @@ __global__ __launch_bounds__(WAVES * 64) void k_apply_fast(ApplyArgs A) {
       if (gi < A.om.g_lo || gi >= A.om.g_hi) continue;
       store_sample(A.om.out, A.om.dtype, row * A.om.stride + gi - A.om.g0, p < G.Lout ? vals[e] : 0.f);
     }
+  }
+}
+
+}  // namespace fast
+}  // namespace sg
+
+// =======================================================================================
+// Fast decision kernel: float32 STFT + exact float64 re-evaluation of ambiguous cells.
+//
+// The stationary mask is a hard compare |X[k]|^2 > T2[k] (one flipped cell
+// moves the output by ~5e-3 of peak), so the decision must agree with a float64 evaluation.
+// Almost every cell is far from its threshold: the float32 transform decides those; a cell is
+// "ambiguous" when | |X| - T | <= delta with delta = 2^-16 * ||x w||_2, ~60x the RMS rounding
+// error of the float32 pipeline (window rounding + 10 butterfly levels).  Ambiguous cells
+// (~1e-5 of all cells on noise-like input) are re-evaluated exactly: all 64 lanes cooperate on
+// the 1024-term float64 DFT sum of that one bin.
+// =======================================================================================
+namespace sg {
+namespace fast {
+
+struct DecideArgs {
+  View view;
+  Geom g;
+  const float* win;        // analysis window, float32 (1024)
+  const double* win64;     // analysis window, float64 (1024)
+  const cf* tw512;         // w_512^j  float32 (512)
+  const cf* tw1024;        // w_1024^j float32 (512)
+  const cx<double>* tw64;  // w_1024^j float64 (512)
+  ThreshConsts tc;         // T2 (raw power compare constants), thresh, pmax, need_floor
+  double mag_scale, top_db;
+  unsigned long long* bits;  // [units][T][wpr]
+  int wpr;
+  int64_t t_begin, t_end;    // frames to decide
+  int quads_per_wave;        // consecutive frame quads handled by one wave
+};
+
+// bin held in register slot q (0..31) of lane c
+__device__ __forceinline__ int bin_of(int c, int q) {
+  return q < 16 ? c + 32 * q : (c == 0 ? 16 : 32 - c) + 32 * (q - 16);
+}
+
+// exact float64 |X[f]|^2 of frame t, computed by the whole wavefront (rare path: kept out of line
+// so that its float64 temporaries do not inflate the register budget of the main loop)
+__device__ __forceinline__ double exact_power(const DecideArgs& A, int64_t row, int64_t chunk, int64_t t, int f,
+                                              int lane) {
+  const int64_t s0 = t * A.g.H - A.g.padL;
+  double re = 0.0, im = 0.0;
+#pragma unroll 4
+  for (int i = 0; i < 16; ++i) {
+    const int m = lane + 64 * i;
+    const double xv = view_sample(A.view, row, chunk, s0 + m) * A.win64[m];
+    const int j = (f * m) & 1023;
+    cx<double> w = A.tw64[j & 511];
+    if (j >= 512) { w.x = -w.x; w.y = -w.y; }
+    re += xv * w.x;
+    im += xv * w.y;
+  }
+  for (int off = 32; off > 0; off >>= 1) {
+    re += __shfl_xor(re, off);
+    im += __shfl_xor(im, off);
+  }
+  return re * re + im * im;
+}
+
+template <int WAVES>
+__global__ __launch_bounds__(WAVES * 64, 2) void k_decide_fast(DecideArgs A) {
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  cf* tw512 = reinterpret_cast<cf*>(smem);
+  cf* regions = tw512 + FN;
+  const int tid = threadIdx.x;
+  const int lane = tid & 63, wave = tid >> 6;
+  const int g = lane >> 4, c = lane & 15;
+  for (int i = tid; i < FN; i += WAVES * 64) tw512[i] = A.tw512[i];
+  const Geom& G = A.g;
+  const int64_t u = blockIdx.y;
+  const int64_t row = (A.view.unit0 + u) / A.view.n_chunks;
+  const int64_t chunk = (A.view.unit0 + u) % A.view.n_chunks;
+  const bool floor_live = A.tc.need_floor[u] != 0;
+
+  // effective compare constants (4x the raw-power constant: the split below works on 2X) as
+  // float32 in LDS, permuted like the mask rows: entry c*32 + q = bin_of(c, q), entry 512 = bin 512
+  float* s_t2 = reinterpret_cast<float*>(regions + WAVES * WAVE_CX);
+  auto t2eff = [&](int f) -> double {
+    double v = A.tc.T2[f];
+    if (floor_live) {
+      double fl = cell_db(A.tc.pmax[u * G.FS + f], A.mag_scale) - A.top_db;
+      if (fl > A.tc.thresh[f]) v = -1.0;
+    }
+    return v;
+  };
+  for (int i = tid; i <= 512; i += WAVES * 64) {
+    double v = t2eff(perm_inv(i));
+    s_t2[i] = v < 0.0 ? -1.0f : (float)(4.0 * v);
+  }
+  cf* fb = regions + wave * WAVE_CX + frame_base(g);
+  const cf wl0 = A.tw1024[c == 0 ? 16 : c];  // w_1024^row1 (lane 0: w_1024^16 for its row 16)
+  __syncthreads();
+
+  {
+    // one frame quad per wave (no loop: loop-invariant twiddle/window loads would be hoisted and
+    // pin >100 VGPRs, costing the second wave per SIMD)
+    const int64_t tq = A.t_begin + ((int64_t)blockIdx.x * WAVES + wave) * 4;  // first frame of the quad
+    if (tq >= A.t_end) return;                                                  // wave-uniform
+    const int64_t t = tq + g;
+    const bool fvalid = t < A.t_end && t < G.T;
+    cf v[32];
+    float nrm2 = 0.f;
+    {
+      const int64_t s0 = t * 256 - G.padL;
+      const int64_t gbase = chunk * A.view.cs - A.view.pad + s0;
+      const bool inside = fvalid && s0 >= 0 && s0 + 1024 <= A.view.Lp && gbase >= A.view.lo &&
+                          gbase + 1024 <= A.view.hi && A.view.dtype == 0;
+      const float* src = (const float*)A.view.x + row * A.view.stride + gbase + 2 * c;
+      const bool aligned = (reinterpret_cast<uintptr_t>(src) & 7) == 0;
+      const float2* wsrc = reinterpret_cast<const float2*>(A.win + 2 * c);
+      asm volatile("" : "+v"(wsrc));  // re-read per quad: hoisting 64 window registers costs a wave
+      if (inside && aligned) {
+        const float2* s2 = reinterpret_cast<const float2*>(src);
+#pragma unroll
+        for (int r = 0; r < 32; ++r) {
+          float2 x2 = s2[16 * r];
+          float2 w2 = wsrc[16 * r];
+          v[r] = {x2.x * w2.x, x2.y * w2.y};
+        }
+      } else {
+        float* fl = reinterpret_cast<float*>(fb);
+#pragma unroll 1
+        for (int r = 0; r < 32; ++r) {
+          float a = 0.f, b = 0.f;
+          if (fvalid) {
+            a = (float)view_sample(A.view, row, chunk, s0 + 2 * c + 32 * r);
+            b = (float)view_sample(A.view, row, chunk, s0 + 2 * c + 32 * r + 1);
+          }
+          fl[2 * c + 32 * r] = a;
+          fl[2 * c + 32 * r + 1] = b;
+        }
+        wave_lds_sync();
+#pragma unroll
+        for (int r = 0; r < 32; ++r) {
+          float2 w2 = wsrc[16 * r];
+          cf x2 = fb[c + 16 * r];
+          v[r] = {x2.x * w2.x, x2.y * w2.y};
+        }
+        wave_lds_sync();
+      }
+#pragma unroll
+      for (int r = 0; r < 32; ++r) nrm2 += v[r].x * v[r].x + v[r].y * v[r].y;
+      // sum over the 16 lanes of this frame
+      nrm2 += __shfl_xor(nrm2, 1);
+      nrm2 += __shfl_xor(nrm2, 2);
+      nrm2 += __shfl_xor(nrm2, 4);
+      nrm2 += __shfl_xor(nrm2, 8);
+    }
+    {
+      // keep the loop-invariant twiddle reads inside the loop: hoisted, they would pin ~100 VGPRs
+      const cf* twl = tw512;
+      asm volatile("" : "+v"(twl));
+      fft512_fwd(v, fb, twl, c);
+    }
+    cf wl = wl0;
+    asm volatile("" : "+v"(wl.x), "+v"(wl.y));
+    float t2[32];
+    float t2_512;
+    {
+      const float* tp = s_t2;
+      asm volatile("" : "+v"(tp));
+      const float4* t4 = reinterpret_cast<const float4*>(tp + c * 32);
+#pragma unroll
+      for (int q4 = 0; q4 < 8; ++q4) {
+        float4 x = t4[q4];
+        t2[4 * q4] = x.x; t2[4 * q4 + 1] = x.y; t2[4 * q4 + 2] = x.z; t2[4 * q4 + 3] = x.w;
+      }
+      t2_512 = tp[512];
+    }
+
+    // powers of the lane's 32 bins (x4): P4[k] = |E2 + w O2|^2, P4[N-k] = |E2 - w O2|^2 with
+    // E2 = a + conj(b), O2 = (a - conj(b)) / i; each is decided as soon as it exists.
+    // ambiguous:  (P4 - T4)^2 <= 2 * (2 delta)^2 * (P4 + T4)  (implied by |2|X| - 2T| <= 2 delta),
+    // delta^2 = 2^-32 * nrm2.
+    const float d2 = 8.0f * 2.3283064e-10f * nrm2;  // 2 * (2 delta)^2
+    const bool live = nrm2 > 0.f;
+    unsigned pred = 0, amb = 0;
+    auto decide = [&](float P, float T, int q) {
+      const float diff = P - T;
+      pred |= (diff > 0.f ? 1u : 0u) << q;
+      amb |= ((live && T >= 0.f && diff * diff <= d2 * (P + T)) ? 1u : 0u) << q;
+    };
+    auto pair_power = [&](cf a, cf b, cf w, float& Pk, float& Pn) {
+      cf E = {a.x + b.x, a.y - b.y};
+      cf O = {a.y + b.y, b.x - a.x};
+      cf wO = cmul(w, O);
+      float px = E.x + wO.x, py = E.y + wO.y, qx = E.x - wO.x, qy = E.y - wO.y;
+      Pk = px * px + py * py;
+      Pn = qx * qx + qy * qy;
+    };
+    bool pred512 = false, amb512 = false;
+    if (c != 0) {
+#pragma unroll
+      for (int k2 = 0; k2 < 16; ++k2) {
+        cf w = k2 == 0 ? wl : mul_tw<false>(wl, twc<32>(k2), tws<32>(k2));
+        float Pk, Pn;
+        pair_power(v[k2], v[31 - k2], w, Pk, Pn);
+        decide(Pk, t2[k2], k2);
+        decide(Pn, t2[31 - k2], 31 - k2);
+      }
+    } else {
+      {
+        cf a = v[0];
+        float x0 = 2.f * (a.x + a.y), xN = 2.f * (a.x - a.y);
+        decide(x0 * x0, t2[0], 0);
+        decide(4.f * (v[8].x * v[8].x + v[8].y * v[8].y), t2[8], 8);
+        const float P5 = xN * xN, d5 = P5 - t2_512;
+        pred512 = d5 > 0.f;
+        amb512 = live && t2_512 >= 0.f && d5 * d5 <= d2 * (P5 + t2_512);
+      }
+#pragma unroll
+      for (int k2 = 1; k2 < 8; ++k2) {
+        cf w = {twc<32>(k2), -tws<32>(k2)};
+        float Pk, Pn;
+        pair_power(v[k2], v[16 - k2], w, Pk, Pn);
+        decide(Pk, t2[k2], k2);
+        decide(Pn, t2[16 - k2], 16 - k2);
+      }
+#pragma unroll
+      for (int j = 0; j < 8; ++j) {
+        cf w = j == 0 ? wl : mul_tw<false>(wl, twc<32>(j), tws<32>(j));
+        float Pk, Pn;
+        pair_power(v[16 + j], v[31 - j], w, Pk, Pn);
+        decide(Pk, t2[16 + j], 16 + j);
+        decide(Pn, t2[31 - j], 31 - j);
+      }
+    }
+    if (!fvalid) { amb = 0; amb512 = false; }
+    // exact re-evaluation, one cell at a time, whole wave cooperating
+    while (true) {
+      const unsigned long long pending = __ballot(amb != 0 || amb512);
+      if (pending == 0) break;
+      const int src = __ffsll((long long)pending) - 1;
+      const unsigned amb_s = (unsigned)__shfl((int)amb, src);
+      const int amb512_s = __shfl((int)amb512, src);
+      const int q = amb_s ? (__ffs((int)amb_s) - 1) : 32;
+      (void)amb512_s;
+      const int cs = src & 15, gs = src >> 4;
+      const int f = q < 32 ? bin_of(cs, q) : 512;
+      const double P = exact_power(A, row, chunk, tq + gs, f, lane);
+      const bool pass = P > t2eff(f);
+      if (lane == src) {
+        if (q < 32) {
+          pred = (pred & ~(1u << q)) | ((pass ? 1u : 0u) << q);
+          amb &= ~(1u << q);
+        } else {
+          pred512 = pass;
+          amb512 = false;
+        }
+      }
+    }
+    // pack: ballots over the wave give 16 consecutive bins per frame and slot
+    unsigned long long myword = 0;  // lane c < 9 of group g ends up with word c of frame tq + g
+#pragma unroll
+    for (int m = 0; m < 8; ++m) {
+      unsigned long long b0 = __ballot((pred >> (2 * m)) & 1u);           // bins 64m      + c
+      unsigned long long b1 = __ballot((pred >> (16 + 2 * m)) & 1u);      // bins 64m + 16 + twisted
+      unsigned long long b2 = __ballot((pred >> (2 * m + 1)) & 1u);       // bins 64m + 32 + c
+      unsigned long long b3 = __ballot((pred >> (16 + 2 * m + 1)) & 1u);  // bins 64m + 48 + twisted
+#pragma unroll
+      for (int gg = 0; gg < 4; ++gg) {
+        unsigned f0 = (unsigned)(b0 >> (16 * gg)) & 0xffffu;
+        unsigned f1 = (unsigned)(b1 >> (16 * gg)) & 0xffffu;
+        unsigned f2 = (unsigned)(b2 >> (16 * gg)) & 0xffffu;
+        unsigned f3 = (unsigned)(b3 >> (16 * gg)) & 0xffffu;
+        // row-2 slots hold bins 16, 31, 30, ..., 17 (c = 0, 1, ..., 15): undo the order
+        unsigned r1 = (((__brev(f1) >> 16) << 1) | (f1 & 1u)) & 0xffffu;
+        unsigned r3 = (((__brev(f3) >> 16) << 1) | (f3 & 1u)) & 0xffffu;
+        unsigned long long word = (unsigned long long)f0 | ((unsigned long long)r1 << 16) |
+                                  ((unsigned long long)f2 << 32) | ((unsigned long long)r3 << 48);
+        if (lane == 16 * gg + m) myword = word;
+      }
+    }
+    {
+      unsigned long long b8 = __ballot(pred512);
+#pragma unroll
+      for (int gg = 0; gg < 4; ++gg)
+        if (lane == 16 * gg + 8) myword = (b8 >> (16 * gg)) & 1ull;
+    }
+    if (fvalid && c < 9) A.bits[(u * G.T + t) * (int64_t)A.wpr + c] = myword;
   }
 }
 

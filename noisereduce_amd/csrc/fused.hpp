@@ -17,13 +17,6 @@ namespace sg {
 
 constexpr int BITS_WPR_MAX = 33;  // 64-bit words per bit row: ceil(F/64), F <= 2049
 
-struct ThreshConsts {
-  // all device pointers
-  const double* T2;        // [F]  compare constant on the RAW power |X|^2 (see k_prep_thresh)
-  const double* thresh;    // [F]  dB threshold (for the floor test)
-  const double* pmax;      // [units][FS] per-(unit, band) max raw power, 0 where not computed
-  const int* need_floor;   // [units] 1: this unit's -top_db floor may be live -> pmax is valid
-};
 
 // ---------------------------------------------------------------------------------------
 __global__ void k_unit_absmax(View view, int64_t n_units, unsigned* __restrict__ umax_bits) {

@@ -230,3 +230,41 @@ def test_silence_and_constant_inputs(nr):
     assert np.all(out == 0)
     out = nr.reduce_noise(y=z, sr=48000, stationary=False)
     assert out.shape == z.shape
+
+
+@pytest.mark.parametrize("kind", ["noise_tone", "pure_tone", "steps"])
+def test_fast_decide_bits_equal_f64_decide(nr, kind):
+    """The float32 + exact-refine decision kernel must produce the SAME mask bits as the
+    float64 STFT decision, including on inputs built to sit on the threshold (a steady tone:
+    every cell of the tone bands has dB ~= mean = threshold)."""
+    from noisereduce_amd import _ffi
+    from noisereduce_amd.spectralgate.stationary import SpectralGateStationary
+    n = 120000
+    t = np.arange(n) / 48000.0
+    rng = np.random.default_rng(5)
+    if kind == "noise_tone":
+        y = O.synth_signal(n, seed=8).astype(np.float64)
+    elif kind == "pure_tone":
+        y = 0.5 * np.sin(2 * np.pi * 1000.0 * t) + 0.25 * np.sin(2 * np.pi * 5250.0 * t) \
+            + 1e-5 * rng.standard_normal(n)
+    else:
+        y = np.where((np.arange(n) // 7000) % 2 == 0, 0.0, 1.0) * (0.3 * rng.standard_normal(n))
+    y = y.astype(np.float32)
+    kw = dict(sr=48000, y_noise=None, prop_decrease=1.0, n_std_thresh_stationary=1.5,
+              chunk_size=50000, clip_noise_stationary=True, padding=6000, n_fft=1024, win_length=None,
+              hop_length=None, time_constant_s=2.0, freq_mask_smooth_hz=500, time_mask_smooth_ms=50,
+              tmp_folder=None, use_tqdm=False, n_jobs=1)
+    sg = SpectralGateStationary(y=y, **kw)
+    out_fast = sg.get_traces()
+    bits_fast = sg._gate.debug_field(3)
+    try:
+        sg._gate.set_option(_ffi.SG_OPT_FORCE_F64_DECIDE, 1)
+        out_f64 = sg.get_traces()
+        bits_f64 = sg._gate.debug_field(3)
+    finally:
+        sg._gate.set_option(_ffi.SG_OPT_FORCE_F64_DECIDE, 0)
+    assert bits_fast.shape == bits_f64.shape
+    assert np.count_nonzero(bits_fast != bits_f64) == 0
+    assert np.array_equal(out_fast, out_f64)
+    want = O.reduce_noise_S(y.astype(np.float64), 48000, stationary=True, chunk_size=50000, padding=6000)
+    assert O.rel_err(out_fast, want) < 2e-4 if kind == "pure_tone" else O.rel_err(out_fast, want) < TOL
