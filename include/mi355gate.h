@@ -154,6 +154,9 @@ int sg_stft(sg_handle* h, const void* x_dev, int dtype, int64_t B, int64_t L, in
  *        3: raw mask as bits uint64[units][T][ceil(F/64)] (fused stationary path only).
  * FS = third entry of sg_debug_dims. */
 int sg_debug_dims(const sg_handle* h, int64_t dims[3]); /* units, T, FS */
+/* Frame range [t0, t1) for which field 3 (mask bits) was computed: the fast path only decides
+ * the frames that reach the kept output samples (+- the smoothing half width). */
+int sg_debug_range(const sg_handle* h, int64_t range[2]);
 int sg_debug_fetch(sg_handle* h, int32_t what, void* host, int64_t bytes, void* stream);
 
 /* ---- options ------------------------------------------------------------------------- */

@@ -67,6 +67,7 @@ _PROTOTYPES = {
     "sg_profile_read": (c_int, [c_void_p, POINTER(c_double), POINTER(c_int64), c_int32, c_int32]),
     "sg_stage_name": (c_char_p, [c_int32]),
     "sg_debug_dims": (c_int, [c_void_p, POINTER(c_int64)]),
+    "sg_debug_range": (c_int, [c_void_p, POINTER(c_int64)]),
     "sg_debug_fetch": (c_int, [c_void_p, c_int32, c_void_p, c_int64, c_void_p]),
 }
 
@@ -307,6 +308,11 @@ class Gate:
             self._check(self.lib.sg_stft(self._h, x.data_ptr(), _sg_dtype(x), B, L, xs, z.data_ptr(),
                                          self._stream()))
         return torch.view_as_complex(z)
+
+    def debug_range(self):
+        r = (c_int64 * 2)()
+        self._check(self.lib.sg_debug_range(self._h, r))
+        return int(r[0]), int(r[1])
 
     def debug_field(self, what):
         """0: raw mask, 1: final mask (float32); 2: power (float64) of the last unit batch,

@@ -60,6 +60,7 @@ struct sg_handle {
   bool dbg_has_P = false;
   bool dbg_fused = false;
   bool dbg_fast = false;
+  int64_t dbg_db = 0, dbg_de = 0;  // frames whose mask bits were decided in the last batch
   bool force_unfused = false;  // sg_set_option(SG_OPT_FORCE_UNFUSED): materialised v1 path
   // per-kernel timing with HIP events on the launch stream (sg_profile_*)
   bool prof_on = false;
@@ -579,7 +580,13 @@ static int stage_apply_ola(sg_handle* h, const View& v, const Geom& g, int64_t u
 }
 
 // Fused stationary mask (variant S): STFT(f64) -> bits -> integer smoothing -> K16 -> float mask.
-static int stage_fused_mask(sg_handle* h, const View& v, const Geom& g, int64_t ub, bool fast, hipStream_t st) {
+static int stage_fused_mask(sg_handle* h, const View& v, const Geom& g, int64_t ub, bool fast, int64_t tb,
+                            int64_t te, hipStream_t st) {
+  // [tb, te): frames whose smoothed mask is needed; decisions are needed nt frames further out
+  const int64_t nt_halo = h->p.smooth_mask ? h->p.n_grad_time : 0;
+  const int64_t db = std::max<int64_t>(0, tb - nt_halo), de = std::min<int64_t>(g.T, te + nt_halo);
+  h->dbg_db = (fast && !h->force_f64_decide) ? db : 0;
+  h->dbg_de = (fast && !h->force_f64_decide) ? de : g.T;
   const int wpr = (g.F + 63) / 64;
   int rc;
   if ((rc = ensure(h, h->bits, (size_t)ub * g.T * wpr * 8))) return rc;
@@ -619,7 +626,7 @@ static int stage_fused_mask(sg_handle* h, const View& v, const Geom& g, int64_t 
     D.mag_scale = h->mag_scale; D.top_db = h->p.top_db;
     D.bits = (unsigned long long*)h->bits.p;
     D.wpr = wpr;
-    D.t_begin = 0; D.t_end = g.T;
+    D.t_begin = db; D.t_end = de;
     D.quads_per_wave = 1;
     const int64_t quads = (D.t_end - D.t_begin + 3) / 4;
     const int64_t per_block = (int64_t)WAVES * D.quads_per_wave;
@@ -638,7 +645,27 @@ static int stage_fused_mask(sg_handle* h, const View& v, const Geom& g, int64_t 
   ProfScope ps(h, SG_STAGE_SMOOTH, st);
   const int nf = h->p.n_grad_freq, nt = h->p.n_grad_time;
   int64_t cells = ub * g.T * g.FS;
-  if (h->p.smooth_mask) {
+  if (h->p.smooth_mask && nf <= 30) {
+    const int rows = SM2_TT + 2 * nt;
+    const bool small = (nf + 1) * (nf + 1) <= 255;
+    size_t lds = smooth_cf_bytes(rows, g.F, small ? 1 : 2) + (size_t)rows * (wpr + 2) * 8;
+    dim3 grid((unsigned)((te - tb + SM2_TT - 1) / SM2_TT), (unsigned)ub);
+    if (small) {
+      auto kern = k_smooth_bits2<uint8_t>;
+      if (lds > 65536)
+        HIPCHK(h, hipFuncSetAttribute(reinterpret_cast<const void*>(kern),
+                                      hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+      hipLaunchKernelGGL(kern, grid, dim3(SM2_THREADS), lds, st, (const unsigned long long*)h->bits.p, g, wpr, nf,
+                         nt, (unsigned short*)h->K16.p, fast ? 1 : 0, tb, te);
+    } else {
+      auto kern = k_smooth_bits2<uint16_t>;
+      if (lds > 65536)
+        HIPCHK(h, hipFuncSetAttribute(reinterpret_cast<const void*>(kern),
+                                      hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+      hipLaunchKernelGGL(kern, grid, dim3(SM2_THREADS), lds, st, (const unsigned long long*)h->bits.p, g, wpr, nf,
+                         nt, (unsigned short*)h->K16.p, fast ? 1 : 0, tb, te);
+    }
+  } else if (h->p.smooth_mask) {
     const int rows = SM_TT + 2 * nt;
     const bool small = (nf + 1) * (nf + 1) <= 255;
     size_t lds = smooth_cf_bytes(rows, g.F, small ? 1 : 2) + (size_t)rows * wpr * 8;
@@ -716,14 +743,17 @@ static int run_S(sg_handle* h, View v, int64_t total_units, const OutMap& om, hi
     const bool fused = h->fused_ok && !h->force_unfused;
     const bool fast = fused && h->fast_ok && !h->force_nofast && h->p.prop_decrease == 1.0;
     if (fast) {
-      if ((rc = stage_fused_mask(h, v, g, nb, true, st))) return rc;
+      // frames the fused apply kernel touches: hops [h_begin, h_end) need frames h-3 .. h
+      const int64_t hb = (om.p0 + g.padL) / 256, he = (om.p1 - 1 + g.padL) / 256 + 1;
+      const int64_t tb = std::max<int64_t>(0, hb - 3), te = std::min<int64_t>(g.T, he);
+      if ((rc = stage_fused_mask(h, v, g, nb, true, tb, std::max(te, tb + 1), st))) return rc;
       if ((rc = stage_apply_fast(h, v, g, nb, om, st))) return rc;
       h->dbg_units = nb; h->dbg_T = g.T; h->dbg_has_P = false; h->dbg_fused = true; h->dbg_fast = true;
       continue;
     }
     h->dbg_fast = false;
     if (fused) {
-      if ((rc = stage_fused_mask(h, v, g, nb, false, st))) return rc;
+      if ((rc = stage_fused_mask(h, v, g, nb, false, 0, g.T, st))) return rc;
     } else {
       if (h->p.stationary) {
         if ((rc = stage_power(h, v, g, nb, st))) return rc;
@@ -994,6 +1024,12 @@ extern "C" const char* sg_stage_name(int32_t stage) {
 extern "C" int sg_debug_dims(const sg_handle* h, int64_t dims[3]) {
   if (!h || !dims) return SG_E_INVALID;
   dims[0] = h->dbg_units; dims[1] = h->dbg_T; dims[2] = h->FS;
+  return SG_OK;
+}
+
+extern "C" int sg_debug_range(const sg_handle* h, int64_t range[2]) {
+  if (!h || !range) return SG_E_INVALID;
+  range[0] = h->dbg_db; range[1] = h->dbg_de;
   return SG_OK;
 }
 

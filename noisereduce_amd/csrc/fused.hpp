@@ -242,6 +242,108 @@ __global__ __launch_bounds__(256) void k_smooth_bits(const unsigned long long* _
   }
 }
 
+// Second-generation smoothing kernel (nf <= 30): phase 1 keeps a 128-bit sliding window of the
+// bit row in registers (no LDS reads in the recurrence) and stores 4 counts per LDS write;
+// phase 2 walks one output column per thread over the whole tile with batched LDS reads.
+// Frames outside [t_begin, t_end) are neither read as outputs nor written.
+constexpr int SM2_TT = 64;
+constexpr int SM2_THREADS = 576;
+
+__device__ __forceinline__ unsigned long long funnel_r(unsigned long long lo, unsigned long long hi, int sh) {
+  // bits [sh, sh+64) of the 128-bit value hi:lo, 0 <= sh < 64
+  return sh == 0 ? lo : ((lo >> sh) | (hi << (64 - sh)));
+}
+
+template <typename CT>
+__global__ __launch_bounds__(SM2_THREADS) void k_smooth_bits2(const unsigned long long* __restrict__ bits, Geom g,
+                                                               int wpr, int nf, int nt,
+                                                               unsigned short* __restrict__ K, int perm,
+                                                               int64_t t_begin, int64_t t_end) {
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  const int rows = SM2_TT + 2 * nt;
+  const int FP = (g.F + 3) & ~3;
+  const int WP = wpr + 2;  // one zero word on each side of every bit row
+  CT* cf = reinterpret_cast<CT*>(smem);
+  unsigned long long* wb = reinterpret_cast<unsigned long long*>(smem + smooth_cf_bytes(rows, g.F, sizeof(CT)));
+  const int64_t u = blockIdx.y;
+  const int64_t t0 = t_begin + (int64_t)blockIdx.x * SM2_TT;
+  for (int i = threadIdx.x; i < rows * WP; i += SM2_THREADS) {
+    const int r = i / WP, w = i - r * WP - 1;
+    const int64_t t = t0 - nt + r;
+    unsigned long long word = 0ull;
+    if (w >= 0 && w < wpr && t >= 0 && t < g.T) {
+      word = bits[(u * g.T + t) * (int64_t)wpr + w];
+      const int nvalid = g.F - 64 * w;  // clear bits beyond bin F-1 (they are unspecified)
+      if (nvalid < 64) word &= (nvalid <= 0 ? 0ull : ((1ull << nvalid) - 1ull));
+    }
+    wb[i] = word;
+  }
+  __syncthreads();
+  // ---- phase 1: along f ----------------------------------------------------------------
+  const unsigned long long m1 = (1ull << (nf + 1)) - 1ull;
+  for (int task = threadIdx.x; task < rows * wpr; task += SM2_THREADS) {
+    const int r = task / wpr, w = task - r * wpr;
+    const unsigned long long* rb = wb + (size_t)r * WP + 1 + w;
+    // 128-bit window starting at bin f0 - nf, f0 = 64 w
+    unsigned long long lo = funnel_r(rb[-1], rb[0], 64 - nf);
+    unsigned long long hi = funnel_r(rb[0], rb[1], 64 - nf);
+    int c = 0;
+    for (int i = 0; i <= 2 * nf; ++i) c += (nf + 1 - (i < nf ? nf - i : i - nf)) * (int)((lo >> i) & 1ull);
+    int R = __popcll((lo >> (nf + 1)) & m1);
+    int L = __popcll(lo & m1);
+    CT* out = cf + (size_t)r * FP + 64 * w;
+    const int nb = min(64, g.F - 64 * w);
+    for (int f4 = 0; f4 < nb; f4 += 4) {
+      unsigned packed = 0;
+      int vals[4];
+#pragma unroll
+      for (int e = 0; e < 4; ++e) {
+        vals[e] = c;
+        packed |= ((unsigned)c & 0xffu) << (8 * e);
+        c += R - L;
+        const int bA = (int)((lo >> (nf + 1)) & 1ull);      // bit(f + 1)
+        R += (int)((lo >> (2 * nf + 2)) & 1ull) - bA;       // + bit(f + nf + 2) - bit(f + 1)
+        L += bA - (int)(lo & 1ull);                         // + bit(f + 1) - bit(f - nf)
+        lo = (lo >> 1) | (hi << 63);
+        hi >>= 1;
+      }
+      if (sizeof(CT) == 1) {
+        *reinterpret_cast<unsigned*>(out + f4) = packed;  // FP is a multiple of 4: rows stay aligned
+      } else {
+#pragma unroll
+        for (int e = 0; e < 4; ++e)
+          if (f4 + e < FP - 64 * w) out[f4 + e] = (CT)vals[e];
+      }
+    }
+  }
+  __syncthreads();
+  // ---- phase 2: along t, one output position per thread ------------------------------------
+  for (int pos = threadIdx.x; pos < g.F; pos += SM2_THREADS) {
+    const int f = perm ? fast::perm_inv(pos) : pos;
+    const CT* col = cf + f;
+    auto at = [&](int r) -> int { return (r >= 0 && r < rows) ? (int)col[(size_t)r * FP] : 0; };
+    const int r0 = nt;  // LDS row of output frame t0
+    int c = 0, R = 0, L = 0;
+    for (int b = -nt; b <= nt + 1; ++b) {
+      const int x = at(r0 + b);
+      if (b <= nt) c += (nt + 1 - (b < 0 ? -b : b)) * x;
+      if (b >= 1) R += x;
+      if (b <= 0) L += x;
+    }
+    unsigned short* kout = K + (u * g.T + t0) * (int64_t)g.FS + pos;
+    const int n_out = (int)min<int64_t>(SM2_TT, min<int64_t>(t_end, g.T) - t0);
+#pragma unroll 4
+    for (int i = 0; i < n_out; ++i) {
+      const int r = r0 + i;
+      const int xa = at(r + nt + 2), xb = at(r + 1), xc = at(r - nt);
+      kout[(int64_t)i * g.FS] = (unsigned short)c;
+      c += R - L;
+      R += xa - xb;
+      L += xb - xc;
+    }
+  }
+}
+
 // no smoothing: K = bit (ktot = 1)
 __global__ void k_bits_to_k16(const unsigned long long* __restrict__ bits, Geom g, int wpr,
                               unsigned short* __restrict__ K, int64_t n_units, int perm) {

@@ -73,7 +73,9 @@ def test_stage_taps(nr, golden_dir):
     raw = sg._gate.debug_field(3)[0].T                                      # (F, T) bits
     assert raw.shape == tuple(g["raw_shape"])
     ref_raw = np.unpackbits(g["raw_bits"], axis=1)[:, :raw.shape[1]].astype(bool)
-    assert np.count_nonzero(raw != ref_raw) == 0, "mask flips vs the reference"
+    d0, d1 = sg._gate.debug_range()       # frames that reach the kept samples (+- smoothing)
+    assert 0 <= d0 < d1 <= raw.shape[1] and d1 - d0 > 150
+    assert np.count_nonzero(raw[:, d0:d1] != ref_raw[:, d0:d1]) == 0, "mask flips vs the reference"
     from noisereduce_amd import _ffi
     try:  # the smoothed mask as floats only exists on the general apply path
         sg._gate.set_option(_ffi.SG_OPT_FORCE_NOFAST, 1)
@@ -257,14 +259,15 @@ def test_fast_decide_bits_equal_f64_decide(nr, kind):
     sg = SpectralGateStationary(y=y, **kw)
     out_fast = sg.get_traces()
     bits_fast = sg._gate.debug_field(3)
+    d0, d1 = sg._gate.debug_range()
     try:
         sg._gate.set_option(_ffi.SG_OPT_FORCE_F64_DECIDE, 1)
         out_f64 = sg.get_traces()
         bits_f64 = sg._gate.debug_field(3)
     finally:
         sg._gate.set_option(_ffi.SG_OPT_FORCE_F64_DECIDE, 0)
-    assert bits_fast.shape == bits_f64.shape
-    assert np.count_nonzero(bits_fast != bits_f64) == 0
+    assert bits_fast.shape == bits_f64.shape and d1 - d0 > 100
+    assert np.count_nonzero(bits_fast[:, d0:d1] != bits_f64[:, d0:d1]) == 0
     assert np.array_equal(out_fast, out_f64)
     want = O.reduce_noise_S(y.astype(np.float64), 48000, stationary=True, chunk_size=50000, padding=6000)
     assert O.rel_err(out_fast, want) < 2e-4 if kind == "pure_tone" else O.rel_err(out_fast, want) < TOL
