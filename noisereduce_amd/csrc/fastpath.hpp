@@ -138,7 +138,8 @@ __device__ __forceinline__ void xchg_write_row(cf* fb, int row, const cf* B) {
 }
 
 // Forward: v[r] = z[c + 16 r]  ->  v[k2] = Zc[row1 + 32 k2], v[16 + k2] = Zc[row2 + 32 k2].
-// fb: this frame's LDS slice; tw512: LDS table w_512^j, j < 512.
+// fb: this frame's LDS slice; tw512: LDS table T[k1][c] = w_512^(k1 c) (row of 16 lanes contiguous:
+// conflict-free, the four frames of a wave read the same row -> broadcast).
 __device__ __forceinline__ void fft512_fwd(cf* v, cf* fb, const cf* tw512, int c) {
   // sched_barriers keep the phases apart: left alone, the scheduler overlaps the loads of one
   // phase with the arithmetic of the previous one and the live range balloons past 256 VGPRs.
@@ -146,7 +147,7 @@ __device__ __forceinline__ void fft512_fwd(cf* v, cf* fb, const cf* tw512, int c
   dft_reg<32, false>(v);
   __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
-  for (int k1 = 1; k1 < 32; ++k1) v[k1] = cmul(v[k1], tw512[k1 * c]);
+  for (int k1 = 1; k1 < 32; ++k1) v[k1] = cmul(v[k1], tw512[k1 * 16 + c]);
   xchg_write_cols(fb, c, v);
   wave_lds_sync();
   __builtin_amdgcn_sched_barrier(0);
@@ -171,7 +172,7 @@ __device__ __forceinline__ void fft512_inv(cf* v, cf* fb, const cf* tw512, int c
   wave_lds_sync();
 #pragma unroll
   for (int k1 = 1; k1 < 32; ++k1) {
-    cf w = tw512[k1 * c];
+    cf w = tw512[k1 * 16 + c];
     w.y = -w.y;
     v[k1] = cmul(v[k1], w);
   }
@@ -182,14 +183,15 @@ __device__ __forceinline__ void fft512_inv(cf* v, cf* fb, const cf* tw512, int c
 
 // One conjugate pair of the real-FFT split -> mask -> merge (see k_apply_istft in kernels.hpp):
 // a = Zc[k], b = Zc[N-k], w = w_1024^k, mk / mn = mask of bin k / N-k.  Returns Zc'[k], Zc'[N-k].
+// The four 1/2 factors of split and merge are NOT applied here: the caller folds 1/4 into the masks.
 __device__ __forceinline__ void pair_mask(cf& a, cf& b, cf w, float mk, float mn) {
-  cf E = {(a.x + b.x) * 0.5f, (a.y - b.y) * 0.5f};
-  cf O = {(a.y + b.y) * 0.5f, (b.x - a.x) * 0.5f};
+  cf E = {a.x + b.x, a.y - b.y};
+  cf O = {a.y + b.y, b.x - a.x};
   cf wO = cmul(w, O);
   cf Yk = {(E.x + wO.x) * mk, (E.y + wO.y) * mk};
   cf Yn = {(E.x - wO.x) * mn, (wO.y - E.y) * mn};
-  cf Ep = {(Yk.x + Yn.x) * 0.5f, (Yk.y - Yn.y) * 0.5f};
-  cf D = {(Yk.x - Yn.x) * 0.5f, (Yk.y + Yn.y) * 0.5f};
+  cf Ep = {Yk.x + Yn.x, Yk.y - Yn.y};
+  cf D = {Yk.x - Yn.x, Yk.y + Yn.y};
   cf Op = cmul(D, cf{w.x, -w.y});
   a = {Ep.x - Op.y, Ep.y + Op.x};
   b = {Ep.x + Op.y, Op.x - Ep.y};
@@ -241,7 +243,7 @@ __global__ __launch_bounds__(WAVES * 64, 2) void k_apply_fast(ApplyArgs A) {
   const int tid = threadIdx.x;
   const int lane = tid & 63, wave = tid >> 6;
   const int g = lane >> 4, c = lane & 15;
-  for (int i = tid; i < FN; i += WAVES * 64) tw512[i] = A.tw512[i];
+  for (int i = tid; i < FN; i += WAVES * 64) tw512[i] = A.tw512[(i >> 4) * (i & 15)];
   const Geom& G = A.g;
   const int64_t u = blockIdx.y;
   const int64_t row = (A.view.unit0 + u) / A.view.n_chunks;
@@ -249,6 +251,26 @@ __global__ __launch_bounds__(WAVES * 64, 2) void k_apply_fast(ApplyArgs A) {
   const int64_t hs = A.h_begin + (int64_t)blockIdx.x * NH;  // first hop of this tile
   const int64_t t = hs - 3 + 4 * wave + g;                   // this lane group's frame
   const bool fvalid = t >= 0 && t < G.T;
+
+  // mask counts of this lane's 32 bins (+ bin 512 for lane c == 0), permuted layout; issued first:
+  // they are consumed only after the forward transform
+  unsigned short kk[32];
+  float k512 = 0.f;
+  {
+    const unsigned short* Krow = A.K + ((u * G.T + (fvalid ? t : 0)) * (int64_t)FSK);
+    const uint4* p4 = reinterpret_cast<const uint4*>(Krow + c * 32);
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+      uint4 w4 = p4[q];
+      unsigned ws[4] = {w4.x, w4.y, w4.z, w4.w};
+#pragma unroll
+      for (int j = 0; j < 4; ++j) {
+        kk[q * 8 + 2 * j] = (unsigned short)(ws[j] & 0xffffu);
+        kk[q * 8 + 2 * j + 1] = (unsigned short)(ws[j] >> 16);
+      }
+    }
+    k512 = (float)Krow[512] * A.kscale;
+  }
 
   cf* fb = regions + wave * WAVE_CX + frame_base(g);
   // gather the frame: v[r] = (x[2c + 32r], x[2c + 32r + 1]) * window
@@ -295,28 +317,17 @@ __global__ __launch_bounds__(WAVES * 64, 2) void k_apply_fast(ApplyArgs A) {
   __syncthreads();  // twiddle table staged
   fft512_fwd(v, fb, tw512, c);
 
-  // mask counts of this lane's 32 bins (+ bin 512 for lane c == 0), permuted layout
-  unsigned short kk[32];
-  float k512 = 0.f;
+  // synthesis window: issued now so that it arrives while the inverse transform runs
+  float2 wsyn[32];
   {
-    const unsigned short* Krow = A.K + ((u * G.T + (fvalid ? t : 0)) * (int64_t)FSK);
-    const uint4* p4 = reinterpret_cast<const uint4*>(Krow + c * 32);
+    const float2* wsrc2 = reinterpret_cast<const float2*>(A.win + 2 * c);
+    asm volatile("" : "+v"(wsrc2));  // opaque: a separate load, not a CSE of the analysis window
 #pragma unroll
-    for (int q = 0; q < 4; ++q) {
-      uint4 w4 = p4[q];
-      unsigned ws[4] = {w4.x, w4.y, w4.z, w4.w};
-#pragma unroll
-      for (int j = 0; j < 4; ++j) {
-        kk[q * 8 + 2 * j] = (unsigned short)(ws[j] & 0xffffu);
-        kk[q * 8 + 2 * j + 1] = (unsigned short)(ws[j] >> 16);
-      }
-    }
-    k512 = (float)Krow[512] * A.kscale;
+    for (int r = 0; r < 32; ++r) wsyn[r] = wsrc2[16 * r];
   }
-
   // split -> mask -> merge on conjugate pairs, all in this lane
   {
-    const float ks = A.kscale;
+    const float ks = A.kscale * 0.25f;  // pair_mask leaves out four 1/2 factors
     if (c != 0) {
       const cf wl = A.tw1024[c];  // w_1024^row1
 #pragma unroll
@@ -329,10 +340,10 @@ __global__ __launch_bounds__(WAVES * 64, 2) void k_apply_fast(ApplyArgs A) {
       // row 0: bins 32 k2; pairs (k2, 16 - k2), k2 = 1..7; specials k2 = 0 (bins 0, 512), 8 (bin 256)
       {
         cf a = v[0];
-        float y0 = (a.x + a.y) * ((float)kk[0] * ks);
+        float y0 = (a.x + a.y) * ((float)kk[0] * A.kscale);
         float yN = (a.x - a.y) * k512;
         v[0] = {0.5f * (y0 + yN), 0.5f * (y0 - yN)};
-        float m8 = (float)kk[8] * ks;
+        float m8 = (float)kk[8] * A.kscale;
         v[8] = {v[8].x * m8, v[8].y * m8};
       }
 #pragma unroll
@@ -350,17 +361,9 @@ __global__ __launch_bounds__(WAVES * 64, 2) void k_apply_fast(ApplyArgs A) {
     }
   }
   fft512_inv(v, fb, tw512, c);
-  // synthesis window (re-read: keeping 64 window registers live across both FFTs would cost a
-  // wave of occupancy), store the time-domain frame (natural order) into this frame's LDS slice
-  {
-    const float2* wsrc2 = reinterpret_cast<const float2*>(A.win + 2 * c);
-    asm volatile("" : "+v"(wsrc2));  // opaque: do not CSE with the analysis-window loads
+  // synthesis window, store the time-domain frame (natural order) into this frame's LDS slice
 #pragma unroll
-    for (int r = 0; r < 32; ++r) {
-      float2 w2 = wsrc2[16 * r];
-      fb[c + 16 * r] = {v[r].x * w2.x, v[r].y * w2.y};
-    }
-  }
+  for (int r = 0; r < 32; ++r) fb[c + 16 * r] = {v[r].x * wsyn[r].x, v[r].y * wsyn[r].y};
   __syncthreads();
 
   // overlap-add: tile hop j (ext hop hs + j) = sum over tile frames i = j..j+3 of quarter j+3-i
@@ -482,7 +485,7 @@ __global__ __launch_bounds__(WAVES * 64, 2) void k_decide_fast(DecideArgs A) {
   const int tid = threadIdx.x;
   const int lane = tid & 63, wave = tid >> 6;
   const int g = lane >> 4, c = lane & 15;
-  for (int i = tid; i < FN; i += WAVES * 64) tw512[i] = A.tw512[i];
+  for (int i = tid; i < FN; i += WAVES * 64) tw512[i] = A.tw512[(i >> 4) * (i & 15)];
   const Geom& G = A.g;
   const int64_t u = blockIdx.y;
   const int64_t row = (A.view.unit0 + u) / A.view.n_chunks;
