@@ -129,18 +129,21 @@ int sg_filter_padded(sg_handle* h, const void* chunk_dev, int in_dtype, void* ou
 
 /* Replaces TorchGate.forward(x, xn) (torchgate.py:200-264): x (B, L) -> out
  * (B, hop*(L//hop)).  xn_dev may be NULL (statistics from x itself, per row) or a
- * (Bn, Ln) noise batch with Bn in {1, B}. */
+ * (Bn, Ln) noise batch with Bn in {1, B}.
+ * mask_out_dev: NULL, or a float[B][T][FS] buffer (T = sg_n_frames(L), FS = round_up(n_fft/2+1,16))
+ * that receives the final (smoothed) mask, for sg_process_batch_backward. */
 int sg_process_batch(sg_handle* h, const void* x_dev, int dtype, int64_t B, int64_t L,
                      int64_t x_stride, const void* xn_dev, int64_t Bn, int64_t Ln,
                      int64_t xn_stride, void* out_dev, int out_dtype, int64_t out_stride,
-                     void* stream);
+                     float* mask_out_dev, void* stream);
 
-/* Adjoint of sg_process_batch with the mask of the LAST forward call held fixed
- * (TorchGate.forward is differentiable w.r.t. x with the mask detached,
- * torchgate.py:126,167): grad_out (B, Lout) -> grad_x (B, L). */
+/* Adjoint of sg_process_batch with the mask held fixed (TorchGate.forward is differentiable
+ * w.r.t. x with the mask detached, torchgate.py:126,167; the reference gets this from autograd
+ * through torch.stft/istft): grad_out (B, Lout) -> grad_x (B, L), both of sample type `dtype`
+ * (SG_F32 or SG_F64).  mask_dev = the buffer filled by sg_process_batch(mask_out_dev). */
 int sg_process_batch_backward(sg_handle* h, const void* grad_out_dev, int dtype, int64_t B,
-                              int64_t L, int64_t go_stride, void* grad_x_dev,
-                              int64_t gx_stride, void* stream);
+                              int64_t L, int64_t go_stride, const float* mask_dev,
+                              void* grad_x_dev, int64_t gx_stride, void* stream);
 
 /* ---- stage taps (used by the parity tests; also plain STFT/ISTFT operators) ------ */
 

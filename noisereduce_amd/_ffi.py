@@ -58,9 +58,10 @@ _PROTOTYPES = {
     "sg_filter_padded": (c_int, [c_void_p, c_void_p, c_int, c_void_p, c_int, c_int64, c_int64,
                                  c_int64, c_int64, c_void_p]),
     "sg_process_batch": (c_int, [c_void_p, c_void_p, c_int, c_int64, c_int64, c_int64, c_void_p,
-                                 c_int64, c_int64, c_int64, c_void_p, c_int, c_int64, c_void_p]),
+                                 c_int64, c_int64, c_int64, c_void_p, c_int, c_int64, c_void_p,
+                                 c_void_p]),
     "sg_process_batch_backward": (c_int, [c_void_p, c_void_p, c_int, c_int64, c_int64, c_int64,
-                                          c_void_p, c_int64, c_void_p]),
+                                          c_void_p, c_void_p, c_int64, c_void_p]),
     "sg_stft": (c_int, [c_void_p, c_void_p, c_int, c_int64, c_int64, c_int64, c_void_p, c_void_p]),
     "sg_set_option": (c_int, [c_void_p, c_int32, c_int64]),
     "sg_profile_enable": (c_int, [c_void_p, c_int32]),
@@ -260,12 +261,18 @@ class Gate:
         return out
 
     # -- variant T -------------------------------------------------------------------
-    def process_batch(self, x, xn=None, out_dtype=None):
+    def process_batch(self, x, xn=None, out_dtype=None, save_mask=False):
+        """TorchGate.forward.  With save_mask=True also returns the final mask
+        (B, T, FS) float32 needed by process_batch_backward."""
         self._on_device(x)
         x, xs = _rows(x)
         B, L = x.shape
         Lout = self.output_length(L)
         out = torch.empty((B, Lout), dtype=out_dtype or x.dtype, device=self.device)
+        mask = None
+        if save_mask:
+            FS = (self.n_bins + 15) // 16 * 16
+            mask = torch.empty((B, self.n_frames(L), FS), dtype=torch.float32, device=self.device)
         if xn is not None:
             self._on_device(xn)
             if xn.dtype != x.dtype:
@@ -277,8 +284,20 @@ class Gate:
         with torch.cuda.device(self.device):
             self._check(self.lib.sg_process_batch(
                 self._h, x.data_ptr(), _sg_dtype(x), B, L, xs, xn_ptr, Bn, Ln, xns, out.data_ptr(),
-                _sg_dtype(out), Lout, self._stream()))
-        return out
+                _sg_dtype(out), Lout, None if mask is None else mask.data_ptr(), self._stream()))
+        return (out, mask) if save_mask else out
+
+    def process_batch_backward(self, grad_out, mask, L):
+        """Adjoint of process_batch with the mask fixed: (B, Lout) -> (B, L)."""
+        self._on_device(grad_out)
+        grad_out, gs = _rows(grad_out)
+        B = grad_out.shape[0]
+        gx = torch.empty((B, L), dtype=grad_out.dtype, device=self.device)
+        with torch.cuda.device(self.device):
+            self._check(self.lib.sg_process_batch_backward(
+                self._h, grad_out.data_ptr(), _sg_dtype(grad_out), B, L, gs, mask.data_ptr(),
+                gx.data_ptr(), L, self._stream()))
+        return gx
 
     def set_option(self, option, value):
         self._check(self.lib.sg_set_option(self._h, int(option), int(value)))

@@ -884,7 +884,7 @@ extern "C" int sg_filter_padded(sg_handle* h, const void* chunk_dev, int in_dtyp
 // ------------------------------------------------------------------------------------------
 extern "C" int sg_process_batch(sg_handle* h, const void* x_dev, int dtype, int64_t B, int64_t L, int64_t x_stride,
                                 const void* xn_dev, int64_t Bn, int64_t Ln, int64_t xn_stride, void* out_dev,
-                                int out_dtype, int64_t out_stride, void* stream) {
+                                int out_dtype, int64_t out_stride, float* mask_out_dev, void* stream) {
   if (!h) return SG_E_INVALID;
   if (h->p.variant != SG_VARIANT_T) FAIL(h, SG_E_INVALID, "sg_process_batch is a variant-T entry point");
   if (!x_dev || !out_dev || !dtype_ok(dtype) || !dtype_ok(out_dtype) || B < 1)
@@ -944,18 +944,58 @@ extern "C" int sg_process_batch(sg_handle* h, const void* x_dev, int dtype, int6
       if ((rc = stage_nonstat_raw(h, v, g, nb, st))) return rc;
     }
     if ((rc = stage_smooth(h, g, nb, st))) return rc;
+    if (mask_out_dev)
+      HIPCHK(h, hipMemcpyAsync(mask_out_dev + (size_t)u0 * g.T * g.FS, h->M.p, (size_t)nb * g.T * g.FS * 4,
+                               hipMemcpyDeviceToDevice, st));
     if ((rc = stage_apply_ola(h, v, g, nb, (const float*)h->M.p, om, 1, st))) return rc;
     h->dbg_units = nb;
     h->dbg_T = g.T;
     h->dbg_has_P = h->p.stationary != 0;
+    h->dbg_fused = false;
+    h->dbg_fast = false;
   }
   return SG_OK;
 }
 
-extern "C" int sg_process_batch_backward(sg_handle* h, const void*, int, int64_t, int64_t, int64_t, void*, int64_t,
-                                         void*) {
+// Adjoint of y = D^-1 OLA( Ws irfft( M .* rfft( Wa frames(x) ) ) ) with M fixed:
+//   g_x = frames^T( Wa irfft( M .* rfft( Ws frames( D^-1 g_y ) ) ) )
+// (irfft(M .* rfft(.)) is self-adjoint for a real mask; Wa and Ws are the same window up to the
+// 1/N scale), i.e. the forward kernels run on g_y / env with an un-normalised overlap-add.
+extern "C" int sg_process_batch_backward(sg_handle* h, const void* grad_out_dev, int dtype, int64_t B, int64_t L,
+                                         int64_t go_stride, const float* mask_dev, void* grad_x_dev,
+                                         int64_t gx_stride, void* stream) {
   if (!h) return SG_E_INVALID;
-  FAIL(h, SG_E_UNSUPPORTED, "sg_process_batch_backward: not implemented yet");
+  if (h->p.variant != SG_VARIANT_T) FAIL(h, SG_E_INVALID, "sg_process_batch_backward is a variant-T entry point");
+  if (!grad_out_dev || !grad_x_dev || !mask_dev || B < 1 || (dtype != SG_F32 && dtype != SG_F64))
+    FAIL(h, SG_E_INVALID, "sg_process_batch_backward: bad argument");
+  hipStream_t st = (hipStream_t)stream;
+  Geom g = make_geom(h, L);
+  const int64_t Lq = g.Lout;
+  int64_t ub = units_per_batch(h, g, B);
+  int rc = ensure_ws(h, g, ub);
+  if (rc) return rc;
+  if ((rc = ensure(h, h->yn, (size_t)ub * Lq * sizeof(float)))) return rc;
+  for (int64_t u0 = 0; u0 < B; u0 += ub) {
+    const int64_t nb = std::min(ub, B - u0);
+    {
+      dim3 grid((unsigned)((Lq + 255) / 256), (unsigned)nb);
+      const char* src = (const char*)grad_out_dev + (size_t)u0 * go_stride * (dtype == SG_F64 ? 8 : 4);
+      hipLaunchKernelGGL(k_env_scale, grid, dim3(256), 0, st, (const void*)src, dtype, go_stride, g,
+                         (const float*)h->wsq32.p, (float*)h->yn.p, Lq);
+      HIPCHK(h, hipGetLastError());
+    }
+    View v{};
+    v.x = h->yn.p; v.dtype = SG_F32; v.stride = Lq; v.N = Lq; v.lo = 0; v.hi = Lq; v.cs = 0; v.pad = 0; v.Lp = Lq;
+    v.n_chunks = 1; v.unit0 = 0;
+    Geom gb = g;
+    gb.Lout = L;  // the adjoint scatters back onto all L input samples
+    OutMap om{};
+    om.out = (char*)grad_x_dev + (size_t)u0 * gx_stride * (dtype == SG_F64 ? 8 : 4);
+    om.dtype = dtype; om.stride = gx_stride;
+    om.p0 = 0; om.p1 = L; om.g_step = 0; om.g0 = 0; om.g_lo = 0; om.g_hi = L;
+    if ((rc = stage_apply_ola(h, v, gb, nb, mask_dev + (size_t)u0 * g.T * g.FS, om, 0, st))) return rc;
+  }
+  return SG_OK;
 }
 
 // ------------------------------------------------------------------------------------------

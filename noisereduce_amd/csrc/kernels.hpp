@@ -245,6 +245,27 @@ __global__ void k_ola(View view, Geom g, OutMap om, const float* __restrict__ se
   store_sample(om.out, om.dtype, row * om.stride + gi - om.g0, val);
 }
 
+// gq[b][p] = g[b][p] / env(p), p < Lout (0 beyond): first step of the adjoint of the ISTFT
+// normalisation (env = sum of window^2 over the frames covering p, guarded like the forward).
+__global__ void k_env_scale(const void* __restrict__ gsrc, int dtype, int64_t stride, Geom g,
+                            const float* __restrict__ wsq, float* __restrict__ gq, int64_t Lq) {
+  const int64_t b = blockIdx.y;
+  const int64_t p = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (p >= Lq) return;
+  float val = 0.f;
+  if (p < g.Lout) {
+    const int64_t e = p + g.padL;
+    int64_t t_hi = e / g.H;
+    if (t_hi > g.T - 1) t_hi = g.T - 1;
+    int64_t t_lo = (e - g.n + g.H) / g.H;
+    if (e - g.n + 1 <= 0) t_lo = 0;
+    float norm = 0.f;
+    for (int64_t t = t_lo; t <= t_hi; ++t) norm += wsq[(int)(e - t * g.H)];
+    val = (float)load_sample(gsrc, dtype, b * stride + p) / (norm > 1e-10f ? norm : 1.0f);
+  }
+  gq[b * Lq + p] = val;
+}
+
 // ---------------------------------------------------------------------------------------
 // Per-band statistics over time (lanes = bins).  block = 64 bins x TG time groups.
 // ---------------------------------------------------------------------------------------

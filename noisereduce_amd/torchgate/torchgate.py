@@ -17,16 +17,19 @@ class _GateFunction(torch.autograd.Function):
     @staticmethod
     def forward(ctx, x, xn, module):
         gate = module._gate_for(x.device)
-        y = gate.process_batch(x, xn)
-        if x.requires_grad:
+        if ctx.needs_input_grad[0]:
+            y, mask = gate.process_batch(x.detach(), xn, save_mask=True)
             ctx.gate = gate
             ctx.L = x.shape[-1]
-            ctx.mask = gate.save_mask()
+            ctx.save_for_backward(mask)
+        else:
+            y = gate.process_batch(x, xn)
         return y
 
     @staticmethod
     def backward(ctx, grad_out):
-        gx = ctx.gate.process_batch_backward(grad_out.contiguous(), ctx.mask, ctx.L)
+        (mask,) = ctx.saved_tensors
+        gx = ctx.gate.process_batch_backward(grad_out.contiguous(), mask, ctx.L)
         return gx, None, None
 
 

