@@ -77,22 +77,34 @@ def main():
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     if world != args.gpus:
         raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}: launch with torch.distributed.run")
-    torch.cuda.set_device(local_rank)
-    device = torch.device("cuda", local_rank)
+    # BENCH_BACKEND=gloo lets the multi-rank code path be exercised on a box with fewer GPUs than
+    # ranks (ranks share devices; RCCL itself refuses that) -- a functional check, not a measurement.
+    backend = os.environ.get("BENCH_BACKEND", "nccl")
+    ndev = torch.cuda.device_count()
+    dev_index = local_rank if backend == "nccl" else local_rank % max(ndev, 1)
+    torch.cuda.set_device(dev_index)
+    device = torch.device("cuda", dev_index)
     if world > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group("nccl", device_id=device)
+        if backend == "nccl":
+            dist.init_process_group("nccl", device_id=device)
+        else:
+            dist.init_process_group(backend)
 
     import __graft_entry__
     if rank == 0:
         __graft_entry__.build()
     if world > 1:
         dist.barrier()
-    from noisereduce_amd.sharded import HipStationaryBackend, TimeShardedStationary, with_halos
+    from noisereduce_amd.sharded import HipStationaryBackend, TimeShardedStationary, alloc_shard, with_halos
     from noisereduce_amd.spectralgate.nonstationary import SpectralGateNonStationary
 
     # this rank's time shard of the (world x 10 min) recording
-    y = synth_on_device(N_PER_GPU, 1234 + rank, device, offset=rank * N_PER_GPU)
+    # (allocated inside a halo-extended buffer so that the seam exchange writes 2*padding samples
+    # per step instead of re-copying the shard)
+    y_ext, y2d = alloc_shard(1, N_PER_GPU, PAD, torch.float32, device)
+    y2d[0].copy_(synth_on_device(N_PER_GPU, 1234 + rank, device, offset=rank * N_PER_GPU))
+    y = y2d[0]
     stationary = not args.nonstationary
 
     def make_gate():
@@ -106,19 +118,19 @@ def main():
             prop_decrease=1.0, use_tqdm=False, n_jobs=1, device=device)
 
     def gate_of(sg):
-        return sg.backend._gate(y[None, :], False) if stationary else sg._gate
+        return sg.backend._gate(y2d, False) if stationary else sg._gate
 
     def step():
         # one whole reduce_noise: (statistics + threshold broadcast) + seam exchange + chunk grid.
         # The engine handle (tables + workspace) is cached across calls by noisereduce_amd._ffi.
         sg = make_gate()
         if stationary:
-            out = sg.run(y)
+            out = sg.run(y2d, ext=y_ext if world > 1 else None)
         else:
             gate = sg._gate
-            ext = with_halos(y[None, :], PAD) if world > 1 else None
+            ext = with_halos(y2d, PAD, ext=y_ext) if world > 1 else None
             if ext is None:
-                out = gate.process_chunks(y[None, :], chunked=True)
+                out = gate.process_chunks(y2d, chunked=True)
             else:
                 out = gate.process_chunks(ext, out_dtype=y.dtype, chunked=True, halo_left=PAD,
                                           halo_right=PAD)

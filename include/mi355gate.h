@@ -101,6 +101,10 @@ int sg_noise_stats(sg_handle* h, const void* noise_dev, int dtype, int64_t C, in
  * sg_get_noise_threshold synchronises the stream. */
 int sg_get_noise_threshold(sg_handle* h, double* thresh_host, int32_t n_bins, void* stream);
 int sg_set_noise_threshold(sg_handle* h, const double* thresh_host, int32_t n_bins, void* stream);
+/* Device-to-device forms (asynchronous on `stream`, no host synchronisation): used to broadcast
+ * the threshold between ranks with RCCL. */
+int sg_get_noise_threshold_dev(sg_handle* h, double* thresh_dev, int32_t n_bins, void* stream);
+int sg_set_noise_threshold_dev(sg_handle* h, const double* thresh_dev, int32_t n_bins, void* stream);
 
 /* Replaces SpectralGate.get_traces + filter_chunk + _read_chunk + _do_filter for a whole
  * (C, N) planar recording that already lives in HBM (base.py:130-226): the reference's

@@ -52,6 +52,8 @@ _PROTOTYPES = {
     "sg_noise_stats": (c_int, [c_void_p, c_void_p, c_int, c_int64, c_int64, c_int64, c_void_p]),
     "sg_get_noise_threshold": (c_int, [c_void_p, POINTER(c_double), c_int32, c_void_p]),
     "sg_set_noise_threshold": (c_int, [c_void_p, POINTER(c_double), c_int32, c_void_p]),
+    "sg_get_noise_threshold_dev": (c_int, [c_void_p, c_void_p, c_int32, c_void_p]),
+    "sg_set_noise_threshold_dev": (c_int, [c_void_p, c_void_p, c_int32, c_void_p]),
     "sg_process_chunks": (c_int, [c_void_p, c_void_p, c_int, c_void_p, c_int, c_int64, c_int64,
                                   c_int64, c_int64, c_int64, c_int64, c_int32, c_int64, c_int64,
                                   c_void_p]),
@@ -228,6 +230,21 @@ class Gate:
         with torch.cuda.device(self.device):
             self._check(self.lib.sg_set_noise_threshold(
                 self._h, t.ctypes.data_as(POINTER(c_double)), int(t.shape[0]), self._stream()))
+
+    def noise_threshold_tensor(self):
+        """The threshold as a float64 device tensor (no host synchronisation)."""
+        t = torch.empty(self.n_bins, dtype=torch.float64, device=self.device)
+        with torch.cuda.device(self.device):
+            self._check(self.lib.sg_get_noise_threshold_dev(self._h, t.data_ptr(), self.n_bins,
+                                                            self._stream()))
+        return t
+
+    def set_noise_threshold_tensor(self, t):
+        self._on_device(t)
+        t = t.to(torch.float64).contiguous()
+        with torch.cuda.device(self.device):
+            self._check(self.lib.sg_set_noise_threshold_dev(self._h, t.data_ptr(), int(t.numel()),
+                                                            self._stream()))
 
     def process_chunks(self, x, out_dtype=None, start_frame=0, end_frame=None, chunked=True,
                        out=None, halo_left=0, halo_right=0):

@@ -15,6 +15,10 @@
 #include "kernels.hpp"
 #include "fused.hpp"
 
+#ifndef SG_APPLY_WAVES
+#define SG_APPLY_WAVES 4  // wavefronts per workgroup of k_apply_fast: tile = 4*W frames -> 4*W-3 hops
+#endif
+
 using namespace sg;
 
 namespace {
@@ -702,7 +706,7 @@ static int stage_fused_mask(sg_handle* h, const View& v, const Geom& g, int64_t 
 static int stage_apply_fast(sg_handle* h, const View& v, const Geom& g, int64_t ub, const OutMap& om,
                             hipStream_t st) {
   ProfScope ps(h, SG_STAGE_APPLY_FAST, st);
-  constexpr int WAVES = 4;
+  constexpr int WAVES = SG_APPLY_WAVES;
   fast::ApplyArgs A;
   A.view = v; A.g = g; A.om = om;
   A.K = (const unsigned short*)h->K16.p;
@@ -823,6 +827,24 @@ extern "C" int sg_set_noise_threshold(sg_handle* h, const double* thresh_host, i
   HIPCHK(h, hipMemcpyAsync(h->thresh.p, thresh_host, (size_t)h->F * sizeof(double), hipMemcpyHostToDevice,
                            (hipStream_t)stream));
   HIPCHK(h, hipStreamSynchronize((hipStream_t)stream));
+  h->has_thresh = true;
+  return SG_OK;
+}
+
+extern "C" int sg_get_noise_threshold_dev(sg_handle* h, double* thresh_dev, int32_t n_bins, void* stream) {
+  if (!h) return SG_E_INVALID;
+  if (!thresh_dev || n_bins != h->F) FAIL(h, SG_E_INVALID, "sg_get_noise_threshold_dev: n_bins must be %d", h->F);
+  if (!h->has_thresh) FAIL(h, SG_E_STATE, "no noise threshold set");
+  HIPCHK(h, hipMemcpyAsync(thresh_dev, h->thresh.p, (size_t)h->F * sizeof(double), hipMemcpyDeviceToDevice,
+                           (hipStream_t)stream));
+  return SG_OK;
+}
+
+extern "C" int sg_set_noise_threshold_dev(sg_handle* h, const double* thresh_dev, int32_t n_bins, void* stream) {
+  if (!h) return SG_E_INVALID;
+  if (!thresh_dev || n_bins != h->F) FAIL(h, SG_E_INVALID, "sg_set_noise_threshold_dev: n_bins must be %d", h->F);
+  HIPCHK(h, hipMemcpyAsync(h->thresh.p, thresh_dev, (size_t)h->F * sizeof(double), hipMemcpyDeviceToDevice,
+                           (hipStream_t)stream));
   h->has_thresh = true;
   return SG_OK;
 }

@@ -25,9 +25,19 @@ __global__ void k_unit_absmax(View view, int64_t n_units, unsigned* __restrict__
   const int64_t row = (view.unit0 + u) / view.n_chunks;
   const int64_t chunk = (view.unit0 + u) % view.n_chunks;
   float m = 0.f;
-  for (int64_t s = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; s < view.Lp;
-       s += (int64_t)gridDim.x * blockDim.x)
-    m = fmaxf(m, fabsf((float)view_sample(view, row, chunk, s)));
+  // the unit's window clipped to the readable part of the row (everything else is zero)
+  const int64_t g0 = chunk * view.cs - view.pad;
+  const int64_t s_lo = max<int64_t>(0, view.lo - g0), s_hi = min<int64_t>(view.Lp, view.hi - g0);
+  if (view.dtype == 0) {
+    const float* src = (const float*)view.x + row * view.stride + g0;
+    for (int64_t s = s_lo + (int64_t)blockIdx.x * blockDim.x + threadIdx.x; s < s_hi;
+         s += (int64_t)gridDim.x * blockDim.x)
+      m = fmaxf(m, fabsf(src[s]));
+  } else {
+    for (int64_t s = s_lo + (int64_t)blockIdx.x * blockDim.x + threadIdx.x; s < s_hi;
+         s += (int64_t)gridDim.x * blockDim.x)
+      m = fmaxf(m, fabsf((float)view_sample(view, row, chunk, s)));
+  }
   // float(double) rounds to nearest: inflate by one ulp so the bound stays an upper bound
   m = m * 1.0000002f;
   for (int off = 32; off > 0; off >>= 1) m = fmaxf(m, __shfl_xor(m, off));

@@ -53,12 +53,26 @@ def exchange_seams(y_local, padding, group=None):
     return left, right
 
 
-def with_halos(y_local, padding, group=None):
-    """(C, padding + S + padding) buffer: [left halo | shard | right halo]."""
+def with_halos(y_local, padding, group=None, ext=None):
+    """(C, padding + S + padding) buffer: [left halo | shard | right halo].  If `ext` is given it
+    must be that buffer with the shard already in its middle (see alloc_shard): only the two halo
+    strips are written, no copy of the shard."""
     if padding == 0:
         return y_local
     left, right = exchange_seams(y_local, padding, group)
-    return torch.cat([left, y_local, right], dim=1)
+    if ext is None:
+        return torch.cat([left, y_local, right], dim=1)
+    S = y_local.shape[1]
+    ext[:, :padding].copy_(left)
+    ext[:, padding + S:].copy_(right)
+    return ext
+
+
+def alloc_shard(channels, shard_len, padding, dtype, device):
+    """Allocate a rank's shard inside a halo-extended buffer.  Returns (ext, shard) where shard is
+    the (channels, shard_len) view to fill with this rank's samples."""
+    ext = torch.zeros((channels, shard_len + 2 * padding), dtype=dtype, device=device)
+    return ext, ext[:, padding:padding + shard_len]
 
 
 class HipStationaryBackend:
@@ -104,14 +118,14 @@ class HipStationaryBackend:
         return self._gate(y_local, True)
 
     def threshold(self, y_local):
-        """Per-band threshold (dB) as a device tensor, for the broadcast."""
-        return torch.from_numpy(self.stats(y_local).get_noise_threshold()).to(y_local.device)
+        """Per-band threshold (dB) as a device tensor, for the broadcast (no host sync)."""
+        return self.stats(y_local).noise_threshold_tensor()
 
     def filter(self, y_local, ext, halo, thresh, owner):
         """Filter the shard.  `ext` is the halo-extended buffer (or y_local when halo == 0)."""
         g = self._gate(y_local, False)
         if not owner:
-            g.set_noise_threshold(thresh.cpu().numpy())
+            g.set_noise_threshold_tensor(thresh)
         S = y_local.shape[1]
         if halo == 0 and ext is y_local:
             return g.process_chunks(y_local, chunked=S > self.chunk_size)
@@ -131,7 +145,9 @@ class TimeShardedStationary:
         self.ws = dist.get_world_size(group) if dist.is_initialized() else 1
         self.rank = dist.get_rank(group) if dist.is_initialized() else 0
 
-    def run(self, y_local):
+    def run(self, y_local, ext=None):
+        """y_local: this rank's (C, S) shard.  ext: optional halo-extended buffer that already
+        holds the shard in its middle (alloc_shard) -- avoids copying the shard every call."""
         if y_local.dim() == 1:
             y_local = y_local[None, :]
         pad, cs = self.backend.padding, self.backend.chunk_size
@@ -149,7 +165,7 @@ class TimeShardedStationary:
             thr = torch.zeros(self.n_bins, dtype=torch.float64, device=y_local.device)
         if self.ws > 1:
             dist.broadcast(thr, src=0, group=self.group)
-            ext = with_halos(y_local, pad, self.group)
+            ext = with_halos(y_local, pad, self.group, ext)
             halo = pad
         else:
             ext, halo = y_local, 0
