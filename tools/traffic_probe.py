@@ -1,0 +1,16 @@
+"""Workload for the HBM-traffic PMC passes: a calibration copy of known size, then reduce_noise
+steps of the bench workload (configs[1])."""
+import os, sys, torch
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+import bench
+import noisereduce_amd as nr
+dev = torch.device("cuda", 0)
+cal = torch.empty(1 << 28, dtype=torch.float32, device=dev).normal_()   # 1 GiB
+for _ in range(3):
+    c2 = cal.clone()                                                   # reads 1 GiB, writes 1 GiB
+torch.cuda.synchronize()
+y = bench.synth_on_device(bench.N_PER_GPU, 1234, dev)
+for _ in range(4):
+    out = nr.reduce_noise(y=y, sr=48000, stationary=True)
+torch.cuda.synchronize()
