@@ -53,7 +53,7 @@ struct sg_handle {
   DevBuf P, pmax, thr_rows, raw, M, seg, yn;
   DevBuf bits, K16, umax, need, T2;  // fused stationary path
   DevBuf part;                       // partial reductions of the column statistics
-  DevBuf tw512, invn;                // fast path tables (n_fft = 1024, hop = 256)
+  DevBuf tw512, invn, perm;          // fast path tables (n_fft = 1024, hop = 256)
   bool fast_ok = false;              // default geometry: fused apply kernel available
   bool force_nofast = false;
   bool force_f64_decide = false;     // SG_OPT_FORCE_F64_DECIDE: float64 STFT for every mask decision
@@ -398,6 +398,9 @@ extern "C" int sg_create(const sg_params* p, const double* window_host, sg_handl
     }
     rc = upload(h, h->tw512, t512.data(), t512.size() * sizeof(cx<float>));
     if (!rc) rc = upload(h, h->invn, invn.data(), invn.size() * sizeof(float));
+    std::vector<int> perm(h->FS, 0);
+    for (int f = 0; f < h->F; ++f) perm[f] = fast::perm_pos(f);
+    if (!rc) rc = upload(h, h->perm, perm.data(), perm.size() * sizeof(int));
     h->fast_ok = true;
   }
   if (!rc) rc = ensure(h, h->thresh, (size_t)h->FS * sizeof(double));
@@ -417,7 +420,7 @@ extern "C" int sg_destroy(sg_handle* h) {
   for (auto e : h->prof_pool) (void)hipEventDestroy(e);
   for (DevBuf* b : {&h->tw64, &h->tw32, &h->wfull64, &h->wa32, &h->ws32, &h->wsq32, &h->kf, &h->kt, &h->thresh,
                     &h->P, &h->pmax, &h->thr_rows, &h->raw, &h->M, &h->seg, &h->yn, &h->bits, &h->K16, &h->umax,
-                    &h->need, &h->T2, &h->part, &h->tw512, &h->invn})
+                    &h->need, &h->T2, &h->part, &h->tw512, &h->invn, &h->perm})
     free_buf(*b);
   delete h;
   return SG_OK;
@@ -541,13 +544,13 @@ static int stage_nonstat_raw(sg_handle* h, const View& v, const Geom& g, int64_t
   return SG_OK;
 }
 
-static int stage_smooth(sg_handle* h, const Geom& g, int64_t ub, hipStream_t st) {
+static int stage_smooth(sg_handle* h, const Geom& g, int64_t ub, const int* perm, hipStream_t st) {
   ProfScope ps(h, SG_STAGE_SMOOTH, st);
   int64_t cells = ub * g.T * g.FS;
   float p = (float)h->p.prop_decrease;
   if (!h->p.smooth_mask) {
     hipLaunchKernelGGL(k_prop_only, dim3(grid_1d(cells, 256)), dim3(256), 0, st, (const float*)h->raw.p, g, p,
-                       (float*)h->M.p, ub);
+                       (float*)h->M.p, ub, perm);
     HIPCHK(h, hipGetLastError());
     return SG_OK;
   }
@@ -560,7 +563,7 @@ static int stage_smooth(sg_handle* h, const Geom& g, int64_t ub, hipStream_t st)
   int prop_before = (h->p.variant == SG_VARIANT_T || h->p.stationary) ? 1 : 0;
   hipLaunchKernelGGL(k_smooth_t, dim3(grid_1d(cells, 256)), dim3(256), 0, st, (const float*)tmp, g,
                      (const float*)h->kt.p, h->p.n_grad_time, (const float*)h->kf.p, h->p.n_grad_freq, p,
-                     prop_before, (float*)h->M.p, ub);
+                     prop_before, (float*)h->M.p, ub, perm);
   HIPCHK(h, hipGetLastError());
   return SG_OK;
 }
@@ -585,7 +588,7 @@ static int stage_apply_ola(sg_handle* h, const View& v, const Geom& g, int64_t u
 
 // Fused stationary mask (variant S): STFT(f64) -> bits -> integer smoothing -> K16 -> float mask.
 static int stage_fused_mask(sg_handle* h, const View& v, const Geom& g, int64_t ub, bool fast, int64_t tb,
-                            int64_t te, hipStream_t st) {
+                            int64_t te, const int* perm, hipStream_t st) {
   // [tb, te): frames whose smoothed mask is needed; decisions are needed nt frames further out
   const int64_t nt_halo = h->p.smooth_mask ? h->p.n_grad_time : 0;
   const int64_t db = std::max<int64_t>(0, tb - nt_halo), de = std::min<int64_t>(g.T, te + nt_halo);
@@ -697,36 +700,46 @@ static int stage_fused_mask(sg_handle* h, const View& v, const Geom& g, int64_t 
   if (fast) return SG_OK;  // the fused apply kernel reads K directly
   hipLaunchKernelGGL(k_k16_to_mask, dim3(grid_1d(cells, 256)), dim3(256), 0, st, (const unsigned short*)h->K16.p,
                      g, nf, nt, 1.0f / (float)h->ktot, (float)h->p.prop_decrease, 1, h->p.smooth_mask ? 1 : 0,
-                     (float*)h->M.p, ub);
+                     (float*)h->M.p, ub, perm);
   HIPCHK(h, hipGetLastError());
   return SG_OK;
 }
 
 // Fused apply (default geometry): FFT -> mask(K) -> IFFT -> overlap-add -> output, one kernel.
 static int stage_apply_fast(sg_handle* h, const View& v, const Geom& g, int64_t ub, const OutMap& om,
+                            const float* mask_f /* nullptr: uint16 counts in h->K16 */, int normalize,
                             hipStream_t st) {
   ProfScope ps(h, SG_STAGE_APPLY_FAST, st);
   constexpr int WAVES = SG_APPLY_WAVES;
   fast::ApplyArgs A;
   A.view = v; A.g = g; A.om = om;
   A.K = (const unsigned short*)h->K16.p;
+  A.Mf = mask_f;
+  A.normalize = normalize;
   A.win = (const float*)h->wa32.p;
   A.wsq = (const float*)h->wsq32.p;
   A.invn = (const float*)h->invn.p;
   A.tw512 = (const fast::cf*)h->tw512.p;
   A.tw1024 = (const fast::cf*)h->tw32.p;
-  A.kscale = (float)(1.0 / ((double)h->ktot * 512.0));
+  A.kscale = mask_f ? (float)(1.0 / 512.0) : (float)(1.0 / ((double)h->ktot * 512.0));
   A.h_begin = (om.p0 + g.padL) / 256;
   A.h_end = (om.p1 - 1 + g.padL) / 256 + 1;
   const int64_t nh = A.h_end - A.h_begin;
   if (nh <= 0) return SG_OK;
   constexpr int NH = 4 * WAVES - 3;
   size_t lds = (size_t)(fast::FN + WAVES * fast::WAVE_CX) * sizeof(fast::cf);
-  auto kern = fast::k_apply_fast<WAVES>;
-  HIPCHK(h, hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize,
-                                (int)lds));
   dim3 grid((unsigned)((nh + NH - 1) / NH), (unsigned)ub);
-  hipLaunchKernelGGL(kern, grid, dim3(WAVES * 64), lds, st, A);
+  if (mask_f) {
+    auto kern = fast::k_apply_fast<WAVES, false>;
+    HIPCHK(h, hipFuncSetAttribute(reinterpret_cast<const void*>(kern),
+                                  hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+    hipLaunchKernelGGL(kern, grid, dim3(WAVES * 64), lds, st, A);
+  } else {
+    auto kern = fast::k_apply_fast<WAVES, true>;
+    HIPCHK(h, hipFuncSetAttribute(reinterpret_cast<const void*>(kern),
+                                  hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+    hipLaunchKernelGGL(kern, grid, dim3(WAVES * 64), lds, st, A);
+  }
   HIPCHK(h, hipGetLastError());
   return SG_OK;
 }
@@ -745,19 +758,22 @@ static int run_S(sg_handle* h, View v, int64_t total_units, const OutMap& om, hi
     int64_t nb = std::min(ub, total_units - u0);
     v.unit0 = u0;
     const bool fused = h->fused_ok && !h->force_unfused;
-    const bool fast = fused && h->fast_ok && !h->force_nofast && h->p.prop_decrease == 1.0;
+    const bool geom_fast = h->fast_ok && !h->force_nofast;  // default geometry: fused apply kernel
+    const bool fast = fused && geom_fast && h->p.prop_decrease == 1.0;
     if (fast) {
       // frames the fused apply kernel touches: hops [h_begin, h_end) need frames h-3 .. h
       const int64_t hb = (om.p0 + g.padL) / 256, he = (om.p1 - 1 + g.padL) / 256 + 1;
       const int64_t tb = std::max<int64_t>(0, hb - 3), te = std::min<int64_t>(g.T, he);
-      if ((rc = stage_fused_mask(h, v, g, nb, true, tb, std::max(te, tb + 1), st))) return rc;
-      if ((rc = stage_apply_fast(h, v, g, nb, om, st))) return rc;
+      if ((rc = stage_fused_mask(h, v, g, nb, true, tb, std::max(te, tb + 1), nullptr, st))) return rc;
+      if ((rc = stage_apply_fast(h, v, g, nb, om, nullptr, 1, st))) return rc;
       h->dbg_units = nb; h->dbg_T = g.T; h->dbg_has_P = false; h->dbg_fused = true; h->dbg_fast = true;
       continue;
     }
-    h->dbg_fast = false;
+    // float mask field (natural bin order for the general apply kernels, lane order for the fused one)
+    const int* perm = geom_fast ? (const int*)h->perm.p : nullptr;
+    h->dbg_fast = geom_fast;
     if (fused) {
-      if ((rc = stage_fused_mask(h, v, g, nb, false, 0, g.T, st))) return rc;
+      if ((rc = stage_fused_mask(h, v, g, nb, false, 0, g.T, perm, st))) return rc;
     } else {
       if (h->p.stationary) {
         if ((rc = stage_power(h, v, g, nb, st))) return rc;
@@ -765,9 +781,13 @@ static int run_S(sg_handle* h, View v, int64_t total_units, const OutMap& om, hi
       } else {
         if ((rc = stage_nonstat_raw(h, v, g, nb, st))) return rc;
       }
-      if ((rc = stage_smooth(h, g, nb, st))) return rc;
+      if ((rc = stage_smooth(h, g, nb, perm, st))) return rc;
     }
-    if ((rc = stage_apply_ola(h, v, g, nb, (const float*)h->M.p, om, 1, st))) return rc;
+    if (geom_fast) {
+      if ((rc = stage_apply_fast(h, v, g, nb, om, (const float*)h->M.p, 1, st))) return rc;
+    } else {
+      if ((rc = stage_apply_ola(h, v, g, nb, (const float*)h->M.p, om, 1, st))) return rc;
+    }
     h->dbg_units = nb;
     h->dbg_T = g.T;
     h->dbg_has_P = h->p.stationary != 0 && !fused;
@@ -965,16 +985,21 @@ extern "C" int sg_process_batch(sg_handle* h, const void* x_dev, int dtype, int6
     } else {
       if ((rc = stage_nonstat_raw(h, v, g, nb, st))) return rc;
     }
-    if ((rc = stage_smooth(h, g, nb, st))) return rc;
-    if (mask_out_dev)
+    const bool geom_fast = h->fast_ok && !h->force_nofast;
+    if ((rc = stage_smooth(h, g, nb, geom_fast ? (const int*)h->perm.p : nullptr, st))) return rc;
+    if (mask_out_dev)  // kept in whatever bin order this handle's apply kernel reads
       HIPCHK(h, hipMemcpyAsync(mask_out_dev + (size_t)u0 * g.T * g.FS, h->M.p, (size_t)nb * g.T * g.FS * 4,
                                hipMemcpyDeviceToDevice, st));
-    if ((rc = stage_apply_ola(h, v, g, nb, (const float*)h->M.p, om, 1, st))) return rc;
+    if (geom_fast) {
+      if ((rc = stage_apply_fast(h, v, g, nb, om, (const float*)h->M.p, 1, st))) return rc;
+    } else {
+      if ((rc = stage_apply_ola(h, v, g, nb, (const float*)h->M.p, om, 1, st))) return rc;
+    }
     h->dbg_units = nb;
     h->dbg_T = g.T;
     h->dbg_has_P = h->p.stationary != 0;
     h->dbg_fused = false;
-    h->dbg_fast = false;
+    h->dbg_fast = geom_fast;
   }
   return SG_OK;
 }
@@ -1015,7 +1040,12 @@ extern "C" int sg_process_batch_backward(sg_handle* h, const void* grad_out_dev,
     om.out = (char*)grad_x_dev + (size_t)u0 * gx_stride * (dtype == SG_F64 ? 8 : 4);
     om.dtype = dtype; om.stride = gx_stride;
     om.p0 = 0; om.p1 = L; om.g_step = 0; om.g0 = 0; om.g_lo = 0; om.g_hi = L;
-    if ((rc = stage_apply_ola(h, v, gb, nb, mask_dev + (size_t)u0 * g.T * g.FS, om, 0, st))) return rc;
+    const float* mk = mask_dev + (size_t)u0 * g.T * g.FS;
+    if (h->fast_ok && !h->force_nofast) {
+      if ((rc = stage_apply_fast(h, v, gb, nb, om, mk, 0, st))) return rc;
+    } else {
+      if ((rc = stage_apply_ola(h, v, gb, nb, mk, om, 0, st))) return rc;
+    }
   }
   return SG_OK;
 }
@@ -1109,7 +1139,7 @@ extern "C" int sg_debug_fetch(sg_handle* h, int32_t what, void* host, int64_t by
       if (!h->dbg_fused) FAIL(h, SG_E_STATE, "bit field only exists on the fused path");
       src = h->bits.p; need = (size_t)h->dbg_units * h->dbg_T * ((h->F + 63) / 64) * 8; break;
     case 1:
-      if (h->dbg_fast) FAIL(h, SG_E_STATE, "fast path keeps the smoothed mask as permuted uint16 counts");
+      if (h->dbg_fast) FAIL(h, SG_E_STATE, "fast path keeps the smoothed mask in the apply kernel's lane order");
       src = h->M.p; need = cells * 4; break;
     case 2:
       if (!h->dbg_has_P) FAIL(h, SG_E_STATE, "power field only exists for stationary gates");

@@ -218,7 +218,8 @@ struct ApplyArgs {
   View view;
   Geom g;
   OutMap om;
-  const unsigned short* K;  // permuted mask counts [units][T][FSK]
+  const unsigned short* K;  // permuted mask counts [units][T][FSK]            (KMASK = true)
+  const float* Mf;          // permuted float mask  [units][T][FSK]            (KMASK = false)
   const float* win;         // analysis == synthesis window (1024)
   const float* wsq;         // window squared (1024)
   const float* invn;        // 1 / sum_q wsq[256 q + s], s < 256 (interior hops)
@@ -227,13 +228,14 @@ struct ApplyArgs {
   float kscale;             // prop_decrease-free mask scale: 1 / (ktot * 512)
   int64_t h_begin;          // first ext hop (256-sample block, ext = unit sample + 512) to produce
   int64_t h_end;
+  int normalize;            // 1: divide by the window envelope (ISTFT); 0: plain overlap-add (adjoint)
 };
 
 // ---------------------------------------------------------------------------------------
 // Fused apply: frames -> FFT -> x mask -> IFFT -> window -> overlap-add -> output samples.
 // One workgroup = WAVES wavefronts = 4*WAVES consecutive frames of one unit -> 4*WAVES-3 hops.
 // ---------------------------------------------------------------------------------------
-template <int WAVES>
+template <int WAVES, bool KMASK>
 __global__ __launch_bounds__(WAVES * 64, 2) void k_apply_fast(ApplyArgs A) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
   cf* tw512 = reinterpret_cast<cf*>(smem);
@@ -252,11 +254,12 @@ __global__ __launch_bounds__(WAVES * 64, 2) void k_apply_fast(ApplyArgs A) {
   const int64_t t = hs - 3 + 4 * wave + g;                   // this lane group's frame
   const bool fvalid = t >= 0 && t < G.T;
 
-  // mask counts of this lane's 32 bins (+ bin 512 for lane c == 0), permuted layout; issued first:
-  // they are consumed only after the forward transform
-  unsigned short kk[32];
+  // mask of this lane's 32 bins (+ bin 512 for lane c == 0), permuted layout; issued first: it is
+  // consumed only after the forward transform.  KMASK: uint16 counts (mask = K / ktot).
+  unsigned short kk[KMASK ? 32 : 1];
+  float mf[KMASK ? 1 : 32];
   float k512 = 0.f;
-  {
+  if constexpr (KMASK) {
     const unsigned short* Krow = A.K + ((u * G.T + (fvalid ? t : 0)) * (int64_t)FSK);
     const uint4* p4 = reinterpret_cast<const uint4*>(Krow + c * 32);
 #pragma unroll
@@ -270,8 +273,20 @@ __global__ __launch_bounds__(WAVES * 64, 2) void k_apply_fast(ApplyArgs A) {
       }
     }
     k512 = (float)Krow[512] * A.kscale;
+  } else {
+    const float* Mrow = A.Mf + ((u * G.T + (fvalid ? t : 0)) * (int64_t)FSK);
+    const float4* p4 = reinterpret_cast<const float4*>(Mrow + c * 32);
+#pragma unroll
+    for (int q = 0; q < 8; ++q) {
+      float4 w4 = p4[q];
+      mf[4 * q] = w4.x; mf[4 * q + 1] = w4.y; mf[4 * q + 2] = w4.z; mf[4 * q + 3] = w4.w;
+    }
+    k512 = Mrow[512] * A.kscale;
   }
-
+  auto mval = [&](int q, float scale) -> float {
+    if constexpr (KMASK) return (float)kk[q] * scale;
+    else return mf[q] * scale;
+  };
   cf* fb = regions + wave * WAVE_CX + frame_base(g);
   // gather the frame: v[r] = (x[2c + 32r], x[2c + 32r + 1]) * window
   cf v[32];
@@ -334,29 +349,29 @@ __global__ __launch_bounds__(WAVES * 64, 2) void k_apply_fast(ApplyArgs A) {
       for (int k2 = 0; k2 < 16; ++k2) {
         // bins k = c + 32 k2 (v[k2]) and 512 - k = row2 + 32 (15 - k2) (v[16 + 15 - k2])
         cf w = k2 == 0 ? wl : mul_tw<false>(wl, twc<32>(k2), tws<32>(k2));
-        pair_mask(v[k2], v[31 - k2], w, (float)kk[k2] * ks, (float)kk[31 - k2] * ks);
+        pair_mask(v[k2], v[31 - k2], w, mval(k2, ks), mval(31 - k2, ks));
       }
     } else {
       // row 0: bins 32 k2; pairs (k2, 16 - k2), k2 = 1..7; specials k2 = 0 (bins 0, 512), 8 (bin 256)
       {
         cf a = v[0];
-        float y0 = (a.x + a.y) * ((float)kk[0] * A.kscale);
+        float y0 = (a.x + a.y) * mval(0, A.kscale);
         float yN = (a.x - a.y) * k512;
         v[0] = {0.5f * (y0 + yN), 0.5f * (y0 - yN)};
-        float m8 = (float)kk[8] * A.kscale;
+        float m8 = mval(8, A.kscale);
         v[8] = {v[8].x * m8, v[8].y * m8};
       }
 #pragma unroll
       for (int k2 = 1; k2 < 8; ++k2) {
         cf w = {twc<32>(k2), -tws<32>(k2)};  // w_1024^(32 k2) = w_32^k2
-        pair_mask(v[k2], v[16 - k2], w, (float)kk[k2] * ks, (float)kk[16 - k2] * ks);
+        pair_mask(v[k2], v[16 - k2], w, mval(k2, ks), mval(16 - k2, ks));
       }
       // row 16: bins 16 + 32 j; pairs (j, 15 - j), j = 0..7
       const cf w16 = A.tw1024[16];
 #pragma unroll
       for (int j = 0; j < 8; ++j) {
         cf w = j == 0 ? w16 : mul_tw<false>(w16, twc<32>(j), tws<32>(j));
-        pair_mask(v[16 + j], v[31 - j], w, (float)kk[16 + j] * ks, (float)kk[31 - j] * ks);
+        pair_mask(v[16 + j], v[31 - j], w, mval(16 + j, ks), mval(31 - j, ks));
       }
     }
   }
@@ -387,7 +402,9 @@ __global__ __launch_bounds__(WAVES * 64, 2) void k_apply_fast(ApplyArgs A) {
         all_valid = false;
       }
     }
-    if (all_valid) {
+    if (!A.normalize) {
+      // adjoint: un-normalised overlap-add
+    } else if (all_valid) {
       float4 n4 = *reinterpret_cast<const float4*>(&A.invn[s4]);
       acc.x *= n4.x; acc.y *= n4.y; acc.z *= n4.z; acc.w *= n4.w;
     } else {

@@ -372,7 +372,8 @@ __global__ void k_bits_to_k16(const unsigned long long* __restrict__ bits, Geom 
 // reference applies prop_decrease before smoothing, else 1).  Written as float for the v1
 // apply kernel (general geometries); the fast apply kernel evaluates this on the fly.
 __global__ void k_k16_to_mask(const unsigned short* __restrict__ K, Geom g, int nf, int nt, float inv_ktot,
-                              float p, int prop_before, int smooth, float* __restrict__ M, int64_t n_units) {
+                              float p, int prop_before, int smooth, float* __restrict__ M, int64_t n_units,
+                              const int* __restrict__ perm) {
   const int64_t cells = n_units * g.T * g.FS;
   for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < cells;
        i += (int64_t)gridDim.x * blockDim.x) {
@@ -391,7 +392,7 @@ __global__ void k_k16_to_mask(const unsigned short* __restrict__ K, Geom g, int 
       int64_t tlo = max<int64_t>(-nt, -t), thi = min<int64_t>(nt, g.T - 1 - t);
       edge = (float)tri(nf, flo, fhi) * (float)tri(nt, (int)tlo, (int)thi) * inv_ktot;
     }
-    M[i] = p * ((float)K[i] * inv_ktot) + (1.0f - p) * edge;
+    M[perm ? i - f + perm[f] : i] = p * ((float)K[i] * inv_ktot) + (1.0f - p) * edge;
   }
 }
 

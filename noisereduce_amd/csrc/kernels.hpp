@@ -467,7 +467,7 @@ __global__ void k_smooth_f(const float* __restrict__ raw, Geom g, const float* _
 
 __global__ void k_smooth_t(const float* __restrict__ tmp, Geom g, const float* __restrict__ kt, int nt,
                            const float* __restrict__ kf, int nf, float p, int prop_before,
-                           float* __restrict__ M, int64_t n_units) {
+                           float* __restrict__ M, int64_t n_units, const int* __restrict__ perm) {
   const int64_t cells = n_units * g.T * g.FS;
   for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < cells;
        i += (int64_t)gridDim.x * blockDim.x) {
@@ -489,17 +489,21 @@ __global__ void k_smooth_t(const float* __restrict__ tmp, Geom g, const float* _
         if (f + a >= 0 && f + a < g.F) ef += kf[a + nf];
       edge = ef * et;
     }
-    M[i] = p * acc + (1.0f - p) * edge;
+    // perm != nullptr: store in the lane order of the fused apply kernel (fast::perm_pos)
+    M[perm ? i - f + perm[f] : i] = p * acc + (1.0f - p) * edge;
   }
 }
 
 // no smoothing: M = p*raw + (1-p)
 __global__ void k_prop_only(const float* __restrict__ raw, Geom g, float p, float* __restrict__ M,
-                            int64_t n_units) {
+                            int64_t n_units, const int* __restrict__ perm) {
   const int64_t cells = n_units * g.T * g.FS;
   for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < cells;
-       i += (int64_t)gridDim.x * blockDim.x)
-    M[i] = p * raw[i] + (1.0f - p);
+       i += (int64_t)gridDim.x * blockDim.x) {
+    const int f = (int)(i % g.FS);
+    if (f >= g.F) continue;
+    M[perm ? i - f + perm[f] : i] = p * raw[i] + (1.0f - p);
+  }
 }
 
 // yn[s] = mean over channels (np.mean(axis=0), stationary.py:61): sequential fp64 sum / C.

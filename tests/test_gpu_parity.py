@@ -290,8 +290,13 @@ def test_torchgate_backward_matches_autograd(kw, dtype):
     y.backward(gy)
     gx = x.grad.detach().double()
     # same mask, torch's own stft/istft in float64
+    from noisereduce_amd import _ffi
     gate = tg._gate_for(x.device)
-    _, mask = gate.process_batch(x.detach(), None, save_mask=True)
+    try:  # natural bin order (the fused apply kernel keeps its masks in lane order)
+        gate.set_option(_ffi.SG_OPT_FORCE_NOFAST, 1)
+        _, mask = gate.process_batch(x.detach(), None, save_mask=True)
+    finally:
+        gate.set_option(_ffi.SG_OPT_FORCE_NOFAST, 0)
     n, W, H = tg.n_fft, tg.win_length, tg.hop_length
     M = mask[:, :, :n // 2 + 1].permute(0, 2, 1).double()
     w = torch.hann_window(W).double().cuda()
