@@ -534,8 +534,12 @@ static int stage_nonstat_raw(sg_handle* h, const View& v, const Geom& g, int64_t
   dim3 grid((g.F + 63) / 64, (unsigned)ub);
   if (h->p.variant == SG_VARIANT_S) {
     // |Z| scale (1/sum_w) cancels in (A-S)/S: work on the unscaled magnitude.
-    hipLaunchKernelGGL(k_iir_sigmoid, grid, dim3(64), 0, st, (const float*)mag, g, h->p.iir_b,
-                       h->p.nonstat_thresh, h->p.nonstat_slope, (float*)h->raw.p);
+    if (g.T >= 4 * IIR_NSEG)
+      hipLaunchKernelGGL(k_iir_sigmoid_seg, grid, dim3(64 * IIR_NSEG), 0, st, (const float*)mag, g, h->p.iir_b,
+                         h->p.nonstat_thresh, h->p.nonstat_slope, (float*)h->raw.p);
+    else
+      hipLaunchKernelGGL(k_iir_sigmoid, grid, dim3(64), 0, st, (const float*)mag, g, h->p.iir_b,
+                         h->p.nonstat_thresh, h->p.nonstat_slope, (float*)h->raw.p);
   } else {
     hipLaunchKernelGGL(k_boxcar_sigmoid, grid, dim3(64), 0, st, (const float*)mag, g, h->p.n_movemean,
                        h->p.nonstat_thresh, h->p.nonstat_slope, (float*)h->raw.p);
@@ -553,6 +557,25 @@ static int stage_smooth(sg_handle* h, const Geom& g, int64_t ub, const int* perm
                        (float*)h->M.p, ub, perm);
     HIPCHK(h, hipGetLastError());
     return SG_OK;
+  }
+  // prop_decrease is applied before smoothing by stationary.py:108-114 and torchgate.py:241-249,
+  // after smoothing by nonstationary.py:78-84.
+  const int prop_before0 = (h->p.variant == SG_VARIANT_T || h->p.stationary) ? 1 : 0;
+  {
+    const int nf = h->p.n_grad_freq, nt = h->p.n_grad_time;
+    const int rows = SMF_TT + 2 * nt, cols = SMF_FB + 2 * nf;
+    size_t lds = ((size_t)rows * cols + (size_t)rows * SMF_FB + 2 * nf + 2 * nt + 2) * sizeof(float);
+    if (!perm && lds <= 150 * 1024 && ub <= 65535) {
+      auto kern = k_smooth_tiled;
+      if (lds > 65536)
+        HIPCHK(h, hipFuncSetAttribute(reinterpret_cast<const void*>(kern),
+                                      hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+      dim3 grid((g.F + SMF_FB - 1) / SMF_FB, (unsigned)((g.T + SMF_TT - 1) / SMF_TT), (unsigned)ub);
+      hipLaunchKernelGGL(kern, grid, dim3(256), lds, st, (const float*)h->raw.p, g, (const float*)h->kf.p, nf,
+                         (const float*)h->kt.p, nt, p, prop_before0, (float*)h->M.p);
+      HIPCHK(h, hipGetLastError());
+      return SG_OK;
+    }
   }
   float* tmp = (float*)h->seg.p;  // seg is not live yet
   hipLaunchKernelGGL(k_smooth_f, dim3(grid_1d(cells, 256)), dim3(256), 0, st, (const float*)h->raw.p, g,
@@ -770,7 +793,7 @@ static int run_S(sg_handle* h, View v, int64_t total_units, const OutMap& om, hi
       continue;
     }
     // float mask field (natural bin order for the general apply kernels, lane order for the fused one)
-    const int* perm = geom_fast ? (const int*)h->perm.p : nullptr;
+    const int* perm = nullptr;
     h->dbg_fast = geom_fast;
     if (fused) {
       if ((rc = stage_fused_mask(h, v, g, nb, false, 0, g.T, perm, st))) return rc;
@@ -986,7 +1009,7 @@ extern "C" int sg_process_batch(sg_handle* h, const void* x_dev, int dtype, int6
       if ((rc = stage_nonstat_raw(h, v, g, nb, st))) return rc;
     }
     const bool geom_fast = h->fast_ok && !h->force_nofast;
-    if ((rc = stage_smooth(h, g, nb, geom_fast ? (const int*)h->perm.p : nullptr, st))) return rc;
+    if ((rc = stage_smooth(h, g, nb, nullptr, st))) return rc;
     if (mask_out_dev)  // kept in whatever bin order this handle's apply kernel reads
       HIPCHK(h, hipMemcpyAsync(mask_out_dev + (size_t)u0 * g.T * g.FS, h->M.p, (size_t)nb * g.T * g.FS * 4,
                                hipMemcpyDeviceToDevice, st));
@@ -1139,7 +1162,8 @@ extern "C" int sg_debug_fetch(sg_handle* h, int32_t what, void* host, int64_t by
       if (!h->dbg_fused) FAIL(h, SG_E_STATE, "bit field only exists on the fused path");
       src = h->bits.p; need = (size_t)h->dbg_units * h->dbg_T * ((h->F + 63) / 64) * 8; break;
     case 1:
-      if (h->dbg_fast) FAIL(h, SG_E_STATE, "fast path keeps the smoothed mask in the apply kernel's lane order");
+      if (h->dbg_fast && h->dbg_fused)
+        FAIL(h, SG_E_STATE, "fast path keeps the smoothed mask as uint16 counts in the apply kernel's lane order");
       src = h->M.p; need = cells * 4; break;
     case 2:
       if (!h->dbg_has_P) FAIL(h, SG_E_STATE, "power field only exists for stationary gates");

@@ -219,7 +219,7 @@ struct ApplyArgs {
   Geom g;
   OutMap om;
   const unsigned short* K;  // permuted mask counts [units][T][FSK]            (KMASK = true)
-  const float* Mf;          // permuted float mask  [units][T][FSK]            (KMASK = false)
+  const float* Mf;          // float mask, natural bin order [units][T][FSK]   (KMASK = false)
   const float* win;         // analysis == synthesis window (1024)
   const float* wsq;         // window squared (1024)
   const float* invn;        // 1 / sum_q wsq[256 q + s], s < 256 (interior hops)
@@ -274,12 +274,13 @@ __global__ __launch_bounds__(WAVES * 64, 2) void k_apply_fast(ApplyArgs A) {
     }
     k512 = (float)Krow[512] * A.kscale;
   } else {
+    // natural bin order: the 16 lanes of a frame read one 64-byte run per slot
     const float* Mrow = A.Mf + ((u * G.T + (fvalid ? t : 0)) * (int64_t)FSK);
-    const float4* p4 = reinterpret_cast<const float4*>(Mrow + c * 32);
+    const int r2 = c == 0 ? 16 : 32 - c;
 #pragma unroll
-    for (int q = 0; q < 8; ++q) {
-      float4 w4 = p4[q];
-      mf[4 * q] = w4.x; mf[4 * q + 1] = w4.y; mf[4 * q + 2] = w4.z; mf[4 * q + 3] = w4.w;
+    for (int q = 0; q < 16; ++q) {
+      mf[q] = Mrow[c + 32 * q];
+      mf[16 + q] = Mrow[r2 + 32 * q];
     }
     k512 = Mrow[512] * A.kscale;
   }

@@ -418,6 +418,75 @@ __global__ void k_iir_sigmoid(const float* __restrict__ A, Geom g, double b, dou
   }
 }
 
+// Segmented form of k_iir_sigmoid: block = 64 bins x NSEG time segments of one unit.  Every
+// segment first runs the recurrence from a zero state (its response to its own input), the
+// carries s_in(seg) = s_end(seg-1) are chained through LDS (s_end = local_end + c^len * s_in), then
+// the segment re-runs with the right initial state.  Same recurrence, 16x the parallelism.
+constexpr int IIR_NSEG = 16;
+
+__global__ __launch_bounds__(64 * IIR_NSEG) void k_iir_sigmoid_seg(const float* __restrict__ A, Geom g, double b,
+                                                                   double nthresh, double slope,
+                                                                   float* __restrict__ raw) {
+  __shared__ double s_end[IIR_NSEG][64];
+  __shared__ double s_pow[IIR_NSEG];
+  __shared__ double s_seed[64];
+  const int l = threadIdx.x & 63, seg = threadIdx.x >> 6;
+  const int f = blockIdx.x * 64 + l;
+  const int64_t u = blockIdx.y;
+  const bool on = f < g.F;
+  const int64_t ts = g.T * seg / IIR_NSEG, te = g.T * (seg + 1) / IIR_NSEG;
+  const float* a = A + u * g.T * g.FS + (on ? f : 0);
+  float* r = raw + u * g.T * g.FS + (on ? f : 0);
+  const double c = 1.0 - b;
+  if (l == 0) s_pow[seg] = pow(c, (double)(te - ts));
+  // ---- forward ----
+  double e = 0.0;
+  if (on) {
+#pragma unroll 8
+    for (int64_t t = ts; t < te; ++t) e = b * (double)a[t * g.FS] + c * e;
+  }
+  s_end[seg][l] = e;
+  __syncthreads();
+  double carry = on ? (double)a[0] : 0.0;  // s[-1] = A[0]  (lfilter_zi steady state)
+  for (int k = 0; k < seg; ++k) carry = s_end[k][l] + s_pow[k] * carry;
+  double s = carry;
+  if (on) {
+#pragma unroll 8
+    for (int64_t t = ts; t < te; ++t) {
+      s = b * (double)a[t * g.FS] + c * s;
+      r[t * g.FS] = (float)s;
+    }
+  }
+  if (seg == IIR_NSEG - 1) s_seed[l] = s;  // exact forward value at T-1
+  __syncthreads();
+  // ---- backward on the forward output ----
+  const double seed = s_seed[l];
+  e = 0.0;
+  if (on) {
+#pragma unroll 8
+    for (int64_t t = te - 1; t >= ts; --t) {
+      double fw = (t == g.T - 1) ? seed : (double)r[t * g.FS];
+      e = b * fw + c * e;
+    }
+  }
+  __syncthreads();  // s_end is reused
+  s_end[seg][l] = e;
+  __syncthreads();
+  carry = seed;  // backward pass is seeded with the forward pass's last value
+  for (int k = IIR_NSEG - 1; k > seg; --k) carry = s_end[k][l] + s_pow[k] * carry;
+  s = carry;
+  if (on) {
+#pragma unroll 4
+    for (int64_t t = te - 1; t >= ts; --t) {
+      double fw = (t == g.T - 1) ? seed : (double)r[t * g.FS];
+      s = b * fw + c * s;
+      double av = (double)a[t * g.FS];
+      double ratio = (av - s) / s;
+      r[t * g.FS] = (float)(1.0 / (1.0 + exp(-(ratio - nthresh) * slope)));
+    }
+  }
+}
+
 // T: boxcar moving mean conv1d(ones(k), padding="same")/k, left pad (k-1)//2
 // (torchgate.py:179-190), then sigmoid((ratio - x0)/temp) (torchgate.py:193-196).
 __global__ void k_boxcar_sigmoid(const float* __restrict__ A, Geom g, int kbox, double nthresh, double slope,
@@ -491,6 +560,63 @@ __global__ void k_smooth_t(const float* __restrict__ tmp, Geom g, const float* _
     }
     // perm != nullptr: store in the lane order of the fused apply kernel (fast::perm_pos)
     M[perm ? i - f + perm[f] : i] = p * acc + (1.0f - p) * edge;
+  }
+}
+
+// LDS-tiled version of k_smooth_f + k_smooth_t: one block = TT frames x FB bins of one unit.
+// raw tile (+halo) -> LDS, f-pass LDS -> LDS, t-pass LDS -> global.  Same arithmetic order as the
+// two-kernel version (taps accumulated left to right).
+constexpr int SMF_TT = 32, SMF_FB = 128;
+
+__global__ __launch_bounds__(256) void k_smooth_tiled(const float* __restrict__ raw, Geom g,
+                                                      const float* __restrict__ kf, int nf,
+                                                      const float* __restrict__ kt, int nt, float p,
+                                                      int prop_before, float* __restrict__ M) {
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  const int rows = SMF_TT + 2 * nt, cols = SMF_FB + 2 * nf;
+  float* tile = reinterpret_cast<float*>(smem);        // [rows][cols]   raw, zero outside the field
+  float* buf = tile + (size_t)rows * cols;              // [rows][SMF_FB] after the f-pass
+  float* taps = buf + (size_t)rows * SMF_FB;            // kf | kt
+  const int64_t u = blockIdx.z;
+  const int64_t t0 = (int64_t)blockIdx.y * SMF_TT;
+  const int f0 = blockIdx.x * SMF_FB;
+  for (int i = threadIdx.x; i < 2 * nf + 1; i += 256) taps[i] = kf[i];
+  for (int i = threadIdx.x; i < 2 * nt + 1; i += 256) taps[2 * nf + 1 + i] = kt[i];
+  for (int i = threadIdx.x; i < rows * cols; i += 256) {
+    const int r = i / cols, cidx = i - r * cols;
+    const int64_t t = t0 - nt + r;
+    const int f = f0 - nf + cidx;
+    tile[i] = (t >= 0 && t < g.T && f >= 0 && f < g.F) ? raw[(u * g.T + t) * g.FS + f] : 0.f;
+  }
+  __syncthreads();
+  const float* tf = taps;
+  const float* tt = taps + 2 * nf + 1;
+  for (int i = threadIdx.x; i < rows * SMF_FB; i += 256) {
+    const int r = i / SMF_FB, cidx = i - r * SMF_FB;
+    const float* src = tile + (size_t)r * cols + cidx;  // window starts at f - nf
+    float acc = 0.f;
+    for (int a = 0; a <= 2 * nf; ++a) acc += tf[a] * src[a];
+    buf[i] = acc;
+  }
+  __syncthreads();
+  for (int i = threadIdx.x; i < SMF_TT * SMF_FB; i += 256) {
+    const int r = i / SMF_FB, cidx = i - r * SMF_FB;
+    const int64_t t = t0 + r;
+    const int f = f0 + cidx;
+    if (t >= g.T || f >= g.F) continue;
+    const float* src = buf + (size_t)r * SMF_FB + cidx;  // row r of buf == frame t - nt
+    float acc = 0.f;
+    for (int b = 0; b <= 2 * nt; ++b) acc += tt[b] * src[(size_t)b * SMF_FB];
+    float edge = 1.0f;
+    if (prop_before) {
+      float ef = 0.f, et = 0.f;
+      for (int a = -nf; a <= nf; ++a)
+        if (f + a >= 0 && f + a < g.F) ef += tf[a + nf];
+      for (int b = -nt; b <= nt; ++b)
+        if (t + b >= 0 && t + b < g.T) et += tt[b + nt];
+      edge = ef * et;
+    }
+    M[(u * g.T + t) * g.FS + f] = p * acc + (1.0f - p) * edge;
   }
 }
 
