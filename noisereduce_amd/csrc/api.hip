@@ -564,8 +564,9 @@ static int stage_smooth(sg_handle* h, const Geom& g, int64_t ub, const int* perm
   {
     const int nf = h->p.n_grad_freq, nt = h->p.n_grad_time;
     const int rows = SMF_TT + 2 * nt, cols = SMF_FB + 2 * nf;
-    size_t lds = ((size_t)rows * cols + (size_t)rows * SMF_FB + 2 * nf + 2 * nt + 2) * sizeof(float);
-    if (!perm && lds <= 150 * 1024 && ub <= 65535) {
+    // +3: the sliding windows read up to 3 entries past the last tap
+    size_t lds = ((size_t)(rows + 3) * (cols | 1) + (size_t)(rows + 3) * (SMF_FB + 1) + 8) * sizeof(float);
+    if (!perm && lds <= 150 * 1024 && ub <= 65535 && nf <= 30 && nt <= 30 && SMF_FB + 2 * nf <= 192) {
       auto kern = k_smooth_tiled;
       if (lds > 65536)
         HIPCHK(h, hipFuncSetAttribute(reinterpret_cast<const void*>(kern),

@@ -564,8 +564,10 @@ __global__ void k_smooth_t(const float* __restrict__ tmp, Geom g, const float* _
 }
 
 // LDS-tiled version of k_smooth_f + k_smooth_t: one block = TT frames x FB bins of one unit.
-// raw tile (+halo) -> LDS, f-pass LDS -> LDS, t-pass LDS -> global.  Same arithmetic order as the
-// two-kernel version (taps accumulated left to right).
+// raw tile (+halo) -> LDS, f-pass LDS -> LDS, t-pass LDS -> global.  Each thread produces FOUR
+// adjacent outputs along the filter axis from a sliding register window (one LDS read per tap per
+// four outputs); taps come through the scalar cache.  LDS pitches are odd: the f-pass walks
+// rows with consecutive lanes, the t-pass walks bins with consecutive lanes -- both conflict-free.
 constexpr int SMF_TT = 32, SMF_FB = 128;
 
 __global__ __launch_bounds__(256) void k_smooth_tiled(const float* __restrict__ raw, Geom g,
@@ -573,50 +575,84 @@ __global__ __launch_bounds__(256) void k_smooth_tiled(const float* __restrict__ 
                                                       const float* __restrict__ kt, int nt, float p,
                                                       int prop_before, float* __restrict__ M) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
-  const int rows = SMF_TT + 2 * nt, cols = SMF_FB + 2 * nf;
-  float* tile = reinterpret_cast<float*>(smem);        // [rows][cols]   raw, zero outside the field
-  float* buf = tile + (size_t)rows * cols;              // [rows][SMF_FB] after the f-pass
-  float* taps = buf + (size_t)rows * SMF_FB;            // kf | kt
+  const int rows = SMF_TT + 2 * nt;
+  const int cols = SMF_FB + 2 * nf;
+  const int tp = cols | 1;             // odd pitch of the raw tile
+  constexpr int BP = SMF_FB + 1;       // odd pitch of the f-pass result
+  float* tile = reinterpret_cast<float*>(smem);  // [rows][tp]  raw, zero outside the field
+  float* buf = tile + (size_t)rows * tp;          // [rows][BP]  after the f-pass
   const int64_t u = blockIdx.z;
   const int64_t t0 = (int64_t)blockIdx.y * SMF_TT;
   const int f0 = blockIdx.x * SMF_FB;
-  for (int i = threadIdx.x; i < 2 * nf + 1; i += 256) taps[i] = kf[i];
-  for (int i = threadIdx.x; i < 2 * nt + 1; i += 256) taps[2 * nf + 1 + i] = kt[i];
-  for (int i = threadIdx.x; i < rows * cols; i += 256) {
-    const int r = i / cols, cidx = i - r * cols;
-    const int64_t t = t0 - nt + r;
-    const int f = f0 - nf + cidx;
-    tile[i] = (t >= 0 && t < g.T && f >= 0 && f < g.F) ? raw[(u * g.T + t) * g.FS + f] : 0.f;
-  }
-  __syncthreads();
-  const float* tf = taps;
-  const float* tt = taps + 2 * nf + 1;
-  for (int i = threadIdx.x; i < rows * SMF_FB; i += 256) {
-    const int r = i / SMF_FB, cidx = i - r * SMF_FB;
-    const float* src = tile + (size_t)r * cols + cidx;  // window starts at f - nf
-    float acc = 0.f;
-    for (int a = 0; a <= 2 * nf; ++a) acc += tf[a] * src[a];
-    buf[i] = acc;
-  }
-  __syncthreads();
-  for (int i = threadIdx.x; i < SMF_TT * SMF_FB; i += 256) {
-    const int r = i / SMF_FB, cidx = i - r * SMF_FB;
-    const int64_t t = t0 + r;
-    const int f = f0 + cidx;
-    if (t >= g.T || f >= g.F) continue;
-    const float* src = buf + (size_t)r * SMF_FB + cidx;  // row r of buf == frame t - nt
-    float acc = 0.f;
-    for (int b = 0; b <= 2 * nt; ++b) acc += tt[b] * src[(size_t)b * SMF_FB];
-    float edge = 1.0f;
-    if (prop_before) {
-      float ef = 0.f, et = 0.f;
-      for (int a = -nf; a <= nf; ++a)
-        if (f + a >= 0 && f + a < g.F) ef += tf[a + nf];
-      for (int b = -nt; b <= nt; ++b)
-        if (t + b >= 0 && t + b < g.T) et += tt[b + nt];
-      edge = ef * et;
+  // tile load: ALL of a thread's global loads are issued before the first LDS store, so the block
+  // pays one memory round trip instead of one per batch (the kernel is latency-bound otherwise)
+  constexpr int LB = 32;
+  for (int i0 = threadIdx.x; i0 < rows * cols; i0 += 256 * LB) {
+    float vals[LB];
+#pragma unroll
+    for (int j = 0; j < LB; ++j) {
+      const int i = i0 + 256 * j;
+      const int r = i / cols, cidx = i - r * cols;
+      const int64_t t = t0 - nt + r;
+      const int f = f0 - nf + cidx;
+      vals[j] = (i < rows * cols && t >= 0 && t < g.T && f >= 0 && f < g.F) ? raw[(u * g.T + t) * g.FS + f] : 0.f;
     }
-    M[(u * g.T + t) * g.FS + f] = p * acc + (1.0f - p) * edge;
+#pragma unroll
+    for (int j = 0; j < LB; ++j) {
+      const int i = i0 + 256 * j;
+      if (i < rows * cols) tile[(i / cols) * tp + (i % cols)] = vals[j];
+    }
+  }
+  __syncthreads();
+  // f-pass: item = (row r, group of 4 bins); consecutive lanes take consecutive rows
+  for (int it = threadIdx.x; it < rows * (SMF_FB / 4); it += 256) {
+    const int r = it % rows, c0 = (it / rows) * 4;
+    const float* src = tile + (size_t)r * tp + c0;  // src[a] = raw at bin (f0 + c0 - nf + a)
+    float w0 = src[0], w1 = src[1], w2 = src[2];
+    float a0 = 0.f, a1 = 0.f, a2 = 0.f, a3 = 0.f;
+#pragma unroll 4
+    for (int a = 0; a <= 2 * nf; ++a) {
+      const float w3 = src[a + 3];
+      const float k = kf[a];
+      a0 += k * w0; a1 += k * w1; a2 += k * w2; a3 += k * w3;
+      w0 = w1; w1 = w2; w2 = w3;
+    }
+    float* dst = buf + (size_t)r * BP + c0;
+    dst[0] = a0; dst[1] = a1; dst[2] = a2; dst[3] = a3;
+  }
+  __syncthreads();
+  // t-pass: item = (group of 4 frames, bin); consecutive lanes take consecutive bins
+  for (int it = threadIdx.x; it < (SMF_TT / 4) * SMF_FB; it += 256) {
+    const int cidx = it % SMF_FB, r0 = (it / SMF_FB) * 4;
+    const int f = f0 + cidx;
+    const float* src = buf + (size_t)r0 * BP + cidx;  // src[b*BP] = frame (t0 + r0 - nt + b)
+    float w0 = src[0], w1 = src[BP], w2 = src[2 * BP];
+    float a0 = 0.f, a1 = 0.f, a2 = 0.f, a3 = 0.f;
+#pragma unroll 4
+    for (int b = 0; b <= 2 * nt; ++b) {
+      const float w3 = src[(size_t)(b + 3) * BP];
+      const float k = kt[b];
+      a0 += k * w0; a1 += k * w1; a2 += k * w2; a3 += k * w3;
+      w0 = w1; w1 = w2; w2 = w3;
+    }
+    if (f >= g.F) continue;
+    const float accs[4] = {a0, a1, a2, a3};
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {
+      const int64_t t = t0 + r0 + e;
+      if (t >= g.T) break;
+      float edge = 1.0f;
+      // conv(1) under zero padding differs from 1 only within nf bins / nt frames of the border
+      if (prop_before && (f < nf || f >= g.F - nf || t < nt || t >= g.T - nt)) {
+        float ef = 0.f, et = 0.f;
+        for (int a = -nf; a <= nf; ++a)
+          if (f + a >= 0 && f + a < g.F) ef += kf[a + nf];
+        for (int b = -nt; b <= nt; ++b)
+          if (t + b >= 0 && t + b < g.T) et += kt[b + nt];
+        edge = ef * et;
+      }
+      M[(u * g.T + t) * g.FS + f] = p * accs[e] + (1.0f - p) * edge;
+    }
   }
 }
 

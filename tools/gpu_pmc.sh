@@ -8,8 +8,8 @@ REPO=${GRAFT_REPO_ROOT:-/root/repo}
 OUT=$REPO/gpurun_out/pmc_$TAG
 mkdir -p "$OUT"
 cd /tmp && export TMPDIR=/tmp
-rocprofv3 --kernel-trace --pmc $CTRS -d "$OUT" -o "$TAG" --output-format csv -- \
-  python "$REPO/bench.py" --steps 3 --warmup 1 --no-cpu-baseline "$@" > "$OUT/bench.json" 2> "$OUT/bench.err"
+CMD=${PMC_CMD:-"python $REPO/bench.py --steps 3 --warmup 1 --no-cpu-baseline $*"}
+rocprofv3 --kernel-trace --pmc $CTRS -d "$OUT" -o "$TAG" --output-format csv -- $CMD > "$OUT/bench.json" 2> "$OUT/bench.err"
 F=$(find "$OUT" -name '*counter_collection.csv' | head -1)
 if [ -n "$F" ]; then
 python3 - "$F" <<'PY'
