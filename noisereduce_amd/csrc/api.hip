@@ -178,18 +178,22 @@ template <typename TC, int N>
 static hipError_t launch_stft_n(const View& v, const Geom& g, int64_t units, const void* tw, const void* wfull,
                                 double* P, float* mag, double* z, double zscale, hipStream_t st) {
   constexpr int WAVES = (N * sizeof(cx<TC>) > 16384) ? 2 : 4;
-  constexpr int FPW = 4;
   size_t lds = (size_t)(N + WAVES * N) * sizeof(cx<TC>);
-  auto kern = k_stft<TC, N, WAVES, FPW>;
-  if (lds > 65536) {
-    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern),
-                                       hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-    if (e != hipSuccess) return e;
-  }
-  dim3 grid((unsigned)((g.T + WAVES * FPW - 1) / (WAVES * FPW)), (unsigned)units);
-  hipLaunchKernelGGL(kern, grid, dim3(WAVES * 64), lds, st, v, g, (const cx<TC>*)tw, (const TC*)wfull, P, mag, z,
-                     zscale);
-  return hipGetLastError();
+  // few units (the noise clip): one frame per wave so that the grid still covers the chip
+  const bool small = units * ((g.T + WAVES * 4 - 1) / (WAVES * 4)) < 1024;
+  auto launch = [&](auto kern, int fpw) -> hipError_t {
+    if (lds > 65536) {
+      hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern),
+                                         hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+      if (e != hipSuccess) return e;
+    }
+    dim3 grid((unsigned)((g.T + WAVES * fpw - 1) / (WAVES * fpw)), (unsigned)units);
+    hipLaunchKernelGGL(kern, grid, dim3(WAVES * 64), lds, st, v, g, (const cx<TC>*)tw, (const TC*)wfull, P, mag,
+                       z, zscale);
+    return hipGetLastError();
+  };
+  if (small) return launch(k_stft<TC, N, WAVES, 1>, 1);
+  return launch(k_stft<TC, N, WAVES, 4>, 4);
 }
 
 template <typename TC>
@@ -629,7 +633,8 @@ static int stage_fused_mask(sg_handle* h, const View& v, const Geom& g, int64_t 
   HIPCHK(h, hipMemsetAsync(h->pmax.p, 0, (size_t)ub * g.FS * 8, st));
   {
     ProfScope ps(h, SG_STAGE_PREP, st);
-    hipLaunchKernelGGL(k_unit_absmax, dim3(32, (unsigned)ub), dim3(256), 0, st, v, ub, (unsigned*)h->umax.p);
+    hipLaunchKernelGGL(k_unit_absmax, dim3((unsigned)std::max<int64_t>(1, std::min<int64_t>(64, 2048 / ub)), (unsigned)ub),
+                       dim3(256), 0, st, v, ub, (unsigned*)h->umax.p);
     HIPCHK(h, hipGetLastError());
     hipLaunchKernelGGL(k_prep_thresh, dim3((unsigned)((ub + 255) / 256)), dim3(256), 0, st,
                        (const double*)h->thresh.p, g.F, h->mag_scale, h->sum_abs_w, h->p.top_db,

@@ -30,9 +30,19 @@ __global__ void k_unit_absmax(View view, int64_t n_units, unsigned* __restrict__
   const int64_t s_lo = max<int64_t>(0, view.lo - g0), s_hi = min<int64_t>(view.Lp, view.hi - g0);
   if (view.dtype == 0) {
     const float* src = (const float*)view.x + row * view.stride + g0;
-    for (int64_t s = s_lo + (int64_t)blockIdx.x * blockDim.x + threadIdx.x; s < s_hi;
-         s += (int64_t)gridDim.x * blockDim.x)
-      m = fmaxf(m, fabsf(src[s]));
+    // 16-byte loads over the aligned middle, scalar loads over the two ragged ends
+    const int64_t a_lo = s_lo + ((4 - ((reinterpret_cast<uintptr_t>(src + s_lo) >> 2) & 3)) & 3);
+    const int64_t n4 = a_lo < s_hi ? (s_hi - a_lo) / 4 : 0;
+    const float4* s4 = reinterpret_cast<const float4*>(src + a_lo);
+#pragma unroll 4
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n4; i += (int64_t)gridDim.x * blockDim.x) {
+      float4 v4 = s4[i];
+      m = fmaxf(fmaxf(m, fmaxf(fabsf(v4.x), fabsf(v4.y))), fmaxf(fabsf(v4.z), fabsf(v4.w)));
+    }
+    if (blockIdx.x == 0) {
+      for (int64_t s = s_lo + threadIdx.x; s < min(a_lo, s_hi); s += blockDim.x) m = fmaxf(m, fabsf(src[s]));
+      for (int64_t s = a_lo + 4 * n4 + threadIdx.x; s < s_hi; s += blockDim.x) m = fmaxf(m, fabsf(src[s]));
+    }
   } else {
     for (int64_t s = s_lo + (int64_t)blockIdx.x * blockDim.x + threadIdx.x; s < s_hi;
          s += (int64_t)gridDim.x * blockDim.x)
@@ -41,7 +51,14 @@ __global__ void k_unit_absmax(View view, int64_t n_units, unsigned* __restrict__
   // float(double) rounds to nearest: inflate by one ulp so the bound stays an upper bound
   m = m * 1.0000002f;
   for (int off = 32; off > 0; off >>= 1) m = fmaxf(m, __shfl_xor(m, off));
-  if ((threadIdx.x & 63) == 0) atomicMax(&umax_bits[u], __float_as_uint(m));
+  // one atomic per block: same-address L2 atomics serialise
+  __shared__ float s_m[16];
+  if ((threadIdx.x & 63) == 0) s_m[threadIdx.x >> 6] = m;
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    for (int w = 1; w < (int)(blockDim.x >> 6); ++w) m = fmaxf(m, s_m[w]);
+    atomicMax(&umax_bits[u], __float_as_uint(m));
+  }
 }
 
 // T2[f]: 20*log10(|X|*mag_scale + eps) > thresh[f]   <=>   |X|^2 > T2[f]   with

@@ -306,8 +306,10 @@ __global__ void k_colmax_final(const double* __restrict__ pmax_part, Geom g, int
     const int64_t u = i / g.FS;
     const int f = (int)(i % g.FS);
     double m = 0.0;
-    if (f < g.F)
+    if (f < g.F) {
+#pragma unroll 8
       for (int ts = 0; ts < nts; ++ts) m = fmax(m, pmax_part[(u * nts + ts) * g.FS + f]);
+    }
     pmax[i] = m;
   }
 }
@@ -356,6 +358,7 @@ __global__ void k_colstats_final(const double* __restrict__ s_part, Geom g, int 
     const int f = (int)(i % g.FS);
     if (f >= g.F) continue;
     double s1 = 0.0, s2 = 0.0;
+#pragma unroll 8
     for (int ts = 0; ts < nts; ++ts) {
       s1 += s_part[((u * nts + ts) * 2 + 0) * g.FS + f];
       s2 += s_part[((u * nts + ts) * 2 + 1) * g.FS + f];
