@@ -197,21 +197,37 @@ __device__ __forceinline__ void pair_mask(cf& a, cf& b, cf w, float mk, float mn
   b = {Ep.x + Op.y, Op.x - Ep.y};
 }
 
-// Position of bin f in the permuted mask row: lane c owns 32 consecutive entries,
-// [0,16): row1(c) bins c + 32 k2 ; [16,32): row2(c) bins row2 + 32 k2 ; entry 512 = bin 512.
-__host__ __device__ inline int perm_pos(int f) {
-  if (f >= 512) return 512;
-  int rho = f & 31, k2 = f >> 5;
-  if (rho <= 15) return rho * 32 + k2;
-  if (rho == 16) return 16 + k2;
-  return (32 - rho) * 32 + 16 + k2;
+// "Entries": lane c works on 16 conjugate-pair slots s = 0..15; entry e = s is the first bin of
+// slot s, entry e = 31 - s its partner.  Mask / threshold tables for the fast kernels are stored
+// in this order (position c*32 + e, plus position 512 = bin 512), so every lane indexes them the
+// same way although lane 0 pairs its bins differently:
+//   lanes c >= 1: slot s = (bin c + 32 s , bin (32-c) + 32 (15-s))         registers (v[s], v[31-s])
+//   lane 0      : slot 0 = bins 0 / 512 (special); entry 31 = bin 256 (self-paired)
+//                 s = 1..7 : (bin 32 s, bin 32 (16-s))                      registers (v[s], v[16-s])
+//                 s = 8..15: (bin 16 + 32 (s-8), bin 16 + 32 (23-s))        registers (v[8+s], v[39-s])
+__host__ __device__ inline int bin_of_entry(int c, int e) {
+  if (c != 0) return e < 16 ? c + 32 * e : (32 - c) + 32 * (e - 16);
+  if (e == 0) return 0;
+  if (e < 8) return 32 * e;
+  if (e < 24) return 16 + 32 * (e - 8);
+  if (e < 31) return 32 * (e - 15);
+  return 256;
 }
-__host__ __device__ inline int perm_inv(int pos) {
+__host__ __device__ inline int perm_inv(int pos) {  // table position -> bin
   if (pos >= 512) return 512;
-  int lane = pos >> 5, slot = pos & 31;
-  if (slot < 16) return lane + 32 * slot;
-  int rho = lane == 0 ? 16 : 32 - lane;
-  return rho + 32 * (slot - 16);
+  return bin_of_entry(pos >> 5, pos & 31);
+}
+__host__ __device__ inline int perm_pos(int f) {    // bin -> table position
+  if (f >= 512) return 512;
+  const int rho = f & 31, k = f >> 5;
+  if (rho != 0 && rho != 16) return rho <= 15 ? rho * 32 + k : (32 - rho) * 32 + 16 + k;
+  if (rho == 16) return 8 + k;          // lane 0, entries 8..23
+  if (k < 8) return k;                  // lane 0, entries 0..7
+  return k == 8 ? 31 : 15 + k;          // bin 256 -> entry 31; bins 32 k (k = 9..15) -> entries 24..30
+}
+// register of lane 0 that holds entry e (lanes c >= 1: register == entry)
+__host__ __device__ constexpr int reg0_of_entry(int e) {
+  return e < 8 ? e : (e < 24 ? e + 8 : (e < 31 ? e - 15 : 8));
 }
 
 struct ApplyArgs {
@@ -276,12 +292,8 @@ __global__ __launch_bounds__(WAVES * 64, 2) void k_apply_fast(ApplyArgs A) {
   } else {
     // natural bin order: the 16 lanes of a frame read one 64-byte run per slot
     const float* Mrow = A.Mf + ((u * G.T + (fvalid ? t : 0)) * (int64_t)FSK);
-    const int r2 = c == 0 ? 16 : 32 - c;
 #pragma unroll
-    for (int q = 0; q < 16; ++q) {
-      mf[q] = Mrow[c + 32 * q];
-      mf[16 + q] = Mrow[r2 + 32 * q];
-    }
+    for (int e = 0; e < 32; ++e) mf[e] = Mrow[bin_of_entry(c, e)];
     k512 = Mrow[512] * A.kscale;
   }
   auto mval = [&](int q, float scale) -> float {
@@ -341,40 +353,66 @@ __global__ __launch_bounds__(WAVES * 64, 2) void k_apply_fast(ApplyArgs A) {
 #pragma unroll
     for (int r = 0; r < 32; ++r) wsyn[r] = wsrc2[16 * r];
   }
-  // split -> mask -> merge on conjugate pairs, all in this lane
+  // split -> mask -> merge on conjugate pairs, all in this lane.  One instruction stream for all
+  // lanes: lane 0 (self-paired rows 0 and 16) only differs in WHICH registers form a pair, handled
+  // with v_cndmask selects on the way in and out (a divergent branch would run the stage twice).
   {
     const float ks = A.kscale * 0.25f;  // pair_mask leaves out four 1/2 factors
-    if (c != 0) {
-      const cf wl = A.tw1024[c];  // w_1024^row1
-#pragma unroll
-      for (int k2 = 0; k2 < 16; ++k2) {
-        // bins k = c + 32 k2 (v[k2]) and 512 - k = row2 + 32 (15 - k2) (v[16 + 15 - k2])
-        cf w = k2 == 0 ? wl : mul_tw<false>(wl, twc<32>(k2), tws<32>(k2));
-        pair_mask(v[k2], v[31 - k2], w, mval(k2, ks), mval(31 - k2, ks));
-      }
-    } else {
-      // row 0: bins 32 k2; pairs (k2, 16 - k2), k2 = 1..7; specials k2 = 0 (bins 0, 512), 8 (bin 256)
-      {
-        cf a = v[0];
-        float y0 = (a.x + a.y) * mval(0, A.kscale);
-        float yN = (a.x - a.y) * k512;
-        v[0] = {0.5f * (y0 + yN), 0.5f * (y0 - yN)};
-        float m8 = mval(8, A.kscale);
-        v[8] = {v[8].x * m8, v[8].y * m8};
-      }
-#pragma unroll
-      for (int k2 = 1; k2 < 8; ++k2) {
-        cf w = {twc<32>(k2), -tws<32>(k2)};  // w_1024^(32 k2) = w_32^k2
-        pair_mask(v[k2], v[16 - k2], w, mval(k2, ks), mval(16 - k2, ks));
-      }
-      // row 16: bins 16 + 32 j; pairs (j, 15 - j), j = 0..7
+    const bool l0 = c == 0;
+    const cf wlo = A.tw1024[c];                         // w_1024^c   (lane 0: 1)
+    cf whi = wlo;                                       // slots >= 8: lane 0 uses i * w_1024^16
+    {
       const cf w16 = A.tw1024[16];
-#pragma unroll
-      for (int j = 0; j < 8; ++j) {
-        cf w = j == 0 ? w16 : mul_tw<false>(w16, twc<32>(j), tws<32>(j));
-        pair_mask(v[16 + j], v[31 - j], w, mval(16 + j, ks), mval(31 - j, ks));
-      }
+      if (l0) whi = {-w16.y, w16.x};
     }
+    auto sel = [&](cf a0, cf a1) -> cf { return {l0 ? a0.x : a1.x, l0 ? a0.y : a1.y}; };
+    cf nv[32];
+    // slot 0: general pair (v[0], v[31]); lane 0: bins 0 / 512 from v[0], bin 256 = v[8] scaled
+    cf s0a = v[0], s0b = v[31];
+    pair_mask(s0a, s0b, wlo, mval(0, ks), mval(31, ks));
+    {
+      const cf a = v[0];
+      const float y0 = (a.x + a.y) * mval(0, A.kscale);
+      const float yN = (a.x - a.y) * k512;
+      const cf z0 = {0.5f * (y0 + yN), 0.5f * (y0 - yN)};
+      const float m8 = mval(31, A.kscale);  // entry 31 of lane 0 = bin 256
+      const cf z8 = {v[8].x * m8, v[8].y * m8};
+      nv[0] = sel(z0, s0a);
+      nv[8] = z8;      // lane 0 only; lanes >= 1 overwrite nv[8] below (slot 8's first bin)
+      nv[31] = s0b;    // lanes >= 1 only; lane 0 overwrites nv[31] below (slot 8's partner)
+    }
+    cf pa[16], pb[16];
+#pragma unroll
+    for (int sl = 1; sl < 16; ++sl) {
+      // operands: lanes >= 1 (v[sl], v[31-sl]); lane 0 (v[sl], v[16-sl]) or (v[8+sl], v[39-sl])
+      cf a = sl < 8 ? v[sl] : sel(v[8 + sl], v[sl]);
+      cf b = sl < 8 ? sel(v[16 - sl], v[31 - sl]) : sel(v[39 - sl], v[31 - sl]);
+      const cf wl = sl < 8 ? wlo : whi;
+      const cf w = mul_tw<false>(wl, twc<32>(sl), tws<32>(sl));
+      pair_mask(a, b, w, mval(sl, ks), mval(31 - sl, ks));
+      pa[sl] = a;
+      pb[sl] = b;
+    }
+    // scatter back: register i receives, for lanes >= 1, entry i; for lane 0, the entry that
+    // lives in register i (reg0_of_entry)
+#pragma unroll
+    for (int i = 1; i < 8; ++i) nv[i] = pa[i];                                   // both
+    {
+      const cf keep8 = nv[8];
+      nv[8] = sel(keep8, pa[8]);
+    }
+#pragma unroll
+    for (int i = 9; i < 16; ++i) nv[i] = sel(pb[16 - i], pa[i]);                 // lane 0: partner of slot 16-i
+#pragma unroll
+    for (int i = 16; i < 24; ++i) nv[i] = sel(pa[i - 8], pb[31 - i]);            // lane 0: first bin of slot i-8
+#pragma unroll
+    for (int i = 24; i < 31; ++i) nv[i] = sel(pb[39 - i], pb[31 - i]);           // lane 0: partner of slot 39-i
+    {
+      const cf keep31 = nv[31];
+      nv[31] = sel(pb[8], keep31);
+    }
+#pragma unroll
+    for (int i = 0; i < 32; ++i) v[i] = nv[i];
   }
   fft512_inv(v, fb, tw512, c);
   // synthesis window, store the time-domain frame (natural order) into this frame's LDS slice
@@ -467,10 +505,6 @@ struct DecideArgs {
   int quads_per_wave;        // consecutive frame quads handled by one wave
 };
 
-// bin held in register slot q (0..31) of lane c
-__device__ __forceinline__ int bin_of(int c, int q) {
-  return q < 16 ? c + 32 * q : (c == 0 ? 16 : 32 - c) + 32 * (q - 16);
-}
 
 // exact float64 |X[f]|^2 of frame t, computed by the whole wavefront (rare path: kept out of line
 // so that its float64 temporaries do not inflate the register budget of the main loop)
@@ -511,7 +545,7 @@ __global__ __launch_bounds__(WAVES * 64, 2) void k_decide_fast(DecideArgs A) {
   const bool floor_live = A.tc.need_floor[u] != 0;
 
   // effective compare constants (4x the raw-power constant: the split below works on 2X) as
-  // float32 in LDS, permuted like the mask rows: entry c*32 + q = bin_of(c, q), entry 512 = bin 512
+  // float32 in LDS, permuted like the mask rows: entry c*32 + e = bin_of_entry(c, e), entry 512 = bin 512
   float* s_t2 = reinterpret_cast<float*>(regions + WAVES * WAVE_CX);
   auto t2eff = [&](int f) -> double {
     double v = A.tc.T2[f];
@@ -526,7 +560,7 @@ __global__ __launch_bounds__(WAVES * 64, 2) void k_decide_fast(DecideArgs A) {
     s_t2[i] = v < 0.0 ? -1.0f : (float)(4.0 * v);
   }
   cf* fb = regions + wave * WAVE_CX + frame_base(g);
-  const cf wl0 = A.tw1024[c == 0 ? 16 : c];  // w_1024^row1 (lane 0: w_1024^16 for its row 16)
+  const cf wl0 = A.tw1024[c];  // w_1024^c (lane 0: 1)
   __syncthreads();
 
   {
@@ -626,42 +660,39 @@ __global__ __launch_bounds__(WAVES * 64, 2) void k_decide_fast(DecideArgs A) {
       Pk = px * px + py * py;
       Pn = qx * qx + qy * qy;
     };
+    // One instruction stream for all lanes (see k_apply_fast): decisions are made per ENTRY
+    // (bin_of_entry); lane 0 selects its operands differently and its bits are permuted back to
+    // register order afterwards.
+    const bool l0 = c == 0;
+    const cf wlo = wl;
+    cf whi = wl;
+    {
+      const cf w16 = A.tw1024[16];
+      if (l0) whi = {-w16.y, w16.x};  // i * w_1024^16
+    }
+    auto sel = [&](cf a0, cf a1) -> cf { return {l0 ? a0.x : a1.x, l0 ? a0.y : a1.y}; };
     bool pred512 = false, amb512 = false;
-    if (c != 0) {
+    {
+      float Pk, Pn;
+      pair_power(v[0], v[31], wlo, Pk, Pn);
+      const cf a = v[0];
+      const float x0 = 2.f * (a.x + a.y), xN = 2.f * (a.x - a.y);
+      const float P256 = 4.f * (v[8].x * v[8].x + v[8].y * v[8].y);
+      decide(l0 ? x0 * x0 : Pk, t2[0], 0);
+      decide(l0 ? P256 : Pn, t2[31], 31);
+      const float P5 = xN * xN, d5 = P5 - t2_512;
+      pred512 = l0 && d5 > 0.f;
+      amb512 = l0 && live && t2_512 >= 0.f && d5 * d5 <= d2 * (P5 + t2_512);
+    }
 #pragma unroll
-      for (int k2 = 0; k2 < 16; ++k2) {
-        cf w = k2 == 0 ? wl : mul_tw<false>(wl, twc<32>(k2), tws<32>(k2));
-        float Pk, Pn;
-        pair_power(v[k2], v[31 - k2], w, Pk, Pn);
-        decide(Pk, t2[k2], k2);
-        decide(Pn, t2[31 - k2], 31 - k2);
-      }
-    } else {
-      {
-        cf a = v[0];
-        float x0 = 2.f * (a.x + a.y), xN = 2.f * (a.x - a.y);
-        decide(x0 * x0, t2[0], 0);
-        decide(4.f * (v[8].x * v[8].x + v[8].y * v[8].y), t2[8], 8);
-        const float P5 = xN * xN, d5 = P5 - t2_512;
-        pred512 = d5 > 0.f;
-        amb512 = live && t2_512 >= 0.f && d5 * d5 <= d2 * (P5 + t2_512);
-      }
-#pragma unroll
-      for (int k2 = 1; k2 < 8; ++k2) {
-        cf w = {twc<32>(k2), -tws<32>(k2)};
-        float Pk, Pn;
-        pair_power(v[k2], v[16 - k2], w, Pk, Pn);
-        decide(Pk, t2[k2], k2);
-        decide(Pn, t2[16 - k2], 16 - k2);
-      }
-#pragma unroll
-      for (int j = 0; j < 8; ++j) {
-        cf w = j == 0 ? wl : mul_tw<false>(wl, twc<32>(j), tws<32>(j));
-        float Pk, Pn;
-        pair_power(v[16 + j], v[31 - j], w, Pk, Pn);
-        decide(Pk, t2[16 + j], 16 + j);
-        decide(Pn, t2[31 - j], 31 - j);
-      }
+    for (int sl = 1; sl < 16; ++sl) {
+      const cf a = sl < 8 ? v[sl] : sel(v[8 + sl], v[sl]);
+      const cf b = sl < 8 ? sel(v[16 - sl], v[31 - sl]) : sel(v[39 - sl], v[31 - sl]);
+      const cf w = mul_tw<false>(sl < 8 ? wlo : whi, twc<32>(sl), tws<32>(sl));
+      float Pk, Pn;
+      pair_power(a, b, w, Pk, Pn);
+      decide(Pk, t2[sl], sl);
+      decide(Pn, t2[31 - sl], 31 - sl);
     }
     if (!fvalid) { amb = 0; amb512 = false; }
     // exact re-evaluation, one cell at a time, whole wave cooperating
@@ -674,7 +705,7 @@ __global__ __launch_bounds__(WAVES * 64, 2) void k_decide_fast(DecideArgs A) {
       const int q = amb_s ? (__ffs((int)amb_s) - 1) : 32;
       (void)amb512_s;
       const int cs = src & 15, gs = src >> 4;
-      const int f = q < 32 ? bin_of(cs, q) : 512;
+      const int f = q < 32 ? bin_of_entry(cs, q) : 512;
       const double P = exact_power(A, row, chunk, tq + gs, f, lane);
       const bool pass = P > t2eff(f);
       if (lane == src) {
@@ -687,6 +718,8 @@ __global__ __launch_bounds__(WAVES * 64, 2) void k_decide_fast(DecideArgs A) {
         }
       }
     }
+    if (l0)  // entry -> register: e 0..7 -> 0..7, 8..23 -> 16..31, 24..30 -> 9..15, 31 -> 8
+      pred = (pred & 0xffu) | ((pred & 0x00ffff00u) << 8) | ((pred >> 15) & 0xfe00u) | ((pred >> 23) & 0x100u);
     // pack: ballots over the wave give 16 consecutive bins per frame and slot
     unsigned long long myword = 0;  // lane c < 9 of group g ends up with word c of frame tq + g
 #pragma unroll
