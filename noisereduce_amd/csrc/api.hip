@@ -684,7 +684,7 @@ static int stage_fused_mask(sg_handle* h, const View& v, const Geom& g, int64_t 
   if (h->p.smooth_mask && nf <= 30) {
     const int rows = SM2_TT + 2 * nt;
     const bool small = (nf + 1) * (nf + 1) <= 255;
-    size_t lds = smooth_cf_bytes(rows, g.F, small ? 1 : 2) + (size_t)rows * (wpr + 2) * 8;
+    size_t lds = smooth2_cf_bytes(rows, g.F, small ? 1 : 2) + (size_t)rows * (wpr + 2) * 8;
     dim3 grid((unsigned)((te - tb + SM2_TT - 1) / SM2_TT), (unsigned)ub);
     if (small) {
       auto kern = k_smooth_bits2<uint8_t>;

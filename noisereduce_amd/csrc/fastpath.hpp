@@ -269,6 +269,7 @@ __global__ __launch_bounds__(WAVES * 64, 2) void k_apply_fast(ApplyArgs A) {
   const int64_t hs = A.h_begin + (int64_t)blockIdx.x * NH;  // first hop of this tile
   const int64_t t = hs - 3 + 4 * wave + g;                   // this lane group's frame
   const bool fvalid = t >= 0 && t < G.T;
+  const float4 inv4 = *reinterpret_cast<const float4*>(&A.invn[(tid & 63) * 4]);  // used by the OLA epilogue
 
   // mask of this lane's 32 bins (+ bin 512 for lane c == 0), permuted layout; issued first: it is
   // consumed only after the forward transform.  KMASK: uint16 counts (mask = K / ktot).
@@ -423,6 +424,7 @@ __global__ __launch_bounds__(WAVES * 64, 2) void k_apply_fast(ApplyArgs A) {
   // overlap-add: tile hop j (ext hop hs + j) = sum over tile frames i = j..j+3 of quarter j+3-i
   const float* fr = reinterpret_cast<const float*>(regions);
   const int s4 = (tid & 63) * 4;
+  const float4 n4 = inv4;  // 1 / window envelope of this thread's four sample phases (loaded at entry)
   for (int j = tid >> 6; j < NH; j += WAVES) {
     const int64_t h = hs + j;
     if (h >= A.h_end) break;
@@ -444,7 +446,6 @@ __global__ __launch_bounds__(WAVES * 64, 2) void k_apply_fast(ApplyArgs A) {
     if (!A.normalize) {
       // adjoint: un-normalised overlap-add
     } else if (all_valid) {
-      float4 n4 = *reinterpret_cast<const float4*>(&A.invn[s4]);
       acc.x *= n4.x; acc.y *= n4.y; acc.z *= n4.z; acc.w *= n4.w;
     } else {
 #pragma unroll

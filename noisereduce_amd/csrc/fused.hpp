@@ -281,6 +281,12 @@ __device__ __forceinline__ unsigned long long funnel_r(unsigned long long lo, un
   return sh == 0 ? lo : ((lo >> sh) | (hi << (64 - sh)));
 }
 
+__host__ __device__ inline int smooth2_pitch(int F) { return ((F + 3) & ~3) + 4 * ((F + 31) / 32) + 4; }
+__host__ __device__ inline size_t smooth2_cf_bytes(int rows, int F, int ct_size) {
+  size_t b = (size_t)rows * smooth2_pitch(F) * ct_size;
+  return (b + 15) & ~(size_t)15;
+}
+
 template <typename CT>
 __global__ __launch_bounds__(SM2_THREADS) void k_smooth_bits2(const unsigned long long* __restrict__ bits, Geom g,
                                                                int wpr, int nf, int nt,
@@ -288,10 +294,13 @@ __global__ __launch_bounds__(SM2_THREADS) void k_smooth_bits2(const unsigned lon
                                                                int64_t t_begin, int64_t t_end) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
   const int rows = SM2_TT + 2 * nt;
-  const int FP = (g.F + 3) & ~3;
+  // phase-1 counts are stored at column f + 4*(f/32): the phase-2 column walk visits bins 32 apart
+  // with consecutive lanes (lane order of the apply kernel), which would be an 8-way bank conflict
+  // on a dense row
+  const int FP = smooth2_pitch(g.F);
   const int WP = wpr + 2;  // one zero word on each side of every bit row
   CT* cf = reinterpret_cast<CT*>(smem);
-  unsigned long long* wb = reinterpret_cast<unsigned long long*>(smem + smooth_cf_bytes(rows, g.F, sizeof(CT)));
+  unsigned long long* wb = reinterpret_cast<unsigned long long*>(smem + smooth2_cf_bytes(rows, g.F, sizeof(CT)));
   const int64_t u = blockIdx.y;
   const int64_t t0 = t_begin + (int64_t)blockIdx.x * SM2_TT;
   for (int i = threadIdx.x; i < rows * WP; i += SM2_THREADS) {
@@ -318,7 +327,7 @@ __global__ __launch_bounds__(SM2_THREADS) void k_smooth_bits2(const unsigned lon
     for (int i = 0; i <= 2 * nf; ++i) c += (nf + 1 - (i < nf ? nf - i : i - nf)) * (int)((lo >> i) & 1ull);
     int R = __popcll((lo >> (nf + 1)) & m1);
     int L = __popcll(lo & m1);
-    CT* out = cf + (size_t)r * FP + 64 * w;
+    CT* out = cf + (size_t)r * FP + 64 * w + 8 * w;  // column(f) = f + 4*(f/32)
     const int nb = min(64, g.F - 64 * w);
     for (int f4 = 0; f4 < nb; f4 += 4) {
       unsigned packed = 0;
@@ -334,12 +343,12 @@ __global__ __launch_bounds__(SM2_THREADS) void k_smooth_bits2(const unsigned lon
         lo = (lo >> 1) | (hi << 63);
         hi >>= 1;
       }
+      const int colo = f4 + ((f4 >> 5) << 2);
       if (sizeof(CT) == 1) {
-        *reinterpret_cast<unsigned*>(out + f4) = packed;  // FP is a multiple of 4: rows stay aligned
+        *reinterpret_cast<unsigned*>(out + colo) = packed;  // FP is a multiple of 4: rows stay aligned
       } else {
 #pragma unroll
-        for (int e = 0; e < 4; ++e)
-          if (f4 + e < FP - 64 * w) out[f4 + e] = (CT)vals[e];
+        for (int e = 0; e < 4; ++e) out[colo + e] = (CT)vals[e];
       }
     }
   }
@@ -347,7 +356,7 @@ __global__ __launch_bounds__(SM2_THREADS) void k_smooth_bits2(const unsigned lon
   // ---- phase 2: along t, one output position per thread ------------------------------------
   for (int pos = threadIdx.x; pos < g.F; pos += SM2_THREADS) {
     const int f = perm ? fast::perm_inv(pos) : pos;
-    const CT* col = cf + f;
+    const CT* col = cf + f + ((f >> 5) << 2);
     auto at = [&](int r) -> int { return (r >= 0 && r < rows) ? (int)col[(size_t)r * FP] : 0; };
     const int r0 = nt;  // LDS row of output frame t0
     int c = 0, R = 0, L = 0;
