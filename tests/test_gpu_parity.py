@@ -310,3 +310,72 @@ def test_torchgate_backward_matches_autograd(kw, dtype):
     assert float((gx - ref).abs().max() / ref.abs().max()) < TOL
     # and the adjoint identity <gy, J v> == <J^T gy, v> holds for the engine's own forward
     assert x.grad.dtype == dtype and x.grad.shape == x.shape
+
+
+def test_unit_batching_is_invisible(nr):
+    """A workspace budget that forces the (channel, chunk) units through several batches must give
+    bit-identical output (config 4 has 9216 units; the workspace is bounded)."""
+    from noisereduce_amd import _ffi
+    C, n = 6, 130000
+    y = np.stack([O.synth_signal(n, seed=40 + c, tone_hz=200.0 * (c + 1)) for c in range(C)])
+    yd = torch.from_numpy(y).cuda()
+    kw = dict(variant=_ffi.SG_VARIANT_S, stationary=True, n_fft=1024, win_length=1024, hop_length=256,
+              n_grad_freq=5, n_grad_time=9, smooth_mask=True, chunk_size=20000, padding=3000,
+              n_std_thresh=1.5, top_db=80.0, ddof=0)
+    big = _ffi.Gate("cuda", **kw)
+    small = _ffi.Gate("cuda", max_workspace_bytes=3 << 20, **kw)   # a couple of units per batch
+    outs = []
+    for gate in (big, small):
+        gate.noise_stats(yd[:, :20000])
+        outs.append(gate.process_chunks(yd, chunked=True).cpu().numpy())
+    assert np.array_equal(outs[0], outs[1])
+    want = O.reduce_noise_S(y.astype(np.float64), 48000, stationary=True, chunk_size=20000, padding=3000)
+    assert O.rel_err(outs[0], want) < TOL
+    big.close(); small.close()
+
+
+@pytest.mark.parametrize("dtype", [np.int32, np.float64, np.float16, np.int64])
+def test_input_dtypes(nr, dtype):
+    """Any real dtype in -> same dtype out (base.py:217-226): native device types, and types that
+    go through float64 on the host like the reference's chunk copy."""
+    y = O.synth_signal(50000, seed=21).astype(np.float64)
+    yi = (y * 20000).astype(dtype) if np.issubdtype(dtype, np.integer) else y.astype(dtype)
+    out = nr.reduce_noise(y=yi, sr=48000, stationary=True)
+    assert out.dtype == dtype and out.shape == yi.shape
+    want = O.reduce_noise_S(yi, 48000, stationary=True)
+    if np.issubdtype(dtype, np.integer):
+        assert np.abs(out.astype(np.int64) - want.astype(np.int64)).max() <= 1
+    else:
+        tol = 2e-3 if dtype == np.float16 else TOL
+        assert O.rel_err(out, want) < tol
+
+
+def test_short_and_ragged_inputs(nr):
+    """Shortest legal input, lengths that are not a multiple of the hop, a last chunk of 1 sample."""
+    for n in (1024, 1025, 1279, 5000, 25001):
+        y = O.synth_signal(n, seed=n).astype(np.float64)
+        kw = dict(stationary=True, chunk_size=25000, padding=2000)
+        assert O.rel_err(nr.reduce_noise(y=y, sr=48000, **kw), O.reduce_noise_S(y, 48000, **kw)) < TOL
+        kw["stationary"] = False
+        assert O.rel_err(nr.reduce_noise(y=y, sr=48000, **kw), O.reduce_noise_S(y, 48000, **kw)) < TOL
+    with pytest.raises(ValueError):
+        nr.reduce_noise(y=np.zeros(500), sr=48000, stationary=True)      # shorter than win_length
+    with pytest.raises(NotImplementedError):
+        nr.reduce_noise(y=np.zeros(5000), sr=48000, stationary=True, n_fft=1000)  # not a power of two
+
+
+def test_use_torch_routing(nr):
+    """reduce_noise(use_torch=True): StreamedTorchGate parameter mapping and chunk loop
+    (streamed_torch_gate.py:66-87), against the torchgate oracle applied per chunk."""
+    y = O.synth_signal(70000, seed=77).astype(np.float64)
+    got = nr.reduce_noise(y=y, sr=48000, stationary=True, use_torch=True, chunk_size=30000, padding=4000)
+    assert got.shape == y.shape and got.dtype == y.dtype
+    # oracle: the reference's chunk loop around TorchGate (float64), xn=None
+    w = torch.hann_window(1024).double().numpy()
+    want = np.zeros_like(y)
+    for ich in range(3):
+        s0, e0 = ich * 30000, min((ich + 1) * 30000, 70000)
+        chunk = O.read_chunk(y[None, :], s0 - 4000, (ich + 1) * 30000 + 4000)
+        f = O.torchgate_T(chunk, 48000, window=w)
+        want[s0:e0] = f[0, 4000:4000 + e0 - s0]
+    assert O.rel_err(got, want) < TOL
