@@ -448,24 +448,29 @@ static int64_t ws_budget(const sg_handle* h) {
   return h->p.max_workspace_bytes > 0 ? h->p.max_workspace_bytes : (int64_t)8 << 30;
 }
 
-static size_t unit_bytes(const sg_handle* h, const Geom& g) {
+// Workspace per unit.  lean: the fused stationary path with the fused apply kernel only keeps the
+// bit mask (T*wpr*8 B) and the uint16 weight sums (T*FS*2 B).
+static size_t unit_bytes(const sg_handle* h, const Geom& g, bool lean) {
   size_t cells = (size_t)g.T * g.FS;
-  return cells * (8 + 4 + 4) + (size_t)g.T * g.n * 4 + (size_t)g.FS * 16;
+  if (lean) return (size_t)g.T * ((g.F + 63) / 64) * 8 + cells * 2 + (size_t)g.FS * 16 + 64;
+  return cells * (8 + 4 + 4 + 2) + (size_t)g.T * g.n * 4 + (size_t)g.FS * 16;
 }
 
-static int64_t units_per_batch(const sg_handle* h, const Geom& g, int64_t total) {
-  int64_t ub = ws_budget(h) / (int64_t)unit_bytes(h, g);
+static int64_t units_per_batch(const sg_handle* h, const Geom& g, int64_t total, bool lean = false) {
+  int64_t ub = ws_budget(h) / (int64_t)unit_bytes(h, g, lean);
   ub = std::max<int64_t>(1, std::min<int64_t>(ub, 32768));
   return std::min(ub, total);
 }
 
-static int ensure_ws(sg_handle* h, const Geom& g, int64_t ub) {
+static int ensure_ws(sg_handle* h, const Geom& g, int64_t ub, bool lean = false) {
   size_t cells = (size_t)ub * g.T * g.FS;
   int rc;
-  if ((rc = ensure(h, h->P, cells * 8))) return rc;  // power (f64) or magnitude (f32)
-  if ((rc = ensure(h, h->raw, cells * 4))) return rc;
-  if ((rc = ensure(h, h->M, cells * 4))) return rc;
-  if ((rc = ensure(h, h->seg, std::max((size_t)ub * g.T * g.n * 4, cells * 4)))) return rc;
+  if (!lean) {
+    if ((rc = ensure(h, h->P, cells * 8))) return rc;  // power (f64) or magnitude (f32)
+    if ((rc = ensure(h, h->raw, cells * 4))) return rc;
+    if ((rc = ensure(h, h->M, cells * 4))) return rc;
+    if ((rc = ensure(h, h->seg, std::max((size_t)ub * g.T * g.n * 4, cells * 4)))) return rc;
+  }
   if ((rc = ensure(h, h->pmax, (size_t)ub * g.FS * 8))) return rc;
   if ((rc = ensure(h, h->thr_rows, (size_t)ub * g.FS * 8))) return rc;
   return SG_OK;
@@ -780,8 +785,10 @@ static int run_S(sg_handle* h, View v, int64_t total_units, const OutMap& om, hi
                         (long long)v.Lp, h->W);
   if (h->p.stationary && !h->has_thresh)
     FAIL(h, SG_E_STATE, "stationary gate: call sg_noise_stats or sg_set_noise_threshold first");
-  int64_t ub = units_per_batch(h, g, total_units);
-  int rc = ensure_ws(h, g, ub);
+  const bool lean = h->fused_ok && !h->force_unfused && h->fast_ok && !h->force_nofast &&
+                    h->p.prop_decrease == 1.0;
+  int64_t ub = units_per_batch(h, g, total_units, lean);
+  int rc = ensure_ws(h, g, ub, lean);
   if (rc) return rc;
   for (int64_t u0 = 0; u0 < total_units; u0 += ub) {
     int64_t nb = std::min(ub, total_units - u0);
