@@ -535,7 +535,23 @@ static int stage_decide(sg_handle* h, const Geom& g, int64_t ub, const double* t
 
 static int stage_nonstat_raw(sg_handle* h, const View& v, const Geom& g, int64_t ub, hipStream_t st) {
   float* mag = (float*)h->P.p;
-  {
+  if (h->fast_ok && !h->force_nofast) {
+    ProfScope ps(h, SG_STAGE_STFT_MAG, st);
+    constexpr int WAVES = 4;
+    fast::MagArgs M;
+    M.view = v; M.g = g;
+    M.win = (const float*)h->wa32.p;
+    M.tw512 = (const fast::cf*)h->tw512.p;
+    M.tw1024 = (const fast::cf*)h->tw32.p;
+    M.mag = mag;
+    size_t lds = (size_t)(fast::FN + WAVES * fast::WAVE_CX) * sizeof(fast::cf);
+    auto kern = fast::k_mag_fast<WAVES>;
+    HIPCHK(h, hipFuncSetAttribute(reinterpret_cast<const void*>(kern),
+                                  hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+    dim3 grid((unsigned)((g.T + 4 * WAVES - 1) / (4 * WAVES)), (unsigned)ub);
+    hipLaunchKernelGGL(kern, grid, dim3(WAVES * 64), lds, st, M);
+    HIPCHK(h, hipGetLastError());
+  } else {
     ProfScope ps(h, SG_STAGE_STFT_MAG, st);
     HIPCHK(h, launch_stft<float>(h->N, v, g, ub, h->tw32.p, h->wa32.p, nullptr, mag, nullptr, 1.0, st));
   }

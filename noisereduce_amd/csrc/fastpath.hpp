@@ -755,3 +755,123 @@ __global__ __launch_bounds__(WAVES * 64, 2) void k_decide_fast(DecideArgs A) {
 
 }  // namespace fast
 }  // namespace sg
+
+// =======================================================================================
+// Magnitude STFT for the non-stationary masks (default geometry): float32 fast core, |X| stored
+// in natural bin order [unit][frame][FS].
+// =======================================================================================
+namespace sg {
+namespace fast {
+
+struct MagArgs {
+  View view;
+  Geom g;
+  const float* win;
+  const cf* tw512;
+  const cf* tw1024;
+  float* mag;  // [units][T][FS]
+};
+
+template <int WAVES>
+__global__ __launch_bounds__(WAVES * 64, 2) void k_mag_fast(MagArgs A) {
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  cf* tw512 = reinterpret_cast<cf*>(smem);
+  cf* regions = tw512 + FN;
+  const int tid = threadIdx.x;
+  const int lane = tid & 63, wave = tid >> 6;
+  const int g = lane >> 4, c = lane & 15;
+  for (int i = tid; i < FN; i += WAVES * 64) tw512[i] = A.tw512[(i >> 4) * (i & 15)];
+  const Geom& G = A.g;
+  const int64_t u = blockIdx.y;
+  const int64_t row = (A.view.unit0 + u) / A.view.n_chunks;
+  const int64_t chunk = (A.view.unit0 + u) % A.view.n_chunks;
+  cf* fb = regions + wave * WAVE_CX + frame_base(g);
+  __syncthreads();
+  const int64_t tq = ((int64_t)blockIdx.x * WAVES + wave) * 4;
+  if (tq >= G.T) return;
+  const int64_t t = tq + g;
+  const bool fvalid = t < G.T;
+  cf v[32];
+  {
+    const int64_t s0 = t * 256 - G.padL;
+    const int64_t gbase = chunk * A.view.cs - A.view.pad + s0;
+    const bool inside = fvalid && s0 >= 0 && s0 + 1024 <= A.view.Lp && gbase >= A.view.lo &&
+                        gbase + 1024 <= A.view.hi && A.view.dtype == 0;
+    const float* src = (const float*)A.view.x + row * A.view.stride + gbase + 2 * c;
+    const bool aligned = (reinterpret_cast<uintptr_t>(src) & 7) == 0;
+    const float2* wsrc = reinterpret_cast<const float2*>(A.win + 2 * c);
+    if (inside && aligned) {
+      const float2* s2 = reinterpret_cast<const float2*>(src);
+#pragma unroll
+      for (int r = 0; r < 32; ++r) {
+        float2 x2 = s2[16 * r];
+        float2 w2 = wsrc[16 * r];
+        v[r] = {x2.x * w2.x, x2.y * w2.y};
+      }
+    } else {
+      float* fl = reinterpret_cast<float*>(fb);
+#pragma unroll 1
+      for (int r = 0; r < 32; ++r) {
+        float a = 0.f, b = 0.f;
+        if (fvalid) {
+          a = (float)view_sample(A.view, row, chunk, s0 + 2 * c + 32 * r);
+          b = (float)view_sample(A.view, row, chunk, s0 + 2 * c + 32 * r + 1);
+        }
+        fl[2 * c + 32 * r] = a;
+        fl[2 * c + 32 * r + 1] = b;
+      }
+      wave_lds_sync();
+#pragma unroll
+      for (int r = 0; r < 32; ++r) {
+        float2 w2 = wsrc[16 * r];
+        cf x2 = fb[c + 16 * r];
+        v[r] = {x2.x * w2.x, x2.y * w2.y};
+      }
+      wave_lds_sync();
+    }
+  }
+  fft512_fwd(v, fb, tw512, c);
+  const bool l0 = c == 0;
+  const cf wlo = A.tw1024[c];
+  cf whi = wlo;
+  {
+    const cf w16 = A.tw1024[16];
+    if (l0) whi = {-w16.y, w16.x};
+  }
+  auto sel = [&](cf a0, cf a1) -> cf { return {l0 ? a0.x : a1.x, l0 ? a0.y : a1.y}; };
+  float* mrow = A.mag + (u * G.T + (fvalid ? t : 0)) * (int64_t)G.FS;
+  auto put = [&](int e, float P4) {  // |X| = sqrt(P4) / 2 at the bin of entry e
+    if (fvalid) mrow[bin_of_entry(c, e)] = 0.5f * sqrtf(P4);
+  };
+  auto pair_power = [&](cf a, cf b, cf w, float& Pk, float& Pn) {
+    cf E = {a.x + b.x, a.y - b.y};
+    cf O = {a.y + b.y, b.x - a.x};
+    cf wO = cmul(w, O);
+    float px = E.x + wO.x, py = E.y + wO.y, qx = E.x - wO.x, qy = E.y - wO.y;
+    Pk = px * px + py * py;
+    Pn = qx * qx + qy * qy;
+  };
+  {
+    float Pk, Pn;
+    pair_power(v[0], v[31], wlo, Pk, Pn);
+    const cf a = v[0];
+    const float x0 = 2.f * (a.x + a.y), xN = 2.f * (a.x - a.y);
+    const float P256 = 4.f * (v[8].x * v[8].x + v[8].y * v[8].y);
+    put(0, l0 ? x0 * x0 : Pk);
+    put(31, l0 ? P256 : Pn);
+    if (l0 && fvalid) mrow[512] = 0.5f * fabsf(xN);
+  }
+#pragma unroll
+  for (int sl = 1; sl < 16; ++sl) {
+    const cf a = sl < 8 ? v[sl] : sel(v[8 + sl], v[sl]);
+    const cf b = sl < 8 ? sel(v[16 - sl], v[31 - sl]) : sel(v[39 - sl], v[31 - sl]);
+    const cf w = mul_tw<false>(sl < 8 ? wlo : whi, twc<32>(sl), tws<32>(sl));
+    float Pk, Pn;
+    pair_power(a, b, w, Pk, Pn);
+    put(sl, Pk);
+    put(31 - sl, Pn);
+  }
+}
+
+}  // namespace fast
+}  // namespace sg
