@@ -170,3 +170,41 @@ class TimeShardedStationary:
         else:
             ext, halo = y_local, 0
         return self.backend.filter(y_local, ext, halo, thr, owner=self.rank == 0)
+
+
+class ChannelShardedStationary:
+    """reduce_noise(stationary=True, y_noise=None) of a (C_total, N) recording whose CHANNELS are
+    dealt to the ranks (BASELINE.json configs[3]: 64 channels, 8 per GPU).  Every rank holds the full
+    timeline of its channels, so chunk windows need no halo; the only exchange is the channel mean
+    of the noise clip (stationary.py:61-64): an all-reduce(sum) of one clip-length float64 vector,
+    after which every rank computes the identical threshold locally."""
+
+    def __init__(self, backend, group=None):
+        self.backend = backend
+        self.group = group
+        self.ws = dist.get_world_size(group) if dist.is_initialized() else 1
+
+    def run(self, y_local, c_total=None):
+        if y_local.dim() == 1:
+            y_local = y_local[None, :]
+        C_local, N = y_local.shape
+        c_total = C_local * self.ws if c_total is None else c_total
+        n_clip = min(N, self.backend.chunk_size)
+        clip_sum = y_local[:, :n_clip].to(torch.float64).sum(dim=0)
+        if self.ws > 1:
+            dist.all_reduce(clip_sum, op=dist.ReduceOp.SUM, group=self.group)
+        clip_mean = (clip_sum / float(c_total)).unsqueeze(0)      # (1, n_clip): its own "channel mean"
+        return self.backend.filter_with_noise(y_local, clip_mean)
+
+
+def _hip_filter_with_noise(self, y_local, noise):
+    """HipStationaryBackend: statistics from an explicit noise clip, then the chunk grid."""
+    from noisereduce_amd.spectralgate.stationary import SpectralGateStationary
+    kw = dict(self.kw)
+    kw["y_noise"] = noise
+    sg = SpectralGateStationary(y=y_local, sr=self.sr, device=self.device, **kw)
+    S = y_local.shape[1]
+    return sg._gate.process_chunks(y_local, chunked=S > self.chunk_size)
+
+
+HipStationaryBackend.filter_with_noise = _hip_filter_with_noise

@@ -44,6 +44,40 @@ class OracleBackend:
         return torch.from_numpy(out)
 
 
+def _worker_channels(rank, world, port, y, want, ret):
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    from noisereduce_amd.sharded import ChannelShardedStationary
+
+    class Backend:
+        chunk_size, padding = CS, PAD
+
+        def filter_with_noise(self, y_local, noise):
+            out = O.reduce_noise_S(y_local.numpy().astype(np.float64), SR, stationary=True,
+                                   y_noise=noise.numpy(), chunk_size=CS, padding=PAD, n_fft=NFFT)
+            return torch.from_numpy(out)
+
+    C = y.shape[0] // world
+    y_local = y[rank * C:(rank + 1) * C].contiguous()
+    out = ChannelShardedStationary(Backend()).run(y_local)
+    ret[rank] = float((out - want[rank * C:(rank + 1) * C]).abs().max() / want.abs().max())
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_channel_sharded_two_ranks_matches_single_process():
+    n = 3 * CS + 777
+    y = np.stack([O.synth_signal(n, seed=60 + c, tone_hz=150.0 * (c + 1)).astype(np.float64) for c in range(4)])
+    want = O.reduce_noise_S(y, SR, stationary=True, chunk_size=CS, padding=PAD, n_fft=NFFT)
+    mgr = mp.Manager()
+    ret = mgr.dict()
+    mp.spawn(_worker_channels, args=(2, _free_port(), torch.from_numpy(y), torch.from_numpy(want), ret),
+             nprocs=2, join=True)
+    # the all-reduced channel mean can differ from numpy's sequential mean in the last bit
+    assert ret[0] < 1e-9 and ret[1] < 1e-9
+
+
 def _free_port():
     s = socket.socket()
     s.bind(("127.0.0.1", 0))
