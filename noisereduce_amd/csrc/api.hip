@@ -54,6 +54,8 @@ struct sg_handle {
   DevBuf bits, K16, umax, need, T2;  // fused stationary path
   DevBuf part;                       // partial reductions of the column statistics
   DevBuf tw512, invn, perm;          // fast path tables (n_fft = 1024, hop = 256)
+  DevBuf seam;                       // partial seam hops of abutting apply tiles
+  bool force_noseam = false;
   bool fast_ok = false;              // default geometry: fused apply kernel available
   bool force_nofast = false;
   bool force_f64_decide = false;     // SG_OPT_FORCE_F64_DECIDE: float64 STFT for every mask decision
@@ -424,7 +426,7 @@ extern "C" int sg_destroy(sg_handle* h) {
   for (auto e : h->prof_pool) (void)hipEventDestroy(e);
   for (DevBuf* b : {&h->tw64, &h->tw32, &h->wfull64, &h->wa32, &h->ws32, &h->wsq32, &h->kf, &h->kt, &h->thresh,
                     &h->P, &h->pmax, &h->thr_rows, &h->raw, &h->M, &h->seg, &h->yn, &h->bits, &h->K16, &h->umax,
-                    &h->need, &h->T2, &h->part, &h->tw512, &h->invn, &h->perm})
+                    &h->need, &h->T2, &h->part, &h->tw512, &h->invn, &h->perm, &h->seam})
     free_buf(*b);
   delete h;
   return SG_OK;
@@ -452,7 +454,8 @@ static int64_t ws_budget(const sg_handle* h) {
 // bit mask (T*wpr*8 B) and the uint16 weight sums (T*FS*2 B).
 static size_t unit_bytes(const sg_handle* h, const Geom& g, bool lean) {
   size_t cells = (size_t)g.T * g.FS;
-  if (lean) return (size_t)g.T * ((g.F + 63) / 64) * 8 + cells * 2 + (size_t)g.FS * 16 + 64;
+  if (lean) return (size_t)g.T * ((g.F + 63) / 64) * 8 + cells * 2 + (size_t)g.FS * 16 + 64 +
+           (size_t)(g.T / 16 + 2) * 6 * 256 * 4;
   return cells * (8 + 4 + 4 + 2) + (size_t)g.T * g.n * 4 + (size_t)g.FS * 16;
 }
 
@@ -776,9 +779,20 @@ static int stage_apply_fast(sg_handle* h, const View& v, const Geom& g, int64_t 
   A.h_end = (om.p1 - 1 + g.padL) / 256 + 1;
   const int64_t nh = A.h_end - A.h_begin;
   if (nh <= 0) return SG_OK;
-  constexpr int NH = 4 * WAVES - 3;
+  constexpr int NF = 4 * WAVES, NH = NF - 3;
   size_t lds = (size_t)(fast::FN + WAVES * fast::WAVE_CX) * sizeof(fast::cf);
-  dim3 grid((unsigned)((nh + NH - 1) / NH), (unsigned)ub);
+  // seam mode: abutting tiles + k_ola_seam for the straddling hops (3/16 fewer transforms)
+  const int64_t tiles_seam = (nh + 3 + NF - 1) / NF;
+  const bool seam = !h->force_noseam && tiles_seam >= 2;
+  A.part = nullptr;
+  A.n_tiles = 0;
+  if (seam) {
+    int rc = ensure(h, h->seam, (size_t)ub * tiles_seam * 6 * 256 * sizeof(float));
+    if (rc) return rc;
+    A.part = (float*)h->seam.p;
+    A.n_tiles = (int)tiles_seam;
+  }
+  dim3 grid((unsigned)(seam ? tiles_seam : (nh + NH - 1) / NH), (unsigned)ub);
   if (mask_f) {
     auto kern = fast::k_apply_fast<WAVES, false>;
     HIPCHK(h, hipFuncSetAttribute(reinterpret_cast<const void*>(kern),
@@ -791,6 +805,10 @@ static int stage_apply_fast(sg_handle* h, const View& v, const Geom& g, int64_t 
     hipLaunchKernelGGL(kern, grid, dim3(WAVES * 64), lds, st, A);
   }
   HIPCHK(h, hipGetLastError());
+  if (seam) {
+    hipLaunchKernelGGL(fast::k_ola_seam<NF>, dim3((unsigned)(tiles_seam - 1), (unsigned)ub), dim3(256), 0, st, A);
+    HIPCHK(h, hipGetLastError());
+  }
   return SG_OK;
 }
 
@@ -1123,6 +1141,7 @@ extern "C" int sg_set_option(sg_handle* h, int32_t option, int64_t value) {
     case SG_OPT_FORCE_UNFUSED: h->force_unfused = value != 0; return SG_OK;
     case SG_OPT_FORCE_NOFAST: h->force_nofast = value != 0; return SG_OK;
     case SG_OPT_FORCE_F64_DECIDE: h->force_f64_decide = value != 0; return SG_OK;
+    case SG_OPT_FORCE_NOSEAM: h->force_noseam = value != 0; return SG_OK;
   }
   FAIL(h, SG_E_INVALID, "sg_set_option: unknown option %d", option);
 }

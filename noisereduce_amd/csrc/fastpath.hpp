@@ -245,6 +245,8 @@ struct ApplyArgs {
   int64_t h_begin;          // first ext hop (256-sample block, ext = unit sample + 512) to produce
   int64_t h_end;
   int normalize;            // 1: divide by the window envelope (ISTFT); 0: plain overlap-add (adjoint)
+  float* part;              // seam mode: [units][tiles][6][256] un-normalised partial hops, else nullptr
+  int n_tiles;
 };
 
 // ---------------------------------------------------------------------------------------
@@ -266,8 +268,13 @@ __global__ __launch_bounds__(WAVES * 64, 2) void k_apply_fast(ApplyArgs A) {
   const int64_t u = blockIdx.y;
   const int64_t row = (A.view.unit0 + u) / A.view.n_chunks;
   const int64_t chunk = (A.view.unit0 + u) % A.view.n_chunks;
-  const int64_t hs = A.h_begin + (int64_t)blockIdx.x * NH;  // first hop of this tile
-  const int64_t t = hs - 3 + 4 * wave + g;                   // this lane group's frame
+  // Tiles either overlap by 3 frames (each tile completes its NH hops on its own) or, in seam mode,
+  // abut: then the 3 hops that straddle two tiles are written as un-normalised partial sums and
+  // combined by k_ola_seam -- 3/16 fewer transforms.
+  const bool seam = A.part != nullptr;
+  const int64_t tf_tile = A.h_begin - 3 + (int64_t)blockIdx.x * (seam ? NF : NH);  // first frame of the tile
+  const int64_t hs = tf_tile + 3;                            // first hop completed inside the tile
+  const int64_t t = tf_tile + 4 * wave + g;                  // this lane group's frame
   const bool fvalid = t >= 0 && t < G.T;
   const float4 inv4 = *reinterpret_cast<const float4*>(&A.invn[(tid & 63) * 4]);  // used by the OLA epilogue
 
@@ -421,33 +428,41 @@ __global__ __launch_bounds__(WAVES * 64, 2) void k_apply_fast(ApplyArgs A) {
   for (int r = 0; r < 32; ++r) fb[c + 16 * r] = {v[r].x * wsyn[r].x, v[r].y * wsyn[r].y};
   __syncthreads();
 
-  // overlap-add: tile hop j (ext hop hs + j) = sum over tile frames i = j..j+3 of quarter j+3-i
+  // overlap-add: tile hop jj (ext hop tf_tile + jj) = sum over tile frames i = jj-3..jj of quarter jj-i
   const float* fr = reinterpret_cast<const float*>(regions);
   const int s4 = (tid & 63) * 4;
   const float4 n4 = inv4;  // 1 / window envelope of this thread's four sample phases (loaded at entry)
-  for (int j = tid >> 6; j < NH; j += WAVES) {
-    const int64_t h = hs + j;
+  const int jj_lo = seam ? 0 : 3, jj_hi = seam ? NF + 3 : NF;
+  for (int jj = jj_lo + (tid >> 6); jj < jj_hi; jj += WAVES) {
+    const int64_t h = tf_tile + jj;
     if (h >= A.h_end) break;
+    if (h < A.h_begin) continue;
     float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
-    float4 nrm = make_float4(0.f, 0.f, 0.f, 0.f);
     bool all_valid = true;
 #pragma unroll
     for (int q = 0; q < 4; ++q) {
-      const int i = j + 3 - q;                 // tile frame contributing quarter q
-      const int64_t ti = hs - 3 + i;
-      if (ti >= 0 && ti < G.T) {
+      const int i = jj - q;                     // tile frame contributing quarter q
+      const int64_t ti = tf_tile + i;
+      if (ti < 0 || ti >= G.T) all_valid = false;
+      if (i >= 0 && i < NF && ti >= 0 && ti < G.T) {
         const int off = ((i >> 2) * WAVE_CX + frame_base(i & 3)) * 2 + 256 * q + s4;  // float index
         float4 f4 = *reinterpret_cast<const float4*>(&fr[off]);
         acc.x += f4.x; acc.y += f4.y; acc.z += f4.z; acc.w += f4.w;
-      } else {
-        all_valid = false;
       }
+    }
+    if (jj < 3 || jj >= NF) {
+      // seam hop: partial sum only; slot 0..2 = leading hops, 3..5 = trailing hops of this tile
+      const int slot = jj < 3 ? jj : 3 + (jj - NF);
+      float* dst = A.part + (((u * A.n_tiles + blockIdx.x) * 6 + slot) * 256 + s4);
+      *reinterpret_cast<float4*>(dst) = acc;
+      continue;
     }
     if (!A.normalize) {
       // adjoint: un-normalised overlap-add
     } else if (all_valid) {
       acc.x *= n4.x; acc.y *= n4.y; acc.z *= n4.z; acc.w *= n4.w;
     } else {
+      float4 nrm = make_float4(0.f, 0.f, 0.f, 0.f);
 #pragma unroll
       for (int q = 0; q < 4; ++q) {
         const int64_t ti = h - q;
@@ -470,6 +485,44 @@ __global__ __launch_bounds__(WAVES * 64, 2) void k_apply_fast(ApplyArgs A) {
       if (gi < A.om.g_lo || gi >= A.om.g_hi) continue;
       store_sample(A.om.out, A.om.dtype, row * A.om.stride + gi - A.om.g0, p < G.Lout ? vals[e] : 0.f);
     }
+  }
+}
+
+// Seam hops of abutting tiles: hop h = tf0 + NF*(b+1) + k (k = 0..2) is the trailing partial k of
+// tile b plus the leading partial k of tile b+1, normalised and stored here.
+template <int NF>
+__global__ __launch_bounds__(256) void k_ola_seam(ApplyArgs A) {
+  const Geom& G = A.g;
+  const int64_t u = blockIdx.y;
+  const int64_t b = blockIdx.x;
+  const int64_t row = (A.view.unit0 + u) / A.view.n_chunks;
+  const int64_t chunk = (A.view.unit0 + u) % A.view.n_chunks;
+  const int s = threadIdx.x;
+  const float* pa = A.part + ((u * A.n_tiles + b) * 6 + 3) * 256;      // trailing hops of tile b
+  const float* pb = A.part + ((u * A.n_tiles + b + 1) * 6 + 0) * 256;  // leading hops of tile b+1
+#pragma unroll
+  for (int k = 0; k < 3; ++k) {
+    const int64_t h = A.h_begin - 3 + (int64_t)NF * (b + 1) + k;
+    if (h < A.h_begin || h >= A.h_end) continue;
+    float val = pa[k * 256 + s] + pb[k * 256 + s];
+    if (A.normalize) {
+      if (h - 3 >= 0 && h < G.T) {
+        val *= A.invn[s];  // same reciprocal table as the in-tile hops
+      } else {
+        float nrm = 0.f;
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+          const int64_t ti = h - q;
+          if (ti >= 0 && ti < G.T) nrm += A.wsq[256 * q + s];
+        }
+        val /= (nrm > 1e-10f ? nrm : 1.f);
+      }
+    }
+    const int64_t p = h * 256 + s - G.padL;
+    if (p < A.om.p0 || p >= A.om.p1) continue;
+    const int64_t gi = chunk * A.om.g_step + (p - A.om.p0);
+    if (gi < A.om.g_lo || gi >= A.om.g_hi) continue;
+    store_sample(A.om.out, A.om.dtype, row * A.om.stride + gi - A.om.g0, p < G.Lout ? val : 0.f);
   }
 }
 

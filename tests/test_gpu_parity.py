@@ -379,3 +379,24 @@ def test_use_torch_routing(nr):
         f = O.torchgate_T(chunk, 48000, window=w)
         want[s0:e0] = f[0, 4000:4000 + e0 - s0]
     assert O.rel_err(got, want) < TOL
+
+
+def test_seam_tiles_equal_overlapping_tiles(nr):
+    """Abutting apply tiles + seam kernel vs self-contained overlapping tiles: same samples."""
+    from noisereduce_amd import _ffi
+    from noisereduce_amd.spectralgate.stationary import SpectralGateStationary
+    y = O.synth_signal(150000, seed=91)
+    kw = dict(sr=48000, y_noise=None, prop_decrease=1.0, n_std_thresh_stationary=1.5,
+              chunk_size=40000, clip_noise_stationary=True, padding=5000, n_fft=1024, win_length=None,
+              hop_length=None, time_constant_s=2.0, freq_mask_smooth_hz=500, time_mask_smooth_ms=50,
+              tmp_folder=None, use_tqdm=False, n_jobs=1)
+    sg = SpectralGateStationary(y=y, **kw)
+    a = sg.get_traces()
+    try:
+        sg._gate.set_option(_ffi.SG_OPT_FORCE_NOSEAM, 1)
+        b = sg.get_traces()
+    finally:
+        sg._gate.set_option(_ffi.SG_OPT_FORCE_NOSEAM, 0)
+    assert O.rel_err(a, b) < 1e-6
+    want = O.reduce_noise_S(y.astype(np.float64), 48000, stationary=True, chunk_size=40000, padding=5000)
+    assert O.rel_err(a, want) < TOL and O.rel_err(b, want) < TOL
