@@ -55,6 +55,7 @@ struct sg_handle {
   DevBuf part;                       // partial reductions of the column statistics
   DevBuf tw512, invn, perm;          // fast path tables (n_fft = 1024, hop = 256)
   DevBuf seam;                       // partial seam hops of abutting apply tiles
+  DevBuf ftab;                       // k_smooth_bits2 phase-1 lookup tables (nf <= 5)
   bool force_noseam = false;
   bool fast_ok = false;              // default geometry: fused apply kernel available
   bool force_nofast = false;
@@ -409,6 +410,26 @@ extern "C" int sg_create(const sg_params* p, const double* window_host, sg_handl
     if (!rc) rc = upload(h, h->perm, perm.data(), perm.size() * sizeof(int));
     h->fast_ok = true;
   }
+  if (!rc && p->smooth_mask && 8 + 2 * p->n_grad_freq <= 18) {
+    // counts of 8 adjacent bins f..f+7 from the 18-bit window b[f-nf .. f-nf+17]: two 9-bit tables
+    const int nf = p->n_grad_freq;
+    std::vector<unsigned long long> tab(1024, 0ull);
+    for (int half = 0; half < 2; ++half)
+      for (int v = 0; v < 512; ++v) {
+        unsigned long long packed = 0;
+        for (int e = 0; e < 8; ++e) {
+          int cnt = 0;
+          for (int b = 0; b < 9; ++b)
+            if ((v >> b) & 1) {
+              int a = (half * 9 + b) - nf - e;  // tap offset of window bit relative to bin f+e
+              if (a >= -nf && a <= nf) cnt += nf + 1 - (a < 0 ? -a : a);
+            }
+          packed |= (unsigned long long)cnt << (8 * e);
+        }
+        tab[half * 512 + v] = packed;
+      }
+    rc = upload(h, h->ftab, tab.data(), tab.size() * sizeof(unsigned long long));
+  }
   if (!rc) rc = ensure(h, h->thresh, (size_t)h->FS * sizeof(double));
   if (rc) {
     g_create_error = h->err;
@@ -426,7 +447,7 @@ extern "C" int sg_destroy(sg_handle* h) {
   for (auto e : h->prof_pool) (void)hipEventDestroy(e);
   for (DevBuf* b : {&h->tw64, &h->tw32, &h->wfull64, &h->wa32, &h->ws32, &h->wsq32, &h->kf, &h->kt, &h->thresh,
                     &h->P, &h->pmax, &h->thr_rows, &h->raw, &h->M, &h->seg, &h->yn, &h->bits, &h->K16, &h->umax,
-                    &h->need, &h->T2, &h->part, &h->tw512, &h->invn, &h->perm, &h->seam})
+                    &h->need, &h->T2, &h->part, &h->tw512, &h->invn, &h->perm, &h->seam, &h->ftab})
     free_buf(*b);
   delete h;
   return SG_OK;
@@ -708,7 +729,8 @@ static int stage_fused_mask(sg_handle* h, const View& v, const Geom& g, int64_t 
   if (h->p.smooth_mask && nf <= 30) {
     const int rows = SM2_TT + 2 * nt;
     const bool small = (nf + 1) * (nf + 1) <= 255;
-    size_t lds = smooth2_cf_bytes(rows, g.F, small ? 1 : 2) + (size_t)rows * (wpr + 2) * 8;
+    const unsigned long long* ftab = (small && h->ftab.p) ? (const unsigned long long*)h->ftab.p : nullptr;
+    size_t lds = smooth2_cf_bytes(rows, g.F, small ? 1 : 2) + (size_t)rows * (wpr + 2) * 8 + (ftab ? 8192 : 0);
     dim3 grid((unsigned)((te - tb + SM2_TT - 1) / SM2_TT), (unsigned)ub);
     if (small) {
       auto kern = k_smooth_bits2<uint8_t>;
@@ -716,14 +738,14 @@ static int stage_fused_mask(sg_handle* h, const View& v, const Geom& g, int64_t 
         HIPCHK(h, hipFuncSetAttribute(reinterpret_cast<const void*>(kern),
                                       hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
       hipLaunchKernelGGL(kern, grid, dim3(SM2_THREADS), lds, st, (const unsigned long long*)h->bits.p, g, wpr, nf,
-                         nt, (unsigned short*)h->K16.p, fast ? 1 : 0, tb, te);
+                         nt, (unsigned short*)h->K16.p, fast ? 1 : 0, tb, te, ftab);
     } else {
       auto kern = k_smooth_bits2<uint16_t>;
       if (lds > 65536)
         HIPCHK(h, hipFuncSetAttribute(reinterpret_cast<const void*>(kern),
                                       hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
       hipLaunchKernelGGL(kern, grid, dim3(SM2_THREADS), lds, st, (const unsigned long long*)h->bits.p, g, wpr, nf,
-                         nt, (unsigned short*)h->K16.p, fast ? 1 : 0, tb, te);
+                         nt, (unsigned short*)h->K16.p, fast ? 1 : 0, tb, te, (const unsigned long long*)nullptr);
     }
   } else if (h->p.smooth_mask) {
     const int rows = SM_TT + 2 * nt;

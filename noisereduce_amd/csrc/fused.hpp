@@ -291,7 +291,8 @@ template <typename CT>
 __global__ __launch_bounds__(SM2_THREADS) void k_smooth_bits2(const unsigned long long* __restrict__ bits, Geom g,
                                                                int wpr, int nf, int nt,
                                                                unsigned short* __restrict__ K, int perm,
-                                                               int64_t t_begin, int64_t t_end) {
+                                                               int64_t t_begin, int64_t t_end,
+                                                               const unsigned long long* __restrict__ ftab) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
   const int rows = SM2_TT + 2 * nt;
   // phase-1 counts are stored at column f + 4*(f/32): the phase-2 column walk visits bins 32 apart
@@ -316,6 +317,27 @@ __global__ __launch_bounds__(SM2_THREADS) void k_smooth_bits2(const unsigned lon
   }
   __syncthreads();
   // ---- phase 1: along f ----------------------------------------------------------------
+  if (ftab != nullptr && sizeof(CT) == 1) {
+    // table form (8 + 2 nf <= 18 window bits): the counts of 8 adjacent bins are linear in the 18
+    // window bits, so they are the sum of two 512-entry tables of 8 packed byte counts.
+    unsigned long long* tab = wb + (size_t)rows * WP;  // [2][512] staged in LDS
+    for (int i = threadIdx.x; i < 1024; i += SM2_THREADS) tab[i] = ftab[i];
+    __syncthreads();
+    const int ngrp = (g.F + 7) / 8;
+    for (int task = threadIdx.x; task < rows * ngrp; task += SM2_THREADS) {
+      const int r = task / ngrp, grp = task - r * ngrp;
+      const int f = 8 * grp;
+      const unsigned long long* rb = wb + (size_t)r * WP + 1;  // word w at rb[w], rb[-1] = 0
+      const int start = f - nf + 64;                           // bit index in the stream that begins at rb[-1]
+      const int wi = (start >> 6) - 1, sh = start & 63;
+      const unsigned win = (unsigned)(funnel_r(rb[wi], rb[wi + 1], sh)) & 0x3ffffu;
+      const unsigned long long cnt = tab[win & 511u] + tab[512 + (win >> 9)];
+      CT* out = cf + (size_t)r * FP + f + ((f >> 5) << 2);
+      *reinterpret_cast<unsigned*>(out) = (unsigned)cnt;
+      *reinterpret_cast<unsigned*>(out + 4) = (unsigned)(cnt >> 32);
+    }
+    __syncthreads();
+  } else {
   const unsigned long long m1 = (1ull << (nf + 1)) - 1ull;
   for (int task = threadIdx.x; task < rows * wpr; task += SM2_THREADS) {
     const int r = task / wpr, w = task - r * wpr;
@@ -353,6 +375,7 @@ __global__ __launch_bounds__(SM2_THREADS) void k_smooth_bits2(const unsigned lon
     }
   }
   __syncthreads();
+  }
   // ---- phase 2: along t, one output position per thread ------------------------------------
   for (int pos = threadIdx.x; pos < g.F; pos += SM2_THREADS) {
     const int f = perm ? fast::perm_inv(pos) : pos;
