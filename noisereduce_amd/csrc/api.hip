@@ -53,7 +53,7 @@ struct sg_handle {
   DevBuf P, pmax, thr_rows, raw, M, seg, yn;
   DevBuf bits, K16, umax, need, T2;  // fused stationary path
   DevBuf part;                       // partial reductions of the column statistics
-  DevBuf tw512, invn, perm;          // fast path tables (n_fft = 1024, hop = 256)
+  DevBuf tw512, invn;                // fast path tables (n_fft = 1024, hop = 256)
   DevBuf seam;                       // partial seam hops of abutting apply tiles
   DevBuf ftab;                       // k_smooth_bits2 phase-1 lookup tables (nf <= 5)
   bool force_noseam = false;
@@ -405,9 +405,6 @@ extern "C" int sg_create(const sg_params* p, const double* window_host, sg_handl
     }
     rc = upload(h, h->tw512, t512.data(), t512.size() * sizeof(cx<float>));
     if (!rc) rc = upload(h, h->invn, invn.data(), invn.size() * sizeof(float));
-    std::vector<int> perm(h->FS, 0);
-    for (int f = 0; f < h->F; ++f) perm[f] = fast::perm_pos(f);
-    if (!rc) rc = upload(h, h->perm, perm.data(), perm.size() * sizeof(int));
     h->fast_ok = true;
   }
   if (!rc && p->smooth_mask && 8 + 2 * p->n_grad_freq <= 18) {
@@ -447,7 +444,7 @@ extern "C" int sg_destroy(sg_handle* h) {
   for (auto e : h->prof_pool) (void)hipEventDestroy(e);
   for (DevBuf* b : {&h->tw64, &h->tw32, &h->wfull64, &h->wa32, &h->ws32, &h->wsq32, &h->kf, &h->kt, &h->thresh,
                     &h->P, &h->pmax, &h->thr_rows, &h->raw, &h->M, &h->seg, &h->yn, &h->bits, &h->K16, &h->umax,
-                    &h->need, &h->T2, &h->part, &h->tw512, &h->invn, &h->perm, &h->seam, &h->ftab})
+                    &h->need, &h->T2, &h->part, &h->tw512, &h->invn, &h->seam, &h->ftab})
     free_buf(*b);
   delete h;
   return SG_OK;
@@ -597,13 +594,13 @@ static int stage_nonstat_raw(sg_handle* h, const View& v, const Geom& g, int64_t
   return SG_OK;
 }
 
-static int stage_smooth(sg_handle* h, const Geom& g, int64_t ub, const int* perm, hipStream_t st) {
+static int stage_smooth(sg_handle* h, const Geom& g, int64_t ub, hipStream_t st) {
   ProfScope ps(h, SG_STAGE_SMOOTH, st);
   int64_t cells = ub * g.T * g.FS;
   float p = (float)h->p.prop_decrease;
   if (!h->p.smooth_mask) {
     hipLaunchKernelGGL(k_prop_only, dim3(grid_1d(cells, 256)), dim3(256), 0, st, (const float*)h->raw.p, g, p,
-                       (float*)h->M.p, ub, perm);
+                       (float*)h->M.p, ub);
     HIPCHK(h, hipGetLastError());
     return SG_OK;
   }
@@ -615,7 +612,7 @@ static int stage_smooth(sg_handle* h, const Geom& g, int64_t ub, const int* perm
     const int rows = SMF_TT + 2 * nt, cols = SMF_FB + 2 * nf;
     // +3: the sliding windows read up to 3 entries past the last tap
     size_t lds = ((size_t)(rows + 3) * (cols | 1) + (size_t)(rows + 3) * (SMF_FB + 1) + 8) * sizeof(float);
-    if (!perm && lds <= 150 * 1024 && ub <= 65535 && nf <= 30 && nt <= 30 && SMF_FB + 2 * nf <= 192) {
+    if (lds <= 150 * 1024 && ub <= 65535 && nf <= 30 && nt <= 30 && SMF_FB + 2 * nf <= 192) {
       auto kern = k_smooth_tiled;
       if (lds > 65536)
         HIPCHK(h, hipFuncSetAttribute(reinterpret_cast<const void*>(kern),
@@ -636,7 +633,7 @@ static int stage_smooth(sg_handle* h, const Geom& g, int64_t ub, const int* perm
   int prop_before = (h->p.variant == SG_VARIANT_T || h->p.stationary) ? 1 : 0;
   hipLaunchKernelGGL(k_smooth_t, dim3(grid_1d(cells, 256)), dim3(256), 0, st, (const float*)tmp, g,
                      (const float*)h->kt.p, h->p.n_grad_time, (const float*)h->kf.p, h->p.n_grad_freq, p,
-                     prop_before, (float*)h->M.p, ub, perm);
+                     prop_before, (float*)h->M.p, ub);
   HIPCHK(h, hipGetLastError());
   return SG_OK;
 }
@@ -659,9 +656,65 @@ static int stage_apply_ola(sg_handle* h, const View& v, const Geom& g, int64_t u
   return SG_OK;
 }
 
+// bits -> K (uint16 weight sums), natural or lane order
+static int stage_smooth_bits(sg_handle* h, const Geom& g, int64_t ub, bool fast, int64_t tb, int64_t te,
+                             hipStream_t st) {
+  const int wpr = (g.F + 63) / 64;
+  ProfScope ps(h, SG_STAGE_SMOOTH, st);
+  const int nf = h->p.n_grad_freq, nt = h->p.n_grad_time;
+  int64_t cells = ub * g.T * g.FS;
+  if (h->p.smooth_mask && nf <= 30) {
+    const int rows = SM2_TT + 2 * nt;
+    const bool small = (nf + 1) * (nf + 1) <= 255;
+    const unsigned long long* ftab = (small && h->ftab.p) ? (const unsigned long long*)h->ftab.p : nullptr;
+    size_t lds = smooth2_cf_bytes(rows, g.F, small ? 1 : 2) + (size_t)rows * (wpr + 2) * 8 + (ftab ? 8192 : 0);
+    dim3 grid((unsigned)((te - tb + SM2_TT - 1) / SM2_TT), (unsigned)ub);
+    if (small) {
+      auto kern = k_smooth_bits2<uint8_t>;
+      if (lds > 65536)
+        HIPCHK(h, hipFuncSetAttribute(reinterpret_cast<const void*>(kern),
+                                      hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+      hipLaunchKernelGGL(kern, grid, dim3(SM2_THREADS), lds, st, (const unsigned long long*)h->bits.p, g, wpr, nf,
+                         nt, (unsigned short*)h->K16.p, fast ? 1 : 0, tb, te, ftab);
+    } else {
+      auto kern = k_smooth_bits2<uint16_t>;
+      if (lds > 65536)
+        HIPCHK(h, hipFuncSetAttribute(reinterpret_cast<const void*>(kern),
+                                      hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+      hipLaunchKernelGGL(kern, grid, dim3(SM2_THREADS), lds, st, (const unsigned long long*)h->bits.p, g, wpr, nf,
+                         nt, (unsigned short*)h->K16.p, fast ? 1 : 0, tb, te, (const unsigned long long*)nullptr);
+    }
+  } else if (h->p.smooth_mask) {
+    const int rows = SM_TT + 2 * nt;
+    const bool small = (nf + 1) * (nf + 1) <= 255;
+    size_t lds = smooth_cf_bytes(rows, g.F, small ? 1 : 2) + (size_t)rows * wpr * 8;
+    dim3 grid((unsigned)((g.T + SM_TT - 1) / SM_TT), (unsigned)ub);
+    if (small) {
+      auto kern = k_smooth_bits<uint8_t>;
+      if (lds > 65536)
+        HIPCHK(h, hipFuncSetAttribute(reinterpret_cast<const void*>(kern),
+                                      hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+      hipLaunchKernelGGL(kern, grid, dim3(256), lds, st, (const unsigned long long*)h->bits.p, g, wpr, nf, nt,
+                         (unsigned short*)h->K16.p, fast ? 1 : 0);
+    } else {
+      auto kern = k_smooth_bits<uint16_t>;
+      if (lds > 65536)
+        HIPCHK(h, hipFuncSetAttribute(reinterpret_cast<const void*>(kern),
+                                      hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+      hipLaunchKernelGGL(kern, grid, dim3(256), lds, st, (const unsigned long long*)h->bits.p, g, wpr, nf, nt,
+                         (unsigned short*)h->K16.p, fast ? 1 : 0);
+    }
+  } else {
+    hipLaunchKernelGGL(k_bits_to_k16, dim3(grid_1d(cells, 256)), dim3(256), 0, st,
+                       (const unsigned long long*)h->bits.p, g, wpr, (unsigned short*)h->K16.p, ub, fast ? 1 : 0);
+  }
+  HIPCHK(h, hipGetLastError());
+  return SG_OK;
+}
+
 // Fused stationary mask (variant S): STFT(f64) -> bits -> integer smoothing -> K16 -> float mask.
 static int stage_fused_mask(sg_handle* h, const View& v, const Geom& g, int64_t ub, bool fast, int64_t tb,
-                            int64_t te, const int* perm, hipStream_t st) {
+                            int64_t te, hipStream_t st) {
   // [tb, te): frames whose smoothed mask is needed; decisions are needed nt frames further out
   const int64_t nt_halo = h->p.smooth_mask ? h->p.n_grad_time : 0;
   const int64_t db = std::max<int64_t>(0, tb - nt_halo), de = std::min<int64_t>(g.T, te + nt_halo);
@@ -723,59 +776,13 @@ static int stage_fused_mask(sg_handle* h, const View& v, const Geom& g, int64_t 
     HIPCHK(h, launch_bits<1>(h->N, v, g, ub, h->tw64.p, h->wfull64.p, tc, h->mag_scale, h->p.top_db,
                              (unsigned long long*)h->pmax.p, (unsigned long long*)h->bits.p, wpr, st));
   }
-  ProfScope ps(h, SG_STAGE_SMOOTH, st);
+  { int rc2 = stage_smooth_bits(h, g, ub, fast, tb, te, st); if (rc2) return rc2; }
   const int nf = h->p.n_grad_freq, nt = h->p.n_grad_time;
   int64_t cells = ub * g.T * g.FS;
-  if (h->p.smooth_mask && nf <= 30) {
-    const int rows = SM2_TT + 2 * nt;
-    const bool small = (nf + 1) * (nf + 1) <= 255;
-    const unsigned long long* ftab = (small && h->ftab.p) ? (const unsigned long long*)h->ftab.p : nullptr;
-    size_t lds = smooth2_cf_bytes(rows, g.F, small ? 1 : 2) + (size_t)rows * (wpr + 2) * 8 + (ftab ? 8192 : 0);
-    dim3 grid((unsigned)((te - tb + SM2_TT - 1) / SM2_TT), (unsigned)ub);
-    if (small) {
-      auto kern = k_smooth_bits2<uint8_t>;
-      if (lds > 65536)
-        HIPCHK(h, hipFuncSetAttribute(reinterpret_cast<const void*>(kern),
-                                      hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-      hipLaunchKernelGGL(kern, grid, dim3(SM2_THREADS), lds, st, (const unsigned long long*)h->bits.p, g, wpr, nf,
-                         nt, (unsigned short*)h->K16.p, fast ? 1 : 0, tb, te, ftab);
-    } else {
-      auto kern = k_smooth_bits2<uint16_t>;
-      if (lds > 65536)
-        HIPCHK(h, hipFuncSetAttribute(reinterpret_cast<const void*>(kern),
-                                      hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-      hipLaunchKernelGGL(kern, grid, dim3(SM2_THREADS), lds, st, (const unsigned long long*)h->bits.p, g, wpr, nf,
-                         nt, (unsigned short*)h->K16.p, fast ? 1 : 0, tb, te, (const unsigned long long*)nullptr);
-    }
-  } else if (h->p.smooth_mask) {
-    const int rows = SM_TT + 2 * nt;
-    const bool small = (nf + 1) * (nf + 1) <= 255;
-    size_t lds = smooth_cf_bytes(rows, g.F, small ? 1 : 2) + (size_t)rows * wpr * 8;
-    dim3 grid((unsigned)((g.T + SM_TT - 1) / SM_TT), (unsigned)ub);
-    if (small) {
-      auto kern = k_smooth_bits<uint8_t>;
-      if (lds > 65536)
-        HIPCHK(h, hipFuncSetAttribute(reinterpret_cast<const void*>(kern),
-                                      hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-      hipLaunchKernelGGL(kern, grid, dim3(256), lds, st, (const unsigned long long*)h->bits.p, g, wpr, nf, nt,
-                         (unsigned short*)h->K16.p, fast ? 1 : 0);
-    } else {
-      auto kern = k_smooth_bits<uint16_t>;
-      if (lds > 65536)
-        HIPCHK(h, hipFuncSetAttribute(reinterpret_cast<const void*>(kern),
-                                      hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-      hipLaunchKernelGGL(kern, grid, dim3(256), lds, st, (const unsigned long long*)h->bits.p, g, wpr, nf, nt,
-                         (unsigned short*)h->K16.p, fast ? 1 : 0);
-    }
-  } else {
-    hipLaunchKernelGGL(k_bits_to_k16, dim3(grid_1d(cells, 256)), dim3(256), 0, st,
-                       (const unsigned long long*)h->bits.p, g, wpr, (unsigned short*)h->K16.p, ub, fast ? 1 : 0);
-  }
-  HIPCHK(h, hipGetLastError());
   if (fast) return SG_OK;  // the fused apply kernel reads K directly
   hipLaunchKernelGGL(k_k16_to_mask, dim3(grid_1d(cells, 256)), dim3(256), 0, st, (const unsigned short*)h->K16.p,
                      g, nf, nt, 1.0f / (float)h->ktot, (float)h->p.prop_decrease, 1, h->p.smooth_mask ? 1 : 0,
-                     (float*)h->M.p, ub, perm);
+                     (float*)h->M.p, ub);
   HIPCHK(h, hipGetLastError());
   return SG_OK;
 }
@@ -856,16 +863,15 @@ static int run_S(sg_handle* h, View v, int64_t total_units, const OutMap& om, hi
       // frames the fused apply kernel touches: hops [h_begin, h_end) need frames h-3 .. h
       const int64_t hb = (om.p0 + g.padL) / 256, he = (om.p1 - 1 + g.padL) / 256 + 1;
       const int64_t tb = std::max<int64_t>(0, hb - 3), te = std::min<int64_t>(g.T, he);
-      if ((rc = stage_fused_mask(h, v, g, nb, true, tb, std::max(te, tb + 1), nullptr, st))) return rc;
+      if ((rc = stage_fused_mask(h, v, g, nb, true, tb, std::max(te, tb + 1), st))) return rc;
       if ((rc = stage_apply_fast(h, v, g, nb, om, nullptr, 1, st))) return rc;
       h->dbg_units = nb; h->dbg_T = g.T; h->dbg_has_P = false; h->dbg_fused = true; h->dbg_fast = true;
       continue;
     }
     // float mask field (natural bin order for the general apply kernels, lane order for the fused one)
-    const int* perm = nullptr;
     h->dbg_fast = geom_fast;
     if (fused) {
-      if ((rc = stage_fused_mask(h, v, g, nb, false, 0, g.T, perm, st))) return rc;
+      if ((rc = stage_fused_mask(h, v, g, nb, false, 0, g.T, st))) return rc;
     } else {
       if (h->p.stationary) {
         if ((rc = stage_power(h, v, g, nb, st))) return rc;
@@ -873,7 +879,7 @@ static int run_S(sg_handle* h, View v, int64_t total_units, const OutMap& om, hi
       } else {
         if ((rc = stage_nonstat_raw(h, v, g, nb, st))) return rc;
       }
-      if ((rc = stage_smooth(h, g, nb, perm, st))) return rc;
+      if ((rc = stage_smooth(h, g, nb, st))) return rc;
     }
     if (geom_fast) {
       if ((rc = stage_apply_fast(h, v, g, nb, om, (const float*)h->M.p, 1, st))) return rc;
@@ -1073,13 +1079,40 @@ extern "C" int sg_process_batch(sg_handle* h, const void* x_dev, int dtype, int6
         if ((rc = stage_colstats(h, g, nb, thr, st))) return rc;
         th = thr;
       }
+      // default geometry, full reduction: decisions as bits -> exact integer smoothing -> uint16 sums
+      // read by the fused apply kernel (same stages as the variant-S fused path)
+      const bool bits_path = h->fast_ok && !h->force_nofast && !h->force_unfused && h->p.prop_decrease == 1.0 &&
+                             h->ktot <= 65535 && (!h->p.smooth_mask || h->p.n_grad_time <= 96);
+      if (bits_path) {
+        const int wpr = (g.F + 63) / 64;
+        if ((rc = ensure(h, h->bits, (size_t)nb * g.T * wpr * 8))) return rc;
+        if ((rc = ensure(h, h->K16, (size_t)nb * g.T * g.FS * 2))) return rc;
+        {
+          ProfScope ps(h, SG_STAGE_DECIDE, st);
+          hipLaunchKernelGGL(k_decide_bits, dim3(grid_1d(nb * g.T * wpr * 64, 256)), dim3(256), 0, st,
+                             (const double*)h->P.p, g, (const double*)h->pmax.p, th, ustride, h->mag_scale,
+                             h->p.top_db, (unsigned long long*)h->bits.p, wpr, nb);
+          HIPCHK(h, hipGetLastError());
+        }
+        if ((rc = stage_smooth_bits(h, g, nb, true, 0, g.T, st))) return rc;
+        if (mask_out_dev) {  // float mask (natural bin order) for the backward pass
+          hipLaunchKernelGGL(k_k16_to_mask_perm, dim3(grid_1d(nb * g.T * g.FS, 256)), dim3(256), 0, st,
+                             (const unsigned short*)h->K16.p, g, 1.0f / (float)h->ktot,
+                             mask_out_dev + (size_t)u0 * g.T * g.FS, nb);
+          HIPCHK(h, hipGetLastError());
+        }
+        if ((rc = stage_apply_fast(h, v, g, nb, om, nullptr, 1, st))) return rc;
+        h->dbg_units = nb; h->dbg_T = g.T; h->dbg_has_P = true; h->dbg_fused = true; h->dbg_fast = true;
+        h->dbg_db = 0; h->dbg_de = g.T;
+        continue;
+      }
       if ((rc = stage_decide(h, g, nb, th, ustride, st))) return rc;
     } else {
       if ((rc = stage_nonstat_raw(h, v, g, nb, st))) return rc;
     }
     const bool geom_fast = h->fast_ok && !h->force_nofast;
-    if ((rc = stage_smooth(h, g, nb, nullptr, st))) return rc;
-    if (mask_out_dev)  // kept in whatever bin order this handle's apply kernel reads
+    if ((rc = stage_smooth(h, g, nb, st))) return rc;
+    if (mask_out_dev)
       HIPCHK(h, hipMemcpyAsync(mask_out_dev + (size_t)u0 * g.T * g.FS, h->M.p, (size_t)nb * g.T * g.FS * 4,
                                hipMemcpyDeviceToDevice, st));
     if (geom_fast) {

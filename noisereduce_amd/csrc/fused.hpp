@@ -8,14 +8,13 @@
 //                   units whose floor may be live), MODE_DECIDE: mask bits via wave ballot
 //   k_smooth_bits   separable triangular smoothing on the bit field in exact integer
 //                   arithmetic -> uint16 weight sums K (mask = K / ktot)
-// The apply kernel (k_apply_istft_k16 in this file) reads K instead of a float mask.
+// fast::k_apply_fast reads K directly (lane order); k_k16_to_mask expands it to a float mask for
+// the general apply kernels.
 #pragma once
 #include "kernels.hpp"
 #include "fastpath.hpp"
 
 namespace sg {
-
-constexpr int BITS_WPR_MAX = 33;  // 64-bit words per bit row: ceil(F/64), F <= 2049
 
 
 // ---------------------------------------------------------------------------------------
@@ -421,8 +420,7 @@ __global__ void k_bits_to_k16(const unsigned long long* __restrict__ bits, Geom 
 // reference applies prop_decrease before smoothing, else 1).  Written as float for the v1
 // apply kernel (general geometries); the fast apply kernel evaluates this on the fly.
 __global__ void k_k16_to_mask(const unsigned short* __restrict__ K, Geom g, int nf, int nt, float inv_ktot,
-                              float p, int prop_before, int smooth, float* __restrict__ M, int64_t n_units,
-                              const int* __restrict__ perm) {
+                              float p, int prop_before, int smooth, float* __restrict__ M, int64_t n_units) {
   const int64_t cells = n_units * g.T * g.FS;
   for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < cells;
        i += (int64_t)gridDim.x * blockDim.x) {
@@ -441,7 +439,21 @@ __global__ void k_k16_to_mask(const unsigned short* __restrict__ K, Geom g, int 
       int64_t tlo = max<int64_t>(-nt, -t), thi = min<int64_t>(nt, g.T - 1 - t);
       edge = (float)tri(nf, flo, fhi) * (float)tri(nt, (int)tlo, (int)thi) * inv_ktot;
     }
-    M[perm ? i - f + perm[f] : i] = p * ((float)K[i] * inv_ktot) + (1.0f - p) * edge;
+    M[i] = p * ((float)K[i] * inv_ktot) + (1.0f - p) * edge;
+  }
+}
+
+
+// K stored in the lane order of the fused apply kernel -> float mask in natural bin order
+// (full reduction: mask = K / ktot); used when a training step needs the mask for the adjoint.
+__global__ void k_k16_to_mask_perm(const unsigned short* __restrict__ K, Geom g, float inv_ktot,
+                                   float* __restrict__ M, int64_t n_units) {
+  const int64_t cells = n_units * g.T * g.FS;
+  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < cells;
+       i += (int64_t)gridDim.x * blockDim.x) {
+    const int pos = (int)(i % g.FS);
+    if (pos >= g.F) continue;
+    M[i - pos + fast::perm_inv(pos)] = (float)K[i] * inv_ktot;
   }
 }
 

@@ -389,6 +389,31 @@ __global__ void k_decide(const double* __restrict__ P, Geom g, const double* __r
   }
 }
 
+// Same decision as k_decide, written as a bit mask (64 bins per word, one wavefront per word) for
+// the integer smoothing / fused apply kernels.
+__global__ void k_decide_bits(const double* __restrict__ P, Geom g, const double* __restrict__ pmax,
+                              const double* __restrict__ thresh, int64_t thresh_ustride, double mag_scale,
+                              double top_db, unsigned long long* __restrict__ bits, int wpr, int64_t n_units) {
+  const int lane = threadIdx.x & 63;
+  const int64_t nwords = n_units * g.T * wpr;
+  for (int64_t wd = (int64_t)blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6); wd < nwords;
+       wd += (int64_t)gridDim.x * (blockDim.x >> 6)) {
+    const int w = (int)(wd % wpr);
+    const int64_t ut = wd / wpr;
+    const int64_t u = ut / g.T;
+    const int f = 64 * w + lane;
+    bool pred = false;
+    if (f < g.F) {
+      double db = cell_db(P[ut * g.FS + f], mag_scale);
+      double fl = cell_db(pmax[u * g.FS + f], mag_scale) - top_db;
+      db = fmax(db, fl);
+      pred = db > thresh[u * thresh_ustride + f];
+    }
+    const unsigned long long word = __ballot(pred);
+    if (lane == 0) bits[wd] = word;
+  }
+}
+
 // ---------------------------------------------------------------------------------------
 // Non-stationary raw masks.
 // ---------------------------------------------------------------------------------------
@@ -539,7 +564,7 @@ __global__ void k_smooth_f(const float* __restrict__ raw, Geom g, const float* _
 
 __global__ void k_smooth_t(const float* __restrict__ tmp, Geom g, const float* __restrict__ kt, int nt,
                            const float* __restrict__ kf, int nf, float p, int prop_before,
-                           float* __restrict__ M, int64_t n_units, const int* __restrict__ perm) {
+                           float* __restrict__ M, int64_t n_units) {
   const int64_t cells = n_units * g.T * g.FS;
   for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < cells;
        i += (int64_t)gridDim.x * blockDim.x) {
@@ -561,8 +586,7 @@ __global__ void k_smooth_t(const float* __restrict__ tmp, Geom g, const float* _
         if (f + a >= 0 && f + a < g.F) ef += kf[a + nf];
       edge = ef * et;
     }
-    // perm != nullptr: store in the lane order of the fused apply kernel (fast::perm_pos)
-    M[perm ? i - f + perm[f] : i] = p * acc + (1.0f - p) * edge;
+    M[i] = p * acc + (1.0f - p) * edge;
   }
 }
 
@@ -661,13 +685,13 @@ __global__ __launch_bounds__(256) void k_smooth_tiled(const float* __restrict__ 
 
 // no smoothing: M = p*raw + (1-p)
 __global__ void k_prop_only(const float* __restrict__ raw, Geom g, float p, float* __restrict__ M,
-                            int64_t n_units, const int* __restrict__ perm) {
+                            int64_t n_units) {
   const int64_t cells = n_units * g.T * g.FS;
   for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < cells;
        i += (int64_t)gridDim.x * blockDim.x) {
     const int f = (int)(i % g.FS);
     if (f >= g.F) continue;
-    M[perm ? i - f + perm[f] : i] = p * raw[i] + (1.0f - p);
+    M[i] = p * raw[i] + (1.0f - p);
   }
 }
 
@@ -682,9 +706,5 @@ __global__ void k_channel_mean(const void* __restrict__ x, int dtype, int64_t C,
   }
 }
 
-__global__ void k_copy_thresh(const double* __restrict__ src, double* __restrict__ dst, int F) {
-  int f = blockIdx.x * blockDim.x + threadIdx.x;
-  if (f < F) dst[f] = src[f];
-}
 
 }  // namespace sg
