@@ -195,6 +195,9 @@ int sg_set_option(sg_handle* h, int32_t option, int64_t value);
  * stream.  sg_profile_read synchronises those events and returns accumulated milliseconds
  * and launch counts per stage (arrays of SG_N_STAGES); reset != 0 clears the accumulators. */
 int sg_profile_enable(sg_handle* h, int32_t on);
+/* Restrict the event pairs to the stages whose bit (1 << SG_STAGE_*) is set; 0 = all stages.  Timing
+ * one kernel costs two event records per step instead of ~30. */
+int sg_profile_select(sg_handle* h, int64_t stage_mask);
 int sg_profile_read(sg_handle* h, double* ms, int64_t* counts, int32_t n_stages, int32_t reset);
 const char* sg_stage_name(int32_t stage);
 

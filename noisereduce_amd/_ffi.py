@@ -68,6 +68,7 @@ _PROTOTYPES = {
     "sg_stft": (c_int, [c_void_p, c_void_p, c_int, c_int64, c_int64, c_int64, c_void_p, c_void_p]),
     "sg_set_option": (c_int, [c_void_p, c_int32, c_int64]),
     "sg_profile_enable": (c_int, [c_void_p, c_int32]),
+    "sg_profile_select": (c_int, [c_void_p, c_int64]),
     "sg_profile_read": (c_int, [c_void_p, POINTER(c_double), POINTER(c_int64), c_int32, c_int32]),
     "sg_stage_name": (c_char_p, [c_int32]),
     "sg_debug_dims": (c_int, [c_void_p, POINTER(c_int64)]),
@@ -323,6 +324,15 @@ class Gate:
     # -- per-kernel timing -----------------------------------------------------------
     def profile_enable(self, on=True):
         self._check(self.lib.sg_profile_enable(self._h, int(bool(on))))
+
+    def profile_select(self, stage_names=None):
+        """Time only the named stages (names as returned by profile_read); None = all."""
+        mask = 0
+        if stage_names:
+            names = [self.lib.sg_stage_name(i).decode() for i in range(SG_N_STAGES)]
+            for n in stage_names:
+                mask |= 1 << names.index(n)
+        self._check(self.lib.sg_profile_select(self._h, mask))
 
     def profile_read(self, reset=True):
         """{stage name: (total ms, launches)} accumulated since the last reset (synchronises)."""

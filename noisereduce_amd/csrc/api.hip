@@ -71,6 +71,7 @@ struct sg_handle {
   bool force_unfused = false;  // sg_set_option(SG_OPT_FORCE_UNFUSED): materialised v1 path
   // per-kernel timing with HIP events on the launch stream (sg_profile_*)
   bool prof_on = false;
+  uint64_t prof_mask = ~0ull;  // stages that get an event pair (sg_profile_select)
   int prof_override = -1;  // >= 0: book every launch under this stage (noise statistics)
   struct ProfRec { int stage; hipEvent_t a, b; };
   std::vector<ProfRec> prof_live;
@@ -98,6 +99,8 @@ struct ProfScope {
   }
   ProfScope(sg_handle* h_, int stage, hipStream_t st_) : h(h_), st(st_) {
     if (!h->prof_on) return;
+    const int booked = h->prof_override >= 0 ? h->prof_override : stage;
+    if (!((h->prof_mask >> booked) & 1ull)) return;
     sg_handle::ProfRec r{h->prof_override >= 0 ? h->prof_override : stage, get(h), get(h)};
     (void)hipEventRecord(r.a, st);
     h->prof_live.push_back(r);
@@ -1204,6 +1207,12 @@ extern "C" int sg_set_option(sg_handle* h, int32_t option, int64_t value) {
 extern "C" int sg_profile_enable(sg_handle* h, int32_t on) {
   if (!h) return SG_E_INVALID;
   h->prof_on = on != 0;
+  return SG_OK;
+}
+
+extern "C" int sg_profile_select(sg_handle* h, int64_t stage_mask) {
+  if (!h) return SG_E_INVALID;
+  h->prof_mask = stage_mask == 0 ? ~0ull : (uint64_t)stage_mask;
   return SG_OK;
 }
 

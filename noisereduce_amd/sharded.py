@@ -87,35 +87,43 @@ class HipStationaryBackend:
                        use_tqdm=False, n_jobs=1)
         self.kw.update(kw)
         self.chunk_size, self.padding = self.kw["chunk_size"], self.kw["padding"]
-        self.sg = None
+        self._g = None
 
-    def _gate(self, y_local, with_stats):
-        from noisereduce_amd import _ffi
-        from noisereduce_amd.spectralgate.stationary import SpectralGateStationary
-        if with_stats:
-            # statistics from the clip this rank holds (stationary.py:47-81)
-            self.sg = SpectralGateStationary(y=y_local, sr=self.sr, device=self.device, **self.kw)
-            return self.sg._gate
-        k = self.kw
-        W = k["n_fft"] if k["win_length"] is None else k["win_length"]
-        H = W // 4 if k["hop_length"] is None else k["hop_length"]
-        from noisereduce_amd.spectralgate.base import SpectralGate
-        probe = SpectralGate.__new__(SpectralGate)  # only to reuse the filter-design arithmetic
-        probe.sr, probe._n_fft, probe._hop_length = self.sr, k["n_fft"], H
-        probe._n_grad_freq = probe._n_grad_time = 1
-        probe.smooth_mask = False
-        if not (k["freq_mask_smooth_hz"] is None and k["time_mask_smooth_ms"] is None):
-            probe._generate_mask_smoothing_filter(k["freq_mask_smooth_hz"], k["time_mask_smooth_ms"])
-        return _ffi.cached_gate(self.device, variant=_ffi.SG_VARIANT_S, stationary=True,
-                                n_fft=k["n_fft"], win_length=W, hop_length=H,
-                                n_grad_freq=probe._n_grad_freq, n_grad_time=probe._n_grad_time,
-                                smooth_mask=probe.smooth_mask, chunk_size=k["chunk_size"],
-                                padding=k["padding"], prop_decrease=k["prop_decrease"],
-                                n_std_thresh=k["n_std_thresh_stationary"], top_db=80.0, ddof=0)
+    def _gate(self, y_local=None, with_stats=False):
+        """The engine handle for these settings (built once per backend, cached per device by _ffi)."""
+        if self._g is None:
+            from noisereduce_amd import _ffi
+            from noisereduce_amd.spectralgate.base import SpectralGate
+            k = self.kw
+            W = k["n_fft"] if k["win_length"] is None else k["win_length"]
+            H = W // 4 if k["hop_length"] is None else k["hop_length"]
+            probe = SpectralGate.__new__(SpectralGate)  # only to reuse the filter-design arithmetic
+            probe.sr, probe._n_fft, probe._hop_length = self.sr, k["n_fft"], H
+            probe._n_grad_freq = probe._n_grad_time = 1
+            probe.smooth_mask = False
+            if not (k["freq_mask_smooth_hz"] is None and k["time_mask_smooth_ms"] is None):
+                probe._generate_mask_smoothing_filter(k["freq_mask_smooth_hz"], k["time_mask_smooth_ms"])
+            self._g = _ffi.cached_gate(self.device, variant=_ffi.SG_VARIANT_S, stationary=True,
+                                       n_fft=k["n_fft"], win_length=W, hop_length=H,
+                                       n_grad_freq=probe._n_grad_freq, n_grad_time=probe._n_grad_time,
+                                       smooth_mask=probe.smooth_mask, chunk_size=k["chunk_size"],
+                                       padding=k["padding"], prop_decrease=k["prop_decrease"],
+                                       n_std_thresh=k["n_std_thresh_stationary"], top_db=80.0, ddof=0)
+        return self._g
 
     def stats(self, y_local):
-        """Noise statistics from this rank's data, left on the device (owning rank only)."""
-        return self._gate(y_local, True)
+        """Noise statistics from this rank's data, left on the device (owning rank only):
+        y_noise=None means the recording itself, clipped to chunk_size (stationary.py:47-64)."""
+        g = self._gate()
+        noise = y_local
+        if self.kw["y_noise"] is not None:
+            noise = self.kw["y_noise"]
+            if noise.dim() == 1:
+                noise = noise[None, :]
+        if self.kw["clip_noise_stationary"] and self.chunk_size is not None:
+            noise = noise[:, :self.chunk_size]
+        g.noise_stats(noise)
+        return g
 
     def threshold(self, y_local):
         """Per-band threshold (dB) as a device tensor, for the broadcast (no host sync)."""
@@ -123,7 +131,7 @@ class HipStationaryBackend:
 
     def filter(self, y_local, ext, halo, thresh, owner):
         """Filter the shard.  `ext` is the halo-extended buffer (or y_local when halo == 0)."""
-        g = self._gate(y_local, False)
+        g = self._gate()
         if not owner:
             g.set_noise_threshold_tensor(thresh)
         S = y_local.shape[1]
