@@ -40,7 +40,7 @@ class SpectralGate:
         self.flat = False
         self._tensor_io = isinstance(y, torch.Tensor)
         if not self._tensor_io:
-            y = np.array(y)
+            y = np.asarray(y)  # read-only here: no need for the reference's defensive copy (base.py:54)
         # reshape data to (#channels, #frames)  (base.py:54-62)
         if len(y.shape) == 1:
             self.y = y[None, :]
@@ -131,8 +131,13 @@ class SpectralGate:
         if self._tensor_io:
             out = out_dev if out_dev.dtype == self._dtype else out_dev.to(self._dtype)
             return out.flatten() if self.flat else out
-        out = out_dev.cpu().numpy().astype(self._dtype, copy=False)
-        return out.flatten() if self.flat else out
+        if out_dev.dtype in _ffi._TORCH_DTYPES and _DEVICE_DTYPES.get(np.dtype(self._dtype)) == out_dev.dtype:
+            # straight DMA into the array we return (one allocation, no staging copy)
+            out = np.empty(tuple(out_dev.shape), dtype=self._dtype)
+            torch.from_numpy(out).copy_(out_dev)
+        else:
+            out = out_dev.cpu().numpy().astype(self._dtype, copy=False)
+        return out.reshape(-1) if self.flat else out
 
     # -- the reference's host-side chunk helpers (kept for API compatibility) -----------------
     def _host_y(self):

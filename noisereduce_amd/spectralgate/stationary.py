@@ -26,7 +26,7 @@ class SpectralGateStationary(SpectralGate):
             noise_dev = self._device_y()
         else:
             if not isinstance(y_noise, torch.Tensor):
-                y_noise = np.array(y_noise)
+                y_noise = np.asarray(y_noise)
             if len(y_noise.shape) == 1:
                 y_noise = y_noise[None, :]
             elif len(y_noise.shape) > 2:

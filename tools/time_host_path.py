@@ -1,0 +1,24 @@
+import os, sys, time, numpy as np, torch
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import noisereduce_amd as nr
+from oracle import spectralgate_oracle as O
+n = 28_800_000
+y = O.synth_signal(n)
+for _ in range(3): out = nr.reduce_noise(y=y, sr=48000, stationary=True)
+def T(f, reps=5):
+    ts = []
+    for _ in range(reps):
+        t0 = time.perf_counter(); r = f(); torch.cuda.synchronize(); ts.append((time.perf_counter() - t0) * 1e3)
+    return round(float(np.median(ts)), 2)
+print("reduce_noise numpy->numpy", T(lambda: nr.reduce_noise(y=y, sr=48000, stationary=True)))
+print("np.array(y)", T(lambda: np.array(y)))
+print("np.asarray(y)", T(lambda: np.asarray(y)))
+d = torch.from_numpy(y).cuda()
+print("H2D", T(lambda: torch.from_numpy(y).to("cuda")))
+print("compute (tensor in/out)", T(lambda: nr.reduce_noise(y=d, sr=48000, stationary=True)))
+o = nr.reduce_noise(y=d, sr=48000, stationary=True)
+print("D2H .cpu()", T(lambda: o.cpu()))
+buf = np.empty_like(y)
+print("D2H into existing numpy", T(lambda: torch.from_numpy(buf).copy_(o)))
+print("np.empty_like + D2H", T(lambda: torch.from_numpy(np.empty_like(y)).copy_(o)))
+print(".cpu().numpy().astype", T(lambda: o.cpu().numpy().astype(np.float32, copy=False)))
