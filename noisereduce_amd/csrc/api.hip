@@ -568,7 +568,7 @@ static int stage_nonstat_raw(sg_handle* h, const View& v, const Geom& g, int64_t
     M.tw512 = (const fast::cf*)h->tw512.p;
     M.tw1024 = (const fast::cf*)h->tw32.p;
     M.mag = mag;
-    size_t lds = (size_t)(fast::FN + WAVES * fast::WAVE_CX) * sizeof(fast::cf);
+    size_t lds = (size_t)(fast::FN + WAVES * fast::WAVE_CX_H) * sizeof(fast::cf);
     auto kern = fast::k_mag_fast<WAVES>;
     HIPCHK(h, hipFuncSetAttribute(reinterpret_cast<const void*>(kern),
                                   hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
@@ -767,7 +767,7 @@ static int stage_fused_mask(sg_handle* h, const View& v, const Geom& g, int64_t 
     D.quads_per_wave = 1;
     const int64_t quads = (D.t_end - D.t_begin + 3) / 4;
     const int64_t per_block = (int64_t)WAVES * D.quads_per_wave;
-    size_t lds = (size_t)(fast::FN + WAVES * fast::WAVE_CX) * sizeof(fast::cf) + 528 * sizeof(float);
+    size_t lds = (size_t)(fast::FN + WAVES * fast::WAVE_CX_H) * sizeof(fast::cf) + 528 * sizeof(float);
     auto kern = fast::k_decide_fast<WAVES>;
     HIPCHK(h, hipFuncSetAttribute(reinterpret_cast<const void*>(kern),
                                   hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));

@@ -181,6 +181,37 @@ __device__ __forceinline__ void fft512_inv(cf* v, cf* fb, const cf* tw512, int c
   __builtin_amdgcn_sched_barrier(0);
 }
 
+// Forward transform with a HALF-size exchange slice (16 rows x 16 columns per frame): rows 0..15 go
+// through LDS first (every lane's row1 lies there), then rows 16..31 reuse the same slice (row2).
+// Two more wave-level syncs, half the LDS per wave -> a third wave per SIMD for the kernels that do
+// not need the slice afterwards (decision and magnitude kernels).
+constexpr int FPITCH_H = 256 + 16;
+constexpr int WAVE_CX_H = 4 * FPITCH_H;
+__device__ __forceinline__ int frame_base_h(int g) { return g * FPITCH_H; }
+
+__device__ __forceinline__ void fft512_fwd_half(cf* v, cf* fb, const cf* tw512, int c) {
+  __builtin_amdgcn_sched_barrier(0);
+  dft_reg<32, false>(v);
+  __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+  for (int k1 = 1; k1 < 32; ++k1) v[k1] = cmul(v[k1], tw512[k1 * 16 + c]);
+  // phase A: rows 0..15
+#pragma unroll
+  for (int k1 = 0; k1 < 16; ++k1) fb[k1 * 16 + (c ^ (2 * ((k1 >> 1) & 7)))] = v[k1];
+  wave_lds_sync();
+  xchg_read_row(fb, row1(c), v);
+  wave_lds_sync();
+  // phase B: rows 16..31 stored at row - 16 (same swizzle: ((row - 16) >> 1) & 7 == (row >> 1) & 7)
+#pragma unroll
+  for (int k1 = 16; k1 < 32; ++k1) fb[(k1 - 16) * 16 + (c ^ (2 * ((k1 >> 1) & 7)))] = v[k1];
+  wave_lds_sync();
+  xchg_read_row(fb, row2(c) - 16, v + 16);
+  wave_lds_sync();
+  dft_reg<16, false>(v);
+  dft_reg<16, false>(v + 16);
+  __builtin_amdgcn_sched_barrier(0);
+}
+
 // One conjugate pair of the real-FFT split -> mask -> merge (see k_apply_istft in kernels.hpp):
 // a = Zc[k], b = Zc[N-k], w = w_1024^k, mk / mn = mask of bin k / N-k.  Returns Zc'[k], Zc'[N-k].
 // The four 1/2 factors of split and merge are NOT applied here: the caller folds 1/4 into the masks.
@@ -584,7 +615,7 @@ __device__ __forceinline__ double exact_power(const DecideArgs& A, int64_t row, 
 }
 
 template <int WAVES>
-__global__ __launch_bounds__(WAVES * 64, 2) void k_decide_fast(DecideArgs A) {
+__global__ __launch_bounds__(WAVES * 64, 3) void k_decide_fast(DecideArgs A) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
   cf* tw512 = reinterpret_cast<cf*>(smem);
   cf* regions = tw512 + FN;
@@ -600,7 +631,7 @@ __global__ __launch_bounds__(WAVES * 64, 2) void k_decide_fast(DecideArgs A) {
 
   // effective compare constants (4x the raw-power constant: the split below works on 2X) as
   // float32 in LDS, permuted like the mask rows: entry c*32 + e = bin_of_entry(c, e), entry 512 = bin 512
-  float* s_t2 = reinterpret_cast<float*>(regions + WAVES * WAVE_CX);
+  float* s_t2 = reinterpret_cast<float*>(regions + WAVES * WAVE_CX_H);
   auto t2eff = [&](int f) -> double {
     double v = A.tc.T2[f];
     if (floor_live) {
@@ -613,7 +644,7 @@ __global__ __launch_bounds__(WAVES * 64, 2) void k_decide_fast(DecideArgs A) {
     double v = t2eff(perm_inv(i));
     s_t2[i] = v < 0.0 ? -1.0f : (float)(4.0 * v);
   }
-  cf* fb = regions + wave * WAVE_CX + frame_base(g);
+  cf* fb = regions + wave * WAVE_CX_H + frame_base_h(g);
   const cf wl0 = A.tw1024[c];  // w_1024^c (lane 0: 1)
   __syncthreads();
 
@@ -644,25 +675,28 @@ __global__ __launch_bounds__(WAVES * 64, 2) void k_decide_fast(DecideArgs A) {
           v[r] = {x2.x * w2.x, x2.y * w2.y};
         }
       } else {
-        float* fl = reinterpret_cast<float*>(fb);
-#pragma unroll 1
-        for (int r = 0; r < 32; ++r) {
-          float a = 0.f, b = 0.f;
-          if (fvalid) {
-            a = (float)view_sample(A.view, row, chunk, s0 + 2 * c + 32 * r);
-            b = (float)view_sample(A.view, row, chunk, s0 + 2 * c + 32 * r + 1);
-          }
-          fl[2 * c + 32 * r] = a;
-          fl[2 * c + 32 * r + 1] = b;
-        }
-        wave_lds_sync();
+        float* fl = reinterpret_cast<float*>(fb);  // half-size slice: stage the frame as two halves of 512 floats
 #pragma unroll
-        for (int r = 0; r < 32; ++r) {
-          float2 w2 = wsrc[16 * r];
-          cf x2 = fb[c + 16 * r];
-          v[r] = {x2.x * w2.x, x2.y * w2.y};
+        for (int hh = 0; hh < 2; ++hh) {
+#pragma unroll 1
+          for (int r = 0; r < 16; ++r) {
+            float a = 0.f, b = 0.f;
+            if (fvalid) {
+              a = (float)view_sample(A.view, row, chunk, s0 + 2 * c + 32 * (r + 16 * hh));
+              b = (float)view_sample(A.view, row, chunk, s0 + 2 * c + 32 * (r + 16 * hh) + 1);
+            }
+            fl[2 * c + 32 * r] = a;
+            fl[2 * c + 32 * r + 1] = b;
+          }
+          wave_lds_sync();
+#pragma unroll
+          for (int r = 0; r < 16; ++r) {
+            float2 w2 = wsrc[16 * (r + 16 * hh)];
+            cf x2 = fb[c + 16 * r];
+            v[r + 16 * hh] = {x2.x * w2.x, x2.y * w2.y};
+          }
+          wave_lds_sync();
         }
-        wave_lds_sync();
       }
 #pragma unroll
       for (int r = 0; r < 32; ++r) nrm2 += v[r].x * v[r].x + v[r].y * v[r].y;
@@ -676,7 +710,7 @@ __global__ __launch_bounds__(WAVES * 64, 2) void k_decide_fast(DecideArgs A) {
       // keep the loop-invariant twiddle reads inside the loop: hoisted, they would pin ~100 VGPRs
       const cf* twl = tw512;
       asm volatile("" : "+v"(twl));
-      fft512_fwd(v, fb, twl, c);
+      fft512_fwd_half(v, fb, twl, c);
     }
     cf wl = wl0;
     asm volatile("" : "+v"(wl.x), "+v"(wl.y));
@@ -826,7 +860,7 @@ struct MagArgs {
 };
 
 template <int WAVES>
-__global__ __launch_bounds__(WAVES * 64, 2) void k_mag_fast(MagArgs A) {
+__global__ __launch_bounds__(WAVES * 64, 3) void k_mag_fast(MagArgs A) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
   cf* tw512 = reinterpret_cast<cf*>(smem);
   cf* regions = tw512 + FN;
@@ -838,7 +872,7 @@ __global__ __launch_bounds__(WAVES * 64, 2) void k_mag_fast(MagArgs A) {
   const int64_t u = blockIdx.y;
   const int64_t row = (A.view.unit0 + u) / A.view.n_chunks;
   const int64_t chunk = (A.view.unit0 + u) % A.view.n_chunks;
-  cf* fb = regions + wave * WAVE_CX + frame_base(g);
+  cf* fb = regions + wave * WAVE_CX_H + frame_base_h(g);
   __syncthreads();
   const int64_t tq = ((int64_t)blockIdx.x * WAVES + wave) * 4;
   if (tq >= G.T) return;
@@ -862,28 +896,31 @@ __global__ __launch_bounds__(WAVES * 64, 2) void k_mag_fast(MagArgs A) {
         v[r] = {x2.x * w2.x, x2.y * w2.y};
       }
     } else {
-      float* fl = reinterpret_cast<float*>(fb);
-#pragma unroll 1
-      for (int r = 0; r < 32; ++r) {
-        float a = 0.f, b = 0.f;
-        if (fvalid) {
-          a = (float)view_sample(A.view, row, chunk, s0 + 2 * c + 32 * r);
-          b = (float)view_sample(A.view, row, chunk, s0 + 2 * c + 32 * r + 1);
-        }
-        fl[2 * c + 32 * r] = a;
-        fl[2 * c + 32 * r + 1] = b;
-      }
-      wave_lds_sync();
+      float* fl = reinterpret_cast<float*>(fb);  // half-size slice: stage the frame as two halves of 512 floats
 #pragma unroll
-      for (int r = 0; r < 32; ++r) {
-        float2 w2 = wsrc[16 * r];
-        cf x2 = fb[c + 16 * r];
-        v[r] = {x2.x * w2.x, x2.y * w2.y};
+      for (int hh = 0; hh < 2; ++hh) {
+#pragma unroll 1
+        for (int r = 0; r < 16; ++r) {
+          float a = 0.f, b = 0.f;
+          if (fvalid) {
+            a = (float)view_sample(A.view, row, chunk, s0 + 2 * c + 32 * (r + 16 * hh));
+            b = (float)view_sample(A.view, row, chunk, s0 + 2 * c + 32 * (r + 16 * hh) + 1);
+          }
+          fl[2 * c + 32 * r] = a;
+          fl[2 * c + 32 * r + 1] = b;
+        }
+        wave_lds_sync();
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+          float2 w2 = wsrc[16 * (r + 16 * hh)];
+          cf x2 = fb[c + 16 * r];
+          v[r + 16 * hh] = {x2.x * w2.x, x2.y * w2.y};
+        }
+        wave_lds_sync();
       }
-      wave_lds_sync();
     }
   }
-  fft512_fwd(v, fb, tw512, c);
+  fft512_fwd_half(v, fb, tw512, c);
   const bool l0 = c == 0;
   const cf wlo = A.tw1024[c];
   cf whi = wlo;
