@@ -182,7 +182,8 @@ static Geom make_geom(const sg_handle* h, int64_t Lp) {
 // ------------------------------------------------------------------------------------------
 template <typename TC, int N>
 static hipError_t launch_stft_n(const View& v, const Geom& g, int64_t units, const void* tw, const void* wfull,
-                                double* P, float* mag, double* z, double zscale, hipStream_t st) {
+                                double* P, float* mag, double* z, double zscale, hipStream_t st,
+                                unsigned long long* pmax_bits) {
   constexpr int WAVES = (N * sizeof(cx<TC>) > 16384) ? 2 : 4;
   size_t lds = (size_t)(N + WAVES * N) * sizeof(cx<TC>);
   // few units (the noise clip): one frame per wave so that the grid still covers the chip
@@ -195,7 +196,7 @@ static hipError_t launch_stft_n(const View& v, const Geom& g, int64_t units, con
     }
     dim3 grid((unsigned)((g.T + WAVES * fpw - 1) / (WAVES * fpw)), (unsigned)units);
     hipLaunchKernelGGL(kern, grid, dim3(WAVES * 64), lds, st, v, g, (const cx<TC>*)tw, (const TC*)wfull, P, mag,
-                       z, zscale);
+                       z, zscale, pmax_bits);
     return hipGetLastError();
   };
   if (small) return launch(k_stft<TC, N, WAVES, 1>, 1);
@@ -205,15 +206,15 @@ static hipError_t launch_stft_n(const View& v, const Geom& g, int64_t units, con
 template <typename TC>
 static hipError_t launch_stft(int N, const View& v, const Geom& g, int64_t units, const void* tw,
                               const void* wfull, double* P, float* mag, double* z, double zscale,
-                              hipStream_t st) {
+                              hipStream_t st, unsigned long long* pmax_bits = nullptr) {
   switch (N) {
-    case 32: return launch_stft_n<TC, 32>(v, g, units, tw, wfull, P, mag, z, zscale, st);
-    case 64: return launch_stft_n<TC, 64>(v, g, units, tw, wfull, P, mag, z, zscale, st);
-    case 128: return launch_stft_n<TC, 128>(v, g, units, tw, wfull, P, mag, z, zscale, st);
-    case 256: return launch_stft_n<TC, 256>(v, g, units, tw, wfull, P, mag, z, zscale, st);
-    case 512: return launch_stft_n<TC, 512>(v, g, units, tw, wfull, P, mag, z, zscale, st);
-    case 1024: return launch_stft_n<TC, 1024>(v, g, units, tw, wfull, P, mag, z, zscale, st);
-    case 2048: return launch_stft_n<TC, 2048>(v, g, units, tw, wfull, P, mag, z, zscale, st);
+    case 32: return launch_stft_n<TC, 32>(v, g, units, tw, wfull, P, mag, z, zscale, st, pmax_bits);
+    case 64: return launch_stft_n<TC, 64>(v, g, units, tw, wfull, P, mag, z, zscale, st, pmax_bits);
+    case 128: return launch_stft_n<TC, 128>(v, g, units, tw, wfull, P, mag, z, zscale, st, pmax_bits);
+    case 256: return launch_stft_n<TC, 256>(v, g, units, tw, wfull, P, mag, z, zscale, st, pmax_bits);
+    case 512: return launch_stft_n<TC, 512>(v, g, units, tw, wfull, P, mag, z, zscale, st, pmax_bits);
+    case 1024: return launch_stft_n<TC, 1024>(v, g, units, tw, wfull, P, mag, z, zscale, st, pmax_bits);
+    case 2048: return launch_stft_n<TC, 2048>(v, g, units, tw, wfull, P, mag, z, zscale, st, pmax_bits);
   }
   return hipErrorInvalidValue;
 }
@@ -513,6 +514,17 @@ static int stat_slices(const Geom& g, int64_t ub) {
 
 // power field + column max of a batch of units
 static int stage_power(sg_handle* h, const View& v, const Geom& g, int64_t ub, hipStream_t st) {
+  if (ub >= 16) {
+    // power field; the per-(unit, band) maximum is folded into the STFT kernel (atomic max: one
+    // address per (unit, band), little contention when there are many units)
+    HIPCHK(h, hipMemsetAsync(h->pmax.p, 0, (size_t)ub * g.FS * 8, st));
+    ProfScope ps(h, SG_STAGE_STFT_POWER, st);
+    HIPCHK(h, launch_stft<double>(h->N, v, g, ub, h->tw64.p, h->wfull64.p, (double*)h->P.p, nullptr, nullptr,
+                                  1.0, st, (unsigned long long*)h->pmax.p));
+    return SG_OK;
+  }
+  // few units (the noise clip): thousands of frames would hammer the same 513 addresses; reduce
+  // the maximum with the two-stage column kernels instead
   {
     ProfScope ps(h, SG_STAGE_STFT_POWER, st);
     HIPCHK(h, launch_stft<double>(h->N, v, g, ub, h->tw64.p, h->wfull64.p, (double*)h->P.p, nullptr, nullptr,

@@ -74,7 +74,8 @@ template <typename TC, int N, int WAVES, int FPW>
 __global__ __launch_bounds__(WAVES * 64) void k_stft(View view, Geom g, const cx<TC>* __restrict__ tw_g,
                                                      const TC* __restrict__ wfull,
                                                      double* __restrict__ P_out, float* __restrict__ mag_out,
-                                                     double* __restrict__ z_out, double z_scale) {
+                                                     double* __restrict__ z_out, double z_scale,
+                                                     unsigned long long* __restrict__ pmax_bits) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
   cx<TC>* tw = reinterpret_cast<cx<TC>*>(smem);
   cx<TC>* bufs = tw + N;
@@ -86,6 +87,9 @@ __global__ __launch_bounds__(WAVES * 64) void k_stft(View view, Geom g, const cx
   const int64_t row = (view.unit0 + u) / view.n_chunks;
   const int64_t chunk = (view.unit0 + u) % view.n_chunks;
   __syncthreads();
+  double vmax[N / 64 + 1];  // running max power of this lane's bins (pmax_bits != nullptr)
+#pragma unroll
+  for (int m = 0; m <= N / 64; ++m) vmax[m] = 0.0;
   for (int fi = 0; fi < FPW; ++fi) {
     const int64_t t = ((int64_t)blockIdx.x * FPW + fi) * WAVES + wave;
     const bool valid = t < g.T;
@@ -103,12 +107,17 @@ __global__ __launch_bounds__(WAVES * 64) void k_stft(View view, Geom g, const cx
     wave_fft<TC, N, false>(buf, tw, lane);
     if (valid) {
       const int64_t rowoff = (u * g.T + t) * g.FS;
-      for (int k = lane; k <= N; k += 64) {
+#pragma unroll
+      for (int m = 0; m <= N / 64; ++m) {
+        const int k = lane + 64 * m;
+        if (k > N) continue;
         cx<TC> a = buf[k == N ? 0 : k];
         cx<TC> b = buf[(k == 0 || k == N) ? 0 : N - k];
         cx<TC> w = tw[k == N ? 0 : k];
         cx<TC> X = rfft_bin(a, b, w, k, N);
-        if (P_out) P_out[rowoff + k] = (double)X.x * (double)X.x + (double)X.y * (double)X.y;
+        const double Pk = (double)X.x * (double)X.x + (double)X.y * (double)X.y;
+        vmax[m] = fmax(vmax[m], Pk);
+        if (P_out) P_out[rowoff + k] = Pk;
         if (mag_out) mag_out[rowoff + k] = sqrtf((float)(X.x * X.x + X.y * X.y));
         if (z_out) {
           int64_t zo = ((u * g.T + t) * g.F + k) * 2;
@@ -118,6 +127,14 @@ __global__ __launch_bounds__(WAVES * 64) void k_stft(View view, Geom g, const cx
       }
     }
     SG_PASS_SYNC();
+  }
+  // per-(unit, band) max power, order-independent (non-negative doubles order like their bits)
+  if (pmax_bits) {
+#pragma unroll
+    for (int m = 0; m <= N / 64; ++m) {
+      const int k = lane + 64 * m;
+      if (k <= N) atomicMax(&pmax_bits[u * g.FS + k], (unsigned long long)__double_as_longlong(vmax[m]));
+    }
   }
 }
 
