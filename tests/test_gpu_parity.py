@@ -400,3 +400,32 @@ def test_seam_tiles_equal_overlapping_tiles(nr):
     assert O.rel_err(a, b) < 1e-6
     want = O.reduce_noise_S(y.astype(np.float64), 48000, stationary=True, chunk_size=40000, padding=5000)
     assert O.rel_err(a, want) < TOL and O.rel_err(b, want) < TOL
+
+
+def test_full_size_config2_properties(nr):
+    """BASELINE.json configs[1] at FULL size (28.8 M samples, 48 chunks): run-to-run determinism,
+    sub-range consistency of get_traces, and the oracle on three whole chunks (first, middle, last)."""
+    import bench
+    from noisereduce_amd.spectralgate.stationary import SpectralGateStationary
+    y = bench.synth_on_device(bench.N_PER_GPU, 1234, torch.device("cuda", 0))
+    out1 = nr.reduce_noise(y=y, sr=48000, stationary=True)
+    out2 = nr.reduce_noise(y=y, sr=48000, stationary=True)
+    assert torch.equal(out1, out2), "not deterministic run to run"
+    assert bool(torch.isfinite(out1).all())
+    kw = dict(sr=48000, y_noise=None, prop_decrease=1.0, n_std_thresh_stationary=1.5, chunk_size=600000,
+              clip_noise_stationary=True, padding=30000, n_fft=1024, win_length=None, hop_length=None,
+              time_constant_s=2.0, freq_mask_smooth_hz=500, time_mask_smooth_ms=50, tmp_folder=None,
+              use_tqdm=False, n_jobs=1)
+    sg = SpectralGateStationary(y=y, **kw)
+    sub = sg.get_traces(start_frame=7_000_123, end_frame=9_500_001)     # spans 5 chunks, ragged ends
+    assert torch.equal(sub, out1[7_000_123:9_500_001])
+    # oracle on whole chunks, threshold from the same clip
+    yh = y.cpu().numpy().astype(np.float64)
+    thr, _, _ = O.noise_threshold_S(yh[None, :600000], 1024, 1024, 256, 1.5, 600000)
+    assert np.max(np.abs(sg.noise_thresh - thr)) < 1e-9
+    filt = O.smoothing_filter(5, 9)
+    o1 = out1.cpu().numpy()
+    for ich in (0, 23, 47):
+        chunk = O.read_chunk(yh[None, :], ich * 600000 - 30000, (ich + 1) * 600000 + 30000)
+        ref = O.gate_stationary_S(chunk, thr, 1024, 1024, 256, 1.0, filt)[0, 30000:630000]
+        assert O.rel_err(o1[ich * 600000:(ich + 1) * 600000], ref) < TOL
