@@ -354,6 +354,13 @@ extern "C" int sg_create(const sg_params* p, const double* window_host, sg_handl
     // fused (bit-mask) path: variant-S stationary gate whose integer smoothing sums fit uint16
     h->fused_ok = p->variant == SG_VARIANT_S && p->stationary && h->ktot <= 65535 &&
                   (!p->smooth_mask || p->n_grad_time <= 96);
+    if (h->fused_ok && p->smooth_mask) {
+      // the integer smoothing kernel holds (64 + 2 nt) rows of all F bins in LDS
+      const int rows = SM2_TT + 2 * p->n_grad_time, wpr = (h->F + 63) / 64;
+      const bool small = (p->n_grad_freq + 1) * (p->n_grad_freq + 1) <= 255;
+      const size_t lds = smooth2_cf_bytes(rows, h->F, small ? 1 : 2) + (size_t)rows * (wpr + 2) * 8 + 8192;
+      if (lds > 150 * 1024 || p->n_grad_freq > 30) h->fused_ok = false;
+    }
   }
   // window embedded in an n_fft frame: scipy zero-pads the windowed frame at the END
   // (scipy/_spectral_py.py:2202) and extends the signal by W//2; torch centres the window

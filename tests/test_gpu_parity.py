@@ -429,3 +429,28 @@ def test_full_size_config2_properties(nr):
         chunk = O.read_chunk(yh[None, :], ich * 600000 - 30000, (ich + 1) * 600000 + 30000)
         ref = O.gate_stationary_S(chunk, thr, 1024, 1024, 256, 1.0, filt)[0, 30000:630000]
         assert O.rel_err(o1[ich * 600000:(ich + 1) * 600000], ref) < TOL
+
+
+@pytest.mark.parametrize("n_fft", [64, 128, 256, 4096])
+@pytest.mark.parametrize("stationary", [True, False])
+def test_fft_size_range(nr, n_fft, stationary):
+    """Smallest and largest supported transforms (general per-wavefront Stockham kernels)."""
+    sr = 48000
+    y = O.synth_signal(60000, seed=n_fft).astype(np.float64)
+    kw = dict(stationary=stationary, n_fft=n_fft, chunk_size=25000, padding=5000)
+    if n_fft <= 128:
+        kw.update(freq_mask_smooth_hz=3000, time_mask_smooth_ms=10)   # at least one bin / one frame
+    got = nr.reduce_noise(y=y, sr=sr, **kw)
+    want = O.reduce_noise_S(y, sr, **kw)
+    assert O.rel_err(got, want) < TOL
+
+
+def test_chunk_size_none_and_zero_padding(nr):
+    """chunk_size=None takes the single-window branch (base.py:174,222); padding=0 is legal."""
+    y = O.synth_signal(70000, seed=5).astype(np.float64)
+    for kw in (dict(stationary=False, chunk_size=None, padding=1000),
+               dict(stationary=True, chunk_size=20000, padding=0),
+               dict(stationary=False, chunk_size=20000, padding=0)):
+        got = nr.reduce_noise(y=y, sr=48000, **kw)
+        want = O.reduce_noise_S(y, 48000, **kw)
+        assert O.rel_err(got, want) < TOL, kw
