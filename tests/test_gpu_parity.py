@@ -454,3 +454,17 @@ def test_chunk_size_none_and_zero_padding(nr):
         got = nr.reduce_noise(y=y, sr=48000, **kw)
         want = O.reduce_noise_S(y, 48000, **kw)
         assert O.rel_err(got, want) < TOL, kw
+
+
+@pytest.mark.parametrize("sr", [8000, 22050, 44100])
+def test_torchgate_sample_rates(sr):
+    """Other smoothing widths (sr=8000 -> 32 bins x 1 frame... wide frequency filter)."""
+    from noisereduce_amd.torchgate import TorchGate
+    rng = np.random.default_rng(sr)
+    x = (0.1 * rng.standard_normal((2, 12000)) + 0.4 * np.sin(2 * np.pi * 300 * np.arange(12000) / sr)[None, :])
+    x = x.astype(np.float32).astype(np.float64)
+    tg = TorchGate(sr=sr).cuda()
+    got = tg(torch.from_numpy(x).cuda()).cpu().numpy()
+    want = O.torchgate_T(x, sr, window=torch.hann_window(1024).double().numpy())
+    assert got.shape == want.shape
+    assert O.rel_err(got, want) < TOL
