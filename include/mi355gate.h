@@ -170,6 +170,7 @@ int sg_debug_fetch(sg_handle* h, int32_t what, void* host, int64_t bytes, void* 
 #define SG_OPT_FORCE_UNFUSED 1 /* value != 0: use the materialised (v1) kernels everywhere */
 #define SG_OPT_FORCE_F64_DECIDE 3 /* value != 0: decide every mask cell from a float64 STFT */
 #define SG_OPT_FORCE_NOSEAM 4   /* value != 0: overlapping apply tiles instead of abutting tiles + seam kernel */
+#define SG_OPT_FORCE_NOLEAN 5   /* value != 0: apply kernel with full-size LDS slices and stored frames */
 #define SG_OPT_FORCE_NOFAST 2  /* value != 0: keep the bit-mask stages but use the general apply kernels */
 int sg_set_option(sg_handle* h, int32_t option, int64_t value);
 

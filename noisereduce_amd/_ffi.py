@@ -22,6 +22,7 @@ SG_E_INVALID, SG_E_UNSUPPORTED, SG_E_HIP, SG_E_NOMEM, SG_E_STATE = -1, -2, -3, -
 SG_N_STAGES = 16
 SG_OPT_FORCE_F64_DECIDE = 3
 SG_OPT_FORCE_NOSEAM = 4
+SG_OPT_FORCE_NOLEAN = 5
 SG_OPT_FORCE_UNFUSED = 1
 SG_OPT_FORCE_NOFAST = 2
 

@@ -57,6 +57,7 @@ struct sg_handle {
   DevBuf seam;                       // partial seam hops of abutting apply tiles
   DevBuf ftab;                       // k_smooth_bits2 phase-1 lookup tables (nf <= 5)
   bool force_noseam = false;
+  bool force_nolean = false;         // SG_OPT_FORCE_NOLEAN: full-size slices + stored frames (2 waves/SIMD)
   bool fast_ok = false;              // default geometry: fused apply kernel available
   bool force_nofast = false;
   bool force_f64_decide = false;     // SG_OPT_FORCE_F64_DECIDE: float64 STFT for every mask decision
@@ -844,16 +845,21 @@ static int stage_apply_fast(sg_handle* h, const View& v, const Geom& g, int64_t 
     A.n_tiles = (int)tiles_seam;
   }
   dim3 grid((unsigned)(seam ? tiles_seam : (nh + NH - 1) / NH), (unsigned)ub);
+  const bool lean = !h->force_nolean;
+  auto go = [&](auto kern, size_t lds_bytes) -> hipError_t {
+    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern),
+                                       hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes);
+    if (e != hipSuccess) return e;
+    hipLaunchKernelGGL(kern, grid, dim3(WAVES * 64), lds_bytes, st, A);
+    return hipGetLastError();
+  };
+  const size_t lds_lean = (size_t)(fast::FN + WAVES * fast::WAVE_CX_H) * sizeof(fast::cf);
   if (mask_f) {
-    auto kern = fast::k_apply_fast<WAVES, false>;
-    HIPCHK(h, hipFuncSetAttribute(reinterpret_cast<const void*>(kern),
-                                  hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-    hipLaunchKernelGGL(kern, grid, dim3(WAVES * 64), lds, st, A);
+    if (lean) HIPCHK(h, go(fast::k_apply_fast<WAVES, false, true>, lds_lean));
+    else HIPCHK(h, go(fast::k_apply_fast<WAVES, false, false>, lds));
   } else {
-    auto kern = fast::k_apply_fast<WAVES, true>;
-    HIPCHK(h, hipFuncSetAttribute(reinterpret_cast<const void*>(kern),
-                                  hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-    hipLaunchKernelGGL(kern, grid, dim3(WAVES * 64), lds, st, A);
+    if (lean) HIPCHK(h, go(fast::k_apply_fast<WAVES, true, true>, lds_lean));
+    else HIPCHK(h, go(fast::k_apply_fast<WAVES, true, false>, lds));
   }
   HIPCHK(h, hipGetLastError());
   if (seam) {
@@ -1219,6 +1225,7 @@ extern "C" int sg_set_option(sg_handle* h, int32_t option, int64_t value) {
     case SG_OPT_FORCE_NOFAST: h->force_nofast = value != 0; return SG_OK;
     case SG_OPT_FORCE_F64_DECIDE: h->force_f64_decide = value != 0; return SG_OK;
     case SG_OPT_FORCE_NOSEAM: h->force_noseam = value != 0; return SG_OK;
+    case SG_OPT_FORCE_NOLEAN: h->force_nolean = value != 0; return SG_OK;
   }
   FAIL(h, SG_E_INVALID, "sg_set_option: unknown option %d", option);
 }

@@ -212,6 +212,32 @@ __device__ __forceinline__ void fft512_fwd_half(cf* v, cf* fb, const cf* tw512, 
   __builtin_amdgcn_sched_barrier(0);
 }
 
+// Inverse transform with the half-size slice: row1 rows (0..15) travel first, then row2 rows.
+__device__ __forceinline__ void fft512_inv_half(cf* v, cf* fb, const cf* tw512, int c) {
+  __builtin_amdgcn_sched_barrier(0);
+  dft_reg<16, true>(v);
+  dft_reg<16, true>(v + 16);
+  xchg_write_row(fb, row1(c), v);
+  wave_lds_sync();
+#pragma unroll
+  for (int k1 = 0; k1 < 16; ++k1) v[k1] = fb[k1 * 16 + (c ^ (2 * ((k1 >> 1) & 7)))];
+  wave_lds_sync();
+  xchg_write_row(fb, row2(c) - 16, v + 16);
+  wave_lds_sync();
+#pragma unroll
+  for (int k1 = 16; k1 < 32; ++k1) v[k1] = fb[(k1 - 16) * 16 + (c ^ (2 * ((k1 >> 1) & 7)))];
+  wave_lds_sync();
+#pragma unroll
+  for (int k1 = 1; k1 < 32; ++k1) {
+    cf w = tw512[k1 * 16 + c];
+    w.y = -w.y;
+    v[k1] = cmul(v[k1], w);
+  }
+  __builtin_amdgcn_sched_barrier(0);
+  dft_reg<32, true>(v);
+  __builtin_amdgcn_sched_barrier(0);
+}
+
 // One conjugate pair of the real-FFT split -> mask -> merge (see k_apply_istft in kernels.hpp):
 // a = Zc[k], b = Zc[N-k], w = w_1024^k, mk / mn = mask of bin k / N-k.  Returns Zc'[k], Zc'[N-k].
 // The four 1/2 factors of split and merge are NOT applied here: the caller folds 1/4 into the masks.
@@ -284,8 +310,10 @@ struct ApplyArgs {
 // Fused apply: frames -> FFT -> x mask -> IFFT -> window -> overlap-add -> output samples.
 // One workgroup = WAVES wavefronts = 4*WAVES consecutive frames of one unit -> 4*WAVES-3 hops.
 // ---------------------------------------------------------------------------------------
-template <int WAVES, bool KMASK>
-__global__ __launch_bounds__(WAVES * 64, 2) void k_apply_fast(ApplyArgs A) {
+// LEAN: half-size exchange slices (two-phase exchange) and wave-private hop accumulators instead of
+// 4 KB of stored frame per frame: 38 KB of LDS per workgroup and <= 168 VGPRs -> 3 waves per SIMD.
+template <int WAVES, bool KMASK, bool LEAN>
+__global__ __launch_bounds__(WAVES * 64, LEAN ? 3 : 2) void k_apply_fast(ApplyArgs A) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
   cf* tw512 = reinterpret_cast<cf*>(smem);
   cf* regions = tw512 + FN;
@@ -339,7 +367,7 @@ __global__ __launch_bounds__(WAVES * 64, 2) void k_apply_fast(ApplyArgs A) {
     if constexpr (KMASK) return (float)kk[q] * scale;
     else return mf[q] * scale;
   };
-  cf* fb = regions + wave * WAVE_CX + frame_base(g);
+  cf* fb = regions + wave * (LEAN ? WAVE_CX_H : WAVE_CX) + (LEAN ? frame_base_h(g) : frame_base(g));
   // gather the frame: v[r] = (x[2c + 32r], x[2c + 32r + 1]) * window
   cf v[32];
   {
@@ -360,35 +388,43 @@ __global__ __launch_bounds__(WAVES * 64, 2) void k_apply_fast(ApplyArgs A) {
       }
     } else {
       // edge / non-float32 / unaligned frames: rolled gather staged through this frame's LDS slice
+      // (LEAN: the slice holds 512 floats, so the frame is staged as two halves)
       float* fl = reinterpret_cast<float*>(fb);
-#pragma unroll 1
-      for (int r = 0; r < 32; ++r) {
-        float a = 0.f, b = 0.f;
-        if (fvalid) {
-          a = (float)view_sample(A.view, row, chunk, s0 + 2 * c + 32 * r);
-          b = (float)view_sample(A.view, row, chunk, s0 + 2 * c + 32 * r + 1);
-        }
-        fl[2 * c + 32 * r] = a;
-        fl[2 * c + 32 * r + 1] = b;
-      }
-      wave_lds_sync();
+      constexpr int NHALF = LEAN ? 2 : 1, RPH = 32 / NHALF;
 #pragma unroll
-      for (int r = 0; r < 32; ++r) {
-        float2 w2 = wsrc[16 * r];
-        cf x2 = fb[c + 16 * r];
-        v[r] = {x2.x * w2.x, x2.y * w2.y};
+      for (int hh = 0; hh < NHALF; ++hh) {
+#pragma unroll 1
+        for (int r = 0; r < RPH; ++r) {
+          float a = 0.f, b = 0.f;
+          if (fvalid) {
+            a = (float)view_sample(A.view, row, chunk, s0 + 2 * c + 32 * (r + RPH * hh));
+            b = (float)view_sample(A.view, row, chunk, s0 + 2 * c + 32 * (r + RPH * hh) + 1);
+          }
+          fl[2 * c + 32 * r] = a;
+          fl[2 * c + 32 * r + 1] = b;
+        }
+        wave_lds_sync();
+#pragma unroll
+        for (int r = 0; r < RPH; ++r) {
+          float2 w2 = wsrc[16 * (r + RPH * hh)];
+          cf x2 = fb[c + 16 * r];
+          v[r + RPH * hh] = {x2.x * w2.x, x2.y * w2.y};
+        }
+        wave_lds_sync();
       }
-      wave_lds_sync();
     }
   }
   __syncthreads();  // twiddle table staged
-  fft512_fwd(v, fb, tw512, c);
+  if constexpr (LEAN) fft512_fwd_half(v, fb, tw512, c);
+  else fft512_fwd(v, fb, tw512, c);
 
-  // synthesis window: issued now so that it arrives while the inverse transform runs
+  // synthesis window: (!LEAN) issued now so that it arrives while the inverse transform runs;
+  // (LEAN) loaded after the inverse transform -- three waves per SIMD hide the latency and the
+  // 64 registers stay free during the transforms
   float2 wsyn[32];
-  {
-    const float2* wsrc2 = reinterpret_cast<const float2*>(A.win + 2 * c);
-    asm volatile("" : "+v"(wsrc2));  // opaque: a separate load, not a CSE of the analysis window
+  const float2* wsrc2 = reinterpret_cast<const float2*>(A.win + 2 * c);
+  asm volatile("" : "+v"(wsrc2));  // opaque: a separate load, not a CSE of the analysis window
+  if constexpr (!LEAN) {
 #pragma unroll
     for (int r = 0; r < 32; ++r) wsyn[r] = wsrc2[16 * r];
   }
@@ -453,10 +489,35 @@ __global__ __launch_bounds__(WAVES * 64, 2) void k_apply_fast(ApplyArgs A) {
 #pragma unroll
     for (int i = 0; i < 32; ++i) v[i] = nv[i];
   }
-  fft512_inv(v, fb, tw512, c);
-  // synthesis window, store the time-domain frame (natural order) into this frame's LDS slice
+  if constexpr (LEAN) {
+    fft512_inv_half(v, fb, tw512, c);
 #pragma unroll
-  for (int r = 0; r < 32; ++r) fb[c + 16 * r] = {v[r].x * wsyn[r].x, v[r].y * wsyn[r].y};
+    for (int r = 0; r < 32; ++r) wsyn[r] = wsrc2[16 * r];
+    // wave-private overlap-add of this wave's 4 frames into 7 hop accumulators (7 KB, reusing the
+    // exchange slices).  Step j: every frame adds its quarter j -> frame g touches hop g + j: the four
+    // lane groups never collide within a step, and a hop receives its quarters in the fixed order
+    // j = 0, 1, 2, 3 (LDS operations of a wave execute in order) -> deterministic sums.
+    float* acc = reinterpret_cast<float*>(regions + wave * WAVE_CX_H);
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      const bool first = (j == 0) || (g == 3);  // first contribution to hop g + j: plain store
+#pragma unroll
+      for (int rr = 0; rr < 8; ++rr) {
+        const int r = 8 * j + rr;
+        float2* dst = reinterpret_cast<float2*>(acc + (g + j) * 256 + 2 * c + 32 * rr);
+        float2 old = *dst;
+        float2 nw = {v[r].x * wsyn[r].x, v[r].y * wsyn[r].y};
+        if (!first) { nw.x += old.x; nw.y += old.y; }
+        *dst = nw;
+      }
+      wave_lds_sync();
+    }
+  } else {
+    fft512_inv(v, fb, tw512, c);
+    // synthesis window, store the time-domain frame (natural order) into this frame's LDS slice
+#pragma unroll
+    for (int r = 0; r < 32; ++r) fb[c + 16 * r] = {v[r].x * wsyn[r].x, v[r].y * wsyn[r].y};
+  }
   __syncthreads();
 
   // overlap-add: tile hop jj (ext hop tf_tile + jj) = sum over tile frames i = jj-3..jj of quarter jj-i
@@ -472,13 +533,31 @@ __global__ __launch_bounds__(WAVES * 64, 2) void k_apply_fast(ApplyArgs A) {
     bool all_valid = true;
 #pragma unroll
     for (int q = 0; q < 4; ++q) {
-      const int i = jj - q;                     // tile frame contributing quarter q
-      const int64_t ti = tf_tile + i;
+      const int64_t ti = tf_tile + jj - q;
       if (ti < 0 || ti >= G.T) all_valid = false;
-      if (i >= 0 && i < NF && ti >= 0 && ti < G.T) {
-        const int off = ((i >> 2) * WAVE_CX + frame_base(i & 3)) * 2 + 256 * q + s4;  // float index
-        float4 f4 = *reinterpret_cast<const float4*>(&fr[off]);
+    }
+    if constexpr (LEAN) {
+      // hop jj lives in the accumulators of wave jj/4 (local hop jj%4 .. ) and, for jj%4 <= 2, of the
+      // wave before it (local hop jj%4 + 4); fixed order: earlier wave first
+      const int wh = jj >> 2, lh = jj & 3;
+      if (wh >= 1 && wh - 1 < WAVES && lh <= 2) {
+        float4 f4 = *reinterpret_cast<const float4*>(&fr[(wh - 1) * WAVE_CX_H * 2 + (lh + 4) * 256 + s4]);
+        acc = f4;
+      }
+      if (wh < WAVES) {
+        float4 f4 = *reinterpret_cast<const float4*>(&fr[wh * WAVE_CX_H * 2 + lh * 256 + s4]);
         acc.x += f4.x; acc.y += f4.y; acc.z += f4.z; acc.w += f4.w;
+      }
+    } else {
+#pragma unroll
+      for (int q = 0; q < 4; ++q) {
+        const int i = jj - q;                     // tile frame contributing quarter q
+        const int64_t ti = tf_tile + i;
+        if (i >= 0 && i < NF && ti >= 0 && ti < G.T) {
+          const int off = ((i >> 2) * WAVE_CX + frame_base(i & 3)) * 2 + 256 * q + s4;  // float index
+          float4 f4 = *reinterpret_cast<const float4*>(&fr[off]);
+          acc.x += f4.x; acc.y += f4.y; acc.z += f4.z; acc.w += f4.w;
+        }
       }
     }
     if (jj < 3 || jj >= NF) {

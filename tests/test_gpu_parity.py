@@ -468,3 +468,25 @@ def test_torchgate_sample_rates(sr):
     want = O.torchgate_T(x, sr, window=torch.hann_window(1024).double().numpy())
     assert got.shape == want.shape
     assert O.rel_err(got, want) < TOL
+
+
+def test_lean_apply_equals_full_slice_apply(nr):
+    """The 3-waves/SIMD apply kernel (half-size slices, wave-private hop accumulators) against the
+    2-waves/SIMD one that stores whole frames."""
+    from noisereduce_amd import _ffi
+    from noisereduce_amd.spectralgate.stationary import SpectralGateStationary
+    y = O.synth_signal(150000, seed=92)
+    kw = dict(sr=48000, y_noise=None, prop_decrease=1.0, n_std_thresh_stationary=1.5,
+              chunk_size=40000, clip_noise_stationary=True, padding=5000, n_fft=1024, win_length=None,
+              hop_length=None, time_constant_s=2.0, freq_mask_smooth_hz=500, time_mask_smooth_ms=50,
+              tmp_folder=None, use_tqdm=False, n_jobs=1)
+    sg = SpectralGateStationary(y=y, **kw)
+    a = sg.get_traces()
+    try:
+        sg._gate.set_option(_ffi.SG_OPT_FORCE_NOLEAN, 1)
+        b = sg.get_traces()
+    finally:
+        sg._gate.set_option(_ffi.SG_OPT_FORCE_NOLEAN, 0)
+    assert O.rel_err(a, b) < 1e-6
+    want = O.reduce_noise_S(y.astype(np.float64), 48000, stationary=True, chunk_size=40000, padding=5000)
+    assert O.rel_err(a, want) < TOL and O.rel_err(b, want) < TOL
