@@ -335,34 +335,41 @@ __global__ __launch_bounds__(WAVES * 64, LEAN ? 3 : 2) void k_apply_fast(ApplyAr
   const int64_t hs = tf_tile + 3;                            // first hop completed inside the tile
   const int64_t t = tf_tile + 4 * wave + g;                  // this lane group's frame
   const bool fvalid = t >= 0 && t < G.T;
-  const float4 inv4 = *reinterpret_cast<const float4*>(&A.invn[(tid & 63) * 4]);  // used by the OLA epilogue
+  // 1 / window envelope of this thread's four sample phases, used by the OLA epilogue: loaded at entry
+  // when registers allow, just before the final barrier in the LEAN kernel (else it is spilled)
+  float4 inv4;
+  if constexpr (!LEAN) inv4 = *reinterpret_cast<const float4*>(&A.invn[(tid & 63) * 4]);
 
-  // mask of this lane's 32 bins (+ bin 512 for lane c == 0), permuted layout; issued first: it is
-  // consumed only after the forward transform.  KMASK: uint16 counts (mask = K / ktot).
+  // mask of this lane's 32 bins (+ bin 512 for lane c == 0), permuted layout.  KMASK: uint16 counts
+  // (mask = K / ktot).  Issued before the forward transform when registers allow (!LEAN: latency
+  // hidden behind the FFT), after it in the LEAN kernel (168-VGPR budget, 3 waves hide the latency).
   unsigned short kk[KMASK ? 32 : 1];
   float mf[KMASK ? 1 : 32];
   float k512 = 0.f;
+  auto load_mask = [&]() {
   if constexpr (KMASK) {
-    const unsigned short* Krow = A.K + ((u * G.T + (fvalid ? t : 0)) * (int64_t)FSK);
-    const uint4* p4 = reinterpret_cast<const uint4*>(Krow + c * 32);
+      const unsigned short* Krow = A.K + ((u * G.T + (fvalid ? t : 0)) * (int64_t)FSK);
+      const uint4* p4 = reinterpret_cast<const uint4*>(Krow + c * 32);
 #pragma unroll
-    for (int q = 0; q < 4; ++q) {
-      uint4 w4 = p4[q];
-      unsigned ws[4] = {w4.x, w4.y, w4.z, w4.w};
+      for (int q = 0; q < 4; ++q) {
+        uint4 w4 = p4[q];
+        unsigned ws[4] = {w4.x, w4.y, w4.z, w4.w};
 #pragma unroll
-      for (int j = 0; j < 4; ++j) {
-        kk[q * 8 + 2 * j] = (unsigned short)(ws[j] & 0xffffu);
-        kk[q * 8 + 2 * j + 1] = (unsigned short)(ws[j] >> 16);
+        for (int j = 0; j < 4; ++j) {
+          kk[q * 8 + 2 * j] = (unsigned short)(ws[j] & 0xffffu);
+          kk[q * 8 + 2 * j + 1] = (unsigned short)(ws[j] >> 16);
+        }
       }
-    }
-    k512 = (float)Krow[512] * A.kscale;
-  } else {
-    // natural bin order: the 16 lanes of a frame read one 64-byte run per slot
-    const float* Mrow = A.Mf + ((u * G.T + (fvalid ? t : 0)) * (int64_t)FSK);
+      k512 = (float)Krow[512] * A.kscale;
+    } else {
+      // natural bin order: the 16 lanes of a frame read one 64-byte run per slot
+      const float* Mrow = A.Mf + ((u * G.T + (fvalid ? t : 0)) * (int64_t)FSK);
 #pragma unroll
-    for (int e = 0; e < 32; ++e) mf[e] = Mrow[bin_of_entry(c, e)];
-    k512 = Mrow[512] * A.kscale;
-  }
+      for (int e = 0; e < 32; ++e) mf[e] = Mrow[bin_of_entry(c, e)];
+      k512 = Mrow[512] * A.kscale;
+    }
+  };
+  if constexpr (!LEAN) load_mask();
   auto mval = [&](int q, float scale) -> float {
     if constexpr (KMASK) return (float)kk[q] * scale;
     else return mf[q] * scale;
@@ -415,8 +422,12 @@ __global__ __launch_bounds__(WAVES * 64, LEAN ? 3 : 2) void k_apply_fast(ApplyAr
     }
   }
   __syncthreads();  // twiddle table staged
-  if constexpr (LEAN) fft512_fwd_half(v, fb, tw512, c);
-  else fft512_fwd(v, fb, tw512, c);
+  if constexpr (LEAN) {
+    fft512_fwd_half(v, fb, tw512, c);
+    load_mask();
+  } else {
+    fft512_fwd(v, fb, tw512, c);
+  }
 
   // synthesis window: (!LEAN) issued now so that it arrives while the inverse transform runs;
   // (LEAN) loaded after the inverse transform -- three waves per SIMD hide the latency and the
@@ -512,6 +523,7 @@ __global__ __launch_bounds__(WAVES * 64, LEAN ? 3 : 2) void k_apply_fast(ApplyAr
       }
       wave_lds_sync();
     }
+    inv4 = *reinterpret_cast<const float4*>(&A.invn[(tid & 63) * 4]);
   } else {
     fft512_inv(v, fb, tw512, c);
     // synthesis window, store the time-domain frame (natural order) into this frame's LDS slice
@@ -523,7 +535,7 @@ __global__ __launch_bounds__(WAVES * 64, LEAN ? 3 : 2) void k_apply_fast(ApplyAr
   // overlap-add: tile hop jj (ext hop tf_tile + jj) = sum over tile frames i = jj-3..jj of quarter jj-i
   const float* fr = reinterpret_cast<const float*>(regions);
   const int s4 = (tid & 63) * 4;
-  const float4 n4 = inv4;  // 1 / window envelope of this thread's four sample phases (loaded at entry)
+  const float4 n4 = inv4;
   const int jj_lo = seam ? 0 : 3, jj_hi = seam ? NF + 3 : NF;
   for (int jj = jj_lo + (tid >> 6); jj < jj_hi; jj += WAVES) {
     const int64_t h = tf_tile + jj;
