@@ -14,6 +14,7 @@
 #include "../../include/mi355gate.h"
 #include "kernels.hpp"
 #include "fused.hpp"
+#include "czt.hpp"
 
 #ifndef SG_APPLY_WAVES
 #define SG_APPLY_WAVES 4  // wavefronts per workgroup of k_apply_fast: tile = 4*W frames -> 4*W-3 hops
@@ -56,6 +57,8 @@ struct sg_handle {
   DevBuf tw512, invn;                // fast path tables (n_fft = 1024, hop = 256)
   DevBuf seam;                       // partial seam hops of abutting apply tiles
   DevBuf ftab;                       // k_smooth_bits2 phase-1 lookup tables (nf <= 5)
+  int czt_M = 0;                     // > 0: n_fft is not a power of two -> chirp-z kernels (czt.hpp) of size M
+  DevBuf czt_tw64, czt_ch64, czt_bh64, czt_tw32, czt_ch32, czt_bh32;
   bool force_noseam = false;
   bool force_nolean = false;         // SG_OPT_FORCE_NOLEAN: full-size slices + stored frames (2 waves/SIMD)
   bool fast_ok = false;              // default geometry: fused apply kernel available
@@ -167,7 +170,8 @@ static int64_t frames_for(const sg_handle* h, int64_t L) {
 static int64_t outlen_for(const sg_handle* h, int64_t L) {
   int64_t T = frames_for(h, L);
   if (h->p.variant == SG_VARIANT_S) return (T - 1) * h->H + h->W - 2 * (int64_t)(h->W / 2);
-  return (T - 1) * (int64_t)h->H;
+  // torch.istft(center=True) trims n_fft//2 from both ends of the n_fft + (T-1) hop buffer
+  return (T - 1) * (int64_t)h->H + (h->n - 2 * (int64_t)(h->n / 2));
 }
 
 static Geom make_geom(const sg_handle* h, int64_t Lp) {
@@ -185,7 +189,9 @@ template <typename TC, int N>
 static hipError_t launch_stft_n(const View& v, const Geom& g, int64_t units, const void* tw, const void* wfull,
                                 double* P, float* mag, double* z, double zscale, hipStream_t st,
                                 unsigned long long* pmax_bits) {
-  constexpr int WAVES = (N * sizeof(cx<TC>) > 16384) ? 2 : 4;
+  // n_fft = 8192 (N = 4096): the whole workgroup cooperates on one frame
+  constexpr int NT = N >= 4096 ? 256 : 64;
+  constexpr int WAVES = N >= 4096 ? 1 : ((N * sizeof(cx<TC>) > 16384) ? 2 : 4);
   size_t lds = (size_t)(N + WAVES * N) * sizeof(cx<TC>);
   // few units (the noise clip): one frame per wave so that the grid still covers the chip
   const bool small = units * ((g.T + WAVES * 4 - 1) / (WAVES * 4)) < 1024;
@@ -196,12 +202,12 @@ static hipError_t launch_stft_n(const View& v, const Geom& g, int64_t units, con
       if (e != hipSuccess) return e;
     }
     dim3 grid((unsigned)((g.T + WAVES * fpw - 1) / (WAVES * fpw)), (unsigned)units);
-    hipLaunchKernelGGL(kern, grid, dim3(WAVES * 64), lds, st, v, g, (const cx<TC>*)tw, (const TC*)wfull, P, mag,
+    hipLaunchKernelGGL(kern, grid, dim3(WAVES * NT), lds, st, v, g, (const cx<TC>*)tw, (const TC*)wfull, P, mag,
                        z, zscale, pmax_bits);
     return hipGetLastError();
   };
-  if (small) return launch(k_stft<TC, N, WAVES, 1>, 1);
-  return launch(k_stft<TC, N, WAVES, 4>, 4);
+  if (small) return launch(k_stft<TC, N, WAVES, 1, NT>, 1);
+  return launch(k_stft<TC, N, WAVES, 4, NT>, 4);
 }
 
 template <typename TC>
@@ -216,6 +222,7 @@ static hipError_t launch_stft(int N, const View& v, const Geom& g, int64_t units
     case 512: return launch_stft_n<TC, 512>(v, g, units, tw, wfull, P, mag, z, zscale, st, pmax_bits);
     case 1024: return launch_stft_n<TC, 1024>(v, g, units, tw, wfull, P, mag, z, zscale, st, pmax_bits);
     case 2048: return launch_stft_n<TC, 2048>(v, g, units, tw, wfull, P, mag, z, zscale, st, pmax_bits);
+    case 4096: return launch_stft_n<TC, 4096>(v, g, units, tw, wfull, P, mag, z, zscale, st, pmax_bits);
   }
   return hipErrorInvalidValue;
 }
@@ -259,17 +266,18 @@ static hipError_t launch_bits(int N, const View& v, const Geom& g, int64_t units
 template <int N>
 static hipError_t launch_apply_n(const View& v, const Geom& g, int64_t units, const void* tw, const float* wa,
                                  const float* ws, const float* M, float* seg, hipStream_t st) {
-  constexpr int WAVES = (N * sizeof(cx<float>) > 16384) ? 2 : 4;
+  constexpr int NT = N >= 4096 ? 256 : 64;
+  constexpr int WAVES = N >= 4096 ? 1 : ((N * sizeof(cx<float>) > 16384) ? 2 : 4);
   constexpr int FPW = 4;
   size_t lds = (size_t)(N + WAVES * N) * sizeof(cx<float>);
-  auto kern = k_apply_istft<N, WAVES, FPW>;
+  auto kern = k_apply_istft<N, WAVES, FPW, NT>;
   if (lds > 65536) {
     hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern),
                                        hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
     if (e != hipSuccess) return e;
   }
   dim3 grid((unsigned)((g.T + WAVES * FPW - 1) / (WAVES * FPW)), (unsigned)units);
-  hipLaunchKernelGGL(kern, grid, dim3(WAVES * 64), lds, st, v, g, (const cx<float>*)tw, wa, ws, M, seg);
+  hipLaunchKernelGGL(kern, grid, dim3(WAVES * NT), lds, st, v, g, (const cx<float>*)tw, wa, ws, M, seg);
   return hipGetLastError();
 }
 
@@ -283,8 +291,101 @@ static hipError_t launch_apply(int N, const View& v, const Geom& g, int64_t unit
     case 512: return launch_apply_n<512>(v, g, units, tw, wa, ws, M, seg, st);
     case 1024: return launch_apply_n<1024>(v, g, units, tw, wa, ws, M, seg, st);
     case 2048: return launch_apply_n<2048>(v, g, units, tw, wa, ws, M, seg, st);
+    case 4096: return launch_apply_n<4096>(v, g, units, tw, wa, ws, M, seg, st);
   }
   return hipErrorInvalidValue;
+}
+
+// ------------------------------------------------------------------------------------------
+// chirp-z kernels (n_fft not a power of two): dispatch on the convolution size M
+// ------------------------------------------------------------------------------------------
+template <int M>
+struct CztShape {
+  static constexpr int NT = M >= 2048 ? 256 : 64;  // threads per frame
+  static constexpr int FR = M >= 2048 ? 1 : 4;     // frames in flight per workgroup
+};
+
+template <typename TC, int M>
+static hipError_t launch_stft_czt_m(const View& v, const Geom& g, int64_t units, const CztTabs<TC>& tb,
+                                    const void* wfull, double* P, float* mag, double* z, double zscale,
+                                    hipStream_t st, unsigned long long* pmax_bits) {
+  constexpr int NT = CztShape<M>::NT, FR = CztShape<M>::FR;
+  const size_t lds = (size_t)FR * M * sizeof(cx<TC>);
+  auto kern = k_stft_czt<TC, M, NT, FR>;
+  if (lds > 65536) {
+    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern),
+                                       hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    if (e != hipSuccess) return e;
+  }
+  const int fpb = units * ((g.T + FR * 4 - 1) / (FR * 4)) < 1024 ? 1 : 4;
+  dim3 grid((unsigned)((g.T + FR * fpb - 1) / (FR * fpb)), (unsigned)units);
+  hipLaunchKernelGGL(kern, grid, dim3(NT * FR), lds, st, v, g, tb, (const TC*)wfull, P, mag, z, zscale, pmax_bits,
+                     fpb);
+  return hipGetLastError();
+}
+
+template <int M>
+static hipError_t launch_apply_czt_m(const View& v, const Geom& g, int64_t units, const CztTabs<float>& tb,
+                                     const float* wa, const float* ws, const float* Mk, float* seg,
+                                     hipStream_t st) {
+  constexpr int NT = CztShape<M>::NT, FR = CztShape<M>::FR;
+  const size_t lds = (size_t)FR * M * sizeof(cx<float>);
+  auto kern = k_apply_istft_czt<M, NT, FR>;
+  if (lds > 65536) {
+    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern),
+                                       hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    if (e != hipSuccess) return e;
+  }
+  const int fpb = 4;
+  dim3 grid((unsigned)((g.T + FR * fpb - 1) / (FR * fpb)), (unsigned)units);
+  hipLaunchKernelGGL(kern, grid, dim3(NT * FR), lds, st, v, g, tb, wa, ws, Mk, seg, fpb);
+  return hipGetLastError();
+}
+
+#define SG_CZT_SWITCH(M_, CALL)            \
+  switch (M_) {                            \
+    case 64: return CALL(64);              \
+    case 128: return CALL(128);            \
+    case 256: return CALL(256);            \
+    case 512: return CALL(512);            \
+    case 1024: return CALL(1024);          \
+    case 2048: return CALL(2048);          \
+    case 4096: return CALL(4096);          \
+    case 8192: return CALL(8192);          \
+  }                                        \
+  return hipErrorInvalidValue
+
+template <typename TC>
+static CztTabs<TC> czt_tabs(const sg_handle* h) {
+  if (sizeof(TC) == 8)
+    return {(const cx<TC>*)h->czt_tw64.p, (const cx<TC>*)h->czt_ch64.p, (const cx<TC>*)h->czt_bh64.p};
+  return {(const cx<TC>*)h->czt_tw32.p, (const cx<TC>*)h->czt_ch32.p, (const cx<TC>*)h->czt_bh32.p};
+}
+
+// forward STFT of `units` units on the kernels that fit the handle's frame length
+template <typename TC>
+static hipError_t stft_any(const sg_handle* h, const View& v, const Geom& g, int64_t units, double* P, float* mag,
+                           double* z, double zscale, hipStream_t st, unsigned long long* pmax_bits = nullptr) {
+  const void* wfull = sizeof(TC) == 8 ? h->wfull64.p : h->wa32.p;
+  if (!h->czt_M) {
+    const void* tw = sizeof(TC) == 8 ? h->tw64.p : h->tw32.p;
+    return launch_stft<TC>(h->N, v, g, units, tw, wfull, P, mag, z, zscale, st, pmax_bits);
+  }
+  const CztTabs<TC> tb = czt_tabs<TC>(h);
+#define SG_CALL(M) launch_stft_czt_m<TC, M>(v, g, units, tb, wfull, P, mag, z, zscale, st, pmax_bits)
+  SG_CZT_SWITCH(h->czt_M, SG_CALL);
+#undef SG_CALL
+}
+
+static hipError_t apply_any(const sg_handle* h, const View& v, const Geom& g, int64_t units, const float* Mk,
+                            float* seg, hipStream_t st) {
+  const float* wa = (const float*)h->wa32.p;
+  const float* ws = (const float*)h->ws32.p;
+  if (!h->czt_M) return launch_apply(h->N, v, g, units, h->tw32.p, wa, ws, Mk, seg, st);
+  const CztTabs<float> tb = czt_tabs<float>(h);
+#define SG_CALL(M) launch_apply_czt_m<M>(v, g, units, tb, wa, ws, Mk, seg, st)
+  SG_CZT_SWITCH(h->czt_M, SG_CALL);
+#undef SG_CALL
 }
 
 static unsigned grid_1d(int64_t work, int block) {
@@ -306,6 +407,75 @@ static std::vector<double> triangle(int m) {
   return v;
 }
 
+// Tables of the chirp-z kernels (czt.hpp) for a frame length n that is not a power of two:
+// chirp conj(b[j]) = exp(-i pi j^2 / n) (j^2 reduced mod 2n in integers), B = FFT_M(b wrapped) / M
+// (host radix-2 transform in long double), master twiddles w_{2M}^k of the M-point device core.
+static int build_czt(sg_handle* h) {
+  typedef long double ld;
+  const ld PI = 3.14159265358979323846264338327950288L;
+  const int n = h->n;
+  int M = 64;
+  while (M < 2 * n - 1) M *= 2;
+  h->czt_M = M;
+  std::vector<ld> br(M, 0.0L), bi(M, 0.0L), cr(n), ci(n);
+  for (int j = 0; j < n; ++j) {
+    const int64_t q = ((int64_t)j * j) % (2 * (int64_t)n);
+    const ld a = PI * (ld)q / (ld)n;
+    cr[j] = cosl(a);
+    ci[j] = -sinl(a);
+    br[j] = cr[j];
+    bi[j] = -ci[j];
+    if (j) {
+      br[M - j] = br[j];
+      bi[M - j] = bi[j];
+    }
+  }
+  // in-place iterative radix-2 DIT
+  for (int i = 1, j = 0; i < M; ++i) {
+    int bit = M >> 1;
+    for (; j & bit; bit >>= 1) j ^= bit;
+    j ^= bit;
+    if (i < j) {
+      std::swap(br[i], br[j]);
+      std::swap(bi[i], bi[j]);
+    }
+  }
+  for (int len = 2; len <= M; len <<= 1) {
+    for (int k = 0; k < len / 2; ++k) {
+      const ld a = -2.0L * PI * (ld)k / (ld)len;
+      const ld wr = cosl(a), wi = sinl(a);
+      for (int i = k; i < M; i += len) {
+        const int j = i + len / 2;
+        const ld xr = br[j] * wr - bi[j] * wi, xi = br[j] * wi + bi[j] * wr;
+        br[j] = br[i] - xr;
+        bi[j] = bi[i] - xi;
+        br[i] += xr;
+        bi[i] += xi;
+      }
+    }
+  }
+  std::vector<cx<double>> tw64(M), ch64(n), bh64(M);
+  std::vector<cx<float>> tw32(M), ch32(n), bh32(M);
+  for (int k = 0; k < M; ++k) {
+    const ld a = -PI * (ld)k / (ld)M;
+    tw64[k] = {(double)cosl(a), (double)sinl(a)};
+    tw32[k] = {(float)cosl(a), (float)sinl(a)};
+    bh64[k] = {(double)(br[k] / (ld)M), (double)(bi[k] / (ld)M)};
+    bh32[k] = {(float)(br[k] / (ld)M), (float)(bi[k] / (ld)M)};
+  }
+  for (int j = 0; j < n; ++j) {
+    ch64[j] = {(double)cr[j], (double)ci[j]};
+    ch32[j] = {(float)cr[j], (float)ci[j]};
+  }
+  int rc = upload(h, h->czt_tw64, tw64.data(), tw64.size() * sizeof(cx<double>));
+  if (!rc) rc = upload(h, h->czt_ch64, ch64.data(), ch64.size() * sizeof(cx<double>));
+  if (!rc) rc = upload(h, h->czt_bh64, bh64.data(), bh64.size() * sizeof(cx<double>));
+  if (!rc) rc = upload(h, h->czt_tw32, tw32.data(), tw32.size() * sizeof(cx<float>));
+  if (!rc) rc = upload(h, h->czt_ch32, ch32.data(), ch32.size() * sizeof(cx<float>));
+  if (!rc) rc = upload(h, h->czt_bh32, bh32.data(), bh32.size() * sizeof(cx<float>));
+  return rc;
+}
+
 extern "C" int sg_create(const sg_params* p, const double* window_host, sg_handle** out) {
   if (!p || !out) {
     g_create_error = "sg_create: null argument";
@@ -316,8 +486,12 @@ extern "C" int sg_create(const sg_params* p, const double* window_host, sg_handl
     return code;
   };
   int n = p->n_fft;
-  if (n < 64 || n > 4096 || (n & (n - 1)))
-    return bad(SG_E_UNSUPPORTED, fmt("n_fft=%d unsupported: must be a power of two in [64, 4096]", n));
+  // powers of two 64..8192 run on the Stockham kernels; every other length 4..4096 on the chirp-z
+  // kernels (czt.hpp)
+  const bool pow2 = n >= 64 && (n & (n - 1)) == 0;
+  if (n < 4 || (pow2 && n > 8192) || (!pow2 && n > 4096))
+    return bad(SG_E_UNSUPPORTED,
+               fmt("n_fft=%d unsupported: must be in [4, 4096], or a power of two up to 8192", n));
   if (p->win_length < 2 || p->win_length > n)
     return bad(SG_E_INVALID, fmt("win_length=%d must be in [2, n_fft=%d]", p->win_length, n));
   if (p->hop_length < 1 || p->hop_length > p->win_length)
@@ -353,7 +527,7 @@ extern "C" int sg_create(const sg_params* p, const double* window_host, sg_handl
     int64_t b = p->smooth_mask ? (int64_t)(p->n_grad_time + 1) * (p->n_grad_time + 1) : 1;
     h->ktot = a * b;
     // fused (bit-mask) path: variant-S stationary gate whose integer smoothing sums fit uint16
-    h->fused_ok = p->variant == SG_VARIANT_S && p->stationary && h->ktot <= 65535 &&
+    h->fused_ok = p->variant == SG_VARIANT_S && p->stationary && h->ktot <= 65535 && pow2 && n <= 4096 &&
                   (!p->smooth_mask || p->n_grad_time <= 96);
     if (h->fused_ok && p->smooth_mask) {
       // the integer smoothing kernel holds (64 + 2 nt) rows of all F bins in LDS
@@ -382,7 +556,9 @@ extern "C" int sg_create(const sg_params* p, const double* window_host, sg_handl
   std::vector<float> wa32(n), ws32(n), wsq32(n);
   for (int k = 0; k < n; ++k) {
     wa32[k] = (float)wfull[k];
-    ws32[k] = (float)(wfull[k] / (double)h->N);
+    // synthesis window incl. the inverse-transform normalisation: the half-size complex core leaves
+    // a factor n/2, the chirp-z inverse a factor n
+    ws32[k] = (float)(wfull[k] / (pow2 ? (double)h->N : (double)n));
     wsq32[k] = (float)(wfull[k] * wfull[k]);
   }
   int rc = SG_OK;
@@ -392,6 +568,7 @@ extern "C" int sg_create(const sg_params* p, const double* window_host, sg_handl
   if (!rc) rc = upload(h, h->wa32, wa32.data(), wa32.size() * sizeof(float));
   if (!rc) rc = upload(h, h->ws32, ws32.data(), ws32.size() * sizeof(float));
   if (!rc) rc = upload(h, h->wsq32, wsq32.data(), wsq32.size() * sizeof(float));
+  if (!rc && !pow2) rc = build_czt(h);
   if (!rc && p->smooth_mask) {
     auto vf = triangle(p->n_grad_freq), vt = triangle(p->n_grad_time);
     double sf = 0, stt = 0;
@@ -456,7 +633,8 @@ extern "C" int sg_destroy(sg_handle* h) {
   for (auto e : h->prof_pool) (void)hipEventDestroy(e);
   for (DevBuf* b : {&h->tw64, &h->tw32, &h->wfull64, &h->wa32, &h->ws32, &h->wsq32, &h->kf, &h->kt, &h->thresh,
                     &h->P, &h->pmax, &h->thr_rows, &h->raw, &h->M, &h->seg, &h->yn, &h->bits, &h->K16, &h->umax,
-                    &h->need, &h->T2, &h->part, &h->tw512, &h->invn, &h->seam, &h->ftab})
+                    &h->need, &h->T2, &h->part, &h->tw512, &h->invn, &h->seam, &h->ftab, &h->czt_tw64, &h->czt_ch64,
+                    &h->czt_bh64, &h->czt_tw32, &h->czt_ch32, &h->czt_bh32})
     free_buf(*b);
   delete h;
   return SG_OK;
@@ -527,16 +705,15 @@ static int stage_power(sg_handle* h, const View& v, const Geom& g, int64_t ub, h
     // address per (unit, band), little contention when there are many units)
     HIPCHK(h, hipMemsetAsync(h->pmax.p, 0, (size_t)ub * g.FS * 8, st));
     ProfScope ps(h, SG_STAGE_STFT_POWER, st);
-    HIPCHK(h, launch_stft<double>(h->N, v, g, ub, h->tw64.p, h->wfull64.p, (double*)h->P.p, nullptr, nullptr,
-                                  1.0, st, (unsigned long long*)h->pmax.p));
+    HIPCHK(h, stft_any<double>(h, v, g, ub, (double*)h->P.p, nullptr, nullptr, 1.0, st,
+                               (unsigned long long*)h->pmax.p));
     return SG_OK;
   }
   // few units (the noise clip): thousands of frames would hammer the same 513 addresses; reduce
   // the maximum with the two-stage column kernels instead
   {
     ProfScope ps(h, SG_STAGE_STFT_POWER, st);
-    HIPCHK(h, launch_stft<double>(h->N, v, g, ub, h->tw64.p, h->wfull64.p, (double*)h->P.p, nullptr, nullptr,
-                                  1.0, st));
+    HIPCHK(h, stft_any<double>(h, v, g, ub, (double*)h->P.p, nullptr, nullptr, 1.0, st));
   }
   ProfScope ps(h, SG_STAGE_COLMAX, st);
   const int nts = stat_slices(g, ub);
@@ -597,7 +774,7 @@ static int stage_nonstat_raw(sg_handle* h, const View& v, const Geom& g, int64_t
     HIPCHK(h, hipGetLastError());
   } else {
     ProfScope ps(h, SG_STAGE_STFT_MAG, st);
-    HIPCHK(h, launch_stft<float>(h->N, v, g, ub, h->tw32.p, h->wa32.p, nullptr, mag, nullptr, 1.0, st));
+    HIPCHK(h, stft_any<float>(h, v, g, ub, nullptr, mag, nullptr, 1.0, st));
   }
   ProfScope ps(h, SG_STAGE_NONSTAT_MASK, st);
   dim3 grid((g.F + 63) / 64, (unsigned)ub);
@@ -665,8 +842,7 @@ static int stage_apply_ola(sg_handle* h, const View& v, const Geom& g, int64_t u
                            const OutMap& om, int normalize, hipStream_t st) {
   {
     ProfScope ps(h, SG_STAGE_APPLY_ISTFT, st);
-    HIPCHK(h, launch_apply(h->N, v, g, ub, h->tw32.p, (const float*)h->wa32.p, (const float*)h->ws32.p, M,
-                           (float*)h->seg.p, st));
+    HIPCHK(h, apply_any(h, v, g, ub, M, (float*)h->seg.p, st));
   }
   int64_t np = om.p1 - om.p0;
   if (np > 0) {
@@ -1213,8 +1389,7 @@ extern "C" int sg_stft(sg_handle* h, const void* x_dev, int dtype, int64_t B, in
   View v{};
   v.x = x_dev; v.dtype = dtype; v.stride = stride; v.N = L; v.lo = 0; v.hi = L; v.cs = 0; v.pad = 0; v.Lp = L; v.n_chunks = 1; v.unit0 = 0;
   Geom g = make_geom(h, L);
-  HIPCHK(h, launch_stft<double>(h->N, v, g, B, h->tw64.p, h->wfull64.p, nullptr, nullptr, z_dev, h->mag_scale,
-                                (hipStream_t)stream));
+  HIPCHK(h, stft_any<double>(h, v, g, B, nullptr, nullptr, z_dev, h->mag_scale, (hipStream_t)stream));
   return SG_OK;
 }
 

@@ -104,18 +104,20 @@ __device__ __forceinline__ cx<T> twN(const cx<T>* tw, int t) {
   return w;
 }
 
-template <typename T, int N, int S, bool INV>
+// NT = threads that cooperate on one transform (64: one wavefront per frame; 256: a whole
+// workgroup per frame, for the sizes whose butterflies would not fit one wave's registers).
+template <typename T, int N, int S, bool INV, int NT = 64>
 struct FftPass {
   static __device__ __forceinline__ void run(cx<T>* buf, const cx<T>* tw, int lane) {
     constexpr int NR = N / S;  // current sub-transform length
     constexpr int R = (NR % 8 == 0) ? 8 : ((NR % 4 == 0) ? 4 : 2);
     constexpr int NB = N / R;  // butterflies in this pass
-    constexpr int PER = (NB + 63) / 64;
+    constexpr int PER = (NB + NT - 1) / NT;
     cx<T> v[PER][R];
 #pragma unroll
     for (int c = 0; c < PER; ++c) {
-      int i = lane + 64 * c;
-      if (NB >= 64 || i < NB) {
+      int i = lane + NT * c;
+      if (NB >= NT || i < NB) {
 #pragma unroll
         for (int j = 0; j < R; ++j) v[c][j] = buf[i + j * NB];
       }
@@ -123,8 +125,8 @@ struct FftPass {
     SG_PASS_SYNC();
 #pragma unroll
     for (int c = 0; c < PER; ++c) {
-      int i = lane + 64 * c;
-      if (NB >= 64 || i < NB) {
+      int i = lane + NT * c;
+      if (NB >= NT || i < NB) {
         int q = i & (S - 1);
         int base = i - q;  // = p * S
         dftR<R, INV>(v[c]);
@@ -138,14 +140,14 @@ struct FftPass {
       }
     }
     SG_PASS_SYNC();
-    if constexpr (NR / R > 1) FftPass<T, N, S * R, INV>::run(buf, tw, lane);
+    if constexpr (NR / R > 1) FftPass<T, N, S * R, INV, NT>::run(buf, tw, lane);
   }
 };
 
 // In-place complex FFT of buf[0..N) (unnormalised; INV uses exp(+i...)).
-template <typename T, int N, bool INV>
+template <typename T, int N, bool INV, int NT = 64>
 __device__ __forceinline__ void wave_fft(cx<T>* buf, const cx<T>* tw, int lane) {
-  FftPass<T, N, 1, INV>::run(buf, tw, lane);
+  FftPass<T, N, 1, INV, NT>::run(buf, tw, lane);
 }
 
 // Real-FFT split: from Zc = FFT_N(x_even + i x_odd) compute bin k of the length-2N real

@@ -70,8 +70,8 @@ __device__ __forceinline__ void store_sample(void* p, int dtype, int64_t idx, fl
 // X is the UNSCALED transform of window * frame (scipy's 1/sum(w) is applied by consumers).
 // Optionally dumps X itself (float64 pairs, [u][t][F]) for the stage tap sg_stft.
 // ---------------------------------------------------------------------------------------
-template <typename TC, int N, int WAVES, int FPW>
-__global__ __launch_bounds__(WAVES * 64) void k_stft(View view, Geom g, const cx<TC>* __restrict__ tw_g,
+template <typename TC, int N, int WAVES, int FPW, int NT = 64>
+__global__ __launch_bounds__(WAVES * NT) void k_stft(View view, Geom g, const cx<TC>* __restrict__ tw_g,
                                                      const TC* __restrict__ wfull,
                                                      double* __restrict__ P_out, float* __restrict__ mag_out,
                                                      double* __restrict__ z_out, double z_scale,
@@ -79,23 +79,23 @@ __global__ __launch_bounds__(WAVES * 64) void k_stft(View view, Geom g, const cx
   extern __shared__ __attribute__((aligned(16))) char smem[];
   cx<TC>* tw = reinterpret_cast<cx<TC>*>(smem);
   cx<TC>* bufs = tw + N;
-  const int lane = threadIdx.x & 63;
-  const int wave = threadIdx.x >> 6;
+  const int lane = threadIdx.x % NT;  // thread within the frame's team (NT = 64: one wavefront)
+  const int wave = threadIdx.x / NT;
   cx<TC>* buf = bufs + wave * N;
-  for (int i = threadIdx.x; i < N; i += WAVES * 64) tw[i] = tw_g[i];
+  for (int i = threadIdx.x; i < N; i += WAVES * NT) tw[i] = tw_g[i];
   const int64_t u = blockIdx.y;
   const int64_t row = (view.unit0 + u) / view.n_chunks;
   const int64_t chunk = (view.unit0 + u) % view.n_chunks;
   __syncthreads();
-  double vmax[N / 64 + 1];  // running max power of this lane's bins (pmax_bits != nullptr)
+  double vmax[N / NT + 1];  // running max power of this lane's bins (pmax_bits != nullptr)
 #pragma unroll
-  for (int m = 0; m <= N / 64; ++m) vmax[m] = 0.0;
+  for (int m = 0; m <= N / NT; ++m) vmax[m] = 0.0;
   for (int fi = 0; fi < FPW; ++fi) {
     const int64_t t = ((int64_t)blockIdx.x * FPW + fi) * WAVES + wave;
     const bool valid = t < g.T;
     // gather window * frame as complex pairs (x[2j], x[2j+1])
     const int64_t s0 = t * g.H - g.padL;
-    for (int j = lane; j < N; j += 64) {
+    for (int j = lane; j < N; j += NT) {
       cx<TC> z = {(TC)0, (TC)0};
       if (valid) {
         z.x = (TC)view_sample(view, row, chunk, s0 + 2 * j) * wfull[2 * j];
@@ -104,12 +104,12 @@ __global__ __launch_bounds__(WAVES * 64) void k_stft(View view, Geom g, const cx
       buf[j] = z;
     }
     SG_PASS_SYNC();
-    wave_fft<TC, N, false>(buf, tw, lane);
+    wave_fft<TC, N, false, NT>(buf, tw, lane);
     if (valid) {
       const int64_t rowoff = (u * g.T + t) * g.FS;
 #pragma unroll
-      for (int m = 0; m <= N / 64; ++m) {
-        const int k = lane + 64 * m;
+      for (int m = 0; m <= N / NT; ++m) {
+        const int k = lane + NT * m;
         if (k > N) continue;
         cx<TC> a = buf[k == N ? 0 : k];
         cx<TC> b = buf[(k == 0 || k == N) ? 0 : N - k];
@@ -131,8 +131,8 @@ __global__ __launch_bounds__(WAVES * 64) void k_stft(View view, Geom g, const cx
   // per-(unit, band) max power, order-independent (non-negative doubles order like their bits)
   if (pmax_bits) {
 #pragma unroll
-    for (int m = 0; m <= N / 64; ++m) {
-      const int k = lane + 64 * m;
+    for (int m = 0; m <= N / NT; ++m) {
+      const int k = lane + NT * m;
       if (k <= N) atomicMax(&pmax_bits[u * g.FS + k], (unsigned long long)__double_as_longlong(vmax[m]));
     }
   }
@@ -145,18 +145,18 @@ __global__ __launch_bounds__(WAVES * 64) void k_stft(View view, Geom g, const cx
 // frame -> window -> rfft -> mask -> irfft -> window is symmetric up to the Hermitian weights,
 // handled by the caller through the window/normalisation tables).
 // ---------------------------------------------------------------------------------------
-template <int N, int WAVES, int FPW>
-__global__ __launch_bounds__(WAVES * 64) void k_apply_istft(View view, Geom g, const cx<float>* __restrict__ tw_g,
+template <int N, int WAVES, int FPW, int NT = 64>
+__global__ __launch_bounds__(WAVES * NT) void k_apply_istft(View view, Geom g, const cx<float>* __restrict__ tw_g,
                                                             const float* __restrict__ win_a,  // analysis window (n)
                                                             const float* __restrict__ win_s,  // synthesis window (n), incl. 1/N
                                                             const float* __restrict__ M, float* __restrict__ seg) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
   cx<float>* tw = reinterpret_cast<cx<float>*>(smem);
   cx<float>* bufs = tw + N;
-  const int lane = threadIdx.x & 63;
-  const int wave = threadIdx.x >> 6;
+  const int lane = threadIdx.x % NT;  // thread within the frame's team (NT = 64: one wavefront)
+  const int wave = threadIdx.x / NT;
   cx<float>* buf = bufs + wave * N;
-  for (int i = threadIdx.x; i < N; i += WAVES * 64) tw[i] = tw_g[i];
+  for (int i = threadIdx.x; i < N; i += WAVES * NT) tw[i] = tw_g[i];
   const int64_t u = blockIdx.y;
   const int64_t row = (view.unit0 + u) / view.n_chunks;
   const int64_t chunk = (view.unit0 + u) % view.n_chunks;
@@ -165,7 +165,7 @@ __global__ __launch_bounds__(WAVES * 64) void k_apply_istft(View view, Geom g, c
     const int64_t t = ((int64_t)blockIdx.x * FPW + fi) * WAVES + wave;
     const bool valid = t < g.T;
     const int64_t s0 = t * g.H - g.padL;
-    for (int j = lane; j < N; j += 64) {
+    for (int j = lane; j < N; j += NT) {
       cx<float> z = {0.f, 0.f};
       if (valid) {
         z.x = (float)view_sample(view, row, chunk, s0 + 2 * j) * win_a[2 * j];
@@ -174,11 +174,11 @@ __global__ __launch_bounds__(WAVES * 64) void k_apply_istft(View view, Geom g, c
       buf[j] = z;
     }
     SG_PASS_SYNC();
-    wave_fft<float, N, false>(buf, tw, lane);
+    wave_fft<float, N, false, NT>(buf, tw, lane);
     // split -> mask -> merge, pairwise in place: task k handles bins k and N-k.
     if (valid) {
       const float* Mrow = M + (u * g.T + t) * g.FS;
-      for (int k = lane; k <= N / 2; k += 64) {
+      for (int k = lane; k <= N / 2; k += NT) {
         if (k == 0) {
           cx<float> a = buf[0];
           float y0 = (a.x + a.y) * Mrow[0];
@@ -208,10 +208,10 @@ __global__ __launch_bounds__(WAVES * 64) void k_apply_istft(View view, Geom g, c
       }
     }
     SG_PASS_SYNC();
-    wave_fft<float, N, true>(buf, tw, lane);
+    wave_fft<float, N, true, NT>(buf, tw, lane);
     if (valid) {
       float2* srow = reinterpret_cast<float2*>(seg + (u * g.T + t) * (int64_t)g.n);
-      for (int j = lane; j < N; j += 64) {
+      for (int j = lane; j < N; j += NT) {
         cx<float> z = buf[j];
         srow[j] = make_float2(z.x * win_s[2 * j], z.y * win_s[2 * j + 1]);
       }

@@ -136,7 +136,8 @@ def stft_torch(x, n_fft, W, H, window=None):
 
 def istft_torch(Z, n_fft, W, H, window=None):
     """torch.istft(Y, n_fft, H, W, window=hann, center=True) as called at
-    torchgate.py:255-262.  Z: (B, F, T).  Returns (B, H*(T-1))."""
+    torchgate.py:255-262.  Z: (B, F, T).  Returns (B, H*(T-1)) -- one sample more when n_fft is
+    odd: torch trims n_fft//2 from both ends of the n_fft + H*(T-1) overlap-add buffer."""
     B, F, T = Z.shape
     wf = _centered_window(n_fft, W, window)
     xs = np.fft.irfft(Z, n=n_fft, axis=1) * wf[None, :, None]
@@ -148,7 +149,7 @@ def istft_torch(Z, n_fft, W, H, window=None):
         x[:, t * H:t * H + n_fft] += xs[:, :, t]
         env[t * H:t * H + n_fft] += w2
     p = n_fft // 2
-    end = p + H * (T - 1)
+    end = out_len - p
     x = x[:, p:end]
     env = env[p:end]
     if not np.all(np.abs(env) > 1e-11):

@@ -54,6 +54,17 @@ S_CASES = {
                       kwargs=dict(stationary=True, n_fft=2048, win_length=1500, hop_length=300)),
     "nonstat_geom": dict(sr=48000, n=30000, seed=23,
                          kwargs=dict(stationary=False, n_fft=1024, win_length=800, hop_length=160)),
+    # frame lengths that are not a power of two (even, odd, small) and the largest power of two
+    "stat_nfft1000": dict(sr=48000, n=30000, seed=24, kwargs=dict(stationary=True, n_fft=1000)),
+    "nonstat_nfft777": dict(sr=22050, n=25000, seed=25, tone_hz=700.0,
+                            kwargs=dict(stationary=False, n_fft=777)),
+    "stat_nfft100": dict(sr=8000, n=12000, seed=26, tone_hz=500.0,
+                         kwargs=dict(stationary=True, n_fft=100, chunk_size=5000, padding=600)),
+    "stat_nfft1536_geom": dict(sr=44100, n=30000, seed=27,
+                               kwargs=dict(stationary=True, n_fft=1536, win_length=1200, hop_length=250,
+                                           prop_decrease=0.7)),
+    "stat_nfft8192": dict(sr=48000, n=70000, seed=28, kwargs=dict(stationary=True, n_fft=8192)),
+    "nonstat_nfft8192": dict(sr=48000, n=70000, seed=29, kwargs=dict(stationary=False, n_fft=8192)),
 }
 
 
@@ -86,6 +97,9 @@ T_CASES = {
     "stat_nosmooth": dict(sr=16000, B=2, L=6000, seed=37,
                           kwargs=dict(freq_mask_smooth_hz=None, time_mask_smooth_ms=None)),
     "stat_sr8k": dict(sr=8000, B=3, L=32000, seed=38, kwargs=dict(nonstationary=True)),
+    # n_fft = 400 (25 ms at 16 kHz, the usual speech front-end frame) and an odd length
+    "stat_nfft400": dict(sr=16000, B=3, L=8000, seed=39, kwargs=dict(n_fft=400)),
+    "nonstat_nfft601": dict(sr=16000, B=2, L=8000, seed=40, kwargs=dict(nonstationary=True, n_fft=601)),
 }
 
 

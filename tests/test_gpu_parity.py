@@ -273,7 +273,8 @@ def test_fast_decide_bits_equal_f64_decide(nr, kind):
     assert O.rel_err(out_fast, want) < 2e-4 if kind == "pure_tone" else O.rel_err(out_fast, want) < TOL
 
 
-@pytest.mark.parametrize("kw", [dict(), dict(nonstationary=True), dict(n_fft=512, win_length=400, hop_length=100)])
+@pytest.mark.parametrize("kw", [dict(), dict(nonstationary=True), dict(n_fft=512, win_length=400, hop_length=100),
+                                dict(n_fft=400), dict(n_fft=601, nonstationary=True)])
 @pytest.mark.parametrize("dtype", [torch.float64, torch.float32])
 def test_torchgate_backward_matches_autograd(kw, dtype):
     """TorchGate is differentiable w.r.t. x with the mask detached (torchgate.py:126,167).  Our
@@ -360,8 +361,9 @@ def test_short_and_ragged_inputs(nr):
         assert O.rel_err(nr.reduce_noise(y=y, sr=48000, **kw), O.reduce_noise_S(y, 48000, **kw)) < TOL
     with pytest.raises(ValueError):
         nr.reduce_noise(y=np.zeros(500), sr=48000, stationary=True)      # shorter than win_length
-    with pytest.raises(NotImplementedError):
-        nr.reduce_noise(y=np.zeros(5000), sr=48000, stationary=True, n_fft=1000)  # not a power of two
+    for n_fft in (5000, 16384):   # beyond the chirp-z range (4096) / the largest Stockham size (8192)
+        with pytest.raises(NotImplementedError):
+            nr.reduce_noise(y=np.zeros(40000), sr=48000, stationary=True, n_fft=n_fft, time_mask_smooth_ms=200)
 
 
 def test_use_torch_routing(nr):
@@ -431,15 +433,18 @@ def test_full_size_config2_properties(nr):
         assert O.rel_err(o1[ich * 600000:(ich + 1) * 600000], ref) < TOL
 
 
-@pytest.mark.parametrize("n_fft", [64, 128, 256, 4096])
+@pytest.mark.parametrize("n_fft", [64, 128, 256, 4096, 8192, 40, 250, 1023, 3000, 4095])
 @pytest.mark.parametrize("stationary", [True, False])
 def test_fft_size_range(nr, n_fft, stationary):
-    """Smallest and largest supported transforms (general per-wavefront Stockham kernels)."""
+    """Smallest and largest supported transforms: powers of two on the Stockham kernels (one wavefront
+    per frame; n_fft = 8192: one workgroup per frame), every other length on the chirp-z kernels."""
     sr = 48000
     y = O.synth_signal(60000, seed=n_fft).astype(np.float64)
     kw = dict(stationary=stationary, n_fft=n_fft, chunk_size=25000, padding=5000)
     if n_fft <= 128:
         kw.update(freq_mask_smooth_hz=3000, time_mask_smooth_ms=10)   # at least one bin / one frame
+    if n_fft >= 3000:
+        kw.update(time_mask_smooth_ms=100)                            # hop >= 750 samples
     got = nr.reduce_noise(y=y, sr=sr, **kw)
     want = O.reduce_noise_S(y, sr, **kw)
     assert O.rel_err(got, want) < TOL

@@ -1,0 +1,32 @@
+"""Device-resident throughput of reduce_noise (stationary / non-stationary) over n_fft, including
+frame lengths that run on the chirp-z kernels.  Usage: python tools/time_nfft.py"""
+import json
+import sys, os
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import numpy as np
+import torch
+import noisereduce_amd as nr
+
+sr, n = 48000, 48000 * 120
+rng = np.random.default_rng(0)
+y = (0.1 * rng.standard_normal(n) + 0.5 * np.sin(2 * np.pi * 1000 * np.arange(n) / sr)).astype(np.float32)
+yd = torch.from_numpy(y).cuda()
+res = {}
+for n_fft in (256, 400, 512, 1000, 1024, 1536, 2048, 3000, 4096, 8192):
+    for stationary in (True, False):
+        kw = dict(stationary=stationary, n_fft=n_fft, time_mask_smooth_ms=200 if n_fft > 2048 else 50)
+        for _ in range(2):
+            nr.reduce_noise(y=yd, sr=sr, **kw)
+        torch.cuda.synchronize()
+        a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        reps = 5
+        a.record()
+        for _ in range(reps):
+            nr.reduce_noise(y=yd, sr=sr, **kw)
+        b.record()
+        torch.cuda.synchronize()
+        ms = a.elapsed_time(b) / reps
+        res[f"n_fft={n_fft},{'stat' if stationary else 'nonstat'}"] = dict(ms=round(ms, 3), Msamples_s=round(n / ms / 1e3, 1))
+        print(n_fft, stationary, round(ms, 3), "ms", round(n / ms / 1e3, 1), "Msamples/s", flush=True)
+os.makedirs("gpurun_out", exist_ok=True)
+json.dump(res, open("gpurun_out/time_nfft.json", "w"), indent=1)
