@@ -7,8 +7,8 @@ padding=30000.  One "step" = one whole reduce_noise pass over the recording, inp
 output resident in HBM (noise statistics + the full chunk grid: every kernel of the path).
 
 N GPUs (weak scaling): the recording is N x 10 min, time-sharded on chunk boundaries, one
-process per GPU; per step the ranks all-gather their seam samples (2*padding per rank) and
-rank 0 broadcasts the per-band threshold -- the only collectives of the path.
+process per GPU; per step ONE all-gather carries every rank's seam samples (2*padding per rank)
+and rank 0's per-band threshold -- the only collective of the path.
 
 Prints ONE JSON line (rank 0).  `roofline` is for the dominant kernel of the step
 (HIP events around every launch, on the launch stream, inside the timed region);
@@ -122,7 +122,7 @@ def main():
         return sg.backend._gate() if stationary else sg._gate
 
     def step():
-        # one whole reduce_noise: (statistics + threshold broadcast) + seam exchange + chunk grid.
+        # one whole reduce_noise: statistics + (seam, threshold) all-gather + chunk grid.
         # The engine handle (tables + workspace) is cached across calls by noisereduce_amd._ffi.
         sg = make_gate()
         if stationary:

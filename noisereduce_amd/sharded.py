@@ -11,9 +11,10 @@ data-path collective.  Two small exchanges remain:
   rank -- the "seam" exchange) and pass them to the kernels as halos.  Outputs need no
   exchange: the reference discards the padded part of every chunk (base.py:150).
 * the stationary threshold is a property of the whole recording (stationary.py:47-81):
-  the rank that owns the noise clip computes it and broadcasts n_fft/2+1 doubles; with
-  channel sharding the channel mean of the clip is an all-reduce(sum) of one clip-length
-  vector.
+  the rank that owns the noise clip computes it; its n_fft/2+1 doubles ride in the SAME
+  all-gather as the seams (one collective per call: small-message collectives over xGMI are
+  latency-bound, ~tens of microseconds each against a ~0.6 ms step).  With channel sharding the
+  channel mean of the clip is an all-reduce(sum) of one clip-length vector.
 
 ``filter_fn`` makes the compute step pluggable so the partition/exchange logic is testable on
 CPU (world_size 2, gloo) against the oracle; the product path uses the HIP engine.
@@ -141,6 +142,47 @@ class HipStationaryBackend:
                                 halo_right=halo)
 
 
+def exchange_seams_and_threshold(y_local, padding, thr, n_bins, group=None, bufs=None):
+    """ONE all-gather carrying every rank's seam samples and rank 0's threshold.
+    Each rank contributes [first `padding` | last `padding` samples of every channel | n_bins float64]
+    as raw bytes (only rank 0's threshold slot is meaningful).  Returns (left_halo, right_halo, thr):
+    halos (C, padding) in y_local's dtype, zeros at the ends of the recording; thr float64 (n_bins,).
+    `bufs`: optional dict that keeps the send/receive buffers between calls."""
+    ws, rank = dist.get_world_size(group), dist.get_rank(group)
+    C, S = y_local.shape
+    if S < padding:
+        raise ValueError("time shard shorter than the chunk padding")
+    es = y_local.element_size()
+    seam_bytes = 2 * C * padding * es
+    sb = (seam_bytes + 7) // 8 * 8                      # threshold slot 8-byte aligned
+    total = sb + n_bins * 8
+    key = (total, ws, y_local.device)
+    if bufs is not None and bufs.get("key") == key:
+        send, recv = bufs["send"], bufs["recv"]
+    else:
+        send = torch.zeros(total, dtype=torch.uint8, device=y_local.device)
+        recv = torch.empty(ws * total, dtype=torch.uint8, device=y_local.device)
+        if bufs is not None:
+            bufs.update(key=key, send=send, recv=recv)
+    if padding:
+        seams = send[:seam_bytes].view(y_local.dtype).view(2, C, padding)
+        seams[0].copy_(y_local[:, :padding])
+        seams[1].copy_(y_local[:, S - padding:])
+    if rank == 0:
+        send[sb:].view(torch.float64).copy_(thr)
+    dist.all_gather_into_tensor(recv, send, group=group)
+    recv = recv.view(ws, total)
+    thr_out = recv[0, sb:].view(torch.float64)
+
+    def seam_of(r, which):
+        return recv[r, :seam_bytes].view(y_local.dtype).view(2, C, padding)[which]
+
+    zero = torch.zeros((C, padding), dtype=y_local.dtype, device=y_local.device)
+    left = seam_of(rank - 1, 1) if (rank > 0 and padding) else zero
+    right = seam_of(rank + 1, 0) if (rank < ws - 1 and padding) else zero
+    return left, right, thr_out
+
+
 class TimeShardedStationary:
     """reduce_noise(stationary=True, y_noise=None) of a recording that is time-sharded over the
     ranks of `group` (rank r holds the r-th chunk-aligned slice, already on its device).
@@ -152,6 +194,9 @@ class TimeShardedStationary:
         self.group = group
         self.ws = dist.get_world_size(group) if dist.is_initialized() else 1
         self.rank = dist.get_rank(group) if dist.is_initialized() else 0
+        # send/receive buffers of the exchange live with the backend (one per process), not with this
+        # per-call object
+        self._bufs = backend.__dict__.setdefault("_xchg_bufs", {})
 
     def run(self, y_local, ext=None):
         """y_local: this rank's (C, S) shard.  ext: optional halo-extended buffer that already
@@ -164,20 +209,20 @@ class TimeShardedStationary:
             raise ValueError("time shards must be chunk-aligned")
         # threshold: y_noise=None means "the first chunk_size samples of the recording"
         # (stationary.py:47-64); they live on rank 0, which broadcasts n_bins doubles.
-        thr = None
         if self.ws == 1:
             self.backend.stats(y_local)
-        elif self.rank == 0:
-            thr = self.backend.threshold(y_local)
+            return self.backend.filter(y_local, y_local, 0, None, owner=True)
+        thr = self.backend.threshold(y_local) if self.rank == 0 else None
+        left, right, thr = exchange_seams_and_threshold(y_local, pad, thr, self.n_bins, self.group,
+                                                        self._bufs)
+        if pad == 0:
+            ext = y_local
+        elif ext is None:
+            ext = torch.cat([left, y_local, right], dim=1)
         else:
-            thr = torch.zeros(self.n_bins, dtype=torch.float64, device=y_local.device)
-        if self.ws > 1:
-            dist.broadcast(thr, src=0, group=self.group)
-            ext = with_halos(y_local, pad, self.group, ext)
-            halo = pad
-        else:
-            ext, halo = y_local, 0
-        return self.backend.filter(y_local, ext, halo, thr, owner=self.rank == 0)
+            ext[:, :pad].copy_(left)
+            ext[:, pad + S:].copy_(right)
+        return self.backend.filter(y_local, ext, pad, thr, owner=self.rank == 0)
 
 
 class ChannelShardedStationary:

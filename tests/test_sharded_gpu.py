@@ -1,0 +1,87 @@
+"""Two ranks, HIP engine: the time- and channel-sharded gates against the single-process oracle.
+The ranks share cuda:0 and talk over gloo (RCCL refuses two ranks on one device) -- the exchange
+code and the engine calls are exactly those of the N-GPU bench (halo-extended shards, one
+all-gather carrying seams + threshold)."""
+import os
+import socket
+
+import numpy as np
+import pytest
+import torch
+import torch.distributed as dist
+import torch.multiprocessing as mp
+
+from oracle import spectralgate_oracle as O
+
+pytestmark = pytest.mark.gpu
+SR, CS, PAD, NFFT = 48000, 50000, 6000, 1024
+TOL = 1e-4
+
+
+def _free_port():
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    p = s.getsockname()[1]
+    s.close()
+    return p
+
+
+def _init(rank, world, port):
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    torch.cuda.set_device(0)
+    return torch.device("cuda", 0)
+
+
+def _worker_time(rank, world, port, y, want, ret):
+    dev = _init(rank, world, port)
+    from noisereduce_amd.sharded import (HipStationaryBackend, TimeShardedStationary, alloc_shard,
+                                         shard_bounds)
+    s0, s1 = shard_bounds(y.shape[1], CS, world, rank)
+    backend = HipStationaryBackend(SR, dev, chunk_size=CS, padding=PAD, n_fft=NFFT)
+    errs = []
+    for dtype in (torch.float64, torch.float32):
+        ext, shard = alloc_shard(y.shape[0], s1 - s0, PAD, dtype, dev)
+        shard.copy_(y[:, s0:s1].to(dtype))
+        gate = TimeShardedStationary(backend, NFFT // 2 + 1)
+        for use_ext in (True, False):          # halos written into the extended buffer / concatenated
+            out = gate.run(shard, ext=ext if use_ext else None)
+            assert out.shape == shard.shape and out.dtype == dtype
+            errs.append(float((out.double().cpu() - want[:, s0:s1]).abs().max() / want.abs().max()))
+    ret[rank] = max(errs)
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_time_sharded_hip_two_ranks():
+    n = 5 * CS + 4321                          # 6 chunks, the last one partial: 3 + 3
+    y = np.stack([O.synth_signal(n, seed=41).astype(np.float64),
+                  O.synth_signal(n, seed=42, tone_hz=2500.0).astype(np.float64)])
+    want = O.reduce_noise_S(y, SR, stationary=True, chunk_size=CS, padding=PAD, n_fft=NFFT)
+    ret = mp.Manager().dict()
+    mp.spawn(_worker_time, args=(2, _free_port(), torch.from_numpy(y), torch.from_numpy(want), ret),
+             nprocs=2, join=True)
+    assert ret[0] < TOL and ret[1] < TOL, dict(ret)
+
+
+def _worker_channels(rank, world, port, y, want, ret):
+    dev = _init(rank, world, port)
+    from noisereduce_amd.sharded import ChannelShardedStationary, HipStationaryBackend
+    C = y.shape[0] // world
+    y_local = y[rank * C:(rank + 1) * C].to(torch.float32).to(dev)
+    backend = HipStationaryBackend(SR, dev, chunk_size=CS, padding=PAD, n_fft=NFFT)
+    out = ChannelShardedStationary(backend).run(y_local)
+    ret[rank] = float((out.double().cpu() - want[rank * C:(rank + 1) * C]).abs().max() / want.abs().max())
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_channel_sharded_hip_two_ranks():
+    n = 2 * CS + 999
+    y = np.stack([O.synth_signal(n, seed=70 + c, tone_hz=180.0 * (c + 1)).astype(np.float64) for c in range(4)])
+    want = O.reduce_noise_S(y, SR, stationary=True, chunk_size=CS, padding=PAD, n_fft=NFFT)
+    ret = mp.Manager().dict()
+    mp.spawn(_worker_channels, args=(2, _free_port(), torch.from_numpy(y), torch.from_numpy(want), ret),
+             nprocs=2, join=True)
+    assert ret[0] < TOL and ret[1] < TOL, dict(ret)
