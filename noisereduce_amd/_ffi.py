@@ -86,11 +86,12 @@ def load_library():
     global _lib
     if _lib is not None:
         return _lib
-    if not os.path.exists(LIB_PATH):
+    path = os.environ.get("SG_LIB_PATH", LIB_PATH)   # development: A/B builds (tools/ablate.sh)
+    if not os.path.exists(path):
         raise ImportError(
-            f"{LIB_PATH} not found: build it with `python -c 'import __graft_entry__ as g; "
+            f"{path} not found: build it with `python -c 'import __graft_entry__ as g; "
             "g.build()'` (hipcc --offload-arch=gfx950).  noisereduce_amd has no CPU fallback.")
-    lib = ctypes.CDLL(LIB_PATH)
+    lib = ctypes.CDLL(path)
     for name, (res, args) in _PROTOTYPES.items():
         fn = getattr(lib, name)  # AttributeError if the .so is stale
         fn.restype = res

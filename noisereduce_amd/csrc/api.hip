@@ -1029,7 +1029,7 @@ static int stage_apply_fast(sg_handle* h, const View& v, const Geom& g, int64_t 
     hipLaunchKernelGGL(kern, grid, dim3(WAVES * 64), lds_bytes, st, A);
     return hipGetLastError();
   };
-  const size_t lds_lean = (size_t)(fast::FN + WAVES * fast::WAVE_CX_H) * sizeof(fast::cf);
+  const size_t lds_lean = (size_t)(fast::FN + WAVES * fast::WAVE_CX_H) * sizeof(fast::cf) + 1024 * sizeof(float);
   if (mask_f) {
     if (lean) HIPCHK(h, go(fast::k_apply_fast<WAVES, false, true>, lds_lean));
     else HIPCHK(h, go(fast::k_apply_fast<WAVES, false, false>, lds));

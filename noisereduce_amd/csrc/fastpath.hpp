@@ -312,6 +312,12 @@ struct ApplyArgs {
 // ---------------------------------------------------------------------------------------
 // LEAN: half-size exchange slices (two-phase exchange) and wave-private hop accumulators instead of
 // 4 KB of stored frame per frame: 38 KB of LDS per workgroup and <= 168 VGPRs -> 3 waves per SIMD.
+// SG_ABLATE (development only, default 0): bit mask that removes one ingredient of k_apply_fast to
+// measure what it costs (results are wrong): 1 mask loads, 2 window loads, 4 output stores,
+// 8 both transforms, 16 input loads.  tools/ablate.sh builds and times the variants.
+#ifndef SG_ABLATE
+#define SG_ABLATE 0
+#endif
 template <int WAVES, bool KMASK, bool LEAN>
 __global__ __launch_bounds__(WAVES * 64, LEAN ? 3 : 2) void k_apply_fast(ApplyArgs A) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
@@ -323,6 +329,13 @@ __global__ __launch_bounds__(WAVES * 64, LEAN ? 3 : 2) void k_apply_fast(ApplyAr
   const int lane = tid & 63, wave = tid >> 6;
   const int g = lane >> 4, c = lane & 15;
   for (int i = tid; i < FN; i += WAVES * 64) tw512[i] = A.tw512[(i >> 4) * (i & 15)];
+  // LEAN: the window table (4 KB) lives in LDS behind the exchange slices: both window passes read it
+  // with ds_read_b64 instead of 64 global loads per lane
+  float* swin = reinterpret_cast<float*>(regions + WAVES * (LEAN ? WAVE_CX_H : WAVE_CX));
+  if constexpr (LEAN) {
+    for (int i = tid; i < 256; i += WAVES * 64)
+      reinterpret_cast<float4*>(swin)[i] = reinterpret_cast<const float4*>(A.win)[i];
+  }
   const Geom& G = A.g;
   const int64_t u = blockIdx.y;
   const int64_t row = (A.view.unit0 + u) / A.view.n_chunks;
@@ -347,7 +360,13 @@ __global__ __launch_bounds__(WAVES * 64, LEAN ? 3 : 2) void k_apply_fast(ApplyAr
   float mf[KMASK ? 1 : 32];
   float k512 = 0.f;
   auto load_mask = [&]() {
-  if constexpr (KMASK) {
+  if constexpr ((SG_ABLATE & 1) != 0) {
+#pragma unroll
+    for (int q = 0; q < (KMASK ? 32 : 1); ++q) kk[q] = (unsigned short)(c + q);
+#pragma unroll
+    for (int q = 0; q < (KMASK ? 1 : 32); ++q) mf[q] = 0.5f + c;
+    k512 = 1.f;
+  } else if constexpr (KMASK) {
       const unsigned short* Krow = A.K + ((u * G.T + (fvalid ? t : 0)) * (int64_t)FSK);
       const uint4* p4 = reinterpret_cast<const uint4*>(Krow + c * 32);
 #pragma unroll
@@ -375,22 +394,61 @@ __global__ __launch_bounds__(WAVES * 64, LEAN ? 3 : 2) void k_apply_fast(ApplyAr
     else return mf[q] * scale;
   };
   cf* fb = regions + wave * (LEAN ? WAVE_CX_H : WAVE_CX) + (LEAN ? frame_base_h(g) : frame_base(g));
+  // LEAN, interior tiles of float32 input: the tile's NF frames cover one contiguous span of
+  // (NF-1)*256 + 1024 samples; the workgroup stages it once in LDS with coalesced 16-byte loads (the
+  // exchange slices are idle until the first transform) instead of every lane gathering 32 float2
+  // from global memory.  Hops are stored with a pitch of 288 floats so that the two lane groups of a
+  // ds_read_b64 pass (frames g, g+1: 256 samples apart) hit disjoint bank halves.
+  constexpr int SPAN = (NF - 1) * 256 + 1024, XPITCH = 288;
+  static_assert(!LEAN || (SPAN / 256) * XPITCH <= WAVES * WAVE_CX_H * 2, "span must fit the exchange slices");
+  bool blk_in = false;
+  if constexpr (LEAN) {
+    const int64_t s0b = tf_tile * 256 - G.padL;
+    const int64_t gb = chunk * A.view.cs - A.view.pad + s0b;
+    blk_in = A.view.dtype == 0 && tf_tile >= 0 && tf_tile + NF <= G.T && s0b >= 0 && s0b + SPAN <= A.view.Lp &&
+             gb >= A.view.lo && gb + SPAN <= A.view.hi && !(SG_ABLATE & 16);
+    if (blk_in) {
+      const float* sp = (const float*)A.view.x + row * A.view.stride + gb;
+      float* xs = reinterpret_cast<float*>(regions);
+      if ((reinterpret_cast<uintptr_t>(sp) & 15) == 0) {
+        for (int i = tid; i < SPAN / 4; i += WAVES * 64) {
+          const float4 q = reinterpret_cast<const float4*>(sp)[i];
+          const int e = 4 * i;
+          *reinterpret_cast<float4*>(&xs[(e >> 8) * XPITCH + (e & 255)]) = q;
+        }
+      } else {
+        for (int i = tid; i < SPAN; i += WAVES * 64) xs[(i >> 8) * XPITCH + (i & 255)] = sp[i];
+      }
+    }
+    __syncthreads();  // twiddles, window and span staged
+  }
   // gather the frame: v[r] = (x[2c + 32r], x[2c + 32r + 1]) * window
   cf v[32];
-  {
+  if (LEAN && blk_in) {
+    const float* xs = reinterpret_cast<const float*>(regions) + (4 * wave + g) * XPITCH + 2 * c;
+    const float2* wl = reinterpret_cast<const float2*>(swin + 2 * c);
+#pragma unroll
+    for (int r = 0; r < 32; ++r) {
+      const float2 x2 = *reinterpret_cast<const float2*>(xs + (r >> 3) * XPITCH + 32 * (r & 7));
+      const float2 w2 = wl[16 * r];
+      v[r] = {x2.x * w2.x, x2.y * w2.y};
+    }
+    __syncthreads();  // every lane has its samples: the span may be overwritten by the exchanges
+  } else {
     const int64_t s0 = t * 256 - G.padL;  // unit-local index of frame sample 0
     const int64_t gbase = chunk * A.view.cs - A.view.pad + s0;
     const bool inside = fvalid && s0 >= 0 && s0 + 1024 <= A.view.Lp && gbase >= A.view.lo &&
                         gbase + 1024 <= A.view.hi && A.view.dtype == 0;
     const float* src = (const float*)A.view.x + row * A.view.stride + gbase + 2 * c;
     const bool aligned = (reinterpret_cast<uintptr_t>(src) & 7) == 0;
-    const float2* wsrc = reinterpret_cast<const float2*>(A.win + 2 * c);
+    const float2* wsrc = LEAN ? reinterpret_cast<const float2*>(swin + 2 * c)
+                              : reinterpret_cast<const float2*>(A.win + 2 * c);
     if (inside && aligned) {
       const float2* s2 = reinterpret_cast<const float2*>(src);
 #pragma unroll
       for (int r = 0; r < 32; ++r) {
-        float2 x2 = s2[16 * r];
-        float2 w2 = wsrc[16 * r];
+        float2 x2 = (SG_ABLATE & 16) ? make_float2(0.001f * r + c, 0.5f) : s2[16 * r];
+        float2 w2 = (SG_ABLATE & 2) ? make_float2(0.5f, 0.25f + r) : wsrc[16 * r];
         v[r] = {x2.x * w2.x, x2.y * w2.y};
       }
     } else {
@@ -421,9 +479,9 @@ __global__ __launch_bounds__(WAVES * 64, LEAN ? 3 : 2) void k_apply_fast(ApplyAr
       }
     }
   }
-  __syncthreads();  // twiddle table staged
+  if constexpr (!LEAN) __syncthreads();  // twiddle table staged
   if constexpr (LEAN) {
-    fft512_fwd_half(v, fb, tw512, c);
+    if constexpr ((SG_ABLATE & 8) == 0) fft512_fwd_half(v, fb, tw512, c);
     load_mask();
   } else {
     fft512_fwd(v, fb, tw512, c);
@@ -433,8 +491,9 @@ __global__ __launch_bounds__(WAVES * 64, LEAN ? 3 : 2) void k_apply_fast(ApplyAr
   // (LEAN) loaded after the inverse transform -- three waves per SIMD hide the latency and the
   // 64 registers stay free during the transforms
   float2 wsyn[32];
-  const float2* wsrc2 = reinterpret_cast<const float2*>(A.win + 2 * c);
-  asm volatile("" : "+v"(wsrc2));  // opaque: a separate load, not a CSE of the analysis window
+  const float2* wsrc2 = LEAN ? reinterpret_cast<const float2*>(swin + 2 * c)
+                             : reinterpret_cast<const float2*>(A.win + 2 * c);
+  if constexpr (!LEAN) asm volatile("" : "+v"(wsrc2));  // opaque: a separate load, not a CSE of the analysis window
   if constexpr (!LEAN) {
 #pragma unroll
     for (int r = 0; r < 32; ++r) wsyn[r] = wsrc2[16 * r];
@@ -501,9 +560,9 @@ __global__ __launch_bounds__(WAVES * 64, LEAN ? 3 : 2) void k_apply_fast(ApplyAr
     for (int i = 0; i < 32; ++i) v[i] = nv[i];
   }
   if constexpr (LEAN) {
-    fft512_inv_half(v, fb, tw512, c);
+    if constexpr ((SG_ABLATE & 8) == 0) fft512_inv_half(v, fb, tw512, c);
 #pragma unroll
-    for (int r = 0; r < 32; ++r) wsyn[r] = wsrc2[16 * r];
+    for (int r = 0; r < 32; ++r) wsyn[r] = (SG_ABLATE & 2) ? make_float2(0.5f, 0.25f + r) : wsrc2[16 * r];
     // wave-private overlap-add of this wave's 4 frames into 7 hop accumulators (7 KB, reusing the
     // exchange slices).  Step j: every frame adds its quarter j -> frame g touches hop g + j: the four
     // lane groups never collide within a step, and a hop receives its quarters in the fixed order
@@ -605,6 +664,7 @@ __global__ __launch_bounds__(WAVES * 64, LEAN ? 3 : 2) void k_apply_fast(ApplyAr
       if (p < A.om.p0 || p >= A.om.p1) continue;
       const int64_t gi = chunk * A.om.g_step + (p - A.om.p0);
       if (gi < A.om.g_lo || gi >= A.om.g_hi) continue;
+      if ((SG_ABLATE & 4) && vals[e] != 12345.678f) continue;
       store_sample(A.om.out, A.om.dtype, row * A.om.stride + gi - A.om.g0, p < G.Lout ? vals[e] : 0.f);
     }
   }
