@@ -963,7 +963,7 @@ static int stage_fused_mask(sg_handle* h, const View& v, const Geom& g, int64_t 
     D.quads_per_wave = 1;
     const int64_t quads = (D.t_end - D.t_begin + 3) / 4;
     const int64_t per_block = (int64_t)WAVES * D.quads_per_wave;
-    size_t lds = (size_t)(fast::FN + WAVES * fast::WAVE_CX_H) * sizeof(fast::cf) + 528 * sizeof(float);
+    size_t lds = (size_t)(fast::FN + WAVES * fast::WAVE_CX_H) * sizeof(fast::cf) + (528 + 1024) * sizeof(float);
     auto kern = fast::k_decide_fast<WAVES>;
     HIPCHK(h, hipFuncSetAttribute(reinterpret_cast<const void*>(kern),
                                   hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));

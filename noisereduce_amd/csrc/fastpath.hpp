@@ -657,6 +657,19 @@ __global__ __launch_bounds__(WAVES * 64, LEAN ? 3 : 2) void k_apply_fast(ApplyAr
       acc.z /= (nrm.z > 1e-10f ? nrm.z : 1.f);
       acc.w /= (nrm.w > 1e-10f ? nrm.w : 1.f);
     }
+    {
+      // whole hop inside the kept range of a float32 output: one 16-byte store per lane
+      const int64_t pb = h * 256 - G.padL;
+      const int64_t gi0 = chunk * A.om.g_step + (pb - A.om.p0);
+      if (A.om.dtype == 0 && pb >= A.om.p0 && pb + 256 <= A.om.p1 && pb + 256 <= G.Lout && gi0 >= A.om.g_lo &&
+          gi0 + 256 <= A.om.g_hi && !(SG_ABLATE & 4)) {
+        float* dst = (float*)A.om.out + (row * A.om.stride + gi0 - A.om.g0 + s4);
+        if ((reinterpret_cast<uintptr_t>(dst) & 15) == 0) {
+          *reinterpret_cast<float4*>(dst) = acc;
+          continue;
+        }
+      }
+    }
     const float vals[4] = {acc.x, acc.y, acc.z, acc.w};
 #pragma unroll
     for (int e = 0; e < 4; ++e) {
@@ -797,26 +810,64 @@ __global__ __launch_bounds__(WAVES * 64, 3) void k_decide_fast(DecideArgs A) {
   }
   cf* fb = regions + wave * WAVE_CX_H + frame_base_h(g);
   const cf wl0 = A.tw1024[c];  // w_1024^c (lane 0: 1)
+  // window table in LDS (behind the compare constants); interior blocks of float32 input also stage
+  // the contiguous sample span of their 4*WAVES frames in the (still idle) exchange slices -- see
+  // k_apply_fast
+  float* swin = s_t2 + 528;
+  for (int i = tid; i < 256; i += WAVES * 64)
+    reinterpret_cast<float4*>(swin)[i] = reinterpret_cast<const float4*>(A.win)[i];
+  constexpr int NFB = 4 * WAVES, SPAN = (NFB - 1) * 256 + 1024, XPITCH = 288;
+  static_assert((SPAN / 256) * XPITCH <= WAVES * WAVE_CX_H * 2, "span must fit the exchange slices");
+  const int64_t tqb = A.t_begin + (int64_t)blockIdx.x * NFB;  // first frame of the workgroup
+  bool blk_in;
+  {
+    const int64_t s0b = tqb * 256 - G.padL;
+    const int64_t gb = chunk * A.view.cs - A.view.pad + s0b;
+    blk_in = A.view.dtype == 0 && tqb + NFB <= A.t_end && tqb + NFB <= G.T && s0b >= 0 &&
+             s0b + SPAN <= A.view.Lp && gb >= A.view.lo && gb + SPAN <= A.view.hi;
+    if (blk_in) {
+      const float* sp = (const float*)A.view.x + row * A.view.stride + gb;
+      float* xs = reinterpret_cast<float*>(regions);
+      if ((reinterpret_cast<uintptr_t>(sp) & 15) == 0) {
+        for (int i = tid; i < SPAN / 4; i += WAVES * 64) {
+          const float4 q = reinterpret_cast<const float4*>(sp)[i];
+          const int e = 4 * i;
+          *reinterpret_cast<float4*>(&xs[(e >> 8) * XPITCH + (e & 255)]) = q;
+        }
+      } else {
+        for (int i = tid; i < SPAN; i += WAVES * 64) xs[(i >> 8) * XPITCH + (i & 255)] = sp[i];
+      }
+    }
+  }
   __syncthreads();
 
   {
     // one frame quad per wave (no loop: loop-invariant twiddle/window loads would be hoisted and
     // pin >100 VGPRs, costing the second wave per SIMD)
-    const int64_t tq = A.t_begin + ((int64_t)blockIdx.x * WAVES + wave) * 4;  // first frame of the quad
-    if (tq >= A.t_end) return;                                                  // wave-uniform
+    const int64_t tq = tqb + wave * 4;  // first frame of the quad
+    if (!blk_in && tq >= A.t_end) return;  // wave-uniform (an interior block has no idle wave)
     const int64_t t = tq + g;
     const bool fvalid = t < A.t_end && t < G.T;
     cf v[32];
     float nrm2 = 0.f;
-    {
+    if (blk_in) {
+      const float* xs = reinterpret_cast<const float*>(regions) + (4 * wave + g) * XPITCH + 2 * c;
+      const float2* wl2 = reinterpret_cast<const float2*>(swin + 2 * c);
+#pragma unroll
+      for (int r = 0; r < 32; ++r) {
+        const float2 x2 = *reinterpret_cast<const float2*>(xs + (r >> 3) * XPITCH + 32 * (r & 7));
+        const float2 w2 = wl2[16 * r];
+        v[r] = {x2.x * w2.x, x2.y * w2.y};
+      }
+      __syncthreads();  // the span may now be overwritten by the exchanges
+    } else {
       const int64_t s0 = t * 256 - G.padL;
       const int64_t gbase = chunk * A.view.cs - A.view.pad + s0;
       const bool inside = fvalid && s0 >= 0 && s0 + 1024 <= A.view.Lp && gbase >= A.view.lo &&
                           gbase + 1024 <= A.view.hi && A.view.dtype == 0;
       const float* src = (const float*)A.view.x + row * A.view.stride + gbase + 2 * c;
       const bool aligned = (reinterpret_cast<uintptr_t>(src) & 7) == 0;
-      const float2* wsrc = reinterpret_cast<const float2*>(A.win + 2 * c);
-      asm volatile("" : "+v"(wsrc));  // re-read per quad: hoisting 64 window registers costs a wave
+      const float2* wsrc = reinterpret_cast<const float2*>(swin + 2 * c);
       if (inside && aligned) {
         const float2* s2 = reinterpret_cast<const float2*>(src);
 #pragma unroll
@@ -849,6 +900,8 @@ __global__ __launch_bounds__(WAVES * 64, 3) void k_decide_fast(DecideArgs A) {
           wave_lds_sync();
         }
       }
+    }
+    {
 #pragma unroll
       for (int r = 0; r < 32; ++r) nrm2 += v[r].x * v[r].x + v[r].y * v[r].y;
       // sum over the 16 lanes of this frame
