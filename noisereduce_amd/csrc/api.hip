@@ -744,6 +744,13 @@ static int stage_colstats(sg_handle* h, const Geom& g, int64_t ub, double* thres
   return SG_OK;
 }
 
+// power field + band statistics -> threshold
+static int stage_stats(sg_handle* h, const View& v, const Geom& g, int64_t ub, double* thresh_out, hipStream_t st) {
+  int rc = stage_power(h, v, g, ub, st);
+  if (rc) return rc;
+  return stage_colstats(h, g, ub, thresh_out, st);
+}
+
 static int stage_decide(sg_handle* h, const Geom& g, int64_t ub, const double* thresh, int64_t ustride,
                         hipStream_t st) {
   ProfScope ps(h, SG_STAGE_DECIDE, st);
@@ -787,7 +794,8 @@ static int stage_nonstat_raw(sg_handle* h, const View& v, const Geom& g, int64_t
       hipLaunchKernelGGL(k_iir_sigmoid, grid, dim3(64), 0, st, (const float*)mag, g, h->p.iir_b,
                          h->p.nonstat_thresh, h->p.nonstat_slope, (float*)h->raw.p);
   } else {
-    hipLaunchKernelGGL(k_boxcar_sigmoid, grid, dim3(64), 0, st, (const float*)mag, g, h->p.n_movemean,
+    dim3 bgrid((unsigned)((g.F + 63) / 64), (unsigned)((g.T + 4 * BOX_TSEG - 1) / (4 * BOX_TSEG)), (unsigned)ub);
+    hipLaunchKernelGGL(k_boxcar_sigmoid, bgrid, dim3(256), 0, st, (const float*)mag, g, h->p.n_movemean,
                        h->p.nonstat_thresh, h->p.nonstat_slope, (float*)h->raw.p);
   }
   HIPCHK(h, hipGetLastError());
@@ -811,7 +819,7 @@ static int stage_smooth(sg_handle* h, const Geom& g, int64_t ub, hipStream_t st)
     const int nf = h->p.n_grad_freq, nt = h->p.n_grad_time;
     const int rows = SMF_TT + 2 * nt, cols = SMF_FB + 2 * nf;
     // +3: the sliding windows read up to 3 entries past the last tap
-    size_t lds = ((size_t)(rows + 3) * (cols | 1) + (size_t)(rows + 3) * (SMF_FB + 1) + 8) * sizeof(float);
+    size_t lds = ((size_t)(rows + 3) * (cols | 1) + (size_t)(rows + 3) * (SMF_FB + 1) + 8 + 128 + SMF_FB + SMF_TT) * sizeof(float);
     if (lds <= 150 * 1024 && ub <= 65535 && nf <= 30 && nt <= 30 && SMF_FB + 2 * nf <= 192) {
       auto kern = k_smooth_tiled;
       if (lds > 65536)
@@ -1115,20 +1123,21 @@ extern "C" int sg_noise_stats(sg_handle* h, const void* noise_dev, int dtype, in
     explicit Tag(sg_handle* h_) : h(h_) { h->prof_override = SG_STAGE_NOISE_STATS; }
     ~Tag() { h->prof_override = -1; }
   } tag(h);
-  int rc = ensure(h, h->yn, (size_t)n * sizeof(double));
-  if (rc) return rc;
-  {
+  int rc = SG_OK;
+  View v{};
+  v.x = noise_dev; v.dtype = dtype; v.stride = row_stride;  // one channel: its mean is the channel itself
+  if (C > 1) {
+    if ((rc = ensure(h, h->yn, (size_t)n * sizeof(double)))) return rc;
     ProfScope ps(h, SG_STAGE_CHANNEL_MEAN, st);
     hipLaunchKernelGGL(k_channel_mean, dim3(grid_1d(n, 256)), dim3(256), 0, st, noise_dev, dtype, C, n,
                        row_stride, (double*)h->yn.p);
     HIPCHK(h, hipGetLastError());
+    v.x = h->yn.p; v.dtype = SG_F64; v.stride = n;
   }
-  View v{};
-  v.x = h->yn.p; v.dtype = SG_F64; v.stride = n; v.N = n; v.lo = 0; v.hi = n; v.cs = 0; v.pad = 0; v.Lp = n; v.n_chunks = 1; v.unit0 = 0;
+  v.N = n; v.lo = 0; v.hi = n; v.cs = 0; v.pad = 0; v.Lp = n; v.n_chunks = 1; v.unit0 = 0;
   Geom g = make_geom(h, n);
   if ((rc = ensure_ws(h, g, 1))) return rc;
-  if ((rc = stage_power(h, v, g, 1, st))) return rc;
-  if ((rc = stage_colstats(h, g, 1, (double*)h->thresh.p, st))) return rc;
+  if ((rc = stage_stats(h, v, g, 1, (double*)h->thresh.p, st))) return rc;
   h->has_thresh = true;
   return SG_OK;
 }
@@ -1259,8 +1268,7 @@ extern "C" int sg_process_batch(sg_handle* h, const void* x_dev, int dtype, int6
   double* thr = (double*)h->thr_rows.p;
   if (xn_dev && h->p.stationary && Bn == 1) {
     vn.unit0 = 0;
-    if ((rc = stage_power(h, vn, gn, 1, st))) return rc;
-    if ((rc = stage_colstats(h, gn, 1, (double*)h->thresh.p, st))) return rc;
+    if ((rc = stage_stats(h, vn, gn, 1, (double*)h->thresh.p, st))) return rc;
   }
   for (int64_t u0 = 0; u0 < B; u0 += ub) {
     int64_t nb = std::min(ub, B - u0);
@@ -1272,8 +1280,7 @@ extern "C" int sg_process_batch(sg_handle* h, const void* x_dev, int dtype, int6
         th = (const double*)h->thresh.p; ustride = 0;
       } else if (xn_dev) {
         vn.unit0 = u0;
-        if ((rc = stage_power(h, vn, gn, nb, st))) return rc;
-        if ((rc = stage_colstats(h, gn, nb, thr, st))) return rc;
+        if ((rc = stage_stats(h, vn, gn, nb, thr, st))) return rc;
         th = thr; ustride = g.FS;
       } else {
         th = nullptr; ustride = g.FS;
@@ -1291,11 +1298,16 @@ extern "C" int sg_process_batch(sg_handle* h, const void* x_dev, int dtype, int6
         const int wpr = (g.F + 63) / 64;
         if ((rc = ensure(h, h->bits, (size_t)nb * g.T * wpr * 8))) return rc;
         if ((rc = ensure(h, h->K16, (size_t)nb * g.T * g.FS * 2))) return rc;
+        if ((rc = ensure(h, h->T2, (size_t)nb * g.FS * 8))) return rc;
         {
           ProfScope ps(h, SG_STAGE_DECIDE, st);
-          hipLaunchKernelGGL(k_decide_bits, dim3(grid_1d(nb * g.T * wpr * 64, 256)), dim3(256), 0, st,
-                             (const double*)h->P.p, g, (const double*)h->pmax.p, th, ustride, h->mag_scale,
-                             h->p.top_db, (unsigned long long*)h->bits.p, wpr, nb);
+          // compare constants in the power domain per (row, band), then a pure compare per cell
+          hipLaunchKernelGGL(k_t2_rows, dim3(grid_1d(nb * g.FS, 256)), dim3(256), 0, st, th, ustride,
+                             (const double*)h->pmax.p, g, h->mag_scale, h->p.top_db, (double*)h->T2.p, nb);
+          HIPCHK(h, hipGetLastError());
+          hipLaunchKernelGGL(k_decide_bits_t2, dim3(grid_1d(nb * g.T * wpr * 64, 256)), dim3(256), 0, st,
+                             (const double*)h->P.p, g, (const double*)h->T2.p, (unsigned long long*)h->bits.p, wpr,
+                             nb);
           HIPCHK(h, hipGetLastError());
         }
         if ((rc = stage_smooth_bits(h, g, nb, true, 0, g.T, st))) return rc;

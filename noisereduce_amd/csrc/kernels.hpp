@@ -406,11 +406,34 @@ __global__ void k_decide(const double* __restrict__ P, Geom g, const double* __r
   }
 }
 
-// Same decision as k_decide, written as a bit mask (64 bins per word, one wavefront per word) for
-// the integer smoothing / fused apply kernels.
-__global__ void k_decide_bits(const double* __restrict__ P, Geom g, const double* __restrict__ pmax,
-                              const double* __restrict__ thresh, int64_t thresh_ustride, double mag_scale,
-                              double top_db, unsigned long long* __restrict__ bits, int wpr, int64_t n_units) {
+// Per-(unit, band) compare constant in the POWER domain (as k_prep_thresh does per band for variant S):
+//   max(dB, rowmax_dB - top_db) > thresh   <=>   floor lifts the band  ||  |X|^2 > T2
+// T2 = -1: every cell passes (floor above the threshold, or a zero cell already passes).
+__global__ void k_t2_rows(const double* __restrict__ thresh, int64_t thresh_ustride, const double* __restrict__ pmax,
+                          Geom g, double mag_scale, double top_db, double* __restrict__ T2, int64_t n_units) {
+  const double eps = 2.220446049250313e-16;
+  const int64_t n = n_units * g.FS;
+  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x) {
+    const int64_t u = i / g.FS;
+    const int f = (int)(i % g.FS);
+    double t2 = 0.0;
+    if (f < g.F) {
+      const double th = thresh[u * thresh_ustride + f];
+      const double fl = cell_db(pmax[i], mag_scale) - top_db;
+      if (fl > th || 20.0 * log10(eps) > th) {
+        t2 = -1.0;
+      } else {
+        const double tm = (exp10(th / 20.0) - eps) / mag_scale;
+        t2 = tm > 0.0 ? tm * tm : 0.0;
+      }
+    }
+    T2[i] = t2;
+  }
+}
+
+// bits[u][t][w] = P > T2[u][f]: one wavefront per 64-bin word, a pure compare (no log10 per cell)
+__global__ void k_decide_bits_t2(const double* __restrict__ P, Geom g, const double* __restrict__ T2,
+                                 unsigned long long* __restrict__ bits, int wpr, int64_t n_units) {
   const int lane = threadIdx.x & 63;
   const int64_t nwords = n_units * g.T * wpr;
   for (int64_t wd = (int64_t)blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6); wd < nwords;
@@ -419,13 +442,7 @@ __global__ void k_decide_bits(const double* __restrict__ P, Geom g, const double
     const int64_t ut = wd / wpr;
     const int64_t u = ut / g.T;
     const int f = 64 * w + lane;
-    bool pred = false;
-    if (f < g.F) {
-      double db = cell_db(P[ut * g.FS + f], mag_scale);
-      double fl = cell_db(pmax[u * g.FS + f], mag_scale) - top_db;
-      db = fmax(db, fl);
-      pred = db > thresh[u * thresh_ustride + f];
-    }
+    const bool pred = f < g.F && P[ut * g.FS + f] > T2[u * g.FS + f];
     const unsigned long long word = __ballot(pred);
     if (lane == 0) bits[wd] = word;
   }
@@ -438,6 +455,13 @@ __global__ void k_decide_bits(const double* __restrict__ P, Geom g, const double
 // (nonstationary.py:106-115), then sigmoid((A-S)/S - thresh) * slope) (nonstationary.py:70-76).
 // One thread per (unit, bin); lanes = bins (coalesced row walk).  raw is used as scratch for
 // the forward pass.
+// sigmoid(((A - S) / S - thresh) * slope): the difference in float64 (cancellation), the smooth
+// remainder (division, exp) in float32 -- the mask is a float32 field and no decision hangs on it.
+__device__ __forceinline__ float sigmoid_ratio(double av, double s, float nthresh, float slope) {
+  const float ratio = (float)(av - s) / (float)s;
+  return 1.0f / (1.0f + __expf(-(ratio - nthresh) * slope));
+}
+
 __global__ void k_iir_sigmoid(const float* __restrict__ A, Geom g, double b, double nthresh, double slope,
                               float* __restrict__ raw) {
   const int f = blockIdx.x * blockDim.x + threadIdx.x;
@@ -458,8 +482,7 @@ __global__ void k_iir_sigmoid(const float* __restrict__ A, Geom g, double b, dou
     if (t == g.T - 1) fw = fprev;  // exact (unrounded) last forward value
     s = b * fw + c * s;
     double av = (double)a[t * g.FS];
-    double ratio = (av - s) / s;
-    r[t * g.FS] = (float)(1.0 / (1.0 + exp(-(ratio - nthresh) * slope)));
+    r[t * g.FS] = sigmoid_ratio(av, s, (float)nthresh, (float)slope);
   }
 }
 
@@ -526,32 +549,34 @@ __global__ __launch_bounds__(64 * IIR_NSEG) void k_iir_sigmoid_seg(const float* 
       double fw = (t == g.T - 1) ? seed : (double)r[t * g.FS];
       s = b * fw + c * s;
       double av = (double)a[t * g.FS];
-      double ratio = (av - s) / s;
-      r[t * g.FS] = (float)(1.0 / (1.0 + exp(-(ratio - nthresh) * slope)));
+      r[t * g.FS] = sigmoid_ratio(av, s, (float)nthresh, (float)slope);
     }
   }
 }
 
 // T: boxcar moving mean conv1d(ones(k), padding="same")/k, left pad (k-1)//2
 // (torchgate.py:179-190), then sigmoid((ratio - x0)/temp) (torchgate.py:193-196).
-__global__ void k_boxcar_sigmoid(const float* __restrict__ A, Geom g, int kbox, double nthresh, double slope,
-                                 float* __restrict__ raw) {
-  const int f = blockIdx.x * blockDim.x + threadIdx.x;
-  const int64_t u = blockIdx.y;
-  if (f >= g.F) return;
+// Block = 64 bins x 4 time segments of BOX_TSEG frames: every thread seeds its window sum directly
+// (kbox loads) and slides it over its own frames -- T/BOX_TSEG-fold the parallelism of one serial
+// walk per band (TorchGate rows are short: 63 frames at 16 kHz / 1 s).
+constexpr int BOX_TSEG = 8;
+__global__ __launch_bounds__(256) void k_boxcar_sigmoid(const float* __restrict__ A, Geom g, int kbox,
+                                                        double nthresh, double slope, float* __restrict__ raw) {
+  const int f = blockIdx.x * 64 + (threadIdx.x & 63);
+  const int64_t u = blockIdx.z;
+  const int64_t t0 = ((int64_t)blockIdx.y * 4 + (threadIdx.x >> 6)) * BOX_TSEG;
+  if (f >= g.F || t0 >= g.T) return;
   const float* a = A + u * g.T * g.FS + f;
   float* r = raw + u * g.T * g.FS + f;
   const int left = (kbox - 1) / 2;
-  // sliding window sum over [t-left, t-left+kbox)
+  // window of frame t: [t - left, t - left + kbox), zero outside [0, T)
   double sum = 0.0;
-  for (int64_t j = 0; j < kbox - left && j < g.T; ++j) sum += (double)a[j * g.FS];
-  for (int64_t t = 0; t < g.T; ++t) {
-    double S = sum / (double)kbox;
-    double av = (double)a[t * g.FS];
-    double ratio = (av - S) / S;
-    r[t * g.FS] = (float)(1.0 / (1.0 + exp(-(ratio - nthresh) * slope)));
-    // slide: drop t-left, add t-left+kbox
-    int64_t drop = t - left, add = t - left + kbox;
+  for (int64_t j = max<int64_t>(t0 - left, 0); j < min<int64_t>(t0 - left + kbox, g.T); ++j) sum += (double)a[j * g.FS];
+  const int64_t t1 = min<int64_t>(t0 + BOX_TSEG, g.T);
+  for (int64_t t = t0; t < t1; ++t) {
+    const double S = sum / (double)kbox;
+    r[t * g.FS] = sigmoid_ratio((double)a[t * g.FS], S, (float)nthresh, (float)slope);
+    const int64_t drop = t - left, add = t - left + kbox;
     if (drop >= 0) sum -= (double)a[drop * g.FS];
     if (add < g.T) sum += (double)a[add * g.FS];
   }
@@ -623,11 +648,37 @@ __global__ __launch_bounds__(256) void k_smooth_tiled(const float* __restrict__ 
   const int cols = SMF_FB + 2 * nf;
   const int tp = cols | 1;             // odd pitch of the raw tile
   constexpr int BP = SMF_FB + 1;       // odd pitch of the f-pass result
-  float* tile = reinterpret_cast<float*>(smem);  // [rows][tp]  raw, zero outside the field
-  float* buf = tile + (size_t)rows * tp;          // [rows][BP]  after the f-pass
+  // taps first (16-byte aligned, padded to multiples of 4): broadcast LDS reads instead of one
+  // scalar-cache round trip per tap inside the filter loops
+  float* skf = reinterpret_cast<float*>(smem);       // [64]
+  float* skt = skf + 64;                             // [64]
+  float* sef = skt + 64;                             // [SMF_FB] conv(1) along f under zero padding
+  float* set_ = sef + SMF_FB;                        // [SMF_TT] conv(1) along t
+  float* tile = set_ + SMF_TT;                       // [rows][tp]  raw, zero outside the field
+  float* buf = tile + (size_t)rows * tp;             // [rows][BP]  after the f-pass
+  if (threadIdx.x < 64) {
+    skf[threadIdx.x] = (int)threadIdx.x <= 2 * nf ? kf[threadIdx.x] : 0.f;
+    skt[threadIdx.x] = (int)threadIdx.x <= 2 * nt ? kt[threadIdx.x] : 0.f;
+  }
   const int64_t u = blockIdx.z;
   const int64_t t0 = (int64_t)blockIdx.y * SMF_TT;
   const int f0 = blockIdx.x * SMF_FB;
+  if (threadIdx.x >= 64 && threadIdx.x < 64 + SMF_FB + SMF_TT) {
+    // edge factors of this tile, straight from the global taps (read again below through LDS)
+    const int j = threadIdx.x - 64;
+    float e = 0.f;
+    if (j < SMF_FB) {
+      const int f = f0 + j;
+      for (int a = -nf; a <= nf; ++a)
+        if (f + a >= 0 && f + a < g.F) e += kf[a + nf];
+      sef[j] = e;
+    } else {
+      const int64_t t = t0 + (j - SMF_FB);
+      for (int b = -nt; b <= nt; ++b)
+        if (t + b >= 0 && t + b < g.T) e += kt[b + nt];
+      set_[j - SMF_FB] = e;
+    }
+  }
   // tile load: ALL of a thread's global loads are issued before the first LDS store, so the block
   // pays one memory round trip instead of one per batch (the kernel is latency-bound otherwise)
   constexpr int LB = 32;
@@ -657,7 +708,7 @@ __global__ __launch_bounds__(256) void k_smooth_tiled(const float* __restrict__ 
 #pragma unroll 4
     for (int a = 0; a <= 2 * nf; ++a) {
       const float w3 = src[a + 3];
-      const float k = kf[a];
+      const float k = skf[a];
       a0 += k * w0; a1 += k * w1; a2 += k * w2; a3 += k * w3;
       w0 = w1; w1 = w2; w2 = w3;
     }
@@ -675,7 +726,7 @@ __global__ __launch_bounds__(256) void k_smooth_tiled(const float* __restrict__ 
 #pragma unroll 4
     for (int b = 0; b <= 2 * nt; ++b) {
       const float w3 = src[(size_t)(b + 3) * BP];
-      const float k = kt[b];
+      const float k = skt[b];
       a0 += k * w0; a1 += k * w1; a2 += k * w2; a3 += k * w3;
       w0 = w1; w1 = w2; w2 = w3;
     }
@@ -687,14 +738,7 @@ __global__ __launch_bounds__(256) void k_smooth_tiled(const float* __restrict__ 
       if (t >= g.T) break;
       float edge = 1.0f;
       // conv(1) under zero padding differs from 1 only within nf bins / nt frames of the border
-      if (prop_before && (f < nf || f >= g.F - nf || t < nt || t >= g.T - nt)) {
-        float ef = 0.f, et = 0.f;
-        for (int a = -nf; a <= nf; ++a)
-          if (f + a >= 0 && f + a < g.F) ef += kf[a + nf];
-        for (int b = -nt; b <= nt; ++b)
-          if (t + b >= 0 && t + b < g.T) et += kt[b + nt];
-        edge = ef * et;
-      }
+      if (prop_before && (f < nf || f >= g.F - nf || t < nt || t >= g.T - nt)) edge = sef[cidx] * set_[r0 + e];
       M[(u * g.T + t) * g.FS + f] = p * accs[e] + (1.0f - p) * edge;
     }
   }
