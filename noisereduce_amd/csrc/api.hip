@@ -192,7 +192,7 @@ static hipError_t launch_stft_n(const View& v, const Geom& g, int64_t units, con
   // n_fft = 8192 (N = 4096): the whole workgroup cooperates on one frame
   constexpr int NT = N >= 4096 ? 256 : 64;
   constexpr int WAVES = N >= 4096 ? 1 : ((N * sizeof(cx<TC>) > 16384) ? 2 : 4);
-  size_t lds = (size_t)(N + WAVES * N) * sizeof(cx<TC>);
+  size_t lds = (size_t)(N + WAVES * lpn<TC>(N)) * sizeof(cx<TC>);
   // few units (the noise clip): one frame per wave so that the grid still covers the chip
   const bool small = units * ((g.T + WAVES * 4 - 1) / (WAVES * 4)) < 1024;
   auto launch = [&](auto kern, int fpw) -> hipError_t {
@@ -234,7 +234,7 @@ static hipError_t launch_bits_n(const View& v, const Geom& g, int64_t units, con
                                 hipStream_t st) {
   constexpr int WAVES = (N * sizeof(cx<double>) > 16384) ? 2 : 4;
   constexpr int FPW = 4;
-  size_t lds = (size_t)(N + WAVES * N) * sizeof(cx<double>) + (size_t)(N + 1) * sizeof(double);
+  size_t lds = (size_t)(N + WAVES * lpn<double>(N)) * sizeof(cx<double>) + (size_t)(N + 1) * sizeof(double);
   auto kern = k_stft_bits<N, WAVES, FPW, MODE>;
   if (lds > 65536) {
     hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern),
@@ -269,7 +269,7 @@ static hipError_t launch_apply_n(const View& v, const Geom& g, int64_t units, co
   constexpr int NT = N >= 4096 ? 256 : 64;
   constexpr int WAVES = N >= 4096 ? 1 : ((N * sizeof(cx<float>) > 16384) ? 2 : 4);
   constexpr int FPW = 4;
-  size_t lds = (size_t)(N + WAVES * N) * sizeof(cx<float>);
+  size_t lds = (size_t)(N + WAVES * lpn<float>(N)) * sizeof(cx<float>);
   auto kern = k_apply_istft<N, WAVES, FPW, NT>;
   if (lds > 65536) {
     hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern),
@@ -310,7 +310,7 @@ static hipError_t launch_stft_czt_m(const View& v, const Geom& g, int64_t units,
                                     const void* wfull, double* P, float* mag, double* z, double zscale,
                                     hipStream_t st, unsigned long long* pmax_bits) {
   constexpr int NT = CztShape<M>::NT, FR = CztShape<M>::FR;
-  const size_t lds = (size_t)FR * M * sizeof(cx<TC>);
+  const size_t lds = (size_t)FR * lpn<TC>(M) * sizeof(cx<TC>);
   auto kern = k_stft_czt<TC, M, NT, FR>;
   if (lds > 65536) {
     hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern),
@@ -329,7 +329,7 @@ static hipError_t launch_apply_czt_m(const View& v, const Geom& g, int64_t units
                                      const float* wa, const float* ws, const float* Mk, float* seg,
                                      hipStream_t st) {
   constexpr int NT = CztShape<M>::NT, FR = CztShape<M>::FR;
-  const size_t lds = (size_t)FR * M * sizeof(cx<float>);
+  const size_t lds = (size_t)FR * lpn<float>(M) * sizeof(cx<float>);
   auto kern = k_apply_istft_czt<M, NT, FR>;
   if (lds > 65536) {
     hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern),

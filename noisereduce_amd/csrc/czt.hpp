@@ -27,7 +27,7 @@ template <typename TC, int M, int NT>
 __device__ __forceinline__ void czt_core(cx<TC>* buf, const CztTabs<TC>& tb, int tl) {
   SG_PASS_SYNC();
   wave_fft<TC, M, false, NT>(buf, tb.tw, tl);
-  for (int j = tl; j < M; j += NT) buf[j] = cmul(buf[j], tb.bhat[j]);
+  for (int j = tl; j < M; j += NT) buf[lp<TC>(j)] = cmul(buf[lp<TC>(j)], tb.bhat[j]);
   SG_PASS_SYNC();
   wave_fft<TC, M, true, NT>(buf, tb.tw, tl);
 }
@@ -41,7 +41,7 @@ __global__ __launch_bounds__(NT* FR) void k_stft_czt(View view, Geom g, CztTabs<
                                                      unsigned long long* __restrict__ pmax_bits, int fpb) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
   const int tl = threadIdx.x % NT, fr = threadIdx.x / NT;
-  cx<TC>* buf = reinterpret_cast<cx<TC>*>(smem) + (size_t)fr * M;
+  cx<TC>* buf = reinterpret_cast<cx<TC>*>(smem) + (size_t)fr * lpn<TC>(M);
   const int64_t u = blockIdx.y;
   const int64_t row = (view.unit0 + u) / view.n_chunks;
   const int64_t chunk = (view.unit0 + u) % view.n_chunks;
@@ -60,7 +60,7 @@ __global__ __launch_bounds__(NT* FR) void k_stft_czt(View view, Geom g, CztTabs<
         const cx<TC> c = tb.chirp[j];
         z = {xw * c.x, xw * c.y};
       }
-      buf[j] = z;
+      buf[lp<TC>(j)] = z;
     }
     czt_core<TC, M, NT>(buf, tb, tl);
     if (valid) {
@@ -69,7 +69,7 @@ __global__ __launch_bounds__(NT* FR) void k_stft_czt(View view, Geom g, CztTabs<
       for (int m = 0; m < VM; ++m) {
         const int k = tl + NT * m;
         if (k >= g.F) continue;
-        cx<TC> X = cmul(buf[k], tb.chirp[k]);
+        cx<TC> X = cmul(buf[lp<TC>(k)], tb.chirp[k]);
         // rfft of a real frame: bins 0 and n/2 are real (pocketfft returns exactly 0 there)
         if (k == 0 || 2 * k == g.n) X.y = (TC)0;
         const double Pk = (double)X.x * (double)X.x + (double)X.y * (double)X.y;
@@ -105,7 +105,7 @@ __global__ __launch_bounds__(NT* FR) void k_apply_istft_czt(View view, Geom g, C
                                                             int fpb) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
   const int tl = threadIdx.x % NT, fr = threadIdx.x / NT;
-  cx<float>* buf = reinterpret_cast<cx<float>*>(smem) + (size_t)fr * M;
+  cx<float>* buf = reinterpret_cast<cx<float>*>(smem) + (size_t)fr * lpn<float>(M);
   const int64_t u = blockIdx.y;
   const int64_t row = (view.unit0 + u) / view.n_chunks;
   const int64_t chunk = (view.unit0 + u) % view.n_chunks;
@@ -120,7 +120,7 @@ __global__ __launch_bounds__(NT* FR) void k_apply_istft_czt(View view, Geom g, C
         const cx<float> c = tb.chirp[j];
         z = {xw * c.x, xw * c.y};
       }
-      buf[j] = z;
+      buf[lp<float>(j)] = z;
     }
     czt_core<float, M, NT>(buf, tb, tl);
     // every thread rewrites its own entries: Y[k] = X[k] * m, restaged as conj(Y[k]) * chirp[k]
@@ -129,20 +129,20 @@ __global__ __launch_bounds__(NT* FR) void k_apply_istft_czt(View view, Geom g, C
       cx<float> z = {0.f, 0.f};
       if (valid && j < g.n) {
         const cx<float> c = tb.chirp[j];
-        cx<float> X = cmul(buf[j], c);
+        cx<float> X = cmul(buf[lp<float>(j)], c);
         const int kk = j < g.F ? j : g.n - j;
         const float m = Mrow[kk];
         if (j == 0 || 2 * j == g.n) X.y = 0.f;  // irfft ignores the imaginary part of DC / Nyquist
         const cx<float> Yc = {X.x * m, -X.y * m};
         z = cmul(Yc, c);
       }
-      buf[j] = z;
+      buf[lp<float>(j)] = z;
     }
     czt_core<float, M, NT>(buf, tb, tl);
     if (valid) {
       float* srow = seg + (u * g.T + t) * (int64_t)g.n;
       for (int j = tl; j < g.n; j += NT) {
-        const cx<float> D = cmul(buf[j], tb.chirp[j]);
+        const cx<float> D = cmul(buf[lp<float>(j)], tb.chirp[j]);
         srow[j] = D.x * win_s[j];
       }
     }

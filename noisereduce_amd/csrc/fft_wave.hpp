@@ -88,6 +88,21 @@ __device__ __forceinline__ void dftR(cx<T>* v) {
   else dft2<INV>(v);
 }
 
+// LDS index padding of the float64 transform buffers: one spare element after every 8.  The
+// Stockham passes scatter their outputs with strides of 8 / 64 elements; unpadded, the 16-byte
+// float64 elements of a wavefront land on the same few banks (128-byte stride: an 8-way conflict
+// per 16-lane pass).  With the padding a stride-8 access advances 9 elements = 36 banks per lane:
+// conflict-free.  float32 buffers stay unpadded (measured: padding costs them the 16-byte alignment
+// of element pairs and more than it gains).  Every user indexes its buffer through lp<T>().
+template <typename T>
+__device__ __forceinline__ int lp(int e) {
+  return sizeof(T) == 8 ? e + (e >> 3) : e;
+}
+template <typename T>
+constexpr int lpn(int n) {  // padded length of an n-element buffer
+  return sizeof(T) == 8 ? n + (n >> 3) : n;
+}
+
 // w_N^t from the master table (w_2N^k, k < N);  conjugated for the inverse transform.
 template <int N, bool INV, typename T>
 __device__ __forceinline__ cx<T> twN(const cx<T>* tw, int t) {
@@ -119,7 +134,7 @@ struct FftPass {
       int i = lane + NT * c;
       if (NB >= NT || i < NB) {
 #pragma unroll
-        for (int j = 0; j < R; ++j) v[c][j] = buf[i + j * NB];
+        for (int j = 0; j < R; ++j) v[c][j] = buf[lp<T>(i + j * NB)];
       }
     }
     SG_PASS_SYNC();
@@ -136,7 +151,7 @@ struct FftPass {
         }
         int o = base * R + q;
 #pragma unroll
-        for (int k = 0; k < R; ++k) buf[o + S * k] = v[c][k];
+        for (int k = 0; k < R; ++k) buf[lp<T>(o + S * k)] = v[c][k];
       }
     }
     SG_PASS_SYNC();

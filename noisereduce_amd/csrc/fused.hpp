@@ -117,10 +117,10 @@ __global__ __launch_bounds__(WAVES * 64) void k_stft_bits(View view, Geom g, con
   extern __shared__ __attribute__((aligned(16))) char smem[];
   cx<double>* tw = reinterpret_cast<cx<double>*>(smem);
   cx<double>* bufs = tw + N;
-  double* sT2 = reinterpret_cast<double*>(bufs + WAVES * N);  // [N+1] compare constants
+  double* sT2 = reinterpret_cast<double*>(bufs + WAVES * lpn<double>(N));  // [N+1] compare constants
   const int lane = threadIdx.x & 63;
   const int wave = threadIdx.x >> 6;
-  cx<double>* buf = bufs + wave * N;
+  cx<double>* buf = bufs + wave * lpn<double>(N);
   const int64_t u = blockIdx.y;
   const bool floor_live = tc.need_floor[u] != 0;
   if (MODE == 0 && !floor_live) return;  // whole block: uniform
@@ -152,7 +152,7 @@ __global__ __launch_bounds__(WAVES * 64) void k_stft_bits(View view, Geom g, con
         z.x = view_sample(view, row, chunk, s0 + 2 * j) * wfull[2 * j];
         z.y = view_sample(view, row, chunk, s0 + 2 * j + 1) * wfull[2 * j + 1];
       }
-      buf[j] = z;
+      buf[lp<double>(j)] = z;
     }
     SG_PASS_SYNC();
     wave_fft<double, N, false>(buf, tw, lane);
@@ -162,8 +162,8 @@ __global__ __launch_bounds__(WAVES * 64) void k_stft_bits(View view, Geom g, con
       const int k = lane + 64 * m;
       bool pred = false;
       if (k <= N) {
-        cx<double> a = buf[k == N ? 0 : k];
-        cx<double> b = buf[(k == 0 || k == N) ? 0 : N - k];
+        cx<double> a = buf[lp<double>(k == N ? 0 : k)];
+        cx<double> b = buf[lp<double>((k == 0 || k == N) ? 0 : N - k)];
         cx<double> w = tw[k == N ? 0 : k];
         cx<double> X = rfft_bin(a, b, w, k, N);
         double P = X.x * X.x + X.y * X.y;

@@ -81,7 +81,7 @@ __global__ __launch_bounds__(WAVES * NT) void k_stft(View view, Geom g, const cx
   cx<TC>* bufs = tw + N;
   const int lane = threadIdx.x % NT;  // thread within the frame's team (NT = 64: one wavefront)
   const int wave = threadIdx.x / NT;
-  cx<TC>* buf = bufs + wave * N;
+  cx<TC>* buf = bufs + wave * lpn<TC>(N);
   for (int i = threadIdx.x; i < N; i += WAVES * NT) tw[i] = tw_g[i];
   const int64_t u = blockIdx.y;
   const int64_t row = (view.unit0 + u) / view.n_chunks;
@@ -101,7 +101,7 @@ __global__ __launch_bounds__(WAVES * NT) void k_stft(View view, Geom g, const cx
         z.x = (TC)view_sample(view, row, chunk, s0 + 2 * j) * wfull[2 * j];
         z.y = (TC)view_sample(view, row, chunk, s0 + 2 * j + 1) * wfull[2 * j + 1];
       }
-      buf[j] = z;
+      buf[lp<TC>(j)] = z;
     }
     SG_PASS_SYNC();
     wave_fft<TC, N, false, NT>(buf, tw, lane);
@@ -111,8 +111,8 @@ __global__ __launch_bounds__(WAVES * NT) void k_stft(View view, Geom g, const cx
       for (int m = 0; m <= N / NT; ++m) {
         const int k = lane + NT * m;
         if (k > N) continue;
-        cx<TC> a = buf[k == N ? 0 : k];
-        cx<TC> b = buf[(k == 0 || k == N) ? 0 : N - k];
+        cx<TC> a = buf[lp<TC>(k == N ? 0 : k)];
+        cx<TC> b = buf[lp<TC>((k == 0 || k == N) ? 0 : N - k)];
         cx<TC> w = tw[k == N ? 0 : k];
         cx<TC> X = rfft_bin(a, b, w, k, N);
         const double Pk = (double)X.x * (double)X.x + (double)X.y * (double)X.y;
@@ -155,7 +155,7 @@ __global__ __launch_bounds__(WAVES * NT) void k_apply_istft(View view, Geom g, c
   cx<float>* bufs = tw + N;
   const int lane = threadIdx.x % NT;  // thread within the frame's team (NT = 64: one wavefront)
   const int wave = threadIdx.x / NT;
-  cx<float>* buf = bufs + wave * N;
+  cx<float>* buf = bufs + wave * lpn<float>(N);
   for (int i = threadIdx.x; i < N; i += WAVES * NT) tw[i] = tw_g[i];
   const int64_t u = blockIdx.y;
   const int64_t row = (view.unit0 + u) / view.n_chunks;
@@ -171,7 +171,7 @@ __global__ __launch_bounds__(WAVES * NT) void k_apply_istft(View view, Geom g, c
         z.x = (float)view_sample(view, row, chunk, s0 + 2 * j) * win_a[2 * j];
         z.y = (float)view_sample(view, row, chunk, s0 + 2 * j + 1) * win_a[2 * j + 1];
       }
-      buf[j] = z;
+      buf[lp<float>(j)] = z;
     }
     SG_PASS_SYNC();
     wave_fft<float, N, false, NT>(buf, tw, lane);
@@ -180,12 +180,12 @@ __global__ __launch_bounds__(WAVES * NT) void k_apply_istft(View view, Geom g, c
       const float* Mrow = M + (u * g.T + t) * g.FS;
       for (int k = lane; k <= N / 2; k += NT) {
         if (k == 0) {
-          cx<float> a = buf[0];
+          cx<float> a = buf[lp<float>(0)];
           float y0 = (a.x + a.y) * Mrow[0];
           float yN = (a.x - a.y) * Mrow[N];
-          buf[0] = {0.5f * (y0 + yN), 0.5f * (y0 - yN)};
+          buf[lp<float>(0)] = {0.5f * (y0 + yN), 0.5f * (y0 - yN)};
         } else {
-          cx<float> a = buf[k], b = buf[N - k];
+          cx<float> a = buf[lp<float>(k)], b = buf[lp<float>(N - k)];
           cx<float> w = tw[k];
           // X[k] = E + w O ; X[N-k] = conj(E) - conj(w) conj(O)
           cx<float> E = {(a.x + b.x) * 0.5f, (a.y - b.y) * 0.5f};
@@ -199,10 +199,10 @@ __global__ __launch_bounds__(WAVES * NT) void k_apply_istft(View view, Geom g, c
           cx<float> D = {(Yk.x - Yn.x) * 0.5f, (Yk.y + Yn.y) * 0.5f};
           cx<float> wc = {w.x, -w.y};
           cx<float> Op = cmul(D, wc);
-          buf[k] = {Ep.x - Op.y, Ep.y + Op.x};
+          buf[lp<float>(k)] = {Ep.x - Op.y, Ep.y + Op.x};
           if (k != N - k) {
             // Zc'[N-k] = conj(E') + i conj(O')  (E', O' are spectra of real sequences)
-            buf[N - k] = {Ep.x + Op.y, -Ep.y + Op.x};
+            buf[lp<float>(N - k)] = {Ep.x + Op.y, -Ep.y + Op.x};
           }
         }
       }
@@ -212,7 +212,7 @@ __global__ __launch_bounds__(WAVES * NT) void k_apply_istft(View view, Geom g, c
     if (valid) {
       float2* srow = reinterpret_cast<float2*>(seg + (u * g.T + t) * (int64_t)g.n);
       for (int j = lane; j < N; j += NT) {
-        cx<float> z = buf[j];
+        cx<float> z = buf[lp<float>(j)];
         srow[j] = make_float2(z.x * win_s[2 * j], z.y * win_s[2 * j + 1]);
       }
     }
