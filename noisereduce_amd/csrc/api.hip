@@ -533,7 +533,7 @@ extern "C" int sg_create(const sg_params* p, const double* window_host, sg_handl
       // the integer smoothing kernel holds (64 + 2 nt) rows of all F bins in LDS
       const int rows = SM2_TT + 2 * p->n_grad_time, wpr = (h->F + 63) / 64;
       const bool small = (p->n_grad_freq + 1) * (p->n_grad_freq + 1) <= 255;
-      const size_t lds = smooth2_cf_bytes(rows, h->F, small ? 1 : 2) + (size_t)rows * (wpr + 2) * 8 + 8192;
+      const size_t lds = smooth2_cf_bytes(rows + 2, h->F, small ? 1 : 2) + (size_t)rows * (wpr + 2) * 8 + 8192;
       if (lds > 150 * 1024 || p->n_grad_freq > 30) h->fused_ok = false;
     }
   }
@@ -874,7 +874,7 @@ static int stage_smooth_bits(sg_handle* h, const Geom& g, int64_t ub, bool fast,
     const int rows = SM2_TT + 2 * nt;
     const bool small = (nf + 1) * (nf + 1) <= 255;
     const unsigned long long* ftab = (small && h->ftab.p) ? (const unsigned long long*)h->ftab.p : nullptr;
-    size_t lds = smooth2_cf_bytes(rows, g.F, small ? 1 : 2) + (size_t)rows * (wpr + 2) * 8 + (ftab ? 8192 : 0);
+    size_t lds = smooth2_cf_bytes(rows + 2, g.F, small ? 1 : 2) + (size_t)rows * (wpr + 2) * 8 + (ftab ? 8192 : 0);
     dim3 grid((unsigned)((te - tb + SM2_TT - 1) / SM2_TT), (unsigned)ub);
     if (small) {
       auto kern = k_smooth_bits2<uint8_t>;

@@ -299,8 +299,10 @@ __global__ __launch_bounds__(SM2_THREADS) void k_smooth_bits2(const unsigned lon
   // on a dense row
   const int FP = smooth2_pitch(g.F);
   const int WP = wpr + 2;  // one zero word on each side of every bit row
-  CT* cf = reinterpret_cast<CT*>(smem);
-  unsigned long long* wb = reinterpret_cast<unsigned long long*>(smem + smooth2_cf_bytes(rows, g.F, sizeof(CT)));
+  CT* cf = reinterpret_cast<CT*>(smem);  // [rows + 2][FP]: two zero rows behind the tile (phase 2 reads them)
+  unsigned long long* wb =
+      reinterpret_cast<unsigned long long*>(smem + smooth2_cf_bytes(rows + 2, g.F, sizeof(CT)));
+  for (int i = threadIdx.x; i < 2 * FP; i += SM2_THREADS) cf[(size_t)rows * FP + i] = (CT)0;
   const int64_t u = blockIdx.y;
   const int64_t t0 = t_begin + (int64_t)blockIdx.x * SM2_TT;
   for (int i = threadIdx.x; i < rows * WP; i += SM2_THREADS) {
@@ -376,25 +378,30 @@ __global__ __launch_bounds__(SM2_THREADS) void k_smooth_bits2(const unsigned lon
   __syncthreads();
   }
   // ---- phase 2: along t, one output position per thread ------------------------------------
+  // The walk reads rows r - nt .. r + nt + 2 for r = nt .. nt + 63: never below row 0, at most two
+  // rows past the tile -- those two rows exist and are zero (cleared above), so no bounds checks
+  // (they were scalar compares/selects per read: the CU's one scalar unit was the bottleneck).
   for (int pos = threadIdx.x; pos < g.F; pos += SM2_THREADS) {
     const int f = perm ? fast::perm_inv(pos) : pos;
     const CT* col = cf + f + ((f >> 5) << 2);
-    auto at = [&](int r) -> int { return (r >= 0 && r < rows) ? (int)col[(size_t)r * FP] : 0; };
-    const int r0 = nt;  // LDS row of output frame t0
     int c = 0, R = 0, L = 0;
     for (int b = -nt; b <= nt + 1; ++b) {
-      const int x = at(r0 + b);
+      const int x = (int)col[(size_t)(nt + b) * FP];
       if (b <= nt) c += (nt + 1 - (b < 0 ? -b : b)) * x;
       if (b >= 1) R += x;
       if (b <= 0) L += x;
     }
     unsigned short* kout = K + (u * g.T + t0) * (int64_t)g.FS + pos;
     const int n_out = (int)min<int64_t>(SM2_TT, min<int64_t>(t_end, g.T) - t0);
+    const CT* pa = col + (size_t)(2 * nt + 2) * FP;  // row r + nt + 2
+    const CT* pb = col + (size_t)(nt + 1) * FP;      // row r + 1
+    const CT* pc = col;                              // row r - nt
 #pragma unroll 4
     for (int i = 0; i < n_out; ++i) {
-      const int r = r0 + i;
-      const int xa = at(r + nt + 2), xb = at(r + 1), xc = at(r - nt);
-      kout[(int64_t)i * g.FS] = (unsigned short)c;
+      const int xa = (int)*pa, xb = (int)*pb, xc = (int)*pc;
+      pa += FP; pb += FP; pc += FP;
+      *kout = (unsigned short)c;
+      kout += g.FS;
       c += R - L;
       R += xa - xb;
       L += xb - xc;
