@@ -11,7 +11,7 @@ accepted and ignored).  ``_do_filter`` stays the operator seam (base.py:158-160)
 import numpy as np
 import torch
 
-from noisereduce_amd import _ffi
+from noisereduce_amd import _ffi, _hostbuf
 
 
 def _triangle(m):
@@ -132,9 +132,10 @@ class SpectralGate:
             out = out_dev if out_dev.dtype == self._dtype else out_dev.to(self._dtype)
             return out.flatten() if self.flat else out
         if out_dev.dtype in _ffi._TORCH_DTYPES and _DEVICE_DTYPES.get(np.dtype(self._dtype)) == out_dev.dtype:
-            # straight DMA into the array we return (one allocation, no staging copy)
-            out = np.empty(tuple(out_dev.shape), dtype=self._dtype)
-            torch.from_numpy(out).copy_(out_dev)
+            # straight DMA into the array we return (no staging copy); the array is backed by a pooled
+            # page-locked buffer when one is available (_hostbuf.py)
+            out, out_t = _hostbuf.result_array(tuple(out_dev.shape), self._dtype)
+            out_t.copy_(out_dev)
         else:
             out = out_dev.cpu().numpy().astype(self._dtype, copy=False)
         return out.reshape(-1) if self.flat else out

@@ -495,3 +495,29 @@ def test_lean_apply_equals_full_slice_apply(nr):
     assert O.rel_err(a, b) < 1e-6
     want = O.reduce_noise_S(y.astype(np.float64), 48000, stationary=True, chunk_size=40000, padding=5000)
     assert O.rel_err(a, want) < TOL and O.rel_err(b, want) < TOL
+
+
+def test_result_buffer_pool(nr):
+    """numpy results live in pooled page-locked buffers (_hostbuf.py): a buffer must not be recycled
+    while any view of an earlier result is alive, and must be recycled afterwards."""
+    import gc
+    from noisereduce_amd import _hostbuf
+    y = O.synth_signal(600000, seed=3)
+    a = nr.reduce_noise(y=y, sr=48000, stationary=True)
+    keep = a[1000:2000]                      # a view keeps the whole buffer alive
+    snap = keep.copy()
+    del a
+    gc.collect()
+    outs = [nr.reduce_noise(y=O.synth_signal(600000, seed=10 + i), sr=48000, stationary=True) for i in range(6)]
+    assert np.array_equal(keep, snap)        # never overwritten by later results
+    assert all(o.flags.writeable and o.dtype == y.dtype and o.shape == y.shape for o in outs)
+    assert not any(np.shares_memory(outs[i], outs[j]) for i in range(6) for j in range(i))
+    live_before = _hostbuf.pool_stats()
+    del outs, keep
+    gc.collect()
+    st = _hostbuf.pool_stats()
+    assert sum(st["idle"].values()) >= 1 and st["total_bytes"] == live_before["total_bytes"]
+    b = nr.reduce_noise(y=y, sr=48000, stationary=True)   # served from the pool again
+    assert _hostbuf.pool_stats()["total_bytes"] == st["total_bytes"]
+    want = O.reduce_noise_S(y.astype(np.float64), 48000, stationary=True)
+    assert O.rel_err(b, want) < TOL
