@@ -1202,12 +1202,12 @@ extern "C" int sg_process_chunks(sg_handle* h, const void* in_dev, int in_dtype,
   int64_t units;
   if (chunked) {
     // base.py:175-216: chunks ich1..ich2, each filtered over [i*cs - pad, (i+1)*cs + pad)
+    // only the chunks that overlap [start_frame, end_frame) become units
     int64_t ich1 = start_frame / cs, ich2 = (end_frame - 1) / cs;
-    int64_t n_chunks = ich2 + 1;  // chunk index == unit % n_chunks; chunks < ich1 are skipped below
-    v.cs = cs; v.Lp = cs + 2 * pad; v.n_chunks = (int32_t)n_chunks;
+    int64_t n_chunks = ich2 - ich1 + 1;
+    v.cs = cs; v.Lp = cs + 2 * pad; v.n_chunks = (int32_t)n_chunks; v.c0 = ich1;
     om.p0 = pad; om.p1 = pad + cs; om.g_step = cs;
     units = C * n_chunks;
-    (void)ich1;  // units of chunks before ich1 write nothing (g_lo clips them); cheap enough for v1
   } else {
     // base.py:222: one window [-pad, end_frame + pad) -- start_frame is ignored by the reference
     v.cs = 0; v.Lp = end_frame + 2 * pad; v.n_chunks = 1;  // _read_chunk may read past end_frame (base.py:136-141)

@@ -44,7 +44,7 @@ __global__ __launch_bounds__(NT* FR) void k_stft_czt(View view, Geom g, CztTabs<
   cx<TC>* buf = reinterpret_cast<cx<TC>*>(smem) + (size_t)fr * lpn<TC>(M);
   const int64_t u = blockIdx.y;
   const int64_t row = (view.unit0 + u) / view.n_chunks;
-  const int64_t chunk = (view.unit0 + u) % view.n_chunks;
+  const int64_t chunk = view.c0 + (view.unit0 + u) % view.n_chunks;
   constexpr int VM = M / 4 / NT + 2;  // F <= M/4 + 1 bins, NT per sweep
   double vmax[VM];
 #pragma unroll
@@ -108,7 +108,7 @@ __global__ __launch_bounds__(NT* FR) void k_apply_istft_czt(View view, Geom g, C
   cx<float>* buf = reinterpret_cast<cx<float>*>(smem) + (size_t)fr * lpn<float>(M);
   const int64_t u = blockIdx.y;
   const int64_t row = (view.unit0 + u) / view.n_chunks;
-  const int64_t chunk = (view.unit0 + u) % view.n_chunks;
+  const int64_t chunk = view.c0 + (view.unit0 + u) % view.n_chunks;
   for (int fi = 0; fi < fpb; ++fi) {
     const int64_t t = ((int64_t)blockIdx.x * fpb + fi) * FR + fr;
     const bool valid = t < g.T;

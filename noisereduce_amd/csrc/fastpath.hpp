@@ -339,7 +339,7 @@ __global__ __launch_bounds__(WAVES * 64, LEAN ? 3 : 2) void k_apply_fast(ApplyAr
   const Geom& G = A.g;
   const int64_t u = blockIdx.y;
   const int64_t row = (A.view.unit0 + u) / A.view.n_chunks;
-  const int64_t chunk = (A.view.unit0 + u) % A.view.n_chunks;
+  const int64_t chunk = A.view.c0 + (A.view.unit0 + u) % A.view.n_chunks;
   // Tiles either overlap by 3 frames (each tile completes its NH hops on its own) or, in seam mode,
   // abut: then the 3 hops that straddle two tiles are written as un-normalised partial sums and
   // combined by k_ola_seam -- 3/16 fewer transforms.
@@ -691,7 +691,7 @@ __global__ __launch_bounds__(256) void k_ola_seam(ApplyArgs A) {
   const int64_t u = blockIdx.y;
   const int64_t b = blockIdx.x;
   const int64_t row = (A.view.unit0 + u) / A.view.n_chunks;
-  const int64_t chunk = (A.view.unit0 + u) % A.view.n_chunks;
+  const int64_t chunk = A.view.c0 + (A.view.unit0 + u) % A.view.n_chunks;
   const int s = threadIdx.x;
   const float* pa = A.part + ((u * A.n_tiles + b) * 6 + 3) * 256;      // trailing hops of tile b
   const float* pb = A.part + ((u * A.n_tiles + b + 1) * 6 + 0) * 256;  // leading hops of tile b+1
@@ -790,7 +790,7 @@ __global__ __launch_bounds__(WAVES * 64, 3) void k_decide_fast(DecideArgs A) {
   const Geom& G = A.g;
   const int64_t u = blockIdx.y;
   const int64_t row = (A.view.unit0 + u) / A.view.n_chunks;
-  const int64_t chunk = (A.view.unit0 + u) % A.view.n_chunks;
+  const int64_t chunk = A.view.c0 + (A.view.unit0 + u) % A.view.n_chunks;
   const bool floor_live = A.tc.need_floor[u] != 0;
 
   // effective compare constants (4x the raw-power constant: the split below works on 2X) as
@@ -1075,7 +1075,7 @@ __global__ __launch_bounds__(WAVES * 64, 3) void k_mag_fast(MagArgs A) {
   const Geom& G = A.g;
   const int64_t u = blockIdx.y;
   const int64_t row = (A.view.unit0 + u) / A.view.n_chunks;
-  const int64_t chunk = (A.view.unit0 + u) % A.view.n_chunks;
+  const int64_t chunk = A.view.c0 + (A.view.unit0 + u) % A.view.n_chunks;
   cf* fb = regions + wave * WAVE_CX_H + frame_base_h(g);
   __syncthreads();
   const int64_t tq = ((int64_t)blockIdx.x * WAVES + wave) * 4;

@@ -22,7 +22,7 @@ __global__ void k_unit_absmax(View view, int64_t n_units, unsigned* __restrict__
   // grid: (splits, units).  Non-negative floats order like their bit patterns.
   const int64_t u = blockIdx.y;
   const int64_t row = (view.unit0 + u) / view.n_chunks;
-  const int64_t chunk = (view.unit0 + u) % view.n_chunks;
+  const int64_t chunk = view.c0 + (view.unit0 + u) % view.n_chunks;
   float m = 0.f;
   // the unit's window clipped to the readable part of the row (everything else is zero)
   const int64_t g0 = chunk * view.cs - view.pad;
@@ -137,7 +137,7 @@ __global__ __launch_bounds__(WAVES * 64) void k_stft_bits(View view, Geom g, con
     }
   }
   const int64_t row = (view.unit0 + u) / view.n_chunks;
-  const int64_t chunk = (view.unit0 + u) % view.n_chunks;
+  const int64_t chunk = view.c0 + (view.unit0 + u) % view.n_chunks;
   __syncthreads();
   double vmax[N / 64 + 1];
 #pragma unroll

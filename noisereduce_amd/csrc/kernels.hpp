@@ -28,6 +28,7 @@ struct View {
   int64_t pad;      // zero/neighbour padding before the chunk start
   int64_t Lp;       // samples per unit window
   int32_t n_chunks; // units per row
+  int64_t c0;       // index of the row's first chunk (sub-range filtering: chunks c0 .. c0 + n_chunks - 1)
   int64_t unit0;    // global index of this batch's first unit (unit = row*n_chunks + chunk)
 };
 
@@ -85,7 +86,7 @@ __global__ __launch_bounds__(WAVES * NT) void k_stft(View view, Geom g, const cx
   for (int i = threadIdx.x; i < N; i += WAVES * NT) tw[i] = tw_g[i];
   const int64_t u = blockIdx.y;
   const int64_t row = (view.unit0 + u) / view.n_chunks;
-  const int64_t chunk = (view.unit0 + u) % view.n_chunks;
+  const int64_t chunk = view.c0 + (view.unit0 + u) % view.n_chunks;
   __syncthreads();
   double vmax[N / NT + 1];  // running max power of this lane's bins (pmax_bits != nullptr)
 #pragma unroll
@@ -159,7 +160,7 @@ __global__ __launch_bounds__(WAVES * NT) void k_apply_istft(View view, Geom g, c
   for (int i = threadIdx.x; i < N; i += WAVES * NT) tw[i] = tw_g[i];
   const int64_t u = blockIdx.y;
   const int64_t row = (view.unit0 + u) / view.n_chunks;
-  const int64_t chunk = (view.unit0 + u) % view.n_chunks;
+  const int64_t chunk = view.c0 + (view.unit0 + u) % view.n_chunks;
   __syncthreads();
   for (int fi = 0; fi < FPW; ++fi) {
     const int64_t t = ((int64_t)blockIdx.x * FPW + fi) * WAVES + wave;
@@ -239,7 +240,7 @@ __global__ void k_ola(View view, Geom g, OutMap om, const float* __restrict__ se
                       int normalize) {
   const int64_t u = blockIdx.y;
   const int64_t row = (view.unit0 + u) / view.n_chunks;
-  const int64_t chunk = (view.unit0 + u) % view.n_chunks;
+  const int64_t chunk = view.c0 + (view.unit0 + u) % view.n_chunks;
   const int64_t p = om.p0 + (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
   if (p >= om.p1) return;
   const int64_t gi = chunk * om.g_step + (p - om.p0);
