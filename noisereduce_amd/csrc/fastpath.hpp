@@ -187,6 +187,7 @@ __device__ __forceinline__ void fft512_inv(cf* v, cf* fb, const cf* tw512, int c
 // not need the slice afterwards (decision and magnitude kernels).
 constexpr int FPITCH_H = 256 + 16;
 constexpr int WAVE_CX_H = 4 * FPITCH_H;
+constexpr int HPITCH = 288;  // floats between the hop accumulators of a wave (k_apply_fast<LEAN>)
 __device__ __forceinline__ int frame_base_h(int g) { return g * FPITCH_H; }
 
 __device__ __forceinline__ void fft512_fwd_half(cf* v, cf* fb, const cf* tw512, int c) {
@@ -314,7 +315,7 @@ struct ApplyArgs {
 // 4 KB of stored frame per frame: 38 KB of LDS per workgroup and <= 168 VGPRs -> 3 waves per SIMD.
 // SG_ABLATE (development only, default 0): bit mask that removes one ingredient of k_apply_fast to
 // measure what it costs (results are wrong): 1 mask loads, 2 window loads, 4 output stores,
-// 8 both transforms, 16 input loads.  tools/ablate.sh builds and times the variants.
+// 8 both transforms, 16 input loads, 32 pair stage, 64 wave-private overlap-add.  tools/ablate.sh builds and times the variants.
 #ifndef SG_ABLATE
 #define SG_ABLATE 0
 #endif
@@ -501,7 +502,7 @@ __global__ __launch_bounds__(WAVES * 64, LEAN ? 3 : 2) void k_apply_fast(ApplyAr
   // split -> mask -> merge on conjugate pairs, all in this lane.  One instruction stream for all
   // lanes: lane 0 (self-paired rows 0 and 16) only differs in WHICH registers form a pair, handled
   // with v_cndmask selects on the way in and out (a divergent branch would run the stage twice).
-  {
+  if constexpr ((SG_ABLATE & 32) == 0) {
     const float ks = A.kscale * 0.25f;  // pair_mask leaves out four 1/2 factors
     const bool l0 = c == 0;
     const cf wlo = A.tw1024[c];                         // w_1024^c   (lane 0: 1)
@@ -567,14 +568,17 @@ __global__ __launch_bounds__(WAVES * 64, LEAN ? 3 : 2) void k_apply_fast(ApplyAr
     // exchange slices).  Step j: every frame adds its quarter j -> frame g touches hop g + j: the four
     // lane groups never collide within a step, and a hop receives its quarters in the fixed order
     // j = 0, 1, 2, 3 (LDS operations of a wave execute in order) -> deterministic sums.
+    // (hop pitch 288 floats: the two lane groups of a ds_read_b64 pass, frames g and g + 1, then hit
+    // disjoint bank halves)
     float* acc = reinterpret_cast<float*>(regions + wave * WAVE_CX_H);
+    static_assert(7 * HPITCH <= WAVE_CX_H * 2, "hop accumulators must fit the wave's exchange slices");
 #pragma unroll
-    for (int j = 0; j < 4; ++j) {
+    for (int j = 0; j < ((SG_ABLATE & 64) ? 0 : 4); ++j) {
       const bool first = (j == 0) || (g == 3);  // first contribution to hop g + j: plain store
 #pragma unroll
       for (int rr = 0; rr < 8; ++rr) {
         const int r = 8 * j + rr;
-        float2* dst = reinterpret_cast<float2*>(acc + (g + j) * 256 + 2 * c + 32 * rr);
+        float2* dst = reinterpret_cast<float2*>(acc + (g + j) * HPITCH + 2 * c + 32 * rr);
         float2 old = *dst;
         float2 nw = {v[r].x * wsyn[r].x, v[r].y * wsyn[r].y};
         if (!first) { nw.x += old.x; nw.y += old.y; }
@@ -612,11 +616,11 @@ __global__ __launch_bounds__(WAVES * 64, LEAN ? 3 : 2) void k_apply_fast(ApplyAr
       // wave before it (local hop jj%4 + 4); fixed order: earlier wave first
       const int wh = jj >> 2, lh = jj & 3;
       if (wh >= 1 && wh - 1 < WAVES && lh <= 2) {
-        float4 f4 = *reinterpret_cast<const float4*>(&fr[(wh - 1) * WAVE_CX_H * 2 + (lh + 4) * 256 + s4]);
+        float4 f4 = *reinterpret_cast<const float4*>(&fr[(wh - 1) * WAVE_CX_H * 2 + (lh + 4) * HPITCH + s4]);
         acc = f4;
       }
       if (wh < WAVES) {
-        float4 f4 = *reinterpret_cast<const float4*>(&fr[wh * WAVE_CX_H * 2 + lh * 256 + s4]);
+        float4 f4 = *reinterpret_cast<const float4*>(&fr[wh * WAVE_CX_H * 2 + lh * HPITCH + s4]);
         acc.x += f4.x; acc.y += f4.y; acc.z += f4.z; acc.w += f4.w;
       }
     } else {
