@@ -636,9 +636,12 @@ __global__ void k_smooth_t(const float* __restrict__ tmp, Geom g, const float* _
 // LDS-tiled version of k_smooth_f + k_smooth_t: one block = TT frames x FB bins of one unit.
 // raw tile (+halo) -> LDS, f-pass LDS -> LDS, t-pass LDS -> global.  Each thread produces FOUR
 // adjacent outputs along the filter axis from a sliding register window (one LDS read per tap per
-// four outputs); taps come through the scalar cache.  LDS pitches are odd: the f-pass walks
+// four outputs); taps and per-tile edge factors sit in LDS.  LDS pitches are odd: the f-pass walks
 // rows with consecutive lanes, the t-pass walks bins with consecutive lanes -- both conflict-free.
-constexpr int SMF_TT = 32, SMF_FB = 128;
+// The kernel is latency-bound (one global round trip per block, then LDS work): the tile is sized
+// for occupancy -- 64 x 64 outputs = 46 KB of LDS at the 48 kHz default (3 blocks/CU); 32 x 128
+// (54 KB, 2 blocks/CU) was 1.6x slower, smaller tiles pay too much halo.
+constexpr int SMF_TT = 64, SMF_FB = 64;
 
 __global__ __launch_bounds__(256) void k_smooth_tiled(const float* __restrict__ raw, Geom g,
                                                       const float* __restrict__ kf, int nf,
