@@ -519,26 +519,25 @@ __global__ __launch_bounds__(64 * IIR_NSEG) void k_iir_sigmoid_seg(const float* 
   double carry = on ? (double)a[0] : 0.0;  // s[-1] = A[0]  (lfilter_zi steady state)
   for (int k = 0; k < seg; ++k) carry = s_end[k][l] + s_pow[k] * carry;
   double s = carry;
+  // the backward recurrence's zero-state response of this segment, s_back[ts] = sum_t b c^(t-ts) fw[t],
+  // is a weighted sum of the forward values: accumulated here in forward order (saves one pass over r)
+  e = 0.0;
   if (on) {
+    double pw = b;
 #pragma unroll 8
     for (int64_t t = ts; t < te; ++t) {
       s = b * (double)a[t * g.FS] + c * s;
-      r[t * g.FS] = (float)s;
+      const float sf = (float)s;
+      r[t * g.FS] = sf;
+      // the backward pass reads the ROUNDED forward value, except the exact last one (seed)
+      e += pw * ((t == g.T - 1) ? s : (double)sf);
+      pw *= c;
     }
   }
   if (seg == IIR_NSEG - 1) s_seed[l] = s;  // exact forward value at T-1
-  __syncthreads();
+  __syncthreads();  // s_end (forward carries) fully consumed, s_seed visible
   // ---- backward on the forward output ----
   const double seed = s_seed[l];
-  e = 0.0;
-  if (on) {
-#pragma unroll 8
-    for (int64_t t = te - 1; t >= ts; --t) {
-      double fw = (t == g.T - 1) ? seed : (double)r[t * g.FS];
-      e = b * fw + c * e;
-    }
-  }
-  __syncthreads();  // s_end is reused
   s_end[seg][l] = e;
   __syncthreads();
   carry = seed;  // backward pass is seeded with the forward pass's last value
