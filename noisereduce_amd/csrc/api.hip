@@ -772,7 +772,7 @@ static int stage_nonstat_raw(sg_handle* h, const View& v, const Geom& g, int64_t
     M.tw512 = (const fast::cf*)h->tw512.p;
     M.tw1024 = (const fast::cf*)h->tw32.p;
     M.mag = mag;
-    size_t lds = (size_t)(fast::FN + WAVES * fast::WAVE_CX_H) * sizeof(fast::cf);
+    size_t lds = (size_t)(fast::FN + WAVES * fast::WAVE_CX_H) * sizeof(fast::cf) + 1024 * sizeof(float);
     auto kern = fast::k_mag_fast<WAVES>;
     HIPCHK(h, hipFuncSetAttribute(reinterpret_cast<const void*>(kern),
                                   hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));

@@ -1081,20 +1081,57 @@ __global__ __launch_bounds__(WAVES * 64, 3) void k_mag_fast(MagArgs A) {
   const int64_t row = (A.view.unit0 + u) / A.view.n_chunks;
   const int64_t chunk = A.view.c0 + (A.view.unit0 + u) % A.view.n_chunks;
   cf* fb = regions + wave * WAVE_CX_H + frame_base_h(g);
+  // window table and (interior blocks of float32 input) the block's contiguous sample span in LDS, as
+  // in k_apply_fast / k_decide_fast
+  float* swin = reinterpret_cast<float*>(regions + WAVES * WAVE_CX_H);
+  for (int i = tid; i < 256; i += WAVES * 64)
+    reinterpret_cast<float4*>(swin)[i] = reinterpret_cast<const float4*>(A.win)[i];
+  constexpr int NFB = 4 * WAVES, SPAN = (NFB - 1) * 256 + 1024, XPITCH = 288;
+  const int64_t tqb = (int64_t)blockIdx.x * NFB;
+  bool blk_in;
+  {
+    const int64_t s0b = tqb * 256 - G.padL;
+    const int64_t gb = chunk * A.view.cs - A.view.pad + s0b;
+    blk_in = A.view.dtype == 0 && tqb + NFB <= G.T && s0b >= 0 && s0b + SPAN <= A.view.Lp &&
+             gb >= A.view.lo && gb + SPAN <= A.view.hi;
+    if (blk_in) {
+      const float* sp = (const float*)A.view.x + row * A.view.stride + gb;
+      float* xs = reinterpret_cast<float*>(regions);
+      if ((reinterpret_cast<uintptr_t>(sp) & 15) == 0) {
+        for (int i = tid; i < SPAN / 4; i += WAVES * 64) {
+          const float4 q = reinterpret_cast<const float4*>(sp)[i];
+          const int e = 4 * i;
+          *reinterpret_cast<float4*>(&xs[(e >> 8) * XPITCH + (e & 255)]) = q;
+        }
+      } else {
+        for (int i = tid; i < SPAN; i += WAVES * 64) xs[(i >> 8) * XPITCH + (i & 255)] = sp[i];
+      }
+    }
+  }
   __syncthreads();
-  const int64_t tq = ((int64_t)blockIdx.x * WAVES + wave) * 4;
-  if (tq >= G.T) return;
+  const int64_t tq = tqb + wave * 4;
+  if (!blk_in && tq >= G.T) return;
   const int64_t t = tq + g;
   const bool fvalid = t < G.T;
   cf v[32];
-  {
+  if (blk_in) {
+    const float* xs = reinterpret_cast<const float*>(regions) + (4 * wave + g) * XPITCH + 2 * c;
+    const float2* wl2 = reinterpret_cast<const float2*>(swin + 2 * c);
+#pragma unroll
+    for (int r = 0; r < 32; ++r) {
+      const float2 x2 = *reinterpret_cast<const float2*>(xs + (r >> 3) * XPITCH + 32 * (r & 7));
+      const float2 w2 = wl2[16 * r];
+      v[r] = {x2.x * w2.x, x2.y * w2.y};
+    }
+    __syncthreads();  // the span may now be overwritten by the exchanges
+  } else {
     const int64_t s0 = t * 256 - G.padL;
     const int64_t gbase = chunk * A.view.cs - A.view.pad + s0;
     const bool inside = fvalid && s0 >= 0 && s0 + 1024 <= A.view.Lp && gbase >= A.view.lo &&
                         gbase + 1024 <= A.view.hi && A.view.dtype == 0;
     const float* src = (const float*)A.view.x + row * A.view.stride + gbase + 2 * c;
     const bool aligned = (reinterpret_cast<uintptr_t>(src) & 7) == 0;
-    const float2* wsrc = reinterpret_cast<const float2*>(A.win + 2 * c);
+    const float2* wsrc = reinterpret_cast<const float2*>(swin + 2 * c);
     if (inside && aligned) {
       const float2* s2 = reinterpret_cast<const float2*>(src);
 #pragma unroll
