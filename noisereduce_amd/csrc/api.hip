@@ -264,6 +264,39 @@ static hipError_t launch_bits(int N, const View& v, const Geom& g, int64_t units
 }
 
 template <int N>
+static hipError_t launch_decide_lds_n(const sg_handle* h, const View& v, const Geom& g, int64_t units,
+                                      const ThreshConsts& tc, unsigned long long* bits, int wpr, hipStream_t st) {
+  constexpr int WAVES = (N * sizeof(cx<float>) > 8192) ? 2 : 4;
+  constexpr int FPW = 4;
+  const size_t lds = (size_t)(N + WAVES * N) * sizeof(cx<float>) + (size_t)(N + 1) * sizeof(float);
+  auto kern = k_decide_lds<N, WAVES, FPW>;
+  if (lds > 65536) {
+    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern),
+                                       hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    if (e != hipSuccess) return e;
+  }
+  dim3 grid((unsigned)((g.T + WAVES * FPW - 1) / (WAVES * FPW)), (unsigned)units);
+  hipLaunchKernelGGL(kern, grid, dim3(WAVES * 64), lds, st, v, g, (const cx<float>*)h->tw32.p,
+                     (const float*)h->wa32.p, (const cx<double>*)h->tw64.p, (const double*)h->wfull64.p, tc,
+                     h->mag_scale, h->p.top_db, bits, wpr);
+  return hipGetLastError();
+}
+
+static hipError_t launch_decide_lds(const sg_handle* h, const View& v, const Geom& g, int64_t units,
+                                    const ThreshConsts& tc, unsigned long long* bits, int wpr, hipStream_t st) {
+  switch (h->N) {
+    case 32: return launch_decide_lds_n<32>(h, v, g, units, tc, bits, wpr, st);
+    case 64: return launch_decide_lds_n<64>(h, v, g, units, tc, bits, wpr, st);
+    case 128: return launch_decide_lds_n<128>(h, v, g, units, tc, bits, wpr, st);
+    case 256: return launch_decide_lds_n<256>(h, v, g, units, tc, bits, wpr, st);
+    case 512: return launch_decide_lds_n<512>(h, v, g, units, tc, bits, wpr, st);
+    case 1024: return launch_decide_lds_n<1024>(h, v, g, units, tc, bits, wpr, st);
+    case 2048: return launch_decide_lds_n<2048>(h, v, g, units, tc, bits, wpr, st);
+  }
+  return hipErrorInvalidValue;
+}
+
+template <int N>
 static hipError_t launch_apply_n(const View& v, const Geom& g, int64_t units, const void* tw, const float* wa,
                                  const float* ws, const float* M, float* seg, hipStream_t st) {
   constexpr int NT = N >= 4096 ? 256 : 64;
@@ -978,6 +1011,10 @@ static int stage_fused_mask(sg_handle* h, const View& v, const Geom& g, int64_t 
     dim3 grid((unsigned)((quads + per_block - 1) / per_block), (unsigned)ub);
     hipLaunchKernelGGL(kern, grid, dim3(WAVES * 64), lds, st, D);
     HIPCHK(h, hipGetLastError());
+  } else if (!h->force_f64_decide) {
+    // other power-of-two frame lengths: float32 LDS transform + exact refinement
+    ProfScope ps(h, SG_STAGE_STFT_BITS, st);
+    HIPCHK(h, launch_decide_lds(h, v, g, ub, tc, (unsigned long long*)h->bits.p, wpr, st));
   } else {
     ProfScope ps(h, SG_STAGE_STFT_BITS, st);
     HIPCHK(h, launch_bits<1>(h->N, v, g, ub, h->tw64.p, h->wfull64.p, tc, h->mag_scale, h->p.top_db,

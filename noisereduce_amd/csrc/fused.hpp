@@ -187,6 +187,122 @@ __global__ __launch_bounds__(WAVES * 64) void k_stft_bits(View view, Geom g, con
 }
 
 // ---------------------------------------------------------------------------------------
+// float32 STFT + decision with exact refinement, any power-of-two n_fft (the default geometry has
+// its own register-resident version, fast::k_decide_fast).  |X|^2 comes from the float32 LDS
+// Stockham core; a cell is AMBIGUOUS when the float32 value cannot be told from the compare constant:
+//     | |X| - sqrt(T2) | <= delta,   delta = 2^-16 * || window * frame ||_2
+// (>= 20x the error bound of a float32 FFT of up to 4096 points), tested without square roots as
+// (P - T2)^2 <= 2 delta^2 (P + T2).  Ambiguous cells (~1e-5 of all) are re-evaluated exactly: the
+// whole wavefront sums the n-term float64 DFT of that bin.  The bits are therefore identical to those
+// of the float64 kernel k_stft_bits<MODE 1> (checked by tests/test_gpu_parity.py).
+// ---------------------------------------------------------------------------------------
+template <int N, int WAVES, int FPW>
+__global__ __launch_bounds__(WAVES * 64) void k_decide_lds(View view, Geom g, const cx<float>* __restrict__ tw_g,
+                                                           const float* __restrict__ win32,
+                                                           const cx<double>* __restrict__ tw64,
+                                                           const double* __restrict__ win64, ThreshConsts tc,
+                                                           double mag_scale, double top_db,
+                                                           unsigned long long* __restrict__ bits, int wpr) {
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  cx<float>* tw = reinterpret_cast<cx<float>*>(smem);
+  cx<float>* bufs = tw + N;
+  float* sT2 = reinterpret_cast<float*>(bufs + WAVES * N);  // [N+1] compare constants (float32)
+  const int lane = threadIdx.x & 63;
+  const int wave = threadIdx.x >> 6;
+  cx<float>* buf = bufs + wave * N;
+  const int64_t u = blockIdx.y;
+  const bool floor_live = tc.need_floor[u] != 0;
+  auto t2eff = [&](int k) -> double {  // exact compare constant of band k (-1: every cell passes)
+    double t2 = tc.T2[k];
+    if (floor_live) {
+      const double fl = cell_db(tc.pmax[u * g.FS + k], mag_scale) - top_db;
+      if (fl > tc.thresh[k]) t2 = -1.0;
+    }
+    return t2;
+  };
+  for (int i = threadIdx.x; i < N; i += WAVES * 64) tw[i] = tw_g[i];
+  for (int i = threadIdx.x; i <= N; i += WAVES * 64) {
+    const double t2 = t2eff(i);
+    // "every cell passes" as a huge negative constant: P - T > 0 and the ambiguity test fails by itself
+    sT2[i] = t2 < 0.0 ? -3.0e38f : (float)t2;
+  }
+  const int64_t row = (view.unit0 + u) / view.n_chunks;
+  const int64_t chunk = view.c0 + (view.unit0 + u) % view.n_chunks;
+  __syncthreads();
+  for (int fi = 0; fi < FPW; ++fi) {
+    const int64_t t = ((int64_t)blockIdx.x * FPW + fi) * WAVES + wave;
+    const bool valid = t < g.T;
+    const int64_t s0 = t * g.H - g.padL;
+    float nrm2 = 0.f;
+    const float* fp = valid ? frame_ptr_f32(view, row, chunk, s0, 2 * N) : nullptr;  // wave-uniform
+    if (fp) {
+      for (int j = lane; j < N; j += 64) {
+        const cx<float> z = {fp[2 * j] * win32[2 * j], fp[2 * j + 1] * win32[2 * j + 1]};
+        nrm2 += z.x * z.x + z.y * z.y;
+        buf[j] = z;
+      }
+    } else {
+      for (int j = lane; j < N; j += 64) {
+        cx<float> z = {0.f, 0.f};
+        if (valid) {
+          z.x = (float)view_sample(view, row, chunk, s0 + 2 * j) * win32[2 * j];
+          z.y = (float)view_sample(view, row, chunk, s0 + 2 * j + 1) * win32[2 * j + 1];
+        }
+        nrm2 += z.x * z.x + z.y * z.y;
+        buf[j] = z;
+      }
+    }
+    for (int off = 32; off > 0; off >>= 1) nrm2 += __shfl_xor(nrm2, off);
+    // 2 delta^2 = 2 * 2^-32 * nrm2; a silent frame (nrm2 == 0) has no ambiguous cells
+    const float d2 = nrm2 > 0.f ? 2.0f * 2.3283064e-10f * nrm2 : -1.0f;
+    SG_PASS_SYNC();
+    wave_fft<float, N, false>(buf, tw, lane);
+    unsigned long long* brow = bits + ((u * g.T + t) * (int64_t)wpr);
+#pragma unroll
+    for (int m = 0; m <= N / 64; ++m) {
+      const int k = lane + 64 * m;
+      bool pred = false, amb = false;
+      if (k <= N) {
+        const cx<float> a = buf[k == N ? 0 : k];
+        const cx<float> b = buf[(k == 0 || k == N) ? 0 : N - k];
+        const cx<float> w = tw[k == N ? 0 : k];
+        const cx<float> X = rfft_bin(a, b, w, k, N);
+        const float P = X.x * X.x + X.y * X.y;
+        const float T = sT2[k];
+        const float diff = P - T;
+        pred = diff > 0.f;
+        amb = valid && diff * diff <= d2 * (P + T);
+      }
+      // exact re-evaluation, one cell at a time, whole wave cooperating (wave-uniform loop)
+      unsigned long long pending = __ballot(amb);
+      while (pending) {
+        const int src = __ffsll((long long)pending) - 1;
+        pending &= pending - 1;
+        const int ks = src + 64 * m;
+        double re = 0.0, im = 0.0;
+        for (int i = lane; i < 2 * N; i += 64) {
+          const double xv = view_sample(view, row, chunk, s0 + i) * win64[i];
+          const int j = (int)(((int64_t)ks * i) & (2 * N - 1));
+          cx<double> w = tw64[j & (N - 1)];
+          if (j >= N) { w.x = -w.x; w.y = -w.y; }
+          re += xv * w.x;
+          im += xv * w.y;
+        }
+        for (int off = 32; off > 0; off >>= 1) {
+          re += __shfl_xor(re, off);
+          im += __shfl_xor(im, off);
+        }
+        const bool pass = re * re + im * im > t2eff(ks);
+        if (lane == src) pred = pass;
+      }
+      const unsigned long long word = __ballot(pred);
+      if (valid && lane == 0) brow[m] = word;
+    }
+    SG_PASS_SYNC();
+  }
+}
+
+// ---------------------------------------------------------------------------------------
 // Integer mask smoothing.  K[t][f] = sum_{a,b} vf[a] vt[b] bit[t+b][f+a], vf/vt the integer
 // triangles [1..m+1..1] (base.py:7-29 times (m+1)), zero outside the unit's (F, T) field
 // (fftconvolve mode="same", stationary.py:114).  Exact: K <= (nf+1)^2 (nt+1)^2 <= 65535.

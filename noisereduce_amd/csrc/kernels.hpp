@@ -54,6 +54,17 @@ __device__ __forceinline__ double view_sample(const View& v, int64_t row, int64_
   return load_sample(v.x, v.dtype, row * v.stride + g);
 }
 
+// Start of the `len` samples [s0, s0 + len) of a unit window when they are all readable float32
+// samples (no zero padding, no conversion), else nullptr: frames take the direct-load path in the
+// interior and the checked per-sample path (view_sample) at the edges / for other dtypes.
+__device__ __forceinline__ const float* frame_ptr_f32(const View& v, int64_t row, int64_t chunk, int64_t s0,
+                                                      int64_t len) {
+  if (v.dtype != 0 || s0 < 0 || s0 + len > v.Lp) return nullptr;
+  const int64_t g = chunk * v.cs - v.pad + s0;
+  if (g < v.lo || g + len > v.hi) return nullptr;
+  return (const float*)v.x + row * v.stride + g;
+}
+
 __device__ __forceinline__ void store_sample(void* p, int dtype, int64_t idx, float val) {
   switch (dtype) {
     case 0: ((float*)p)[idx] = val; break;
@@ -96,13 +107,19 @@ __global__ __launch_bounds__(WAVES * NT) void k_stft(View view, Geom g, const cx
     const bool valid = t < g.T;
     // gather window * frame as complex pairs (x[2j], x[2j+1])
     const int64_t s0 = t * g.H - g.padL;
-    for (int j = lane; j < N; j += NT) {
-      cx<TC> z = {(TC)0, (TC)0};
-      if (valid) {
-        z.x = (TC)view_sample(view, row, chunk, s0 + 2 * j) * wfull[2 * j];
-        z.y = (TC)view_sample(view, row, chunk, s0 + 2 * j + 1) * wfull[2 * j + 1];
+    const float* fp = valid ? frame_ptr_f32(view, row, chunk, s0, 2 * N) : nullptr;  // team-uniform
+    if (fp) {
+      for (int j = lane; j < N; j += NT)
+        buf[lp<TC>(j)] = {(TC)fp[2 * j] * wfull[2 * j], (TC)fp[2 * j + 1] * wfull[2 * j + 1]};
+    } else {
+      for (int j = lane; j < N; j += NT) {
+        cx<TC> z = {(TC)0, (TC)0};
+        if (valid) {
+          z.x = (TC)view_sample(view, row, chunk, s0 + 2 * j) * wfull[2 * j];
+          z.y = (TC)view_sample(view, row, chunk, s0 + 2 * j + 1) * wfull[2 * j + 1];
+        }
+        buf[lp<TC>(j)] = z;
       }
-      buf[lp<TC>(j)] = z;
     }
     SG_PASS_SYNC();
     wave_fft<TC, N, false, NT>(buf, tw, lane);
@@ -166,13 +183,19 @@ __global__ __launch_bounds__(WAVES * NT) void k_apply_istft(View view, Geom g, c
     const int64_t t = ((int64_t)blockIdx.x * FPW + fi) * WAVES + wave;
     const bool valid = t < g.T;
     const int64_t s0 = t * g.H - g.padL;
-    for (int j = lane; j < N; j += NT) {
-      cx<float> z = {0.f, 0.f};
-      if (valid) {
-        z.x = (float)view_sample(view, row, chunk, s0 + 2 * j) * win_a[2 * j];
-        z.y = (float)view_sample(view, row, chunk, s0 + 2 * j + 1) * win_a[2 * j + 1];
+    const float* fp = valid ? frame_ptr_f32(view, row, chunk, s0, 2 * N) : nullptr;  // team-uniform
+    if (fp) {
+      for (int j = lane; j < N; j += NT)
+        buf[lp<float>(j)] = {fp[2 * j] * win_a[2 * j], fp[2 * j + 1] * win_a[2 * j + 1]};
+    } else {
+      for (int j = lane; j < N; j += NT) {
+        cx<float> z = {0.f, 0.f};
+        if (valid) {
+          z.x = (float)view_sample(view, row, chunk, s0 + 2 * j) * win_a[2 * j];
+          z.y = (float)view_sample(view, row, chunk, s0 + 2 * j + 1) * win_a[2 * j + 1];
+        }
+        buf[lp<float>(j)] = z;
       }
-      buf[lp<float>(j)] = z;
     }
     SG_PASS_SYNC();
     wave_fft<float, N, false, NT>(buf, tw, lane);

@@ -234,8 +234,9 @@ def test_silence_and_constant_inputs(nr):
     assert out.shape == z.shape
 
 
+@pytest.mark.parametrize("n_fft", [1024, 512, 2048, 256])
 @pytest.mark.parametrize("kind", ["noise_tone", "pure_tone", "steps"])
-def test_fast_decide_bits_equal_f64_decide(nr, kind):
+def test_fast_decide_bits_equal_f64_decide(nr, kind, n_fft):
     """The float32 + exact-refine decision kernel must produce the SAME mask bits as the
     float64 STFT decision, including on inputs built to sit on the threshold (a steady tone:
     every cell of the tone bands has dB ~= mean = threshold)."""
@@ -253,7 +254,7 @@ def test_fast_decide_bits_equal_f64_decide(nr, kind):
         y = np.where((np.arange(n) // 7000) % 2 == 0, 0.0, 1.0) * (0.3 * rng.standard_normal(n))
     y = y.astype(np.float32)
     kw = dict(sr=48000, y_noise=None, prop_decrease=1.0, n_std_thresh_stationary=1.5,
-              chunk_size=50000, clip_noise_stationary=True, padding=6000, n_fft=1024, win_length=None,
+              chunk_size=50000, clip_noise_stationary=True, padding=6000, n_fft=n_fft, win_length=None,
               hop_length=None, time_constant_s=2.0, freq_mask_smooth_hz=500, time_mask_smooth_ms=50,
               tmp_folder=None, use_tqdm=False, n_jobs=1)
     sg = SpectralGateStationary(y=y, **kw)
@@ -269,7 +270,8 @@ def test_fast_decide_bits_equal_f64_decide(nr, kind):
     assert bits_fast.shape == bits_f64.shape and d1 - d0 > 100
     assert np.count_nonzero(bits_fast[:, d0:d1] != bits_f64[:, d0:d1]) == 0
     assert np.array_equal(out_fast, out_f64)
-    want = O.reduce_noise_S(y.astype(np.float64), 48000, stationary=True, chunk_size=50000, padding=6000)
+    want = O.reduce_noise_S(y.astype(np.float64), 48000, stationary=True, chunk_size=50000, padding=6000,
+                            n_fft=n_fft)
     assert O.rel_err(out_fast, want) < 2e-4 if kind == "pure_tone" else O.rel_err(out_fast, want) < TOL
 
 
