@@ -1016,33 +1016,36 @@ __global__ __launch_bounds__(WAVES * 64, 3) void k_decide_fast(DecideArgs A) {
     }
     if (l0)  // entry -> register: e 0..7 -> 0..7, 8..23 -> 16..31, 24..30 -> 9..15, 31 -> 8
       pred = (pred & 0xffu) | ((pred & 0x00ffff00u) << 8) | ((pred >> 15) & 0xfe00u) | ((pred >> 23) & 0x100u);
-    // pack: ballots over the wave give 16 consecutive bins per frame and slot
-    unsigned long long myword = 0;  // lane c < 9 of group g ends up with word c of frame tq + g
+    // pack: ballots over the wave give 16 consecutive bins per frame and slot.  Lane (g, c = m) keeps
+    // the four ballots of word m with vector selects and slices out its frame's 16-bit fields with
+    // per-lane shifts afterwards (doing the slicing per frame on the scalar unit cost ~450 SALU
+    // instructions per wave; the CU has one scalar unit for all its waves).
+    unsigned long long q0 = 0, q1 = 0, q2 = 0, q3 = 0;
 #pragma unroll
     for (int m = 0; m < 8; ++m) {
-      unsigned long long b0 = __ballot((pred >> (2 * m)) & 1u);           // bins 64m      + c
-      unsigned long long b1 = __ballot((pred >> (16 + 2 * m)) & 1u);      // bins 64m + 16 + twisted
-      unsigned long long b2 = __ballot((pred >> (2 * m + 1)) & 1u);       // bins 64m + 32 + c
-      unsigned long long b3 = __ballot((pred >> (16 + 2 * m + 1)) & 1u);  // bins 64m + 48 + twisted
-#pragma unroll
-      for (int gg = 0; gg < 4; ++gg) {
-        unsigned f0 = (unsigned)(b0 >> (16 * gg)) & 0xffffu;
-        unsigned f1 = (unsigned)(b1 >> (16 * gg)) & 0xffffu;
-        unsigned f2 = (unsigned)(b2 >> (16 * gg)) & 0xffffu;
-        unsigned f3 = (unsigned)(b3 >> (16 * gg)) & 0xffffu;
-        // row-2 slots hold bins 16, 31, 30, ..., 17 (c = 0, 1, ..., 15): undo the order
-        unsigned r1 = (((__brev(f1) >> 16) << 1) | (f1 & 1u)) & 0xffffu;
-        unsigned r3 = (((__brev(f3) >> 16) << 1) | (f3 & 1u)) & 0xffffu;
-        unsigned long long word = (unsigned long long)f0 | ((unsigned long long)r1 << 16) |
-                                  ((unsigned long long)f2 << 32) | ((unsigned long long)r3 << 48);
-        if (lane == 16 * gg + m) myword = word;
-      }
+      const unsigned long long b0 = __ballot((pred >> (2 * m)) & 1u);           // bins 64m      + c
+      const unsigned long long b1 = __ballot((pred >> (16 + 2 * m)) & 1u);      // bins 64m + 16 + twisted
+      const unsigned long long b2 = __ballot((pred >> (2 * m + 1)) & 1u);       // bins 64m + 32 + c
+      const unsigned long long b3 = __ballot((pred >> (16 + 2 * m + 1)) & 1u);  // bins 64m + 48 + twisted
+      const bool mine = c == m;
+      q0 = mine ? b0 : q0;
+      q1 = mine ? b1 : q1;
+      q2 = mine ? b2 : q2;
+      q3 = mine ? b3 : q3;
     }
+    const unsigned long long b8 = __ballot(pred512);
+    unsigned long long myword;  // lane c < 9 of group g ends up with word c of frame tq + g
     {
-      unsigned long long b8 = __ballot(pred512);
-#pragma unroll
-      for (int gg = 0; gg < 4; ++gg)
-        if (lane == 16 * gg + 8) myword = (b8 >> (16 * gg)) & 1ull;
+      const int sh = 16 * g;
+      const unsigned f0 = (unsigned)(q0 >> sh) & 0xffffu;
+      const unsigned f1 = (unsigned)(q1 >> sh) & 0xffffu;
+      const unsigned f2 = (unsigned)(q2 >> sh) & 0xffffu;
+      const unsigned f3 = (unsigned)(q3 >> sh) & 0xffffu;
+      // row-2 slots hold bins 16, 31, 30, ..., 17 (c = 0, 1, ..., 15): undo the order
+      const unsigned r1 = (((__brev(f1) >> 16) << 1) | (f1 & 1u)) & 0xffffu;
+      const unsigned r3 = (((__brev(f3) >> 16) << 1) | (f3 & 1u)) & 0xffffu;
+      myword = (unsigned long long)(f0 | (r1 << 16)) | ((unsigned long long)(f2 | (r3 << 16)) << 32);
+      if (c == 8) myword = (b8 >> sh) & 1ull;
     }
     if (fvalid && c < 9) A.bits[(u * G.T + t) * (int64_t)A.wpr + c] = myword;
   }
