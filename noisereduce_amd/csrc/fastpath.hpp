@@ -810,7 +810,9 @@ __global__ __launch_bounds__(WAVES * 64, 3) void k_decide_fast(DecideArgs A) {
   };
   for (int i = tid; i <= 512; i += WAVES * 64) {
     double v = t2eff(perm_inv(i));
-    s_t2[i] = v < 0.0 ? -1.0f : (float)(4.0 * v);
+    // "every cell passes" as a huge negative constant: P - T > 0, and (P - T)^2 overflows to +inf while
+    // d2 * (P + T) is negative, so the ambiguity test fails without an extra T >= 0 term
+    s_t2[i] = v < 0.0 ? -3.0e38f : (float)(4.0 * v);
   }
   cf* fb = regions + wave * WAVE_CX_H + frame_base_h(g);
   const cf wl0 = A.tw1024[c];  // w_1024^c (lane 0: 1)
@@ -940,13 +942,14 @@ __global__ __launch_bounds__(WAVES * 64, 3) void k_decide_fast(DecideArgs A) {
     // E2 = a + conj(b), O2 = (a - conj(b)) / i; each is decided as soon as it exists.
     // ambiguous:  (P4 - T4)^2 <= 2 * (2 delta)^2 * (P4 + T4)  (implied by |2|X| - 2T| <= 2 delta),
     // delta^2 = 2^-32 * nrm2.
-    const float d2 = 8.0f * 2.3283064e-10f * nrm2;  // 2 * (2 delta)^2
-    const bool live = nrm2 > 0.f;
+    // 2 * (2 delta)^2; a silent frame (nrm2 == 0) gets a negative factor: no ambiguous cells (the tests
+    // below are then pure vector compares -- boolean terms would be combined on the scalar unit)
+    const float d2 = nrm2 > 0.f ? 8.0f * 2.3283064e-10f * nrm2 : -1.0f;
     unsigned pred = 0, amb = 0;
     auto decide = [&](float P, float T, int q) {
       const float diff = P - T;
       pred |= (diff > 0.f ? 1u : 0u) << q;
-      amb |= ((live && T >= 0.f && diff * diff <= d2 * (P + T)) ? 1u : 0u) << q;
+      amb |= ((diff * diff <= d2 * (P + T)) ? 1u : 0u) << q;
     };
     auto pair_power = [&](cf a, cf b, cf w, float& Pk, float& Pn) {
       cf E = {a.x + b.x, a.y - b.y};
@@ -978,7 +981,7 @@ __global__ __launch_bounds__(WAVES * 64, 3) void k_decide_fast(DecideArgs A) {
       decide(l0 ? P256 : Pn, t2[31], 31);
       const float P5 = xN * xN, d5 = P5 - t2_512;
       pred512 = l0 && d5 > 0.f;
-      amb512 = l0 && live && t2_512 >= 0.f && d5 * d5 <= d2 * (P5 + t2_512);
+      amb512 = l0 && d5 * d5 <= d2 * (P5 + t2_512);
     }
 #pragma unroll
     for (int sl = 1; sl < 16; ++sl) {
