@@ -1322,21 +1322,36 @@ extern "C" int sg_process_batch(sg_handle* h, const void* x_dev, int dtype, int6
       } else {
         th = nullptr; ustride = g.FS;
       }
-      if ((rc = stage_power(h, v, g, nb, st))) return rc;
-      if (!th) {
-        if ((rc = stage_colstats(h, g, nb, thr, st))) return rc;
-        th = thr;
-      }
       // default geometry, full reduction: decisions as bits -> exact integer smoothing -> uint16 sums
       // read by the fused apply kernel (same stages as the variant-S fused path)
       const bool bits_path = h->fast_ok && !h->force_nofast && !h->force_unfused && h->p.prop_decrease == 1.0 &&
                              h->ktot <= 65535 && (!h->p.smooth_mask || h->p.n_grad_time <= 96);
+      // short rows: statistics + constants + decisions of a (row, 64 bands) tile in one kernel
+      const size_t tile_bytes = (size_t)g.T * 64 * sizeof(double);
+      const bool row_fused = bits_path && tile_bytes <= 64 * 1024;
+      if (row_fused) {
+        ProfScope ps(h, SG_STAGE_STFT_POWER, st);
+        HIPCHK(h, stft_any<double>(h, v, g, nb, (double*)h->P.p, nullptr, nullptr, 1.0, st));
+      } else {
+        if ((rc = stage_power(h, v, g, nb, st))) return rc;
+        if (!th) {
+          if ((rc = stage_colstats(h, g, nb, thr, st))) return rc;
+          th = thr;
+        }
+      }
       if (bits_path) {
         const int wpr = (g.F + 63) / 64;
         if ((rc = ensure(h, h->bits, (size_t)nb * g.T * wpr * 8))) return rc;
         if ((rc = ensure(h, h->K16, (size_t)nb * g.T * g.FS * 2))) return rc;
         if ((rc = ensure(h, h->T2, (size_t)nb * g.FS * 8))) return rc;
-        {
+        if (row_fused) {
+          ProfScope ps(h, SG_STAGE_DECIDE, st);
+          hipLaunchKernelGGL(k_row_decide, dim3((unsigned)wpr, (unsigned)nb), dim3(64 * STAT_TG), tile_bytes, st,
+                             (const double*)h->P.p, g, th, ustride, h->mag_scale, h->p.top_db, h->p.n_std_thresh,
+                             h->p.ddof, (double*)h->pmax.p, th ? nullptr : thr, (unsigned long long*)h->bits.p,
+                             wpr);
+          HIPCHK(h, hipGetLastError());
+        } else {
           ProfScope ps(h, SG_STAGE_DECIDE, st);
           // compare constants in the power domain per (row, band), then a pure compare per cell
           hipLaunchKernelGGL(k_t2_rows, dim3(grid_1d(nb * g.FS, 256)), dim3(256), 0, st, th, ustride,

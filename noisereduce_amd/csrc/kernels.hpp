@@ -455,6 +455,86 @@ __global__ void k_t2_rows(const double* __restrict__ thresh, int64_t thresh_ustr
   }
 }
 
+// Short rows (TorchGate: 63 frames per 1 s clip): statistics, compare constants and decisions of one
+// (row, 64 bands) tile in ONE kernel -- the tile of powers (T x 64 float64 <= 64 KB) is read once into
+// LDS instead of four passes over the field (column max, moments, constants, compare).
+//   thresh_in == nullptr: threshold from the row's own statistics (torchgate.py:158-160), same
+//   summation order as k_colstats/k_colstats_final with one time slice; else thresh_in[u*ustride + f].
+// Outputs: bits (64 bands per word), pmax and thresh_out (stage taps).
+__global__ __launch_bounds__(64 * STAT_TG) void k_row_decide(const double* __restrict__ P, Geom g,
+                                                             const double* __restrict__ thresh_in,
+                                                             int64_t thresh_ustride, double mag_scale,
+                                                             double top_db, double n_std, int ddof,
+                                                             double* __restrict__ pmax, double* __restrict__ thresh_out,
+                                                             unsigned long long* __restrict__ bits, int wpr) {
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  double* tile = reinterpret_cast<double*>(smem);  // [T][64]
+  __shared__ double r1[STAT_TG][64], r2[STAT_TG][64];
+  const double eps = 2.220446049250313e-16;
+  const int l = threadIdx.x & 63, tg = threadIdx.x >> 6;
+  const int w = blockIdx.x;
+  const int f = 64 * w + l;
+  const int64_t u = blockIdx.y;
+  const bool on = f < g.F;
+  double m = 0.0;
+  for (int64_t t = tg; t < g.T; t += STAT_TG) {
+    const double pv = on ? P[(u * g.T + t) * g.FS + f] : 0.0;
+    tile[t * 64 + l] = pv;
+    m = fmax(m, pv);
+  }
+  r1[tg][l] = m;
+  __syncthreads();
+  for (int i = 0; i < STAT_TG; ++i) m = fmax(m, r1[i][l]);
+  const double mdb = cell_db(m, mag_scale);
+  double th;
+  if (thresh_in == nullptr) {
+    __syncthreads();  // r1 is reused
+    double s1 = 0.0, s2 = 0.0;
+    for (int64_t t = tg; t < g.T; t += STAT_TG) {
+      double d = cell_db(tile[t * 64 + l], mag_scale) - mdb;  // <= 0
+      d = fmax(d, -top_db);
+      s1 += d;
+      s2 += d * d;
+    }
+    r1[tg][l] = s1;
+    r2[tg][l] = s2;
+    __syncthreads();
+    s1 = r1[0][l];
+    s2 = r2[0][l];
+    for (int i = 1; i < STAT_TG; ++i) {
+      s1 += r1[i][l];
+      s2 += r2[i][l];
+    }
+    const double Tn = (double)g.T;
+    const double mean_d = s1 / Tn;
+    double var = (s2 - s1 * s1 / Tn) / (Tn - (double)ddof);
+    if (var < 0.0) var = 0.0;
+    th = (mdb + mean_d) + sqrt(var) * n_std;
+  } else {
+    th = on ? thresh_in[u * thresh_ustride + f] : 0.0;
+  }
+  // compare constant in the power domain (see k_t2_rows)
+  double t2 = 0.0;
+  if (on) {
+    const double fl = mdb - top_db;
+    if (fl > th || 20.0 * log10(eps) > th) {
+      t2 = -1.0;
+    } else {
+      const double tm = (exp10(th / 20.0) - eps) / mag_scale;
+      t2 = tm > 0.0 ? tm * tm : 0.0;
+    }
+  }
+  if (tg == 0 && f < g.FS) {
+    pmax[u * g.FS + f] = on ? m : 0.0;
+    if (thresh_out && on) thresh_out[u * g.FS + f] = th;
+  }
+  for (int64_t t = tg; t < g.T; t += STAT_TG) {
+    const bool pred = on && tile[t * 64 + l] > t2;
+    const unsigned long long word = __ballot(pred);
+    if (l == 0) bits[(u * g.T + t) * (int64_t)wpr + w] = word;
+  }
+}
+
 // bits[u][t][w] = P > T2[u][f]: one wavefront per 64-bin word, a pure compare (no log10 per cell)
 __global__ void k_decide_bits_t2(const double* __restrict__ P, Geom g, const double* __restrict__ T2,
                                  unsigned long long* __restrict__ bits, int wpr, int64_t n_units) {
