@@ -70,6 +70,8 @@ def main():
     ap.add_argument("--warmup", type=int, default=5)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--nonstationary", action="store_true", help="configs[2] instead of configs[1]")
+    ap.add_argument("--streams", type=int, default=1,
+                    help="independent calls in flight on separate HIP streams (serving mode; default 1)")
     args = ap.parse_args()
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
@@ -108,6 +110,14 @@ def main():
     stationary = not args.nonstationary
 
     backend = HipStationaryBackend(SR, device, chunk_size=CHUNK, padding=PAD, n_fft=NFFT)
+    # --streams S > 1 (serving mode, not the default): S independent calls in flight, each on its own
+    # HIP stream with its own engine handle -- the latency-bound statistics chain and the kernel tails
+    # of one call hide under the kernels of another.  The default times one call at a time.
+    n_streams = max(1, args.streams) if stationary else 1
+    backends = [backend] + [HipStationaryBackend(SR, device, slot=i, chunk_size=CHUNK, padding=PAD, n_fft=NFFT)
+                            for i in range(1, n_streams)]
+    streams = [torch.cuda.current_stream(device)] + [torch.cuda.Stream(device) for _ in range(1, n_streams)]
+    step_no = [0]
 
     def make_gate():
         if stationary:
@@ -124,6 +134,11 @@ def main():
     def step():
         # one whole reduce_noise: statistics + (seam, threshold) all-gather + chunk grid.
         # The engine handle (tables + workspace) is cached across calls by noisereduce_amd._ffi.
+        if stationary and n_streams > 1:
+            i = step_no[0] % n_streams
+            step_no[0] += 1
+            with torch.cuda.stream(streams[i]):
+                return TimeShardedStationary(backends[i], NFFT // 2 + 1).run(y2d, ext=y_ext if world > 1 else None)
         sg = make_gate()
         if stationary:
             out = sg.run(y2d, ext=y_ext if world > 1 else None)
@@ -181,7 +196,9 @@ def main():
                 a[0] += ms
                 a[1] += cnt
         avg_ms = agg[dom][0] / agg[dom][1]
-        launches_per_step = agg[dom][1] / args.steps
+        # the event pairs live in the handle of stream 0: it ran every n_streams-th step
+        steps_profiled = (args.steps + n_streams - 1) // n_streams
+        launches_per_step = agg[dom][1] / steps_profiled
         algo_bytes = ALGO_BYTES_PER_SAMPLE * N_PER_GPU / launches_per_step
         achieved = algo_bytes / (avg_ms * 1e-3) / 1e9
         traffic = None
@@ -201,7 +218,8 @@ def main():
                        ": synthetic 48 kHz mono 10 min per GPU, %s reduce_noise, n_fft=1024 hop=256, "
                        "chunk_size=600000 padding=30000, float32 in/out resident in HBM"
                        % ("stationary" if stationary else "non-stationary"),
-                       "samples_per_gpu": N_PER_GPU, "sharding": "time (chunk-aligned), seam all-gather"},
+                       "samples_per_gpu": N_PER_GPU, "sharding": "time (chunk-aligned), seam all-gather",
+                       "calls_in_flight": n_streams},
             "roofline": {"bound": "hbm", "kernel": dom, "achieved": round(achieved, 2), "peak": HBM_PEAK_GBS,
                          "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBS, 5), "traffic": traffic,
                          "avg_launch_ms": round(avg_ms, 4), "algorithmic_bytes_per_launch": int(algo_bytes),

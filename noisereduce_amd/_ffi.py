@@ -391,7 +391,9 @@ class Gate:
 _GATE_CACHE = {}
 
 
-def cached_gate(device, **kw):
+def cached_gate(device, slot=0, **kw):
+    """`slot` distinguishes handles with identical parameters: calls that are in flight at the same time
+    on different streams must not share a handle (its workspace is per call)."""
     dev = resolve_device(device)
 
     def norm(v):
@@ -404,7 +406,7 @@ def cached_gate(device, **kw):
         if isinstance(v, (float, np.floating)):
             return float(v)
         return v
-    key = (dev.index,) + tuple(sorted((k, norm(v)) for k, v in kw.items()))
+    key = (dev.index, int(slot)) + tuple(sorted((k, norm(v)) for k, v in kw.items()))
     g = _GATE_CACHE.get(key)
     if g is None:
         if len(_GATE_CACHE) >= 8:  # bound the number of live workspaces

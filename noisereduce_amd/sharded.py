@@ -79,8 +79,8 @@ def alloc_shard(channels, shard_len, padding, dtype, device):
 class HipStationaryBackend:
     """Compute steps of the sharded stationary gate on this rank's MI355X."""
 
-    def __init__(self, sr, device, **kw):
-        self.sr, self.device = sr, device
+    def __init__(self, sr, device, slot=0, **kw):
+        self.sr, self.device, self.slot = sr, device, slot
         self.kw = dict(y_noise=None, n_std_thresh_stationary=1.5, chunk_size=600000,
                        clip_noise_stationary=True, padding=30000, n_fft=1024, win_length=None,
                        hop_length=None, time_constant_s=2.0, freq_mask_smooth_hz=500,
@@ -104,7 +104,7 @@ class HipStationaryBackend:
             probe.smooth_mask = False
             if not (k["freq_mask_smooth_hz"] is None and k["time_mask_smooth_ms"] is None):
                 probe._generate_mask_smoothing_filter(k["freq_mask_smooth_hz"], k["time_mask_smooth_ms"])
-            self._g = _ffi.cached_gate(self.device, variant=_ffi.SG_VARIANT_S, stationary=True,
+            self._g = _ffi.cached_gate(self.device, slot=self.slot, variant=_ffi.SG_VARIANT_S, stationary=True,
                                        n_fft=k["n_fft"], win_length=W, hop_length=H,
                                        n_grad_freq=probe._n_grad_freq, n_grad_time=probe._n_grad_time,
                                        smooth_mask=probe.smooth_mask, chunk_size=k["chunk_size"],
