@@ -18,33 +18,33 @@ class StreamedTorchGate(SpectralGate):
                  n_std_thresh_stationary=1.5, tmp_folder=None, chunk_size=600000, padding=30000,
                  n_fft=1024, win_length=None, hop_length=None, clip_noise_stationary=True,
                  use_tqdm=False, n_jobs=1, device="cuda"):
-        super().__init__(y=y, sr=sr, chunk_size=chunk_size, padding=padding, n_fft=n_fft,
-                         win_length=win_length, hop_length=hop_length,
-                         time_constant_s=time_constant_s,
-                         freq_mask_smooth_hz=freq_mask_smooth_hz,
-                         time_mask_smooth_ms=time_mask_smooth_ms, tmp_folder=tmp_folder,
-                         prop_decrease=prop_decrease, use_tqdm=use_tqdm, n_jobs=n_jobs,
-                         device=device)
-        # noise clip (streamed_torch_gate.py:55-63): trimmed to len(y), kept 2-D
-        if y_noise is not None:
-            if not isinstance(y_noise, torch.Tensor):
-                y_noise = torch.from_numpy(np.asarray(y_noise))
-            if y_noise.shape[-1] > self.n_frames and clip_noise_stationary:
-                y_noise = y_noise[..., : self.n_frames]
-            y_noise = y_noise.to(self.device)
-            if y_noise.ndim == 1:
-                y_noise = y_noise.unsqueeze(0)
-            y_noise = y_noise.to(torch.float64)
-        self.y_noise = y_noise
-        # parameter mapping of streamed_torch_gate.py:66-79
-        self.tg = TG(sr=sr, nonstationary=not stationary,
-                     n_std_thresh_stationary=n_std_thresh_stationary,
-                     n_thresh_nonstationary=thresh_n_mult_nonstationary,
-                     temp_coeff_nonstationary=1 / sigmoid_slope_nonstationary,
-                     n_movemean_nonstationary=int(time_constant_s / self._hop_length * sr),
-                     prop_decrease=prop_decrease, n_fft=self._n_fft, win_length=self._win_length,
-                     hop_length=self._hop_length, freq_mask_smooth_hz=freq_mask_smooth_hz,
-                     time_mask_smooth_ms=time_mask_smooth_ms).to(self.device)
+        base_kw = dict(chunk_size=chunk_size, padding=padding, n_fft=n_fft, win_length=win_length,
+                       hop_length=hop_length, time_constant_s=time_constant_s, tmp_folder=tmp_folder,
+                       freq_mask_smooth_hz=freq_mask_smooth_hz, time_mask_smooth_ms=time_mask_smooth_ms,
+                       prop_decrease=prop_decrease, use_tqdm=use_tqdm, n_jobs=n_jobs, device=device)
+        super().__init__(y=y, sr=sr, **base_kw)
+        self.y_noise = self._prepare_noise(y_noise, clip_noise_stationary)
+        # the reference's parameter mapping onto TorchGate (streamed_torch_gate.py:66-79): the time
+        # constant becomes a moving-mean length in frames, the sigmoid slope a temperature
+        gate_kw = dict(nonstationary=not stationary, prop_decrease=prop_decrease,
+                       n_std_thresh_stationary=n_std_thresh_stationary,
+                       n_thresh_nonstationary=thresh_n_mult_nonstationary,
+                       temp_coeff_nonstationary=1 / sigmoid_slope_nonstationary,
+                       n_movemean_nonstationary=int(time_constant_s / self._hop_length * sr),
+                       n_fft=self._n_fft, win_length=self._win_length, hop_length=self._hop_length,
+                       freq_mask_smooth_hz=freq_mask_smooth_hz, time_mask_smooth_ms=time_mask_smooth_ms)
+        self.tg = TG(sr=sr, **gate_kw).to(self.device)
+
+    def _prepare_noise(self, y_noise, clip):
+        """Noise clip as a float64 (rows, n) device tensor, trimmed to the length of y when `clip`
+        (streamed_torch_gate.py:55-63); None stays None."""
+        if y_noise is None:
+            return None
+        t = y_noise if isinstance(y_noise, torch.Tensor) else torch.from_numpy(np.asarray(y_noise))
+        if clip and t.shape[-1] > self.n_frames:
+            t = t[..., : self.n_frames]
+        t = t.to(self.device, torch.float64)
+        return t.unsqueeze(0) if t.ndim == 1 else t
 
     def _do_filter(self, chunk):
         """float64 (C, Lp) chunk -> TorchGate batch (streamed_torch_gate.py:81-87).  The
