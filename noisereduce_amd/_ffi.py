@@ -409,8 +409,10 @@ def cached_gate(device, slot=0, **kw):
     key = (dev.index, int(slot)) + tuple(sorted((k, norm(v)) for k, v in kw.items()))
     g = _GATE_CACHE.get(key)
     if g is None:
-        if len(_GATE_CACHE) >= 8:  # bound the number of live workspaces
-            _GATE_CACHE.pop(next(iter(_GATE_CACHE))).close()
+        if len(_GATE_CACHE) >= 8:  # bound the number of cached workspaces
+            # dropped, not closed: an object that still holds the evicted gate keeps it alive, and
+            # Gate.__del__ frees the handle with the last reference
+            _GATE_CACHE.pop(next(iter(_GATE_CACHE)))
         g = Gate(dev, **kw)
         _GATE_CACHE[key] = g
     return g

@@ -523,3 +523,19 @@ def test_result_buffer_pool(nr):
     assert _hostbuf.pool_stats()["total_bytes"] == st["total_bytes"]
     want = O.reduce_noise_S(y.astype(np.float64), 48000, stationary=True)
     assert O.rel_err(b, want) < TOL
+
+
+def test_gate_cache_eviction_keeps_live_gates_usable(nr):
+    """The handle cache holds 8 parameter sets; an evicted gate that an object still refers to must
+    stay usable (it is freed with its last reference, not at eviction)."""
+    from noisereduce_amd.spectralgate.stationary import SpectralGateStationary
+    y = O.synth_signal(30000, seed=2).astype(np.float64)
+    kw = dict(sr=48000, y_noise=None, prop_decrease=1.0, n_std_thresh_stationary=1.5, chunk_size=600000,
+              clip_noise_stationary=True, padding=30000, n_fft=1024, win_length=None, hop_length=None,
+              time_constant_s=2.0, freq_mask_smooth_hz=500, time_mask_smooth_ms=50, tmp_folder=None,
+              use_tqdm=False, n_jobs=1)
+    first = SpectralGateStationary(y=y, **kw)
+    ref = first.get_traces()
+    for i in range(10):                               # 10 other parameter sets push `first`'s gate out
+        nr.reduce_noise(y=y, sr=48000, stationary=True, prop_decrease=0.5 + 0.01 * i)
+    assert np.array_equal(first.get_traces(), ref)
