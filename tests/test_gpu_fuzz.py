@@ -95,3 +95,31 @@ def test_random_torchgate_matches_oracle(seed):
     got = tg(torch.from_numpy(x).to(dt).cuda(), None if xn is None else torch.from_numpy(xn).to(dt).cuda())
     assert got.dtype == dt and tuple(got.shape) == want.shape
     assert O.rel_err(got.double().cpu().numpy(), want) < (2e-4 if f32 else TOL), (kw, sr, B, L, xn_shape)
+
+
+def test_odd_input_containers():
+    """Fortran-ordered / strided arrays, lists, float16 and int64 samples, strided, transposed and CPU
+    tensors: same numbers as for a plain float64 array (output dtype and container follow the input)."""
+    import noisereduce_amd as nr
+    n = 50000
+    base = np.stack([O.synth_signal(n, seed=s).astype(np.float64) for s in (1, 2)])
+    kw = dict(sr=48000, stationary=True, chunk_size=20000, padding=3000)
+    want = O.reduce_noise_S(base, **kw)
+
+    def check(y, w=want, tol=TOL, dtype=np.float64, tensor=False):
+        got = nr.reduce_noise(y=y, **kw)
+        assert isinstance(got, torch.Tensor) == tensor
+        g = got.cpu().numpy() if tensor else got
+        assert g.dtype == dtype and g.shape == w.shape
+        assert O.rel_err(g.astype(np.float64), w) < tol
+
+    check(np.asfortranarray(base))
+    check(np.repeat(base, 2, axis=1)[:, ::2])
+    check(base[0].tolist(), O.reduce_noise_S(base[0], **kw))
+    h = base.astype(np.float16)
+    check(h, O.reduce_noise_S(h.astype(np.float64), **kw), 2e-3, np.float16)
+    i64 = (base * 30000).astype(np.int64)
+    check(i64, np.trunc(O.reduce_noise_S(i64.astype(np.float64), **kw)), 1e-3, np.int64)
+    check(torch.from_numpy(np.repeat(base, 2, axis=1)).cuda()[:, ::2], tensor=True)
+    check(torch.from_numpy(np.ascontiguousarray(base.T)).cuda().T, tensor=True)
+    check(torch.from_numpy(base), tensor=True)          # CPU tensor in -> tensor out
