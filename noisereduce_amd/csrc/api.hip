@@ -163,9 +163,10 @@ static void free_buf(DevBuf& b) {
 
 static int64_t frames_for(const sg_handle* h, int64_t L) {
   // S: zero extension W//2 per side, padded=False (scipy/_spectral_py.py:2052,2185-2189).
-  // T: torch.stft(center=True): 1 + L // hop.
+  // T: torch.stft(center=True) pads n_fft//2 per side: 1 + (L + 2 (n//2) - n) // hop
+  //    (= 1 + L // hop for even n_fft).
   if (h->p.variant == SG_VARIANT_S) return (L + 2 * (int64_t)(h->W / 2) - h->W) / h->H + 1;
-  return 1 + L / h->H;
+  return 1 + (L + 2 * (int64_t)(h->n / 2) - h->n) / h->H;
 }
 static int64_t outlen_for(const sg_handle* h, int64_t L) {
   int64_t T = frames_for(h, L);

@@ -121,13 +121,14 @@ def _centered_window(n_fft, W, window=None):
 def stft_torch(x, n_fft, W, H, window=None):
     """torch.stft(x, n_fft, H, W, window=hann, center=True, pad_mode="constant",
     return_complex=True) as called at torchgate.py:142-151,223-232.
-    x: (B, L).  Returns (B, F, T) complex128, unscaled, T = 1 + L // H."""
+    x: (B, L).  Returns (B, F, T) complex128, unscaled, T = 1 + (L + 2 (n_fft // 2) - n_fft) // H
+    (= 1 + L // H for even n_fft; an odd n_fft pads one sample less than a frame)."""
     x = np.asarray(x, dtype=np.float64)
     B, L = x.shape
     wf = _centered_window(n_fft, W, window)
     p = n_fft // 2
     ext = np.concatenate([np.zeros((B, p)), x, np.zeros((B, p))], axis=1)
-    T = 1 + L // H
+    T = 1 + (L + 2 * p - n_fft) // H
     idx = np.arange(n_fft)[None, :] + H * np.arange(T)[:, None]
     frames = ext[:, idx] * wf[None, None, :]
     Z = np.fft.rfft(frames, axis=-1)

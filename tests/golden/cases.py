@@ -100,6 +100,9 @@ T_CASES = {
     # n_fft = 400 (25 ms at 16 kHz, the usual speech front-end frame) and an odd length
     "stat_nfft400": dict(sr=16000, B=3, L=8000, seed=39, kwargs=dict(n_fft=400)),
     "nonstat_nfft601": dict(sr=16000, B=2, L=8000, seed=40, kwargs=dict(nonstationary=True, n_fft=601)),
+    # odd n_fft with a length that is a multiple of the hop: torch.stft pads one sample less than a frame,
+    # so there is one frame fewer than 1 + L // hop
+    "stat_nfft601_hopmult": dict(sr=16000, B=2, L=9000, seed=41, kwargs=dict(n_fft=601, hop_length=150)),
 }
 
 
