@@ -1,0 +1,144 @@
+"""Wider randomised parity sweep than tests/test_gpu_fuzz.py: noise clips, clipping off, chunk_size=None,
+tiny chunks, odd windows, no / one-axis smoothing, threshold and sigmoid parameters, sub-range
+get_traces.  usage: python tools/fuzz_wide.py [first_seed] [count]"""
+import os, sys, numpy as np, torch
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import noisereduce_amd as nr
+from noisereduce_amd.torchgate import TorchGate
+from oracle import spectralgate_oracle as O
+
+
+STATS = dict(compared=0, valueerror=0, max_err_S=0.0, max_err_T=0.0)
+
+
+def case_S(seed):
+    r = np.random.default_rng(77000 + seed)
+    n_fft = int(r.choice([64, 100, 128, 255, 256, 400, 512, 1000, 1024, 1024, 1536, 2048]))
+    win = n_fft if r.random() < 0.5 else int(r.integers(max(8, n_fft // 3), n_fft + 1))
+    hop = win // 4 if r.random() < 0.5 else int(r.integers(max(1, win // 10), max(2, win // 2) + 1))
+    sr = int(r.choice([8000, 11025, 16000, 32000, 44100, 48000, 96000]))
+    C = int(r.choice([1, 1, 2, 4]))
+    n = int(r.integers(3 * n_fft + 5, 50000))
+    cs = None if r.random() < 0.15 else int(r.integers(max(2 * n_fft, 500), 25000))
+    pad = int(r.integers(0, 4 * n_fft))
+    stationary = bool(r.random() < 0.55)
+    kw = dict(stationary=stationary, n_fft=n_fft, win_length=win, hop_length=hop, chunk_size=cs, padding=pad,
+              prop_decrease=float(r.choice([1.0, 1.0, 0.8, 0.3, 0.0])),
+              n_std_thresh_stationary=float(r.choice([1.5, 0.5, 2.5])),
+              thresh_n_mult_nonstationary=float(r.choice([2, 1, 3.5])),
+              sigmoid_slope_nonstationary=float(r.choice([10, 4, 25])),
+              time_constant_s=float(r.choice([2.0, 0.3, 5.0])),
+              clip_noise_stationary=bool(r.random() < 0.8))
+    sm = r.random()
+    f_hz = float(r.choice([1.2, 2.5, 6.0])) * sr / (n_fft / 2) + 1.0
+    t_ms = float(r.choice([1.2, 3.0, 7.0])) * hop / sr * 1000.0 + 0.01
+    if sm < 0.1:
+        kw.update(freq_mask_smooth_hz=None, time_mask_smooth_ms=None)
+    elif sm < 0.2:
+        kw.update(freq_mask_smooth_hz=f_hz, time_mask_smooth_ms=None)
+    elif sm < 0.3:
+        kw.update(freq_mask_smooth_hz=None, time_mask_smooth_ms=t_ms)
+    else:
+        kw.update(freq_mask_smooth_hz=f_hz, time_mask_smooth_ms=t_ms)
+    noise = None
+    if stationary and r.random() < 0.4:
+        nl = int(r.integers(max(win, 2 * n_fft), 30000))
+        noise = ("2d" if (C > 1 and r.random() < 0.5) else "1d", nl)
+    dtype = str(r.choice(["float32", "float64", "float64", "int16"]))
+    return sr, C, n, dtype, noise, kw
+
+
+def run_S(seed):
+    sr, C, n, dtype, noise, kw = case_S(seed)
+    y = np.stack([O.synth_signal(n, seed=seed * 5 + c, tone_hz=250.0 * (c + 1)).astype(np.float64) for c in range(C)])
+    y = np.round(y * 15000).astype(np.int16) if dtype == "int16" else y.astype(dtype)
+    if C == 1:
+        y = y[0]
+    if noise is not None:
+        rr = np.random.default_rng(seed + 9)
+        shape = (C, noise[1]) if noise[0] == "2d" else (noise[1],)
+        yn = (0.1 * rr.standard_normal(shape) * (15000 if dtype == "int16" else 1)).astype(np.float32).astype(np.float64)
+        kw["y_noise"] = yn
+    try:
+        want = O.reduce_noise_S(y.astype(np.float64), sr, **kw)
+    except ValueError as e:
+        try:
+            nr.reduce_noise(y=y, sr=sr, **kw)
+        except ValueError:
+            STATS["valueerror"] += 1
+            return
+        raise AssertionError("oracle raised ValueError (%s) but the engine did not" % e)
+    got = nr.reduce_noise(y=y, sr=sr, **kw)
+    assert got.shape == y.shape and got.dtype == y.dtype
+    if dtype == "int16":
+        assert np.max(np.abs(got.astype(np.int64) - np.trunc(want).astype(np.int64))) <= 1
+    else:
+        e = O.rel_err(got.astype(np.float64), want)
+        STATS["max_err_S"] = max(STATS["max_err_S"], e)
+        assert e < (1e-4 if dtype == "float64" else 3e-4), e
+    STATS["compared"] += 1
+
+
+def case_T(seed):
+    r = np.random.default_rng(88000 + seed)
+    n_fft = int(r.choice([128, 255, 256, 400, 512, 601, 1024, 1024, 2048]))
+    win = n_fft if r.random() < 0.6 else int(r.integers(max(8, n_fft // 3), n_fft + 1))
+    hop = win // 4 if r.random() < 0.6 else int(r.integers(max(1, win // 10), max(2, win // 3) + 1))
+    sr = int(r.choice([8000, 16000, 22050, 44100]))
+    B = int(r.integers(1, 5))
+    L = int(r.integers(2 * win, 2 * win + 9000))
+    if r.random() < 0.3:
+        L = (L // hop) * hop                      # lengths that are exact multiples of the hop
+        L = max(L, 2 * win)
+    kw = dict(nonstationary=bool(r.random() < 0.5), n_fft=n_fft, win_length=win, hop_length=hop,
+              prop_decrease=float(r.choice([1.0, 1.0, 0.5, 0.0])),
+              n_std_thresh_stationary=float(r.choice([1.5, 0.7, 2.2])),
+              n_thresh_nonstationary=float(r.choice([1.3, 0.8, 2.0])),
+              temp_coeff_nonstationary=float(r.choice([0.1, 0.05, 0.3])),
+              n_movemean_nonstationary=int(r.integers(2, 30)))
+    sm = r.random()
+    f_hz = float(r.choice([1.2, 3.0, 9.0])) * sr / (n_fft / 2) + 1.0
+    t_ms = float(r.choice([1.2, 3.0, 6.0])) * hop / sr * 1000.0 + 0.01
+    if sm < 0.1:
+        kw.update(freq_mask_smooth_hz=None, time_mask_smooth_ms=None)
+    elif sm < 0.2:
+        kw.update(freq_mask_smooth_hz=f_hz, time_mask_smooth_ms=None)
+    elif sm < 0.3:
+        kw.update(freq_mask_smooth_hz=None, time_mask_smooth_ms=t_ms)
+    else:
+        kw.update(freq_mask_smooth_hz=f_hz, time_mask_smooth_ms=t_ms)
+    xn = None
+    if not kw["nonstationary"] and r.random() < 0.5:
+        xn = (int(r.choice([1, B])), int(r.integers(2 * win, 2 * win + 5000)))
+    return sr, B, L, xn, bool(r.random() < 0.5), kw
+
+
+def run_T(seed):
+    sr, B, L, xn_shape, f32, kw = case_T(seed)
+    rr = np.random.default_rng(seed)
+    t = np.arange(L) / sr
+    x = (0.1 * rr.standard_normal((B, L)) + 0.4 * np.sin(2 * np.pi * 0.02 * sr * t)[None, :]).astype(np.float32).astype(np.float64)
+    xn = None if xn_shape is None else (0.1 * rr.standard_normal(xn_shape)).astype(np.float32).astype(np.float64)
+    want = O.torchgate_T(x, sr, xn=xn, window=torch.hann_window(kw["win_length"]).double().numpy(), **kw)
+    tg = TorchGate(sr=sr, **kw).cuda()
+    dt = torch.float32 if f32 else torch.float64
+    got = tg(torch.from_numpy(x).to(dt).cuda(), None if xn is None else torch.from_numpy(xn).to(dt).cuda())
+    assert tuple(got.shape) == want.shape, (tuple(got.shape), want.shape)
+    e = O.rel_err(got.double().cpu().numpy(), want)
+    STATS["max_err_T"] = max(STATS["max_err_T"], e)
+    assert e < (3e-4 if f32 else 1e-4), e
+    STATS["compared"] += 1
+
+
+if __name__ == "__main__":
+    first = int(sys.argv[1]) if len(sys.argv) > 1 else 0
+    count = int(sys.argv[2]) if len(sys.argv) > 2 else 300
+    bad = 0
+    for seed in range(first, first + count):
+        for name, fn, cs in (("S", run_S, case_S), ("T", run_T, case_T)):
+            try:
+                fn(seed)
+            except BaseException as e:
+                bad += 1
+                print("FAIL", name, seed, type(e).__name__, str(e)[:200].replace("\n", " "), cs(seed), flush=True)
+    print("done", count, "seeds,", bad, "failures", STATS)
