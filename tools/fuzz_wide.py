@@ -130,12 +130,42 @@ def run_T(seed):
     STATS["compared"] += 1
 
 
+def run_sub(seed):
+    """get_traces(start, end) on a persistent object against the same slice of the full result."""
+    from noisereduce_amd.spectralgate.stationary import SpectralGateStationary
+    from noisereduce_amd.spectralgate.nonstationary import SpectralGateNonStationary
+    r = np.random.default_rng(99000 + seed)
+    n = int(r.integers(20000, 90000))
+    C = int(r.choice([1, 2]))
+    cs = int(r.integers(3000, 20000))
+    pad = int(r.integers(0, 3000))
+    y = np.stack([O.synth_signal(n, seed=seed * 3 + c).astype(np.float64) for c in range(C)])
+    kw = dict(y=y, sr=48000, chunk_size=cs, padding=pad, n_fft=1024, win_length=None, hop_length=None,
+              time_constant_s=2.0, freq_mask_smooth_hz=500, time_mask_smooth_ms=50, tmp_folder=None,
+              prop_decrease=1.0, use_tqdm=False, n_jobs=1)
+    if r.random() < 0.5:
+        sg = SpectralGateStationary(y_noise=None, n_std_thresh_stationary=1.5, clip_noise_stationary=True, **kw)
+    else:
+        sg = SpectralGateNonStationary(thresh_n_mult_nonstationary=2, sigmoid_slope_nonstationary=10, **kw)
+    full = sg.get_traces()
+    a = int(r.integers(0, n - cs - 2))
+    b = int(r.integers(a + cs + 1, n + 1))          # more than one chunk: the chunked branch
+    part = sg.get_traces(start_frame=a, end_frame=b)
+    # the reference restarts the chunk grid at start_frame only when start_frame is a chunk boundary;
+    # in general chunk i still covers [i*cs, (i+1)*cs), so the slice must equal the full result
+    assert part.shape == (C, b - a)
+    e = O.rel_err(part, full[:, a:b])
+    STATS["max_err_S"] = max(STATS["max_err_S"], e)
+    assert e < 1e-6, e
+    STATS["compared"] += 1
+
+
 if __name__ == "__main__":
     first = int(sys.argv[1]) if len(sys.argv) > 1 else 0
     count = int(sys.argv[2]) if len(sys.argv) > 2 else 300
     bad = 0
     for seed in range(first, first + count):
-        for name, fn, cs in (("S", run_S, case_S), ("T", run_T, case_T)):
+        for name, fn, cs in (("S", run_S, case_S), ("T", run_T, case_T), ("sub", run_sub, lambda s_: s_)):
             try:
                 fn(seed)
             except BaseException as e:
