@@ -4,7 +4,7 @@ is channel-sharded 8 per GPU), stationary, generated on the device.  Checks a fe
 units against the oracle and reports throughput."""
 import json, os, sys, time
 import numpy as np, torch
-ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 sys.path.insert(0, ROOT)
 import __graft_entry__; __graft_entry__.build()
 import noisereduce_amd as nr

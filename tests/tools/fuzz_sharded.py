@@ -1,8 +1,8 @@
 """Random time-sharded configurations on 2 or 3 ranks sharing cuda:0 (gloo), HIP engine, against the
-single-process oracle.  usage: python tools/fuzz_sharded.py [world] [cases]"""
+single-process oracle.  usage: python tests/tools/fuzz_sharded.py [world] [cases]"""
 import os, socket, sys
 import numpy as np, torch, torch.distributed as dist, torch.multiprocessing as mp
-sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
 from oracle import spectralgate_oracle as O
 
 

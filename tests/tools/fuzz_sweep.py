@@ -1,7 +1,7 @@
 """One-off wide sweep of the randomised parity cases of tests/test_gpu_fuzz.py (seeds beyond the ones
-the test suite runs).  usage: python tools/fuzz_sweep.py [first_seed] [count]"""
+the test suite runs).  usage: python tests/tools/fuzz_sweep.py [first_seed] [count]"""
 import os, sys, traceback, numpy as np, torch
-sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
 from tests import test_gpu_fuzz as F
 first = int(sys.argv[1]) if len(sys.argv) > 1 else 100
 count = int(sys.argv[2]) if len(sys.argv) > 2 else 300

@@ -1,8 +1,8 @@
 """Wider randomised parity sweep than tests/test_gpu_fuzz.py: noise clips, clipping off, chunk_size=None,
 tiny chunks, odd windows, no / one-axis smoothing, threshold and sigmoid parameters, sub-range
-get_traces.  usage: python tools/fuzz_wide.py [first_seed] [count]"""
+get_traces.  usage: python tests/tools/fuzz_wide.py [first_seed] [count]"""
 import os, sys, numpy as np, torch
-sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
 import noisereduce_amd as nr
 from noisereduce_amd.torchgate import TorchGate
 from oracle import spectralgate_oracle as O
