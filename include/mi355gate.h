@@ -132,7 +132,8 @@ int sg_filter_padded(sg_handle* h, const void* chunk_dev, int in_dtype, void* ou
 /* ---- variant T -------------------------------------------------------------------- */
 
 /* Replaces TorchGate.forward(x, xn) (torchgate.py:200-264): x (B, L) -> out
- * (B, hop*(L//hop)).  xn_dev may be NULL (statistics from x itself, per row) or a
+ * (B, sg_output_length(L)) = hop*(T-1) (+1 for an odd n_fft), T = sg_n_frames(L) =
+ * 1 + (L + 2*(n_fft/2) - n_fft)/hop -- hop*(L/hop) for an even n_fft.  xn_dev may be NULL (statistics from x itself, per row) or a
  * (Bn, Ln) noise batch with Bn in {1, B}.
  * mask_out_dev: NULL, or a float[B][T][FS] buffer (T = sg_n_frames(L), FS = round_up(n_fft/2+1,16))
  * that receives the final (smoothed) mask, for sg_process_batch_backward. */
