@@ -539,3 +539,28 @@ def test_gate_cache_eviction_keeps_live_gates_usable(nr):
     for i in range(10):                               # 10 other parameter sets push `first`'s gate out
         nr.reduce_noise(y=y, sr=48000, stationary=True, prop_decrease=0.5 + 0.01 * i)
     assert np.array_equal(first.get_traces(), ref)
+
+
+def test_plain_c_caller_matches_python_path(nr, tmp_path):
+    """tests/c_abi/example.c: a C99 program (no Python, no torch) that calls the C ABI directly.
+    Its output samples must equal those of the Python path on the same signal."""
+    import subprocess
+    from tests.test_host_cpu import _build_c_example
+    exe = _build_c_example(tmp_path)
+    n = 700_000                                      # two chunks, the second one partial
+    res = subprocess.run([exe, str(n)], check=True, capture_output=True, text=True).stdout.split()
+    # the program's signal: 32-bit LCG noise + a 1 kHz sawtooth
+    s = np.empty(n, dtype=np.uint32)
+    state = np.uint64(12345)
+    a, c, m = np.uint64(1664525), np.uint64(1013904223), np.uint64(0xFFFFFFFF)
+    for i in range(n):
+        state = (state * a + c) & m
+        s[i] = state
+    y = (np.float32(0.2) * ((s >> np.uint32(8)).astype(np.float32) / np.float32(8388608.0) - np.float32(1.0))
+         + np.float32(0.3) * ((np.arange(n) % 48) - 24).astype(np.float32) / np.float32(24.0)).astype(np.float32)
+    out = nr.reduce_noise(y=y, sr=48000, stationary=True)
+    got = [float(v) for v in res[res.index("first") + 1:res.index("first") + 4]]
+    want = [float(out[1000]), float(out[n // 2]), float(out[n - 1000])]
+    assert np.allclose(got, want, rtol=0, atol=1e-7 * np.max(np.abs(out))), (got, want)
+    e_out = float(res[res.index("out") + 1])
+    assert abs(e_out - float(np.sum(out.astype(np.float64) ** 2))) < 1e-5 * e_out

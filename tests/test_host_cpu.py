@@ -86,3 +86,36 @@ def test_torchgate_module_surface():
         TorchGate(sr=48000, freq_mask_smooth_hz=10)
     with pytest.raises(AssertionError):
         TorchGate(sr=16000, prop_decrease=1.5)
+
+
+def _build_c_example(tmp_path):
+    """gcc-compile tests/c_abi/example.c (plain C99, no torch, no C++) and link it against the built
+    library and the HIP runtime.  Returns the path of the binary."""
+    import shutil
+    import subprocess
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    if shutil.which("gcc") is None or not os.path.exists("/opt/rocm/lib/libamdhip64.so"):
+        pytest.skip("gcc / HIP runtime not available")
+    import __graft_entry__
+    __graft_entry__.build()
+    libdir = os.path.join(root, "noisereduce_amd")
+    exe = str(tmp_path / "c_abi_example")
+    subprocess.run(["gcc", "-std=c99", "-Wall", "-Wextra", "-Werror", os.path.join(root, "tests", "c_abi", "example.c"),
+                    "-I" + os.path.join(root, "include"), "-L" + libdir, "-lmi355gate", "-L/opt/rocm/lib",
+                    "-lamdhip64", "-Wl,-rpath," + libdir, "-Wl,-rpath,/opt/rocm/lib", "-o", exe], check=True)
+    return exe
+
+
+def test_header_is_plain_c_and_c_example_links(tmp_path):
+    """include/mi355gate.h must be valid C99 (and C++), and a plain-C caller must link against the
+    library with nothing but the HIP runtime next to it."""
+    import shutil
+    import subprocess
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    if shutil.which("gcc") is None:
+        pytest.skip("gcc not available")
+    hdr = os.path.join(root, "include", "mi355gate.h")
+    subprocess.run(["gcc", "-std=c99", "-Wall", "-Wextra", "-pedantic", "-Werror", "-fsyntax-only", "-x", "c", hdr],
+                   check=True)
+    subprocess.run(["g++", "-std=c++11", "-fsyntax-only", "-x", "c++", hdr], check=True)
+    assert os.path.exists(_build_c_example(tmp_path))
