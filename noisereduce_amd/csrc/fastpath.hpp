@@ -346,7 +346,6 @@ __global__ __launch_bounds__(WAVES * 64, LEAN ? 3 : 2) void k_apply_fast(ApplyAr
   // combined by k_ola_seam -- 3/16 fewer transforms.
   const bool seam = A.part != nullptr;
   const int64_t tf_tile = A.h_begin - 3 + (int64_t)blockIdx.x * (seam ? NF : NH);  // first frame of the tile
-  const int64_t hs = tf_tile + 3;                            // first hop completed inside the tile
   const int64_t t = tf_tile + 4 * wave + g;                  // this lane group's frame
   const bool fvalid = t >= 0 && t < G.T;
   // 1 / window envelope of this thread's four sample phases, used by the OLA epilogue: loaded at entry
