@@ -13,7 +13,10 @@ torch 2.10.0) and stores its outputs under ``tests/golden/``;
 ``tests/test_oracle_golden.py`` checks every function here against them.  The
 reference's own tests hold no assertions and no golden vectors
 (/root/reference/test_reduction.py:17,31,45,59,73,101), so those generated
-fixtures are the pin.
+fixtures are the pin.  In addition the building blocks (STFT/ISTFT both flavours,
+the one-pole forward-backward smoother, the boxcar) are compared at test time with
+the scipy / torch primitives the reference calls, which are installed wherever
+the tests run.
 
 The arithmetic the reference delegates to third-party code is restated from
 the libraries installed next to it (unpinned in /root/reference/setup.py:24-27;

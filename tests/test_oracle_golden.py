@@ -82,3 +82,52 @@ def test_smoothing_filter_shape_and_sum():
     K = O.smoothing_filter(5, 9)
     assert K.shape == (11, 19) and abs(K.sum() - 1) < 1e-15
     assert np.allclose(O.triangle(3), np.array([1, 2, 3, 4, 3, 2, 1]) / 4)
+
+
+# ---- building blocks against the third-party primitives the reference calls ----
+@pytest.mark.parametrize("n_fft,W,H", [(1024, 1024, 256), (512, 400, 100), (1000, 1000, 250), (777, 600, 151)])
+def test_stft_istft_blocks_match_scipy(n_fft, W, H):
+    """stft_scipy / istft_scipy restate scipy.signal.stft / istft exactly as the reference calls them
+    (stationary.py:87-93,120-125)."""
+    import scipy.signal
+    x = O.synth_signal(9000, seed=n_fft).astype(np.float64)
+    _, _, Z = scipy.signal.stft(x, nfft=n_fft, noverlap=W - H, nperseg=W, padded=False)
+    Zo = O.stft_scipy(x, n_fft, W, H)
+    assert Zo.shape == Z.shape and np.max(np.abs(Zo - Z)) < 1e-13 * max(1.0, np.max(np.abs(Z)))
+    _, y = scipy.signal.istft(Z, nfft=n_fft, noverlap=W - H, nperseg=W)
+    yo = O.istft_scipy(Z, n_fft, W, H)
+    assert yo.shape == y.shape and np.max(np.abs(yo - y)) < 1e-13
+
+
+@pytest.mark.parametrize("n_fft,W,H", [(1024, 1024, 256), (512, 400, 100), (601, 601, 150)])
+def test_stft_istft_blocks_match_torch(n_fft, W, H):
+    """stft_torch / istft_torch restate torch.stft / torch.istft(center=True) (torchgate.py:223-262),
+    including the frame count and output length for an odd n_fft."""
+    import torch
+    for L in (3 * n_fft + 17, 40 * H):                    # generic length, exact multiple of the hop
+        x = np.random.default_rng(L).standard_normal((2, L))
+        w = torch.hann_window(W, dtype=torch.float64)
+        Z = torch.stft(torch.from_numpy(x), n_fft, H, W, window=w, center=True, pad_mode="constant",
+                       return_complex=True)
+        Zo = O.stft_torch(x, n_fft, W, H, window=w.numpy())
+        assert Zo.shape == tuple(Z.shape) and np.max(np.abs(Zo - Z.numpy())) < 1e-10
+        y = torch.istft(Z, n_fft, H, W, window=w, center=True).numpy()
+        yo = O.istft_torch(Z.numpy(), n_fft, W, H, window=w.numpy())
+        assert yo.shape == y.shape and np.max(np.abs(yo - y)) < 1e-10
+
+
+def test_filtfilt_and_boxcar_blocks_match_libraries():
+    """One-pole forward-backward smoother == scipy.signal.filtfilt(padtype=None) (nonstationary.py:115);
+    boxcar == conv1d(ones(k), padding="same") / k (torchgate.py:179-190)."""
+    import scipy.signal
+    import torch
+    rng = np.random.default_rng(3)
+    A = np.abs(rng.standard_normal((17, 300)))
+    b = O.iir_coefficient(0.5, 48000, 256)
+    ref = scipy.signal.filtfilt([b], [1, b - 1], A, axis=-1, padtype=None)
+    assert np.max(np.abs(O.filtfilt_onepole(b, A) - ref)) < 1e-13
+    for k in (3, 8, 20):
+        X = torch.from_numpy(A)[None]                    # (1, F, T)
+        ref = torch.nn.functional.conv1d(X.reshape(-1, 1, A.shape[1]), torch.ones(1, 1, k, dtype=torch.float64),
+                                         padding="same").reshape(A.shape).numpy() / k
+        assert np.max(np.abs(O.boxcar_same(A, k) - ref)) < 1e-13
