@@ -119,3 +119,26 @@ def test_header_is_plain_c_and_c_example_links(tmp_path):
                    check=True)
     subprocess.run(["g++", "-std=c++11", "-fsyntax-only", "-x", "c++", hdr], check=True)
     assert os.path.exists(_build_c_example(tmp_path))
+
+
+def test_committed_bench_line_has_the_contract_fields():
+    """The bench line committed under profiles/ (produced by `python bench.py` on an MI355X) carries every
+    field of the driver's contract, incl. the roofline and cpu_baseline objects."""
+    import glob
+    import json
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    files = sorted(glob.glob(os.path.join(root, "profiles", "r*_bench.json")))
+    assert files, "no bench line committed under profiles/"
+    line = json.loads(open(files[-1]).read().strip().splitlines()[-1])
+    for k in ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling",
+              "vs_baseline", "dtype", "data", "config", "roofline", "cpu_baseline"):
+        assert k in line, k
+    assert line["unit"] == "Msamples/s" and line["higher_is_better"] is True and line["scaling"] == "weak"
+    assert "workload" in line["config"] and "model" not in line["config"]
+    r = line["roofline"]
+    assert r["bound"] in ("hbm", "mfma") and abs(r["frac"] - r["achieved"] / r["peak"]) < 1e-3
+    c = line["cpu_baseline"]
+    assert c["kind"] in ("reference", "port") and c["cores"] >= 1 and c["value"] > 0 and c["sample"]
+    # value is consistent with ms_per_step and the workload size
+    assert abs(line["value"] - line["config"]["samples_per_gpu"] * line["n_gpus"] / line["ms_per_step"] / 1e3) \
+        < 0.01 * line["value"]
