@@ -127,9 +127,13 @@ def test_committed_bench_line_has_the_contract_fields():
     import glob
     import json
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-    files = sorted(glob.glob(os.path.join(root, "profiles", "r*_bench.json")))
+    files = glob.glob(os.path.join(root, "profiles", "r*_bench.json"))
     assert files, "no bench line committed under profiles/"
-    line = json.loads(open(files[-1]).read().strip().splitlines()[-1])
+
+    def version(path):  # r01_v11_bench.json -> (1, 11)
+        m = re.match(r"r(\d+)_v(\d+)", os.path.basename(path))
+        return (int(m.group(1)), int(m.group(2)))
+    line = json.loads(open(max(files, key=version)).read().strip().splitlines()[-1])
     for k in ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling",
               "vs_baseline", "dtype", "data", "config", "roofline", "cpu_baseline"):
         assert k in line, k
