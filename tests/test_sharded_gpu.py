@@ -85,3 +85,16 @@ def test_channel_sharded_hip_two_ranks():
     mp.spawn(_worker_channels, args=(2, _free_port(), torch.from_numpy(y), torch.from_numpy(want), ret),
              nprocs=2, join=True)
     assert ret[0] < TOL and ret[1] < TOL, dict(ret)
+
+
+def test_rccl_single_rank_collectives():
+    """The collectives of the sharded gate on the real "nccl" (= RCCL) backend: a world_size-1 group in a
+    subprocess (one GPU is all a test box has) -- uint8 all_gather_into_tensor with seams + threshold,
+    barrier, float64 all_reduce."""
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = dict(os.environ, MASTER_ADDR="127.0.0.1", MASTER_PORT=str(_free_port()))
+    res = subprocess.run([sys.executable, os.path.join(root, "tests", "tools", "nccl_single_rank.py")], env=env,
+                         capture_output=True, text=True, timeout=300)
+    assert res.returncode == 0 and "collectives ok" in res.stdout, res.stdout[-2000:] + res.stderr[-2000:]
