@@ -29,6 +29,11 @@ extern "C" {
 
 #define SG_VERSION 100 /* 0.1.0 */
 
+/* The library is built with -fvisibility=hidden: only the entry points declared here are exported. */
+#ifndef SG_API
+#define SG_API __attribute__((visibility("default")))
+#endif
+
 /* error codes */
 #define SG_OK 0
 #define SG_E_INVALID (-1)     /* bad argument (maps to ValueError)            */
@@ -72,22 +77,28 @@ typedef struct sg_params {
 
 typedef struct sg_handle sg_handle;
 
-int sg_version(void);
+SG_API int sg_version(void);
 
 /* Last error text of a handle (or of the last failed sg_create when h == NULL). */
-const char* sg_last_error(const sg_handle* h);
+SG_API const char* sg_last_error(const sg_handle* h);
 
 /* Replaces SpectralGate.__init__ parameter resolution (base.py:33-97) and
  * TorchGate.__init__ (torchgate.py:31-71): builds twiddle/window/smoothing tables on the
  * current HIP device.  `window_host`: win_length doubles, or NULL for the periodic Hann
  * window both references use (scipy get_window('hann'), torch.hann_window). */
-int sg_create(const sg_params* p, const double* window_host, sg_handle** out);
-int sg_destroy(sg_handle* h);
+SG_API int sg_create(const sg_params* p, const double* window_host, sg_handle** out);
+SG_API int sg_destroy(sg_handle* h);
 
 /* Geometry helpers: number of STFT frames and ISTFT output length for a length-L signal
  * (scipy/_spectral_py.py:2185-2189,1715; torch.stft/istft center=True). */
-int sg_n_frames(const sg_handle* h, int64_t L, int64_t* n_frames);
-int sg_output_length(const sg_handle* h, int64_t L, int64_t* out_len);
+SG_API int sg_n_frames(const sg_handle* h, int64_t L, int64_t* n_frames);
+SG_API int sg_output_length(const sg_handle* h, int64_t L, int64_t* out_len);
+
+/* Workspace (bytes of HBM) the handle will own after an sg_process_chunks call on a (C, N) recording
+ * (chunked as in sg_process_chunks) -- so that a caller can budget device memory next to the recording
+ * (base.py:180-216 streams through a memmap instead; here units are processed in batches bounded by
+ * sg_params.max_workspace_bytes).  Pure host arithmetic, no device work. */
+SG_API int sg_workspace_bytes(const sg_handle* h, int64_t C, int64_t N, int32_t chunked, int64_t* bytes);
 
 /* ---- variant S -------------------------------------------------------------------- */
 
@@ -95,16 +106,16 @@ int sg_output_length(const sg_handle* h, int64_t L, int64_t* out_len);
  * (stationary.py:47-81): channel mean of the (C, n) noise clip, STFT, dB with -top_db
  * floor, per-band mean/std over time, thresh = mean + n_std*std.  The caller applies
  * clip_noise_stationary (n = min(n, chunk_size)).  Result stays on the device. */
-int sg_noise_stats(sg_handle* h, const void* noise_dev, int dtype, int64_t C, int64_t n,
+SG_API int sg_noise_stats(sg_handle* h, const void* noise_dev, int dtype, int64_t C, int64_t n,
                    int64_t row_stride, void* stream);
 /* Read back / override the per-band threshold in dB (n_fft/2+1 doubles).
  * sg_get_noise_threshold synchronises the stream. */
-int sg_get_noise_threshold(sg_handle* h, double* thresh_host, int32_t n_bins, void* stream);
-int sg_set_noise_threshold(sg_handle* h, const double* thresh_host, int32_t n_bins, void* stream);
+SG_API int sg_get_noise_threshold(sg_handle* h, double* thresh_host, int32_t n_bins, void* stream);
+SG_API int sg_set_noise_threshold(sg_handle* h, const double* thresh_host, int32_t n_bins, void* stream);
 /* Device-to-device forms (asynchronous on `stream`, no host synchronisation): used to broadcast
  * the threshold between ranks with RCCL. */
-int sg_get_noise_threshold_dev(sg_handle* h, double* thresh_dev, int32_t n_bins, void* stream);
-int sg_set_noise_threshold_dev(sg_handle* h, const double* thresh_dev, int32_t n_bins, void* stream);
+SG_API int sg_get_noise_threshold_dev(sg_handle* h, double* thresh_dev, int32_t n_bins, void* stream);
+SG_API int sg_set_noise_threshold_dev(sg_handle* h, const double* thresh_dev, int32_t n_bins, void* stream);
 
 /* Replaces SpectralGate.get_traces + filter_chunk + _read_chunk + _do_filter for a whole
  * (C, N) planar recording that already lives in HBM (base.py:130-226): the reference's
@@ -117,7 +128,7 @@ int sg_set_noise_threshold_dev(sg_handle* h, const double* thresh_dev, int32_t n
  * of every row (0 for a plain recording).  A rank that holds one time shard of a longer
  * recording passes its neighbours' seam samples this way so that chunk windows read real
  * data instead of zeros across the shard boundary. */
-int sg_process_chunks(sg_handle* h, const void* in_dev, int in_dtype, void* out_dev,
+SG_API int sg_process_chunks(sg_handle* h, const void* in_dev, int in_dtype, void* out_dev,
                       int out_dtype, int64_t C, int64_t N, int64_t in_stride,
                       int64_t out_stride, int64_t start_frame, int64_t end_frame,
                       int32_t chunked, int64_t halo_left, int64_t halo_right, void* stream);
@@ -125,7 +136,7 @@ int sg_process_chunks(sg_handle* h, const void* in_dev, int in_dtype, void* out_
 /* Replaces SpectralGate._do_filter(chunk) (base.py:158-160; stationary.py:129-133;
  * nonstationary.py:99-103): (C, Lp) padded chunk in, (C, Lp) filtered chunk out, the
  * last Lp - sg_output_length(Lp) samples are zero like the reference's. */
-int sg_filter_padded(sg_handle* h, const void* chunk_dev, int in_dtype, void* out_dev,
+SG_API int sg_filter_padded(sg_handle* h, const void* chunk_dev, int in_dtype, void* out_dev,
                      int out_dtype, int64_t C, int64_t Lp, int64_t in_stride,
                      int64_t out_stride, void* stream);
 
@@ -137,7 +148,7 @@ int sg_filter_padded(sg_handle* h, const void* chunk_dev, int in_dtype, void* ou
  * (Bn, Ln) noise batch with Bn in {1, B}.
  * mask_out_dev: NULL, or a float[B][T][FS] buffer (T = sg_n_frames(L), FS = round_up(n_fft/2+1,16))
  * that receives the final (smoothed) mask, for sg_process_batch_backward. */
-int sg_process_batch(sg_handle* h, const void* x_dev, int dtype, int64_t B, int64_t L,
+SG_API int sg_process_batch(sg_handle* h, const void* x_dev, int dtype, int64_t B, int64_t L,
                      int64_t x_stride, const void* xn_dev, int64_t Bn, int64_t Ln,
                      int64_t xn_stride, void* out_dev, int out_dtype, int64_t out_stride,
                      float* mask_out_dev, void* stream);
@@ -146,7 +157,7 @@ int sg_process_batch(sg_handle* h, const void* x_dev, int dtype, int64_t B, int6
  * w.r.t. x with the mask detached, torchgate.py:126,167; the reference gets this from autograd
  * through torch.stft/istft): grad_out (B, Lout) -> grad_x (B, L), both of sample type `dtype`
  * (SG_F32 or SG_F64).  mask_dev = the buffer filled by sg_process_batch(mask_out_dev). */
-int sg_process_batch_backward(sg_handle* h, const void* grad_out_dev, int dtype, int64_t B,
+SG_API int sg_process_batch_backward(sg_handle* h, const void* grad_out_dev, int dtype, int64_t B,
                               int64_t L, int64_t go_stride, const float* mask_dev,
                               void* grad_x_dev, int64_t gx_stride, void* stream);
 
@@ -154,18 +165,18 @@ int sg_process_batch_backward(sg_handle* h, const void* grad_out_dev, int dtype,
 
 /* Forward STFT of (B, L) rows -> complex float64 Z[B][T][F] (interleaved re,im), same
  * scaling as the variant's reference call (S: 1/sum(w), scipy stft; T: unscaled). */
-int sg_stft(sg_handle* h, const void* x_dev, int dtype, int64_t B, int64_t L, int64_t stride,
+SG_API int sg_stft(sg_handle* h, const void* x_dev, int dtype, int64_t B, int64_t L, int64_t stride,
             double* z_dev, void* stream);
 /* Fields of the last processed unit batch, copied to the host (synchronises):
  * what = 0: raw mask  float[units][T][FS];  1: final mask float[units][T][FS];
  *        2: power     double[units][T][FS] (stationary, materialised path only);
  *        3: raw mask as bits uint64[units][T][ceil(F/64)] (fused stationary path only).
  * FS = third entry of sg_debug_dims. */
-int sg_debug_dims(const sg_handle* h, int64_t dims[3]); /* units, T, FS */
+SG_API int sg_debug_dims(const sg_handle* h, int64_t dims[3]); /* units, T, FS */
 /* Frame range [t0, t1) for which field 3 (mask bits) was computed: the fast path only decides
  * the frames that reach the kept output samples (+- the smoothing half width). */
-int sg_debug_range(const sg_handle* h, int64_t range[2]);
-int sg_debug_fetch(sg_handle* h, int32_t what, void* host, int64_t bytes, void* stream);
+SG_API int sg_debug_range(const sg_handle* h, int64_t range[2]);
+SG_API int sg_debug_fetch(sg_handle* h, int32_t what, void* host, int64_t bytes, void* stream);
 
 /* ---- options ------------------------------------------------------------------------- */
 #define SG_OPT_FORCE_UNFUSED 1 /* value != 0: use the materialised (v1) kernels everywhere */
@@ -173,7 +184,7 @@ int sg_debug_fetch(sg_handle* h, int32_t what, void* host, int64_t bytes, void* 
 #define SG_OPT_FORCE_NOSEAM 4   /* value != 0: overlapping apply tiles instead of abutting tiles + seam kernel */
 #define SG_OPT_FORCE_NOLEAN 5   /* value != 0: apply kernel with full-size LDS slices and stored frames */
 #define SG_OPT_FORCE_NOFAST 2  /* value != 0: keep the bit-mask stages but use the general apply kernels */
-int sg_set_option(sg_handle* h, int32_t option, int64_t value);
+SG_API int sg_set_option(sg_handle* h, int32_t option, int64_t value);
 
 /* ---- per-kernel timing (bench.py's roofline leg) ------------------------------------- */
 #define SG_STAGE_CHANNEL_MEAN 0
@@ -196,12 +207,12 @@ int sg_set_option(sg_handle* h, int32_t option, int64_t value);
 /* When enabled, every kernel launch is bracketed by a hipEvent pair recorded on the launch
  * stream.  sg_profile_read synchronises those events and returns accumulated milliseconds
  * and launch counts per stage (arrays of SG_N_STAGES); reset != 0 clears the accumulators. */
-int sg_profile_enable(sg_handle* h, int32_t on);
+SG_API int sg_profile_enable(sg_handle* h, int32_t on);
 /* Restrict the event pairs to the stages whose bit (1 << SG_STAGE_*) is set; 0 = all stages.  Timing
  * one kernel costs two event records per step instead of ~30. */
-int sg_profile_select(sg_handle* h, int64_t stage_mask);
-int sg_profile_read(sg_handle* h, double* ms, int64_t* counts, int32_t n_stages, int32_t reset);
-const char* sg_stage_name(int32_t stage);
+SG_API int sg_profile_select(sg_handle* h, int64_t stage_mask);
+SG_API int sg_profile_read(sg_handle* h, double* ms, int64_t* counts, int32_t n_stages, int32_t reset);
+SG_API const char* sg_stage_name(int32_t stage);
 
 #ifdef __cplusplus
 }

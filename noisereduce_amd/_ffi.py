@@ -7,6 +7,7 @@ calls raise.
 """
 import ctypes
 import os
+import threading
 from ctypes import (POINTER, Structure, byref, c_char_p, c_double, c_int, c_int32,
                     c_int64, c_void_p)
 
@@ -51,6 +52,7 @@ _PROTOTYPES = {
     "sg_destroy": (c_int, [c_void_p]),
     "sg_n_frames": (c_int, [c_void_p, c_int64, POINTER(c_int64)]),
     "sg_output_length": (c_int, [c_void_p, c_int64, POINTER(c_int64)]),
+    "sg_workspace_bytes": (c_int, [c_void_p, c_int64, c_int64, c_int32, POINTER(c_int64)]),
     "sg_noise_stats": (c_int, [c_void_p, c_void_p, c_int, c_int64, c_int64, c_int64, c_void_p]),
     "sg_get_noise_threshold": (c_int, [c_void_p, POINTER(c_double), c_int32, c_void_p]),
     "sg_set_noise_threshold": (c_int, [c_void_p, POINTER(c_double), c_int32, c_void_p]),
@@ -154,6 +156,11 @@ class Gate:
                      max_workspace_bytes=int(max_workspace_bytes))
         self.params = p
         self.n_bins = int(n_fft) // 2 + 1
+        # A handle carries per-call state (workspace, the stationary threshold h->thresh): callers that
+        # share a cached handle serialise on `lock`, and `thresh_owner` names the object whose threshold
+        # the handle currently holds (None: unknown) -- see SpectralGateStationary._bind().
+        self.lock = threading.RLock()
+        self.thresh_owner = None
         wptr = None
         if window is not None:
             w = np.ascontiguousarray(np.asarray(window, dtype=np.float64))
@@ -211,6 +218,12 @@ class Gate:
     def output_length(self, L):
         out = c_int64()
         self._check(self.lib.sg_output_length(self._h, int(L), byref(out)))
+        return out.value
+
+    def workspace_bytes(self, C, N, chunked=True):
+        """HBM the handle will own after process_chunks on a (C, N) recording (host arithmetic only)."""
+        out = c_int64()
+        self._check(self.lib.sg_workspace_bytes(self._h, int(C), int(N), int(bool(chunked)), byref(out)))
         return out.value
 
     # -- variant S -------------------------------------------------------------------
@@ -387,8 +400,12 @@ class Gate:
 
 # Handles are cached per (device, parameters): a handle owns its twiddle/window tables and a
 # grown-on-demand workspace, so repeated reduce_noise()/TorchGate calls with the same settings
-# reuse them instead of paying hipMalloc/hipFree per call.  Not thread-safe (like the handle).
+# reuse them instead of paying hipMalloc/hipFree per call.  The cache itself is guarded by
+# _CACHE_LOCK; a handle is NOT re-entrant: users hold Gate.lock around a call sequence that depends on
+# handle state (noise statistics -> filter).  The stationary threshold is per OBJECT (reference
+# stationary.py:79-81), never per handle: objects re-load theirs when Gate.thresh_owner is not them.
 _GATE_CACHE = {}
+_CACHE_LOCK = threading.Lock()
 
 
 def cached_gate(device, slot=0, **kw):
@@ -407,17 +424,19 @@ def cached_gate(device, slot=0, **kw):
             return float(v)
         return v
     key = (dev.index, int(slot)) + tuple(sorted((k, norm(v)) for k, v in kw.items()))
-    g = _GATE_CACHE.get(key)
-    if g is None:
-        if len(_GATE_CACHE) >= 8:  # bound the number of cached workspaces
-            # dropped, not closed: an object that still holds the evicted gate keeps it alive, and
-            # Gate.__del__ frees the handle with the last reference
-            _GATE_CACHE.pop(next(iter(_GATE_CACHE)))
-        g = Gate(dev, **kw)
-        _GATE_CACHE[key] = g
-    return g
+    with _CACHE_LOCK:
+        g = _GATE_CACHE.get(key)
+        if g is None:
+            if len(_GATE_CACHE) >= 8:  # bound the number of cached workspaces
+                # dropped, not closed: an object that still holds the evicted gate keeps it alive, and
+                # Gate.__del__ frees the handle with the last reference
+                _GATE_CACHE.pop(next(iter(_GATE_CACHE)))
+            g = Gate(dev, **kw)
+            _GATE_CACHE[key] = g
+        return g
 
 
 def clear_gate_cache():
-    while _GATE_CACHE:
-        _GATE_CACHE.popitem()[1].close()
+    with _CACHE_LOCK:
+        while _GATE_CACHE:
+            _GATE_CACHE.popitem()[1].close()

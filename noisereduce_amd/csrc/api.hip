@@ -1146,6 +1146,20 @@ static int run_S(sg_handle* h, View v, int64_t total_units, const OutMap& om, hi
 
 static bool dtype_ok(int d) { return d >= SG_F32 && d <= SG_I32; }
 
+extern "C" int sg_workspace_bytes(const sg_handle* h, int64_t C, int64_t N, int32_t chunked, int64_t* bytes) {
+  if (!h || !bytes || C < 1 || N < 1) return SG_E_INVALID;
+  const int64_t cs = h->p.chunk_size, pad = h->p.padding;
+  const int64_t Lp = chunked ? cs + 2 * pad : N + 2 * pad;
+  const int64_t units = chunked ? C * ((N + cs - 1) / cs) : C;
+  if (Lp < h->W) return SG_E_INVALID;
+  const Geom g = make_geom(h, Lp);
+  const bool lean = h->p.variant == SG_VARIANT_S && h->fused_ok && !h->force_unfused && h->fast_ok &&
+                    !h->force_nofast && h->p.prop_decrease == 1.0;
+  const int64_t ub = units_per_batch(h, g, units, lean);
+  *bytes = ub * (int64_t)unit_bytes(h, g, lean);
+  return SG_OK;
+}
+
 // ------------------------------------------------------------------------------------------
 // variant S entry points
 // ------------------------------------------------------------------------------------------

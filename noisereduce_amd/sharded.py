@@ -19,6 +19,8 @@ data-path collective.  Two small exchanges remain:
 ``filter_fn`` makes the compute step pluggable so the partition/exchange logic is testable on
 CPU (world_size 2, gloo) against the oracle; the product path uses the HIP engine.
 """
+import contextlib
+
 import numpy as np
 import torch
 import torch.distributed as dist
@@ -41,9 +43,15 @@ def exchange_seams(y_local, padding, group=None):
     ws = dist.get_world_size(group)
     rank = dist.get_rank(group)
     C, S = y_local.shape
-    if S < padding:
-        raise ValueError("time shard shorter than the chunk padding")
-    seams = torch.stack([y_local[:, :padding], y_local[:, S - padding:]]).contiguous()
+    if S >= padding:
+        seams = torch.stack([y_local[:, :padding], y_local[:, S - padding:]]).contiguous()
+    else:
+        # short last shard: zero-filled seams (== the zero padding beyond the recording's end); raising
+        # here would strand the other ranks in the all-gather
+        seams = y_local.new_zeros((2, C, padding))
+        if S:
+            seams[0][:, :S] = y_local
+            seams[1][:, padding - S:] = y_local
     if ws == 1:
         z = torch.zeros_like(seams[0])
         return z, z.clone()
@@ -112,6 +120,10 @@ class HipStationaryBackend:
                                        n_std_thresh=k["n_std_thresh_stationary"], top_db=80.0, ddof=0)
         return self._g
 
+    def lock(self):
+        """The engine handle's lock (callers hold it across stats -> filter)."""
+        return self._gate().lock
+
     def stats(self, y_local):
         """Noise statistics from this rank's data, left on the device (owning rank only):
         y_noise=None means the recording itself, clipped to chunk_size (stationary.py:47-64)."""
@@ -124,6 +136,7 @@ class HipStationaryBackend:
         if self.kw["clip_noise_stationary"] and self.chunk_size is not None:
             noise = noise[:, :self.chunk_size]
         g.noise_stats(noise)
+        g.thresh_owner = None   # the handle no longer holds any SpectralGateStationary object's threshold
         return g
 
     def threshold(self, y_local):
@@ -135,6 +148,7 @@ class HipStationaryBackend:
         g = self._gate()
         if not owner:
             g.set_noise_threshold_tensor(thresh)
+            g.thresh_owner = None
         S = y_local.shape[1]
         if halo == 0 and ext is y_local:
             return g.process_chunks(y_local, chunked=S > self.chunk_size)
@@ -142,19 +156,45 @@ class HipStationaryBackend:
                                 halo_right=halo)
 
 
-def exchange_seams_and_threshold(y_local, padding, thr, n_bins, group=None, bufs=None):
-    """ONE all-gather carrying every rank's seam samples and rank 0's threshold.
-    Each rank contributes [first `padding` | last `padding` samples of every channel | n_bins float64]
-    as raw bytes (only rank 0's threshold slot is meaningful).  Returns (left_halo, right_halo, thr):
-    halos (C, padding) in y_local's dtype, zeros at the ends of the recording; thr float64 (n_bins,).
-    `bufs`: optional dict that keeps the send/receive buffers between calls."""
+def _check_shard_lengths(lens, chunk_size, padding):
+    """Validate the time shards of ALL ranks (identical verdict on every rank: called with the gathered
+    lengths, so every rank raises -- or none does).  Non-empty shards must be contiguous from rank 0;
+    every shard but the last non-empty one must be a positive multiple of chunk_size and at least
+    `padding` long (its seams are real samples); the last one may be short (its missing seam samples lie
+    beyond the end of the recording == the reference's zero padding, base.py:139-141)."""
+    nonempty = [i for i, n in enumerate(lens) if n > 0]
+    if not nonempty:
+        return
+    last = nonempty[-1]
+    for r in range(last):
+        n = lens[r]
+        if n <= 0:
+            raise ValueError(f"time shard of rank {r} is empty but rank {last} holds samples "
+                             f"(shard lengths {list(lens)})")
+        if chunk_size and n % chunk_size != 0:
+            raise ValueError(f"time shard of rank {r} ({n} samples) is not chunk-aligned "
+                             f"(chunk_size {chunk_size}; shard lengths {list(lens)})")
+        if n < padding:
+            raise ValueError(f"time shard of rank {r} ({n} samples) is shorter than the chunk padding "
+                             f"({padding})")
+
+
+def exchange_seams_and_threshold(y_local, padding, thr, n_bins, group=None, bufs=None, chunk_size=None):
+    """ONE all-gather carrying every rank's shard length, seam samples and rank 0's threshold.
+    Each rank contributes [int64 shard length | first `padding` | last `padding` samples of every channel
+    | n_bins float64] as raw bytes (only rank 0's threshold slot is meaningful).  Returns
+    (left_halo, right_halo, thr): halos (C, padding) in y_local's dtype, zeros at the ends of the
+    recording; thr float64 (n_bins,).
+    No rank raises BEFORE the collective (the others would block in it until the RCCL timeout): a shard
+    shorter than `padding` sends zero-filled seams, and the shard layout is validated from the gathered
+    lengths -- by every rank with the same verdict -- the first time this (length, world) is seen.
+    `bufs`: optional dict that keeps the send/receive buffers (and the validation memo) between calls."""
     ws, rank = dist.get_world_size(group), dist.get_rank(group)
     C, S = y_local.shape
-    if S < padding:
-        raise ValueError("time shard shorter than the chunk padding")
     es = y_local.element_size()
+    HDR = 8
     seam_bytes = 2 * C * padding * es
-    sb = (seam_bytes + 7) // 8 * 8                      # threshold slot 8-byte aligned
+    sb = HDR + (seam_bytes + 7) // 8 * 8                # threshold slot 8-byte aligned
     total = sb + n_bins * 8
     key = (total, ws, y_local.device)
     if bufs is not None and bufs.get("key") == key:
@@ -163,19 +203,34 @@ def exchange_seams_and_threshold(y_local, padding, thr, n_bins, group=None, bufs
         send = torch.zeros(total, dtype=torch.uint8, device=y_local.device)
         recv = torch.empty(ws * total, dtype=torch.uint8, device=y_local.device)
         if bufs is not None:
-            bufs.update(key=key, send=send, recv=recv)
+            bufs.update(key=key, send=send, recv=recv, checked=None, len_dev=None)
+    if bufs is None or bufs.get("len_dev") != S:
+        send[:HDR].view(torch.int64).fill_(S)
+        if bufs is not None:
+            bufs["len_dev"] = S
     if padding:
-        seams = send[:seam_bytes].view(y_local.dtype).view(2, C, padding)
-        seams[0].copy_(y_local[:, :padding])
-        seams[1].copy_(y_local[:, S - padding:])
+        seams = send[HDR:HDR + seam_bytes].view(y_local.dtype).view(2, C, padding)
+        if S >= padding:
+            seams[0].copy_(y_local[:, :padding])
+            seams[1].copy_(y_local[:, S - padding:])
+        else:   # short (last) shard: what lies beyond it is the zero padding of the recording's end
+            seams.zero_()
+            if S:
+                seams[0][:, :S].copy_(y_local)
+                seams[1][:, padding - S:].copy_(y_local)
     if rank == 0:
         send[sb:].view(torch.float64).copy_(thr)
     dist.all_gather_into_tensor(recv, send, group=group)
     recv = recv.view(ws, total)
+    if bufs is None or bufs.get("checked") != (S, chunk_size, padding):
+        lens = recv[:, :HDR].contiguous().view(torch.int64).flatten().cpu().tolist()   # one host sync, first call only
+        _check_shard_lengths(lens, chunk_size, padding)
+        if bufs is not None:
+            bufs["checked"] = (S, chunk_size, padding)
     thr_out = recv[0, sb:].view(torch.float64)
 
     def seam_of(r, which):
-        return recv[r, :seam_bytes].view(y_local.dtype).view(2, C, padding)[which]
+        return recv[r, HDR:HDR + seam_bytes].view(y_local.dtype).view(2, C, padding)[which]
 
     zero = torch.zeros((C, padding), dtype=y_local.dtype, device=y_local.device)
     left = seam_of(rank - 1, 1) if (rank > 0 and padding) else zero
@@ -205,24 +260,30 @@ class TimeShardedStationary:
             y_local = y_local[None, :]
         pad, cs = self.backend.padding, self.backend.chunk_size
         S = y_local.shape[1]
-        if self.ws > 1 and self.rank != self.ws - 1 and S % cs != 0:
-            raise ValueError("time shards must be chunk-aligned")
+        # (shard layout -- chunk alignment, lengths vs padding -- is validated collectively inside the
+        # exchange, from the gathered lengths: a rank-local raise here would strand the other ranks in
+        # the all-gather)
         # threshold: y_noise=None means "the first chunk_size samples of the recording"
         # (stationary.py:47-64); they live on rank 0, which broadcasts n_bins doubles.
-        if self.ws == 1:
-            self.backend.stats(y_local)
-            return self.backend.filter(y_local, y_local, 0, None, owner=True)
-        thr = self.backend.threshold(y_local) if self.rank == 0 else None
-        left, right, thr = exchange_seams_and_threshold(y_local, pad, thr, self.n_bins, self.group,
-                                                        self._bufs)
-        if pad == 0:
-            ext = y_local
-        elif ext is None:
-            ext = torch.cat([left, y_local, right], dim=1)
-        else:
-            ext[:, :pad].copy_(left)
-            ext[:, pad + S:].copy_(right)
-        return self.backend.filter(y_local, ext, pad, thr, owner=self.rank == 0)
+        # the statistics -> filter sequence depends on handle state: one call at a time per handle
+        lock = getattr(self.backend, "lock", None)
+        with (lock() if lock is not None else contextlib.nullcontext()):
+            if self.ws == 1:
+                self.backend.stats(y_local)
+                return self.backend.filter(y_local, y_local, 0, None, owner=True)
+            thr = self.backend.threshold(y_local) if self.rank == 0 else None
+            left, right, thr = exchange_seams_and_threshold(y_local, pad, thr, self.n_bins, self.group,
+                                                            self._bufs, chunk_size=cs)
+            if S == 0:      # more ranks than chunks: this rank took part in the exchange and has nothing to filter
+                return y_local.new_empty((y_local.shape[0], 0))
+            if pad == 0:
+                ext = y_local
+            elif ext is None:
+                ext = torch.cat([left, y_local, right], dim=1)
+            else:
+                ext[:, :pad].copy_(left)
+                ext[:, pad + S:].copy_(right)
+            return self.backend.filter(y_local, ext, pad, thr, owner=self.rank == 0)
 
 
 class ChannelShardedStationary:
@@ -242,7 +303,16 @@ class ChannelShardedStationary:
             y_local = y_local[None, :]
         C_local, N = y_local.shape
         c_total = C_local * self.ws if c_total is None else c_total
-        n_clip = min(N, self.backend.chunk_size)
+        kw = getattr(self.backend, "kw", {})
+        y_noise = kw.get("y_noise")
+        if y_noise is not None:
+            # an explicit noise clip is the same on every rank (stationary.py:47-58): no exchange at all
+            noise = y_noise if y_noise.dim() == 2 else y_noise[None, :]
+            return self.backend.filter_with_noise(y_local, noise, clip=kw.get("clip_noise_stationary", True))
+        # y_noise=None: the recording itself, clipped to chunk_size unless clip_noise_stationary=False
+        # or chunk_size=None (stationary.py:61-64)
+        cs = self.backend.chunk_size
+        n_clip = min(N, cs) if (kw.get("clip_noise_stationary", True) and cs is not None) else N
         clip_sum = y_local[:, :n_clip].to(torch.float64).sum(dim=0)
         if self.ws > 1:
             dist.all_reduce(clip_sum, op=dist.ReduceOp.SUM, group=self.group)
@@ -250,14 +320,15 @@ class ChannelShardedStationary:
         return self.backend.filter_with_noise(y_local, clip_mean)
 
 
-def _hip_filter_with_noise(self, y_local, noise):
-    """HipStationaryBackend: statistics from an explicit noise clip, then the chunk grid."""
+def _hip_filter_with_noise(self, y_local, noise, clip=False):
+    """HipStationaryBackend: statistics from an explicit noise clip, then the chunk grid.
+    clip=False: `noise` already IS the clip the statistics are taken from (the all-reduced channel mean)."""
     from noisereduce_amd.spectralgate.stationary import SpectralGateStationary
     kw = dict(self.kw)
     kw["y_noise"] = noise
-    sg = SpectralGateStationary(y=y_local, sr=self.sr, device=self.device, **kw)
-    S = y_local.shape[1]
-    return sg._gate.process_chunks(y_local, chunked=S > self.chunk_size)
+    kw["clip_noise_stationary"] = clip
+    sg = SpectralGateStationary(y=y_local, sr=self.sr, device=self.device, slot=self.slot, **kw)
+    return sg.get_traces()
 
 
 HipStationaryBackend.filter_with_noise = _hip_filter_with_noise

@@ -173,9 +173,15 @@ class SpectralGate:
             raise NotImplementedError
         is_np = isinstance(chunk, np.ndarray)
         dev = self._to_device(chunk)
-        out = self._gate.filter_padded(dev, out_dtype=dev.dtype if dev.dtype.is_floating_point
-                                       else torch.float64)
+        with self._gate.lock:
+            self._bind()
+            out = self._gate.filter_padded(dev, out_dtype=dev.dtype if dev.dtype.is_floating_point
+                                           else torch.float64)
         return out.cpu().numpy() if is_np else out
+
+    def _bind(self):
+        """Load per-object state into the shared engine handle (stationary gate: its threshold)."""
+
 
     def get_traces(self, start_frame=None, end_frame=None):
         """Grab filtered data iterating over chunks (base.py:167-226) -- on the device."""
@@ -187,6 +193,8 @@ class SpectralGate:
             end_frame = self.n_frames
         ydev = self._device_y()
         chunked = self._chunk_size is not None and end_frame - start_frame > self._chunk_size
-        out = self._gate.process_chunks(ydev, out_dtype=ydev.dtype, start_frame=start_frame,
-                                        end_frame=end_frame, chunked=chunked)
+        with self._gate.lock:
+            self._bind()
+            out = self._gate.process_chunks(ydev, out_dtype=ydev.dtype, start_frame=start_frame,
+                                            end_frame=end_frame, chunked=chunked)
         return self._finish(out)

@@ -11,7 +11,7 @@ class SpectralGateStationary(SpectralGate):
     def __init__(self, y, sr, y_noise, n_std_thresh_stationary, chunk_size,
                  clip_noise_stationary, padding, n_fft, win_length, hop_length, time_constant_s,
                  freq_mask_smooth_hz, time_mask_smooth_ms, tmp_folder, prop_decrease, use_tqdm,
-                 n_jobs, device="cuda"):
+                 n_jobs, device="cuda", slot=0):
         super().__init__(y=y, sr=sr, chunk_size=chunk_size, padding=padding, n_fft=n_fft,
                          win_length=win_length, hop_length=hop_length,
                          time_constant_s=time_constant_s,
@@ -35,18 +35,32 @@ class SpectralGateStationary(SpectralGate):
         if clip_noise_stationary and chunk_size is not None:
             noise_dev = noise_dev[:, :chunk_size]          # stationary.py:63-64
 
-        self._gate = _ffi.cached_gate(self.device, stationary=True, n_std_thresh=n_std_thresh_stationary,
-                               top_db=80.0, ddof=0, **self._gate_kwargs())
+        self._gate = _ffi.cached_gate(self.device, slot=slot, stationary=True,
+                                      n_std_thresh=n_std_thresh_stationary, top_db=80.0, ddof=0,
+                                      **self._gate_kwargs())
         # channel mean -> STFT -> dB -> per-band mean/std -> threshold (stationary.py:61-81),
-        # all on the device; the result stays there.
-        self._gate.noise_stats(noise_dev)
+        # all on the device; the result stays there.  The engine handle is shared by every object with
+        # the same settings, the threshold is NOT: like the reference (self.noise_thresh,
+        # stationary.py:79-81) it belongs to this object -- a float64 device tensor copied out of the
+        # handle here and loaded back by _bind() whenever another object used the handle in between.
+        self._token = object()   # identity of this object's threshold (no reference cycle through the handle)
+        with self._gate.lock:
+            self._gate.noise_stats(noise_dev)
+            self._thr_dev = self._gate.noise_threshold_tensor()
+            self._gate.thresh_owner = self._token
         self._noise_thresh = None
+
+    def _bind(self):
+        """Make the shared handle hold THIS object's threshold (caller holds self._gate.lock)."""
+        if self._gate.thresh_owner is not self._token:
+            self._gate.set_noise_threshold_tensor(self._thr_dev)
+            self._gate.thresh_owner = self._token
 
     @property
     def noise_thresh(self):
         """Per-band threshold in dB (stationary.py:79-81), fetched from the device on demand."""
         if self._noise_thresh is None:
-            self._noise_thresh = self._gate.get_noise_threshold()
+            self._noise_thresh = self._thr_dev.cpu().numpy()
         return self._noise_thresh
 
     def spectral_gating_stationary(self, chunk):

@@ -53,7 +53,7 @@ def test_random_configuration_matches_oracle(seed):
         # truncation to int16 (base.py:218-226): off by at most one count from the truncated oracle
         assert np.max(np.abs(got.astype(np.int64) - want.astype(np.int16).astype(np.int64))) <= 1
     else:
-        assert O.rel_err(got.astype(np.float64), want) < (TOL if dtype == "float64" else 2e-4), (kw, sr, C, n)
+        assert O.rel_err(got.astype(np.float64), want) < TOL, (kw, sr, C, n)
     # tensor input on the device: same numbers as the numpy path
     if dtype != "int16":
         got_t = nr.reduce_noise(y=torch.from_numpy(np.ascontiguousarray(y)).cuda(), sr=sr, **kw)
@@ -94,7 +94,7 @@ def test_random_torchgate_matches_oracle(seed):
     dt = torch.float32 if f32 else torch.float64
     got = tg(torch.from_numpy(x).to(dt).cuda(), None if xn is None else torch.from_numpy(xn).to(dt).cuda())
     assert got.dtype == dt and tuple(got.shape) == want.shape
-    assert O.rel_err(got.double().cpu().numpy(), want) < (2e-4 if f32 else TOL), (kw, sr, B, L, xn_shape)
+    assert O.rel_err(got.double().cpu().numpy(), want) < TOL, (kw, sr, B, L, xn_shape)
 
 
 def test_odd_input_containers():

@@ -272,7 +272,7 @@ def test_fast_decide_bits_equal_f64_decide(nr, kind, n_fft):
     assert np.array_equal(out_fast, out_f64)
     want = O.reduce_noise_S(y.astype(np.float64), 48000, stationary=True, chunk_size=50000, padding=6000,
                             n_fft=n_fft)
-    assert O.rel_err(out_fast, want) < 2e-4 if kind == "pure_tone" else O.rel_err(out_fast, want) < TOL
+    assert O.rel_err(out_fast, want) < TOL
 
 
 @pytest.mark.parametrize("kw", [dict(), dict(nonstationary=True), dict(n_fft=512, win_length=400, hop_length=100),

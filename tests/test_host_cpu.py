@@ -27,6 +27,11 @@ def test_cabi_library_exports_every_declared_symbol():
         assert hasattr(lib, name), name
     assert lib.sg_version() == 100
     assert lib.sg_stage_name(8) == b"k_apply_istft"
+    # and nothing else: the library is built with -fvisibility=hidden (no mangled kernel stubs leak)
+    import subprocess
+    out = subprocess.run(["nm", "-D", "--defined-only", _ffi.LIB_PATH], capture_output=True, text=True, check=True)
+    exported = {ln.split()[-1] for ln in out.stdout.splitlines() if ln.strip() and ln.split()[-2] in "TDBRW"}
+    assert exported == declared, sorted(exported ^ declared)
 
 
 def test_sg_params_struct_layout_matches_header():

@@ -128,3 +128,59 @@ def test_shard_bounds_cover_and_align():
         assert edges[0][0] == 0 and edges[-1][1] == n
         for (a0, a1), (b0, b1) in zip(edges, edges[1:]):
             assert a1 == b0 and (a1 % cs == 0 or a1 == n)
+
+
+# ---- edge layouts: short last shard, more ranks than chunks, collective validation ----
+def _worker_layout(rank, world, port, y, want, bounds, ret):
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    from noisereduce_amd.sharded import TimeShardedStationary
+    s0, s1 = bounds[rank]
+    y_local = y[:, s0:s1].contiguous()
+    try:
+        out = TimeShardedStationary(OracleBackend(), NFFT // 2 + 1).run(y_local)
+        err = float((out - want[:, s0:s1]).abs().max() / want.abs().max()) if s1 > s0 else 0.0
+        ret[rank] = ("ok", err, tuple(out.shape))
+    except ValueError as e:          # must be raised by EVERY rank (after the collective), never by one
+        ret[rank] = ("ValueError", str(e), None)
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def _run_layout(n, world, bounds=None):
+    from noisereduce_amd.sharded import shard_bounds
+    y = np.stack([O.synth_signal(n, seed=15).astype(np.float64)])
+    want = O.reduce_noise_S(y, SR, stationary=True, chunk_size=CS, padding=PAD, n_fft=NFFT)
+    if bounds is None:
+        bounds = [shard_bounds(n, CS, world, r) for r in range(world)]
+    mgr = mp.Manager()
+    ret = mgr.dict()
+    mp.spawn(_worker_layout, args=(world, _free_port(), torch.from_numpy(y), torch.from_numpy(want), bounds, ret),
+             nprocs=world, join=True)
+    return [ret[r] for r in range(world)], bounds
+
+
+def test_time_sharded_last_shard_shorter_than_padding():
+    # 1 full chunk + 1000 samples (< PAD = 3000): rank 1's shard is shorter than the seam it must send
+    res, bounds = _run_layout(CS + 1000, 2)
+    assert bounds == [(0, CS), (CS, CS + 1000)]
+    for kind, err, _ in res:
+        assert kind == "ok" and err < 1e-12, (kind, err)
+
+
+def test_time_sharded_more_ranks_than_chunks():
+    # 2 chunks on 3 ranks: rank 2 holds nothing, takes part in the exchange and returns an empty result
+    res, bounds = _run_layout(2 * CS - 5, 3)
+    assert bounds[2][0] == bounds[2][1]
+    assert res[2][0] == "ok" and res[2][2] == (1, 0)
+    for kind, err, _ in res[:2]:
+        assert kind == "ok" and err < 1e-12, (kind, err)
+
+
+def test_time_sharded_bad_layout_raises_on_every_rank():
+    # rank 0's shard is not chunk-aligned: every rank must raise (none may hang in the all-gather)
+    n = 2 * CS
+    res, _ = _run_layout(n, 2, bounds=[(0, CS + 17), (CS + 17, n)])
+    assert [r[0] for r in res] == ["ValueError", "ValueError"], res
+    assert "not chunk-aligned" in res[0][1] and res[0][1] == res[1][1]
