@@ -1,19 +1,26 @@
 #!/usr/bin/env python3
 """bench.py -- Msamples/s of reduce_noise on MI355X (BASELINE.json metric).
 
-Workload (configs[1]): synthetic 48 kHz mono, 10 min (28.8 M samples) of white noise + 1 kHz
-tone, float32, stationary reduce_noise, n_fft=1024, hop=256, chunk_size=600000,
-padding=30000.  One "step" = one whole reduce_noise pass over the recording, input and
-output resident in HBM (noise statistics + the full chunk grid: every kernel of the path).
+Default workload (configs[1]): synthetic 48 kHz mono, 10 min (28.8 M samples) of white noise + 1 kHz
+tone, float32, stationary reduce_noise, n_fft=1024, hop=256, chunk_size=600000, padding=30000.  One
+"step" = one whole reduce_noise pass over the recording, input and output resident in HBM (noise
+statistics + the full chunk grid: every kernel of the path).
 
-N GPUs (weak scaling): the recording is N x 10 min, time-sharded on chunk boundaries, one
-process per GPU; per step ONE all-gather carries every rank's seam samples (2*padding per rank)
-and rank 0's per-band threshold -- the only collective of the path.
+N GPUs (weak scaling), one process per GPU:
+  --workload config2 (default): the recording is N x 10 min, time-sharded on chunk boundaries; per step
+      ONE all-gather (RCCL) carries every rank's seam samples (2*padding per rank) and rank 0's per-band
+      threshold -- the only collective of the path.
+  --workload config4: BASELINE.json configs[3] -- 8 channels x 30 min per GPU (64 channels on 8 GPUs),
+      channel-sharded; per step ONE all-reduce of the noise clip's channel sum (stationary.py:61-64).
+  --workload config3: configs[2] (non-stationary), time-sharded like config2 (seam all-gather only).
 
-Prints ONE JSON line (rank 0).  `roofline` is for the dominant kernel of the step
-(HIP events around every launch, on the launch stream, inside the timed region);
-`cpu_baseline` times the numpy oracle (a port of the reference's CPU path) on a bounded
-sample of the same workload on the host cores.
+Prints ONE JSON line (rank 0).  `roofline` is for the dominant kernel of the step (HIP events around
+every launch, on the launch stream, inside the timed region); `cpu_baseline` times the numpy oracle (a
+port of the reference's CPU path) on the host cores: 1 core and a process pool over chunks (the
+reference's n_jobs semantics, base.py:206-216).  Extra keys (outside the timed region, N = 1 only):
+`other_configs` (configs[2], configs[4] forward / forward+backward, the PCIe-inclusive numpy->numpy
+rate), `parity` (the engine's result of this run against the oracle on one chunk), and at N > 1
+`distributed` (world size, backend, per-step collective time, per-rank oracle spot check, halo check).
 """
 import argparse
 import json
@@ -34,6 +41,7 @@ N_PER_GPU = SR * SECONDS            # 28.8 M samples
 CHUNK, PAD, NFFT, HOP = 600000, 30000, 1024, 256
 ALGO_BYTES_PER_SAMPLE = 8           # 4 B float32 read + 4 B float32 written
 HBM_PEAK_GBS = 8000.0               # MI355X_MICROARCH.md: 8 TB/s spec
+C4_CHANNELS, C4_SAMPLES = 8, SR * 1800   # configs[3]: one GPU's share
 
 
 def synth_on_device(n, seed, device, tone_hz=1000.0, offset=0):
@@ -45,9 +53,35 @@ def synth_on_device(n, seed, device, tone_hz=1000.0, offset=0):
     return (noise + 0.5 * torch.sin(2 * np.pi * tone_hz * t).float()).contiguous()
 
 
-def cpu_baseline():
-    """numpy oracle ("port") on the host: stationary reduce_noise of the first 60 s of the
-    workload (2.88 M samples = 5 chunks), 1 warm-up + median of 3."""
+# ---------------------------------------------------------------------------------------------
+# CPU baseline (oracle = port of the reference's numpy/scipy path)
+# ---------------------------------------------------------------------------------------------
+def _pool_chunk(args):
+    """One (chunk) unit of the reference's chunk grid on one host core (base.py:144-156)."""
+    seed_n, ich, thr, stationary = args
+    from oracle import spectralgate_oracle as O
+    y = _pool_chunk.cache.get(seed_n)
+    if y is None:
+        y = O.synth_signal(seed_n, dtype=np.float32).astype(np.float64)
+        _pool_chunk.cache[seed_n] = y
+    chunk = O.read_chunk(y[None, :], ich * CHUNK - PAD, (ich + 1) * CHUNK + PAD)
+    filt = O.smoothing_filter(5, 9)
+    if stationary:
+        out = O.gate_stationary_S(chunk, thr, NFFT, NFFT, HOP, 1.0, filt)
+    else:
+        out = O.gate_nonstationary_S(chunk, NFFT, NFFT, HOP, 1.0, filt, O.iir_coefficient(2.0, SR, HOP), 2, 10)
+    return float(out[0, PAD]), ich
+
+
+_pool_chunk.cache = {}
+
+
+def cpu_baseline(budget_s=25.0):
+    """(a) 1 core: stationary reduce_noise of the first 60 s of the workload (5 chunks), 1 warm-up +
+    median of 3.  (b) all cores: the 48 chunks of the full 10-min workload dealt to a process pool
+    (one chunk per task = the reference's joblib n_jobs semantics, base.py:206-216), median of 3 after
+    one warm-up pass (which also generates each worker's copy of the recording)."""
+    import multiprocessing as mp
     from oracle import spectralgate_oracle as O
     n = SR * 60
     y = O.synth_signal(n, dtype=np.float32).astype(np.float64)
@@ -57,22 +91,53 @@ def cpu_baseline():
         O.reduce_noise_S(y, SR, stationary=True, n_fft=NFFT, chunk_size=CHUNK, padding=PAD)
         times.append(time.perf_counter() - t0)
     med = float(np.median(times[1:]))
-    return {"value": round(n / med / 1e6, 3), "unit": "Msamples/s", "cores": 1, "kind": "port",
-            "sample": "first 60 s (2.88 M samples, 5 chunks) of the workload, stationary, "
-                      "oracle/spectralgate_oracle.py reduce_noise_S, float64, numpy single thread, "
-                      "median of 3 after 1 warm-up; os.cpu_count()=%d" % (os.cpu_count() or 0)}
+    res = {"value": round(n / med / 1e6, 3), "unit": "Msamples/s", "cores": 1, "kind": "port",
+           "sample": "first 60 s (2.88 M samples, 5 chunks) of the workload, stationary, "
+                     "oracle/spectralgate_oracle.py reduce_noise_S, float64, numpy single thread, "
+                     "median of 3 after 1 warm-up; os.cpu_count()=%d" % (os.cpu_count() or 0)}
+    # multi-core leg
+    try:
+        n_chunks = N_PER_GPU // CHUNK
+        workers = max(1, min(n_chunks, (os.cpu_count() or 1)))
+        yfull = O.synth_signal(N_PER_GPU, dtype=np.float32).astype(np.float64)
+        thr, _, _ = O.noise_threshold_S(yfull[None, :CHUNK], NFFT, NFFT, HOP, 1.5, CHUNK)
+        del yfull
+        ctx = mp.get_context("spawn")     # never fork a process that holds a HIP context
+        tasks = [(N_PER_GPU, i, thr, True) for i in range(n_chunks)]
+        t_start = time.perf_counter()
+        with ctx.Pool(workers) as pool:
+            ts = []
+            for rep in range(4):
+                t0 = time.perf_counter()
+                pool.map(_pool_chunk, tasks, chunksize=1)
+                ts.append(time.perf_counter() - t0)
+                if time.perf_counter() - t_start > budget_s and rep >= 1:
+                    break
+        medp = float(np.median(ts[1:])) if len(ts) > 1 else ts[0]
+        res["multicore"] = {"value": round(N_PER_GPU / medp / 1e6, 2), "unit": "Msamples/s", "cores": workers,
+                            "kind": "port", "sample": "all %d chunks of the 10-min workload, one chunk per task in a "
+                            "%d-process pool (n_jobs semantics of base.py:206-216), threshold precomputed, "
+                            "median of %d passes after 1 warm-up" % (n_chunks, workers, max(1, len(ts) - 1))}
+    except Exception as e:  # the single-core number stands on its own
+        res["multicore"] = {"error": repr(e)}
+    return res
 
 
+# ---------------------------------------------------------------------------------------------
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=20)
     ap.add_argument("--warmup", type=int, default=5)
     ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--nonstationary", action="store_true", help="configs[2] instead of configs[1]")
+    ap.add_argument("--no-extras", action="store_true", help="skip other_configs / parity legs")
+    ap.add_argument("--workload", choices=["config2", "config3", "config4"], default="config2")
+    ap.add_argument("--nonstationary", action="store_true", help="alias of --workload config3")
     ap.add_argument("--streams", type=int, default=1,
                     help="independent calls in flight on separate HIP streams (serving mode; default 1)")
     args = ap.parse_args()
+    if args.nonstationary:
+        args.workload = "config3"
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
@@ -81,76 +146,97 @@ def main():
         raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}: launch with torch.distributed.run")
     # BENCH_BACKEND=gloo lets the multi-rank code path be exercised on a box with fewer GPUs than
     # ranks (ranks share devices; RCCL itself refuses that) -- a functional check, not a measurement.
-    backend = os.environ.get("BENCH_BACKEND", "nccl")
+    pg_backend = os.environ.get("BENCH_BACKEND", "nccl")
     ndev = torch.cuda.device_count()
-    dev_index = local_rank if backend == "nccl" else local_rank % max(ndev, 1)
+    dev_index = local_rank if pg_backend == "nccl" else local_rank % max(ndev, 1)
     torch.cuda.set_device(dev_index)
     device = torch.device("cuda", dev_index)
     if world > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        if backend == "nccl":
+        if pg_backend == "nccl":
             dist.init_process_group("nccl", device_id=device)
         else:
-            dist.init_process_group(backend)
+            dist.init_process_group(pg_backend)
 
     import __graft_entry__
     if rank == 0:
         __graft_entry__.build()
     if world > 1:
         dist.barrier()
-    from noisereduce_amd.sharded import HipStationaryBackend, TimeShardedStationary, alloc_shard, with_halos
-    from noisereduce_amd.spectralgate.nonstationary import SpectralGateNonStationary
+    from noisereduce_amd.sharded import (ChannelShardedStationary, HipStationaryBackend, TimeShardedStationary,
+                                         alloc_shard, with_halos)
+    from noisereduce_amd.spectralgate.nonstationary import SpectralGateNonStationary, iir_coefficient
+    from oracle import spectralgate_oracle as O   # checker only, never inside the timed region
 
-    # this rank's time shard of the (world x 10 min) recording
-    # (allocated inside a halo-extended buffer so that the seam exchange writes 2*padding samples
-    # per step instead of re-copying the shard)
-    y_ext, y2d = alloc_shard(1, N_PER_GPU, PAD, torch.float32, device)
-    y2d[0].copy_(synth_on_device(N_PER_GPU, 1234 + rank, device, offset=rank * N_PER_GPU))
-    y = y2d[0]
-    stationary = not args.nonstationary
-
+    wl = args.workload
+    stationary = wl != "config3"
     backend = HipStationaryBackend(SR, device, chunk_size=CHUNK, padding=PAD, n_fft=NFFT)
+    n_streams = max(1, args.streams) if wl == "config2" else 1
+
+    if wl == "config4":
+        # this rank's 8 channels of the (8 * world)-channel recording, generated on the device
+        y2d = torch.empty((C4_CHANNELS, C4_SAMPLES), dtype=torch.float32, device=device)
+        for c in range(C4_CHANNELS):
+            gc = rank * C4_CHANNELS + c
+            y2d[c] = synth_on_device(C4_SAMPLES, 1234 + gc, device, tone_hz=200.0 * (gc + 1))
+        y_ext = None
+        samples_per_gpu = C4_CHANNELS * C4_SAMPLES
+        csg = ChannelShardedStationary(backend)
+    else:
+        # this rank's time shard of the (world x 10 min) recording (allocated inside a halo-extended buffer
+        # so that the seam exchange writes 2*padding samples per step instead of re-copying the shard)
+        y_ext, y2d = alloc_shard(1, N_PER_GPU, PAD, torch.float32, device)
+        y2d[0].copy_(synth_on_device(N_PER_GPU, 1234 + rank, device, offset=rank * N_PER_GPU))
+        samples_per_gpu = N_PER_GPU
+    y = y2d[0]
+    torch.cuda.synchronize(device)
+
     # --streams S > 1 (serving mode, not the default): S independent calls in flight, each on its own
-    # HIP stream with its own engine handle -- the latency-bound statistics chain and the kernel tails
-    # of one call hide under the kernels of another.  The default times one call at a time.
-    n_streams = max(1, args.streams) if stationary else 1
+    # HIP stream with its own engine handle and (N > 1) its own halo-extended buffer.
     backends = [backend] + [HipStationaryBackend(SR, device, slot=i, chunk_size=CHUNK, padding=PAD, n_fft=NFFT)
                             for i in range(1, n_streams)]
     streams = [torch.cuda.current_stream(device)] + [torch.cuda.Stream(device) for _ in range(1, n_streams)]
+    exts = [y_ext]
+    for s in streams[1:]:
+        s.wait_stream(torch.cuda.current_stream(device))      # the shard was synthesised on the default stream
+        if world > 1:
+            e, sh = alloc_shard(1, N_PER_GPU, PAD, torch.float32, device)
+            sh.copy_(y2d)
+            exts.append(e)
+        else:
+            exts.append(None)
+    torch.cuda.synchronize(device)
     step_no = [0]
 
-    def make_gate():
-        if stationary:
-            return TimeShardedStationary(backend, NFFT // 2 + 1)
-        return SpectralGateNonStationary(
+    nonstat_gate = None
+    if wl == "config3":
+        nonstat_gate = SpectralGateNonStationary(
             y=y, sr=SR, chunk_size=CHUNK, padding=PAD, n_fft=NFFT, win_length=None, hop_length=None,
             time_constant_s=2.0, freq_mask_smooth_hz=500, time_mask_smooth_ms=50,
             thresh_n_mult_nonstationary=2, sigmoid_slope_nonstationary=10, tmp_folder=None,
-            prop_decrease=1.0, use_tqdm=False, n_jobs=1, device=device)
+            prop_decrease=1.0, use_tqdm=False, n_jobs=1, device=device)._gate
 
-    def gate_of(sg):
-        return sg.backend._gate() if stationary else sg._gate
+    def engine_gate():
+        return nonstat_gate if wl == "config3" else backend._gate()
 
     def step():
-        # one whole reduce_noise: statistics + (seam, threshold) all-gather + chunk grid.
-        # The engine handle (tables + workspace) is cached across calls by noisereduce_amd._ffi.
-        if stationary and n_streams > 1:
+        # one whole reduce_noise: statistics + exchange + chunk grid.  The engine handle (tables +
+        # workspace) is cached across calls by noisereduce_amd._ffi.
+        if wl == "config4":
+            return csg.run(y2d, c_total=C4_CHANNELS * world)
+        if wl == "config2":
             i = step_no[0] % n_streams
             step_no[0] += 1
-            with torch.cuda.stream(streams[i]):
-                return TimeShardedStationary(backends[i], NFFT // 2 + 1).run(y2d, ext=y_ext if world > 1 else None)
-        sg = make_gate()
-        if stationary:
-            out = sg.run(y2d, ext=y_ext if world > 1 else None)
-        else:
-            gate = sg._gate
-            ext = with_halos(y2d, PAD, ext=y_ext) if world > 1 else None
-            if ext is None:
-                out = gate.process_chunks(y2d, chunked=True)
-            else:
-                out = gate.process_chunks(ext, out_dtype=y.dtype, chunked=True, halo_left=PAD,
-                                          halo_right=PAD)
-        return out
+            if n_streams > 1:
+                with torch.cuda.stream(streams[i]):
+                    return TimeShardedStationary(backends[i], NFFT // 2 + 1).run(
+                        y2d if i == 0 or world == 1 else exts[i][:, PAD:PAD + N_PER_GPU],
+                        ext=exts[i] if world > 1 else None)
+            return TimeShardedStationary(backend, NFFT // 2 + 1).run(y2d, ext=y_ext if world > 1 else None)
+        ext = with_halos(y2d, PAD, ext=y_ext) if world > 1 else None
+        if ext is None:
+            return nonstat_gate.process_chunks(y2d, chunked=True)
+        return nonstat_gate.process_chunks(ext, out_dtype=y.dtype, chunked=True, halo_left=PAD, halo_right=PAD)
 
     def sync():
         if world > 1:
@@ -159,7 +245,7 @@ def main():
 
     for _ in range(args.warmup):
         step()
-    gate = gate_of(make_gate())
+    gate = engine_gate()
     # untimed survey pass: every kernel bracketed by HIP events -> per-kernel table + dominant kernel
     gate.profile_read(reset=True)
     gate.profile_select(None)
@@ -169,24 +255,88 @@ def main():
         step()
     survey = gate.profile_read(reset=True)
     dom = max(survey, key=lambda k: survey[k][0])
-    # timed region: HIP events (on the launch stream) only around the dominant kernel
+    # timed region: HIP events (on the launch stream) only around the dominant kernel, plus one event per
+    # step boundary (median of the per-step times next to the mean)
     gate.profile_select([dom])
+    marks = [torch.cuda.Event(enable_timing=True) for _ in range(args.steps + 1)] if n_streams == 1 else None
     sync()
     t0 = time.perf_counter()
-    for _ in range(args.steps):
-        step()
+    for i in range(args.steps):
+        if marks:
+            marks[i].record()
+        out = step()
+    if marks:
+        marks[args.steps].record()
     sync()
     elapsed = time.perf_counter() - t0
     profs = [gate.profile_read(reset=True)]
     gate.profile_enable(False)
     gate.profile_select(None)
+    per_step = [marks[i].elapsed_time(marks[i + 1]) for i in range(args.steps)] if marks else None
     if world > 1:
         tt = torch.tensor([elapsed], device=device, dtype=torch.float64)
         dist.all_reduce(tt, op=dist.ReduceOp.MAX)
         elapsed = float(tt.item())
 
+    # ---- outside the timed region: distributed checks (every rank), then rank-0 extras -------------
+    distributed = None
+    if world > 1:
+        info = {}
+        if wl != "config4":
+            # (1) the halo this rank received equals the neighbour's samples (regenerated here)
+            ok = True
+            if rank > 0:
+                left = synth_on_device(N_PER_GPU, 1234 + rank - 1, device, offset=(rank - 1) * N_PER_GPU)[-PAD:]
+                ok &= bool(torch.equal(y_ext[0, :PAD], left))
+            if rank < world - 1:
+                right = synth_on_device(N_PER_GPU, 1234 + rank + 1, device, offset=(rank + 1) * N_PER_GPU)[:PAD]
+                ok &= bool(torch.equal(y_ext[0, PAD + N_PER_GPU:], right))
+            info["halo_ok"] = ok
+            # (2) oracle on this rank's FIRST chunk (its window reaches into the left neighbour's shard)
+            eh = y_ext[0, :CHUNK + 2 * PAD].cpu().numpy().astype(np.float64)[None, :]
+            filt = O.smoothing_filter(5, 9)
+            if stationary:
+                thr = gate.get_noise_threshold()
+                ref = O.gate_stationary_S(eh, thr, NFFT, NFFT, HOP, 1.0, filt)[0, PAD:PAD + CHUNK]
+            else:
+                ref = O.gate_nonstationary_S(eh, NFFT, NFFT, HOP, 1.0, filt, iir_coefficient(2.0, SR, HOP), 2, 10)[0, PAD:PAD + CHUNK]
+            info["rel_err_chunk0"] = O.rel_err(out[0, :CHUNK].cpu().numpy(), ref)
+        else:
+            # oracle on (local channel 3, chunk 1) with the threshold the engine derived from the all-reduced clip
+            from noisereduce_amd.spectralgate.stationary import SpectralGateStationary  # noqa: F401
+            thr_t = engine_gate().noise_threshold_tensor().cpu().numpy()
+            c, ich = 3, 1
+            s0 = ich * CHUNK
+            chunk = y2d[c, s0 - PAD:s0 + CHUNK + PAD].cpu().numpy().astype(np.float64)[None, :]
+            ref = O.gate_stationary_S(chunk, thr_t, NFFT, NFFT, HOP, 1.0, O.smoothing_filter(5, 9))[0, PAD:PAD + CHUNK]
+            info["rel_err_unit"] = O.rel_err(out[c, s0:s0 + CHUNK].cpu().numpy(), ref)
+        # (3) collective time per step: the exchange alone, same payload, 20 repetitions
+        torch.cuda.synchronize(device)
+        dist.barrier()
+        tc0 = time.perf_counter()
+        reps = 20
+        for _ in range(reps):
+            if wl == "config4":
+                cs_ = y2d[:, :CHUNK].to(torch.float64).sum(dim=0)
+                dist.all_reduce(cs_, op=dist.ReduceOp.SUM)
+            else:
+                with_halos(y2d, PAD, ext=y_ext)
+        torch.cuda.synchronize(device)
+        info["collective_ms"] = (time.perf_counter() - tc0) / reps * 1e3
+        gathered = [None] * world
+        dist.all_gather_object(gathered, info)
+        distributed = {"world_size": world, "backend": pg_backend + (" (RCCL)" if pg_backend == "nccl" else ""),
+                       "collective": ("all_reduce(sum) of the noise clip's channel sum, %d float64" % CHUNK)
+                       if wl == "config4" else "all_gather of [shard length | 2*padding seam samples | threshold] per rank",
+                       "collective_ms_per_step_max": round(max(g["collective_ms"] for g in gathered), 4),
+                       "per_rank": gathered}
+        bad = [g for g in gathered if g.get("halo_ok") is False or max(g.get("rel_err_chunk0", 0), g.get("rel_err_unit", 0)) > 1e-4]
+        if bad and rank == 0:
+            print("bench.py: distributed parity check FAILED: %r" % (gathered,), file=sys.stderr)
+        distributed["parity_ok"] = not bad
+
     if rank == 0:
-        total = float(N_PER_GPU) * world * args.steps
+        total = float(samples_per_gpu) * world * args.steps
         value = total / elapsed / 1e6
         # dominant kernel over the timed region
         agg = {}
@@ -199,41 +349,138 @@ def main():
         # the event pairs live in the handle of stream 0: it ran every n_streams-th step
         steps_profiled = (args.steps + n_streams - 1) // n_streams
         launches_per_step = agg[dom][1] / steps_profiled
-        algo_bytes = ALGO_BYTES_PER_SAMPLE * N_PER_GPU / launches_per_step
+        algo_bytes = ALGO_BYTES_PER_SAMPLE * samples_per_gpu / launches_per_step
         achieved = algo_bytes / (avg_ms * 1e-3) / 1e9
         traffic = None
         tp = os.path.join(ROOT, "profiles", "traffic.json")
-        if os.path.exists(tp):
+        traffic_src = None
+        if wl == "config2" and os.path.exists(tp):
             try:
                 traffic = json.load(open(tp)).get(dom)
+                traffic_src = ("profiles/traffic.json: rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of this "
+                               "workload (FETCH_SIZE x2 corrected), committed -- NOT measured in this run")
             except Exception:
                 traffic = None
+        desc = {"config2": "configs[1]: synthetic 48 kHz mono 10 min per GPU, stationary reduce_noise",
+                "config3": "configs[2]: synthetic 48 kHz mono 10 min per GPU, non-stationary reduce_noise",
+                "config4": "configs[3]: synthetic 48 kHz, 8 channels x 30 min per GPU (64 channels on 8 GPUs), "
+                           "stationary reduce_noise"}[wl]
         line = {
-            "metric": "Msamples/s reduce_noise (48 kHz mono, n_fft=1024)",
+            "metric": "Msamples/s reduce_noise (48 kHz mono, n_fft=1024)" if wl != "config4"
+                      else "Msamples/s reduce_noise (48 kHz 64-channel, n_fft=1024)",
             "value": round(value, 1), "unit": "Msamples/s", "n_gpus": world, "steps": args.steps,
             "warmup": args.warmup, "ms_per_step": round(elapsed / args.steps * 1e3, 4),
             "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32",
             "data": "synthetic",
-            "config": {"workload": ("configs[1]" if stationary else "configs[2]") +
-                       ": synthetic 48 kHz mono 10 min per GPU, %s reduce_noise, n_fft=1024 hop=256, "
-                       "chunk_size=600000 padding=30000, float32 in/out resident in HBM"
-                       % ("stationary" if stationary else "non-stationary"),
-                       "samples_per_gpu": N_PER_GPU, "sharding": "time (chunk-aligned), seam all-gather",
+            "config": {"workload": desc + ", n_fft=1024 hop=256, chunk_size=600000 padding=30000, "
+                                          "float32 in/out resident in HBM",
+                       "samples_per_gpu": samples_per_gpu,
+                       "sharding": "channels (8 per GPU), all-reduce of the clip's channel sum" if wl == "config4"
+                                   else "time (chunk-aligned), seam all-gather",
                        "calls_in_flight": n_streams},
             "roofline": {"bound": "hbm", "kernel": dom, "achieved": round(achieved, 2), "peak": HBM_PEAK_GBS,
                          "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBS, 5), "traffic": traffic,
+                         "traffic_source": traffic_src,
                          "avg_launch_ms": round(avg_ms, 4), "algorithmic_bytes_per_launch": int(algo_bytes),
                          "whole_step_frac": round(value * 1e6 / world * ALGO_BYTES_PER_SAMPLE / 1e9
                                                   / HBM_PEAK_GBS, 5)},
             "kernel_ms_per_step": {k: round(v[0] / survey_steps, 4) for k, v in
                                    sorted(survey.items(), key=lambda kv: -kv[1][0])},
         }
+        if per_step:
+            line["ms_per_step_median"] = round(float(np.median(per_step)), 4)
+            line["ms_per_step_min"] = round(float(np.min(per_step)), 4)
+            line["value_at_median_step"] = round(samples_per_gpu * world / (float(np.median(per_step)) * 1e-3) / 1e6, 1)
+        if distributed:
+            line["distributed"] = distributed
+        if world == 1 and not args.no_extras:
+            line.update(extras(device, wl, out, y2d, gate, O))
         if world == 1 and not args.no_cpu_baseline:
             line["cpu_baseline"] = cpu_baseline()
         print(json.dumps(line))
     if world > 1:
         dist.barrier()
         dist.destroy_process_group()
+
+
+def _time_events(fn, warm, reps):
+    """median / mean milliseconds of fn() from HIP events on the current stream."""
+    for _ in range(warm):
+        fn()
+    ev = [torch.cuda.Event(enable_timing=True) for _ in range(reps + 1)]
+    for i in range(reps):
+        ev[i].record()
+        fn()
+    ev[reps].record()
+    torch.cuda.synchronize()
+    ts = [ev[i].elapsed_time(ev[i + 1]) for i in range(reps)]
+    return float(np.median(ts)), float(np.mean(ts))
+
+
+def extras(device, wl, out, y2d, gate, O):
+    """Legs the driver cannot otherwise see (all OUTSIDE the timed region): parity of THIS run's output
+    against the oracle on one chunk, the other BASELINE configs (device-resident), the PCIe-inclusive rate."""
+    import noisereduce_amd as nr
+    from noisereduce_amd.spectralgate.nonstationary import iir_coefficient
+    from noisereduce_amd.torchgate import TorchGate
+    res = {}
+    # -- parity of the run just timed: one whole chunk (chunk 1: both halos are real samples)
+    filt = O.smoothing_filter(5, 9)
+    ich = 1
+    yh = y2d[0, ich * CHUNK - PAD:(ich + 1) * CHUNK + PAD].cpu().numpy().astype(np.float64)[None, :]
+    if wl == "config3":
+        ref = O.gate_nonstationary_S(yh, NFFT, NFFT, HOP, 1.0, filt, iir_coefficient(2.0, SR, HOP), 2, 10)
+        thr_err = None
+    else:
+        if wl == "config4":
+            clip = y2d[:, :CHUNK].cpu().numpy().astype(np.float64)
+        else:
+            clip = y2d[:1, :CHUNK].cpu().numpy().astype(np.float64)
+        thr, _, _ = O.noise_threshold_S(clip, NFFT, NFFT, HOP, 1.5, CHUNK)
+        thr_err = float(np.max(np.abs(gate.get_noise_threshold() - thr)))
+        ref = O.gate_stationary_S(yh, thr, NFFT, NFFT, HOP, 1.0, filt)
+    got = out[0, ich * CHUNK:(ich + 1) * CHUNK].cpu().numpy()
+    res["parity"] = {"rel_err_vs_oracle": O.rel_err(got, ref[0, PAD:PAD + CHUNK]), "tolerance": 1e-4,
+                     "checked": "channel 0, chunk 1 (600000 samples) of the last timed step, oracle float64",
+                     "threshold_max_abs_err_db": thr_err}
+    if wl != "config2":
+        return res
+    oc = {}
+    y = y2d[0]
+    med, mean = _time_events(lambda: nr.reduce_noise(y=y, sr=SR, stationary=False), 3, 10)
+    oc["config3_nonstationary"] = {"ms_median": round(med, 4), "ms_mean": round(mean, 4),
+                                   "Msamples_s": round(y.numel() / (med * 1e-3) / 1e6, 1),
+                                   "what": "configs[2]: same recording, stationary=False, device-resident"}
+    torch.manual_seed(0)
+    t = torch.arange(16000, device=device, dtype=torch.float64) / 16000
+    x = (0.1 * torch.randn(256, 16000, device=device) + 0.5 * torch.sin(2 * np.pi * 440 * t).float()).float()
+    tg = TorchGate(sr=16000).to(device)
+    med, mean = _time_events(lambda: tg(x), 10, 50)
+    oc["config5_torchgate_forward"] = {"ms_median": round(med, 4), "ms_mean": round(mean, 4),
+                                       "Msamples_s": round(x.numel() / (med * 1e-3) / 1e6, 1),
+                                       "what": "configs[4]: TorchGate(sr=16000) on 256 x 16000 float32"}
+    xg = x.clone().requires_grad_()
+
+    def fb():
+        xg.grad = None
+        tg(xg).sum().backward()
+    med, mean = _time_events(fb, 10, 50)
+    oc["config5_torchgate_forward_backward"] = {"ms_median": round(med, 4), "ms_mean": round(mean, 4),
+                                                "Msamples_s": round(x.numel() / (med * 1e-3) / 1e6, 1)}
+    # PCIe-inclusive: numpy in -> numpy out (H2D + compute + D2H), wall clock
+    yh = y.cpu().numpy()
+    ts = []
+    for i in range(7):
+        t0 = time.perf_counter()
+        nr.reduce_noise(y=yh, sr=SR, stationary=True)
+        ts.append(time.perf_counter() - t0)
+    medh = float(np.median(ts[2:]))
+    oc["config2_numpy_to_numpy_pcie_inclusive"] = {
+        "ms_median": round(medh * 1e3, 3), "Msamples_s": round(yh.size / medh / 1e6, 1),
+        "what": "host float32 array in, host array out (63 GB/s PCIe each way bounds this at 7.9 Gsamples/s); "
+                "never the headline value"}
+    res["other_configs"] = oc
+    return res
 
 
 if __name__ == "__main__":
