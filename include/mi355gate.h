@@ -183,6 +183,7 @@ SG_API int sg_debug_fetch(sg_handle* h, int32_t what, void* host, int64_t bytes,
 #define SG_OPT_FORCE_F64_DECIDE 3 /* value != 0: decide every mask cell from a float64 STFT */
 #define SG_OPT_FORCE_NOSEAM 4   /* value != 0: overlapping apply tiles instead of abutting tiles + seam kernel */
 #define SG_OPT_FORCE_NOLEAN 5   /* value != 0: apply kernel with full-size LDS slices and stored frames */
+#define SG_OPT_FORCE_SPLIT 6    /* value != 0: default geometry: decide / smooth / apply as three kernels instead of the one-pass kernel */
 #define SG_OPT_FORCE_NOFAST 2  /* value != 0: keep the bit-mask stages but use the general apply kernels */
 SG_API int sg_set_option(sg_handle* h, int32_t option, int64_t value);
 
@@ -203,7 +204,8 @@ SG_API int sg_set_option(sg_handle* h, int32_t option, int64_t value);
 #define SG_STAGE_STFT_BITS 13
 #define SG_STAGE_APPLY_FAST 14
 #define SG_STAGE_DECIDE_FAST 15
-#define SG_N_STAGES 16
+#define SG_STAGE_ONEPASS 16
+#define SG_N_STAGES 17
 /* When enabled, every kernel launch is bracketed by a hipEvent pair recorded on the launch
  * stream.  sg_profile_read synchronises those events and returns accumulated milliseconds
  * and launch counts per stage (arrays of SG_N_STAGES); reset != 0 clears the accumulators. */

@@ -15,6 +15,7 @@
 #include "kernels.hpp"
 #include "fused.hpp"
 #include "czt.hpp"
+#include "onepass.hpp"
 
 #ifndef SG_APPLY_WAVES
 #define SG_APPLY_WAVES 4  // wavefronts per workgroup of k_apply_fast: tile = 4*W frames -> 4*W-3 hops
@@ -57,6 +58,13 @@ struct sg_handle {
   DevBuf tw512, invn;                // fast path tables (n_fft = 1024, hop = 256)
   DevBuf seam;                       // partial seam hops of abutting apply tiles
   DevBuf ftab;                       // k_smooth_bits2 phase-1 lookup tables (nf <= 5)
+  // one-pass gate (onepass.hpp): published mask bits per tile, publication flags, work counter, tables
+  DevBuf xbits, xflags, xticket, ftab3;
+  unsigned epoch = 0;                // launch counter: the value a tile's flag must carry to be current
+  bool force_split = false;          // SG_OPT_FORCE_SPLIT: decide / smooth / apply as three kernels
+  bool dbg_xbits = false;            // the last batch's mask bits live in xbits (tile-blocked)
+  int64_t dbg_tf0 = 0;               // first frame of tile 0 of that batch
+  int dbg_ntt = 0;                   // tiles per unit incl. the two halo tiles
   int czt_M = 0;                     // > 0: n_fft is not a power of two -> chirp-z kernels (czt.hpp) of size M
   DevBuf czt_tw64, czt_ch64, czt_bh64, czt_tw32, czt_ch32, czt_bh32;
   bool force_noseam = false;
@@ -649,6 +657,24 @@ extern "C" int sg_create(const sg_params* p, const double* window_host, sg_handl
         tab[half * 512 + v] = packed;
       }
     rc = upload(h, h->ftab, tab.data(), tab.size() * sizeof(unsigned long long));
+    // the same counts from three 6-bit slices of the window (1.5 KB: lives in LDS next to the one-pass
+    // kernel's other tables)
+    std::vector<unsigned long long> tab3(192, 0ull);
+    for (int j = 0; j < 3; ++j)
+      for (int v = 0; v < 64; ++v) {
+        unsigned long long packed = 0;
+        for (int e = 0; e < 8; ++e) {
+          int cnt = 0;
+          for (int b = 0; b < 6; ++b)
+            if ((v >> b) & 1) {
+              int a = (j * 6 + b) - nf - e;
+              if (a >= -nf && a <= nf) cnt += nf + 1 - (a < 0 ? -a : a);
+            }
+          packed |= (unsigned long long)cnt << (8 * e);
+        }
+        tab3[j * 64 + v] = packed;
+      }
+    if (!rc) rc = upload(h, h->ftab3, tab3.data(), tab3.size() * sizeof(unsigned long long));
   }
   if (!rc) rc = ensure(h, h->thresh, (size_t)h->FS * sizeof(double));
   if (rc) {
@@ -667,7 +693,8 @@ extern "C" int sg_destroy(sg_handle* h) {
   for (auto e : h->prof_pool) (void)hipEventDestroy(e);
   for (DevBuf* b : {&h->tw64, &h->tw32, &h->wfull64, &h->wa32, &h->ws32, &h->wsq32, &h->kf, &h->kt, &h->thresh,
                     &h->P, &h->pmax, &h->thr_rows, &h->raw, &h->M, &h->seg, &h->yn, &h->bits, &h->K16, &h->umax,
-                    &h->need, &h->T2, &h->part, &h->tw512, &h->invn, &h->seam, &h->ftab, &h->czt_tw64, &h->czt_ch64,
+                    &h->need, &h->T2, &h->part, &h->tw512, &h->invn, &h->seam, &h->ftab, &h->xbits, &h->xflags,
+                    &h->xticket, &h->ftab3, &h->czt_tw64, &h->czt_ch64,
                     &h->czt_bh64, &h->czt_tw32, &h->czt_ch32, &h->czt_bh32})
     free_buf(*b);
   delete h;
@@ -953,18 +980,13 @@ static int stage_smooth_bits(sg_handle* h, const Geom& g, int64_t ub, bool fast,
   return SG_OK;
 }
 
-// Fused stationary mask (variant S): STFT(f64) -> bits -> integer smoothing -> K16 -> float mask.
-static int stage_fused_mask(sg_handle* h, const View& v, const Geom& g, int64_t ub, bool fast, int64_t tb,
-                            int64_t te, hipStream_t st) {
-  // [tb, te): frames whose smoothed mask is needed; decisions are needed nt frames further out
-  const int64_t nt_halo = h->p.smooth_mask ? h->p.n_grad_time : 0;
-  const int64_t db = std::max<int64_t>(0, tb - nt_halo), de = std::min<int64_t>(g.T, te + nt_halo);
-  h->dbg_db = (fast && !h->force_f64_decide) ? db : 0;
-  h->dbg_de = (fast && !h->force_f64_decide) ? de : g.T;
+// Compare constants + per-unit floor flags + (rare) float64 floor pre-pass: what every decision kernel of
+// the fused stationary path needs before it can run.
+static int stage_prep_floor(sg_handle* h, const View& v, const Geom& g, int64_t ub, ThreshConsts* tc_out,
+                            hipStream_t st) {
   const int wpr = (g.F + 63) / 64;
   int rc;
   if ((rc = ensure(h, h->bits, (size_t)ub * g.T * wpr * 8))) return rc;
-  if ((rc = ensure(h, h->K16, (size_t)ub * g.T * g.FS * 2))) return rc;
   if ((rc = ensure(h, h->umax, (size_t)ub * 4))) return rc;
   if ((rc = ensure(h, h->need, (size_t)ub * 4))) return rc;
   if ((rc = ensure(h, h->T2, (size_t)g.FS * 8))) return rc;
@@ -987,6 +1009,24 @@ static int stage_fused_mask(sg_handle* h, const View& v, const Geom& g, int64_t 
     HIPCHK(h, launch_bits<0>(h->N, v, g, ub, h->tw64.p, h->wfull64.p, tc, h->mag_scale, h->p.top_db,
                              (unsigned long long*)h->pmax.p, (unsigned long long*)h->bits.p, wpr, st));
   }
+  *tc_out = tc;
+  return SG_OK;
+}
+
+// Fused stationary mask (variant S): STFT(f64) -> bits -> integer smoothing -> K16 -> float mask.
+static int stage_fused_mask(sg_handle* h, const View& v, const Geom& g, int64_t ub, bool fast, int64_t tb,
+                            int64_t te, hipStream_t st) {
+  // [tb, te): frames whose smoothed mask is needed; decisions are needed nt frames further out
+  const int64_t nt_halo = h->p.smooth_mask ? h->p.n_grad_time : 0;
+  const int64_t db = std::max<int64_t>(0, tb - nt_halo), de = std::min<int64_t>(g.T, te + nt_halo);
+  h->dbg_db = (fast && !h->force_f64_decide) ? db : 0;
+  h->dbg_de = (fast && !h->force_f64_decide) ? de : g.T;
+  h->dbg_xbits = false;
+  const int wpr = (g.F + 63) / 64;
+  int rc;
+  if ((rc = ensure(h, h->K16, (size_t)ub * g.T * g.FS * 2))) return rc;
+  ThreshConsts tc{};
+  if ((rc = stage_prep_floor(h, v, g, ub, &tc, st))) return rc;
   if (fast && !h->force_f64_decide) {
     ProfScope ps(h, SG_STAGE_DECIDE_FAST, st);
     constexpr int WAVES = 4;
@@ -1091,6 +1131,90 @@ static int stage_apply_fast(sg_handle* h, const View& v, const Geom& g, int64_t 
   return SG_OK;
 }
 
+// One-pass stationary gate (default geometry, onepass.hpp): forward transform once per frame; decide,
+// publish the tile's bits, smooth in LDS, x mask, inverse transform, overlap-add -- one kernel (+ the
+// seam kernel for the 3 hops that straddle two tiles).  Returns 1 when the shape is not eligible
+// (the caller then runs the three-kernel path).
+static bool onepass_ok(const sg_handle* h, const Geom& g, const OutMap& om) {
+  if (h->force_split || h->force_f64_decide || h->force_noseam || h->force_nolean) return false;
+  if (!h->p.smooth_mask || h->p.n_grad_freq > 5 || h->p.n_grad_time > fast::OP_MAX_NT || !h->ftab3.p) return false;
+  if (g.F != 513) return false;
+  const int64_t hb = (om.p0 + g.padL) / 256, he = (om.p1 - 1 + g.padL) / 256 + 1;
+  return (he - hb + 3 + 15) / 16 >= 2;  // at least two abutting tiles (seam mode)
+}
+
+static int stage_onepass(sg_handle* h, const View& v, const Geom& g, int64_t ub, const OutMap& om, hipStream_t st) {
+  constexpr int WAVES = 4, NF = 16;
+  int rc;
+  ThreshConsts tc{};
+  if ((rc = stage_prep_floor(h, v, g, ub, &tc, st))) return rc;
+  fast::OnePassArgs P;
+  fast::ApplyArgs& A = P.A;
+  A.view = v; A.g = g; A.om = om;
+  A.K = nullptr; A.Mf = nullptr;
+  A.normalize = 1;
+  A.win = (const float*)h->wa32.p;
+  A.wsq = (const float*)h->wsq32.p;
+  A.invn = (const float*)h->invn.p;
+  A.tw512 = (const fast::cf*)h->tw512.p;
+  A.tw1024 = (const fast::cf*)h->tw32.p;
+  A.kscale = (float)(1.0 / ((double)h->ktot * 512.0));
+  A.h_begin = (om.p0 + g.padL) / 256;
+  A.h_end = (om.p1 - 1 + g.padL) / 256 + 1;
+  const int64_t nh = A.h_end - A.h_begin;
+  const int64_t n_tiles = (nh + 3 + NF - 1) / NF;
+  const int64_t ntt = n_tiles + 2;
+  if ((rc = ensure(h, h->seam, (size_t)ub * n_tiles * 6 * 256 * sizeof(float)))) return rc;
+  A.part = (float*)h->seam.p;
+  A.n_tiles = (int)n_tiles;
+  if ((rc = ensure(h, h->xbits, (size_t)ub * ntt * fast::OP_TILE_WORDS * 8))) return rc;
+  {
+    const void* before = h->xflags.p;
+    if ((rc = ensure(h, h->xflags, (size_t)ub * ntt * 4))) return rc;
+    if (h->xflags.p != before) {  // fresh flags carry no epoch yet
+      HIPCHK(h, hipMemsetAsync(h->xflags.p, 0, h->xflags.bytes, st));
+      h->epoch = 0;
+    }
+  }
+  if ((rc = ensure(h, h->xticket, 64))) return rc;
+  HIPCHK(h, hipMemsetAsync(h->xticket.p, 0, 4, st));
+  if (++h->epoch == 0) {  // wrapped: flags of 2^32 launches ago could alias
+    HIPCHK(h, hipMemsetAsync(h->xflags.p, 0, h->xflags.bytes, st));
+    h->epoch = 1;
+  }
+  P.win64 = (const double*)h->wfull64.p;
+  P.tw64 = (const cx<double>*)h->tw64.p;
+  P.tc = tc;
+  P.mag_scale = h->mag_scale; P.top_db = h->p.top_db;
+  P.xbits = (unsigned long long*)h->xbits.p;
+  P.flags = (unsigned*)h->xflags.p;
+  P.ticket = (unsigned*)h->xticket.p;
+  P.epoch = h->epoch;
+  P.nf = h->p.n_grad_freq; P.nt = h->p.n_grad_time;
+  P.ftab3 = (const unsigned long long*)h->ftab3.p;
+  {
+    ProfScope ps(h, SG_STAGE_ONEPASS, st);
+    const size_t lds = (size_t)(fast::FN + WAVES * fast::WAVE_CX_H) * sizeof(fast::cf) + (1024 + 528) * sizeof(float) +
+                       192 * 8 + 16;
+    auto kern = fast::k_gate_onepass<WAVES>;
+    HIPCHK(h, hipFuncSetAttribute(reinterpret_cast<const void*>(kern),
+                                  hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+    hipLaunchKernelGGL(kern, dim3((unsigned)(ub * ntt)), dim3(WAVES * 64), lds, st, P);
+    HIPCHK(h, hipGetLastError());
+  }
+  {
+    ProfScope ps(h, SG_STAGE_APPLY_FAST, st);
+    hipLaunchKernelGGL(fast::k_ola_seam<NF>, dim3((unsigned)(n_tiles - 1), (unsigned)ub), dim3(256), 0, st, A);
+    HIPCHK(h, hipGetLastError());
+  }
+  h->dbg_xbits = true;
+  h->dbg_tf0 = A.h_begin - 3;
+  h->dbg_ntt = (int)ntt;
+  h->dbg_db = std::max<int64_t>(0, A.h_begin - 3 - NF);
+  h->dbg_de = std::min<int64_t>(g.T, A.h_begin - 3 + NF * (n_tiles + 1));
+  return SG_OK;
+}
+
 // Variant S over a set of units described by `v` (unit0 filled per batch).
 static int run_S(sg_handle* h, View v, int64_t total_units, const OutMap& om, hipStream_t st) {
   Geom g = make_geom(h, v.Lp);
@@ -1109,6 +1233,11 @@ static int run_S(sg_handle* h, View v, int64_t total_units, const OutMap& om, hi
     const bool fused = h->fused_ok && !h->force_unfused;
     const bool geom_fast = h->fast_ok && !h->force_nofast;  // default geometry: fused apply kernel
     const bool fast = fused && geom_fast && h->p.prop_decrease == 1.0;
+    if (fast && onepass_ok(h, g, om)) {
+      if ((rc = stage_onepass(h, v, g, nb, om, st))) return rc;
+      h->dbg_units = nb; h->dbg_T = g.T; h->dbg_has_P = false; h->dbg_fused = true; h->dbg_fast = true;
+      continue;
+    }
     if (fast) {
       // frames the fused apply kernel touches: hops [h_begin, h_end) need frames h-3 .. h
       const int64_t hb = (om.p0 + g.padL) / 256, he = (om.p1 - 1 + g.padL) / 256 + 1;
@@ -1480,6 +1609,7 @@ extern "C" int sg_set_option(sg_handle* h, int32_t option, int64_t value) {
     case SG_OPT_FORCE_F64_DECIDE: h->force_f64_decide = value != 0; return SG_OK;
     case SG_OPT_FORCE_NOSEAM: h->force_noseam = value != 0; return SG_OK;
     case SG_OPT_FORCE_NOLEAN: h->force_nolean = value != 0; return SG_OK;
+    case SG_OPT_FORCE_SPLIT: h->force_split = value != 0; return SG_OK;
   }
   FAIL(h, SG_E_INVALID, "sg_set_option: unknown option %d", option);
 }
@@ -1524,7 +1654,8 @@ extern "C" const char* sg_stage_name(int32_t stage) {
                                            "noise statistics (all kernels)", "k_unit_absmax+k_prep_thresh",
                                            "k_stft_bits<max> (floor pre-pass)", "k_stft_bits<decide>",
                                            "k_apply_fast (fft+mask+ifft+ola)",
-                                           "k_decide_fast (f32 stft + exact f64 refine)"};
+                                           "k_decide_fast (f32 stft + exact f64 refine)",
+                                           "k_gate_onepass (fft+decide+smooth+mask+ifft+ola)"};
   return (stage >= 0 && stage < SG_N_STAGES) ? names[stage] : "?";
 }
 
@@ -1564,6 +1695,25 @@ extern "C" int sg_debug_fetch(sg_handle* h, int32_t what, void* host, int64_t by
   }
   if ((size_t)bytes != need) FAIL(h, SG_E_INVALID, "sg_debug_fetch: need %zu bytes, got %lld", need, (long long)bytes);
   HIPCHK(h, hipStreamSynchronize((hipStream_t)stream));
+  if (what == 3 && h->dbg_xbits) {
+    // one-pass path: the bits live tile-blocked in the exchange buffer [unit][tile][16][9]; rearrange into
+    // the natural [unit][T][wpr] layout (frames outside sg_debug_range stay zero)
+    const int wpr = (h->F + 63) / 64;
+    const size_t words = (size_t)h->dbg_units * h->dbg_ntt * fast::OP_TILE_WORDS;
+    std::vector<unsigned long long> tmp(words);
+    HIPCHK(h, hipMemcpy(tmp.data(), h->xbits.p, words * 8, hipMemcpyDeviceToHost));
+    unsigned long long* dst = (unsigned long long*)host;
+    std::memset(dst, 0, need);
+    for (int64_t u = 0; u < h->dbg_units; ++u)
+      for (int64_t j = 0; j < h->dbg_ntt; ++j)
+        for (int i = 0; i < 16; ++i) {
+          const int64_t t = h->dbg_tf0 + (j - 1) * 16 + i;
+          if (t < 0 || t >= h->dbg_T) continue;
+          for (int w = 0; w < wpr; ++w)
+            dst[(u * h->dbg_T + t) * wpr + w] = tmp[((size_t)u * h->dbg_ntt + j) * fast::OP_TILE_WORDS + i * fast::OP_XW + w];
+        }
+    return SG_OK;
+  }
   HIPCHK(h, hipMemcpy(host, src, need, hipMemcpyDeviceToHost));
   return SG_OK;
 }

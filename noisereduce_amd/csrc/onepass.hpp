@@ -1,0 +1,613 @@
+// One-pass stationary gate for the default geometry (n_fft = win = 1024, hop = 256, float32 transforms):
+// every frame's forward transform is computed ONCE.
+//
+//   k_decide_fast + k_smooth_bits2 + k_apply_fast          (3 transforms per frame, K round trip in HBM)
+//     ->  k_gate_onepass                                    (2 transforms per frame, no mask field in HBM)
+//
+// A workgroup owns one TILE of 16 consecutive frames of one unit (4 wavefronts x 4 frames, the register
+// FFT of fastpath.hpp).  After the forward transform it decides its 16 x 513 cells (float32 + exact
+// float64 refinement, bit-identical to k_decide_fast), and keeps the spectra IN REGISTERS while
+//   1. the mask bits of the tile (16 x 9 words = 1152 B) are PUBLISHED to the neighbouring tiles through
+//      a tile-blocked exchange buffer in HBM (write-through stores, drained, then an epoch-valued flag);
+//   2. it waits for the flags of tiles j-1 and j+1 and reads their nt adjacent rows (nt <= 16: the time
+//      half-width of the smoothing filter, base.py:115) -- 2*nt*72 B;
+//   3. the (16 + 2 nt) x 513 bit tile is smoothed in LDS with the exact integer separable triangle
+//      filter (the arithmetic of k_smooth_bits2: table lookups along f, weighted sums along t) into the
+//      uint16 weight sums K of its own 16 frames;
+// then x mask -> inverse transform -> window -> overlap-add -> store exactly as k_apply_fast<LEAN>.
+// The smoothing buffers live in the exchange slices, which are idle between the two transforms: the
+// kernel needs no more LDS than k_apply_fast (3 workgroups per CU).
+//
+// Inter-workgroup protocol (MI355X_MICROARCH.md, "Workgroup dispatch, XCD placement & inter-workgroup
+// visibility"): payload and flag are 8/4-byte agent-scope relaxed atomics on both sides (sc1 stores and
+// loads: write-through, L1-bypassing -- per-XCD L2s are not coherent), the payload stores are drained
+// (s_waitcnt vmcnt(0) + workgroup barrier) before the flag is stored; every tile's payload is 1152 B =
+// 9 x 128 B, 128-byte aligned: no cache line is shared between producers.
+// Deadlock freedom does not rely on dispatch order: a workgroup takes a TICKET (atomic counter) when it
+// starts and works on tile number `ticket`; it publishes before it waits for anything, so the only
+// workgroup that can wait for a tile nobody has started yet is the one with the highest ticket, and
+// every other resident workgroup finishes and frees its slot.
+#pragma once
+#include "fastpath.hpp"
+
+namespace sg {
+namespace fast {
+
+constexpr int OP_XW = 9;                 // 64-bit words per frame row (513 bins)
+constexpr int OP_TILE_WORDS = 16 * OP_XW;  // payload of one tile: 144 words = 1152 B
+constexpr int OP_MAX_NT = 16;            // neighbours hold 16 frames each
+constexpr int OP_KP = 528;               // K row pitch (uint16 entries) of a wave's private K tile
+constexpr int OP_HG = 65;                // 8-bin groups per row (513 bins)
+
+struct OnePassArgs {
+  ApplyArgs A;              // view, geometry, output map, tables, seam buffer (A.K / A.Mf unused)
+  const double* win64;      // analysis window, float64 (exact refinement)
+  const cx<double>* tw64;   // w_1024^j float64
+  ThreshConsts tc;
+  double mag_scale, top_db;
+  unsigned long long* xbits;  // [units][n_tiles + 2][16][OP_XW] published mask bits
+  unsigned* flags;            // [units][n_tiles + 2] epoch of the last publication
+  unsigned* ticket;           // work counter (zeroed before the launch)
+  unsigned epoch;
+  int nf, nt;
+  const unsigned long long* ftab3;  // [3][64]: packed byte counts of 8 adjacent bins per 6 window bits
+};
+
+// exact float64 |X[f]|^2 of frame t (see k_decide_fast)
+__device__ __forceinline__ double op_exact_power(const OnePassArgs& P, int64_t row, int64_t chunk, int64_t t, int f,
+                                                 int lane) {
+  const int64_t s0 = t * P.A.g.H - P.A.g.padL;
+  double re = 0.0, im = 0.0;
+#pragma unroll 4
+  for (int i = 0; i < 16; ++i) {
+    const int m = lane + 64 * i;
+    const double xv = view_sample(P.A.view, row, chunk, s0 + m) * P.win64[m];
+    const int j = (f * m) & 1023;
+    cx<double> w = P.tw64[j & 511];
+    if (j >= 512) { w.x = -w.x; w.y = -w.y; }
+    re += xv * w.x;
+    im += xv * w.y;
+  }
+  for (int off = 32; off > 0; off >>= 1) {
+    re += __shfl_xor(re, off);
+    im += __shfl_xor(im, off);
+  }
+  return re * re + im * im;
+}
+
+typedef unsigned short op_us2 __attribute__((ext_vector_type(2)));
+
+// OP_ABLATE (development only, default 0; results are wrong): 1 no decision stage, 2 no wait for the
+// neighbours' flags, 4 no smoothing (K = constant), 8 no exact refinement
+#ifndef OP_ABLATE
+#define OP_ABLATE 0
+#endif
+
+template <int WAVES>
+__global__ __launch_bounds__(WAVES * 64, 3) void k_gate_onepass(OnePassArgs P) {
+  static_assert(WAVES == 4, "tile = 16 frames");
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  cf* tw512 = reinterpret_cast<cf*>(smem);
+  cf* regions = tw512 + FN;
+  float* swin = reinterpret_cast<float*>(regions + WAVES * WAVE_CX_H);
+  float* s_t2 = swin + 1024;
+  unsigned long long* s_tab = reinterpret_cast<unsigned long long*>(s_t2 + 528);
+  unsigned* s_misc = reinterpret_cast<unsigned*>(s_tab + 192);
+  constexpr int NF = 4 * WAVES;
+  const ApplyArgs& A = P.A;
+  const Geom& G = A.g;
+  const int tid = threadIdx.x;
+  const int lane = tid & 63, wave = tid >> 6;
+  const int g = lane >> 4, c = lane & 15;
+  const int nt = P.nt, nf = P.nf;
+
+  if (tid == 0) s_misc[0] = atomicAdd(P.ticket, 1u);
+  for (int i = tid; i < FN; i += WAVES * 64) tw512[i] = A.tw512[(i >> 4) * (i & 15)];
+  for (int i = tid; i < 256; i += WAVES * 64)
+    reinterpret_cast<float4*>(swin)[i] = reinterpret_cast<const float4*>(A.win)[i];
+  if (tid < 192) s_tab[tid] = P.ftab3[tid];
+  __syncthreads();
+  const int ntt = A.n_tiles + 2;                 // tiles per unit incl. one decide-only halo tile per side
+  const unsigned ticket = s_misc[0];
+  const int64_t u = ticket / (unsigned)ntt;
+  const int jt = (int)(ticket % (unsigned)ntt) - 1;   // -1 and n_tiles: halo tiles
+  const bool halo_tile = jt < 0 || jt >= A.n_tiles;
+  const int64_t row = (A.view.unit0 + u) / A.view.n_chunks;
+  const int64_t chunk = A.view.c0 + (A.view.unit0 + u) % A.view.n_chunks;
+  const bool floor_live = P.tc.need_floor[u] != 0;
+
+  // compare constants (x4: the split works on 2X), permuted like the lanes' entries -- see k_decide_fast
+  auto t2eff = [&](int f) -> double {
+    double v = P.tc.T2[f];
+    if (floor_live) {
+      double fl = cell_db(P.tc.pmax[u * G.FS + f], P.mag_scale) - P.top_db;
+      if (fl > P.tc.thresh[f]) v = -1.0;
+    }
+    return v;
+  };
+  for (int i = tid; i <= 512; i += WAVES * 64) {
+    double v = t2eff(perm_inv(i));
+    s_t2[i] = v < 0.0 ? -3.0e38f : (float)(4.0 * v);
+  }
+
+  const int64_t tf_tile = A.h_begin - 3 + (int64_t)jt * NF;  // first frame of the tile (abutting tiles)
+  const int64_t tq = tf_tile + 4 * wave;
+  const int64_t t = tq + g;                                  // this lane group's frame
+  const bool fvalid = t >= 0 && t < G.T;
+  cf* fb = regions + wave * WAVE_CX_H + frame_base_h(g);
+
+  // ---- stage the tile's contiguous sample span (interior tiles of float32 input) -----------------
+  constexpr int SPAN = (NF - 1) * 256 + 1024, XPITCH = 288;
+  static_assert((SPAN / 256) * XPITCH <= WAVES * WAVE_CX_H * 2, "span must fit the exchange slices");
+  bool blk_in;
+  {
+    const int64_t s0b = tf_tile * 256 - G.padL;
+    const int64_t gb = chunk * A.view.cs - A.view.pad + s0b;
+    blk_in = A.view.dtype == 0 && tf_tile >= 0 && tf_tile + NF <= G.T && s0b >= 0 && s0b + SPAN <= A.view.Lp &&
+             gb >= A.view.lo && gb + SPAN <= A.view.hi;
+    if (blk_in) {
+      const float* sp = (const float*)A.view.x + row * A.view.stride + gb;
+      float* xs = reinterpret_cast<float*>(regions);
+      if ((reinterpret_cast<uintptr_t>(sp) & 15) == 0) {
+        for (int i = tid; i < SPAN / 4; i += WAVES * 64) {
+          const float4 q = reinterpret_cast<const float4*>(sp)[i];
+          const int e = 4 * i;
+          *reinterpret_cast<float4*>(&xs[(e >> 8) * XPITCH + (e & 255)]) = q;
+        }
+      } else {
+        for (int i = tid; i < SPAN; i += WAVES * 64) xs[(i >> 8) * XPITCH + (i & 255)] = sp[i];
+      }
+    }
+  }
+  __syncthreads();  // tables, compare constants and span staged
+
+  // ---- gather: v[r] = (x[2c + 32r], x[2c + 32r + 1]) * window ---------------------------------------
+  cf v[32];
+  float nrm2 = 0.f;
+  if (blk_in) {
+    const float* xs = reinterpret_cast<const float*>(regions) + (4 * wave + g) * XPITCH + 2 * c;
+    const float2* wl = reinterpret_cast<const float2*>(swin + 2 * c);
+#pragma unroll
+    for (int r = 0; r < 32; ++r) {
+      const float2 x2 = *reinterpret_cast<const float2*>(xs + (r >> 3) * XPITCH + 32 * (r & 7));
+      const float2 w2 = wl[16 * r];
+      v[r] = {x2.x * w2.x, x2.y * w2.y};
+    }
+  } else {
+    const int64_t s0 = t * 256 - G.padL;
+    const int64_t gbase = chunk * A.view.cs - A.view.pad + s0;
+    const bool inside = fvalid && s0 >= 0 && s0 + 1024 <= A.view.Lp && gbase >= A.view.lo &&
+                        gbase + 1024 <= A.view.hi && A.view.dtype == 0;
+    const float* src = (const float*)A.view.x + row * A.view.stride + gbase + 2 * c;
+    const bool aligned = (reinterpret_cast<uintptr_t>(src) & 7) == 0;
+    const float2* wsrc = reinterpret_cast<const float2*>(swin + 2 * c);
+    if (inside && aligned) {
+      const float2* s2 = reinterpret_cast<const float2*>(src);
+#pragma unroll
+      for (int r = 0; r < 32; ++r) {
+        float2 x2 = s2[16 * r];
+        float2 w2 = wsrc[16 * r];
+        v[r] = {x2.x * w2.x, x2.y * w2.y};
+      }
+    } else {
+      float* fl = reinterpret_cast<float*>(fb);  // half-size slice: the frame is staged as two halves
+#pragma unroll
+      for (int hh = 0; hh < 2; ++hh) {
+#pragma unroll 1
+        for (int r = 0; r < 16; ++r) {
+          float a = 0.f, b = 0.f;
+          if (fvalid) {
+            a = (float)view_sample(A.view, row, chunk, s0 + 2 * c + 32 * (r + 16 * hh));
+            b = (float)view_sample(A.view, row, chunk, s0 + 2 * c + 32 * (r + 16 * hh) + 1);
+          }
+          fl[2 * c + 32 * r] = a;
+          fl[2 * c + 32 * r + 1] = b;
+        }
+        wave_lds_sync();
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+          float2 w2 = wsrc[16 * (r + 16 * hh)];
+          cf x2 = fb[c + 16 * r];
+          v[r + 16 * hh] = {x2.x * w2.x, x2.y * w2.y};
+        }
+        wave_lds_sync();
+      }
+    }
+  }
+  __syncthreads();  // every lane has its samples: the span may be overwritten by the exchanges
+  {
+#pragma unroll
+    for (int r = 0; r < 32; ++r) nrm2 += v[r].x * v[r].x + v[r].y * v[r].y;
+    nrm2 += __shfl_xor(nrm2, 1);
+    nrm2 += __shfl_xor(nrm2, 2);
+    nrm2 += __shfl_xor(nrm2, 4);
+    nrm2 += __shfl_xor(nrm2, 8);
+  }
+  {
+    const cf* twl = tw512;
+    asm volatile("" : "+v"(twl));
+    fft512_fwd_half(v, fb, twl, c);
+  }
+
+  // ---- decide (k_decide_fast): mask bits of this lane's 32 entries -----------------------------------
+  unsigned long long myword;  // lane c < 9 of group g: word c of frame tq + g
+  if constexpr ((OP_ABLATE & 1) != 0) {
+    myword = (unsigned long long)__float_as_uint(v[c].x + nrm2);
+  } else {
+    cf wl = A.tw1024[c];
+    asm volatile("" : "+v"(wl.x), "+v"(wl.y));
+    // compare constants are read from LDS where they are used (the spectra stay live through this phase:
+    // 32 more registers for a preloaded table would spill)
+    const float* t2 = s_t2 + c * 32;
+    asm volatile("" : "+v"(t2));
+    const float t2_512 = s_t2[512];
+    const float d2 = nrm2 > 0.f ? 8.0f * 2.3283064e-10f * nrm2 : -1.0f;
+    unsigned pred = 0, amb = 0;
+    auto decide = [&](float Pw, float T, int q) {
+      const float diff = Pw - T;
+      pred |= (diff > 0.f ? 1u : 0u) << q;
+      amb |= ((diff * diff <= d2 * (Pw + T)) ? 1u : 0u) << q;
+    };
+    auto pair_power = [&](cf a, cf b, cf w, float& Pk, float& Pn) {
+      cf E = {a.x + b.x, a.y - b.y};
+      cf O = {a.y + b.y, b.x - a.x};
+      cf wO = cmul(w, O);
+      float px = E.x + wO.x, py = E.y + wO.y, qx = E.x - wO.x, qy = E.y - wO.y;
+      Pk = px * px + py * py;
+      Pn = qx * qx + qy * qy;
+    };
+    const bool l0 = c == 0;
+    const cf wlo = wl;
+    cf whi = wl;
+    {
+      const cf w16 = A.tw1024[16];
+      if (l0) whi = {-w16.y, w16.x};  // i * w_1024^16
+    }
+    auto sel = [&](cf a0, cf a1) -> cf { return {l0 ? a0.x : a1.x, l0 ? a0.y : a1.y}; };
+    bool pred512 = false, amb512 = false;
+    {
+      float Pk, Pn;
+      pair_power(v[0], v[31], wlo, Pk, Pn);
+      const cf a = v[0];
+      const float x0 = 2.f * (a.x + a.y), xN = 2.f * (a.x - a.y);
+      const float P256 = 4.f * (v[8].x * v[8].x + v[8].y * v[8].y);
+      decide(l0 ? x0 * x0 : Pk, t2[0], 0);
+      decide(l0 ? P256 : Pn, t2[31], 31);
+      const float P5 = xN * xN, d5 = P5 - t2_512;
+      pred512 = l0 && d5 > 0.f;
+      amb512 = l0 && d5 * d5 <= d2 * (P5 + t2_512);
+    }
+#pragma unroll
+    for (int sl = 1; sl < 16; ++sl) {
+      const cf a = sl < 8 ? v[sl] : sel(v[8 + sl], v[sl]);
+      const cf b = sl < 8 ? sel(v[16 - sl], v[31 - sl]) : sel(v[39 - sl], v[31 - sl]);
+      const cf w = mul_tw<false>(sl < 8 ? wlo : whi, twc<32>(sl), tws<32>(sl));
+      float Pk, Pn;
+      pair_power(a, b, w, Pk, Pn);
+      decide(Pk, t2[sl], sl);
+      decide(Pn, t2[31 - sl], 31 - sl);
+    }
+    if (!fvalid) { amb = 0; amb512 = false; pred = 0; pred512 = false; }
+    // exact re-evaluation, one cell at a time, whole wave cooperating
+    while ((OP_ABLATE & 8) == 0) {
+      const unsigned long long pending = __ballot(amb != 0 || amb512);
+      if (pending == 0) break;
+      const int src = __ffsll((long long)pending) - 1;
+      const unsigned amb_s = (unsigned)__shfl((int)amb, src);
+      const int q = amb_s ? (__ffs((int)amb_s) - 1) : 32;
+      const int cs = src & 15, gs = src >> 4;
+      const int f = q < 32 ? bin_of_entry(cs, q) : 512;
+      const double Pe = op_exact_power(P, row, chunk, tq + gs, f, lane);
+      const bool pass = Pe > t2eff(f);
+      if (lane == src) {
+        if (q < 32) {
+          pred = (pred & ~(1u << q)) | ((pass ? 1u : 0u) << q);
+          amb &= ~(1u << q);
+        } else {
+          pred512 = pass;
+          amb512 = false;
+        }
+      }
+    }
+    if (l0)  // entry -> register: e 0..7 -> 0..7, 8..23 -> 16..31, 24..30 -> 9..15, 31 -> 8
+      pred = (pred & 0xffu) | ((pred & 0x00ffff00u) << 8) | ((pred >> 15) & 0xfe00u) | ((pred >> 23) & 0x100u);
+    unsigned long long q0 = 0, q1 = 0, q2 = 0, q3 = 0;
+#pragma unroll
+    for (int m = 0; m < 8; ++m) {
+      const unsigned long long b0 = __ballot((pred >> (2 * m)) & 1u);
+      const unsigned long long b1 = __ballot((pred >> (16 + 2 * m)) & 1u);
+      const unsigned long long b2 = __ballot((pred >> (2 * m + 1)) & 1u);
+      const unsigned long long b3 = __ballot((pred >> (16 + 2 * m + 1)) & 1u);
+      const bool mine = c == m;
+      q0 = mine ? b0 : q0;
+      q1 = mine ? b1 : q1;
+      q2 = mine ? b2 : q2;
+      q3 = mine ? b3 : q3;
+    }
+    const unsigned long long b8 = __ballot(pred512);
+    {
+      const int sh = 16 * g;
+      const unsigned f0 = (unsigned)(q0 >> sh) & 0xffffu;
+      const unsigned f1 = (unsigned)(q1 >> sh) & 0xffffu;
+      const unsigned f2 = (unsigned)(q2 >> sh) & 0xffffu;
+      const unsigned f3 = (unsigned)(q3 >> sh) & 0xffffu;
+      const unsigned r1 = (((__brev(f1) >> 16) << 1) | (f1 & 1u)) & 0xffffu;
+      const unsigned r3 = (((__brev(f3) >> 16) << 1) | (f3 & 1u)) & 0xffffu;
+      myword = (unsigned long long)(f0 | (r1 << 16)) | ((unsigned long long)(f2 | (r3 << 16)) << 32);
+      if (c == 8) myword = (b8 >> sh) & 1ull;
+    }
+  }
+
+  // ---- publish this tile's bits; the spectra stay in v[] ---------------------------------------------
+  unsigned long long* xb_mine = P.xbits + ((size_t)u * ntt + (jt + 1)) * OP_TILE_WORDS;
+  if (c < OP_XW)
+    __hip_atomic_store(&xb_mine[(4 * wave + g) * OP_XW + c], myword, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // payload drained before the flag may be stored
+  __syncthreads();                                   // ... by every wave; the exchange slices are idle from here
+  if (tid == 0)
+    __hip_atomic_store(&P.flags[(size_t)u * ntt + (jt + 1)], P.epoch, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+  if (halo_tile) return;
+
+  // ---- bit tile of rows tf_tile - nt .. tf_tile + 16 + nt in LDS -------------------------------------
+  const int rows = NF + 2 * nt;
+  constexpr int WP = OP_XW + 2;  // one zero word on each side of every row
+  unsigned long long* wb = reinterpret_cast<unsigned long long*>(regions);
+  unsigned long long* Hb = wb + (((size_t)rows * WP + 1) & ~(size_t)1);
+  if (c < OP_XW) wb[(nt + 4 * wave + g) * WP + 1 + c] = myword;
+  for (int r = tid; r < rows; r += WAVES * 64) {
+    wb[r * WP] = 0ull;
+    wb[r * WP + WP - 1] = 0ull;
+  }
+  if (tid < 2 && !(OP_ABLATE & 2)) {
+    const unsigned* fp = &P.flags[(size_t)u * ntt + (jt + 1) + (tid ? 1 : -1)];
+    while (__hip_atomic_load(fp, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != P.epoch) __builtin_amdgcn_s_sleep(4);
+  }
+  __syncthreads();
+  for (int i = tid; i < 2 * nt * OP_XW; i += WAVES * 64) {
+    const int side = i >= nt * OP_XW;
+    const int rem = i - side * nt * OP_XW;
+    const int rr = rem / OP_XW, w = rem - rr * OP_XW;
+    const unsigned long long* src =
+        side ? xb_mine + OP_TILE_WORDS + rr * OP_XW + w : xb_mine - OP_TILE_WORDS + (NF - nt + rr) * OP_XW + w;
+    const unsigned long long word = __hip_atomic_load(src, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    wb[(side ? nt + NF + rr : rr) * WP + 1 + w] = word;
+  }
+  __syncthreads();
+
+  // ---- smoothing, phase 1 (along f): packed byte counts of 8 adjacent bins per (row, group) ----------
+  for (int task = tid; task < ((OP_ABLATE & 4) ? 0 : rows * OP_HG); task += WAVES * 64) {
+    const int r = task / OP_HG, grp = task - r * OP_HG;
+    const unsigned long long* rb = wb + (size_t)r * WP + 1;  // word w at rb[w], rb[-1] = 0
+    const int start = 8 * grp - nf + 64;                     // bit index in the stream that begins at rb[-1]
+    const int wi = (start >> 6) - 1, sh = start & 63;
+    const unsigned long long lo = rb[wi], hi = rb[wi + 1];
+    const unsigned win = (unsigned)(sh == 0 ? lo : ((lo >> sh) | (hi << (64 - sh)))) & 0x3ffffu;
+    Hb[task] = s_tab[win & 63u] + s_tab[64 + ((win >> 6) & 63u)] + s_tab[128 + (win >> 12)];
+  }
+  __syncthreads();
+
+  // ---- phase 2 (along t): this wave's 4 frames, lane = 8-bin group (bin 512 rides in every lane) ------
+  unsigned kacc[4][4];
+  unsigned kx[4];
+#pragma unroll
+  for (int i = 0; i < 4; ++i) {
+    kx[i] = 0u;
+#pragma unroll
+    for (int q = 0; q < 4; ++q) kacc[i][q] = 0u;
+  }
+  {
+    const unsigned long long* hrow = Hb + (size_t)(4 * wave) * OP_HG;
+    const int nr = (OP_ABLATE & 4) ? 1 : 4 + 2 * nt;
+#pragma unroll 2
+    for (int r = 0; r < nr; ++r) {
+      const unsigned long long h8 = hrow[(size_t)r * OP_HG + lane];
+      const unsigned hx = (unsigned)(hrow[(size_t)r * OP_HG + 64] & 0xffull);
+      const unsigned hl = (unsigned)h8, hh = (unsigned)(h8 >> 32);
+      unsigned p[4];
+      p[0] = __builtin_amdgcn_perm(0u, hl, 0x0c010c00u);   // (b0, b1) as two uint16
+      p[1] = __builtin_amdgcn_perm(0u, hl, 0x0c030c02u);   // (b2, b3)
+      p[2] = __builtin_amdgcn_perm(0u, hh, 0x0c010c00u);
+      p[3] = __builtin_amdgcn_perm(0u, hh, 0x0c030c02u);
+#pragma unroll
+      for (int i = 0; i < 4; ++i) {
+        const int d = r - i - nt;                    // wave-uniform
+        const int ad = d < 0 ? -d : d;
+        const unsigned w = ad <= nt ? (unsigned)(nt + 1 - ad) : 0u;
+        const unsigned w2 = w | (w << 16);
+        op_us2 ww = __builtin_bit_cast(op_us2, w2);
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+          op_us2 acc = __builtin_bit_cast(op_us2, kacc[i][q]);
+          op_us2 pv = __builtin_bit_cast(op_us2, p[q]);
+          acc = acc + pv * ww;
+          kacc[i][q] = __builtin_bit_cast(unsigned, acc);
+        }
+        kx[i] += hx * w;
+      }
+    }
+  }
+  __syncthreads();  // every wave has its sums: the H rows (shared) may be overwritten
+
+  // ---- K of this wave's 4 frames through its own slice: natural order in, lane order out -------------
+  unsigned short* kt = reinterpret_cast<unsigned short*>(regions + wave * WAVE_CX_H);
+  static_assert(4 * OP_KP * 2 <= WAVE_CX_H * 8, "K tile must fit the wave's slice");
+#pragma unroll
+  for (int i = 0; i < 4; ++i) {
+    *reinterpret_cast<uint4*>(kt + i * OP_KP + 8 * lane) = make_uint4(kacc[i][0], kacc[i][1], kacc[i][2], kacc[i][3]);
+    if (lane == 0) kt[i * OP_KP + 512] = (unsigned short)kx[i];
+  }
+  wave_lds_sync();
+  // entry e of this lane = bin c + 32 e (e < 16) or (32 - c) + 32 (e - 16); lane 0 pairs its bins
+  // differently (bin_of_entry): read where used, two 16-bit LDS loads per conjugate pair
+  const unsigned short* krow = kt + g * OP_KP;
+  const unsigned short* k_lo = krow + (c == 0 ? 0 : c);        // entries e < 16 of lanes c >= 1
+  const unsigned short* k_hi = krow + (c == 0 ? 0 : 32 - c);   // entries e >= 16
+  const float k512 = (float)krow[512] * A.kscale;
+  auto mval = [&](int q, float scale) -> float {
+    const int b0 = bin_of_entry(0, q);                         // lane 0 (compile-time)
+    const unsigned short* pl = q < 16 ? k_lo : k_hi;
+    const int off = q < 16 ? 32 * q : 32 * (q - 16);
+    const unsigned short kv = c == 0 ? krow[b0] : pl[off];
+    return (float)kv * scale;
+  };
+  {
+    const float ks = A.kscale * 0.25f;  // pair_mask leaves out four 1/2 factors
+    const bool l0 = c == 0;
+    const cf wlo = A.tw1024[c];
+    cf whi = wlo;
+    {
+      const cf w16 = A.tw1024[16];
+      if (l0) whi = {-w16.y, w16.x};
+    }
+    auto sel = [&](cf a0, cf a1) -> cf { return {l0 ? a0.x : a1.x, l0 ? a0.y : a1.y}; };
+    cf nv[32];
+    cf s0a = v[0], s0b = v[31];
+    pair_mask(s0a, s0b, wlo, mval(0, ks), mval(31, ks));
+    {
+      const cf a = v[0];
+      const float y0 = (a.x + a.y) * mval(0, A.kscale);
+      const float yN = (a.x - a.y) * k512;
+      const cf z0 = {0.5f * (y0 + yN), 0.5f * (y0 - yN)};
+      const float m8 = mval(31, A.kscale);  // entry 31 of lane 0 = bin 256
+      const cf z8 = {v[8].x * m8, v[8].y * m8};
+      nv[0] = sel(z0, s0a);
+      nv[8] = z8;
+      nv[31] = s0b;
+    }
+    cf pa[16], pb[16];
+#pragma unroll
+    for (int sl = 1; sl < 16; ++sl) {
+      cf a = sl < 8 ? v[sl] : sel(v[8 + sl], v[sl]);
+      cf b = sl < 8 ? sel(v[16 - sl], v[31 - sl]) : sel(v[39 - sl], v[31 - sl]);
+      const cf wl = sl < 8 ? wlo : whi;
+      const cf w = mul_tw<false>(wl, twc<32>(sl), tws<32>(sl));
+      pair_mask(a, b, w, mval(sl, ks), mval(31 - sl, ks));
+      pa[sl] = a;
+      pb[sl] = b;
+    }
+#pragma unroll
+    for (int i = 1; i < 8; ++i) nv[i] = pa[i];
+    {
+      const cf keep8 = nv[8];
+      nv[8] = sel(keep8, pa[8]);
+    }
+#pragma unroll
+    for (int i = 9; i < 16; ++i) nv[i] = sel(pb[16 - i], pa[i]);
+#pragma unroll
+    for (int i = 16; i < 24; ++i) nv[i] = sel(pa[i - 8], pb[31 - i]);
+#pragma unroll
+    for (int i = 24; i < 31; ++i) nv[i] = sel(pb[39 - i], pb[31 - i]);
+    {
+      const cf keep31 = nv[31];
+      nv[31] = sel(pb[8], keep31);
+    }
+#pragma unroll
+    for (int i = 0; i < 32; ++i) v[i] = nv[i];
+  }
+  wave_lds_sync();  // K tile consumed: the slice is reused by the inverse transform
+
+  // ---- inverse transform, synthesis window, wave-private overlap-add (k_apply_fast<LEAN>) -------------
+  {
+    // fresh address arithmetic for the inverse exchange: shared with the forward transform (CSE) the 16 row
+    // addresses would stay live -- and be spilled -- across the whole smoothing phase
+    cf* fbi = fb;
+    const cf* twi = tw512;
+    asm volatile("" : "+v"(fbi), "+v"(twi));
+    fft512_inv_half(v, fbi, twi, c);
+  }
+  float* acc = reinterpret_cast<float*>(regions + wave * WAVE_CX_H);
+  {
+    const float2* wsrc2 = reinterpret_cast<const float2*>(swin + 2 * c);
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      const bool first = (j == 0) || (g == 3);
+#pragma unroll
+      for (int rr = 0; rr < 8; ++rr) {
+        const int r = 8 * j + rr;
+        float2* dst = reinterpret_cast<float2*>(acc + (g + j) * HPITCH + 2 * c + 32 * rr);
+        const float2 old = *dst;
+        const float2 ws = wsrc2[16 * r];
+        float2 nw = {v[r].x * ws.x, v[r].y * ws.y};
+        if (!first) { nw.x += old.x; nw.y += old.y; }
+        *dst = nw;
+      }
+      wave_lds_sync();
+    }
+  }
+  const float4 n4 = *reinterpret_cast<const float4*>(&A.invn[(tid & 63) * 4]);
+  __syncthreads();
+
+  // ---- cross-wave combine, normalise, store (seam mode: abutting tiles) -------------------------------
+  const float* fr = reinterpret_cast<const float*>(regions);
+  const int s4 = (tid & 63) * 4;
+  for (int jj = (tid >> 6); jj < NF + 3; jj += WAVES) {
+    const int64_t h = tf_tile + jj;
+    if (h >= A.h_end) break;
+    if (h < A.h_begin) continue;
+    float4 a4 = make_float4(0.f, 0.f, 0.f, 0.f);
+    bool all_valid = true;
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+      const int64_t ti = tf_tile + jj - q;
+      if (ti < 0 || ti >= G.T) all_valid = false;
+    }
+    {
+      const int wh = jj >> 2, lh = jj & 3;
+      if (wh >= 1 && wh - 1 < WAVES && lh <= 2) {
+        a4 = *reinterpret_cast<const float4*>(&fr[(wh - 1) * WAVE_CX_H * 2 + (lh + 4) * HPITCH + s4]);
+      }
+      if (wh < WAVES) {
+        const float4 f4 = *reinterpret_cast<const float4*>(&fr[wh * WAVE_CX_H * 2 + lh * HPITCH + s4]);
+        a4.x += f4.x; a4.y += f4.y; a4.z += f4.z; a4.w += f4.w;
+      }
+    }
+    if (jj < 3 || jj >= NF) {
+      const int slot = jj < 3 ? jj : 3 + (jj - NF);
+      float* dst = A.part + ((((size_t)u * A.n_tiles + jt) * 6 + slot) * 256 + s4);
+      *reinterpret_cast<float4*>(dst) = a4;
+      continue;
+    }
+    if (!A.normalize) {
+    } else if (all_valid) {
+      a4.x *= n4.x; a4.y *= n4.y; a4.z *= n4.z; a4.w *= n4.w;
+    } else {
+      float4 nrm = make_float4(0.f, 0.f, 0.f, 0.f);
+#pragma unroll
+      for (int q = 0; q < 4; ++q) {
+        const int64_t ti = h - q;
+        if (ti >= 0 && ti < G.T) {
+          const float4 w4 = *reinterpret_cast<const float4*>(&A.wsq[256 * q + s4]);
+          nrm.x += w4.x; nrm.y += w4.y; nrm.z += w4.z; nrm.w += w4.w;
+        }
+      }
+      a4.x /= (nrm.x > 1e-10f ? nrm.x : 1.f);
+      a4.y /= (nrm.y > 1e-10f ? nrm.y : 1.f);
+      a4.z /= (nrm.z > 1e-10f ? nrm.z : 1.f);
+      a4.w /= (nrm.w > 1e-10f ? nrm.w : 1.f);
+    }
+    {
+      const int64_t pb = h * 256 - G.padL;
+      const int64_t gi0 = chunk * A.om.g_step + (pb - A.om.p0);
+      if (A.om.dtype == 0 && pb >= A.om.p0 && pb + 256 <= A.om.p1 && pb + 256 <= G.Lout && gi0 >= A.om.g_lo &&
+          gi0 + 256 <= A.om.g_hi) {
+        float* dst = (float*)A.om.out + (row * A.om.stride + gi0 - A.om.g0 + s4);
+        if ((reinterpret_cast<uintptr_t>(dst) & 15) == 0) {
+          *reinterpret_cast<float4*>(dst) = a4;
+          continue;
+        }
+      }
+    }
+    const float vals[4] = {a4.x, a4.y, a4.z, a4.w};
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {
+      const int64_t p = h * 256 + s4 + e - G.padL;
+      if (p < A.om.p0 || p >= A.om.p1) continue;
+      const int64_t gi = chunk * A.om.g_step + (p - A.om.p0);
+      if (gi < A.om.g_lo || gi >= A.om.g_hi) continue;
+      store_sample(A.om.out, A.om.dtype, row * A.om.stride + gi - A.om.g0, p < G.Lout ? vals[e] : 0.f);
+    }
+  }
+}
+
+}  // namespace fast
+}  // namespace sg
