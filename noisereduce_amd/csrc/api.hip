@@ -59,7 +59,7 @@ struct sg_handle {
   DevBuf seam;                       // partial seam hops of abutting apply tiles
   DevBuf ftab;                       // k_smooth_bits2 phase-1 lookup tables (nf <= 5)
   // one-pass gate (onepass.hpp): published mask bits per tile, publication flags, work counter, tables
-  DevBuf xbits, xflags, xticket, ftab3;
+  DevBuf xbits, xflags, xticket, ftab3, xexp;  // ftab3: per-lane MFMA operands, xexp: bit -> byte table
   unsigned epoch = 0;                // launch counter: the value a tile's flag must carry to be current
   bool force_split = false;          // SG_OPT_FORCE_SPLIT: decide / smooth / apply as three kernels
   bool dbg_xbits = false;            // the last batch's mask bits live in xbits (tile-blocked)
@@ -657,24 +657,33 @@ extern "C" int sg_create(const sg_params* p, const double* window_host, sg_handl
         tab[half * 512 + v] = packed;
       }
     rc = upload(h, h->ftab, tab.data(), tab.size() * sizeof(unsigned long long));
-    // the same counts from three 6-bit slices of the window (1.5 KB: lives in LDS next to the one-pass
-    // kernel's other tables)
-    std::vector<unsigned long long> tab3(192, 0ull);
-    for (int j = 0; j < 3; ++j)
-      for (int v = 0; v < 64; ++v) {
-        unsigned long long packed = 0;
-        for (int e = 0; e < 8; ++e) {
-          int cnt = 0;
-          for (int b = 0; b < 6; ++b)
-            if ((v >> b) & 1) {
-              int a = (j * 6 + b) - nf - e;
-              if (a >= -nf && a <= nf) cnt += nf + 1 - (a < 0 ? -a : a);
-            }
-          packed |= (unsigned long long)cnt << (8 * e);
-        }
-        tab3[j * 64 + v] = packed;
+  }
+  if (!rc && h->fast_ok && p->smooth_mask && p->n_grad_freq <= 8 && p->n_grad_time <= fast::OP_MAX_NT) {
+    // per-lane operands of the one-pass kernel's MFMA smoothing (onepass.hpp), v_mfma_i32_16x16x32_i8 layout:
+    // lane l = (q = l / 16, j = l % 16) supplies bytes e = 0..7 = k slots 8 q + e of row/column j
+    const int nf = p->n_grad_freq, nt = p->n_grad_time;
+    std::vector<unsigned long long> mc(192, 0ull), ex(256, 0ull);
+    auto wt = [&](int r, int i) {  // time weight of tile row r (frame r - nt) for output frame i
+      const int d = r - i - nt, ad = d < 0 ? -d : d;
+      return ad <= nt ? nt + 1 - ad : 0;
+    };
+    auto trow = [&](int m) { return m < nt ? m : 16 + m; };  // neighbour-list index -> tile row
+    for (int l = 0; l < 64; ++l) {
+      const int q = l / 16, j = l % 16;
+      for (int e = 0; e < 8; ++e) {
+        const int a = 8 * q + e - 8 - j, aa = a < 0 ? -a : a;
+        mc[l] |= (unsigned long long)(aa <= nf ? nf + 1 - aa : 0) << (8 * e);
+        int w1;
+        if (e < 4) w1 = wt(nt + 4 * q + e, j);
+        else { const int m = 4 * q + e - 4; w1 = m < 2 * nt ? wt(trow(m), j) : 0; }
+        mc[64 + l] |= (unsigned long long)w1 << (8 * e);
+        if (e < 4) { const int m = 16 + 4 * q + e; mc[128 + l] |= (unsigned long long)(m < 2 * nt ? wt(trow(m), j) : 0) << (8 * e); }
       }
-    if (!rc) rc = upload(h, h->ftab3, tab3.data(), tab3.size() * sizeof(unsigned long long));
+    }
+    for (int v = 0; v < 256; ++v)
+      for (int e = 0; e < 8; ++e) ex[v] |= (unsigned long long)((v >> e) & 1) << (8 * e);
+    rc = upload(h, h->ftab3, mc.data(), mc.size() * 8);
+    if (!rc) rc = upload(h, h->xexp, ex.data(), ex.size() * 8);
   }
   if (!rc) rc = ensure(h, h->thresh, (size_t)h->FS * sizeof(double));
   if (rc) {
@@ -694,7 +703,7 @@ extern "C" int sg_destroy(sg_handle* h) {
   for (DevBuf* b : {&h->tw64, &h->tw32, &h->wfull64, &h->wa32, &h->ws32, &h->wsq32, &h->kf, &h->kt, &h->thresh,
                     &h->P, &h->pmax, &h->thr_rows, &h->raw, &h->M, &h->seg, &h->yn, &h->bits, &h->K16, &h->umax,
                     &h->need, &h->T2, &h->part, &h->tw512, &h->invn, &h->seam, &h->ftab, &h->xbits, &h->xflags,
-                    &h->xticket, &h->ftab3, &h->czt_tw64, &h->czt_ch64,
+                    &h->xticket, &h->ftab3, &h->xexp, &h->czt_tw64, &h->czt_ch64,
                     &h->czt_bh64, &h->czt_tw32, &h->czt_ch32, &h->czt_bh32})
     free_buf(*b);
   delete h;
@@ -1137,7 +1146,7 @@ static int stage_apply_fast(sg_handle* h, const View& v, const Geom& g, int64_t 
 // (the caller then runs the three-kernel path).
 static bool onepass_ok(const sg_handle* h, const Geom& g, const OutMap& om) {
   if (h->force_split || h->force_f64_decide || h->force_noseam || h->force_nolean) return false;
-  if (!h->p.smooth_mask || h->p.n_grad_freq > 5 || h->p.n_grad_time > fast::OP_MAX_NT || !h->ftab3.p) return false;
+  if (!h->p.smooth_mask || h->p.n_grad_freq > 8 || h->p.n_grad_time > fast::OP_MAX_NT || !h->ftab3.p) return false;
   if (g.F != 513) return false;
   const int64_t hb = (om.p0 + g.padL) / 256, he = (om.p1 - 1 + g.padL) / 256 + 1;
   return (he - hb + 3 + 15) / 16 >= 2;  // at least two abutting tiles (seam mode)
@@ -1191,11 +1200,12 @@ static int stage_onepass(sg_handle* h, const View& v, const Geom& g, int64_t ub,
   P.ticket = (unsigned*)h->xticket.p;
   P.epoch = h->epoch;
   P.nf = h->p.n_grad_freq; P.nt = h->p.n_grad_time;
-  P.ftab3 = (const unsigned long long*)h->ftab3.p;
+  P.mconst = (const unsigned long long*)h->ftab3.p;
+  P.exp8 = (const unsigned long long*)h->xexp.p;
   {
     ProfScope ps(h, SG_STAGE_ONEPASS, st);
     const size_t lds = (size_t)(fast::FN + WAVES * fast::WAVE_CX_H) * sizeof(fast::cf) + (1024 + 528) * sizeof(float) +
-                       192 * 8 + 16;
+                       256 * 8 + 16;
     auto kern = fast::k_gate_onepass<WAVES>;
     HIPCHK(h, hipFuncSetAttribute(reinterpret_cast<const void*>(kern),
                                   hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));

@@ -50,7 +50,8 @@ struct OnePassArgs {
   unsigned* ticket;           // work counter (zeroed before the launch)
   unsigned epoch;
   int nf, nt;
-  const unsigned long long* ftab3;  // [3][64]: packed byte counts of 8 adjacent bins per 6 window bits
+  const unsigned long long* mconst;  // [3][64] per-lane MFMA operands: freq band B, time weights A (slots 0..31, 32..63)
+  const unsigned long long* exp8;    // [256]: byte v -> 8 bytes (v >> e) & 1
 };
 
 // exact float64 |X[f]|^2 of frame t (see k_decide_fast)
@@ -91,21 +92,21 @@ __global__ __launch_bounds__(WAVES * 64, 3) void k_gate_onepass(OnePassArgs P) {
   cf* regions = tw512 + FN;
   float* swin = reinterpret_cast<float*>(regions + WAVES * WAVE_CX_H);
   float* s_t2 = swin + 1024;
-  unsigned long long* s_tab = reinterpret_cast<unsigned long long*>(s_t2 + 528);
-  unsigned* s_misc = reinterpret_cast<unsigned*>(s_tab + 192);
+  unsigned long long* s_exp = reinterpret_cast<unsigned long long*>(s_t2 + 528);
+  unsigned* s_misc = reinterpret_cast<unsigned*>(s_exp + 256);
   constexpr int NF = 4 * WAVES;
   const ApplyArgs& A = P.A;
   const Geom& G = A.g;
   const int tid = threadIdx.x;
   const int lane = tid & 63, wave = tid >> 6;
   const int g = lane >> 4, c = lane & 15;
-  const int nt = P.nt, nf = P.nf;
+  const int nt = P.nt;
 
   if (tid == 0) s_misc[0] = atomicAdd(P.ticket, 1u);
   for (int i = tid; i < FN; i += WAVES * 64) tw512[i] = A.tw512[(i >> 4) * (i & 15)];
   for (int i = tid; i < 256; i += WAVES * 64)
     reinterpret_cast<float4*>(swin)[i] = reinterpret_cast<const float4*>(A.win)[i];
-  if (tid < 192) s_tab[tid] = P.ftab3[tid];
+  s_exp[tid] = P.exp8[tid];
   __syncthreads();
   const int ntt = A.n_tiles + 2;                 // tiles per unit incl. one decide-only halo tile per side
   const unsigned ticket = s_misc[0];
@@ -279,6 +280,9 @@ __global__ __launch_bounds__(WAVES * 64, 3) void k_gate_onepass(OnePassArgs P) {
     }
 #pragma unroll
     for (int sl = 1; sl < 16; ++sl) {
+      // keep the constant loads next to their use: hoisted to the top of the stage (the scheduler's default)
+      // they occupy 32 registers next to the 64 of the spectra
+      if ((sl & 3) == 0) __builtin_amdgcn_sched_barrier(0);
       const cf a = sl < 8 ? v[sl] : sel(v[8 + sl], v[sl]);
       const cf b = sl < 8 ? sel(v[16 - sl], v[31 - sl]) : sel(v[39 - sl], v[31 - sl]);
       const cf w = mul_tw<false>(sl < 8 ? wlo : whi, twc<32>(sl), tws<32>(sl));
@@ -287,6 +291,7 @@ __global__ __launch_bounds__(WAVES * 64, 3) void k_gate_onepass(OnePassArgs P) {
       decide(Pk, t2[sl], sl);
       decide(Pn, t2[31 - sl], 31 - sl);
     }
+    __builtin_amdgcn_sched_barrier(0);
     if (!fvalid) { amb = 0; amb512 = false; pred = 0; pred512 = false; }
     // exact re-evaluation, one cell at a time, whole wave cooperating
     while ((OP_ABLATE & 8) == 0) {
@@ -348,19 +353,55 @@ __global__ __launch_bounds__(WAVES * 64, 3) void k_gate_onepass(OnePassArgs P) {
     __hip_atomic_store(&P.flags[(size_t)u * ntt + (jt + 1)], P.epoch, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
   if (halo_tile) return;
 
-  // ---- bit tile of rows tf_tile - nt .. tf_tile + 16 + nt in LDS -------------------------------------
-  const int rows = NF + 2 * nt;
-  constexpr int WP = OP_XW + 2;  // one zero word on each side of every row
-  unsigned long long* wb = reinterpret_cast<unsigned long long*>(regions);
-  unsigned long long* Hb = wb + (((size_t)rows * WP + 1) & ~(size_t)1);
+  // ---- smoothing on the matrix cores (exact integer arithmetic, v_mfma_i32_16x16x32_i8) ----------------
+  // The separable triangle filter is two small dense contractions per 16-bin block:
+  //   H[row][bin]  = sum_k  bit[row][16 b - 8 + k] * vf[k - 8 - j]        (A = 16 rows x 32 bins of 0/1 bytes,
+  //                                                                          B = 32 x 16 band matrix, constant)
+  //   K[frame][bin] = sum_row vt[row - frame - nt] * H[row][bin]           (A = 16 frames x 32 row slots, constant,
+  //                                                                          B = H as bytes: H <= (nf+1)^2 <= 81)
+  // The first product's result layout (lane = bin column, 4 consecutive rows per lane group) IS the second
+  // product's B layout once its k slots are numbered accordingly, so H never leaves the registers.  Row block 0
+  // = the tile's OWN 16 rows: its H is computed before the neighbours' flags are polled (the hand-off latency
+  // hides behind it); row blocks 1, 2 = the 2 nt neighbour rows.
+  constexpr int WP = OP_XW + 2;        // one zero word on each side of every bit row
+  constexpr int WPB = WP * 8;          // bytes per row
+  constexpr int SLICE_B = WAVE_CX_H * 8;
+  char* rbytes = reinterpret_cast<char*>(regions);
+  unsigned long long* wb = reinterpret_cast<unsigned long long*>(rbytes + 4 * OP_KP * 2);  // tail of slice 0: 48 rows
+  static_assert(4 * OP_KP * 2 + 48 * WPB <= SLICE_B, "bit rows must fit behind wave 0's K rows");
+  const unsigned char* wbb = reinterpret_cast<const unsigned char*>(wb);
   if (c < OP_XW) wb[(nt + 4 * wave + g) * WP + 1 + c] = myword;
-  for (int r = tid; r < rows; r += WAVES * 64) {
+  for (int r = tid; r < 48; r += WAVES * 64) {
     wb[r * WP] = 0ull;
     wb[r * WP + WP - 1] = 0ull;
   }
+  const int q4 = lane >> 4, j16 = lane & 15;
+  const long Bf = (long)P.mconst[lane], At1 = (long)P.mconst[64 + lane], At2 = (long)P.mconst[128 + lane];
+  const bool three = 2 * nt > 16;      // a third row block (wave-uniform)
+  // neighbour-list index m -> tile row: m < nt: row m (previous tile), else row nt + 16 + (m - nt) (next tile)
+  const int m1 = j16, m2 = 16 + j16;
+  const int r1 = m1 < 2 * nt ? (m1 < nt ? m1 : 16 + m1) : 0;
+  const int r2 = m2 < 2 * nt ? (m2 < nt ? m2 : 16 + m2) : 0;
+  __syncthreads();
+  typedef int op_v4i __attribute__((ext_vector_type(4)));
+  const op_v4i zero4 = {0, 0, 0, 0};
+  unsigned hown[9];   // H of the own rows, 4 bytes per 16-bin block
+  {
+    const unsigned char* rp = wbb + (nt + j16) * WPB + 7 + q4;
+#pragma unroll
+    for (int nb = 0; nb < 9; ++nb) {
+      const int b = wave + 4 * nb;
+      hown[nb] = 0u;
+      if (b < 33) {
+        const long a = (long)s_exp[rp[2 * b]];
+        const op_v4i h = __builtin_amdgcn_mfma_i32_16x16x32_i8(a, Bf, zero4, 0, 0, 0);
+        hown[nb] = (unsigned)h[0] | ((unsigned)h[1] << 8) | ((unsigned)h[2] << 16) | ((unsigned)h[3] << 24);
+      }
+    }
+  }
   if (tid < 2 && !(OP_ABLATE & 2)) {
     const unsigned* fp = &P.flags[(size_t)u * ntt + (jt + 1) + (tid ? 1 : -1)];
-    while (__hip_atomic_load(fp, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != P.epoch) __builtin_amdgcn_s_sleep(4);
+    while (__hip_atomic_load(fp, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != P.epoch) __builtin_amdgcn_s_sleep(2);
   }
   __syncthreads();
   for (int i = tid; i < 2 * nt * OP_XW; i += WAVES * 64) {
@@ -373,70 +414,36 @@ __global__ __launch_bounds__(WAVES * 64, 3) void k_gate_onepass(OnePassArgs P) {
     wb[(side ? nt + NF + rr : rr) * WP + 1 + w] = word;
   }
   __syncthreads();
-
-  // ---- smoothing, phase 1 (along f): packed byte counts of 8 adjacent bins per (row, group) ----------
-  for (int task = tid; task < ((OP_ABLATE & 4) ? 0 : rows * OP_HG); task += WAVES * 64) {
-    const int r = task / OP_HG, grp = task - r * OP_HG;
-    const unsigned long long* rb = wb + (size_t)r * WP + 1;  // word w at rb[w], rb[-1] = 0
-    const int start = 8 * grp - nf + 64;                     // bit index in the stream that begins at rb[-1]
-    const int wi = (start >> 6) - 1, sh = start & 63;
-    const unsigned long long lo = rb[wi], hi = rb[wi + 1];
-    const unsigned win = (unsigned)(sh == 0 ? lo : ((lo >> sh) | (hi << (64 - sh)))) & 0x3ffffu;
-    Hb[task] = s_tab[win & 63u] + s_tab[64 + ((win >> 6) & 63u)] + s_tab[128 + (win >> 12)];
-  }
-  __syncthreads();
-
-  // ---- phase 2 (along t): this wave's 4 frames, lane = 8-bin group (bin 512 rides in every lane) ------
-  unsigned kacc[4][4];
-  unsigned kx[4];
-#pragma unroll
-  for (int i = 0; i < 4; ++i) {
-    kx[i] = 0u;
-#pragma unroll
-    for (int q = 0; q < 4; ++q) kacc[i][q] = 0u;
-  }
   {
-    const unsigned long long* hrow = Hb + (size_t)(4 * wave) * OP_HG;
-    const int nr = (OP_ABLATE & 4) ? 1 : 4 + 2 * nt;
-#pragma unroll 2
-    for (int r = 0; r < nr; ++r) {
-      const unsigned long long h8 = hrow[(size_t)r * OP_HG + lane];
-      const unsigned hx = (unsigned)(hrow[(size_t)r * OP_HG + 64] & 0xffull);
-      const unsigned hl = (unsigned)h8, hh = (unsigned)(h8 >> 32);
-      unsigned p[4];
-      p[0] = __builtin_amdgcn_perm(0u, hl, 0x0c010c00u);   // (b0, b1) as two uint16
-      p[1] = __builtin_amdgcn_perm(0u, hl, 0x0c030c02u);   // (b2, b3)
-      p[2] = __builtin_amdgcn_perm(0u, hh, 0x0c010c00u);
-      p[3] = __builtin_amdgcn_perm(0u, hh, 0x0c030c02u);
+    const unsigned char* rp1 = wbb + r1 * WPB + 7 + q4;
+    const unsigned char* rp2 = wbb + r2 * WPB + 7 + q4;
 #pragma unroll
-      for (int i = 0; i < 4; ++i) {
-        const int d = r - i - nt;                    // wave-uniform
-        const int ad = d < 0 ? -d : d;
-        const unsigned w = ad <= nt ? (unsigned)(nt + 1 - ad) : 0u;
-        const unsigned w2 = w | (w << 16);
-        op_us2 ww = __builtin_bit_cast(op_us2, w2);
-#pragma unroll
-        for (int q = 0; q < 4; ++q) {
-          op_us2 acc = __builtin_bit_cast(op_us2, kacc[i][q]);
-          op_us2 pv = __builtin_bit_cast(op_us2, p[q]);
-          acc = acc + pv * ww;
-          kacc[i][q] = __builtin_bit_cast(unsigned, acc);
+    for (int nb = 0; nb < 9; ++nb) {
+      const int b = wave + 4 * nb;
+      if (b < 33) {
+        const long a1 = (long)s_exp[rp1[2 * b]];
+        const op_v4i h1 = __builtin_amdgcn_mfma_i32_16x16x32_i8(a1, Bf, zero4, 0, 0, 0);
+        const unsigned p1 = (unsigned)h1[0] | ((unsigned)h1[1] << 8) | ((unsigned)h1[2] << 16) | ((unsigned)h1[3] << 24);
+        const long bt1 = (long)(((unsigned long long)p1 << 32) | (unsigned long long)hown[nb]);
+        op_v4i d = __builtin_amdgcn_mfma_i32_16x16x32_i8(At1, bt1, zero4, 0, 0, 0);
+        if (three) {
+          const long a2 = (long)s_exp[rp2[2 * b]];
+          const op_v4i h2 = __builtin_amdgcn_mfma_i32_16x16x32_i8(a2, Bf, zero4, 0, 0, 0);
+          const unsigned p2 = (unsigned)h2[0] | ((unsigned)h2[1] << 8) | ((unsigned)h2[2] << 16) | ((unsigned)h2[3] << 24);
+          d = __builtin_amdgcn_mfma_i32_16x16x32_i8(At2, (long)(unsigned long long)p2, d, 0, 0, 0);
         }
-        kx[i] += hx * w;
+        // lane group q4 holds output frames 4 q4 .. 4 q4 + 3 = wave q4's frames: K rows live in THAT wave's slice
+        unsigned short* kd = reinterpret_cast<unsigned short*>(rbytes + q4 * SLICE_B) + 16 * b + j16;
+        kd[0] = (unsigned short)d[0];
+        kd[OP_KP] = (unsigned short)d[1];
+        kd[2 * OP_KP] = (unsigned short)d[2];
+        kd[3 * OP_KP] = (unsigned short)d[3];
       }
     }
   }
-  __syncthreads();  // every wave has its sums: the H rows (shared) may be overwritten
+  __syncthreads();  // K of all 16 frames complete; from here every wave touches only its own slice
 
-  // ---- K of this wave's 4 frames through its own slice: natural order in, lane order out -------------
-  unsigned short* kt = reinterpret_cast<unsigned short*>(regions + wave * WAVE_CX_H);
-  static_assert(4 * OP_KP * 2 <= WAVE_CX_H * 8, "K tile must fit the wave's slice");
-#pragma unroll
-  for (int i = 0; i < 4; ++i) {
-    *reinterpret_cast<uint4*>(kt + i * OP_KP + 8 * lane) = make_uint4(kacc[i][0], kacc[i][1], kacc[i][2], kacc[i][3]);
-    if (lane == 0) kt[i * OP_KP + 512] = (unsigned short)kx[i];
-  }
-  wave_lds_sync();
+  const unsigned short* kt = reinterpret_cast<const unsigned short*>(rbytes + wave * SLICE_B);
   // entry e of this lane = bin c + 32 e (e < 16) or (32 - c) + 32 (e - 16); lane 0 pairs its bins
   // differently (bin_of_entry): read where used, two 16-bit LDS loads per conjugate pair
   const unsigned short* krow = kt + g * OP_KP;
@@ -512,8 +519,9 @@ __global__ __launch_bounds__(WAVES * 64, 3) void k_gate_onepass(OnePassArgs P) {
     // addresses would stay live -- and be spilled -- across the whole smoothing phase
     cf* fbi = fb;
     const cf* twi = tw512;
-    asm volatile("" : "+v"(fbi), "+v"(twi));
-    fft512_inv_half(v, fbi, twi, c);
+    int ci = c;
+    asm volatile("" : "+v"(fbi), "+v"(twi), "+v"(ci));
+    fft512_inv_half(v, fbi, twi, ci);
   }
   float* acc = reinterpret_cast<float*>(regions + wave * WAVE_CX_H);
   {
