@@ -917,17 +917,19 @@ __global__ __launch_bounds__(WAVES * 64, 3) void k_decide_fast(DecideArgs A) {
     }
     {
       // keep the loop-invariant twiddle reads inside the loop: hoisted, they would pin ~100 VGPRs
-      const cf* twl = tw512;
-      asm volatile("" : "+v"(twl));
-      fft512_fwd_half(v, fb, twl, c);
+      // (an opaque zero OFFSET: an opaque pointer would lose the LDS address space -> FLAT loads)
+      int z0 = 0;
+      asm volatile("" : "+v"(z0));
+      fft512_fwd_half(v, fb, tw512 + z0, c);
     }
     cf wl = wl0;
     asm volatile("" : "+v"(wl.x), "+v"(wl.y));
     float t2[32];
     float t2_512;
     {
-      const float* tp = s_t2;
-      asm volatile("" : "+v"(tp));
+      int zt = 0;
+      asm volatile("" : "+v"(zt));
+      const float* tp = s_t2 + zt;
       const float4* t4 = reinterpret_cast<const float4*>(tp + c * 32);
 #pragma unroll
       for (int q4 = 0; q4 < 8; ++q4) {

@@ -225,9 +225,11 @@ __global__ __launch_bounds__(WAVES * 64, 3) void k_gate_onepass(OnePassArgs P) {
     nrm2 += __shfl_xor(nrm2, 8);
   }
   {
-    const cf* twl = tw512;
-    asm volatile("" : "+v"(twl));
-    fft512_fwd_half(v, fb, twl, c);
+    // an opaque ZERO OFFSET (not an opaque pointer: that would lose the LDS address space and turn every
+    // access into a FLAT instruction) keeps the loop-invariant twiddle reads from being hoisted and pinned
+    int z0 = 0;
+    asm volatile("" : "+v"(z0));
+    fft512_fwd_half(v, fb, tw512 + z0, c);
   }
 
   // ---- decide (k_decide_fast): mask bits of this lane's 32 entries -----------------------------------
@@ -239,8 +241,9 @@ __global__ __launch_bounds__(WAVES * 64, 3) void k_gate_onepass(OnePassArgs P) {
     asm volatile("" : "+v"(wl.x), "+v"(wl.y));
     // compare constants are read from LDS where they are used (the spectra stay live through this phase:
     // 32 more registers for a preloaded table would spill)
-    const float* t2 = s_t2 + c * 32;
-    asm volatile("" : "+v"(t2));
+    int zt = 0;
+    asm volatile("" : "+v"(zt));
+    const float* t2 = s_t2 + c * 32 + zt;
     const float t2_512 = s_t2[512];
     const float d2 = nrm2 > 0.f ? 8.0f * 2.3283064e-10f * nrm2 : -1.0f;
     unsigned pred = 0, amb = 0;
@@ -517,11 +520,9 @@ __global__ __launch_bounds__(WAVES * 64, 3) void k_gate_onepass(OnePassArgs P) {
   {
     // fresh address arithmetic for the inverse exchange: shared with the forward transform (CSE) the 16 row
     // addresses would stay live -- and be spilled -- across the whole smoothing phase
-    cf* fbi = fb;
-    const cf* twi = tw512;
-    int ci = c;
-    asm volatile("" : "+v"(fbi), "+v"(twi), "+v"(ci));
-    fft512_inv_half(v, fbi, twi, ci);
+    int zi = 0, ci = c;
+    asm volatile("" : "+v"(zi), "+v"(ci));
+    fft512_inv_half(v, fb + zi, tw512 + zi, ci);
   }
   float* acc = reinterpret_cast<float*>(regions + wave * WAVE_CX_H);
   {
