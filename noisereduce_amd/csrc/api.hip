@@ -1205,7 +1205,7 @@ static int stage_onepass(sg_handle* h, const View& v, const Geom& g, int64_t ub,
   {
     ProfScope ps(h, SG_STAGE_ONEPASS, st);
     const size_t lds = (size_t)(fast::FN + WAVES * fast::WAVE_CX_H) * sizeof(fast::cf) + (1024 + 528) * sizeof(float) +
-                       256 * 8 + 16;
+                       256 * 8 + 514 * 8 + 16;
     auto kern = fast::k_gate_onepass<WAVES>;
     HIPCHK(h, hipFuncSetAttribute(reinterpret_cast<const void*>(kern),
                                   hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));

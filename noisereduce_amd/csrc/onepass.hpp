@@ -93,7 +93,8 @@ __global__ __launch_bounds__(WAVES * 64, 3) void k_gate_onepass(OnePassArgs P) {
   float* swin = reinterpret_cast<float*>(regions + WAVES * WAVE_CX_H);
   float* s_t2 = swin + 1024;
   unsigned long long* s_exp = reinterpret_cast<unsigned long long*>(s_t2 + 528);
-  unsigned* s_misc = reinterpret_cast<unsigned*>(s_exp + 256);
+  double* s_t2d = reinterpret_cast<double*>(s_exp + 256);   // exact compare constants (refinement), same order
+  unsigned* s_misc = reinterpret_cast<unsigned*>(s_t2d + 514);
   constexpr int NF = 4 * WAVES;
   const ApplyArgs& A = P.A;
   const Geom& G = A.g;
@@ -129,6 +130,7 @@ __global__ __launch_bounds__(WAVES * 64, 3) void k_gate_onepass(OnePassArgs P) {
   for (int i = tid; i <= 512; i += WAVES * 64) {
     double v = t2eff(perm_inv(i));
     s_t2[i] = v < 0.0 ? -3.0e38f : (float)(4.0 * v);
+    s_t2d[i] = v;   // the rare exact re-evaluation compares against this (no log10 in the hot kernel body)
   }
 
   const int64_t tf_tile = A.h_begin - 3 + (int64_t)jt * NF;  // first frame of the tile (abutting tiles)
@@ -233,12 +235,42 @@ __global__ __launch_bounds__(WAVES * 64, 3) void k_gate_onepass(OnePassArgs P) {
   }
 
   // ---- decide (k_decide_fast): mask bits of this lane's 32 entries -----------------------------------
+  // ---- real-FFT split, ONCE: conjugate pair (a, b) = (Zc[k], Zc[N-k]) -> X2[k] = E + w O, conj-pair value
+  // X2n = E - w O (both 2x the spectrum; E = a + conj b, O = (a - conj b)/i).  Slot order (see k_apply_fast):
+  // lanes >= 1 pair registers (sl, 31 - sl); lane 0 pairs its self-conjugate rows differently, handled by
+  // selects on the way in HERE only -- the decision stage and the mask stage both read pa/pb in slot order.
+  cf pa[16], pb[16];
+  const cf raw0 = v[0], raw8 = v[8];   // lane 0: bins 0 / 512 and bin 256 are not part of a pair
+  const bool l0 = c == 0;
+  cf wlo = A.tw1024[c];
+  asm volatile("" : "+v"(wlo.x), "+v"(wlo.y));
+  cf whi = wlo;
+  {
+    const cf w16 = A.tw1024[16];
+    if (l0) whi = {-w16.y, w16.x};  // i * w_1024^16
+  }
+  {
+    auto sel = [&](cf a0, cf a1) -> cf { return {l0 ? a0.x : a1.x, l0 ? a0.y : a1.y}; };
+    auto split = [&](cf a, cf b2, cf w, cf& xa, cf& xb) {
+      cf E = {a.x + b2.x, a.y - b2.y};
+      cf O = {a.y + b2.y, b2.x - a.x};
+      cf wO = cmul(w, O);
+      xa = {E.x + wO.x, E.y + wO.y};
+      xb = {E.x - wO.x, E.y - wO.y};
+    };
+    split(v[0], v[31], wlo, pa[0], pb[0]);
+#pragma unroll
+    for (int sl = 1; sl < 16; ++sl) {
+      const cf a = sl < 8 ? v[sl] : sel(v[8 + sl], v[sl]);
+      const cf b2 = sl < 8 ? sel(v[16 - sl], v[31 - sl]) : sel(v[39 - sl], v[31 - sl]);
+      const cf w = mul_tw<false>(sl < 8 ? wlo : whi, twc<32>(sl), tws<32>(sl));
+      split(a, b2, w, pa[sl], pb[sl]);
+    }
+  }
+
+  // ---- decide (k_decide_fast): mask bits of this lane's 32 entries -----------------------------------
   unsigned long long myword;  // lane c < 9 of group g: word c of frame tq + g
-  if constexpr ((OP_ABLATE & 1) != 0) {
-    myword = (unsigned long long)__float_as_uint(v[c].x + nrm2);
-  } else {
-    cf wl = A.tw1024[c];
-    asm volatile("" : "+v"(wl.x), "+v"(wl.y));
+  {
     // compare constants are read from LDS where they are used (the spectra stay live through this phase:
     // 32 more registers for a preloaded table would spill)
     int zt = 0;
@@ -252,29 +284,12 @@ __global__ __launch_bounds__(WAVES * 64, 3) void k_gate_onepass(OnePassArgs P) {
       pred |= (diff > 0.f ? 1u : 0u) << q;
       amb |= ((diff * diff <= d2 * (Pw + T)) ? 1u : 0u) << q;
     };
-    auto pair_power = [&](cf a, cf b, cf w, float& Pk, float& Pn) {
-      cf E = {a.x + b.x, a.y - b.y};
-      cf O = {a.y + b.y, b.x - a.x};
-      cf wO = cmul(w, O);
-      float px = E.x + wO.x, py = E.y + wO.y, qx = E.x - wO.x, qy = E.y - wO.y;
-      Pk = px * px + py * py;
-      Pn = qx * qx + qy * qy;
-    };
-    const bool l0 = c == 0;
-    const cf wlo = wl;
-    cf whi = wl;
-    {
-      const cf w16 = A.tw1024[16];
-      if (l0) whi = {-w16.y, w16.x};  // i * w_1024^16
-    }
-    auto sel = [&](cf a0, cf a1) -> cf { return {l0 ? a0.x : a1.x, l0 ? a0.y : a1.y}; };
     bool pred512 = false, amb512 = false;
     {
-      float Pk, Pn;
-      pair_power(v[0], v[31], wlo, Pk, Pn);
-      const cf a = v[0];
-      const float x0 = 2.f * (a.x + a.y), xN = 2.f * (a.x - a.y);
-      const float P256 = 4.f * (v[8].x * v[8].x + v[8].y * v[8].y);
+      const float Pk = pa[0].x * pa[0].x + pa[0].y * pa[0].y;
+      const float Pn = pb[0].x * pb[0].x + pb[0].y * pb[0].y;
+      const float x0 = 2.f * (raw0.x + raw0.y), xN = 2.f * (raw0.x - raw0.y);
+      const float P256 = 4.f * (raw8.x * raw8.x + raw8.y * raw8.y);
       decide(l0 ? x0 * x0 : Pk, t2[0], 0);
       decide(l0 ? P256 : Pn, t2[31], 31);
       const float P5 = xN * xN, d5 = P5 - t2_512;
@@ -283,39 +298,50 @@ __global__ __launch_bounds__(WAVES * 64, 3) void k_gate_onepass(OnePassArgs P) {
     }
 #pragma unroll
     for (int sl = 1; sl < 16; ++sl) {
-      // keep the constant loads next to their use: hoisted to the top of the stage (the scheduler's default)
-      // they occupy 32 registers next to the 64 of the spectra
-      if ((sl & 3) == 0) __builtin_amdgcn_sched_barrier(0);
-      const cf a = sl < 8 ? v[sl] : sel(v[8 + sl], v[sl]);
-      const cf b = sl < 8 ? sel(v[16 - sl], v[31 - sl]) : sel(v[39 - sl], v[31 - sl]);
-      const cf w = mul_tw<false>(sl < 8 ? wlo : whi, twc<32>(sl), tws<32>(sl));
-      float Pk, Pn;
-      pair_power(a, b, w, Pk, Pn);
-      decide(Pk, t2[sl], sl);
-      decide(Pn, t2[31 - sl], 31 - sl);
+      if ((sl & 3) == 0) __builtin_amdgcn_sched_barrier(0);  // keep the constant loads next to their use
+      decide(pa[sl].x * pa[sl].x + pa[sl].y * pa[sl].y, t2[sl], sl);
+      decide(pb[sl].x * pb[sl].x + pb[sl].y * pb[sl].y, t2[31 - sl], 31 - sl);
     }
     __builtin_amdgcn_sched_barrier(0);
     if (!fvalid) { amb = 0; amb512 = false; pred = 0; pred512 = false; }
-    // exact re-evaluation, one cell at a time, whole wave cooperating
-    while ((OP_ABLATE & 8) == 0) {
-      const unsigned long long pending = __ballot(amb != 0 || amb512);
-      if (pending == 0) break;
-      const int src = __ffsll((long long)pending) - 1;
-      const unsigned amb_s = (unsigned)__shfl((int)amb, src);
-      const int q = amb_s ? (__ffs((int)amb_s) - 1) : 32;
-      const int cs = src & 15, gs = src >> 4;
-      const int f = q < 32 ? bin_of_entry(cs, q) : 512;
-      const double Pe = op_exact_power(P, row, chunk, tq + gs, f, lane);
-      const bool pass = Pe > t2eff(f);
-      if (lane == src) {
-        if (q < 32) {
-          pred = (pred & ~(1u << q)) | ((pass ? 1u : 0u) << q);
-          amb &= ~(1u << q);
-        } else {
-          pred512 = pass;
-          amb512 = false;
+    // exact re-evaluation, one cell at a time, whole wave cooperating.  Rare (about one wave in fifty has an
+    // ambiguous cell), but its float64 temporaries do not fit next to the 64 registers of the split spectra:
+    // the wave parks half of them (pb: 8 KB) in its idle exchange slice for the duration.
+    if ((OP_ABLATE & 8) == 0 && __ballot(amb != 0 || amb512) != 0ull) {
+      float* park = reinterpret_cast<float*>(regions + wave * WAVE_CX_H) + lane;
+      static_assert(64 * 32 * 4 <= WAVE_CX_H * 8, "parked registers must fit the wave's slice");
+#pragma unroll
+      for (int i = 0; i < 16; ++i) {
+        park[(2 * i) * 64] = pb[i].x;
+        park[(2 * i + 1) * 64] = pb[i].y;
+      }
+      while (true) {
+        const unsigned long long pending = __ballot(amb != 0 || amb512);
+        if (pending == 0) break;
+        const int src = __ffsll((long long)pending) - 1;
+        const unsigned amb_s = (unsigned)__shfl((int)amb, src);
+        const int q = amb_s ? (__ffs((int)amb_s) - 1) : 32;
+        const int cs = src & 15, gs = src >> 4;
+        const int f = q < 32 ? bin_of_entry(cs, q) : 512;
+        const double Pe = op_exact_power(P, row, chunk, tq + gs, f, lane);
+        const bool pass = Pe > s_t2d[q < 32 ? cs * 32 + q : 512];
+        if (lane == src) {
+          if (q < 32) {
+            pred = (pred & ~(1u << q)) | ((pass ? 1u : 0u) << q);
+            amb &= ~(1u << q);
+          } else {
+            pred512 = pass;
+            amb512 = false;
+          }
         }
       }
+      wave_lds_sync();
+#pragma unroll
+      for (int i = 0; i < 16; ++i) {
+        pb[i].x = park[(2 * i) * 64];
+        pb[i].y = park[(2 * i + 1) * 64];
+      }
+      wave_lds_sync();
     }
     if (l0)  // entry -> register: e 0..7 -> 0..7, 8..23 -> 16..31, 24..30 -> 9..15, 31 -> 8
       pred = (pred & 0xffu) | ((pred & 0x00ffff00u) << 8) | ((pred >> 15) & 0xfe00u) | ((pred >> 23) & 0x100u);
@@ -461,58 +487,45 @@ __global__ __launch_bounds__(WAVES * 64, 3) void k_gate_onepass(OnePassArgs P) {
     return (float)kv * scale;
   };
   {
-    const float ks = A.kscale * 0.25f;  // pair_mask leaves out four 1/2 factors
-    const bool l0 = c == 0;
-    const cf wlo = A.tw1024[c];
-    cf whi = wlo;
-    {
-      const cf w16 = A.tw1024[16];
-      if (l0) whi = {-w16.y, w16.x};
-    }
+    // mask -> merge (the second half of pair_mask): Yk = X2[k] mk, Yn = conj-pair value x mn, then back to the
+    // half-size complex spectrum.  The four 1/2 factors of split and merge ride in the mask scale.
+    const float ks = A.kscale * 0.25f;
     auto sel = [&](cf a0, cf a1) -> cf { return {l0 ? a0.x : a1.x, l0 ? a0.y : a1.y}; };
-    cf nv[32];
-    cf s0a = v[0], s0b = v[31];
-    pair_mask(s0a, s0b, wlo, mval(0, ks), mval(31, ks));
+    auto merge = [&](cf& xa, cf& xb, cf w, float mk, float mn) {
+      cf Yk = {xa.x * mk, xa.y * mk};
+      cf Yn = {xb.x * mn, (-xb.y) * mn};
+      cf Ep = {Yk.x + Yn.x, Yk.y - Yn.y};
+      cf D = {Yk.x - Yn.x, Yk.y + Yn.y};
+      cf Op = cmul(D, cf{w.x, -w.y});
+      xa = {Ep.x - Op.y, Ep.y + Op.x};
+      xb = {Ep.x + Op.y, Op.x - Ep.y};
+    };
+    merge(pa[0], pb[0], wlo, mval(0, ks), mval(31, ks));
+    cf z0, z8;
     {
-      const cf a = v[0];
-      const float y0 = (a.x + a.y) * mval(0, A.kscale);
-      const float yN = (a.x - a.y) * k512;
-      const cf z0 = {0.5f * (y0 + yN), 0.5f * (y0 - yN)};
+      const float y0 = (raw0.x + raw0.y) * mval(0, A.kscale);
+      const float yN = (raw0.x - raw0.y) * k512;
+      z0 = {0.5f * (y0 + yN), 0.5f * (y0 - yN)};
       const float m8 = mval(31, A.kscale);  // entry 31 of lane 0 = bin 256
-      const cf z8 = {v[8].x * m8, v[8].y * m8};
-      nv[0] = sel(z0, s0a);
-      nv[8] = z8;
-      nv[31] = s0b;
+      z8 = {raw8.x * m8, raw8.y * m8};
     }
-    cf pa[16], pb[16];
 #pragma unroll
     for (int sl = 1; sl < 16; ++sl) {
-      cf a = sl < 8 ? v[sl] : sel(v[8 + sl], v[sl]);
-      cf b = sl < 8 ? sel(v[16 - sl], v[31 - sl]) : sel(v[39 - sl], v[31 - sl]);
-      const cf wl = sl < 8 ? wlo : whi;
-      const cf w = mul_tw<false>(wl, twc<32>(sl), tws<32>(sl));
-      pair_mask(a, b, w, mval(sl, ks), mval(31 - sl, ks));
-      pa[sl] = a;
-      pb[sl] = b;
+      const cf w = mul_tw<false>(sl < 8 ? wlo : whi, twc<32>(sl), tws<32>(sl));
+      merge(pa[sl], pb[sl], w, mval(sl, ks), mval(31 - sl, ks));
     }
+    // scatter back: register i receives, for lanes >= 1, entry i; for lane 0, the entry that lives in register i
+    v[0] = sel(z0, pa[0]);
 #pragma unroll
-    for (int i = 1; i < 8; ++i) nv[i] = pa[i];
-    {
-      const cf keep8 = nv[8];
-      nv[8] = sel(keep8, pa[8]);
-    }
+    for (int i = 1; i < 8; ++i) v[i] = pa[i];
+    v[8] = sel(z8, pa[8]);
 #pragma unroll
-    for (int i = 9; i < 16; ++i) nv[i] = sel(pb[16 - i], pa[i]);
+    for (int i = 9; i < 16; ++i) v[i] = sel(pb[16 - i], pa[i]);
 #pragma unroll
-    for (int i = 16; i < 24; ++i) nv[i] = sel(pa[i - 8], pb[31 - i]);
+    for (int i = 16; i < 24; ++i) v[i] = sel(pa[i - 8], pb[31 - i]);
 #pragma unroll
-    for (int i = 24; i < 31; ++i) nv[i] = sel(pb[39 - i], pb[31 - i]);
-    {
-      const cf keep31 = nv[31];
-      nv[31] = sel(pb[8], keep31);
-    }
-#pragma unroll
-    for (int i = 0; i < 32; ++i) v[i] = nv[i];
+    for (int i = 24; i < 31; ++i) v[i] = sel(pb[39 - i], pb[31 - i]);
+    v[31] = sel(pb[8], pb[0]);
   }
   wave_lds_sync();  // K tile consumed: the slice is reused by the inverse transform
 
