@@ -60,6 +60,7 @@ struct sg_handle {
   DevBuf ftab;                       // k_smooth_bits2 phase-1 lookup tables (nf <= 5)
   // one-pass gate (onepass.hpp): published mask bits per tile, publication flags, work counter, tables
   DevBuf xbits, xflags, xticket, ftab3, xexp;  // ftab3: per-lane MFMA operands, xexp: bit -> byte table
+  unsigned ticket_base = 0;          // tickets handed out by all previous launches
   unsigned epoch = 0;                // launch counter: the value a tile's flag must carry to be current
   bool force_split = false;          // SG_OPT_FORCE_SPLIT: decide / smooth / apply as three kernels
   bool dbg_xbits = false;            // the last batch's mask bits live in xbits (tile-blocked)
@@ -153,6 +154,16 @@ static int ensure(sg_handle* h, DevBuf& b, size_t bytes) {
     FAIL(h, SG_E_NOMEM, "workspace allocation of %zu bytes failed: %s", bytes, hipGetErrorString(e));
   }
   b.bytes = bytes;
+  return SG_OK;
+}
+
+// ensure() + zero fill when the buffer was (re)allocated: for state that kernels keep clean themselves
+static int ensure_zeroed(sg_handle* h, DevBuf& b, size_t bytes, hipStream_t st, bool* fresh = nullptr) {
+  const void* before = b.p;
+  int rc = ensure(h, b, bytes);
+  if (rc) return rc;
+  if (fresh) *fresh = b.p != before;
+  if (b.p != before) HIPCHK(h, hipMemsetAsync(b.p, 0, b.bytes, st));
   return SG_OK;
 }
 
@@ -996,11 +1007,12 @@ static int stage_prep_floor(sg_handle* h, const View& v, const Geom& g, int64_t 
   const int wpr = (g.F + 63) / 64;
   int rc;
   if ((rc = ensure(h, h->bits, (size_t)ub * g.T * wpr * 8))) return rc;
-  if ((rc = ensure(h, h->umax, (size_t)ub * 4))) return rc;
+  // umax is kept clean by its consumer (k_prep_thresh zeroes what it read); pmax rows are zeroed by
+  // k_prep_thresh for exactly the units whose floor can be live (the only rows anybody reads): no memset
+  // launches on the critical path
+  if ((rc = ensure_zeroed(h, h->umax, (size_t)ub * 4, st))) return rc;
   if ((rc = ensure(h, h->need, (size_t)ub * 4))) return rc;
   if ((rc = ensure(h, h->T2, (size_t)g.FS * 8))) return rc;
-  HIPCHK(h, hipMemsetAsync(h->umax.p, 0, (size_t)ub * 4, st));
-  HIPCHK(h, hipMemsetAsync(h->pmax.p, 0, (size_t)ub * g.FS * 8, st));
   {
     ProfScope ps(h, SG_STAGE_PREP, st);
     hipLaunchKernelGGL(k_unit_absmax, dim3((unsigned)std::max<int64_t>(1, std::min<int64_t>(64, 2048 / ub)), (unsigned)ub),
@@ -1008,7 +1020,7 @@ static int stage_prep_floor(sg_handle* h, const View& v, const Geom& g, int64_t 
     HIPCHK(h, hipGetLastError());
     hipLaunchKernelGGL(k_prep_thresh, dim3((unsigned)((ub + 255) / 256)), dim3(256), 0, st,
                        (const double*)h->thresh.p, g.F, h->mag_scale, h->sum_abs_w, h->p.top_db,
-                       (const unsigned*)h->umax.p, ub, (double*)h->T2.p, (int*)h->need.p);
+                       (unsigned*)h->umax.p, ub, (double*)h->T2.p, (int*)h->need.p, (double*)h->pmax.p, g.FS);
     HIPCHK(h, hipGetLastError());
   }
   ThreshConsts tc{(const double*)h->T2.p, (const double*)h->thresh.p, (const double*)h->pmax.p,
@@ -1178,15 +1190,14 @@ static int stage_onepass(sg_handle* h, const View& v, const Geom& g, int64_t ub,
   A.n_tiles = (int)n_tiles;
   if ((rc = ensure(h, h->xbits, (size_t)ub * ntt * fast::OP_TILE_WORDS * 8))) return rc;
   {
-    const void* before = h->xflags.p;
-    if ((rc = ensure(h, h->xflags, (size_t)ub * ntt * 4))) return rc;
-    if (h->xflags.p != before) {  // fresh flags carry no epoch yet
-      HIPCHK(h, hipMemsetAsync(h->xflags.p, 0, h->xflags.bytes, st));
-      h->epoch = 0;
-    }
+    bool fresh = false;
+    if ((rc = ensure_zeroed(h, h->xflags, (size_t)ub * ntt * 4, st, &fresh))) return rc;
+    if (fresh) h->epoch = 0;  // fresh flags carry no epoch yet
+    // the work counter is never reset: every launch takes exactly ub * ntt tickets, the kernel subtracts the
+    // running base
+    if ((rc = ensure_zeroed(h, h->xticket, 64, st, &fresh))) return rc;
+    if (fresh) h->ticket_base = 0;
   }
-  if ((rc = ensure(h, h->xticket, 64))) return rc;
-  HIPCHK(h, hipMemsetAsync(h->xticket.p, 0, 4, st));
   if (++h->epoch == 0) {  // wrapped: flags of 2^32 launches ago could alias
     HIPCHK(h, hipMemsetAsync(h->xflags.p, 0, h->xflags.bytes, st));
     h->epoch = 1;
@@ -1199,6 +1210,8 @@ static int stage_onepass(sg_handle* h, const View& v, const Geom& g, int64_t ub,
   P.flags = (unsigned*)h->xflags.p;
   P.ticket = (unsigned*)h->xticket.p;
   P.epoch = h->epoch;
+  P.ticket_base = h->ticket_base;
+  h->ticket_base += (unsigned)(ub * ntt);
   P.nf = h->p.n_grad_freq; P.nt = h->p.n_grad_time;
   P.mconst = (const unsigned long long*)h->ftab3.p;
   P.exp8 = (const unsigned long long*)h->xexp.p;

@@ -67,9 +67,13 @@ __global__ void k_unit_absmax(View view, int64_t n_units, unsigned* __restrict__
 //   zero cell fails                            -> T2 = max(T2, 0)  (0 > 0 is false)
 // need_floor[u]: the floor max(dB, rowmax - top_db) can only lift a cell above thresh[f] if
 // rowmax_dB - top_db > thresh[f]; |X[k]| <= sum|x w| <= max|x| * sum|w| bounds rowmax.
+// Also keeps two buffers clean so that no memset launch sits on the critical path: umax_bits (zeroed after it
+// was read: k_unit_absmax of the NEXT call accumulates into it with atomicMax) and the pmax rows of the units
+// whose floor can be live (the floor pre-pass accumulates into them; nobody reads the other rows).
 __global__ void k_prep_thresh(const double* __restrict__ thresh, int F, double mag_scale, double sum_abs_w,
-                              double top_db, const unsigned* __restrict__ umax_bits, int64_t n_units,
-                              double* __restrict__ T2, int* __restrict__ need_floor) {
+                              double top_db, unsigned* __restrict__ umax_bits, int64_t n_units,
+                              double* __restrict__ T2, int* __restrict__ need_floor, double* __restrict__ pmax,
+                              int FS) {
   const double eps = 2.220446049250313e-16;
   __shared__ double s_min[256];
   double mn = 1e300;
@@ -98,8 +102,12 @@ __global__ void k_prep_thresh(const double* __restrict__ thresh, int F, double m
   for (int64_t u = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; u < n_units;
        u += (int64_t)gridDim.x * blockDim.x) {
     double ub = (double)__uint_as_float(umax_bits[u]) * sum_abs_w * mag_scale;
+    umax_bits[u] = 0u;
     double ub_db = 20.0 * log10(ub + eps) + 1e-6;  // margin covers log10/rounding slack
-    need_floor[u] = (ub_db - top_db > min_thresh) ? 1 : 0;
+    const int need = (ub_db - top_db > min_thresh) ? 1 : 0;
+    need_floor[u] = need;
+    if (need)
+      for (int f = 0; f < FS; ++f) pmax[u * (int64_t)FS + f] = 0.0;
   }
 }
 

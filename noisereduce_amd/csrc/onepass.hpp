@@ -47,7 +47,8 @@ struct OnePassArgs {
   double mag_scale, top_db;
   unsigned long long* xbits;  // [units][n_tiles + 2][16][OP_XW] published mask bits
   unsigned* flags;            // [units][n_tiles + 2] epoch of the last publication
-  unsigned* ticket;           // work counter (zeroed before the launch)
+  unsigned* ticket;           // work counter: never reset, a launch takes exactly units * (n_tiles + 2) tickets
+  unsigned ticket_base;       // its value before this launch
   unsigned epoch;
   int nf, nt;
   const unsigned long long* mconst;  // [3][64] per-lane MFMA operands: freq band B, time weights A (slots 0..31, 32..63)
@@ -103,7 +104,7 @@ __global__ __launch_bounds__(WAVES * 64, 3) void k_gate_onepass(OnePassArgs P) {
   const int g = lane >> 4, c = lane & 15;
   const int nt = P.nt;
 
-  if (tid == 0) s_misc[0] = atomicAdd(P.ticket, 1u);
+  if (tid == 0) s_misc[0] = atomicAdd(P.ticket, 1u) - P.ticket_base;
   for (int i = tid; i < FN; i += WAVES * 64) tw512[i] = A.tw512[(i >> 4) * (i & 15)];
   for (int i = tid; i < 256; i += WAVES * 64)
     reinterpret_cast<float4*>(swin)[i] = reinterpret_cast<const float4*>(A.win)[i];
@@ -462,7 +463,7 @@ __global__ __launch_bounds__(WAVES * 64, 3) void k_gate_onepass(OnePassArgs P) {
           d = __builtin_amdgcn_mfma_i32_16x16x32_i8(At2, (long)(unsigned long long)p2, d, 0, 0, 0);
         }
         // lane group q4 holds output frames 4 q4 .. 4 q4 + 3 = wave q4's frames: K rows live in THAT wave's slice
-        unsigned short* kd = reinterpret_cast<unsigned short*>(rbytes + q4 * SLICE_B) + 16 * b + j16;
+        unsigned short* kd = reinterpret_cast<unsigned short*>(rbytes + q4 * (SLICE_B + 64)) + 16 * b + j16;  // +64 B per slice: the four lane groups hit disjoint banks
         kd[0] = (unsigned short)d[0];
         kd[OP_KP] = (unsigned short)d[1];
         kd[2 * OP_KP] = (unsigned short)d[2];
@@ -472,7 +473,7 @@ __global__ __launch_bounds__(WAVES * 64, 3) void k_gate_onepass(OnePassArgs P) {
   }
   __syncthreads();  // K of all 16 frames complete; from here every wave touches only its own slice
 
-  const unsigned short* kt = reinterpret_cast<const unsigned short*>(rbytes + wave * SLICE_B);
+  const unsigned short* kt = reinterpret_cast<const unsigned short*>(rbytes + wave * (SLICE_B + 64));
   // entry e of this lane = bin c + 32 e (e < 16) or (32 - c) + 32 (e - 16); lane 0 pairs its bins
   // differently (bin_of_entry): read where used, two 16-bit LDS loads per conjugate pair
   const unsigned short* krow = kt + g * OP_KP;
