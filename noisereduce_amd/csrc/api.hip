@@ -59,7 +59,7 @@ struct sg_handle {
   DevBuf seam;                       // partial seam hops of abutting apply tiles
   DevBuf ftab;                       // k_smooth_bits2 phase-1 lookup tables (nf <= 5)
   // one-pass gate (onepass.hpp): published mask bits per tile, publication flags, work counter, tables
-  DevBuf xbits, xflags, xticket, ftab3, xexp;  // ftab3: per-lane MFMA operands, xexp: bit -> byte table
+  DevBuf xbits, xpart, xticket, ftab3, xexp;  // ftab3: per-lane MFMA operands, xexp: bit -> byte table
   unsigned ticket_base = 0;          // tickets handed out by all previous launches
   unsigned epoch = 0;                // launch counter: the value a tile's flag must carry to be current
   bool force_split = false;          // SG_OPT_FORCE_SPLIT: decide / smooth / apply as three kernels
@@ -713,7 +713,7 @@ extern "C" int sg_destroy(sg_handle* h) {
   for (auto e : h->prof_pool) (void)hipEventDestroy(e);
   for (DevBuf* b : {&h->tw64, &h->tw32, &h->wfull64, &h->wa32, &h->ws32, &h->wsq32, &h->kf, &h->kt, &h->thresh,
                     &h->P, &h->pmax, &h->thr_rows, &h->raw, &h->M, &h->seg, &h->yn, &h->bits, &h->K16, &h->umax,
-                    &h->need, &h->T2, &h->part, &h->tw512, &h->invn, &h->seam, &h->ftab, &h->xbits, &h->xflags,
+                    &h->need, &h->T2, &h->part, &h->tw512, &h->invn, &h->seam, &h->ftab, &h->xbits, &h->xpart,
                     &h->xticket, &h->ftab3, &h->xexp, &h->czt_tw64, &h->czt_ch64,
                     &h->czt_bh64, &h->czt_tw32, &h->czt_ch32, &h->czt_bh32})
     free_buf(*b);
@@ -1185,21 +1185,21 @@ static int stage_onepass(sg_handle* h, const View& v, const Geom& g, int64_t ub,
   const int64_t nh = A.h_end - A.h_begin;
   const int64_t n_tiles = (nh + 3 + NF - 1) / NF;
   const int64_t ntt = n_tiles + 2;
-  if ((rc = ensure(h, h->seam, (size_t)ub * n_tiles * 6 * 256 * sizeof(float)))) return rc;
-  A.part = (float*)h->seam.p;
+  if ((rc = ensure_zeroed(h, h->xpart, (size_t)ub * n_tiles * 3 * 256 * 8, st))) return rc;
+  A.part = nullptr;
   A.n_tiles = (int)n_tiles;
-  if ((rc = ensure(h, h->xbits, (size_t)ub * ntt * fast::OP_TILE_WORDS * 8))) return rc;
+  if ((rc = ensure_zeroed(h, h->xbits, (size_t)ub * ntt * fast::OP_TILE_WORDS * 8, st))) return rc;
   {
+    // granule buffers are zero when (re)allocated and the epoch only grows: a fresh granule never carries it.
+    // The work counter is never reset: every launch takes exactly ub * ntt tickets, the kernel subtracts the
+    // running base.
     bool fresh = false;
-    if ((rc = ensure_zeroed(h, h->xflags, (size_t)ub * ntt * 4, st, &fresh))) return rc;
-    if (fresh) h->epoch = 0;  // fresh flags carry no epoch yet
-    // the work counter is never reset: every launch takes exactly ub * ntt tickets, the kernel subtracts the
-    // running base
     if ((rc = ensure_zeroed(h, h->xticket, 64, st, &fresh))) return rc;
     if (fresh) h->ticket_base = 0;
   }
-  if (++h->epoch == 0) {  // wrapped: flags of 2^32 launches ago could alias
-    HIPCHK(h, hipMemsetAsync(h->xflags.p, 0, h->xflags.bytes, st));
+  if (++h->epoch == 0) {  // wrapped: tags of 2^32 launches ago could alias
+    HIPCHK(h, hipMemsetAsync(h->xbits.p, 0, h->xbits.bytes, st));
+    HIPCHK(h, hipMemsetAsync(h->xpart.p, 0, h->xpart.bytes, st));
     h->epoch = 1;
   }
   P.win64 = (const double*)h->wfull64.p;
@@ -1207,7 +1207,7 @@ static int stage_onepass(sg_handle* h, const View& v, const Geom& g, int64_t ub,
   P.tc = tc;
   P.mag_scale = h->mag_scale; P.top_db = h->p.top_db;
   P.xbits = (unsigned long long*)h->xbits.p;
-  P.flags = (unsigned*)h->xflags.p;
+  P.part2 = (unsigned long long*)h->xpart.p;
   P.ticket = (unsigned*)h->xticket.p;
   P.epoch = h->epoch;
   P.ticket_base = h->ticket_base;
@@ -1223,11 +1223,6 @@ static int stage_onepass(sg_handle* h, const View& v, const Geom& g, int64_t ub,
     HIPCHK(h, hipFuncSetAttribute(reinterpret_cast<const void*>(kern),
                                   hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
     hipLaunchKernelGGL(kern, dim3((unsigned)(ub * ntt)), dim3(WAVES * 64), lds, st, P);
-    HIPCHK(h, hipGetLastError());
-  }
-  {
-    ProfScope ps(h, SG_STAGE_APPLY_FAST, st);
-    hipLaunchKernelGGL(fast::k_ola_seam<NF>, dim3((unsigned)(n_tiles - 1), (unsigned)ub), dim3(256), 0, st, A);
     HIPCHK(h, hipGetLastError());
   }
   h->dbg_xbits = true;
@@ -1733,7 +1728,10 @@ extern "C" int sg_debug_fetch(sg_handle* h, int32_t what, void* host, int64_t by
           const int64_t t = h->dbg_tf0 + (j - 1) * 16 + i;
           if (t < 0 || t >= h->dbg_T) continue;
           for (int w = 0; w < wpr; ++w)
-            dst[(u * h->dbg_T + t) * wpr + w] = tmp[((size_t)u * h->dbg_ntt + j) * fast::OP_TILE_WORDS + i * fast::OP_XW + w];
+          {
+            const unsigned long long* gr = &tmp[((size_t)u * h->dbg_ntt + j) * fast::OP_TILE_WORDS + (i * fast::OP_XW + w) * 2];
+            dst[(u * h->dbg_T + t) * wpr + w] = (gr[0] & 0xffffffffull) | (gr[1] << 32);
+          }
         }
     return SG_OK;
   }

@@ -34,7 +34,7 @@ namespace sg {
 namespace fast {
 
 constexpr int OP_XW = 9;                 // 64-bit words per frame row (513 bins)
-constexpr int OP_TILE_WORDS = 16 * OP_XW;  // payload of one tile: 144 words = 1152 B
+constexpr int OP_TILE_WORDS = 16 * OP_XW * 2;  // payload of one tile: 288 tagged granules = 2304 B (18 x 128 B)
 constexpr int OP_MAX_NT = 16;            // neighbours hold 16 frames each
 constexpr int OP_KP = 528;               // K row pitch (uint16 entries) of a wave's private K tile
 constexpr int OP_HG = 65;                // 8-bin groups per row (513 bins)
@@ -45,12 +45,12 @@ struct OnePassArgs {
   const cx<double>* tw64;   // w_1024^j float64
   ThreshConsts tc;
   double mag_scale, top_db;
-  unsigned long long* xbits;  // [units][n_tiles + 2][16][OP_XW] published mask bits
-  unsigned* flags;            // [units][n_tiles + 2] epoch of the last publication
+  unsigned long long* xbits;  // [units][n_tiles + 2][16][OP_XW][2] published mask bits: granules {32 bits, epoch}
   unsigned* ticket;           // work counter: never reset, a launch takes exactly units * (n_tiles + 2) tickets
   unsigned ticket_base;       // its value before this launch
   unsigned epoch;
   int nf, nt;
+  unsigned long long* part2;  // [units][n_tiles][3][256] trailing partial hops of every tile: granules {float, epoch}
   const unsigned long long* mconst;  // [3][64] per-lane MFMA operands: freq band B, time weights A (slots 0..31, 32..63)
   const unsigned long long* exp8;    // [256]: byte v -> 8 bytes (v >> e) & 1
 };
@@ -78,9 +78,22 @@ __device__ __forceinline__ double op_exact_power(const OnePassArgs& P, int64_t r
 }
 
 typedef unsigned short op_us2 __attribute__((ext_vector_type(2)));
+typedef unsigned op_v4u __attribute__((ext_vector_type(4)));
+
+// 16-byte write-through store / L1-bypassing load (the sc1 forms the 8-byte agent-scope atomics compile to):
+// two tagged 8-byte granules per instruction.  Each 8-byte half carries its own tag, so the pair needs no
+// atomicity beyond the 8-byte granule.
+__device__ __forceinline__ void op_st16_sc1(void* p, op_v4u v) {
+  asm volatile("global_store_dwordx4 %0, %1, off sc1" : : "v"(p), "v"(v) : "memory");
+}
+__device__ __forceinline__ op_v4u op_ld16_sc1(const void* p) {
+  op_v4u v;
+  asm volatile("global_load_dwordx4 %0, %1, off sc1\n\ts_waitcnt vmcnt(0)" : "=v"(v) : "v"(p) : "memory");
+  return v;
+}
 
 // OP_ABLATE (development only, default 0; results are wrong): 1 no decision stage, 2 no wait for the
-// neighbours' flags, 4 no smoothing (K = constant), 8 no exact refinement
+// neighbours' flags, 8 no exact refinement, 16 no wait for the previous tile's trailing hops
 #ifndef OP_ABLATE
 #define OP_ABLATE 0
 #endif
@@ -375,12 +388,14 @@ __global__ __launch_bounds__(WAVES * 64, 3) void k_gate_onepass(OnePassArgs P) {
 
   // ---- publish this tile's bits; the spectra stay in v[] ---------------------------------------------
   unsigned long long* xb_mine = P.xbits + ((size_t)u * ntt + (jt + 1)) * OP_TILE_WORDS;
-  if (c < OP_XW)
-    __hip_atomic_store(&xb_mine[(4 * wave + g) * OP_XW + c], myword, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // payload drained before the flag may be stored
-  __syncthreads();                                   // ... by every wave; the exchange slices are idle from here
-  if (tid == 0)
-    __hip_atomic_store(&P.flags[(size_t)u * ntt + (jt + 1)], P.epoch, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+  // data-tagged granules: every 8-byte store carries 32 mask bits and the launch epoch.  A consumer polls the
+  // granules it needs until their tags are current: no separate flag, no drain of the stores, one write-through
+  // and one read on the critical path instead of two of each.
+  if (c < OP_XW) {
+    const op_v4u gr = {(unsigned)myword, P.epoch, (unsigned)(myword >> 32), P.epoch};
+    op_st16_sc1(&xb_mine[((4 * wave + g) * OP_XW + c) * 2], gr);
+  }
+  __syncthreads();   // every wave is past its forward exchange: the slices are idle from here
   if (halo_tile) return;
 
   // ---- smoothing on the matrix cores (exact integer arithmetic, v_mfma_i32_16x16x32_i8) ----------------
@@ -429,19 +444,20 @@ __global__ __launch_bounds__(WAVES * 64, 3) void k_gate_onepass(OnePassArgs P) {
       }
     }
   }
-  if (tid < 2 && !(OP_ABLATE & 2)) {
-    const unsigned* fp = &P.flags[(size_t)u * ntt + (jt + 1) + (tid ? 1 : -1)];
-    while (__hip_atomic_load(fp, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != P.epoch) __builtin_amdgcn_s_sleep(2);
-  }
-  __syncthreads();
+  // neighbour rows: one 16-byte load per 64-bit word (2 nt x 9 words <= 288: at most two per thread), polled
+  // until both tags are current
   for (int i = tid; i < 2 * nt * OP_XW; i += WAVES * 64) {
     const int side = i >= nt * OP_XW;
     const int rem = i - side * nt * OP_XW;
     const int rr = rem / OP_XW, w = rem - rr * OP_XW;
-    const unsigned long long* src =
-        side ? xb_mine + OP_TILE_WORDS + rr * OP_XW + w : xb_mine - OP_TILE_WORDS + (NF - nt + rr) * OP_XW + w;
-    const unsigned long long word = __hip_atomic_load(src, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-    wb[(side ? nt + NF + rr : rr) * WP + 1 + w] = word;
+    const unsigned long long* src = side ? xb_mine + OP_TILE_WORDS + (rr * OP_XW + w) * 2
+                                         : xb_mine - OP_TILE_WORDS + ((NF - nt + rr) * OP_XW + w) * 2;
+    op_v4u gr = op_ld16_sc1(src);
+    while (!(OP_ABLATE & 2) && (gr[1] != P.epoch || gr[3] != P.epoch)) {
+      __builtin_amdgcn_s_sleep(1);
+      gr = op_ld16_sc1(src);
+    }
+    wb[(side ? nt + NF + rr : rr) * WP + 1 + w] = (unsigned long long)gr[0] | ((unsigned long long)gr[2] << 32);
   }
   __syncthreads();
   {
@@ -563,10 +579,15 @@ __global__ __launch_bounds__(WAVES * 64, 3) void k_gate_onepass(OnePassArgs P) {
   // ---- cross-wave combine, normalise, store (seam mode: abutting tiles) -------------------------------
   const float* fr = reinterpret_cast<const float*>(regions);
   const int s4 = (tid & 63) * 4;
-  for (int jj = (tid >> 6); jj < NF + 3; jj += WAVES) {
+  // Hops that straddle two tiles: tile j publishes its three TRAILING partial hops (un-normalised sums) the
+  // same way as the mask bits (write-through stores, drained, epoch flag per hop); tile j+1 adds its LEADING
+  // partials and finalises them.  Per wave: trailing hop first (published early), interior hops, leading hop
+  // last (tile j, one ticket earlier, has usually published by then).  Publishing never waits: no cycles.
+  for (int it = 0; it < 5; ++it) {
+    const int jj = wave < 3 ? (it == 0 ? NF + wave : (it == 4 ? wave : wave + 4 * it)) : (it < 4 ? 3 + 4 * it : -1);
+    if (jj < 0) break;
     const int64_t h = tf_tile + jj;
-    if (h >= A.h_end) break;
-    if (h < A.h_begin) continue;
+    if (h >= A.h_end || h < A.h_begin) continue;
     float4 a4 = make_float4(0.f, 0.f, 0.f, 0.f);
     bool all_valid = true;
 #pragma unroll
@@ -584,11 +605,32 @@ __global__ __launch_bounds__(WAVES * 64, 3) void k_gate_onepass(OnePassArgs P) {
         a4.x += f4.x; a4.y += f4.y; a4.z += f4.z; a4.w += f4.w;
       }
     }
-    if (jj < 3 || jj >= NF) {
-      const int slot = jj < 3 ? jj : 3 + (jj - NF);
-      float* dst = A.part + ((((size_t)u * A.n_tiles + jt) * 6 + slot) * 256 + s4);
-      *reinterpret_cast<float4*>(dst) = a4;
+    if (jj >= NF) {
+      // trailing partial hop -> tagged granules {float, epoch}
+      const int k = jj - NF;
+      unsigned long long* dst = P.part2 + (((size_t)u * A.n_tiles + jt) * 3 + k) * 256 + s4;
+      const op_v4u ga = {__float_as_uint(a4.x), P.epoch, __float_as_uint(a4.y), P.epoch};
+      const op_v4u gb = {__float_as_uint(a4.z), P.epoch, __float_as_uint(a4.w), P.epoch};
+      op_st16_sc1(dst, ga);
+      op_st16_sc1(dst + 2, gb);
       continue;
+    }
+    if (jj < 3) {
+      // h >= h_begin implies jt >= 1: the previous tile exists
+      const unsigned long long* src = P.part2 + (((size_t)u * A.n_tiles + jt - 1) * 3 + jj) * 256 + s4;
+      op_v4u ga, gb;
+      while (true) {
+        asm volatile("global_load_dwordx4 %0, %2, off sc1\n\tglobal_load_dwordx4 %1, %2, off offset:16 sc1\n\ts_waitcnt vmcnt(0)"
+                     : "=&v"(ga), "=&v"(gb) : "v"(src) : "memory");
+        const unsigned e = P.epoch;
+        if ((OP_ABLATE & 16) || (ga[1] == e && ga[3] == e && gb[1] == e && gb[3] == e)) break;
+        __builtin_amdgcn_s_sleep(1);
+      }
+      // trailing partial of the previous tile + leading partial of this one (the order k_ola_seam adds them in)
+      a4.x = __uint_as_float(ga[0]) + a4.x;
+      a4.y = __uint_as_float(ga[2]) + a4.y;
+      a4.z = __uint_as_float(gb[0]) + a4.z;
+      a4.w = __uint_as_float(gb[2]) + a4.w;
     }
     if (!A.normalize) {
     } else if (all_valid) {
