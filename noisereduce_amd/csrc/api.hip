@@ -827,6 +827,26 @@ static int stage_colstats(sg_handle* h, const Geom& g, int64_t ub, double* thres
 
 // power field + band statistics -> threshold
 static int stage_stats(sg_handle* h, const View& v, const Geom& g, int64_t ub, double* thresh_out, hipStream_t st) {
+  if (ub < 16) {
+    // few units (the noise clip): STFT -> one pass over the power field -> final (3 launches instead of 5)
+    {
+      ProfScope ps(h, SG_STAGE_STFT_POWER, st);
+      HIPCHK(h, stft_any<double>(h, v, g, ub, (double*)h->P.p, nullptr, nullptr, 1.0, st));
+    }
+    ProfScope ps(h, SG_STAGE_COLSTATS, st);
+    const int nts = std::min(stat_slices(g, ub), STAT_TG * STAT1_MAXS);
+    int rc = ensure(h, h->part, (size_t)ub * nts * STAT1_NP * g.FS * 8);
+    if (rc) return rc;
+    dim3 grid((g.F + 63) / 64, (unsigned)ub, nts);
+    hipLaunchKernelGGL(k_colstats1, grid, dim3(64 * STAT_TG), 0, st, (const double*)h->P.p, g, h->mag_scale,
+                       (double*)h->part.p);
+    HIPCHK(h, hipGetLastError());
+    hipLaunchKernelGGL(k_colstats1_final, dim3((unsigned)((g.FS + 63) / 64), (unsigned)ub), dim3(64 * STAT_TG), 0, st,
+                       (const double*)h->part.p, (const double*)h->P.p, g, nts, h->mag_scale, h->p.top_db,
+                       h->p.n_std_thresh, h->p.ddof, (double*)h->pmax.p, thresh_out);
+    HIPCHK(h, hipGetLastError());
+    return SG_OK;
+  }
   int rc = stage_power(h, v, g, ub, st);
   if (rc) return rc;
   return stage_colstats(h, g, ub, thresh_out, st);

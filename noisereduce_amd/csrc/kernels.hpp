@@ -389,6 +389,169 @@ __global__ __launch_bounds__(64 * STAT_TG) void k_colstats(const double* __restr
   }
 }
 
+// ---------------------------------------------------------------------------------------
+// Single-pass column statistics (few units: the noise clip).  The -top_db floor max(dB, rowmax - top_db)
+// needs the band maximum BEFORE the moments -- two passes over the power field and four launches
+// (k_colmax, k_colmax_final, k_colstats, k_colstats_final).  But only a band's very smallest cells can lie
+// more than top_db below its maximum (in practice a handful of cells of the real-valued DC / Nyquist bins):
+// one pass gathers max, the TWO smallest powers of every time slice and the moments of the UNfloored dB about
+// a pivot (the band's first frame); the final kernel replaces the contribution of the cells that turn out to
+// be floored.  If both tracked minima of some slice are floored there may be a third: that band (rare) is
+// recomputed exactly by its whole wave.
+// ---------------------------------------------------------------------------------------
+constexpr int STAT1_NP = 5;  // partials per (slice, band): max, min1, min2, s1, s2
+
+__device__ __forceinline__ void min2_push(double& m1, double& m2, double x) {  // keep the two smallest
+  const double lo = fmin(m1, x), hi = fmax(m1, x);
+  m1 = lo;
+  m2 = fmin(m2, hi);
+}
+
+__global__ __launch_bounds__(64 * STAT_TG) void k_colstats1(const double* __restrict__ P, Geom g, double mag_scale,
+                                                            double* __restrict__ part /* [u][nts][NP][FS] */) {
+  __shared__ double r[STAT1_NP][STAT_TG][64];
+  const int l = threadIdx.x & 63;
+  const int f = blockIdx.x * 64 + l;
+  const int tg = threadIdx.x >> 6;
+  const int64_t u = blockIdx.y;
+  const int ts = blockIdx.z, nts = gridDim.z;
+  const int64_t tb = g.T * ts / nts, te = g.T * (ts + 1) / nts;
+  double mx = 0.0, m1 = 1e300, m2 = 1e300, s1 = 0.0, s2 = 0.0;
+  if (f < g.F) {
+    const double pivot = cell_db(P[(u * g.T) * g.FS + f], mag_scale);
+#pragma unroll 3
+    for (int64_t t = tb + tg; t < te; t += STAT_TG) {
+      const double Pv = P[(u * g.T + t) * g.FS + f];
+      mx = fmax(mx, Pv);
+      min2_push(m1, m2, Pv);
+      const double d = cell_db(Pv, mag_scale) - pivot;
+      s1 += d;
+      s2 += d * d;
+    }
+  }
+  r[0][tg][l] = mx; r[1][tg][l] = m1; r[2][tg][l] = m2; r[3][tg][l] = s1; r[4][tg][l] = s2;
+  __syncthreads();
+  if (tg == 0 && f < g.F) {
+    for (int i = 1; i < STAT_TG; ++i) {
+      mx = fmax(mx, r[0][i][l]);
+      min2_push(m1, m2, r[1][i][l]);
+      min2_push(m1, m2, r[2][i][l]);
+      s1 += r[3][i][l];
+      s2 += r[4][i][l];
+    }
+    double* o = part + ((u * nts + ts) * STAT1_NP) * (int64_t)g.FS + f;
+    o[0] = mx; o[g.FS] = m1; o[2 * g.FS] = m2; o[3 * g.FS] = s1; o[4 * g.FS] = s2;
+  }
+}
+
+// one workgroup = 64 bands of one unit; the STAT_TG thread groups split the slices
+constexpr int STAT1_MAXS = 16;  // slices per thread group (nts <= STAT_TG * STAT1_MAXS)
+__global__ __launch_bounds__(64 * STAT_TG) void k_colstats1_final(const double* __restrict__ part,
+                                                                  const double* __restrict__ P, Geom g, int nts,
+                                                                  double mag_scale, double top_db, double n_std,
+                                                                  int ddof, double* __restrict__ pmax,
+                                                                  double* __restrict__ thresh) {
+  __shared__ double r[3][STAT_TG][64];
+  __shared__ int r_exact[STAT_TG][64];
+  const int l = threadIdx.x & 63, tg = threadIdx.x >> 6;
+  const int f = blockIdx.x * 64 + l;
+  const int64_t u = blockIdx.y;
+  const int64_t i = u * g.FS + f;
+  const bool live = f < g.F;
+  const double Tn = (double)g.T;
+  double mx = 0.0, s1 = 0.0, s2 = 0.0;
+  double m1[STAT1_MAXS], m2[STAT1_MAXS];
+#pragma unroll
+  for (int k = 0; k < STAT1_MAXS; ++k) {
+    const int ts = tg + STAT_TG * k;
+    m1[k] = 1e300; m2[k] = 1e300;
+    if (live && ts < nts) {
+      const double* o = part + ((u * nts + ts) * STAT1_NP) * (int64_t)g.FS + f;
+      mx = fmax(mx, o[0]);
+      m1[k] = o[g.FS];
+      m2[k] = o[2 * g.FS];
+      s1 += o[3 * g.FS];
+      s2 += o[4 * g.FS];
+    }
+  }
+  r[0][tg][l] = mx;
+  __syncthreads();
+#pragma unroll
+  for (int k = 0; k < STAT_TG; ++k) mx = fmax(mx, r[0][k][l]);
+  const double mdb = cell_db(mx, mag_scale);
+  const double pivot = live ? cell_db(P[(u * g.T) * g.FS + f], mag_scale) : 0.0;
+  bool exact = false;
+  {
+    // cells below the floor: replace d by the floored value (both about the pivot).
+    // dB < mdb - top_db  <=>  P < Pfl (cell_db is monotone; at the boundary both forms of the cell give the
+    // same floored value): the logarithm is only evaluated for cells that ARE floored
+    const double dfl = (mdb - top_db) - pivot;
+    const double am = (exp10((mdb - top_db) / 20.0) - 2.220446049250313e-16) / mag_scale;
+    const double Pfl = am > 0.0 ? am * am : 0.0;
+#pragma unroll
+    for (int k = 0; k < STAT1_MAXS; ++k) {
+      if (m1[k] < Pfl) {
+        const double d = cell_db(m1[k], mag_scale) - pivot;
+        if (d < dfl) {
+          s1 += dfl - d;
+          s2 += dfl * dfl - d * d;
+        }
+        if (m2[k] < Pfl) {
+          const double d2 = cell_db(m2[k], mag_scale) - pivot;
+          if (d2 < dfl) {
+            s1 += dfl - d2;
+            s2 += dfl * dfl - d2 * d2;
+          }
+          exact = true;  // a third floored cell of this slice would have gone unseen
+        }
+      }
+    }
+  }
+  __syncthreads();
+  r[1][tg][l] = s1; r[2][tg][l] = s2; r_exact[tg][l] = exact ? 1 : 0;
+  __syncthreads();
+  if (tg != 0) return;
+  s1 = 0.0; s2 = 0.0; exact = false;
+#pragma unroll
+  for (int k = 0; k < STAT_TG; ++k) {  // fixed order: deterministic
+    s1 += r[1][k][l];
+    s2 += r[2][k][l];
+    exact = exact || r_exact[k][l] != 0;
+  }
+  if (live) {
+    pmax[i] = mx;
+    double var = (s2 - s1 * s1 / Tn) / (Tn - (double)ddof);
+    if (var < 0.0) var = 0.0;
+    thresh[i] = (pivot + s1 / Tn) + sqrt(var) * n_std;
+  } else if (f < g.FS) {
+    pmax[i] = 0.0;
+  }
+  // rare: bands whose slices may hide more floored cells -- the wave recomputes them like k_colstats
+  unsigned long long todo = __ballot(exact && live);
+  while (todo) {
+    const int src = __ffsll((long long)todo) - 1;
+    todo &= todo - 1;
+    const int fb = blockIdx.x * 64 + src;
+    const double mb = __shfl(mdb, src);
+    double a1 = 0.0, a2 = 0.0;
+    for (int64_t t = l; t < g.T; t += 64) {
+      double d = cell_db(P[(u * g.T + t) * g.FS + fb], mag_scale) - mb;
+      d = fmax(d, -top_db);
+      a1 += d;
+      a2 += d * d;
+    }
+    for (int off = 32; off > 0; off >>= 1) {
+      a1 += __shfl_xor(a1, off);
+      a2 += __shfl_xor(a2, off);
+    }
+    if (l == src) {
+      double var = (a2 - a1 * a1 / Tn) / (Tn - (double)ddof);
+      if (var < 0.0) var = 0.0;
+      thresh[i] = (mb + a1 / Tn) + sqrt(var) * n_std;
+    }
+  }
+}
+
 // thresh[u][f] = mean_t(dBfl) + n_std * std_t(dBfl)   (stationary.py:75-81; torchgate.py:158-160)
 __global__ void k_colstats_final(const double* __restrict__ s_part, Geom g, int nts,
                                  const double* __restrict__ pmax, double mag_scale, double n_std, int ddof,
