@@ -223,3 +223,94 @@ def test_nonstationary_silent_chunk_is_nan_like_the_reference(nr):
     got2 = nr.reduce_noise(y=y2, sr=48000, stationary=False)
     assert np.isfinite(want2).all() and np.isfinite(got2).all()
     assert O.rel_err(got2, want2) < TOL
+
+
+# ---------------------------------------------------------------------------------------------
+# 4. one-pass gate (onepass.hpp) against the three-kernel path it replaces
+# ---------------------------------------------------------------------------------------------
+def _sg(y, sr, cs, pad, **over):
+    from noisereduce_amd.spectralgate.stationary import SpectralGateStationary
+    kw = dict(SG_KW, sr=sr, chunk_size=cs, padding=pad)
+    kw.update(over)
+    return SpectralGateStationary(y=y, **kw)
+
+
+@pytest.mark.parametrize("sr,n,cs,pad,C,over", [
+    (48000, 130000, 40000, 5000, 1, {}),                                   # nt = 9, nf = 5: three row blocks
+    (44100, 200542, 600000, 30000, 1, {}),                                 # nt = 8: two row blocks, single chunk
+    (84000, 150000, 50000, 4000, 2, {}),                                   # nt = 16 (the neighbours' last row), nf = 3
+    (48000, 99999, 20000, 3000, 2, dict(freq_mask_smooth_hz=800)),         # nf = 8 (widest band matrix)
+    (48000, 70000, 30000, 2000, 1, dict(time_mask_smooth_ms=None)),        # nt = 1
+    (48000, 6000, 600000, 30000, 1, {}),                                   # two tiles only
+    (48000, 300001, 100000, 0, 3, {}),                                     # no padding: tiles at the unit edges
+    (88200, 120000, 50000, 4000, 1, {}),                                   # nt = 17: not eligible -> three-kernel path
+])
+def test_onepass_equals_three_kernel_path(sr, n, cs, pad, C, over):
+    """k_gate_onepass (one forward transform per frame, tiles exchange mask bits, smoothing on the matrix
+    cores, seam hops combined in-kernel) must reproduce the decide / smooth / apply kernels BIT FOR BIT: same
+    transforms, same decisions, same integer smoothing.  And both must match the oracle."""
+    from noisereduce_amd import _ffi
+    y = np.stack([O.synth_signal(n, sr=sr, seed=70 + c, tone_hz=500.0 * (c + 1)) for c in range(C)])
+    if C == 1:
+        y = y[0]
+    sg = _sg(y, sr, cs, pad, **over)
+    g = sg._gate
+    try:
+        a = sg.get_traces()
+        a2 = sg.get_traces()
+        g.set_option(_ffi.SG_OPT_FORCE_SPLIT, 1)
+        b = sg.get_traces()
+    finally:
+        g.set_option(_ffi.SG_OPT_FORCE_SPLIT, 0)
+    assert np.array_equal(a, a2), "one-pass path is not deterministic run to run"
+    assert np.array_equal(a, b), "one-pass path differs from the three-kernel path"
+    kw = dict(stationary=True, chunk_size=cs, padding=pad)
+    kw.update(over)
+    assert O.rel_err(a, O.reduce_noise_S(y.astype(np.float64), sr, **kw)) < TOL
+
+
+def test_onepass_epochs_do_not_alias_between_calls(nr):
+    """The exchange buffers are never cleared: granules carry the launch epoch.  Alternate two recordings of
+    different sizes (different tile counts -> the same buffer words mean different tiles) on ONE handle; every
+    call must give its recording's result."""
+    ys = [O.synth_signal(170000, seed=1).astype(np.float32), O.synth_signal(61000, seed=2, noise_sigma=0.3).astype(np.float32),
+          np.stack([O.synth_signal(90000, seed=3), O.synth_signal(90000, seed=4, tone_hz=2500.0)]).astype(np.float32)]
+    kw = dict(sr=48000, stationary=True, chunk_size=25000, padding=3000)
+    refs = [nr.reduce_noise(y=y, **kw) for y in ys]
+    for y, r in zip(ys, refs):
+        assert O.rel_err(r, O.reduce_noise_S(y.astype(np.float64), 48000, stationary=True, chunk_size=25000, padding=3000)) < TOL
+    for it in range(30):
+        i = (it * 7 + it // 3) % 3
+        assert np.array_equal(nr.reduce_noise(y=ys[i], **kw), refs[i]), (it, i)
+
+
+def test_onepass_under_uneven_load(nr):
+    """Hand-offs between tiles under uneven load: two host threads drive two handles (slots) at once, one with
+    a long multi-channel recording and one with many short calls (MI355X_MICROARCH.md: test every hand-off
+    under uneven load, checking every word)."""
+    from noisereduce_amd.spectralgate.stationary import SpectralGateStationary
+    big = np.stack([O.synth_signal(900000, seed=10 + c, tone_hz=300.0 * (c + 1)) for c in range(6)]).astype(np.float32)
+    small = O.synth_signal(50000, seed=99).astype(np.float32)
+    kw_b = dict(SG_KW, chunk_size=100000, padding=8000)
+    kw_s = dict(SG_KW, chunk_size=12000, padding=2000)
+    sb = SpectralGateStationary(y=torch.from_numpy(big).cuda(), slot=1, **kw_b)
+    ss = SpectralGateStationary(y=torch.from_numpy(small).cuda(), slot=2, **kw_s)
+    ref_b, ref_s = sb.get_traces().clone(), ss.get_traces().clone()
+    assert O.rel_err(ref_s.cpu().numpy(), O.reduce_noise_S(small.astype(np.float64), 48000, stationary=True,
+                                                           chunk_size=12000, padding=2000)) < TOL
+    bad = []
+
+    def run(sg, ref, reps, stream):
+        with torch.cuda.stream(stream):
+            for _ in range(reps):
+                out = sg.get_traces()
+                if not torch.equal(out, ref):
+                    bad.append(float((out - ref).abs().max()))
+        stream.synchronize()
+
+    s1, s2 = torch.cuda.Stream(), torch.cuda.Stream()
+    torch.cuda.synchronize()
+    th = [threading.Thread(target=run, args=(sb, ref_b, 10, s1)), threading.Thread(target=run, args=(ss, ref_s, 150, s2))]
+    [t.start() for t in th]
+    [t.join() for t in th]
+    assert not bad, bad
