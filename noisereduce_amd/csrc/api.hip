@@ -16,6 +16,7 @@
 #include "fused.hpp"
 #include "czt.hpp"
 #include "onepass.hpp"
+#include "nonstat.hpp"
 
 #ifndef SG_APPLY_WAVES
 #define SG_APPLY_WAVES 4  // wavefronts per workgroup of k_apply_fast: tile = 4*W frames -> 4*W-3 hops
@@ -59,7 +60,8 @@ struct sg_handle {
   DevBuf seam;                       // partial seam hops of abutting apply tiles
   DevBuf ftab;                       // k_smooth_bits2 phase-1 lookup tables (nf <= 5)
   // one-pass gate (onepass.hpp): published mask bits per tile, publication flags, work counter, tables
-  DevBuf xbits, xpart, xticket, ftab3, xexp;  // ftab3: per-lane MFMA operands, xexp: bit -> byte table
+  DevBuf xbits, xpart, xticket, ftab3, xexp;
+  DevBuf nsp, nsc;                   // non-stationary mask: per-sub-tile partials / carries (nonstat.hpp)  // ftab3: per-lane MFMA operands, xexp: bit -> byte table
   unsigned ticket_base = 0;          // tickets handed out by all previous launches
   unsigned epoch = 0;                // launch counter: the value a tile's flag must carry to be current
   bool force_split = false;          // SG_OPT_FORCE_SPLIT: decide / smooth / apply as three kernels
@@ -714,7 +716,7 @@ extern "C" int sg_destroy(sg_handle* h) {
   for (DevBuf* b : {&h->tw64, &h->tw32, &h->wfull64, &h->wa32, &h->ws32, &h->wsq32, &h->kf, &h->kt, &h->thresh,
                     &h->P, &h->pmax, &h->thr_rows, &h->raw, &h->M, &h->seg, &h->yn, &h->bits, &h->K16, &h->umax,
                     &h->need, &h->T2, &h->part, &h->tw512, &h->invn, &h->seam, &h->ftab, &h->xbits, &h->xpart,
-                    &h->xticket, &h->ftab3, &h->xexp, &h->czt_tw64, &h->czt_ch64,
+                    &h->xticket, &h->ftab3, &h->xexp, &h->nsp, &h->nsc, &h->czt_tw64, &h->czt_ch64,
                     &h->czt_bh64, &h->czt_tw32, &h->czt_ch32, &h->czt_bh32})
     free_buf(*b);
   delete h;
@@ -862,7 +864,7 @@ static int stage_decide(sg_handle* h, const Geom& g, int64_t ub, const double* t
   return SG_OK;
 }
 
-static int stage_nonstat_raw(sg_handle* h, const View& v, const Geom& g, int64_t ub, hipStream_t st) {
+static int stage_mag(sg_handle* h, const View& v, const Geom& g, int64_t ub, hipStream_t st) {
   float* mag = (float*)h->P.p;
   if (h->fast_ok && !h->force_nofast) {
     ProfScope ps(h, SG_STAGE_STFT_MAG, st);
@@ -884,6 +886,67 @@ static int stage_nonstat_raw(sg_handle* h, const View& v, const Geom& g, int64_t
     ProfScope ps(h, SG_STAGE_STFT_MAG, st);
     HIPCHK(h, stft_any<float>(h, v, g, ub, nullptr, mag, nullptr, 1.0, st));
   }
+  return SG_OK;
+}
+
+// Variant-S non-stationary mask in two passes over |X| (nonstat.hpp): partials -> chain -> IIR + sigmoid + smoothing.
+static bool nonstat2_ok(const sg_handle* h, const Geom& g) {
+  if (h->p.variant != SG_VARIANT_S || h->p.stationary || !h->p.smooth_mask || h->force_unfused) return false;
+  const int nf = h->p.n_grad_freq, nt = h->p.n_grad_time;
+  if (nf > NS_MAX_NF) return false;
+  switch (nt) {  // instantiated time half-widths (k_iir_mask keeps the tile column in registers)
+    case 1: case 2: case 3: case 4: case 5: case 6: case 8: case 9: break;
+    default: return false;
+  }
+  const double b = h->p.iir_b, c = 1.0 - b;
+  if (!(b > 0.0 && b < 1.0)) return false;
+  // the backward sweep regenerates the forward values in reverse: error growth c^-rows must stay small
+  return std::pow(c, (double)(NS_TT + 2 * nt)) >= 1e-3 && g.T >= 1;
+}
+
+static int stage_nonstat_mask2(sg_handle* h, const View& v, const Geom& g, int64_t ub, hipStream_t st) {
+  int rc = stage_mag(h, v, g, ub, st);
+  if (rc) return rc;
+  const float* mag = (const float*)h->P.p;
+  NsTiling tl{g.T, h->p.n_grad_time};
+  const int64_t nk = tl.n_tiles();
+  const size_t bytes = (size_t)ub * nk * 3 * 2 * g.FS * sizeof(double);
+  if ((rc = ensure(h, h->nsp, bytes))) return rc;
+  if ((rc = ensure(h, h->nsc, bytes))) return rc;
+  {
+    ProfScope ps(h, SG_STAGE_NONSTAT_MASK, st);
+    hipLaunchKernelGGL(k_iir_part, dim3((unsigned)((g.F + 63) / 64), (unsigned)((nk + 3) / 4), (unsigned)ub), dim3(256), 0,
+                       st, mag, g, tl, h->p.iir_b, (double*)h->nsp.p);
+    HIPCHK(h, hipGetLastError());
+    hipLaunchKernelGGL(k_iir_chain, dim3((unsigned)((ub * g.FS + 63) / 64)), dim3(64), (size_t)nk * 3 * 2 * sizeof(double), st, mag,
+                       (const double*)h->nsp.p, g, tl, h->p.iir_b, (double*)h->nsc.p, ub);
+    HIPCHK(h, hipGetLastError());
+  }
+  {
+    ProfScope ps(h, SG_STAGE_SMOOTH, st);
+    const int nf = h->p.n_grad_freq, nt = h->p.n_grad_time;
+    const int BW = 64 - 2 * nf;
+    const unsigned gx = (unsigned)(((g.F + BW - 1) / BW + 3) / 4);
+    auto launch = [&](auto kern) -> hipError_t {
+      hipLaunchKernelGGL(kern, dim3(gx, (unsigned)nk, (unsigned)ub), dim3(256), 0, st, mag, (const double*)h->nsc.p, g, tl,
+                         h->p.iir_b, h->p.nonstat_thresh, h->p.nonstat_slope, (const float*)h->kf.p, nf,
+                         (float)h->p.prop_decrease, (float*)h->M.p);
+      return hipGetLastError();
+    };
+    switch (nt) {
+#define SG_NS_CASE(NT_) case NT_: HIPCHK(h, launch(k_iir_mask<NT_>)); break;
+      SG_NS_CASE(1) SG_NS_CASE(2) SG_NS_CASE(3) SG_NS_CASE(4) SG_NS_CASE(5) SG_NS_CASE(6) SG_NS_CASE(8) SG_NS_CASE(9)
+#undef SG_NS_CASE
+      default: FAIL(h, SG_E_UNSUPPORTED, "no k_iir_mask instantiation for n_grad_time=%d", nt);
+    }
+  }
+  return SG_OK;
+}
+
+static int stage_nonstat_raw(sg_handle* h, const View& v, const Geom& g, int64_t ub, hipStream_t st) {
+  int rc0 = stage_mag(h, v, g, ub, st);
+  if (rc0) return rc0;
+  float* mag = (float*)h->P.p;
   ProfScope ps(h, SG_STAGE_NONSTAT_MASK, st);
   dim3 grid((g.F + 63) / 64, (unsigned)ub);
   if (h->p.variant == SG_VARIANT_S) {
@@ -1293,10 +1356,13 @@ static int run_S(sg_handle* h, View v, int64_t total_units, const OutMap& om, hi
       if (h->p.stationary) {
         if ((rc = stage_power(h, v, g, nb, st))) return rc;
         if ((rc = stage_decide(h, g, nb, (const double*)h->thresh.p, 0, st))) return rc;
+      } else if (nonstat2_ok(h, g)) {
+        if ((rc = stage_nonstat_mask2(h, v, g, nb, st))) return rc;
       } else {
         if ((rc = stage_nonstat_raw(h, v, g, nb, st))) return rc;
       }
-      if ((rc = stage_smooth(h, g, nb, st))) return rc;
+      if (h->p.stationary || !nonstat2_ok(h, g))
+        if ((rc = stage_smooth(h, g, nb, st))) return rc;
     }
     if (geom_fast) {
       if ((rc = stage_apply_fast(h, v, g, nb, om, (const float*)h->M.p, 1, st))) return rc;
