@@ -32,8 +32,10 @@ cal_w = [v[2] for k, v in res.get("WRITE_SIZE", {}).items() if "copyBuffer" in k
 kf = GiB / (max(cal_f) * 1024) if cal_f else None
 kw = GiB / (max(cal_w) * 1024) if cal_w else None
 print("calibration factors (true bytes / (counter*1024)): fetch", kf, "write", kw)
-names = {"k_apply_fast": "k_apply_fast (fft+mask+ifft+ola)", "k_decide_fast": "k_decide_fast (f32 stft + exact f64 refine)",
-         "k_smooth_bits2": "k_smooth_f+k_smooth_t", "k_unit_absmax": "k_unit_absmax+k_prep_thresh"}
+names = {"k_gate_onepass": "k_gate_onepass (fft+decide+smooth+mask+ifft+ola)",
+         "k_apply_fast": "k_apply_fast (fft+mask+ifft+ola)", "k_decide_fast": "k_decide_fast (f32 stft + exact f64 refine)",
+         "k_smooth_bits2": "k_smooth_f+k_smooth_t", "k_unit_absmax": "k_unit_absmax+k_prep_thresh",
+         "k_stft<double": "noise statistics: k_stft<double>", "k_colstats1(": "noise statistics: k_colstats1"}
 traffic = {}; detail = {}
 for short, stage in names.items():
     fr = [v for k, v in res.get("FETCH_SIZE", {}).items() if short in k]
