@@ -62,6 +62,8 @@ struct sg_handle {
   // one-pass gate (onepass.hpp): published mask bits per tile, publication flags, work counter, tables
   DevBuf xbits, xpart, xticket, ftab3, xexp;
   DevBuf nsp, nsc;                   // non-stationary mask: per-sub-tile partials / carries (nonstat.hpp)  // ftab3: per-lane MFMA operands, xexp: bit -> byte table
+  unsigned* err_host = nullptr;      // host-mapped error word written by k_gate_onepass when a hand-off times out
+  unsigned* err_dev = nullptr;
   unsigned ticket_base = 0;          // tickets handed out by all previous launches
   unsigned epoch = 0;                // launch counter: the value a tile's flag must carry to be current
   bool force_split = false;          // SG_OPT_FORCE_SPLIT: decide / smooth / apply as three kernels
@@ -713,6 +715,7 @@ extern "C" int sg_destroy(sg_handle* h) {
   (void)hipDeviceSynchronize();
   for (auto& r : h->prof_live) { (void)hipEventDestroy(r.a); (void)hipEventDestroy(r.b); }
   for (auto e : h->prof_pool) (void)hipEventDestroy(e);
+  if (h->err_host) (void)hipHostFree(h->err_host);
   for (DevBuf* b : {&h->tw64, &h->tw32, &h->wfull64, &h->wa32, &h->ws32, &h->wsq32, &h->kf, &h->kt, &h->thresh,
                     &h->P, &h->pmax, &h->thr_rows, &h->raw, &h->M, &h->seg, &h->yn, &h->bits, &h->K16, &h->umax,
                     &h->need, &h->T2, &h->part, &h->tw512, &h->invn, &h->seam, &h->ftab, &h->xbits, &h->xpart,
@@ -1271,6 +1274,16 @@ static int stage_onepass(sg_handle* h, const View& v, const Geom& g, int64_t ub,
   if ((rc = ensure_zeroed(h, h->xpart, (size_t)ub * n_tiles * 3 * 256 * 8, st))) return rc;
   A.part = nullptr;
   A.n_tiles = (int)n_tiles;
+  if (!h->err_host) {
+    HIPCHK(h, hipHostMalloc((void**)&h->err_host, 64, hipHostMallocMapped));
+    *h->err_host = 0u;
+    HIPCHK(h, hipHostGetDevicePointer((void**)&h->err_dev, h->err_host, 0));
+  }
+  if (*h->err_host != 0u) {
+    const unsigned e = *h->err_host;
+    *h->err_host = 0u;
+    FAIL(h, SG_E_HIP, "k_gate_onepass: a tile hand-off of an earlier call timed out (code %u): its output is invalid", e);
+  }
   if ((rc = ensure_zeroed(h, h->xbits, (size_t)ub * ntt * fast::OP_TILE_WORDS * 8, st))) return rc;
   {
     // granule buffers are zero when (re)allocated and the epoch only grows: a fresh granule never carries it.
@@ -1293,6 +1306,7 @@ static int stage_onepass(sg_handle* h, const View& v, const Geom& g, int64_t ub,
   P.part2 = (unsigned long long*)h->xpart.p;
   P.ticket = (unsigned*)h->xticket.p;
   P.epoch = h->epoch;
+  P.err = h->err_dev;
   P.ticket_base = h->ticket_base;
   h->ticket_base += (unsigned)(ub * ntt);
   P.nf = h->p.n_grad_freq; P.nt = h->p.n_grad_time;

@@ -37,7 +37,7 @@ constexpr int OP_XW = 9;                 // 64-bit words per frame row (513 bins
 constexpr int OP_TILE_WORDS = 16 * OP_XW * 2;  // payload of one tile: 288 tagged granules = 2304 B (18 x 128 B)
 constexpr int OP_MAX_NT = 16;            // neighbours hold 16 frames each
 constexpr int OP_KP = 528;               // K row pitch (uint16 entries) of a wave's private K tile
-constexpr int OP_HG = 65;                // 8-bin groups per row (513 bins)
+constexpr int OP_SPIN_MAX = 1 << 20;     // polls before a hand-off is declared lost (~1 s): no unbounded spin
 
 struct OnePassArgs {
   ApplyArgs A;              // view, geometry, output map, tables, seam buffer (A.K / A.Mf unused)
@@ -49,6 +49,7 @@ struct OnePassArgs {
   unsigned* ticket;           // work counter: never reset, a launch takes exactly units * (n_tiles + 2) tickets
   unsigned ticket_base;       // its value before this launch
   unsigned epoch;
+  unsigned* err;              // host-mapped word: bit 0 / 1 = a bit / partial-hop hand-off timed out
   int nf, nt;
   unsigned long long* part2;  // [units][n_tiles][3][256] trailing partial hops of every tile: granules {float, epoch}
   const unsigned long long* mconst;  // [3][64] per-lane MFMA operands: freq band B, time weights A (slots 0..31, 32..63)
@@ -453,7 +454,11 @@ __global__ __launch_bounds__(WAVES * 64, 3) void k_gate_onepass(OnePassArgs P) {
     const unsigned long long* src = side ? xb_mine + OP_TILE_WORDS + (rr * OP_XW + w) * 2
                                          : xb_mine - OP_TILE_WORDS + ((NF - nt + rr) * OP_XW + w) * 2;
     op_v4u gr = op_ld16_sc1(src);
-    while (!(OP_ABLATE & 2) && (gr[1] != P.epoch || gr[3] != P.epoch)) {
+    for (int spin = 0; !(OP_ABLATE & 2) && (gr[1] != P.epoch || gr[3] != P.epoch); ++spin) {
+      if (spin >= OP_SPIN_MAX) {   // every spin is bounded: report instead of hanging the device
+        atomicOr_system(P.err, 1u);
+        break;
+      }
       __builtin_amdgcn_s_sleep(1);
       gr = op_ld16_sc1(src);
     }
@@ -619,11 +624,15 @@ __global__ __launch_bounds__(WAVES * 64, 3) void k_gate_onepass(OnePassArgs P) {
       // h >= h_begin implies jt >= 1: the previous tile exists
       const unsigned long long* src = P.part2 + (((size_t)u * A.n_tiles + jt - 1) * 3 + jj) * 256 + s4;
       op_v4u ga, gb;
-      while (true) {
+      for (int spin = 0;; ++spin) {
         asm volatile("global_load_dwordx4 %0, %2, off sc1\n\tglobal_load_dwordx4 %1, %2, off offset:16 sc1\n\ts_waitcnt vmcnt(0)"
                      : "=&v"(ga), "=&v"(gb) : "v"(src) : "memory");
         const unsigned e = P.epoch;
         if ((OP_ABLATE & 16) || (ga[1] == e && ga[3] == e && gb[1] == e && gb[3] == e)) break;
+        if (spin >= OP_SPIN_MAX) {
+          atomicOr_system(P.err, 2u);
+          break;
+        }
         __builtin_amdgcn_s_sleep(1);
       }
       // trailing partial of the previous tile + leading partial of this one (the order k_ola_seam adds them in)
