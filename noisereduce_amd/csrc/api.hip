@@ -1265,7 +1265,8 @@ static int stage_onepass(sg_handle* h, const View& v, const Geom& g, int64_t ub,
   A.invn = (const float*)h->invn.p;
   A.tw512 = (const fast::cf*)h->tw512.p;
   A.tw1024 = (const fast::cf*)h->tw32.p;
-  A.kscale = (float)(1.0 / ((double)h->ktot * 512.0));
+  const bool prop = h->p.prop_decrease != 1.0;
+  A.kscale = prop ? (float)(1.0 / 512.0) : (float)(1.0 / ((double)h->ktot * 512.0));
   A.h_begin = (om.p0 + g.padL) / 256;
   A.h_end = (om.p1 - 1 + g.padL) / 256 + 1;
   const int64_t nh = A.h_end - A.h_begin;
@@ -1310,17 +1311,23 @@ static int stage_onepass(sg_handle* h, const View& v, const Geom& g, int64_t ub,
   P.ticket_base = h->ticket_base;
   h->ticket_base += (unsigned)(ub * ntt);
   P.nf = h->p.n_grad_freq; P.nt = h->p.n_grad_time;
+  P.prop = (float)h->p.prop_decrease;
+  P.inv_ktot = 1.0f / (float)h->ktot;
   P.mconst = (const unsigned long long*)h->ftab3.p;
   P.exp8 = (const unsigned long long*)h->xexp.p;
   {
     ProfScope ps(h, SG_STAGE_ONEPASS, st);
     const size_t lds = (size_t)(fast::FN + WAVES * fast::WAVE_CX_H) * sizeof(fast::cf) + (1024 + 528) * sizeof(float) +
-                       256 * 8 + 514 * 8 + 16;
-    auto kern = fast::k_gate_onepass<WAVES>;
-    HIPCHK(h, hipFuncSetAttribute(reinterpret_cast<const void*>(kern),
-                                  hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-    hipLaunchKernelGGL(kern, dim3((unsigned)(ub * ntt)), dim3(WAVES * 64), lds, st, P);
-    HIPCHK(h, hipGetLastError());
+                       256 * 8 + 514 * 8 + 16 + (prop ? 528 * sizeof(float) : 0);
+    auto go = [&](auto kern) -> hipError_t {
+      hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize,
+                                         (int)lds);
+      if (e != hipSuccess) return e;
+      hipLaunchKernelGGL(kern, dim3((unsigned)(ub * ntt)), dim3(WAVES * 64), lds, st, P);
+      return hipGetLastError();
+    };
+    if (prop) HIPCHK(h, go(fast::k_gate_onepass<WAVES, true>));
+    else HIPCHK(h, go(fast::k_gate_onepass<WAVES, false>));
   }
   h->dbg_xbits = true;
   h->dbg_tf0 = A.h_begin - 3;
@@ -1337,8 +1344,11 @@ static int run_S(sg_handle* h, View v, int64_t total_units, const OutMap& om, hi
                         (long long)v.Lp, h->W);
   if (h->p.stationary && !h->has_thresh)
     FAIL(h, SG_E_STATE, "stationary gate: call sg_noise_stats or sg_set_noise_threshold first");
-  const bool lean = h->fused_ok && !h->force_unfused && h->fast_ok && !h->force_nofast &&
-                    h->p.prop_decrease == 1.0;
+  // one-pass gate (any prop_decrease) or, with prop_decrease == 1, the three-kernel bit-mask path: only bit /
+  // count fields in the workspace
+  const bool onepass = h->fused_ok && !h->force_unfused && h->fast_ok && !h->force_nofast && onepass_ok(h, g, om);
+  const bool lean = onepass || (h->fused_ok && !h->force_unfused && h->fast_ok && !h->force_nofast &&
+                                h->p.prop_decrease == 1.0);
   int64_t ub = units_per_batch(h, g, total_units, lean);
   int rc = ensure_ws(h, g, ub, lean);
   if (rc) return rc;
@@ -1348,7 +1358,7 @@ static int run_S(sg_handle* h, View v, int64_t total_units, const OutMap& om, hi
     const bool fused = h->fused_ok && !h->force_unfused;
     const bool geom_fast = h->fast_ok && !h->force_nofast;  // default geometry: fused apply kernel
     const bool fast = fused && geom_fast && h->p.prop_decrease == 1.0;
-    if (fast && onepass_ok(h, g, om)) {
+    if (onepass) {
       if ((rc = stage_onepass(h, v, g, nb, om, st))) return rc;
       h->dbg_units = nb; h->dbg_T = g.T; h->dbg_has_P = false; h->dbg_fused = true; h->dbg_fast = true;
       continue;

@@ -51,6 +51,7 @@ struct OnePassArgs {
   unsigned epoch;
   unsigned* err;              // host-mapped word: bit 0 / 1 = a bit / partial-hop hand-off timed out
   int nf, nt;
+  float prop, inv_ktot;       // PROP instantiation: prop_decrease and 1 / ktot (A.kscale = 1/512 then)
   unsigned long long* part2;  // [units][n_tiles][3][256] trailing partial hops of every tile: granules {float, epoch}
   const unsigned long long* mconst;  // [3][64] per-lane MFMA operands: freq band B, time weights A (slots 0..31, 32..63)
   const unsigned long long* exp8;    // [256]: byte v -> 8 bytes (v >> e) & 1
@@ -99,7 +100,9 @@ __device__ __forceinline__ op_v4u op_ld16_sc1(const void* p) {
 #define OP_ABLATE 0
 #endif
 
-template <int WAVES>
+// PROP: prop_decrease < 1 (stationary.py:108-114 applies it BEFORE the smoothing: mask = p K / ktot + (1 - p) edge,
+// edge = the smoothing filter's weight inside the spectrogram -- 1 except near its borders)
+template <int WAVES, bool PROP>
 __global__ __launch_bounds__(WAVES * 64, 3) void k_gate_onepass(OnePassArgs P) {
   static_assert(WAVES == 4, "tile = 16 frames");
   extern __shared__ __attribute__((aligned(16))) char smem[];
@@ -110,6 +113,7 @@ __global__ __launch_bounds__(WAVES * 64, 3) void k_gate_onepass(OnePassArgs P) {
   unsigned long long* s_exp = reinterpret_cast<unsigned long long*>(s_t2 + 528);
   double* s_t2d = reinterpret_cast<double*>(s_exp + 256);   // exact compare constants (refinement), same order
   unsigned* s_misc = reinterpret_cast<unsigned*>(s_t2d + 514);
+  float* s_ef = reinterpret_cast<float*>(s_misc + 4);       // PROP: integer weight of the valid taps along f, per bin
   constexpr int NF = 4 * WAVES;
   const ApplyArgs& A = P.A;
   const Geom& G = A.g;
@@ -123,6 +127,14 @@ __global__ __launch_bounds__(WAVES * 64, 3) void k_gate_onepass(OnePassArgs P) {
   for (int i = tid; i < 256; i += WAVES * 64)
     reinterpret_cast<float4*>(swin)[i] = reinterpret_cast<const float4*>(A.win)[i];
   s_exp[tid] = P.exp8[tid];
+  if constexpr (PROP) {
+    for (int f = tid; f <= 512; f += WAVES * 64) {
+      const int lo = max(-P.nf, -f), hi = min(P.nf, 512 - f);
+      int sum = 0;
+      for (int a = lo; a <= hi; ++a) sum += P.nf + 1 - (a < 0 ? -a : a);
+      s_ef[f] = (float)sum;
+    }
+  }
   __syncthreads();
   const int ntt = A.n_tiles + 2;                 // tiles per unit incl. one decide-only halo tile per side
   const unsigned ticket = s_misc[0];
@@ -500,12 +512,29 @@ __global__ __launch_bounds__(WAVES * 64, 3) void k_gate_onepass(OnePassArgs P) {
   const unsigned short* krow = kt + g * OP_KP;
   const unsigned short* k_lo = krow + (c == 0 ? 0 : c);        // entries e < 16 of lanes c >= 1
   const unsigned short* k_hi = krow + (c == 0 ? 0 : 32 - c);   // entries e >= 16
-  const float k512 = (float)krow[512] * A.kscale;
+  // PROP: weight of the valid taps along t for this lane group's frame (closed form of the triangle's tails)
+  float tt = 0.f;
+  if constexpr (PROP) {
+    const int64_t tl_ = t < nt ? nt - t : 0, tr_ = (G.T - 1 - t) < nt ? nt - (G.T - 1 - t) : 0;
+    tt = (float)((int64_t)(nt + 1) * (nt + 1) - tl_ * (tl_ + 1) / 2 - tr_ * (tr_ + 1) / 2);
+  }
+  const float* e_lo = s_ef + (c == 0 ? 0 : c);
+  const float* e_hi = s_ef + (c == 0 ? 0 : 32 - c);
+  // the float mask exactly as k_k16_to_mask writes it: p * (K / ktot) + (1 - p) * edge, edge = tf * tt / ktot
+  auto mfull = [&](unsigned short kv, float tf) -> float {
+    const float edge = tf * tt * P.inv_ktot;
+    return P.prop * ((float)kv * P.inv_ktot) + (1.0f - P.prop) * edge;
+  };
+  const float k512 = PROP ? mfull(krow[512], s_ef[512]) * A.kscale : (float)krow[512] * A.kscale;
   auto mval = [&](int q, float scale) -> float {
     const int b0 = bin_of_entry(0, q);                         // lane 0 (compile-time)
     const unsigned short* pl = q < 16 ? k_lo : k_hi;
     const int off = q < 16 ? 32 * q : 32 * (q - 16);
     const unsigned short kv = c == 0 ? krow[b0] : pl[off];
+    if constexpr (PROP) {
+      const float tf = c == 0 ? s_ef[b0] : (q < 16 ? e_lo : e_hi)[off];
+      return mfull(kv, tf) * scale;
+    }
     return (float)kv * scale;
   };
   {

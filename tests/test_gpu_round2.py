@@ -244,6 +244,8 @@ def _sg(y, sr, cs, pad, **over):
     (48000, 6000, 600000, 30000, 1, {}),                                   # two tiles only
     (48000, 300001, 100000, 0, 3, {}),                                     # no padding: tiles at the unit edges
     (88200, 120000, 50000, 4000, 1, {}),                                   # nt = 17: not eligible -> three-kernel path
+    (48000, 130000, 40000, 5000, 2, dict(prop_decrease=0.8)),              # partial reduction: p K / ktot + (1 - p) edge
+    (44100, 9000, 600000, 30000, 1, dict(prop_decrease=0.35)),             # ... on a short single chunk (all tiles at edges)
 ])
 def test_onepass_equals_three_kernel_path(sr, n, cs, pad, C, over):
     """k_gate_onepass (one forward transform per frame, tiles exchange mask bits, smoothing on the matrix
@@ -263,7 +265,12 @@ def test_onepass_equals_three_kernel_path(sr, n, cs, pad, C, over):
     finally:
         g.set_option(_ffi.SG_OPT_FORCE_SPLIT, 0)
     assert np.array_equal(a, a2), "one-pass path is not deterministic run to run"
-    assert np.array_equal(a, b), "one-pass path differs from the three-kernel path"
+    if over.get("prop_decrease", 1.0) == 1.0:
+        assert np.array_equal(a, b), "one-pass path differs from the three-kernel path"
+    else:
+        # partial reduction: the split path expands a float mask field first (same formula; the compiler may
+        # contract its multiply-adds differently)
+        assert O.rel_err(a, b) < 2e-6
     kw = dict(stationary=True, chunk_size=cs, padding=pad)
     kw.update(over)
     assert O.rel_err(a, O.reduce_noise_S(y.astype(np.float64), sr, **kw)) < TOL
