@@ -61,6 +61,7 @@ struct sg_handle {
   DevBuf ftab;                       // k_smooth_bits2 phase-1 lookup tables (nf <= 5)
   // one-pass gate (onepass.hpp): published mask bits per tile, publication flags, work counter, tables
   DevBuf xbits, xpart, xticket, ftab3, xexp;
+  DevBuf xin;                        // float32 copy of a recording held in another sample dtype
   DevBuf nsp, nsc;                   // non-stationary mask: per-sub-tile partials / carries (nonstat.hpp)  // ftab3: per-lane MFMA operands, xexp: bit -> byte table
   unsigned* err_host = nullptr;      // host-mapped error word written by k_gate_onepass when a hand-off times out
   unsigned* err_dev = nullptr;
@@ -719,7 +720,7 @@ extern "C" int sg_destroy(sg_handle* h) {
   for (DevBuf* b : {&h->tw64, &h->tw32, &h->wfull64, &h->wa32, &h->ws32, &h->wsq32, &h->kf, &h->kt, &h->thresh,
                     &h->P, &h->pmax, &h->thr_rows, &h->raw, &h->M, &h->seg, &h->yn, &h->bits, &h->K16, &h->umax,
                     &h->need, &h->T2, &h->part, &h->tw512, &h->invn, &h->seam, &h->ftab, &h->xbits, &h->xpart,
-                    &h->xticket, &h->ftab3, &h->xexp, &h->nsp, &h->nsc, &h->czt_tw64, &h->czt_ch64,
+                    &h->xticket, &h->ftab3, &h->xexp, &h->nsp, &h->nsc, &h->xin, &h->czt_tw64, &h->czt_ch64,
                     &h->czt_bh64, &h->czt_tw32, &h->czt_ch32, &h->czt_bh32})
     free_buf(*b);
   delete h;
@@ -1089,7 +1090,7 @@ static int stage_smooth_bits(sg_handle* h, const Geom& g, int64_t ub, bool fast,
 // Compare constants + per-unit floor flags + (rare) float64 floor pre-pass: what every decision kernel of
 // the fused stationary path needs before it can run.
 static int stage_prep_floor(sg_handle* h, const View& v, const Geom& g, int64_t ub, ThreshConsts* tc_out,
-                            hipStream_t st) {
+                            hipStream_t st, const View* v_exact = nullptr) {
   const int wpr = (g.F + 63) / 64;
   int rc;
   if ((rc = ensure(h, h->bits, (size_t)ub * g.T * wpr * 8))) return rc;
@@ -1113,7 +1114,8 @@ static int stage_prep_floor(sg_handle* h, const View& v, const Geom& g, int64_t 
                   (const int*)h->need.p};
   {
     ProfScope ps(h, SG_STAGE_STFT_MAX, st);
-    HIPCHK(h, launch_bits<0>(h->N, v, g, ub, h->tw64.p, h->wfull64.p, tc, h->mag_scale, h->p.top_db,
+    // (float64 transform of the ORIGINAL samples when `v` is a float32 copy)
+    HIPCHK(h, launch_bits<0>(h->N, v_exact ? *v_exact : v, g, ub, h->tw64.p, h->wfull64.p, tc, h->mag_scale, h->p.top_db,
                              (unsigned long long*)h->pmax.p, (unsigned long long*)h->bits.p, wpr, st));
   }
   *tc_out = tc;
@@ -1250,12 +1252,14 @@ static bool onepass_ok(const sg_handle* h, const Geom& g, const OutMap& om) {
   return (he - hb + 3 + 15) / 16 >= 2;  // at least two abutting tiles (seam mode)
 }
 
-static int stage_onepass(sg_handle* h, const View& v, const Geom& g, int64_t ub, const OutMap& om, hipStream_t st) {
+static int stage_onepass(sg_handle* h, const View& v, const View& vx, const Geom& g, int64_t ub, const OutMap& om,
+                         hipStream_t st) {
   constexpr int WAVES = 4, NF = 16;
   int rc;
   ThreshConsts tc{};
-  if ((rc = stage_prep_floor(h, v, g, ub, &tc, st))) return rc;
+  if ((rc = stage_prep_floor(h, v, g, ub, &tc, st, &vx))) return rc;
   fast::OnePassArgs P;
+  P.view_exact = vx;
   fast::ApplyArgs& A = P.A;
   A.view = v; A.g = g; A.om = om;
   A.K = nullptr; A.Mf = nullptr;
@@ -1352,6 +1356,24 @@ static int run_S(sg_handle* h, View v, int64_t total_units, const OutMap& om, hi
   int64_t ub = units_per_batch(h, g, total_units, lean);
   int rc = ensure_ws(h, g, ub, lean);
   if (rc) return rc;
+  // Samples that are not float32: the register-FFT kernels would take the checked per-sample path for every
+  // frame (in every kernel).  Convert the readable part of the rows ONCE -- (float)sample is what those kernels
+  // compute anyway -- and keep the original view for the float64 work (exact refinement, floor pre-pass).
+  const View vx = v;
+  if (v.dtype != SG_F32 && h->fast_ok && !h->force_nofast && (onepass || (!h->p.stationary && nonstat2_ok(h, g)))) {
+    const int64_t rows = total_units / std::max<int64_t>(1, v.n_chunks), len = v.hi - v.lo;
+    const size_t bytes = (size_t)rows * len * sizeof(float);
+    if (len > 0 && bytes <= ((size_t)16 << 30)) {
+      if ((rc = ensure(h, h->xin, bytes))) return rc;
+      ProfScope ps(h, SG_STAGE_PREP, st);
+      hipLaunchKernelGGL(k_to_f32, dim3(grid_1d(rows * len, 256)), dim3(256), 0, st, v.x, v.dtype, v.stride, v.lo, len, rows,
+                         (float*)h->xin.p);
+      HIPCHK(h, hipGetLastError());
+      v.x = (const float*)h->xin.p - v.lo;   // index g of row r -> xin[r * len + (g - lo)]
+      v.dtype = SG_F32;
+      v.stride = len;
+    }
+  }
   for (int64_t u0 = 0; u0 < total_units; u0 += ub) {
     int64_t nb = std::min(ub, total_units - u0);
     v.unit0 = u0;
@@ -1359,7 +1381,9 @@ static int run_S(sg_handle* h, View v, int64_t total_units, const OutMap& om, hi
     const bool geom_fast = h->fast_ok && !h->force_nofast;  // default geometry: fused apply kernel
     const bool fast = fused && geom_fast && h->p.prop_decrease == 1.0;
     if (onepass) {
-      if ((rc = stage_onepass(h, v, g, nb, om, st))) return rc;
+      View vxb = vx;
+      vxb.unit0 = u0;
+      if ((rc = stage_onepass(h, v, vxb, g, nb, om, st))) return rc;
       h->dbg_units = nb; h->dbg_T = g.T; h->dbg_has_P = false; h->dbg_fused = true; h->dbg_fast = true;
       continue;
     }

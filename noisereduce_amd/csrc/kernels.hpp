@@ -74,6 +74,18 @@ __device__ __forceinline__ void store_sample(void* p, int dtype, int64_t idx, fl
   }
 }
 
+// The readable part [lo, hi) of every row as float32 -- what every float32 transform kernel makes of a sample
+// anyway ((float)sample): non-float32 recordings are converted ONCE instead of per frame and kernel on the
+// checked per-sample path.  out[r * (hi - lo) + i] = (float)x[r * stride + lo + i].
+__global__ void k_to_f32(const void* __restrict__ x, int dtype, int64_t stride, int64_t lo, int64_t len, int64_t rows,
+                         float* __restrict__ out) {
+  const int64_t n = rows * len;
+  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x) {
+    const int64_t r = i / len, j = i - r * len;
+    out[i] = (float)load_sample(x, dtype, r * stride + lo + j);
+  }
+}
+
 // ---------------------------------------------------------------------------------------
 // Forward STFT.  One wavefront per frame, FPW frames per wave, WAVES waves per block.
 //   TC = double: stores the power |X|^2 (float64) -- the decision-critical quantity

@@ -41,6 +41,7 @@ constexpr int OP_SPIN_MAX = 1 << 20;     // polls before a hand-off is declared 
 
 struct OnePassArgs {
   ApplyArgs A;              // view, geometry, output map, tables, seam buffer (A.K / A.Mf unused)
+  View view_exact;          // the caller's samples in their own dtype (A.view may be a float32 copy): exact refinement
   const double* win64;      // analysis window, float64 (exact refinement)
   const cx<double>* tw64;   // w_1024^j float64
   ThreshConsts tc;
@@ -65,7 +66,7 @@ __device__ __forceinline__ double op_exact_power(const OnePassArgs& P, int64_t r
 #pragma unroll 4
   for (int i = 0; i < 16; ++i) {
     const int m = lane + 64 * i;
-    const double xv = view_sample(P.A.view, row, chunk, s0 + m) * P.win64[m];
+    const double xv = view_sample(P.view_exact, row, chunk, s0 + m) * P.win64[m];   // the ORIGINAL samples
     const int j = (f * m) & 1023;
     cx<double> w = P.tw64[j & 511];
     if (j >= 512) { w.x = -w.x; w.y = -w.y; }
