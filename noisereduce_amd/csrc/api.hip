@@ -899,7 +899,7 @@ static bool nonstat2_ok(const sg_handle* h, const Geom& g) {
   const int nf = h->p.n_grad_freq, nt = h->p.n_grad_time;
   if (nf > NS_MAX_NF) return false;
   switch (nt) {  // instantiated time half-widths (k_iir_mask keeps the tile column in registers)
-    case 1: case 2: case 3: case 4: case 5: case 6: case 8: case 9: break;
+    case 1: case 2: case 3: case 4: case 5: case 6: case 7: case 8: case 9: case 10: case 12: case 16: case 18: break;
     default: return false;
   }
   const double b = h->p.iir_b, c = 1.0 - b;
@@ -939,7 +939,8 @@ static int stage_nonstat_mask2(sg_handle* h, const View& v, const Geom& g, int64
     };
     switch (nt) {
 #define SG_NS_CASE(NT_) case NT_: HIPCHK(h, launch(k_iir_mask<NT_>)); break;
-      SG_NS_CASE(1) SG_NS_CASE(2) SG_NS_CASE(3) SG_NS_CASE(4) SG_NS_CASE(5) SG_NS_CASE(6) SG_NS_CASE(8) SG_NS_CASE(9)
+      SG_NS_CASE(1) SG_NS_CASE(2) SG_NS_CASE(3) SG_NS_CASE(4) SG_NS_CASE(5) SG_NS_CASE(6) SG_NS_CASE(7) SG_NS_CASE(8)
+      SG_NS_CASE(9) SG_NS_CASE(10) SG_NS_CASE(12) SG_NS_CASE(16) SG_NS_CASE(18)
 #undef SG_NS_CASE
       default: FAIL(h, SG_E_UNSUPPORTED, "no k_iir_mask instantiation for n_grad_time=%d", nt);
     }

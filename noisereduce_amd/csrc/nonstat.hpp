@@ -251,7 +251,7 @@ __device__ __forceinline__ void ns_mask_tile(const float* __restrict__ A, const 
 // grid (bin blocks, time tiles, units).  Interior tiles (every row of the tile and its halos inside [0, T)) take
 // the predicate-free instantiation, the first tile and the last one or two the EDGE one (block-uniform branch).
 template <int NT>
-__global__ __launch_bounds__(256, 3) void k_iir_mask(const float* __restrict__ A, const double* __restrict__ carry,
+__global__ __launch_bounds__(256, (NT <= 9 ? 3 : 2)) void k_iir_mask(const float* __restrict__ A, const double* __restrict__ carry,
                                                      Geom g, NsTiling tl, double b, double nthresh, double slope,
                                                      const float* __restrict__ kf, int nf, float p,
                                                      float* __restrict__ M) {

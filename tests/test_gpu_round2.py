@@ -321,3 +321,27 @@ def test_onepass_under_uneven_load(nr):
     [t.start() for t in th]
     [t.join() for t in th]
     assert not bad, bad
+
+
+# ---------------------------------------------------------------------------------------------
+# 5. two-pass non-stationary mask (nonstat.hpp) over its instantiated time half-widths
+# ---------------------------------------------------------------------------------------------
+@pytest.mark.parametrize("sr,kw", [
+    (48000, dict()),                                         # nt = 9, nf = 5 (the default geometry)
+    (48000, dict(n_fft=512)),                                # hop 128: nt = 18, nf = 2; general STFT kernels
+    (64000, dict()),                                         # nt = 12
+    (48000, dict(time_mask_smooth_ms=30)),                   # nt = 5
+    (48000, dict(time_mask_smooth_ms=90)),                   # nt = 16
+    (48000, dict(time_mask_smooth_ms=60)),                   # nt = 11: not instantiated -> segmented-scan kernels
+    (22050, dict(time_constant_s=0.5, prop_decrease=0.7)),   # nt = 4, short time constant, partial reduction
+    (48000, dict(time_constant_s=0.05)),                     # c^rows too small for the reverse regeneration -> old kernels
+    (48000, dict(freq_mask_smooth_hz=None)),                 # nf = 1 ... time smoothing only
+])
+def test_nonstationary_two_pass_mask(nr, sr, kw):
+    """k_iir_part / k_iir_chain / k_iir_mask (or the fall-back kernels) against the oracle's filtfilt + sigmoid +
+    fftconvolve (nonstationary.py:47-115), chunked so that tiles touch both unit edges and a short last tile."""
+    n, cs, pad = 170000, 50000, 6000
+    y = np.stack([O.synth_signal(n, sr=sr, seed=31 + c, tone_hz=700.0 * (c + 1)) for c in range(2)]).astype(np.float32)
+    got = nr.reduce_noise(y=y, sr=sr, stationary=False, chunk_size=cs, padding=pad, **kw)
+    want = O.reduce_noise_S(y.astype(np.float64), sr, stationary=False, chunk_size=cs, padding=pad, **kw)
+    assert O.rel_err(got, want) < TOL
