@@ -96,14 +96,15 @@ __global__ __launch_bounds__(64) void k_iir_chain(const float* __restrict__ A, c
   const double* pb = part + (u * nk * 3 * 2) * (int64_t)g.FS + f;
   double* cb = carry + (u * nk * 3 * 2) * (int64_t)g.FS + f;
   double s = (double)A[u * g.T * g.FS + f];  // s[-1] = A[0]  (lfilter_zi steady state)
-  // the chain is serial, its operands are not: 8 sub-tiles' partials are fetched together
+  // the chain is serial, its operands are not: 32 sub-tiles' partials are fetched together
   const int64_t st2 = 2 * (int64_t)g.FS;
-  for (int j0 = 0; j0 < nj; j0 += 8) {
-    double e[8];
+  constexpr int CB = 32;
+  for (int j0 = 0; j0 < nj; j0 += CB) {
+    double e[CB];
 #pragma unroll
-    for (int q = 0; q < 8; ++q) e[q] = j0 + q < nj ? pb[(j0 + q) * st2] : 0.0;
+    for (int q = 0; q < CB; ++q) e[q] = j0 + q < nj ? pb[(j0 + q) * st2] : 0.0;
 #pragma unroll
-    for (int q = 0; q < 8; ++q)
+    for (int q = 0; q < CB; ++q)
       if (j0 + q < nj) {
         cb[(j0 + q) * st2] = s;
         s = e[q] + pw1[j0 + q] * s;
@@ -113,16 +114,17 @@ __global__ __launch_bounds__(64) void k_iir_chain(const float* __restrict__ A, c
   // E_b = sum_t b c^(t-start) s_f[t] = E0 + s_in * b c (1 - c^(2 len)) / (1 - c^2)   (s_f = s0 + c^(t-start+1) s_in)
   double S = s;  // seed: the forward pass's last value
   const double gq = b * c / (1.0 - c * c);
-  for (int j1 = nj - 1; j1 >= 0; j1 -= 8) {
-    double e0[8], sin[8];
+  constexpr int CB2 = 16;
+  for (int j1 = nj - 1; j1 >= 0; j1 -= CB2) {
+    double e0[CB2], sin[CB2];
 #pragma unroll
-    for (int q = 0; q < 8; ++q) {
+    for (int q = 0; q < CB2; ++q) {
       const int j = j1 - q;
       e0[q] = j >= 0 ? pb[j * st2 + g.FS] : 0.0;
       sin[q] = j >= 0 ? cb[j * st2] : 0.0;
     }
 #pragma unroll
-    for (int q = 0; q < 8; ++q) {
+    for (int q = 0; q < CB2; ++q) {
       const int j = j1 - q;
       if (j >= 0) {
         cb[j * st2 + g.FS] = S;
