@@ -652,10 +652,19 @@ __global__ __launch_bounds__(64 * STAT_TG) void k_row_decide(const double* __res
   const int64_t u = blockIdx.y;
   const bool on = f < g.F;
   double m = 0.0;
-  for (int64_t t = tg; t < g.T; t += STAT_TG) {
-    const double pv = on ? P[(u * g.T + t) * g.FS + f] : 0.0;
-    tile[t * 64 + l] = pv;
-    m = fmax(m, pv);
+  for (int64_t t0 = tg; t0 < g.T; t0 += 16 * STAT_TG) {   // 16 independent loads in flight per thread
+    double pv[16];
+#pragma unroll
+    for (int q = 0; q < 16; ++q) {
+      const int64_t t = t0 + q * STAT_TG;
+      pv[q] = (on && t < g.T) ? P[(u * g.T + t) * g.FS + f] : 0.0;
+    }
+#pragma unroll
+    for (int q = 0; q < 16; ++q) {
+      const int64_t t = t0 + q * STAT_TG;
+      if (t < g.T) tile[t * 64 + l] = pv[q];
+      m = fmax(m, pv[q]);
+    }
   }
   r1[tg][l] = m;
   __syncthreads();
