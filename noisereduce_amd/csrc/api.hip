@@ -751,7 +751,8 @@ static size_t unit_bytes(const sg_handle* h, const Geom& g, bool lean) {
   size_t cells = (size_t)g.T * g.FS;
   if (lean) return (size_t)g.T * ((g.F + 63) / 64) * 8 + cells * 2 + (size_t)g.FS * 16 + 64 +
            (size_t)(g.T / 16 + 2) * 6 * 256 * 4;
-  return cells * (8 + 4 + 4 + 2) + (size_t)g.T * g.n * 4 + (size_t)g.FS * 16;
+  return cells * (8 + 4 + 4 + 2) + (size_t)g.T * g.n * 4 + (size_t)g.FS * 16 +
+         (size_t)(g.T / NS_TT + 1) * 3 * 2 * g.FS * 8 * 2;   // + partials and carries of the two-pass non-stationary mask
 }
 
 static int64_t units_per_batch(const sg_handle* h, const Geom& g, int64_t total, bool lean = false) {

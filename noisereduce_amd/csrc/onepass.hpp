@@ -142,8 +142,10 @@ __global__ __launch_bounds__(WAVES * 64, 3) void k_gate_onepass(OnePassArgs P) {
   const int64_t u = ticket / (unsigned)ntt;
   const int jt = (int)(ticket % (unsigned)ntt) - 1;   // -1 and n_tiles: halo tiles
   const bool halo_tile = jt < 0 || jt >= A.n_tiles;
-  const int64_t row = (A.view.unit0 + u) / A.view.n_chunks;
-  const int64_t chunk = A.view.c0 + (A.view.unit0 + u) % A.view.n_chunks;
+  // (32-bit division: unit indices fit, and a 64-bit divide is ~150 instructions of every workgroup's prologue)
+  const unsigned gu = (unsigned)(A.view.unit0 + u), nch = (unsigned)A.view.n_chunks;
+  const int64_t row = gu / nch;
+  const int64_t chunk = A.view.c0 + gu % nch;
   const bool floor_live = P.tc.need_floor[u] != 0;
 
   // compare constants (x4: the split works on 2X), permuted like the lanes' entries -- see k_decide_fast
