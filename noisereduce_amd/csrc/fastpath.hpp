@@ -85,12 +85,21 @@ __device__ __forceinline__ void dft_reg(cf* v) {
     dft_reg<R / 2, INV>(o);
 #pragma unroll
     for (int k = 0; k < R / 2; ++k) {
-      cf t;
-      if (k == 0) t = o[k];
-      else if (k == R / 4) t = rot90<INV>(o[k]);
-      else t = mul_tw<INV>(o[k], twc<R>(k), tws<R>(k));
-      v[k] = cadd(e[k], t);
-      v[k + R / 2] = csub(e[k], t);
+      if (k == 0 || k == R / 4) {
+        const cf t = k == 0 ? o[k] : rot90<INV>(o[k]);
+        v[k] = cadd(e[k], t);
+        v[k + R / 2] = csub(e[k], t);
+      } else {
+        // butterfly with the twiddle folded into fused multiply-adds: p = e + w o (4 FMAs), q = e - w o = 2 e - p
+        // (2 FMAs) -- 6 instructions instead of 4 (complex product) + 4 (add, subtract)
+        const float c = twc<R>(k), s = INV ? -tws<R>(k) : tws<R>(k);   // w = c - i s (forward), c + i s (inverse)
+        const cf a = e[k], b = o[k];
+        cf p;
+        p.x = fmaf(b.x, c, fmaf(b.y, s, a.x));
+        p.y = fmaf(b.y, c, fmaf(-b.x, s, a.y));
+        v[k] = p;
+        v[k + R / 2] = {fmaf(2.0f, a.x, -p.x), fmaf(2.0f, a.y, -p.y)};
+      }
     }
   }
 }
