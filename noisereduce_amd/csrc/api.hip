@@ -1324,7 +1324,7 @@ static int stage_onepass(sg_handle* h, const View& v, const View& vx, const Geom
   {
     ProfScope ps(h, SG_STAGE_ONEPASS, st);
     const size_t lds = (size_t)(fast::FN + WAVES * fast::WAVE_CX_H) * sizeof(fast::cf) + (1024 + 528) * sizeof(float) +
-                       256 * 8 + 514 * 8 + 16 + (prop ? 528 * sizeof(float) : 0);
+                       256 * 8 + 514 * 8 + 16 + (prop ? 528 : 0);
     auto go = [&](auto kern) -> hipError_t {
       hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize,
                                          (int)lds);

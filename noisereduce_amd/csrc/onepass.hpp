@@ -114,7 +114,7 @@ __global__ __launch_bounds__(WAVES * 64, 3) void k_gate_onepass(OnePassArgs P) {
   unsigned long long* s_exp = reinterpret_cast<unsigned long long*>(s_t2 + 528);
   double* s_t2d = reinterpret_cast<double*>(s_exp + 256);   // exact compare constants (refinement), same order
   unsigned* s_misc = reinterpret_cast<unsigned*>(s_t2d + 514);
-  float* s_ef = reinterpret_cast<float*>(s_misc + 4);       // PROP: integer weight of the valid taps along f, per bin
+  unsigned char* s_ef = reinterpret_cast<unsigned char*>(s_misc + 4);  // PROP: integer weight (<= 81) of the valid taps along f, per bin
   constexpr int NF = 4 * WAVES;
   const ApplyArgs& A = P.A;
   const Geom& G = A.g;
@@ -123,17 +123,29 @@ __global__ __launch_bounds__(WAVES * 64, 3) void k_gate_onepass(OnePassArgs P) {
   const int g = lane >> 4, c = lane & 15;
   const int nt = P.nt;
 
-  if (tid == 0) s_misc[0] = atomicAdd(P.ticket, 1u) - P.ticket_base;
-  for (int i = tid; i < FN; i += WAVES * 64) tw512[i] = A.tw512[(i >> 4) * (i & 15)];
-  for (int i = tid; i < 256; i += WAVES * 64)
-    reinterpret_cast<float4*>(swin)[i] = reinterpret_cast<const float4*>(A.win)[i];
-  s_exp[tid] = P.exp8[tid];
+  double t2pre[3];   // compare constants of entries tid, tid + 256 and 512 (they do not depend on the ticket)
+  {
+    // table loads first, the ticket's atomic behind them in the same queue: one memory round trip, not two
+    static_assert(FN == 2 * WAVES * 64 && WAVES * 64 == 256, "one pass of the prologue loads per thread");
+    const cf tw_a = A.tw512[(tid >> 4) * (tid & 15)];
+    const cf tw_b = A.tw512[((tid + 256) >> 4) * (tid & 15)];
+    const float4 w4 = reinterpret_cast<const float4*>(A.win)[tid];
+    const unsigned long long e8 = P.exp8[tid];
+    t2pre[0] = P.tc.T2[perm_inv(tid)];
+    t2pre[1] = P.tc.T2[perm_inv(tid + 256)];
+    t2pre[2] = P.tc.T2[perm_inv(512)];
+    if (tid == 0) s_misc[0] = atomicAdd(P.ticket, 1u) - P.ticket_base;
+    tw512[tid] = tw_a;
+    tw512[tid + 256] = tw_b;
+    reinterpret_cast<float4*>(swin)[tid] = w4;
+    s_exp[tid] = e8;
+  }
   if constexpr (PROP) {
     for (int f = tid; f <= 512; f += WAVES * 64) {
       const int lo = max(-P.nf, -f), hi = min(P.nf, 512 - f);
       int sum = 0;
       for (int a = lo; a <= hi; ++a) sum += P.nf + 1 - (a < 0 ? -a : a);
-      s_ef[f] = (float)sum;
+      s_ef[f] = (unsigned char)sum;
     }
   }
   __syncthreads();
@@ -149,20 +161,13 @@ __global__ __launch_bounds__(WAVES * 64, 3) void k_gate_onepass(OnePassArgs P) {
   const bool floor_live = P.tc.need_floor[u] != 0;
 
   // compare constants (x4: the split works on 2X), permuted like the lanes' entries -- see k_decide_fast
-  auto t2eff = [&](int f) -> double {
-    double v = P.tc.T2[f];
+  auto t2eff = [&](int f, double v) -> double {
     if (floor_live) {
       double fl = cell_db(P.tc.pmax[u * G.FS + f], P.mag_scale) - P.top_db;
       if (fl > P.tc.thresh[f]) v = -1.0;
     }
     return v;
   };
-  for (int i = tid; i <= 512; i += WAVES * 64) {
-    double v = t2eff(perm_inv(i));
-    s_t2[i] = v < 0.0 ? -3.0e38f : (float)(4.0 * v);
-    s_t2d[i] = v;   // the rare exact re-evaluation compares against this (no log10 in the hot kernel body)
-  }
-
   const int64_t tf_tile = A.h_begin - 3 + (int64_t)jt * NF;  // first frame of the tile (abutting tiles)
   const int64_t tq = tf_tile + 4 * wave;
   const int64_t t = tq + g;                                  // this lane group's frame
@@ -178,18 +183,37 @@ __global__ __launch_bounds__(WAVES * 64, 3) void k_gate_onepass(OnePassArgs P) {
     const int64_t gb = chunk * A.view.cs - A.view.pad + s0b;
     blk_in = A.view.dtype == 0 && tf_tile >= 0 && tf_tile + NF <= G.T && s0b >= 0 && s0b + SPAN <= A.view.Lp &&
              gb >= A.view.lo && gb + SPAN <= A.view.hi;
-    if (blk_in) {
-      const float* sp = (const float*)A.view.x + row * A.view.stride + gb;
-      float* xs = reinterpret_cast<float*>(regions);
-      if ((reinterpret_cast<uintptr_t>(sp) & 15) == 0) {
-        for (int i = tid; i < SPAN / 4; i += WAVES * 64) {
-          const float4 q = reinterpret_cast<const float4*>(sp)[i];
-          const int e = 4 * i;
-          *reinterpret_cast<float4*>(&xs[(e >> 8) * XPITCH + (e & 255)]) = q;
-        }
-      } else {
-        for (int i = tid; i < SPAN; i += WAVES * 64) xs[(i >> 8) * XPITCH + (i & 255)] = sp[i];
+    auto fill_t2 = [&]() {
+#pragma unroll
+      for (int k = 0; k < 3; ++k) {
+        const int i = tid + k * WAVES * 64;
+        if (i > 512) break;
+        const double v = t2eff(perm_inv(i), t2pre[k]);
+        s_t2[i] = v < 0.0 ? -3.0e38f : (float)(4.0 * v);
+        s_t2d[i] = v;   // the rare exact re-evaluation compares against this (no log10 in the hot kernel body)
       }
+    };
+    const float* sp = (const float*)A.view.x + row * A.view.stride + gb;
+    float* xs = reinterpret_cast<float*>(regions);
+    if (blk_in && (reinterpret_cast<uintptr_t>(sp) & 15) == 0) {
+      // span loads in flight while the compare constants are built
+      constexpr int NQ = (SPAN / 4 + WAVES * 64 - 1) / (WAVES * 64);
+      float4 q[NQ];
+#pragma unroll
+      for (int k = 0; k < NQ; ++k) {
+        const int i = tid + k * WAVES * 64;
+        q[k] = i < SPAN / 4 ? reinterpret_cast<const float4*>(sp)[i] : make_float4(0.f, 0.f, 0.f, 0.f);
+      }
+      fill_t2();
+#pragma unroll
+      for (int k = 0; k < NQ; ++k) {
+        const int e = 4 * (tid + k * WAVES * 64);
+        if (e < SPAN) *reinterpret_cast<float4*>(&xs[(e >> 8) * XPITCH + (e & 255)]) = q[k];
+      }
+    } else {
+      fill_t2();
+      if (blk_in)
+        for (int i = tid; i < SPAN; i += WAVES * 64) xs[(i >> 8) * XPITCH + (i & 255)] = sp[i];
     }
   }
   __syncthreads();  // tables, compare constants and span staged
@@ -521,21 +545,21 @@ __global__ __launch_bounds__(WAVES * 64, 3) void k_gate_onepass(OnePassArgs P) {
     const int64_t tl_ = t < nt ? nt - t : 0, tr_ = (G.T - 1 - t) < nt ? nt - (G.T - 1 - t) : 0;
     tt = (float)((int64_t)(nt + 1) * (nt + 1) - tl_ * (tl_ + 1) / 2 - tr_ * (tr_ + 1) / 2);
   }
-  const float* e_lo = s_ef + (c == 0 ? 0 : c);
-  const float* e_hi = s_ef + (c == 0 ? 0 : 32 - c);
+  const unsigned char* e_lo = s_ef + (c == 0 ? 0 : c);
+  const unsigned char* e_hi = s_ef + (c == 0 ? 0 : 32 - c);
   // the float mask exactly as k_k16_to_mask writes it: p * (K / ktot) + (1 - p) * edge, edge = tf * tt / ktot
   auto mfull = [&](unsigned short kv, float tf) -> float {
     const float edge = tf * tt * P.inv_ktot;
     return P.prop * ((float)kv * P.inv_ktot) + (1.0f - P.prop) * edge;
   };
-  const float k512 = PROP ? mfull(krow[512], s_ef[512]) * A.kscale : (float)krow[512] * A.kscale;
+  const float k512 = PROP ? mfull(krow[512], (float)s_ef[512]) * A.kscale : (float)krow[512] * A.kscale;
   auto mval = [&](int q, float scale) -> float {
     const int b0 = bin_of_entry(0, q);                         // lane 0 (compile-time)
     const unsigned short* pl = q < 16 ? k_lo : k_hi;
     const int off = q < 16 ? 32 * q : 32 * (q - 16);
     const unsigned short kv = c == 0 ? krow[b0] : pl[off];
     if constexpr (PROP) {
-      const float tf = c == 0 ? s_ef[b0] : (q < 16 ? e_lo : e_hi)[off];
+      const float tf = (float)(c == 0 ? s_ef[b0] : (q < 16 ? e_lo : e_hi)[off]);
       return mfull(kv, tf) * scale;
     }
     return (float)kv * scale;
@@ -620,6 +644,68 @@ __global__ __launch_bounds__(WAVES * 64, 3) void k_gate_onepass(OnePassArgs P) {
   // same way as the mask bits (write-through stores, drained, epoch flag per hop); tile j+1 adds its LEADING
   // partials and finalises them.  Per wave: trailing hop first (published early), interior hops, leading hop
   // last (tile j, one ticket earlier, has usually published by then).  Publishing never waits: no cycles.
+  // Interior tiles (every hop inside the output range, all four frames of each hop present, float32 output,
+  // aligned rows): straight-line version of the loop below, same sums in the same order.
+  {
+    const int64_t pb0 = tf_tile * 256 - G.padL;
+    const int64_t gi00 = chunk * A.om.g_step + (pb0 - A.om.p0);
+    float* dbase = (float*)A.om.out + (row * A.om.stride + gi00 - A.om.g0);
+    float* dst0 = dbase + s4;
+    const bool tile_fast = A.om.dtype == 0 && A.normalize && tf_tile >= 3 && tf_tile + NF + 2 < G.T &&
+                           tf_tile >= A.h_begin && tf_tile + NF + 2 < A.h_end && pb0 >= A.om.p0 &&
+                           pb0 + NF * 256 <= A.om.p1 && pb0 + NF * 256 <= G.Lout && gi00 >= A.om.g_lo &&
+                           gi00 + NF * 256 <= A.om.g_hi && (reinterpret_cast<uintptr_t>(dbase) & 15) == 0 && WAVES == 4;
+    if (tile_fast) {
+      constexpr int R = WAVE_CX_H * 2;
+      auto ld4 = [&](int off) { return *reinterpret_cast<const float4*>(&fr[off + s4]); };
+      auto fin = [&](float4 a, int jj) {
+        a.x *= n4.x; a.y *= n4.y; a.z *= n4.z; a.w *= n4.w;
+        *reinterpret_cast<float4*>(dst0 + jj * 256) = a;
+      };
+      if (wave == 3) {
+#pragma unroll
+        for (int it = 0; it < 4; ++it) fin(ld4(it * R + 3 * HPITCH), 3 + 4 * it);
+        return;
+      }
+      {
+        const float4 a4 = ld4((WAVES - 1) * R + (wave + 4) * HPITCH);
+        unsigned long long* dst = P.part2 + (((size_t)u * A.n_tiles + jt) * 3 + wave) * 256 + s4;
+        const op_v4u ga = {__float_as_uint(a4.x), P.epoch, __float_as_uint(a4.y), P.epoch};
+        const op_v4u gb = {__float_as_uint(a4.z), P.epoch, __float_as_uint(a4.w), P.epoch};
+        op_st16_sc1(dst, ga);
+        op_st16_sc1(dst + 2, gb);
+      }
+#pragma unroll
+      for (int it = 1; it < 4; ++it) {
+        float4 a4 = ld4((it - 1) * R + (wave + 4) * HPITCH);
+        const float4 f4 = ld4(it * R + wave * HPITCH);
+        a4.x += f4.x; a4.y += f4.y; a4.z += f4.z; a4.w += f4.w;
+        fin(a4, wave + 4 * it);
+      }
+      {
+        float4 a4 = ld4(wave * HPITCH);
+        const unsigned long long* src = P.part2 + (((size_t)u * A.n_tiles + jt - 1) * 3 + wave) * 256 + s4;
+        op_v4u ga, gb;
+        for (int spin = 0;; ++spin) {
+          asm volatile("global_load_dwordx4 %0, %2, off sc1\n\tglobal_load_dwordx4 %1, %2, off offset:16 sc1\n\ts_waitcnt vmcnt(0)"
+                       : "=&v"(ga), "=&v"(gb) : "v"(src) : "memory");
+          const unsigned e = P.epoch;
+          if ((OP_ABLATE & 16) || (ga[1] == e && ga[3] == e && gb[1] == e && gb[3] == e)) break;
+          if (spin >= OP_SPIN_MAX) {
+            atomicOr_system(P.err, 2u);
+            break;
+          }
+          __builtin_amdgcn_s_sleep(1);
+        }
+        a4.x = __uint_as_float(ga[0]) + a4.x;
+        a4.y = __uint_as_float(ga[2]) + a4.y;
+        a4.z = __uint_as_float(gb[0]) + a4.z;
+        a4.w = __uint_as_float(gb[2]) + a4.w;
+        fin(a4, wave);
+      }
+      return;
+    }
+  }
   for (int it = 0; it < 5; ++it) {
     const int jj = wave < 3 ? (it == 0 ? NF + wave : (it == 4 ? wave : wave + 4 * it)) : (it < 4 ? 3 + 4 * it : -1);
     if (jj < 0) break;
