@@ -17,6 +17,7 @@
 #include "czt.hpp"
 #include "onepass.hpp"
 #include "nonstat.hpp"
+#include "fast64.hpp"
 
 #ifndef SG_APPLY_WAVES
 #define SG_APPLY_WAVES 4  // wavefronts per workgroup of k_apply_fast: tile = 4*W frames -> 4*W-3 hops
@@ -425,6 +426,23 @@ template <typename TC>
 static hipError_t stft_any(const sg_handle* h, const View& v, const Geom& g, int64_t units, double* P, float* mag,
                            double* z, double zscale, hipStream_t st, unsigned long long* pmax_bits = nullptr) {
   const void* wfull = sizeof(TC) == 8 ? h->wfull64.p : h->wa32.p;
+  if (sizeof(TC) == 8 && h->fast_ok && !h->force_nofast && P && !mag && !z && v.dtype == SG_F32 &&
+      units * ((g.T + 15) / 16) >= 512) {
+    // default geometry, float32 samples, float64 powers only, enough 16-frame blocks for two per CU: register FFT
+    // core (fast64.hpp).  (A single noise clip is faster on k_stft's one-frame-per-wave grid: 13.7 vs 18 us.)
+    constexpr int WAVES = 4;
+    fast::Pow64Args A{v, g, (const double*)h->wfull64.p, (const fast::cd*)h->tw64.p, P, pmax_bits};
+    const size_t lds = (size_t)(fast::FN + WAVES * 4 * fast::FSLOTS_D + 32) * sizeof(fast::cd);
+    dim3 grid((unsigned)((g.T + WAVES * 4 - 1) / (WAVES * 4)), (unsigned)units);
+    auto go = [&](auto kern) -> hipError_t {
+      hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern),
+                                         hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+      if (e != hipSuccess) return e;
+      hipLaunchKernelGGL(kern, grid, dim3(WAVES * 64), lds, st, A);
+      return hipGetLastError();
+    };
+    return pmax_bits ? go(fast::k_power_fast64<WAVES, true>) : go(fast::k_power_fast64<WAVES, false>);
+  }
   if (!h->czt_M) {
     const void* tw = sizeof(TC) == 8 ? h->tw64.p : h->tw32.p;
     return launch_stft<TC>(h->N, v, g, units, tw, wfull, P, mag, z, zscale, st, pmax_bits);

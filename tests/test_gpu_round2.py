@@ -345,3 +345,32 @@ def test_nonstationary_two_pass_mask(nr, sr, kw):
     got = nr.reduce_noise(y=y, sr=sr, stationary=False, chunk_size=cs, padding=pad, **kw)
     want = O.reduce_noise_S(y.astype(np.float64), sr, stationary=False, chunk_size=cs, padding=pad, **kw)
     assert O.rel_err(got, want) < TOL
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("B,L,xn", [(256, 16000, False), (64, 40000, False), (96, 20000, True)])
+def test_float64_power_kernel_matches_the_lds_transform(B, L, xn):
+    """`k_power_fast64` (float64 powers on the register FFT core; short rows: fused row statistics, long rows:
+    per-band maxima by atomics) against the nine-pass LDS transform it replaces (`SG_OPT_FORCE_NOFAST`) -- same
+    output -- and against the oracle (torchgate.py:200-264) on a few rows."""
+    from noisereduce_amd import _ffi
+    from noisereduce_amd.torchgate import TorchGate
+    torch.manual_seed(B + L)
+    t = torch.arange(L, dtype=torch.float64) / 16000
+    x = (0.1 * torch.randn(B, L, dtype=torch.float64) + 0.3 * torch.sin(2 * np.pi * 700 * t)).float().cuda()
+    noise = (0.1 * torch.randn(B, 12000, dtype=torch.float64)).float().cuda() if xn else None
+    tg = TorchGate(sr=16000, nonstationary=False).cuda()
+    gate = tg._gate_for(x.device)
+    y_fast = gate.process_batch(x, noise)
+    try:
+        gate.set_option(_ffi.SG_OPT_FORCE_NOFAST, 1)
+        y_ref = gate.process_batch(x, noise)
+    finally:
+        gate.set_option(_ffi.SG_OPT_FORCE_NOFAST, 0)
+    # one flipped mask cell would show as ~1e-4 of the peak; float32 rounding of the two apply kernels as ~1e-7
+    assert O.rel_err(y_fast.cpu().numpy(), y_ref.cpu().numpy()) < 2e-6
+    rows = [0, B // 2, B - 1]
+    want = O.torchgate_T(x[rows].cpu().numpy().astype(np.float64), 16000, nonstationary=False,
+                         xn=None if noise is None else noise[rows].cpu().numpy().astype(np.float64),
+                         window=torch.hann_window(1024).double().numpy())
+    assert O.rel_err(y_fast[rows].cpu().numpy(), want) < TOL
