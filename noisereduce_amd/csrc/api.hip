@@ -12,6 +12,12 @@
 #include <vector>
 
 #include "../../include/mi355gate.h"
+// Floating-point contraction only INSIDE a source expression (the language rule), never across statements: with the
+// compiler's default (fast) the back end fuses a product into whichever neighbouring add it meets first, and that
+// choice changes with unrelated edits -- two kernels that share a formula then round differently in the cells where
+// both products of a sum are inexact.  The one-pass gate and the three-kernel path are bit-identical by
+// construction only under this rule; where a fused multiply-add is wanted across statements the code says fmaf().
+#pragma clang fp contract(on)
 #include "kernels.hpp"
 #include "fused.hpp"
 #include "czt.hpp"
