@@ -251,17 +251,34 @@ __device__ __forceinline__ void fft512_inv_half(cf* v, cf* fb, const cf* tw512, 
 // One conjugate pair of the real-FFT split -> mask -> merge (see k_apply_istft in kernels.hpp):
 // a = Zc[k], b = Zc[N-k], w = w_1024^k, mk / mn = mask of bin k / N-k.  Returns Zc'[k], Zc'[N-k].
 // The four 1/2 factors of split and merge are NOT applied here: the caller folds 1/4 into the masks.
+// The two halves are shared by every kernel that splits or merges (k_apply_fast, k_gate_onepass, the decision and
+// magnitude kernels): the same fused multiply-adds in the same order, so the kernels agree to the bit.
+//   split: E = a + conj b, O = (a - conj b) / i;  xa = E + w O = 2 X[k],  xb = E - w O = 2 E - xa (conj-pair value)
+__device__ __forceinline__ void split_pair(cf a, cf b, cf w, cf& xa, cf& xb) {
+  const cf E = {a.x + b.x, a.y - b.y};
+  const cf O = {a.y + b.y, b.x - a.x};
+  xa.x = fmaf(w.x, O.x, fmaf(-w.y, O.y, E.x));
+  xa.y = fmaf(w.x, O.y, fmaf(w.y, O.x, E.y));
+  xb.x = fmaf(2.0f, E.x, -xa.x);
+  xb.y = fmaf(2.0f, E.y, -xa.y);
+}
+//   merge: Yk = xa mk, Yn = conj(xb) mn;  Ep = Yk + conj Yn, D = Yk - conj Yn, Op = D conj(w);
+//          a' = (Ep.x - Op.y, Ep.y + Op.x),  b' = (Ep.x + Op.y, Op.x - Ep.y) = (2 Ep.x - a'.x, a'.y - 2 Ep.y)
+__device__ __forceinline__ void merge_pair(cf& xa, cf& xb, cf w, float mk, float mn) {
+  const float nx = xb.x * mn, ny = -xb.y * mn;
+  const cf Ep = {fmaf(xa.x, mk, nx), fmaf(xa.y, mk, -ny)};
+  const cf D = {fmaf(xa.x, mk, -nx), fmaf(xa.y, mk, ny)};
+  const float ax = fmaf(D.x, w.y, fmaf(-D.y, w.x, Ep.x));
+  const float ay = fmaf(D.x, w.x, fmaf(D.y, w.y, Ep.y));
+  xa = {ax, ay};
+  xb = {fmaf(2.0f, Ep.x, -ax), fmaf(-2.0f, Ep.y, ay)};
+}
 __device__ __forceinline__ void pair_mask(cf& a, cf& b, cf w, float mk, float mn) {
-  cf E = {a.x + b.x, a.y - b.y};
-  cf O = {a.y + b.y, b.x - a.x};
-  cf wO = cmul(w, O);
-  cf Yk = {(E.x + wO.x) * mk, (E.y + wO.y) * mk};
-  cf Yn = {(E.x - wO.x) * mn, (wO.y - E.y) * mn};
-  cf Ep = {Yk.x + Yn.x, Yk.y - Yn.y};
-  cf D = {Yk.x - Yn.x, Yk.y + Yn.y};
-  cf Op = cmul(D, cf{w.x, -w.y});
-  a = {Ep.x - Op.y, Ep.y + Op.x};
-  b = {Ep.x + Op.y, Op.x - Ep.y};
+  cf xa, xb;
+  split_pair(a, b, w, xa, xb);
+  merge_pair(xa, xb, w, mk, mn);
+  a = xa;
+  b = xb;
 }
 
 // "Entries": lane c works on 16 conjugate-pair slots s = 0..15; entry e = s is the first bin of
@@ -975,12 +992,10 @@ __global__ __launch_bounds__(WAVES * 64, 3) void k_decide_fast(DecideArgs A) {
       amb |= ((diff * diff <= d2 * (P + T)) ? 1u : 0u) << q;
     };
     auto pair_power = [&](cf a, cf b, cf w, float& Pk, float& Pn) {
-      cf E = {a.x + b.x, a.y - b.y};
-      cf O = {a.y + b.y, b.x - a.x};
-      cf wO = cmul(w, O);
-      float px = E.x + wO.x, py = E.y + wO.y, qx = E.x - wO.x, qy = E.y - wO.y;
-      Pk = px * px + py * py;
-      Pn = qx * qx + qy * qy;
+      cf p, q;
+      split_pair(a, b, w, p, q);
+      Pk = p.x * p.x + p.y * p.y;
+      Pn = q.x * q.x + q.y * q.y;
     };
     // One instruction stream for all lanes (see k_apply_fast): decisions are made per ENTRY
     // (bin_of_entry); lane 0 selects its operands differently and its bits are permuted back to
@@ -1181,12 +1196,10 @@ __global__ __launch_bounds__(WAVES * 64, 3) void k_mag_fast(MagArgs A) {
     if (fvalid) mrow[bin_of_entry(c, e)] = 0.5f * sqrtf(P4);
   };
   auto pair_power = [&](cf a, cf b, cf w, float& Pk, float& Pn) {
-    cf E = {a.x + b.x, a.y - b.y};
-    cf O = {a.y + b.y, b.x - a.x};
-    cf wO = cmul(w, O);
-    float px = E.x + wO.x, py = E.y + wO.y, qx = E.x - wO.x, qy = E.y - wO.y;
-    Pk = px * px + py * py;
-    Pn = qx * qx + qy * qy;
+    cf p, q;
+    split_pair(a, b, w, p, q);
+    Pk = p.x * p.x + p.y * p.y;
+    Pn = q.x * q.x + q.y * q.y;
   };
   {
     float Pk, Pn;

@@ -305,13 +305,7 @@ __global__ __launch_bounds__(WAVES * 64, 3) void k_gate_onepass(OnePassArgs P) {
   }
   {
     auto sel = [&](cf a0, cf a1) -> cf { return {l0 ? a0.x : a1.x, l0 ? a0.y : a1.y}; };
-    auto split = [&](cf a, cf b2, cf w, cf& xa, cf& xb) {
-      cf E = {a.x + b2.x, a.y - b2.y};
-      cf O = {a.y + b2.y, b2.x - a.x};
-      cf wO = cmul(w, O);
-      xa = {E.x + wO.x, E.y + wO.y};
-      xb = {E.x - wO.x, E.y - wO.y};
-    };
+    auto split = [&](cf a, cf b2, cf w, cf& xa, cf& xb) { split_pair(a, b2, w, xa, xb); };
     split(v[0], v[31], wlo, pa[0], pb[0]);
 #pragma unroll
     for (int sl = 1; sl < 16; ++sl) {
@@ -569,15 +563,7 @@ __global__ __launch_bounds__(WAVES * 64, 3) void k_gate_onepass(OnePassArgs P) {
     // half-size complex spectrum.  The four 1/2 factors of split and merge ride in the mask scale.
     const float ks = A.kscale * 0.25f;
     auto sel = [&](cf a0, cf a1) -> cf { return {l0 ? a0.x : a1.x, l0 ? a0.y : a1.y}; };
-    auto merge = [&](cf& xa, cf& xb, cf w, float mk, float mn) {
-      cf Yk = {xa.x * mk, xa.y * mk};
-      cf Yn = {xb.x * mn, (-xb.y) * mn};
-      cf Ep = {Yk.x + Yn.x, Yk.y - Yn.y};
-      cf D = {Yk.x - Yn.x, Yk.y + Yn.y};
-      cf Op = cmul(D, cf{w.x, -w.y});
-      xa = {Ep.x - Op.y, Ep.y + Op.x};
-      xb = {Ep.x + Op.y, Op.x - Ep.y};
-    };
+    auto merge = [&](cf& xa, cf& xb, cf w, float mk, float mn) { merge_pair(xa, xb, w, mk, mn); };
     merge(pa[0], pb[0], wlo, mval(0, ks), mval(31, ks));
     cf z0, z8;
     {
