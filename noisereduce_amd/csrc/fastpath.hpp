@@ -863,24 +863,25 @@ __global__ __launch_bounds__(WAVES * 64, 3) void k_decide_fast(DecideArgs A) {
   constexpr int NFB = 4 * WAVES, SPAN = (NFB - 1) * 256 + 1024, XPITCH = 288;
   static_assert((SPAN / 256) * XPITCH <= WAVES * WAVE_CX_H * 2, "span must fit the exchange slices");
   const int64_t tqb = A.t_begin + (int64_t)blockIdx.x * NFB;  // first frame of the workgroup
-  bool blk_in;
+  // every block stages its span (see k_apply_fast): 16-byte loads in the interior, checked loads at the edges
+  bool blk_vec;
   {
     const int64_t s0b = tqb * 256 - G.padL;
     const int64_t gb = chunk * A.view.cs - A.view.pad + s0b;
-    blk_in = A.view.dtype == 0 && tqb + NFB <= A.t_end && tqb + NFB <= G.T && s0b >= 0 &&
-             s0b + SPAN <= A.view.Lp && gb >= A.view.lo && gb + SPAN <= A.view.hi;
-    if (blk_in) {
-      const float* sp = (const float*)A.view.x + row * A.view.stride + gb;
-      float* xs = reinterpret_cast<float*>(regions);
-      if ((reinterpret_cast<uintptr_t>(sp) & 15) == 0) {
-        for (int i = tid; i < SPAN / 4; i += WAVES * 64) {
-          const float4 q = reinterpret_cast<const float4*>(sp)[i];
-          const int e = 4 * i;
-          *reinterpret_cast<float4*>(&xs[(e >> 8) * XPITCH + (e & 255)]) = q;
-        }
-      } else {
-        for (int i = tid; i < SPAN; i += WAVES * 64) xs[(i >> 8) * XPITCH + (i & 255)] = sp[i];
+    const float* sp = (const float*)A.view.x + row * A.view.stride + gb;
+    blk_vec = A.view.dtype == 0 && tqb + NFB <= A.t_end && tqb + NFB <= G.T && s0b >= 0 &&
+              s0b + SPAN <= A.view.Lp && gb >= A.view.lo && gb + SPAN <= A.view.hi &&
+              (reinterpret_cast<uintptr_t>(sp) & 15) == 0;
+    float* xs = reinterpret_cast<float*>(regions);
+    if (blk_vec) {
+      for (int i = tid; i < SPAN / 4; i += WAVES * 64) {
+        const float4 q = reinterpret_cast<const float4*>(sp)[i];
+        const int e = 4 * i;
+        *reinterpret_cast<float4*>(&xs[(e >> 8) * XPITCH + (e & 255)]) = q;
       }
+    } else {
+      for (int i = tid; i < SPAN; i += WAVES * 64)
+        xs[(i >> 8) * XPITCH + (i & 255)] = (float)view_sample(A.view, row, chunk, s0b + i);
     }
   }
   __syncthreads();
@@ -889,62 +890,32 @@ __global__ __launch_bounds__(WAVES * 64, 3) void k_decide_fast(DecideArgs A) {
     // one frame quad per wave (no loop: loop-invariant twiddle/window loads would be hoisted and
     // pin >100 VGPRs, costing the second wave per SIMD)
     const int64_t tq = tqb + wave * 4;  // first frame of the quad
-    if (!blk_in && tq >= A.t_end) return;  // wave-uniform (an interior block has no idle wave)
     const int64_t t = tq + g;
     const bool fvalid = t < A.t_end && t < G.T;
     cf v[32];
     float nrm2 = 0.f;
-    if (blk_in) {
+    {
       const float* xs = reinterpret_cast<const float*>(regions) + (4 * wave + g) * XPITCH + 2 * c;
       const float2* wl2 = reinterpret_cast<const float2*>(swin + 2 * c);
-#pragma unroll
-      for (int r = 0; r < 32; ++r) {
-        const float2 x2 = *reinterpret_cast<const float2*>(xs + (r >> 3) * XPITCH + 32 * (r & 7));
-        const float2 w2 = wl2[16 * r];
-        v[r] = {x2.x * w2.x, x2.y * w2.y};
-      }
-      __syncthreads();  // the span may now be overwritten by the exchanges
-    } else {
-      const int64_t s0 = t * 256 - G.padL;
-      const int64_t gbase = chunk * A.view.cs - A.view.pad + s0;
-      const bool inside = fvalid && s0 >= 0 && s0 + 1024 <= A.view.Lp && gbase >= A.view.lo &&
-                          gbase + 1024 <= A.view.hi && A.view.dtype == 0;
-      const float* src = (const float*)A.view.x + row * A.view.stride + gbase + 2 * c;
-      const bool aligned = (reinterpret_cast<uintptr_t>(src) & 7) == 0;
-      const float2* wsrc = reinterpret_cast<const float2*>(swin + 2 * c);
-      if (inside && aligned) {
-        const float2* s2 = reinterpret_cast<const float2*>(src);
+      if (blk_vec) {
 #pragma unroll
         for (int r = 0; r < 32; ++r) {
-          float2 x2 = s2[16 * r];
-          float2 w2 = wsrc[16 * r];
+          const float2 x2 = *reinterpret_cast<const float2*>(xs + (r >> 3) * XPITCH + 32 * (r & 7));
+          const float2 w2 = wl2[16 * r];
           v[r] = {x2.x * w2.x, x2.y * w2.y};
         }
       } else {
-        float* fl = reinterpret_cast<float*>(fb);  // half-size slice: stage the frame as two halves of 512 floats
 #pragma unroll
-        for (int hh = 0; hh < 2; ++hh) {
-#pragma unroll 1
-          for (int r = 0; r < 16; ++r) {
-            float a = 0.f, b = 0.f;
-            if (fvalid) {
-              a = (float)view_sample(A.view, row, chunk, s0 + 2 * c + 32 * (r + 16 * hh));
-              b = (float)view_sample(A.view, row, chunk, s0 + 2 * c + 32 * (r + 16 * hh) + 1);
-            }
-            fl[2 * c + 32 * r] = a;
-            fl[2 * c + 32 * r + 1] = b;
-          }
-          wave_lds_sync();
-#pragma unroll
-          for (int r = 0; r < 16; ++r) {
-            float2 w2 = wsrc[16 * (r + 16 * hh)];
-            cf x2 = fb[c + 16 * r];
-            v[r + 16 * hh] = {x2.x * w2.x, x2.y * w2.y};
-          }
-          wave_lds_sync();
+        for (int r = 0; r < 32; ++r) {
+          float2 x2 = *reinterpret_cast<const float2*>(xs + (r >> 3) * XPITCH + 32 * (r & 7));
+          if (!fvalid) x2 = make_float2(0.f, 0.f);
+          const float2 w2 = wl2[16 * r];
+          v[r] = {x2.x * w2.x, x2.y * w2.y};
         }
       }
     }
+    __syncthreads();  // the span may now be overwritten by the exchanges
+    if (tq >= A.t_end) return;  // wave-uniform; no barrier below
     {
 #pragma unroll
       for (int r = 0; r < 32; ++r) nrm2 += v[r].x * v[r].x + v[r].y * v[r].y;

@@ -174,15 +174,17 @@ __global__ __launch_bounds__(WAVES * 64, 3) void k_gate_onepass(OnePassArgs P) {
   const bool fvalid = t >= 0 && t < G.T;
   cf* fb = regions + wave * WAVE_CX_H + frame_base_h(g);
 
-  // ---- stage the tile's contiguous sample span (interior tiles of float32 input) -----------------
+  // ---- stage the tile's contiguous sample span: interior tiles of float32 input with 16-byte loads, the others
+  // (unit edges, halo tiles) sample by sample through view_sample -- zero outside the readable range ------------
   constexpr int SPAN = (NF - 1) * 256 + 1024, XPITCH = 288;
   static_assert((SPAN / 256) * XPITCH <= WAVES * WAVE_CX_H * 2, "span must fit the exchange slices");
-  bool blk_in;
+  bool blk_vec;
   {
     const int64_t s0b = tf_tile * 256 - G.padL;
     const int64_t gb = chunk * A.view.cs - A.view.pad + s0b;
-    blk_in = A.view.dtype == 0 && tf_tile >= 0 && tf_tile + NF <= G.T && s0b >= 0 && s0b + SPAN <= A.view.Lp &&
-             gb >= A.view.lo && gb + SPAN <= A.view.hi;
+    const float* sp = (const float*)A.view.x + row * A.view.stride + gb;
+    blk_vec = A.view.dtype == 0 && tf_tile >= 0 && tf_tile + NF <= G.T && s0b >= 0 && s0b + SPAN <= A.view.Lp &&
+              gb >= A.view.lo && gb + SPAN <= A.view.hi && (reinterpret_cast<uintptr_t>(sp) & 15) == 0;
     auto fill_t2 = [&]() {
 #pragma unroll
       for (int k = 0; k < 3; ++k) {
@@ -193,9 +195,8 @@ __global__ __launch_bounds__(WAVES * 64, 3) void k_gate_onepass(OnePassArgs P) {
         s_t2d[i] = v;   // the rare exact re-evaluation compares against this (no log10 in the hot kernel body)
       }
     };
-    const float* sp = (const float*)A.view.x + row * A.view.stride + gb;
     float* xs = reinterpret_cast<float*>(regions);
-    if (blk_in && (reinterpret_cast<uintptr_t>(sp) & 15) == 0) {
+    if (blk_vec) {
       // span loads in flight while the compare constants are built
       constexpr int NQ = (SPAN / 4 + WAVES * 64 - 1) / (WAVES * 64);
       float4 q[NQ];
@@ -212,8 +213,8 @@ __global__ __launch_bounds__(WAVES * 64, 3) void k_gate_onepass(OnePassArgs P) {
       }
     } else {
       fill_t2();
-      if (blk_in)
-        for (int i = tid; i < SPAN; i += WAVES * 64) xs[(i >> 8) * XPITCH + (i & 255)] = sp[i];
+      for (int i = tid; i < SPAN; i += WAVES * 64)
+        xs[(i >> 8) * XPITCH + (i & 255)] = (float)view_sample(A.view, row, chunk, s0b + i);
     }
   }
   __syncthreads();  // tables, compare constants and span staged
@@ -221,53 +222,23 @@ __global__ __launch_bounds__(WAVES * 64, 3) void k_gate_onepass(OnePassArgs P) {
   // ---- gather: v[r] = (x[2c + 32r], x[2c + 32r + 1]) * window ---------------------------------------
   cf v[32];
   float nrm2 = 0.f;
-  if (blk_in) {
+  {
     const float* xs = reinterpret_cast<const float*>(regions) + (4 * wave + g) * XPITCH + 2 * c;
     const float2* wl = reinterpret_cast<const float2*>(swin + 2 * c);
-#pragma unroll
-    for (int r = 0; r < 32; ++r) {
-      const float2 x2 = *reinterpret_cast<const float2*>(xs + (r >> 3) * XPITCH + 32 * (r & 7));
-      const float2 w2 = wl[16 * r];
-      v[r] = {x2.x * w2.x, x2.y * w2.y};
-    }
-  } else {
-    const int64_t s0 = t * 256 - G.padL;
-    const int64_t gbase = chunk * A.view.cs - A.view.pad + s0;
-    const bool inside = fvalid && s0 >= 0 && s0 + 1024 <= A.view.Lp && gbase >= A.view.lo &&
-                        gbase + 1024 <= A.view.hi && A.view.dtype == 0;
-    const float* src = (const float*)A.view.x + row * A.view.stride + gbase + 2 * c;
-    const bool aligned = (reinterpret_cast<uintptr_t>(src) & 7) == 0;
-    const float2* wsrc = reinterpret_cast<const float2*>(swin + 2 * c);
-    if (inside && aligned) {
-      const float2* s2 = reinterpret_cast<const float2*>(src);
+    if (blk_vec) {
 #pragma unroll
       for (int r = 0; r < 32; ++r) {
-        float2 x2 = s2[16 * r];
-        float2 w2 = wsrc[16 * r];
+        const float2 x2 = *reinterpret_cast<const float2*>(xs + (r >> 3) * XPITCH + 32 * (r & 7));
+        const float2 w2 = wl[16 * r];
         v[r] = {x2.x * w2.x, x2.y * w2.y};
       }
     } else {
-      float* fl = reinterpret_cast<float*>(fb);  // half-size slice: the frame is staged as two halves
 #pragma unroll
-      for (int hh = 0; hh < 2; ++hh) {
-#pragma unroll 1
-        for (int r = 0; r < 16; ++r) {
-          float a = 0.f, b = 0.f;
-          if (fvalid) {
-            a = (float)view_sample(A.view, row, chunk, s0 + 2 * c + 32 * (r + 16 * hh));
-            b = (float)view_sample(A.view, row, chunk, s0 + 2 * c + 32 * (r + 16 * hh) + 1);
-          }
-          fl[2 * c + 32 * r] = a;
-          fl[2 * c + 32 * r + 1] = b;
-        }
-        wave_lds_sync();
-#pragma unroll
-        for (int r = 0; r < 16; ++r) {
-          float2 w2 = wsrc[16 * (r + 16 * hh)];
-          cf x2 = fb[c + 16 * r];
-          v[r + 16 * hh] = {x2.x * w2.x, x2.y * w2.y};
-        }
-        wave_lds_sync();
+      for (int r = 0; r < 32; ++r) {
+        float2 x2 = *reinterpret_cast<const float2*>(xs + (r >> 3) * XPITCH + 32 * (r & 7));
+        if (!fvalid) x2 = make_float2(0.f, 0.f);   // frames before / past the unit: zeros
+        const float2 w2 = wl[16 * r];
+        v[r] = {x2.x * w2.x, x2.y * w2.y};
       }
     }
   }
