@@ -23,8 +23,19 @@ struct ThreshConsts {
   const double* T2;        // [F]  compare constant on the RAW power |X|^2 (see k_prep_thresh)
   const double* thresh;    // [F]  dB threshold (for the floor test)
   const double* pmax;      // [units][FS] per-(unit, band) max raw power, 0 where not computed
-  const int* need_floor;   // [units] 1: this unit's -top_db floor may be live -> pmax is valid
+  const int* need_floor;   // [units] 1: this unit's -top_db floor may be live -> pmax is valid;
+                           //         2: the unit holds a non-finite sample -> no cell of it passes (T2_NEVER)
 };
+
+// Compare constant meaning "no cell passes".  A band with a NaN threshold (NaN in the noise clip: stationary.py:75-81
+// give mean(NaN) = NaN, and `dB > NaN` is False) and every band of a unit with a non-finite sample (np.max over a
+// band that holds a NaN is NaN: _amp_to_db makes the whole band NaN, stationary.py:96-106) gate everything.
+constexpr double T2_NEVER = 1e300;
+// float32 copy of a (4x) compare constant for the float32 decision kernels: -1 ("all pass") and T2_NEVER map to
+// huge finite values of either sign -- P - T overflows when squared, so the ambiguity test fails by itself
+__device__ __forceinline__ float t2_to_f32(double v, double scale) {
+  return v < 0.0 ? -3.0e38f : (v > 1e37 ? 3.0e38f : (float)(scale * v));
+}
 
 namespace fast {
 
@@ -833,7 +844,8 @@ __global__ __launch_bounds__(WAVES * 64, 3) void k_decide_fast(DecideArgs A) {
   const int64_t u = blockIdx.y;
   const int64_t row = (A.view.unit0 + u) / A.view.n_chunks;
   const int64_t chunk = A.view.c0 + (A.view.unit0 + u) % A.view.n_chunks;
-  const bool floor_live = A.tc.need_floor[u] != 0;
+  const int need = A.tc.need_floor[u];
+  const bool floor_live = need == 1;
 
   // effective compare constants (4x the raw-power constant: the split below works on 2X) as
   // float32 in LDS, permuted like the mask rows: entry c*32 + e = bin_of_entry(c, e), entry 512 = bin 512
@@ -844,13 +856,14 @@ __global__ __launch_bounds__(WAVES * 64, 3) void k_decide_fast(DecideArgs A) {
       double fl = cell_db(A.tc.pmax[u * G.FS + f], A.mag_scale) - A.top_db;
       if (fl > A.tc.thresh[f]) v = -1.0;
     }
+    if (need == 2) v = T2_NEVER;
     return v;
   };
   for (int i = tid; i <= 512; i += WAVES * 64) {
     double v = t2eff(perm_inv(i));
     // "every cell passes" as a huge negative constant: P - T > 0, and (P - T)^2 overflows to +inf while
     // d2 * (P + T) is negative, so the ambiguity test fails without an extra T >= 0 term
-    s_t2[i] = v < 0.0 ? -3.0e38f : (float)(4.0 * v);
+    s_t2[i] = t2_to_f32(v, 4.0);
   }
   cf* fb = regions + wave * WAVE_CX_H + frame_base_h(g);
   const cf wl0 = A.tw1024[c];  // w_1024^c (lane 0: 1)

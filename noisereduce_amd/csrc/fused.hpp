@@ -23,7 +23,10 @@ __global__ void k_unit_absmax(View view, int64_t n_units, unsigned* __restrict__
   const int64_t u = blockIdx.y;
   const int64_t row = (view.unit0 + u) / view.n_chunks;
   const int64_t chunk = view.c0 + (view.unit0 + u) % view.n_chunks;
-  float m = 0.f;
+  // max |x| on the BIT PATTERNS (sign cleared): non-negative floats order like unsigned integers, and NaN / Inf
+  // patterns are larger than every finite one -- a non-finite sample survives the reduction (fmaxf drops NaN)
+  unsigned mi = 0u;
+  auto ab = [](float x) -> unsigned { return __float_as_uint(x) & 0x7fffffffu; };
   // the unit's window clipped to the readable part of the row (everything else is zero)
   const int64_t g0 = chunk * view.cs - view.pad;
   const int64_t s_lo = max<int64_t>(0, view.lo - g0), s_hi = min<int64_t>(view.Lp, view.hi - g0);
@@ -36,27 +39,27 @@ __global__ void k_unit_absmax(View view, int64_t n_units, unsigned* __restrict__
 #pragma unroll 4
     for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n4; i += (int64_t)gridDim.x * blockDim.x) {
       float4 v4 = s4[i];
-      m = fmaxf(fmaxf(m, fmaxf(fabsf(v4.x), fabsf(v4.y))), fmaxf(fabsf(v4.z), fabsf(v4.w)));
+      mi = max(max(mi, max(ab(v4.x), ab(v4.y))), max(ab(v4.z), ab(v4.w)));
     }
     if (blockIdx.x == 0) {
-      for (int64_t s = s_lo + threadIdx.x; s < min(a_lo, s_hi); s += blockDim.x) m = fmaxf(m, fabsf(src[s]));
-      for (int64_t s = a_lo + 4 * n4 + threadIdx.x; s < s_hi; s += blockDim.x) m = fmaxf(m, fabsf(src[s]));
+      for (int64_t s = s_lo + threadIdx.x; s < min(a_lo, s_hi); s += blockDim.x) mi = max(mi, ab(src[s]));
+      for (int64_t s = a_lo + 4 * n4 + threadIdx.x; s < s_hi; s += blockDim.x) mi = max(mi, ab(src[s]));
     }
   } else {
     for (int64_t s = s_lo + (int64_t)blockIdx.x * blockDim.x + threadIdx.x; s < s_hi;
          s += (int64_t)gridDim.x * blockDim.x)
-      m = fmaxf(m, fabsf((float)view_sample(view, row, chunk, s)));
+      mi = max(mi, ab((float)view_sample(view, row, chunk, s)));
   }
   // float(double) rounds to nearest: inflate by one ulp so the bound stays an upper bound
-  m = m * 1.0000002f;
-  for (int off = 32; off > 0; off >>= 1) m = fmaxf(m, __shfl_xor(m, off));
+  if (mi < 0x7f800000u) mi = __float_as_uint(__uint_as_float(mi) * 1.0000002f);
+  for (int off = 32; off > 0; off >>= 1) mi = max(mi, (unsigned)__shfl_xor((int)mi, off));
   // one atomic per block: same-address L2 atomics serialise
-  __shared__ float s_m[16];
-  if ((threadIdx.x & 63) == 0) s_m[threadIdx.x >> 6] = m;
+  __shared__ unsigned s_m[16];
+  if ((threadIdx.x & 63) == 0) s_m[threadIdx.x >> 6] = mi;
   __syncthreads();
   if (threadIdx.x == 0) {
-    for (int w = 1; w < (int)(blockDim.x >> 6); ++w) m = fmaxf(m, s_m[w]);
-    atomicMax(&umax_bits[u], __float_as_uint(m));
+    for (int w = 1; w < (int)(blockDim.x >> 6); ++w) mi = max(mi, s_m[w]);
+    atomicMax(&umax_bits[u], mi);
   }
 }
 
@@ -83,7 +86,9 @@ __global__ void k_prep_thresh(const double* __restrict__ thresh, int F, double m
     if (blockIdx.x == 0) {
       double zero_db = 20.0 * log10(eps);
       double t2;
-      if (zero_db > th) {
+      if (th != th) {
+        t2 = T2_NEVER;   // NaN threshold: `dB > NaN` is False for every cell of the band
+      } else if (zero_db > th) {
         t2 = -1.0;
       } else {
         double tm = (exp10(th / 20.0) - eps) / mag_scale;
@@ -101,10 +106,12 @@ __global__ void k_prep_thresh(const double* __restrict__ thresh, int F, double m
   const double min_thresh = s_min[0];
   for (int64_t u = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; u < n_units;
        u += (int64_t)gridDim.x * blockDim.x) {
-    double ub = (double)__uint_as_float(umax_bits[u]) * sum_abs_w * mag_scale;
+    const unsigned mbits = umax_bits[u];
+    double ub = (double)__uint_as_float(mbits) * sum_abs_w * mag_scale;
     umax_bits[u] = 0u;
     double ub_db = 20.0 * log10(ub + eps) + 1e-6;  // margin covers log10/rounding slack
-    const int need = (ub_db - top_db > min_thresh) ? 1 : 0;
+    // 2: a NaN / Inf sample in the unit -- every band's maximum is NaN, no cell passes (T2_NEVER)
+    const int need = mbits >= 0x7f800000u ? 2 : ((ub_db - top_db > min_thresh) ? 1 : 0);
     need_floor[u] = need;
     if (need)
       for (int f = 0; f < FS; ++f) pmax[u * (int64_t)FS + f] = 0.0;
@@ -130,7 +137,8 @@ __global__ __launch_bounds__(WAVES * 64) void k_stft_bits(View view, Geom g, con
   const int wave = threadIdx.x >> 6;
   cx<double>* buf = bufs + wave * lpn<double>(N);
   const int64_t u = blockIdx.y;
-  const bool floor_live = tc.need_floor[u] != 0;
+  const int need = tc.need_floor[u];
+  const bool floor_live = need == 1;
   if (MODE == 0 && !floor_live) return;  // whole block: uniform
   for (int i = threadIdx.x; i < N; i += WAVES * 64) tw[i] = tw_g[i];
   if (MODE == 1) {
@@ -141,6 +149,7 @@ __global__ __launch_bounds__(WAVES * 64) void k_stft_bits(View view, Geom g, con
         double fl = cell_db(tc.pmax[u * g.FS + i], mag_scale) - top_db;
         if (fl > tc.thresh[i]) t2 = -1.0;
       }
+      if (need == 2) t2 = T2_NEVER;
       sT2[i] = t2;
     }
   }
@@ -219,20 +228,22 @@ __global__ __launch_bounds__(WAVES * 64) void k_decide_lds(View view, Geom g, co
   const int wave = threadIdx.x >> 6;
   cx<float>* buf = bufs + wave * N;
   const int64_t u = blockIdx.y;
-  const bool floor_live = tc.need_floor[u] != 0;
+  const int need = tc.need_floor[u];
+  const bool floor_live = need == 1;
   auto t2eff = [&](int k) -> double {  // exact compare constant of band k (-1: every cell passes)
     double t2 = tc.T2[k];
     if (floor_live) {
       const double fl = cell_db(tc.pmax[u * g.FS + k], mag_scale) - top_db;
       if (fl > tc.thresh[k]) t2 = -1.0;
     }
+    if (need == 2) t2 = T2_NEVER;
     return t2;
   };
   for (int i = threadIdx.x; i < N; i += WAVES * 64) tw[i] = tw_g[i];
   for (int i = threadIdx.x; i <= N; i += WAVES * 64) {
     const double t2 = t2eff(i);
     // "every cell passes" as a huge negative constant: P - T > 0 and the ambiguity test fails by itself
-    sT2[i] = t2 < 0.0 ? -3.0e38f : (float)t2;
+    sT2[i] = t2_to_f32(t2, 1.0);
   }
   const int64_t row = (view.unit0 + u) / view.n_chunks;
   const int64_t chunk = view.c0 + (view.unit0 + u) % view.n_chunks;

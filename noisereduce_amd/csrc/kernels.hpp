@@ -383,7 +383,7 @@ __global__ __launch_bounds__(64 * STAT_TG) void k_colstats(const double* __restr
     const double mdb = cell_db(pmax[u * g.FS + f], mag_scale);
     for (int64_t t = tb + tg; t < te; t += STAT_TG) {
       double d = cell_db(P[(u * g.T + t) * g.FS + f], mag_scale) - mdb;  // <= 0
-      d = fmax(d, -top_db);
+      d = (d != d) ? d : fmax(d, -top_db);   // (fmax would drop a NaN; numpy / torch keep it)
       s1 += d;
       s2 += d * d;
     }
@@ -548,7 +548,7 @@ __global__ __launch_bounds__(64 * STAT_TG) void k_colstats1_final(const double* 
     double a1 = 0.0, a2 = 0.0;
     for (int64_t t = l; t < g.T; t += 64) {
       double d = cell_db(P[(u * g.T + t) * g.FS + fb], mag_scale) - mb;
-      d = fmax(d, -top_db);
+      d = (d != d) ? d : fmax(d, -top_db);   // (fmax would drop a NaN; numpy / torch keep it)
       a1 += d;
       a2 += d * d;
     }
@@ -601,7 +601,8 @@ __global__ void k_decide(const double* __restrict__ P, Geom g, const double* __r
     double db = cell_db(P[i], mag_scale);
     double fl = cell_db(pmax[u * g.FS + f], mag_scale) - top_db;
     db = fmax(db, fl);
-    raw[i] = db > thresh[u * thresh_ustride + f] ? 1.0f : 0.0f;
+    // (np.maximum(x, NaN) is NaN: a band whose maximum is NaN passes nowhere)
+    raw[i] = (fl == fl && db > thresh[u * thresh_ustride + f]) ? 1.0f : 0.0f;
   }
 }
 
@@ -619,7 +620,9 @@ __global__ void k_t2_rows(const double* __restrict__ thresh, int64_t thresh_ustr
     if (f < g.F) {
       const double th = thresh[u * thresh_ustride + f];
       const double fl = cell_db(pmax[i], mag_scale) - top_db;
-      if (fl > th || 20.0 * log10(eps) > th) {
+      if (th != th || fl != fl) {
+        t2 = 1e300;   // NaN threshold or NaN in the band (its maximum is NaN): no cell passes (T2_NEVER)
+      } else if (fl > th || 20.0 * log10(eps) > th) {
         t2 = -1.0;
       } else {
         const double tm = (exp10(th / 20.0) - eps) / mag_scale;
@@ -663,12 +666,15 @@ __global__ __launch_bounds__(64 * STAT_TG) void k_row_decide(const double* __res
     for (int q = 0; q < 16; ++q) {
       const int64_t t = t0 + q * STAT_TG;
       if (t < g.T) tile[t * 64 + l] = pv[q];
-      m = fmax(m, pv[q]);
+      m = (m != m || pv[q] != pv[q]) ? NAN : fmax(m, pv[q]);   // NaN-sticky like torch.max: the band is NaN then
     }
   }
   r1[tg][l] = m;
   __syncthreads();
-  for (int i = 0; i < STAT_TG; ++i) m = fmax(m, r1[i][l]);
+  for (int i = 0; i < STAT_TG; ++i) {
+    const double mm = r1[i][l];
+    m = (m != m || mm != mm) ? NAN : fmax(m, mm);
+  }
   const double mdb = cell_db(m, mag_scale);
   double th;
   if (thresh_in == nullptr) {
@@ -676,7 +682,7 @@ __global__ __launch_bounds__(64 * STAT_TG) void k_row_decide(const double* __res
     double s1 = 0.0, s2 = 0.0;
     for (int64_t t = tg; t < g.T; t += STAT_TG) {
       double d = cell_db(tile[t * 64 + l], mag_scale) - mdb;  // <= 0
-      d = fmax(d, -top_db);
+      d = (d != d) ? d : fmax(d, -top_db);   // (fmax would drop a NaN; numpy / torch keep it)
       s1 += d;
       s2 += d * d;
     }
@@ -701,7 +707,9 @@ __global__ __launch_bounds__(64 * STAT_TG) void k_row_decide(const double* __res
   double t2 = 0.0;
   if (on) {
     const double fl = mdb - top_db;
-    if (fl > th || 20.0 * log10(eps) > th) {
+    if (th != th || fl != fl) {
+      t2 = 1e300;   // NaN threshold / NaN in the band: no cell passes (T2_NEVER)
+    } else if (fl > th || 20.0 * log10(eps) > th) {
       t2 = -1.0;
     } else {
       const double tm = (exp10(th / 20.0) - eps) / mag_scale;

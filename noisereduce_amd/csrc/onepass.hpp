@@ -158,7 +158,8 @@ __global__ __launch_bounds__(WAVES * 64, 3) void k_gate_onepass(OnePassArgs P) {
   const unsigned gu = (unsigned)(A.view.unit0 + u), nch = (unsigned)A.view.n_chunks;
   const int64_t row = gu / nch;
   const int64_t chunk = A.view.c0 + gu % nch;
-  const bool floor_live = P.tc.need_floor[u] != 0;
+  const int need = P.tc.need_floor[u];
+  const bool floor_live = need == 1;
 
   // compare constants (x4: the split works on 2X), permuted like the lanes' entries -- see k_decide_fast
   auto t2eff = [&](int f, double v) -> double {
@@ -166,6 +167,7 @@ __global__ __launch_bounds__(WAVES * 64, 3) void k_gate_onepass(OnePassArgs P) {
       double fl = cell_db(P.tc.pmax[u * G.FS + f], P.mag_scale) - P.top_db;
       if (fl > P.tc.thresh[f]) v = -1.0;
     }
+    if (need == 2) v = T2_NEVER;   // non-finite sample in the unit
     return v;
   };
   const int64_t tf_tile = A.h_begin - 3 + (int64_t)jt * NF;  // first frame of the tile (abutting tiles)
@@ -191,7 +193,7 @@ __global__ __launch_bounds__(WAVES * 64, 3) void k_gate_onepass(OnePassArgs P) {
         const int i = tid + k * WAVES * 64;
         if (i > 512) break;
         const double v = t2eff(perm_inv(i), t2pre[k]);
-        s_t2[i] = v < 0.0 ? -3.0e38f : (float)(4.0 * v);
+        s_t2[i] = t2_to_f32(v, 4.0);
         s_t2d[i] = v;   // the rare exact re-evaluation compares against this (no log10 in the hot kernel body)
       }
     };

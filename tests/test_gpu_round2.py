@@ -374,3 +374,49 @@ def test_float64_power_kernel_matches_the_lds_transform(B, L, xn):
                          xn=None if noise is None else noise[rows].cpu().numpy().astype(np.float64),
                          window=torch.hann_window(1024).double().numpy())
     assert O.rel_err(y_fast[rows].cpu().numpy(), want) < TOL
+
+
+def _nonfinite_agree(got, want, tol=TOL):
+    gn, wn = ~np.isfinite(got), ~np.isfinite(want)
+    assert np.array_equal(gn, wn), "non-finite samples in different places: engine %d, oracle %d" % (gn.sum(), wn.sum())
+    both = ~gn
+    if both.any():
+        assert np.abs(got[both] - want[both]).max() <= tol * max(1e-3, np.abs(want[both]).max())
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("case", ["signal", "signal_chunks", "noise_clip", "nonstationary", "torchgate_row"])
+def test_nan_sample_gates_like_the_reference(nr, case):
+    """A NaN sample: numpy / torch maxima and means keep it (stationary.py:75-81, 96-106; torchgate.py:140-160), so the
+    whole band -- in practice every band of the chunk / row that sees the sample -- compares False, and the NaN
+    itself survives the multiplication by a zero mask.  The engine's reductions use fmax (which drops a NaN):
+    non-finite samples are tracked explicitly (bit-pattern maximum in k_unit_absmax, NaN-sticky row maxima,
+    T2_NEVER compare constants).  Same non-finite output samples, same finite rest."""
+    rng = np.random.default_rng(7)
+    n = 48000 * 2
+    y = (0.1 * rng.standard_normal(n)).astype(np.float32)
+    with np.errstate(all="ignore"):
+        if case == "torchgate_row":
+            from noisereduce_amd.torchgate import TorchGate
+            x = (0.1 * rng.standard_normal((6, 16000))).astype(np.float32)
+            x[2, 9000] = np.nan
+            got = TorchGate(sr=16000, nonstationary=False).cuda()(torch.from_numpy(x).cuda()).cpu().numpy()
+            want = O.torchgate_T(x.astype(np.float64), 16000, nonstationary=False,
+                                 window=torch.hann_window(1024).double().numpy())
+            assert np.isnan(got[2]).any() and np.isfinite(got[[0, 1, 3, 4, 5]]).all()
+        elif case == "noise_clip":
+            yn = (0.1 * rng.standard_normal(30000)).astype(np.float32)
+            yn[4000] = np.nan
+            got = nr.reduce_noise(y=y, sr=48000, y_noise=yn, stationary=True, n_fft=1024)
+            want = O.reduce_noise_S(y.astype(np.float64), 48000, y_noise=yn.astype(np.float64), stationary=True, n_fft=1024)
+            assert np.isfinite(got).all() and np.abs(got).max() == 0.0   # NaN thresholds: everything is gated
+        else:
+            y[50000] = np.nan
+            kw = dict(sr=48000, stationary=case != "nonstationary", n_fft=1024)
+            if case == "signal_chunks":
+                kw.update(chunk_size=20000, padding=2000)
+            got = nr.reduce_noise(y=y, **kw)
+            want = O.reduce_noise_S(y.astype(np.float64), **kw)
+            if case == "signal_chunks":   # only the chunks that see the sample are gated
+                assert np.abs(got[:20000]).max() > 0 and np.isfinite(got[:20000]).all()
+    _nonfinite_agree(got, want)
