@@ -73,7 +73,7 @@ __global__ __launch_bounds__(NT* FR) void k_stft_czt(View view, Geom g, CztTabs<
         // rfft of a real frame: bins 0 and n/2 are real (pocketfft returns exactly 0 there)
         if (k == 0 || 2 * k == g.n) X.y = (TC)0;
         const double Pk = (double)X.x * (double)X.x + (double)X.y * (double)X.y;
-        vmax[m] = fmax(vmax[m], Pk);
+        vmax[m] = nanmax(vmax[m], Pk);
         if (P_out) P_out[rowoff + k] = Pk;
         if (mag_out) mag_out[rowoff + k] = sqrtf((float)(X.x * X.x + X.y * X.y));
         if (z_out) {

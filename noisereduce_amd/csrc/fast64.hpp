@@ -211,8 +211,8 @@ __global__ __launch_bounds__(WAVES * 64, 2) void k_power_fast64(Pow64Args A) {
     if constexpr (PMAX) {
       // maximum over the wave's four frames first (lanes c, c + 16, c + 32, c + 48), one atomic per bin
       double m = fvalid ? Pv : 0.0;
-      m = fmax(m, __shfl_xor(m, 16));
-      m = fmax(m, __shfl_xor(m, 32));
+      m = nanmax(m, __shfl_xor(m, 16));
+      m = nanmax(m, __shfl_xor(m, 32));
       if (g == 0) atomicMax(&mrow[bin], (unsigned long long)__double_as_longlong(m));
     }
   };

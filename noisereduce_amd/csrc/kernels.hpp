@@ -54,6 +54,11 @@ __device__ __forceinline__ double view_sample(const View& v, int64_t row, int64_
   return load_sample(v.x, v.dtype, row * v.stride + g);
 }
 
+// Maximum that KEEPS a NaN (numpy / torch maxima do; fmax drops it): a band that holds a NaN has a NaN maximum, and
+// the reference's `max(dB, rowmax - top_db) > thresh` is then False for the whole band.  The canonical positive NaN also
+// wins the bit-pattern atomicMax of the per-band maxima.
+__device__ __forceinline__ double nanmax(double a, double b) { return (a != a || b != b) ? (double)NAN : fmax(a, b); }
+
 // Start of the `len` samples [s0, s0 + len) of a unit window when they are all readable float32
 // samples (no zero padding, no conversion), else nullptr: frames take the direct-load path in the
 // interior and the checked per-sample path (view_sample) at the edges / for other dtypes.
@@ -146,7 +151,7 @@ __global__ __launch_bounds__(WAVES * NT) void k_stft(View view, Geom g, const cx
         cx<TC> w = tw[k == N ? 0 : k];
         cx<TC> X = rfft_bin(a, b, w, k, N);
         const double Pk = (double)X.x * (double)X.x + (double)X.y * (double)X.y;
-        vmax[m] = fmax(vmax[m], Pk);
+        vmax[m] = nanmax(vmax[m], Pk);
         if (P_out) P_out[rowoff + k] = Pk;
         if (mag_out) mag_out[rowoff + k] = sqrtf((float)(X.x * X.x + X.y * X.y));
         if (z_out) {
@@ -342,11 +347,11 @@ __global__ __launch_bounds__(64 * STAT_TG) void k_colmax(const double* __restric
   const int64_t tb = g.T * ts / nts, te = g.T * (ts + 1) / nts;
   double m = 0.0;
   if (f < g.F)
-    for (int64_t t = tb + tg; t < te; t += STAT_TG) m = fmax(m, P[(u * g.T + t) * g.FS + f]);
+    for (int64_t t = tb + tg; t < te; t += STAT_TG) m = nanmax(m, P[(u * g.T + t) * g.FS + f]);
   red[tg][threadIdx.x & 63] = m;
   __syncthreads();
   if (tg == 0 && f < g.F) {
-    for (int i = 1; i < STAT_TG; ++i) m = fmax(m, red[i][threadIdx.x & 63]);
+    for (int i = 1; i < STAT_TG; ++i) m = nanmax(m, red[i][threadIdx.x & 63]);
     pmax_part[(u * nts + ts) * g.FS + f] = m;
   }
 }
@@ -361,7 +366,7 @@ __global__ void k_colmax_final(const double* __restrict__ pmax_part, Geom g, int
     double m = 0.0;
     if (f < g.F) {
 #pragma unroll 8
-      for (int ts = 0; ts < nts; ++ts) m = fmax(m, pmax_part[(u * nts + ts) * g.FS + f]);
+      for (int ts = 0; ts < nts; ++ts) m = nanmax(m, pmax_part[(u * nts + ts) * g.FS + f]);
     }
     pmax[i] = m;
   }

@@ -420,3 +420,22 @@ def test_nan_sample_gates_like_the_reference(nr, case):
             if case == "signal_chunks":   # only the chunks that see the sample are gated
                 assert np.abs(got[:20000]).max() > 0 and np.isfinite(got[:20000]).all()
     _nonfinite_agree(got, want)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("n_fft,smooth", [(512, True), (2048, True), (1000, True), (4096, True), (4096, False)])
+def test_nan_sample_other_frame_lengths(nr, n_fft, smooth):
+    """The same NaN rule on the kernels of the other frame lengths (float32 LDS decision, chirp-z transform, the
+    unfused power-field path with per-band maxima)."""
+    rng = np.random.default_rng(3)
+    n = 48000 * 2
+    y = (0.1 * rng.standard_normal(n)).astype(np.float32)
+    y[50000] = np.nan
+    kw = dict(sr=48000, stationary=True, n_fft=n_fft, chunk_size=20000, padding=2000)
+    if not smooth:
+        kw.update(freq_mask_smooth_hz=None, time_mask_smooth_ms=None)
+    got = nr.reduce_noise(y=y, **kw)
+    with np.errstate(all="ignore"):
+        want = O.reduce_noise_S(y.astype(np.float64), **kw)
+    assert np.abs(got[:20000]).max() > 0
+    _nonfinite_agree(got, want)
