@@ -530,9 +530,15 @@ __global__ __launch_bounds__(WAVES * 64, LEAN ? 3 : 2) void k_apply_fast(ApplyAr
     }
   }
   if constexpr (!LEAN) __syncthreads();  // twiddle table staged
+  // (LEAN) a wave whose four frames all lie outside the row holds zeros: its transforms, masks and merge are skipped
+  // (zeros in, zeros out), only the overlap-add below runs.  Short rows end with such waves: a TorchGate row of 63
+  // frames fills 5 tiles of 16.
+  const bool wave_live = !LEAN || (tf_tile + 4 * wave + 3 >= 0 && tf_tile + 4 * wave < G.T);
   if constexpr (LEAN) {
-    if constexpr ((SG_ABLATE & 8) == 0) fft512_fwd_half(v, fb, tw512, c);
-    load_mask();
+    if (wave_live) {
+      if constexpr ((SG_ABLATE & 8) == 0) fft512_fwd_half(v, fb, tw512, c);
+      load_mask();
+    }
   } else {
     fft512_fwd(v, fb, tw512, c);
   }
@@ -551,7 +557,7 @@ __global__ __launch_bounds__(WAVES * 64, LEAN ? 3 : 2) void k_apply_fast(ApplyAr
   // split -> mask -> merge on conjugate pairs, all in this lane.  One instruction stream for all
   // lanes: lane 0 (self-paired rows 0 and 16) only differs in WHICH registers form a pair, handled
   // with v_cndmask selects on the way in and out (a divergent branch would run the stage twice).
-  if constexpr ((SG_ABLATE & 32) == 0) {
+  if (((SG_ABLATE & 32) == 0) && wave_live) {
     const float ks = A.kscale * 0.25f;  // pair_mask leaves out four 1/2 factors
     const bool l0 = c == 0;
     const cf wlo = A.tw1024[c];                         // w_1024^c   (lane 0: 1)
@@ -610,7 +616,7 @@ __global__ __launch_bounds__(WAVES * 64, LEAN ? 3 : 2) void k_apply_fast(ApplyAr
     for (int i = 0; i < 32; ++i) v[i] = nv[i];
   }
   if constexpr (LEAN) {
-    if constexpr ((SG_ABLATE & 8) == 0) fft512_inv_half(v, fb, tw512, c);
+    if (((SG_ABLATE & 8) == 0) && wave_live) fft512_inv_half(v, fb, tw512, c);
 #pragma unroll
     for (int r = 0; r < 32; ++r) wsyn[r] = (SG_ABLATE & 2) ? make_float2(0.5f, 0.25f + r) : wsrc2[16 * r];
     // wave-private overlap-add of this wave's 4 frames into 7 hop accumulators (7 KB, reusing the
