@@ -1180,7 +1180,7 @@ static int stage_fused_mask(sg_handle* h, const View& v, const Geom& g, int64_t 
     D.quads_per_wave = 1;
     const int64_t quads = (D.t_end - D.t_begin + 3) / 4;
     const int64_t per_block = (int64_t)WAVES * D.quads_per_wave;
-    size_t lds = (size_t)(fast::FN + WAVES * fast::WAVE_CX_H) * sizeof(fast::cf) + (528 + 1024) * sizeof(float);
+    size_t lds = (size_t)(fast::FN + WAVES * fast::WAVE_CX_H) * sizeof(fast::cf) + (T2_FLOATS + 1024) * sizeof(float);
     auto kern = fast::k_decide_fast<WAVES>;
     HIPCHK(h, hipFuncSetAttribute(reinterpret_cast<const void*>(kern),
                                   hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
@@ -1347,7 +1347,7 @@ static int stage_onepass(sg_handle* h, const View& v, const View& vx, const Geom
   P.exp8 = (const unsigned long long*)h->xexp.p;
   {
     ProfScope ps(h, SG_STAGE_ONEPASS, st);
-    const size_t lds = (size_t)(fast::FN + WAVES * fast::WAVE_CX_H) * sizeof(fast::cf) + (1024 + 528) * sizeof(float) +
+    const size_t lds = (size_t)(fast::FN + WAVES * fast::WAVE_CX_H) * sizeof(fast::cf) + (1024 + T2_FLOATS) * sizeof(float) +
                        256 * 8 + 514 * 8 + 16 + (prop ? 528 : 0);
     auto go = [&](auto kern) -> hipError_t {
       hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize,

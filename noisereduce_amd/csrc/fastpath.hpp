@@ -31,6 +31,11 @@ struct ThreshConsts {
 // give mean(NaN) = NaN, and `dB > NaN` is False) and every band of a unit with a non-finite sample (np.max over a
 // band that holds a NaN is NaN: _amp_to_db makes the whole band NaN, stationary.py:96-106) gate everything.
 constexpr double T2_NEVER = 1e300;
+// LDS layout of the float32 compare constants of the decision stages: lane c's 32 entries start at c * 36 floats (a
+// pitch of 32 puts the lanes of equal parity on the same banks: every read was an 8-way conflict -- 45 % of the LDS
+// cycles of k_gate_onepass); 36 keeps 16-byte alignment and spreads the 16 lanes over all 64 banks.
+constexpr int T2_PITCH = 36, T2_POS512 = 16 * T2_PITCH, T2_FLOATS = 592;
+__host__ __device__ constexpr int t2_pos(int i) { return i >= 512 ? T2_POS512 : (i >> 5) * T2_PITCH + (i & 31); }
 // float32 copy of a (4x) compare constant for the float32 decision kernels: -1 ("all pass") and T2_NEVER map to
 // huge finite values of either sign -- P - T overflows when squared, so the ambiguity test fails by itself
 __device__ __forceinline__ float t2_to_f32(double v, double scale) {
@@ -869,14 +874,14 @@ __global__ __launch_bounds__(WAVES * 64, 3) void k_decide_fast(DecideArgs A) {
     double v = t2eff(perm_inv(i));
     // "every cell passes" as a huge negative constant: P - T > 0, and (P - T)^2 overflows to +inf while
     // d2 * (P + T) is negative, so the ambiguity test fails without an extra T >= 0 term
-    s_t2[i] = t2_to_f32(v, 4.0);
+    s_t2[t2_pos(i)] = t2_to_f32(v, 4.0);
   }
   cf* fb = regions + wave * WAVE_CX_H + frame_base_h(g);
   const cf wl0 = A.tw1024[c];  // w_1024^c (lane 0: 1)
   // window table in LDS (behind the compare constants); interior blocks of float32 input also stage
   // the contiguous sample span of their 4*WAVES frames in the (still idle) exchange slices -- see
   // k_apply_fast
-  float* swin = s_t2 + 528;
+  float* swin = s_t2 + T2_FLOATS;
   for (int i = tid; i < 256; i += WAVES * 64)
     reinterpret_cast<float4*>(swin)[i] = reinterpret_cast<const float4*>(A.win)[i];
   constexpr int NFB = 4 * WAVES, SPAN = (NFB - 1) * 256 + 1024, XPITCH = 288;
@@ -959,13 +964,13 @@ __global__ __launch_bounds__(WAVES * 64, 3) void k_decide_fast(DecideArgs A) {
       int zt = 0;
       asm volatile("" : "+v"(zt));
       const float* tp = s_t2 + zt;
-      const float4* t4 = reinterpret_cast<const float4*>(tp + c * 32);
+      const float4* t4 = reinterpret_cast<const float4*>(tp + c * T2_PITCH);
 #pragma unroll
       for (int q4 = 0; q4 < 8; ++q4) {
         float4 x = t4[q4];
         t2[4 * q4] = x.x; t2[4 * q4 + 1] = x.y; t2[4 * q4 + 2] = x.z; t2[4 * q4 + 3] = x.w;
       }
-      t2_512 = tp[512];
+      t2_512 = tp[T2_POS512];
     }
 
     // powers of the lane's 32 bins (x4): P4[k] = |E2 + w O2|^2, P4[N-k] = |E2 - w O2|^2 with

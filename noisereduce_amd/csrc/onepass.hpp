@@ -111,7 +111,7 @@ __global__ __launch_bounds__(WAVES * 64, 3) void k_gate_onepass(OnePassArgs P) {
   cf* regions = tw512 + FN;
   float* swin = reinterpret_cast<float*>(regions + WAVES * WAVE_CX_H);
   float* s_t2 = swin + 1024;
-  unsigned long long* s_exp = reinterpret_cast<unsigned long long*>(s_t2 + 528);
+  unsigned long long* s_exp = reinterpret_cast<unsigned long long*>(s_t2 + T2_FLOATS);
   double* s_t2d = reinterpret_cast<double*>(s_exp + 256);   // exact compare constants (refinement), same order
   unsigned* s_misc = reinterpret_cast<unsigned*>(s_t2d + 514);
   unsigned char* s_ef = reinterpret_cast<unsigned char*>(s_misc + 4);  // PROP: integer weight (<= 81) of the valid taps along f, per bin
@@ -193,7 +193,7 @@ __global__ __launch_bounds__(WAVES * 64, 3) void k_gate_onepass(OnePassArgs P) {
         const int i = tid + k * WAVES * 64;
         if (i > 512) break;
         const double v = t2eff(perm_inv(i), t2pre[k]);
-        s_t2[i] = t2_to_f32(v, 4.0);
+        s_t2[t2_pos(i)] = t2_to_f32(v, 4.0);
         s_t2d[i] = v;   // the rare exact re-evaluation compares against this (no log10 in the hot kernel body)
       }
     };
@@ -296,8 +296,8 @@ __global__ __launch_bounds__(WAVES * 64, 3) void k_gate_onepass(OnePassArgs P) {
     // 32 more registers for a preloaded table would spill)
     int zt = 0;
     asm volatile("" : "+v"(zt));
-    const float* t2 = s_t2 + c * 32 + zt;
-    const float t2_512 = s_t2[512];
+    const float* t2 = s_t2 + c * T2_PITCH + zt;
+    const float t2_512 = s_t2[T2_POS512];
     const float d2 = nrm2 > 0.f ? 8.0f * 2.3283064e-10f * nrm2 : -1.0f;
     unsigned pred = 0, amb = 0;
     auto decide = [&](float Pw, float T, int q) {
