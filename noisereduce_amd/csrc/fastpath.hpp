@@ -1056,27 +1056,30 @@ __global__ __launch_bounds__(WAVES * 64, 3) void k_decide_fast(DecideArgs A) {
     // the four ballots of word m with vector selects and slices out its frame's 16-bit fields with
     // per-lane shifts afterwards (doing the slicing per frame on the scalar unit cost ~450 SALU
     // instructions per wave; the CU has one scalar unit for all its waves).
-    unsigned long long q0 = 0, q1 = 0, q2 = 0, q3 = 0;
-#pragma unroll
-    for (int m = 0; m < 8; ++m) {
-      const unsigned long long b0 = __ballot((pred >> (2 * m)) & 1u);           // bins 64m      + c
-      const unsigned long long b1 = __ballot((pred >> (16 + 2 * m)) & 1u);      // bins 64m + 16 + twisted
-      const unsigned long long b2 = __ballot((pred >> (2 * m + 1)) & 1u);       // bins 64m + 32 + c
-      const unsigned long long b3 = __ballot((pred >> (16 + 2 * m + 1)) & 1u);  // bins 64m + 48 + twisted
-      const bool mine = c == m;
-      q0 = mine ? b0 : q0;
-      q1 = mine ? b1 : q1;
-      q2 = mine ? b2 : q2;
-      q3 = mine ? b3 : q3;
-    }
+    // 16 x 16 bit transpose of both halves of `pred` across the frame's 16 lanes (see k_gate_onepass): lane k then
+    // holds entry k (low half) and entry 16 + k (high half) of lanes 0..15
+    unsigned tr = pred;
+    auto tstep = [&](int sft, unsigned msk) {
+      const unsigned y = (unsigned)__shfl_xor((int)tr, sft);
+      const bool up = (c & sft) != 0;
+      const unsigned ysh = up ? (y >> sft) : (y << sft);
+      const unsigned mk = up ? msk : ~msk;
+      tr = (tr & ~mk) | (ysh & mk);
+    };
+    tstep(8, 0x00ff00ffu);
+    tstep(4, 0x0f0f0f0fu);
+    tstep(2, 0x33333333u);
+    tstep(1, 0x55555555u);
     const unsigned long long b8 = __ballot(pred512);
     unsigned long long myword;  // lane c < 9 of group g ends up with word c of frame tq + g
     {
       const int sh = 16 * g;
-      const unsigned f0 = (unsigned)(q0 >> sh) & 0xffffu;
-      const unsigned f1 = (unsigned)(q1 >> sh) & 0xffffu;
-      const unsigned f2 = (unsigned)(q2 >> sh) & 0xffffu;
-      const unsigned f3 = (unsigned)(q3 >> sh) & 0xffffu;
+      const int srcl = (lane & 48) | ((2 * c) & 15);
+      const unsigned wa = (unsigned)__shfl((int)tr, srcl), wb2 = (unsigned)__shfl((int)tr, srcl + 1);
+      const unsigned f0 = wa & 0xffffu;    // bins 64m      + c
+      const unsigned f1 = wa >> 16;        // bins 64m + 16 + twisted
+      const unsigned f2 = wb2 & 0xffffu;   // bins 64m + 32 + c
+      const unsigned f3 = wb2 >> 16;       // bins 64m + 48 + twisted
       // row-2 slots hold bins 16, 31, 30, ..., 17 (c = 0, 1, ..., 15): undo the order
       const unsigned r1 = (((__brev(f1) >> 16) << 1) | (f1 & 1u)) & 0xffffu;
       const unsigned r3 = (((__brev(f3) >> 16) << 1) | (f3 & 1u)) & 0xffffu;

@@ -299,11 +299,23 @@ __global__ __launch_bounds__(WAVES * 64, 3) void k_gate_onepass(OnePassArgs P) {
     const float* t2 = s_t2 + c * T2_PITCH + zt;
     const float t2_512 = s_t2[T2_POS512];
     const float d2 = nrm2 > 0.f ? 8.0f * 2.3283064e-10f * nrm2 : -1.0f;
-    unsigned pred = 0, amb = 0;
-    auto decide = [&](float Pw, float T, int q) {
-      const float diff = Pw - T;
-      pred |= (diff > 0.f ? 1u : 0u) << q;
-      amb |= ((diff * diff <= d2 * (Pw + T)) ? 1u : 0u) << q;
+    // Decisions as SIGN BITS shifted into accumulators (v_alignbit: acc = acc << 1 | sign), no compares or selects:
+    //   passes    <=>  T - P < 0                      (sign of nd)
+    //   ambiguous <=>  d2 (P + T) - (T - P)^2 >= 0    (sign of e CLEAR)
+    // Slot sl decides entry sl (accumulators A, in slot order: bit 15 - sl) and entry 31 - sl (accumulators B: bit
+    // 15 - sl = entry 16 + that bit, already in place); A is bit-reversed at the end.
+    unsigned pA = 0, pB = 0, nA = 0, nB = 0;
+    auto decideA = [&](float Pw, float T) {
+      const float nd = T - Pw;
+      const float e = fmaf(-nd, nd, d2 * (Pw + T));
+      pA = __builtin_amdgcn_alignbit(pA, __float_as_uint(nd), 31);
+      nA = __builtin_amdgcn_alignbit(nA, __float_as_uint(e), 31);
+    };
+    auto decideB = [&](float Pw, float T) {
+      const float nd = T - Pw;
+      const float e = fmaf(-nd, nd, d2 * (Pw + T));
+      pB = __builtin_amdgcn_alignbit(pB, __float_as_uint(nd), 31);
+      nB = __builtin_amdgcn_alignbit(nB, __float_as_uint(e), 31);
     };
     bool pred512 = false, amb512 = false;
     {
@@ -311,8 +323,8 @@ __global__ __launch_bounds__(WAVES * 64, 3) void k_gate_onepass(OnePassArgs P) {
       const float Pn = pb[0].x * pb[0].x + pb[0].y * pb[0].y;
       const float x0 = 2.f * (raw0.x + raw0.y), xN = 2.f * (raw0.x - raw0.y);
       const float P256 = 4.f * (raw8.x * raw8.x + raw8.y * raw8.y);
-      decide(l0 ? x0 * x0 : Pk, t2[0], 0);
-      decide(l0 ? P256 : Pn, t2[31], 31);
+      decideA(l0 ? x0 * x0 : Pk, t2[0]);
+      decideB(l0 ? P256 : Pn, t2[31]);
       const float P5 = xN * xN, d5 = P5 - t2_512;
       pred512 = l0 && d5 > 0.f;
       amb512 = l0 && d5 * d5 <= d2 * (P5 + t2_512);
@@ -320,10 +332,14 @@ __global__ __launch_bounds__(WAVES * 64, 3) void k_gate_onepass(OnePassArgs P) {
 #pragma unroll
     for (int sl = 1; sl < 16; ++sl) {
       if ((sl & 3) == 0) __builtin_amdgcn_sched_barrier(0);  // keep the constant loads next to their use
-      decide(pa[sl].x * pa[sl].x + pa[sl].y * pa[sl].y, t2[sl], sl);
-      decide(pb[sl].x * pb[sl].x + pb[sl].y * pb[sl].y, t2[31 - sl], 31 - sl);
+      decideA(pa[sl].x * pa[sl].x + pa[sl].y * pa[sl].y, t2[sl]);
+      decideB(pb[sl].x * pb[sl].x + pb[sl].y * pb[sl].y, t2[31 - sl]);
     }
     __builtin_amdgcn_sched_barrier(0);
+    unsigned pred = (__brev(pA) >> 16) | (pB << 16);
+    unsigned amb = ~((__brev(nA) >> 16) | (nB << 16));
+    // a unit with non-finite samples (compare constants = T2_NEVER): NaN powers have no meaningful sign
+    if (need == 2) { pred = 0; amb = 0; pred512 = false; amb512 = false; }
     if (!fvalid) { amb = 0; amb512 = false; pred = 0; pred512 = false; }
     // exact re-evaluation, one cell at a time, whole wave cooperating.  Rare (about one wave in fifty has an
     // ambiguous cell), but its float64 temporaries do not fit next to the 64 registers of the split spectra:
@@ -366,26 +382,28 @@ __global__ __launch_bounds__(WAVES * 64, 3) void k_gate_onepass(OnePassArgs P) {
     }
     if (l0)  // entry -> register: e 0..7 -> 0..7, 8..23 -> 16..31, 24..30 -> 9..15, 31 -> 8
       pred = (pred & 0xffu) | ((pred & 0x00ffff00u) << 8) | ((pred >> 15) & 0xfe00u) | ((pred >> 23) & 0x100u);
-    unsigned long long q0 = 0, q1 = 0, q2 = 0, q3 = 0;
-#pragma unroll
-    for (int m = 0; m < 8; ++m) {
-      const unsigned long long b0 = __ballot((pred >> (2 * m)) & 1u);
-      const unsigned long long b1 = __ballot((pred >> (16 + 2 * m)) & 1u);
-      const unsigned long long b2 = __ballot((pred >> (2 * m + 1)) & 1u);
-      const unsigned long long b3 = __ballot((pred >> (16 + 2 * m + 1)) & 1u);
-      const bool mine = c == m;
-      q0 = mine ? b0 : q0;
-      q1 = mine ? b1 : q1;
-      q2 = mine ? b2 : q2;
-      q3 = mine ? b3 : q3;
-    }
+    // Lane (g, c) holds the 32 decisions of frame g in ENTRY order; word m of the frame's bit row needs entry 2m (and
+    // 16 + 2m, 2m + 1, 17 + 2m) of all 16 lanes.  A 16 x 16 bit transpose of both 16-bit halves at once -- four
+    // xor-shuffle steps, each swapping the off-diagonal s x s blocks -- leaves in lane k: low half = entry k of lanes
+    // 0..15, high half = entry 16 + k.  (32 wave ballots + per-lane selects did the same in ~200 instructions.)
+    unsigned tr = pred;
+    auto tstep = [&](int sft, unsigned msk) {
+      const unsigned y = (unsigned)__shfl_xor((int)tr, sft);
+      const bool up = (c & sft) != 0;
+      const unsigned ysh = up ? (y >> sft) : (y << sft);
+      const unsigned mk = up ? msk : ~msk;
+      tr = (tr & ~mk) | (ysh & mk);
+    };
+    tstep(8, 0x00ff00ffu);
+    tstep(4, 0x0f0f0f0fu);
+    tstep(2, 0x33333333u);
+    tstep(1, 0x55555555u);
     const unsigned long long b8 = __ballot(pred512);
     {
       const int sh = 16 * g;
-      const unsigned f0 = (unsigned)(q0 >> sh) & 0xffffu;
-      const unsigned f1 = (unsigned)(q1 >> sh) & 0xffffu;
-      const unsigned f2 = (unsigned)(q2 >> sh) & 0xffffu;
-      const unsigned f3 = (unsigned)(q3 >> sh) & 0xffffu;
+      const int srcl = (lane & 48) | ((2 * c) & 15);
+      const unsigned wa = (unsigned)__shfl((int)tr, srcl), wb2 = (unsigned)__shfl((int)tr, srcl + 1);
+      const unsigned f0 = wa & 0xffffu, f1 = wa >> 16, f2 = wb2 & 0xffffu, f3 = wb2 >> 16;
       const unsigned r1 = (((__brev(f1) >> 16) << 1) | (f1 & 1u)) & 0xffffu;
       const unsigned r3 = (((__brev(f3) >> 16) << 1) | (f3 & 1u)) & 0xffffu;
       myword = (unsigned long long)(f0 | (r1 << 16)) | ((unsigned long long)(f2 | (r3 << 16)) << 32);
