@@ -17,6 +17,10 @@
  *   - a handle is not thread-safe; use one handle per (device, stream).
  *   - caller owns input/output buffers; the library owns its workspace (grown on demand,
  *     bounded by sg_params.max_workspace_bytes; large jobs are processed in unit batches).
+ *   - non-finite samples: a NaN behaves as in the reference (spectralgate/stationary.py:75-106,
+ *     torchgate/torchgate.py:140-160: numpy / torch maxima and means keep it): every band of the
+ *     chunk / row that sees it is gated, a NaN in the noise clip gates everything, the NaN itself
+ *     survives in the output.  An Inf sample is treated like a NaN.
  */
 #ifndef MI355GATE_H
 #define MI355GATE_H
