@@ -62,6 +62,7 @@ struct sg_handle {
   // workspace
   DevBuf P, pmax, thr_rows, raw, M, seg, yn;
   DevBuf bits, K16, umax, need, T2;  // fused stationary path
+  DevBuf logtab;                     // db_fast (kernels.hpp): {rd(1 / c_i), -log2 of it} for 128 mantissa centres
   DevBuf part;                       // partial reductions of the column statistics
   DevBuf tw512, invn;                // fast path tables (n_fft = 1024, hop = 256)
   DevBuf seam;                       // partial seam hops of abutting apply tiles
@@ -470,6 +471,12 @@ static hipError_t apply_any(const sg_handle* h, const View& v, const Geom& g, in
 #undef SG_CALL
 }
 
+static DbFast db_fast_consts(const sg_handle* h) {
+  const double eps = 2.220446049250313e-16;
+  const double ymin = eps * 134217728.0 / h->mag_scale;   // eps 2^27 / mag_scale
+  return DbFast{(const double*)h->logtab.p, 20.0 * std::log10(h->mag_scale), ymin * ymin, eps / h->mag_scale};
+}
+
 static unsigned grid_1d(int64_t work, int block) {
   int64_t b = (work + block - 1) / block;
   return (unsigned)std::min<int64_t>(std::max<int64_t>(b, 1), 256 * 32);
@@ -645,6 +652,17 @@ extern "C" int sg_create(const sg_params* p, const double* window_host, sg_handl
   }
   int rc = SG_OK;
   if (!rc) rc = upload(h, h->tw64, tw64.data(), tw64.size() * sizeof(cx<double>));
+  {
+    // db_fast: centre c_i = 1 + (i + 1/2) / 128 of the i-th mantissa slice; the logarithm is that of the ROUNDED
+    // reciprocal, so that log2(m) = -log2(t_i) + log2(1 + (m t_i - 1)) holds exactly
+    std::vector<double> lt(256);
+    for (int i = 0; i < 128; ++i) {
+      const double ti = (double)(1.0L / (1.0L + ((long double)i + 0.5L) / 128.0L));
+      lt[2 * i] = ti;
+      lt[2 * i + 1] = (double)(-log2l((long double)ti));
+    }
+    if (!rc) rc = upload(h, h->logtab, lt.data(), lt.size() * sizeof(double));
+  }
   if (!rc) rc = upload(h, h->tw32, tw32.data(), tw32.size() * sizeof(cx<float>));
   if (!rc) rc = upload(h, h->wfull64, wfull.data(), wfull.size() * sizeof(double));
   if (!rc) rc = upload(h, h->wa32, wa32.data(), wa32.size() * sizeof(float));
@@ -745,7 +763,7 @@ extern "C" int sg_destroy(sg_handle* h) {
                     &h->P, &h->pmax, &h->thr_rows, &h->raw, &h->M, &h->seg, &h->yn, &h->bits, &h->K16, &h->umax,
                     &h->need, &h->T2, &h->part, &h->tw512, &h->invn, &h->seam, &h->ftab, &h->xbits, &h->xpart,
                     &h->xticket, &h->ftab3, &h->xexp, &h->nsp, &h->nsc, &h->xin, &h->czt_tw64, &h->czt_ch64,
-                    &h->czt_bh64, &h->czt_tw32, &h->czt_ch32, &h->czt_bh32})
+                    &h->czt_bh64, &h->czt_tw32, &h->czt_ch32, &h->czt_bh32, &h->logtab})
     free_buf(*b);
   delete h;
   return SG_OK;
@@ -1671,7 +1689,7 @@ extern "C" int sg_process_batch(sg_handle* h, const void* x_dev, int dtype, int6
           hipLaunchKernelGGL(k_row_decide, dim3((unsigned)wpr, (unsigned)nb), dim3(64 * STAT_TG), tile_bytes, st,
                              (const double*)h->P.p, g, th, ustride, h->mag_scale, h->p.top_db, h->p.n_std_thresh,
                              h->p.ddof, (double*)h->pmax.p, th ? nullptr : thr, (unsigned long long*)h->bits.p,
-                             wpr);
+                             wpr, db_fast_consts(h));
           HIPCHK(h, hipGetLastError());
         } else {
           ProfScope ps(h, SG_STAGE_DECIDE, st);

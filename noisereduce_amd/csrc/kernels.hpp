@@ -335,6 +335,40 @@ __device__ __forceinline__ double cell_db(double P, double mag_scale) {
   return 20.0 * log10(sqrt(P) * mag_scale + 2.220446049250313e-16);
 }
 
+// cell_db without the library logarithm and square root, for kernels whose time IS those two (k_row_decide: 8 M cells
+// x ~110 float64 operations).  With y = sqrt(P) s:  20 log10(y + eps) = 10 log10(2) log2(P) + 20 log10(s) +
+// (20 / ln 10) log1p(eps / y), and
+//   log2(P)  = exponent + log2(m), m in [1, 2): table of 128 centres c_i (top 7 mantissa bits): r = m / c_i - 1 as ONE
+//              fma with the rounded reciprocal t_i = rd(1 / c_i), |r| <= 2^-8; log2(m) = -log2(t_i) [tabulated for the
+//              ROUNDED t_i, so the split is exact] + log2(1 + r) [degree-6 series, next term < 2e-18];
+//   log1p(x) = x for x = eps / y < 2^-27 (error x^2 / 2 < 3e-17), y from the hardware reciprocal square root (its
+//              2^-26 relative accuracy is ample for a term this small).
+// Cells outside that range (y <= eps 2^27: silence; non-finite) take the plain formula.  Agreement with cell_db:
+// a few 1e-14 dB, the size of cell_db's own rounding.
+struct DbFast {
+  const double* tab;   // [128][2] = {t_i, -log2(t_i)} (device; staged in LDS by the kernel)
+  double db0;          // 20 log10(mag_scale)
+  double pmin;         // (eps 2^27 / mag_scale)^2
+  double eps_s;        // eps / mag_scale
+};
+__device__ __forceinline__ double db_fast(double P, const double* __restrict__ s_tab, const DbFast& k, double mag_scale) {
+  if (!(P > k.pmin && P < 1e300)) return cell_db(P, mag_scale);
+  const long long b = __double_as_longlong(P);
+  const int e = (int)(b >> 52) - 1023;
+  const int i = (int)(b >> 45) & 127;
+  const double m = __longlong_as_double((b & 0x000fffffffffffffLL) | 0x3ff0000000000000LL);
+  const double2 t = reinterpret_cast<const double2*>(s_tab)[i];
+  const double r = fma(m, t.x, -1.0);
+  double p = fma(r, -1.0 / 6.0, 0.2);
+  p = fma(r, p, -0.25);
+  p = fma(r, p, 1.0 / 3.0);
+  p = fma(r, p, -0.5);
+  p = fma(r, p, 1.0);
+  const double l2 = ((double)e + t.y) + (r * p) * 1.4426950408889634074;   // 1 / ln 2
+  const double rho = k.eps_s * __builtin_amdgcn_rsq(P);
+  return fma(3.0102999566398119521, l2, k.db0) + 8.6858896380650365530 * rho;   // 10 log10(2); 20 / ln 10
+}
+
 // Time is split into gridDim.z slices (deterministic two-stage reduction: partials, then a
 // fixed-order final sum) so that a single unit (the noise clip) still fills the chip.
 __global__ __launch_bounds__(64 * STAT_TG) void k_colmax(const double* __restrict__ P, Geom g,
@@ -649,10 +683,13 @@ __global__ __launch_bounds__(64 * STAT_TG) void k_row_decide(const double* __res
                                                              int64_t thresh_ustride, double mag_scale,
                                                              double top_db, double n_std, int ddof,
                                                              double* __restrict__ pmax, double* __restrict__ thresh_out,
-                                                             unsigned long long* __restrict__ bits, int wpr) {
+                                                             unsigned long long* __restrict__ bits, int wpr,
+                                                             DbFast dbk) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
   double* tile = reinterpret_cast<double*>(smem);  // [T][64]
   __shared__ double r1[STAT_TG][64], r2[STAT_TG][64];
+  __shared__ __attribute__((aligned(16))) double s_tab[256];
+  s_tab[threadIdx.x] = dbk.tab[threadIdx.x];   // 64 * STAT_TG = 256 threads
   const double eps = 2.220446049250313e-16;
   const int l = threadIdx.x & 63, tg = threadIdx.x >> 6;
   const int w = blockIdx.x;
@@ -686,7 +723,7 @@ __global__ __launch_bounds__(64 * STAT_TG) void k_row_decide(const double* __res
     __syncthreads();  // r1 is reused
     double s1 = 0.0, s2 = 0.0;
     for (int64_t t = tg; t < g.T; t += STAT_TG) {
-      double d = cell_db(tile[t * 64 + l], mag_scale) - mdb;  // <= 0
+      double d = db_fast(tile[t * 64 + l], s_tab, dbk, mag_scale) - mdb;  // <= 0
       d = (d != d) ? d : fmax(d, -top_db);   // (fmax would drop a NaN; numpy / torch keep it)
       s1 += d;
       s2 += d * d;
