@@ -888,7 +888,7 @@ static int stage_stats(sg_handle* h, const View& v, const Geom& g, int64_t ub, d
     if (rc) return rc;
     dim3 grid((g.F + 63) / 64, (unsigned)ub, nts);
     hipLaunchKernelGGL(k_colstats1, grid, dim3(64 * STAT_TG), 0, st, (const double*)h->P.p, g, h->mag_scale,
-                       (double*)h->part.p);
+                       (double*)h->part.p, db_fast_consts(h));
     HIPCHK(h, hipGetLastError());
     hipLaunchKernelGGL(k_colstats1_final, dim3((unsigned)((g.FS + 63) / 64), (unsigned)ub), dim3(64 * STAT_TG), 0, st,
                        (const double*)h->part.p, (const double*)h->P.p, g, nts, h->mag_scale, h->p.top_db,

@@ -459,8 +459,12 @@ __device__ __forceinline__ void min2_push(double& m1, double& m2, double x) {  /
 }
 
 __global__ __launch_bounds__(64 * STAT_TG) void k_colstats1(const double* __restrict__ P, Geom g, double mag_scale,
-                                                            double* __restrict__ part /* [u][nts][NP][FS] */) {
+                                                            double* __restrict__ part /* [u][nts][NP][FS] */,
+                                                            DbFast dbk) {
   __shared__ double r[STAT1_NP][STAT_TG][64];
+  __shared__ __attribute__((aligned(16))) double s_tab[256];
+  s_tab[threadIdx.x] = dbk.tab[threadIdx.x];   // 64 * STAT_TG = 256 threads
+  __syncthreads();
   const int l = threadIdx.x & 63;
   const int f = blockIdx.x * 64 + l;
   const int tg = threadIdx.x >> 6;
@@ -469,15 +473,29 @@ __global__ __launch_bounds__(64 * STAT_TG) void k_colstats1(const double* __rest
   const int64_t tb = g.T * ts / nts, te = g.T * (ts + 1) / nts;
   double mx = 0.0, m1 = 1e300, m2 = 1e300, s1 = 0.0, s2 = 0.0;
   if (f < g.F) {
-    const double pivot = cell_db(P[(u * g.T) * g.FS + f], mag_scale);
-#pragma unroll 3
-    for (int64_t t = tb + tg; t < te; t += STAT_TG) {
-      const double Pv = P[(u * g.T + t) * g.FS + f];
-      mx = fmax(mx, Pv);
-      min2_push(m1, m2, Pv);
-      const double d = cell_db(Pv, mag_scale) - pivot;
-      s1 += d;
-      s2 += d * d;
+    // the thread's cells in batches of 8 independent loads (the pivot cell rides in the first batch): the pass is a
+    // chain of memory round trips, not a stream
+    const double* col = P + (u * g.T) * g.FS + f;
+    const double p0 = col[0];
+    double pivot = 0.0;
+    for (int64_t t0 = tb + tg; t0 < te; t0 += 8 * STAT_TG) {
+      double pv[8];
+#pragma unroll
+      for (int q = 0; q < 8; ++q) {
+        const int64_t t = t0 + q * STAT_TG;
+        pv[q] = t < te ? col[t * g.FS] : 0.0;
+      }
+      if (t0 == tb + tg) pivot = cell_db(p0, mag_scale);   // (plain formula: k_colstats1_final recomputes it)
+#pragma unroll
+      for (int q = 0; q < 8; ++q) {
+        if (t0 + q * STAT_TG < te) {
+          mx = fmax(mx, pv[q]);
+          min2_push(m1, m2, pv[q]);
+          const double d = db_fast(pv[q], s_tab, dbk, mag_scale) - pivot;
+          s1 += d;
+          s2 += d * d;
+        }
+      }
     }
   }
   r[0][tg][l] = mx; r[1][tg][l] = m1; r[2][tg][l] = m2; r[3][tg][l] = s1; r[4][tg][l] = s2;
@@ -511,16 +529,16 @@ __global__ __launch_bounds__(64 * STAT_TG) void k_colstats1_final(const double* 
   const bool live = f < g.F;
   const double Tn = (double)g.T;
   double mx = 0.0, s1 = 0.0, s2 = 0.0;
-  double m1[STAT1_MAXS], m2[STAT1_MAXS];
+  const double p0 = live ? P[(u * g.T) * g.FS + f] : 1.0;   // pivot cell: loaded with the partials, one round trip
+  double m1[STAT1_MAXS];
 #pragma unroll
   for (int k = 0; k < STAT1_MAXS; ++k) {
     const int ts = tg + STAT_TG * k;
-    m1[k] = 1e300; m2[k] = 1e300;
+    m1[k] = 1e300;
     if (live && ts < nts) {
       const double* o = part + ((u * nts + ts) * STAT1_NP) * (int64_t)g.FS + f;
       mx = fmax(mx, o[0]);
       m1[k] = o[g.FS];
-      m2[k] = o[2 * g.FS];
       s1 += o[3 * g.FS];
       s2 += o[4 * g.FS];
     }
@@ -530,7 +548,7 @@ __global__ __launch_bounds__(64 * STAT_TG) void k_colstats1_final(const double* 
 #pragma unroll
   for (int k = 0; k < STAT_TG; ++k) mx = fmax(mx, r[0][k][l]);
   const double mdb = cell_db(mx, mag_scale);
-  const double pivot = live ? cell_db(P[(u * g.T) * g.FS + f], mag_scale) : 0.0;
+  const double pivot = live ? cell_db(p0, mag_scale) : 0.0;
   bool exact = false;
   {
     // cells below the floor: replace d by the floored value (both about the pivot).
@@ -539,21 +557,32 @@ __global__ __launch_bounds__(64 * STAT_TG) void k_colstats1_final(const double* 
     const double dfl = (mdb - top_db) - pivot;
     const double am = (exp10((mdb - top_db) / 20.0) - 2.220446049250313e-16) / mag_scale;
     const double Pfl = am > 0.0 ? am * am : 0.0;
+    // (hot path: compares only.  The corrections sit in a ROLLED loop that re-reads the two minima -- unrolled with
+    // its two inlined logarithms per slice the kernel was 40 KB of straight-line code, fetched cold on every call)
+    bool any = false;
 #pragma unroll
-    for (int k = 0; k < STAT1_MAXS; ++k) {
-      if (m1[k] < Pfl) {
-        const double d = cell_db(m1[k], mag_scale) - pivot;
-        if (d < dfl) {
-          s1 += dfl - d;
-          s2 += dfl * dfl - d * d;
-        }
-        if (m2[k] < Pfl) {
-          const double d2 = cell_db(m2[k], mag_scale) - pivot;
-          if (d2 < dfl) {
-            s1 += dfl - d2;
-            s2 += dfl * dfl - d2 * d2;
+    for (int k = 0; k < STAT1_MAXS; ++k) any = any || (m1[k] < Pfl);
+    if (any) {
+#pragma unroll 1
+      for (int k = 0; k < STAT1_MAXS; ++k) {
+        const int ts = tg + STAT_TG * k;
+        if (!(live && ts < nts)) continue;
+        const double* o = part + ((u * nts + ts) * STAT1_NP) * (int64_t)g.FS + f;
+        const double a1 = o[g.FS], a2 = o[2 * g.FS];
+        if (a1 < Pfl) {
+          const double d = cell_db(a1, mag_scale) - pivot;
+          if (d < dfl) {
+            s1 += dfl - d;
+            s2 += dfl * dfl - d * d;
           }
-          exact = true;  // a third floored cell of this slice would have gone unseen
+          if (a2 < Pfl) {
+            const double d2 = cell_db(a2, mag_scale) - pivot;
+            if (d2 < dfl) {
+              s1 += dfl - d2;
+              s2 += dfl * dfl - d2 * d2;
+            }
+            exact = true;  // a third floored cell of this slice would have gone unseen
+          }
         }
       }
     }
