@@ -1225,6 +1225,28 @@ static int stage_fused_mask(sg_handle* h, const View& v, const Geom& g, int64_t 
   return SG_OK;
 }
 
+// Hand-offs between workgroups of one launch (tagged granules, bounded polls): the host-mapped error word, the
+// verdict on earlier launches, a fresh epoch.  Granule buffers are zero when (re)allocated and the epoch only grows:
+// a fresh granule never carries it.
+static int handoff_prepare(sg_handle* h, hipStream_t st) {
+  if (!h->err_host) {
+    HIPCHK(h, hipHostMalloc((void**)&h->err_host, 64, hipHostMallocMapped));
+    *h->err_host = 0u;
+    HIPCHK(h, hipHostGetDevicePointer((void**)&h->err_dev, h->err_host, 0));
+  }
+  if (*h->err_host != 0u) {
+    const unsigned e = *h->err_host;
+    *h->err_host = 0u;
+    FAIL(h, SG_E_HIP, "a tile hand-off of an earlier call timed out (code %u): its output is invalid", e);
+  }
+  if (++h->epoch == 0) {  // wrapped: tags of 2^32 launches ago could alias
+    if (h->xbits.p) HIPCHK(h, hipMemsetAsync(h->xbits.p, 0, h->xbits.bytes, st));
+    if (h->xpart.p) HIPCHK(h, hipMemsetAsync(h->xpart.p, 0, h->xpart.bytes, st));
+    h->epoch = 1;
+  }
+  return SG_OK;
+}
+
 // Fused apply (default geometry): FFT -> mask(K) -> IFFT -> overlap-add -> output, one kernel.
 static int stage_apply_fast(sg_handle* h, const View& v, const Geom& g, int64_t ub, const OutMap& om,
                             const float* mask_f /* nullptr: uint16 counts in h->K16 */, int normalize,
@@ -1251,16 +1273,29 @@ static int stage_apply_fast(sg_handle* h, const View& v, const Geom& g, int64_t 
   // seam mode: abutting tiles + k_ola_seam for the straddling hops (3/16 fewer transforms)
   const int64_t tiles_seam = (nh + 3 + NF - 1) / NF;
   const bool seam = !h->force_noseam && tiles_seam >= 2;
+  const bool lean = !h->force_nolean;
+  // lean kernel: the straddling hops are handed from tile to tile inside the launch; else partial sums + k_ola_seam
+  const bool inkernel = seam && lean;
   A.part = nullptr;
+  A.part2 = nullptr;
+  A.epoch = 0;
+  A.err = nullptr;
   A.n_tiles = 0;
-  if (seam) {
+  if (inkernel) {
+    int rc = ensure_zeroed(h, h->xpart, (size_t)ub * tiles_seam * 3 * 256 * 8, st);
+    if (rc) return rc;
+    if ((rc = handoff_prepare(h, st))) return rc;
+    A.part2 = (unsigned long long*)h->xpart.p;
+    A.epoch = h->epoch;
+    A.err = h->err_dev;
+    A.n_tiles = (int)tiles_seam;
+  } else if (seam) {
     int rc = ensure(h, h->seam, (size_t)ub * tiles_seam * 6 * 256 * sizeof(float));
     if (rc) return rc;
     A.part = (float*)h->seam.p;
     A.n_tiles = (int)tiles_seam;
   }
   dim3 grid((unsigned)(seam ? tiles_seam : (nh + NH - 1) / NH), (unsigned)ub);
-  const bool lean = !h->force_nolean;
   auto go = [&](auto kern, size_t lds_bytes) -> hipError_t {
     hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern),
                                        hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes);
@@ -1277,7 +1312,7 @@ static int stage_apply_fast(sg_handle* h, const View& v, const Geom& g, int64_t 
     else HIPCHK(h, go(fast::k_apply_fast<WAVES, true, false>, lds));
   }
   HIPCHK(h, hipGetLastError());
-  if (seam) {
+  if (seam && !inkernel) {
     hipLaunchKernelGGL(fast::k_ola_seam<NF>, dim3((unsigned)(tiles_seam - 1), (unsigned)ub), dim3(256), 0, st, A);
     HIPCHK(h, hipGetLastError());
   }
@@ -1322,17 +1357,10 @@ static int stage_onepass(sg_handle* h, const View& v, const View& vx, const Geom
   const int64_t ntt = n_tiles + 2;
   if ((rc = ensure_zeroed(h, h->xpart, (size_t)ub * n_tiles * 3 * 256 * 8, st))) return rc;
   A.part = nullptr;
+  A.part2 = nullptr;   // (the one-pass kernel has its own hand-off arguments)
+  A.epoch = 0;
+  A.err = nullptr;
   A.n_tiles = (int)n_tiles;
-  if (!h->err_host) {
-    HIPCHK(h, hipHostMalloc((void**)&h->err_host, 64, hipHostMallocMapped));
-    *h->err_host = 0u;
-    HIPCHK(h, hipHostGetDevicePointer((void**)&h->err_dev, h->err_host, 0));
-  }
-  if (*h->err_host != 0u) {
-    const unsigned e = *h->err_host;
-    *h->err_host = 0u;
-    FAIL(h, SG_E_HIP, "k_gate_onepass: a tile hand-off of an earlier call timed out (code %u): its output is invalid", e);
-  }
   if ((rc = ensure_zeroed(h, h->xbits, (size_t)ub * ntt * fast::OP_TILE_WORDS * 8, st))) return rc;
   {
     // granule buffers are zero when (re)allocated and the epoch only grows: a fresh granule never carries it.
@@ -1342,11 +1370,7 @@ static int stage_onepass(sg_handle* h, const View& v, const View& vx, const Geom
     if ((rc = ensure_zeroed(h, h->xticket, 64, st, &fresh))) return rc;
     if (fresh) h->ticket_base = 0;
   }
-  if (++h->epoch == 0) {  // wrapped: tags of 2^32 launches ago could alias
-    HIPCHK(h, hipMemsetAsync(h->xbits.p, 0, h->xbits.bytes, st));
-    HIPCHK(h, hipMemsetAsync(h->xpart.p, 0, h->xpart.bytes, st));
-    h->epoch = 1;
-  }
+  if ((rc = handoff_prepare(h, st))) return rc;
   P.win64 = (const double*)h->wfull64.p;
   P.tw64 = (const cx<double>*)h->tw64.p;
   P.tc = tc;

@@ -330,6 +330,22 @@ __host__ __device__ constexpr int reg0_of_entry(int e) {
   return e < 8 ? e : (e < 24 ? e + 8 : (e < 31 ? e - 15 : 8));
 }
 
+constexpr int OP_SPIN_MAX = 1 << 20;     // polls before a hand-off is declared lost (~1 s): no unbounded spin
+typedef unsigned short op_us2 __attribute__((ext_vector_type(2)));
+typedef unsigned op_v4u __attribute__((ext_vector_type(4)));
+
+// 16-byte write-through store / L1-bypassing load (the sc1 forms the 8-byte agent-scope atomics compile to):
+// two tagged 8-byte granules per instruction.  Each 8-byte half carries its own tag, so the pair needs no
+// atomicity beyond the 8-byte granule.
+__device__ __forceinline__ void op_st16_sc1(void* p, op_v4u v) {
+  asm volatile("global_store_dwordx4 %0, %1, off sc1" : : "v"(p), "v"(v) : "memory");
+}
+__device__ __forceinline__ op_v4u op_ld16_sc1(const void* p) {
+  op_v4u v;
+  asm volatile("global_load_dwordx4 %0, %1, off sc1\n\ts_waitcnt vmcnt(0)" : "=v"(v) : "v"(p) : "memory");
+  return v;
+}
+
 struct ApplyArgs {
   View view;
   Geom g;
@@ -347,6 +363,12 @@ struct ApplyArgs {
   int normalize;            // 1: divide by the window envelope (ISTFT); 0: plain overlap-add (adjoint)
   float* part;              // seam mode: [units][tiles][6][256] un-normalised partial hops, else nullptr
   int n_tiles;
+  // seam mode of the LEAN kernel: the three hops that straddle two tiles are handed over INSIDE the launch (tile j
+  // publishes its trailing partial hops as tagged granules {float, epoch}, tile j + 1 -- a later block of the
+  // same row of the grid -- adds its leading partials and finalises them): no k_ola_seam launch
+  unsigned long long* part2;   // [units][tiles][3][256] granules, or nullptr (then `part` + k_ola_seam)
+  unsigned epoch;              // tag of this launch
+  unsigned* err;               // host-mapped error word (bounded polls)
 };
 
 // ---------------------------------------------------------------------------------------
@@ -386,7 +408,7 @@ __global__ __launch_bounds__(WAVES * 64, LEAN ? 3 : 2) void k_apply_fast(ApplyAr
   // Tiles either overlap by 3 frames (each tile completes its NH hops on its own) or, in seam mode,
   // abut: then the 3 hops that straddle two tiles are written as un-normalised partial sums and
   // combined by k_ola_seam -- 3/16 fewer transforms.
-  const bool seam = A.part != nullptr;
+  const bool seam = A.n_tiles > 0;
   const int64_t tf_tile = A.h_begin - 3 + (int64_t)blockIdx.x * (seam ? NF : NH);  // first frame of the tile
   const int64_t t = tf_tile + 4 * wave + g;                  // this lane group's frame
   const bool fvalid = t >= 0 && t < G.T;
@@ -660,10 +682,15 @@ __global__ __launch_bounds__(WAVES * 64, LEAN ? 3 : 2) void k_apply_fast(ApplyAr
   const int s4 = (tid & 63) * 4;
   const float4 n4 = inv4;
   const int jj_lo = seam ? 0 : 3, jj_hi = seam ? NF + 3 : NF;
-  for (int jj = jj_lo + (tid >> 6); jj < jj_hi; jj += WAVES) {
+  const bool inkernel = LEAN && seam && A.part2 != nullptr;
+  // in-kernel seam: per wave the TRAILING hop first (published early), the interior hops, the LEADING hop last (the
+  // previous tile -- an earlier block -- has usually published by then); publishing never waits
+  const int n_it = (jj_hi - jj_lo - (tid >> 6) + WAVES - 1) / WAVES;
+  for (int it = 0; it < n_it; ++it) {
+    int jj = jj_lo + (tid >> 6) + it * WAVES;
+    if (inkernel && (tid >> 6) < 3) jj = it == 0 ? NF + (tid >> 6) : (it == n_it - 1 ? (tid >> 6) : (tid >> 6) + WAVES * it);
     const int64_t h = tf_tile + jj;
-    if (h >= A.h_end) break;
-    if (h < A.h_begin) continue;
+    if (h >= A.h_end || h < A.h_begin) continue;
     float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
     bool all_valid = true;
 #pragma unroll
@@ -695,7 +722,35 @@ __global__ __launch_bounds__(WAVES * 64, LEAN ? 3 : 2) void k_apply_fast(ApplyAr
         }
       }
     }
-    if (jj < 3 || jj >= NF) {
+    if (inkernel && jj >= NF) {
+      unsigned long long* dst = A.part2 + (((size_t)u * A.n_tiles + blockIdx.x) * 3 + (jj - NF)) * 256 + s4;
+      const op_v4u ga = {__float_as_uint(acc.x), A.epoch, __float_as_uint(acc.y), A.epoch};
+      const op_v4u gb = {__float_as_uint(acc.z), A.epoch, __float_as_uint(acc.w), A.epoch};
+      op_st16_sc1(dst, ga);
+      op_st16_sc1(dst + 2, gb);
+      continue;
+    }
+    if (inkernel && jj < 3) {
+      // h >= h_begin implies blockIdx.x >= 1: the previous tile exists and was dispatched before this one
+      const unsigned long long* src = A.part2 + (((size_t)u * A.n_tiles + blockIdx.x - 1) * 3 + jj) * 256 + s4;
+      op_v4u ga, gb;
+      for (int spin = 0;; ++spin) {
+        asm volatile("global_load_dwordx4 %0, %2, off sc1\n\tglobal_load_dwordx4 %1, %2, off offset:16 sc1\n\ts_waitcnt vmcnt(0)"
+                     : "=&v"(ga), "=&v"(gb) : "v"(src) : "memory");
+        const unsigned e = A.epoch;
+        if (ga[1] == e && ga[3] == e && gb[1] == e && gb[3] == e) break;
+        if (spin >= OP_SPIN_MAX) {
+          atomicOr_system(A.err, 4u);
+          break;
+        }
+        __builtin_amdgcn_s_sleep(1);
+      }
+      // trailing partial of the previous tile + leading partial of this one (the order k_ola_seam adds them in)
+      acc.x = __uint_as_float(ga[0]) + acc.x;
+      acc.y = __uint_as_float(ga[2]) + acc.y;
+      acc.z = __uint_as_float(gb[0]) + acc.z;
+      acc.w = __uint_as_float(gb[2]) + acc.w;
+    } else if (jj < 3 || jj >= NF) {
       // seam hop: partial sum only; slot 0..2 = leading hops, 3..5 = trailing hops of this tile
       const int slot = jj < 3 ? jj : 3 + (jj - NF);
       float* dst = A.part + (((u * A.n_tiles + blockIdx.x) * 6 + slot) * 256 + s4);

@@ -37,7 +37,6 @@ constexpr int OP_XW = 9;                 // 64-bit words per frame row (513 bins
 constexpr int OP_TILE_WORDS = 16 * OP_XW * 2;  // payload of one tile: 288 tagged granules = 2304 B (18 x 128 B)
 constexpr int OP_MAX_NT = 16;            // neighbours hold 16 frames each
 constexpr int OP_KP = 528;               // K row pitch (uint16 entries) of a wave's private K tile
-constexpr int OP_SPIN_MAX = 1 << 20;     // polls before a hand-off is declared lost (~1 s): no unbounded spin
 
 struct OnePassArgs {
   ApplyArgs A;              // view, geometry, output map, tables, seam buffer (A.K / A.Mf unused)
@@ -78,21 +77,6 @@ __device__ __forceinline__ double op_exact_power(const OnePassArgs& P, int64_t r
     im += __shfl_xor(im, off);
   }
   return re * re + im * im;
-}
-
-typedef unsigned short op_us2 __attribute__((ext_vector_type(2)));
-typedef unsigned op_v4u __attribute__((ext_vector_type(4)));
-
-// 16-byte write-through store / L1-bypassing load (the sc1 forms the 8-byte agent-scope atomics compile to):
-// two tagged 8-byte granules per instruction.  Each 8-byte half carries its own tag, so the pair needs no
-// atomicity beyond the 8-byte granule.
-__device__ __forceinline__ void op_st16_sc1(void* p, op_v4u v) {
-  asm volatile("global_store_dwordx4 %0, %1, off sc1" : : "v"(p), "v"(v) : "memory");
-}
-__device__ __forceinline__ op_v4u op_ld16_sc1(const void* p) {
-  op_v4u v;
-  asm volatile("global_load_dwordx4 %0, %1, off sc1\n\ts_waitcnt vmcnt(0)" : "=v"(v) : "v"(p) : "memory");
-  return v;
 }
 
 // OP_ABLATE (development only, default 0; results are wrong): 1 no decision stage, 2 no wait for the
