@@ -116,3 +116,55 @@ def make_input_T(case):
     if case.get("xn"):
         xn = (0.1 * rng.standard_normal(case["xn"])).astype(np.float32).astype(np.float64)
     return x, xn
+
+
+# ---- non-finite samples: a NaN in the signal, in the noise clip, in one TorchGate row (separate tables: the
+# comparisons have to be NaN-aware) ----------------------------------------------------------------------
+S_NAN_CASES = {
+    "signal_chunks": dict(sr=48000, n=90000, seed=51, nan_at=40000,
+                          kwargs=dict(stationary=True, chunk_size=25000, padding=4000)),
+    "noise_clip": dict(sr=48000, n=30000, seed=52, noise_len=20000, nan_in_noise=5000,
+                       kwargs=dict(stationary=True)),
+    "nonstat": dict(sr=48000, n=30000, seed=53, nan_at=12000, kwargs=dict(stationary=False)),
+    "signal_nfft1000": dict(sr=48000, n=60000, seed=54, nan_at=33000,
+                            kwargs=dict(stationary=True, n_fft=1000, chunk_size=20000, padding=2000)),
+}
+T_NAN_CASES = {
+    "row": dict(sr=16000, B=3, L=9000, seed=55, nan_at=(1, 4000), kwargs=dict()),
+    "row_xn": dict(sr=16000, B=3, L=9000, seed=56, xn=(1, 5000), nan_at=(2, 100), kwargs=dict()),
+}
+
+
+def make_input_S_nan(case):
+    y, y_noise = make_input_S(case)
+    if "nan_at" in case:
+        y = y.copy()
+        y[..., case["nan_at"]] = np.nan
+    if "nan_in_noise" in case:
+        y_noise = y_noise.copy()
+        y_noise[..., case["nan_in_noise"]] = np.nan
+    return y, y_noise
+
+
+def make_input_T_nan(case):
+    x, xn = make_input_T(case)
+    x = x.copy()
+    x[case["nan_at"]] = np.nan
+    return x, xn
+
+
+def nonfinite_agree(got, want, tol):
+    """Same non-finite samples; the finite rest within tol of max(1e-3, peak).  Returns an error string or None."""
+    got = np.asarray(got, dtype=np.float64)
+    want = np.asarray(want, dtype=np.float64)
+    if got.shape != want.shape:
+        return "shape %s vs %s" % (got.shape, want.shape)
+    gn, wn = ~np.isfinite(got), ~np.isfinite(want)
+    if not np.array_equal(gn, wn):
+        return "non-finite samples differ: %d vs %d" % (gn.sum(), wn.sum())
+    ok = ~gn
+    if ok.any():
+        err = np.abs(got[ok] - want[ok]).max() / max(1e-3, np.abs(want[ok]).max())
+        if err > tol:
+            return "finite rest differs by %.3e" % err
+    return None

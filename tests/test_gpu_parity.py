@@ -564,3 +564,30 @@ def test_plain_c_caller_matches_python_path(nr, tmp_path):
     assert np.allclose(got, want, rtol=0, atol=1e-7 * np.max(np.abs(out))), (got, want)
     e_out = float(res[res.index("out") + 1])
     assert abs(e_out - float(np.sum(out.astype(np.float64) ** 2))) < 1e-5 * e_out
+
+
+# ---- a NaN sample: against golden vectors of the live reference (tests/golden/make_golden.py gen_nan) ----
+from tests.golden.cases import (S_NAN_CASES, T_NAN_CASES, make_input_S_nan, make_input_T_nan,  # noqa: E402
+                                nonfinite_agree)
+
+
+@pytest.mark.parametrize("name", sorted(S_NAN_CASES))
+@pytest.mark.parametrize("dtype", [np.float64, np.float32])
+def test_nan_sample_golden(nr, golden_dir, name, dtype):
+    case = S_NAN_CASES[name]
+    g = _load(golden_dir, "S_nan_" + name)
+    y, y_noise = make_input_S_nan(case)
+    out = nr.reduce_noise(y=y.astype(dtype), sr=case["sr"],
+                          y_noise=None if y_noise is None else y_noise.astype(dtype), **case["kwargs"])
+    assert nonfinite_agree(out, g["out"], TOL) is None, nonfinite_agree(out, g["out"], TOL)
+
+
+@pytest.mark.parametrize("name", sorted(T_NAN_CASES))
+def test_nan_sample_torchgate_golden(golden_dir, name):
+    from noisereduce_amd.torchgate import TorchGate
+    case = T_NAN_CASES[name]
+    g = _load(golden_dir, "T_nan_" + name)
+    x, xn = make_input_T_nan(case)
+    tg = TorchGate(sr=case["sr"], **case["kwargs"]).cuda()
+    out = tg(torch.from_numpy(x).float().cuda(), None if xn is None else torch.from_numpy(xn).float().cuda())
+    assert nonfinite_agree(out.cpu().numpy(), g["out"], TOL) is None, nonfinite_agree(out.cpu().numpy(), g["out"], TOL)

@@ -131,3 +131,30 @@ def test_filtfilt_and_boxcar_blocks_match_libraries():
         ref = torch.nn.functional.conv1d(X.reshape(-1, 1, A.shape[1]), torch.ones(1, 1, k, dtype=torch.float64),
                                          padding="same").reshape(A.shape).numpy() / k
         assert np.max(np.abs(O.boxcar_same(A, k) - ref)) < 1e-13
+
+
+# ---- non-finite samples: the oracle keeps the reference's NaN behaviour (golden vectors from the live reference) ----
+from tests.golden.cases import (S_NAN_CASES, T_NAN_CASES, make_input_S_nan, make_input_T_nan,  # noqa: E402
+                                nonfinite_agree)
+
+
+@pytest.mark.parametrize("name", sorted(S_NAN_CASES))
+def test_nan_sample_S_matches_reference(golden_dir, name):
+    case = S_NAN_CASES[name]
+    g = _load(golden_dir, "S_nan_" + name)
+    y, y_noise = make_input_S_nan(case)
+    assert sha(y) == str(g["in_sha"])
+    with np.errstate(all="ignore"):
+        out = O.reduce_noise_S(y, case["sr"], y_noise=y_noise, **case["kwargs"])
+    assert nonfinite_agree(out, g["out"], 1e-9) is None, nonfinite_agree(out, g["out"], 1e-9)
+
+
+@pytest.mark.parametrize("name", sorted(T_NAN_CASES))
+def test_nan_sample_T_matches_reference(golden_dir, name):
+    case = T_NAN_CASES[name]
+    g = _load(golden_dir, "T_nan_" + name)
+    x, xn = make_input_T_nan(case)
+    assert sha(x) == str(g["in_sha"])
+    with np.errstate(all="ignore"):
+        out = O.torchgate_T(x, case["sr"], xn=xn, window=g["window"], **case["kwargs"])
+    assert nonfinite_agree(out, g["out"], TOL_T) is None, nonfinite_agree(out, g["out"], TOL_T)
