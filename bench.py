@@ -123,6 +123,31 @@ def cpu_baseline(budget_s=25.0):
     return res
 
 
+def launcher_command(n, argv=None, port=None):
+    """The command `python bench.py --gpus N` re-executes itself as when it was started without a launcher."""
+    import socket
+    if port is None:
+        with socket.socket() as sk:
+            sk.bind(("127.0.0.1", 0))
+            port = sk.getsockname()[1]
+    return [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(n),
+            "--master-addr", "127.0.0.1", "--master-port", str(port), os.path.abspath(__file__)] + \
+           list(sys.argv[1:] if argv is None else argv)
+
+
+def self_launch(n):
+    import subprocess
+    env = dict(os.environ)
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    env.setdefault("OMP_NUM_THREADS", "1")
+    if torch.cuda.is_available() and torch.cuda.device_count() < n and "BENCH_BACKEND" not in env:
+        print(f"bench.py: --gpus {n} but {torch.cuda.device_count()} device(s) visible: RCCL refuses ranks that share a "
+              "device; set BENCH_BACKEND=gloo for a functional run", file=sys.stderr)
+    rc = subprocess.call(launcher_command(n), env=env)
+    if rc:
+        raise SystemExit(rc)
+
+
 # ---------------------------------------------------------------------------------------------
 def main():
     ap = argparse.ArgumentParser()
@@ -139,11 +164,16 @@ def main():
     if args.nonstationary:
         args.workload = "config3"
 
+    if "WORLD_SIZE" not in os.environ and args.gpus > 1:
+        # started bare (`python bench.py --gpus N`): become the launcher -- one rank per GPU through
+        # torch.distributed.run on a free local port; rank 0 prints the one JSON line on our stdout
+        return self_launch(args.gpus)
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     if world != args.gpus:
-        raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}: launch with torch.distributed.run")
+        raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}: start `python bench.py --gpus N` bare (it "
+                         "launches its own ranks) or through torch.distributed.run with --nproc-per-node N")
     # BENCH_BACKEND=gloo lets the multi-rank code path be exercised on a box with fewer GPUs than
     # ranks (ranks share devices; RCCL itself refuses that) -- a functional check, not a measurement.
     pg_backend = os.environ.get("BENCH_BACKEND", "nccl")
@@ -414,7 +444,7 @@ def _time_events(fn, warm, reps):
     ev[reps].record()
     torch.cuda.synchronize()
     ts = [ev[i].elapsed_time(ev[i + 1]) for i in range(reps)]
-    return float(np.median(ts)), float(np.mean(ts))
+    return float(np.median(ts)), float(np.mean(ts)), [round(t, 4) for t in ts]
 
 
 def extras(device, wl, out, y2d, gate, O):
@@ -447,16 +477,17 @@ def extras(device, wl, out, y2d, gate, O):
         return res
     oc = {}
     y = y2d[0]
-    med, mean = _time_events(lambda: nr.reduce_noise(y=y, sr=SR, stationary=False), 3, 10)
-    oc["config3_nonstationary"] = {"ms_median": round(med, 4), "ms_mean": round(mean, 4),
+    med, mean, reps3 = _time_events(lambda: nr.reduce_noise(y=y, sr=SR, stationary=False), 5, 20)
+    oc["config3_nonstationary"] = {"ms_median": round(med, 4), "ms_mean": round(mean, 4), "ms_per_rep": reps3,
                                    "Msamples_s": round(y.numel() / (med * 1e-3) / 1e6, 1),
                                    "what": "configs[2]: same recording, stationary=False, device-resident"}
     torch.manual_seed(0)
     t = torch.arange(16000, device=device, dtype=torch.float64) / 16000
     x = (0.1 * torch.randn(256, 16000, device=device) + 0.5 * torch.sin(2 * np.pi * 440 * t).float()).float()
     tg = TorchGate(sr=16000).to(device)
-    med, mean = _time_events(lambda: tg(x), 10, 50)
+    med, mean, reps5 = _time_events(lambda: tg(x), 10, 50)
     oc["config5_torchgate_forward"] = {"ms_median": round(med, 4), "ms_mean": round(mean, 4),
+                                       "ms_max": max(reps5),
                                        "Msamples_s": round(x.numel() / (med * 1e-3) / 1e6, 1),
                                        "what": "configs[4]: TorchGate(sr=16000) on 256 x 16000 float32"}
     xg = x.clone().requires_grad_()
@@ -464,8 +495,9 @@ def extras(device, wl, out, y2d, gate, O):
     def fb():
         xg.grad = None
         tg(xg).sum().backward()
-    med, mean = _time_events(fb, 10, 50)
+    med, mean, reps5b = _time_events(fb, 10, 50)
     oc["config5_torchgate_forward_backward"] = {"ms_median": round(med, 4), "ms_mean": round(mean, 4),
+                                                "ms_max": max(reps5b),
                                                 "Msamples_s": round(x.numel() / (med * 1e-3) / 1e6, 1)}
     # PCIe-inclusive: numpy in -> numpy out (H2D + compute + D2H), wall clock
     yh = y.cpu().numpy()

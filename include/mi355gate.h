@@ -45,6 +45,7 @@ extern "C" {
 #define SG_E_HIP (-3)         /* HIP runtime error                            */
 #define SG_E_NOMEM (-4)       /* workspace allocation failed                  */
 #define SG_E_STATE (-5)       /* call order (e.g. no noise threshold yet)     */
+#define SG_E_HANDOFF (-6)     /* a bounded inter-workgroup wait timed out: output invalid, re-run (sg_check_errors) */
 
 /* sample dtypes of caller buffers */
 #define SG_F32 0
@@ -188,8 +189,21 @@ SG_API int sg_debug_fetch(sg_handle* h, int32_t what, void* host, int64_t bytes,
 #define SG_OPT_FORCE_NOSEAM 4   /* value != 0: overlapping apply tiles instead of abutting tiles + seam kernel */
 #define SG_OPT_FORCE_NOLEAN 5   /* value != 0: apply kernel with full-size LDS slices and stored frames */
 #define SG_OPT_FORCE_SPLIT 6    /* value != 0: default geometry: decide / smooth / apply as three kernels instead of the one-pass kernel */
+#define SG_OPT_INJECT_HANDOFF_FAULT 7 /* tests: the next launch with in-launch hand-offs reports `value` (bits 0..2) as lost hand-offs */
 #define SG_OPT_FORCE_NOFAST 2  /* value != 0: keep the bit-mask stages but use the general apply kernels */
 SG_API int sg_set_option(sg_handle* h, int32_t option, int64_t value);
+
+/* ---- deferred device-side errors -------------------------------------------------------- */
+/* The fused kernels of the default geometry hand data from workgroup to workgroup INSIDE a launch (mask bits,
+ * partial hops; placement-independent ticket protocol, every wait bounded to about a second).  A wait that
+ * times out -- the device was preempted or time-sliced for that long -- cannot be reported by the asynchronous
+ * call that enqueued the kernel.  sg_check_errors synchronises `stream` and returns SG_E_HANDOFF when a launch
+ * enqueued on this handle since the previous check lost a hand-off: those calls' outputs are invalid and must
+ * be re-run.  sg_get_noise_threshold and sg_debug_fetch (which synchronise anyway) report the same way; a caller
+ * that never checks gets SG_E_HANDOFF from its NEXT compute call on the handle.  The Python layer checks after
+ * every call that returns host arrays and re-runs a failed call on the kernels without in-launch hand-offs.
+ * (No counterpart in the reference: base.py:206-216 joins its joblib workers.) */
+SG_API int sg_check_errors(sg_handle* h, void* stream);
 
 /* ---- per-kernel timing (bench.py's roofline leg) ------------------------------------- */
 #define SG_STAGE_CHANNEL_MEAN 0

@@ -19,17 +19,23 @@ LIB_PATH = os.path.join(_HERE, "libmi355gate.so")
 
 SG_F32, SG_F64, SG_I16, SG_I32 = 0, 1, 2, 3
 SG_VARIANT_S, SG_VARIANT_T = 0, 1
-SG_E_INVALID, SG_E_UNSUPPORTED, SG_E_HIP, SG_E_NOMEM, SG_E_STATE = -1, -2, -3, -4, -5
+SG_E_INVALID, SG_E_UNSUPPORTED, SG_E_HIP, SG_E_NOMEM, SG_E_STATE, SG_E_HANDOFF = -1, -2, -3, -4, -5, -6
 SG_N_STAGES = 17
 SG_OPT_FORCE_F64_DECIDE = 3
 SG_OPT_FORCE_NOSEAM = 4
 SG_OPT_FORCE_NOLEAN = 5
 SG_OPT_FORCE_SPLIT = 6
+SG_OPT_INJECT_HANDOFF_FAULT = 7
 SG_OPT_FORCE_UNFUSED = 1
 SG_OPT_FORCE_NOFAST = 2
 
 _TORCH_DTYPES = {torch.float32: SG_F32, torch.float64: SG_F64, torch.int16: SG_I16,
                  torch.int32: SG_I32}
+
+
+class HandoffTimeout(RuntimeError):
+    """SG_E_HANDOFF: a bounded inter-workgroup wait of a fused kernel timed out (the device was preempted for
+    about a second); the outputs of the calls enqueued since the last check are invalid and must be re-run."""
 
 
 class SgParams(Structure):
@@ -71,6 +77,7 @@ _PROTOTYPES = {
                                           c_void_p, c_void_p, c_int64, c_void_p]),
     "sg_stft": (c_int, [c_void_p, c_void_p, c_int, c_int64, c_int64, c_int64, c_void_p, c_void_p]),
     "sg_set_option": (c_int, [c_void_p, c_int32, c_int64]),
+    "sg_check_errors": (c_int, [c_void_p, c_void_p]),
     "sg_profile_enable": (c_int, [c_void_p, c_int32]),
     "sg_profile_select": (c_int, [c_void_p, c_int64]),
     "sg_profile_read": (c_int, [c_void_p, POINTER(c_double), POINTER(c_int64), c_int32, c_int32]),
@@ -185,6 +192,8 @@ class Gate:
             raise NotImplementedError(msg)
         if rc == SG_E_NOMEM:
             raise MemoryError(msg)
+        if rc == SG_E_HANDOFF:
+            raise HandoffTimeout(msg)
         raise RuntimeError(f"libmi355gate error {rc}: {msg}")
 
     def _check(self, rc):
@@ -336,6 +345,32 @@ class Gate:
 
     def set_option(self, option, value):
         self._check(self.lib.sg_set_option(self._h, int(option), int(value)))
+
+    def check_errors(self):
+        """Synchronise the current stream and raise HandoffTimeout if a launch enqueued on this handle since the
+        last check lost an in-launch hand-off (include/mi355gate.h: sg_check_errors)."""
+        with torch.cuda.device(self.device):
+            self._check(self.lib.sg_check_errors(self._h, self._stream()))
+
+    def run_checked(self, fn):
+        """fn() -> device tensor, then check_errors(); a call that lost a hand-off is re-run ONCE on the kernels
+        without in-launch hand-offs (three-kernel gate, apply + seam kernel).  For callers that synchronise
+        anyway (host arrays out); holds the handle's lock."""
+        with self.lock:
+            try:
+                out = fn()
+                self.check_errors()
+                return out
+            except HandoffTimeout:
+                self.set_option(SG_OPT_FORCE_SPLIT, 1)
+                self.set_option(SG_OPT_FORCE_NOLEAN, 1)
+                try:
+                    out = fn()
+                    self.check_errors()
+                    return out
+                finally:
+                    self.set_option(SG_OPT_FORCE_SPLIT, 0)
+                    self.set_option(SG_OPT_FORCE_NOLEAN, 0)
 
     # -- per-kernel timing -----------------------------------------------------------
     def profile_enable(self, on=True):

@@ -68,11 +68,12 @@ struct sg_handle {
   DevBuf seam;                       // partial seam hops of abutting apply tiles
   DevBuf ftab;                       // k_smooth_bits2 phase-1 lookup tables (nf <= 5)
   // one-pass gate (onepass.hpp): published mask bits per tile, publication flags, work counter, tables
-  DevBuf xbits, xpart, xticket, ftab3, xexp;
+  DevBuf xbits, xpart, xticket, xtick2, ftab3, xexp;
   DevBuf xin;                        // float32 copy of a recording held in another sample dtype
   DevBuf nsp, nsc;                   // non-stationary mask: per-sub-tile partials / carries (nonstat.hpp)  // ftab3: per-lane MFMA operands, xexp: bit -> byte table
   unsigned* err_host = nullptr;      // host-mapped error word written by k_gate_onepass when a hand-off times out
   unsigned* err_dev = nullptr;
+  unsigned inject_fault = 0;         // SG_OPT_INJECT_HANDOFF_FAULT (tests): error bits the next hand-off launch reports
   unsigned ticket_base = 0;          // tickets handed out by all previous launches
   unsigned epoch = 0;                // launch counter: the value a tile's flag must carry to be current
   bool force_split = false;          // SG_OPT_FORCE_SPLIT: decide / smooth / apply as three kernels
@@ -172,11 +173,12 @@ static int ensure(sg_handle* h, DevBuf& b, size_t bytes) {
 
 // ensure() + zero fill when the buffer was (re)allocated: for state that kernels keep clean themselves
 static int ensure_zeroed(sg_handle* h, DevBuf& b, size_t bytes, hipStream_t st, bool* fresh = nullptr) {
-  const void* before = b.p;
+  // freshness from the SIZE, not the pointer: the allocator may hand the freed address straight back
+  const bool grow = b.bytes < bytes;
   int rc = ensure(h, b, bytes);
   if (rc) return rc;
-  if (fresh) *fresh = b.p != before;
-  if (b.p != before) HIPCHK(h, hipMemsetAsync(b.p, 0, b.bytes, st));
+  if (fresh) *fresh = grow;
+  if (grow) HIPCHK(h, hipMemsetAsync(b.p, 0, b.bytes, st));
   return SG_OK;
 }
 
@@ -762,7 +764,7 @@ extern "C" int sg_destroy(sg_handle* h) {
   for (DevBuf* b : {&h->tw64, &h->tw32, &h->wfull64, &h->wa32, &h->ws32, &h->wsq32, &h->kf, &h->kt, &h->thresh,
                     &h->P, &h->pmax, &h->thr_rows, &h->raw, &h->M, &h->seg, &h->yn, &h->bits, &h->K16, &h->umax,
                     &h->need, &h->T2, &h->part, &h->tw512, &h->invn, &h->seam, &h->ftab, &h->xbits, &h->xpart,
-                    &h->xticket, &h->ftab3, &h->xexp, &h->nsp, &h->nsc, &h->xin, &h->czt_tw64, &h->czt_ch64,
+                    &h->xticket, &h->xtick2, &h->ftab3, &h->xexp, &h->nsp, &h->nsc, &h->xin, &h->czt_tw64, &h->czt_ch64,
                     &h->czt_bh64, &h->czt_tw32, &h->czt_ch32, &h->czt_bh32, &h->logtab})
     free_buf(*b);
   delete h;
@@ -1229,15 +1231,30 @@ static int stage_fused_mask(sg_handle* h, const View& v, const Geom& g, int64_t 
 // verdict on earlier launches, a fresh epoch.  Granule buffers are zero when (re)allocated and the epoch only grows:
 // a fresh granule never carries it.
 static int handoff_prepare(sg_handle* h, hipStream_t st) {
+  {
+    // The work counter is never reset: every launch takes exactly its grid size in tickets, the kernels subtract
+    // the running base.
+    bool fresh = false;
+    int rc = ensure_zeroed(h, h->xticket, 64, st, &fresh);
+    if (rc) return rc;
+    if (fresh) h->ticket_base = 0;
+  }
   if (!h->err_host) {
     HIPCHK(h, hipHostMalloc((void**)&h->err_host, 64, hipHostMallocMapped));
     *h->err_host = 0u;
     HIPCHK(h, hipHostGetDevicePointer((void**)&h->err_dev, h->err_host, 0));
   }
   if (*h->err_host != 0u) {
+    // only reached by callers that never synchronise through the library (sg_check_errors and every synchronising
+    // entry point report a lost hand-off for the call that suffered it)
     const unsigned e = *h->err_host;
     *h->err_host = 0u;
-    FAIL(h, SG_E_HIP, "a tile hand-off of an earlier call timed out (code %u): its output is invalid", e);
+    FAIL(h, SG_E_HANDOFF, "a tile hand-off of an EARLIER call on this handle timed out (code %u): that call's output "
+                          "is invalid (call sg_check_errors after a call to learn about it in time)", e);
+  }
+  if (h->inject_fault) {  // test hook: this launch "loses" a hand-off
+    *h->err_host = h->inject_fault;
+    h->inject_fault = 0;
   }
   if (++h->epoch == 0) {  // wrapped: tags of 2^32 launches ago could alias
     if (h->xbits.p) HIPCHK(h, hipMemsetAsync(h->xbits.p, 0, h->xbits.bytes, st));
@@ -1245,6 +1262,26 @@ static int handoff_prepare(sg_handle* h, hipStream_t st) {
     h->epoch = 1;
   }
   return SG_OK;
+}
+
+// After the stream has been synchronised: did a hand-off of the work just completed time out?
+static int handoff_verdict(sg_handle* h) {
+  if (h->err_host && *h->err_host != 0u) {
+    const unsigned e = *h->err_host;
+    *h->err_host = 0u;
+    FAIL(h, SG_E_HANDOFF, "a tile hand-off timed out (code %u: %s%s%s): the output of the call(s) enqueued since the "
+                          "last check is invalid; re-run them (SG_OPT_FORCE_SPLIT + SG_OPT_FORCE_NOLEAN select the "
+                          "kernels without in-launch hand-offs)",
+         e, (e & 1u) ? "mask bits " : "", (e & 2u) ? "partial hops (one-pass gate) " : "",
+         (e & 4u) ? "partial hops (fused apply)" : "");
+  }
+  return SG_OK;
+}
+
+extern "C" int sg_check_errors(sg_handle* h, void* stream) {
+  if (!h) return SG_E_INVALID;
+  HIPCHK(h, hipStreamSynchronize((hipStream_t)stream));
+  return handoff_verdict(h);
 }
 
 // Fused apply (default geometry): FFT -> mask(K) -> IFFT -> overlap-add -> output, one kernel.
@@ -1281,6 +1318,7 @@ static int stage_apply_fast(sg_handle* h, const View& v, const Geom& g, int64_t 
   A.epoch = 0;
   A.err = nullptr;
   A.n_tiles = 0;
+  A.ticket = nullptr;
   if (inkernel) {
     int rc = ensure_zeroed(h, h->xpart, (size_t)ub * tiles_seam * 3 * 256 * 8, st);
     if (rc) return rc;
@@ -1289,6 +1327,9 @@ static int stage_apply_fast(sg_handle* h, const View& v, const Geom& g, int64_t 
     A.epoch = h->epoch;
     A.err = h->err_dev;
     A.n_tiles = (int)tiles_seam;
+    // tile = ticket (fastpath.hpp: ApplyArgs::ticket): one self-resetting counter per unit
+    if ((rc = ensure_zeroed(h, h->xtick2, (size_t)ub * 64, st))) return rc;
+    A.ticket = (unsigned*)h->xtick2.p;
   } else if (seam) {
     int rc = ensure(h, h->seam, (size_t)ub * tiles_seam * 6 * 256 * sizeof(float));
     if (rc) return rc;
@@ -1303,7 +1344,7 @@ static int stage_apply_fast(sg_handle* h, const View& v, const Geom& g, int64_t 
     hipLaunchKernelGGL(kern, grid, dim3(WAVES * 64), lds_bytes, st, A);
     return hipGetLastError();
   };
-  const size_t lds_lean = (size_t)(fast::FN + WAVES * fast::WAVE_CX_H) * sizeof(fast::cf) + 1024 * sizeof(float);
+  const size_t lds_lean = (size_t)(fast::FN + WAVES * fast::WAVE_CX_H) * sizeof(fast::cf) + 1024 * sizeof(float) + 16;
   if (mask_f) {
     if (lean) HIPCHK(h, go(fast::k_apply_fast<WAVES, false, true>, lds_lean));
     else HIPCHK(h, go(fast::k_apply_fast<WAVES, false, false>, lds));
@@ -1362,14 +1403,7 @@ static int stage_onepass(sg_handle* h, const View& v, const View& vx, const Geom
   A.err = nullptr;
   A.n_tiles = (int)n_tiles;
   if ((rc = ensure_zeroed(h, h->xbits, (size_t)ub * ntt * fast::OP_TILE_WORDS * 8, st))) return rc;
-  {
-    // granule buffers are zero when (re)allocated and the epoch only grows: a fresh granule never carries it.
-    // The work counter is never reset: every launch takes exactly ub * ntt tickets, the kernel subtracts the
-    // running base.
-    bool fresh = false;
-    if ((rc = ensure_zeroed(h, h->xticket, 64, st, &fresh))) return rc;
-    if (fresh) h->ticket_base = 0;
-  }
+  // granule buffers are zero when (re)allocated and the epoch only grows: a fresh granule never carries it
   if ((rc = handoff_prepare(h, st))) return rc;
   P.win64 = (const double*)h->wfull64.p;
   P.tw64 = (const cx<double>*)h->tw64.p;
@@ -1550,7 +1584,7 @@ extern "C" int sg_get_noise_threshold(sg_handle* h, double* thresh_host, int32_t
   HIPCHK(h, hipMemcpyAsync(thresh_host, h->thresh.p, (size_t)h->F * sizeof(double), hipMemcpyDeviceToHost,
                            (hipStream_t)stream));
   HIPCHK(h, hipStreamSynchronize((hipStream_t)stream));
-  return SG_OK;
+  return handoff_verdict(h);
 }
 
 extern "C" int sg_set_noise_threshold(sg_handle* h, const double* thresh_host, int32_t n_bins, void* stream) {
@@ -1830,6 +1864,7 @@ extern "C" int sg_set_option(sg_handle* h, int32_t option, int64_t value) {
     case SG_OPT_FORCE_NOSEAM: h->force_noseam = value != 0; return SG_OK;
     case SG_OPT_FORCE_NOLEAN: h->force_nolean = value != 0; return SG_OK;
     case SG_OPT_FORCE_SPLIT: h->force_split = value != 0; return SG_OK;
+    case SG_OPT_INJECT_HANDOFF_FAULT: h->inject_fault = (unsigned)value & 7u; return SG_OK;
   }
   FAIL(h, SG_E_INVALID, "sg_set_option: unknown option %d", option);
 }
@@ -1915,6 +1950,7 @@ extern "C" int sg_debug_fetch(sg_handle* h, int32_t what, void* host, int64_t by
   }
   if ((size_t)bytes != need) FAIL(h, SG_E_INVALID, "sg_debug_fetch: need %zu bytes, got %lld", need, (long long)bytes);
   HIPCHK(h, hipStreamSynchronize((hipStream_t)stream));
+  { int rc = handoff_verdict(h); if (rc) return rc; }
   if (what == 3 && h->dbg_xbits) {
     // one-pass path: the bits live tile-blocked in the exchange buffer [unit][tile][16][9]; rearrange into
     // the natural [unit][T][wpr] layout (frames outside sg_debug_range stay zero)

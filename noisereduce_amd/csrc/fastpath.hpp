@@ -364,11 +364,18 @@ struct ApplyArgs {
   float* part;              // seam mode: [units][tiles][6][256] un-normalised partial hops, else nullptr
   int n_tiles;
   // seam mode of the LEAN kernel: the three hops that straddle two tiles are handed over INSIDE the launch (tile j
-  // publishes its trailing partial hops as tagged granules {float, epoch}, tile j + 1 -- a later block of the
-  // same row of the grid -- adds its leading partials and finalises them): no k_ola_seam launch
+  // publishes its trailing partial hops as tagged granules {float, epoch}, tile j + 1 adds its leading partials
+  // and finalises them): no k_ola_seam launch.  Placement-independent like k_gate_onepass (onepass.hpp): the grid is
+  // one-dimensional and a workgroup works on tile number `ticket` (one atomic per workgroup on a counter that is
+  // never reset), NOT on its blockIdx -- HIP promises nothing about dispatch order.  A tile publishes before it
+  // waits, and it only ever waits for the tile one ticket earlier, whose workgroup is therefore already running.
+  // One counter PER UNIT (blockIdx.y picks the unit -- units are independent --, the ticket picks the tile inside
+  // it; 64 bytes apart): a single counter serialises the atomics of a short launch at one memory channel (TorchGate,
+  // 1280 workgroups: +11 us of 52).  The workgroup that draws a unit's last ticket puts the counter back to zero.
   unsigned long long* part2;   // [units][tiles][3][256] granules, or nullptr (then `part` + k_ola_seam)
   unsigned epoch;              // tag of this launch
   unsigned* err;               // host-mapped error word (bounded polls)
+  unsigned* ticket;            // [units][16] work counters (in-kernel hand-off only), zero between launches
 };
 
 // ---------------------------------------------------------------------------------------
@@ -402,14 +409,29 @@ __global__ __launch_bounds__(WAVES * 64, LEAN ? 3 : 2) void k_apply_fast(ApplyAr
       reinterpret_cast<float4*>(swin)[i] = reinterpret_cast<const float4*>(A.win)[i];
   }
   const Geom& G = A.g;
-  const int64_t u = blockIdx.y;
+  // which tile: the grid position, or -- when hops are handed from tile to tile inside the launch -- a ticket
+  unsigned bx = blockIdx.x, by = blockIdx.y;
+  if constexpr (LEAN) {
+    if (A.ticket != nullptr) {   // (uniform) the table loads above and the atomic share one memory round trip
+      unsigned* s_tk = reinterpret_cast<unsigned*>(swin + 1024);
+      if (tid == 0) {
+        unsigned* ctr = A.ticket + (size_t)by * 16;
+        const unsigned tk = atomicAdd(ctr, 1u);
+        if (tk + 1u == (unsigned)A.n_tiles) atomicExch(ctr, 0u);   // all of this unit's tickets are out
+        *s_tk = tk;
+      }
+      __syncthreads();
+      bx = *s_tk;
+    }
+  }
+  const int64_t u = by;
   const int64_t row = (A.view.unit0 + u) / A.view.n_chunks;
   const int64_t chunk = A.view.c0 + (A.view.unit0 + u) % A.view.n_chunks;
   // Tiles either overlap by 3 frames (each tile completes its NH hops on its own) or, in seam mode,
   // abut: then the 3 hops that straddle two tiles are written as un-normalised partial sums and
   // combined by k_ola_seam -- 3/16 fewer transforms.
   const bool seam = A.n_tiles > 0;
-  const int64_t tf_tile = A.h_begin - 3 + (int64_t)blockIdx.x * (seam ? NF : NH);  // first frame of the tile
+  const int64_t tf_tile = A.h_begin - 3 + (int64_t)bx * (seam ? NF : NH);  // first frame of the tile
   const int64_t t = tf_tile + 4 * wave + g;                  // this lane group's frame
   const bool fvalid = t >= 0 && t < G.T;
   // 1 / window envelope of this thread's four sample phases, used by the OLA epilogue: loaded at entry
@@ -684,7 +706,7 @@ __global__ __launch_bounds__(WAVES * 64, LEAN ? 3 : 2) void k_apply_fast(ApplyAr
   const int jj_lo = seam ? 0 : 3, jj_hi = seam ? NF + 3 : NF;
   const bool inkernel = LEAN && seam && A.part2 != nullptr;
   // in-kernel seam: per wave the TRAILING hop first (published early), the interior hops, the LEADING hop last (the
-  // previous tile -- an earlier block -- has usually published by then); publishing never waits
+  // previous tile -- one ticket earlier -- has usually published by then); publishing never waits
   const int n_it = (jj_hi - jj_lo - (tid >> 6) + WAVES - 1) / WAVES;
   for (int it = 0; it < n_it; ++it) {
     int jj = jj_lo + (tid >> 6) + it * WAVES;
@@ -723,7 +745,7 @@ __global__ __launch_bounds__(WAVES * 64, LEAN ? 3 : 2) void k_apply_fast(ApplyAr
       }
     }
     if (inkernel && jj >= NF) {
-      unsigned long long* dst = A.part2 + (((size_t)u * A.n_tiles + blockIdx.x) * 3 + (jj - NF)) * 256 + s4;
+      unsigned long long* dst = A.part2 + (((size_t)u * A.n_tiles + bx) * 3 + (jj - NF)) * 256 + s4;
       const op_v4u ga = {__float_as_uint(acc.x), A.epoch, __float_as_uint(acc.y), A.epoch};
       const op_v4u gb = {__float_as_uint(acc.z), A.epoch, __float_as_uint(acc.w), A.epoch};
       op_st16_sc1(dst, ga);
@@ -731,8 +753,8 @@ __global__ __launch_bounds__(WAVES * 64, LEAN ? 3 : 2) void k_apply_fast(ApplyAr
       continue;
     }
     if (inkernel && jj < 3) {
-      // h >= h_begin implies blockIdx.x >= 1: the previous tile exists and was dispatched before this one
-      const unsigned long long* src = A.part2 + (((size_t)u * A.n_tiles + blockIdx.x - 1) * 3 + jj) * 256 + s4;
+      // h >= h_begin implies bx >= 1: the previous tile exists, and its workgroup holds the previous ticket
+      const unsigned long long* src = A.part2 + (((size_t)u * A.n_tiles + bx - 1) * 3 + jj) * 256 + s4;
       op_v4u ga, gb;
       for (int spin = 0;; ++spin) {
         asm volatile("global_load_dwordx4 %0, %2, off sc1\n\tglobal_load_dwordx4 %1, %2, off offset:16 sc1\n\ts_waitcnt vmcnt(0)"
@@ -753,7 +775,7 @@ __global__ __launch_bounds__(WAVES * 64, LEAN ? 3 : 2) void k_apply_fast(ApplyAr
     } else if (jj < 3 || jj >= NF) {
       // seam hop: partial sum only; slot 0..2 = leading hops, 3..5 = trailing hops of this tile
       const int slot = jj < 3 ? jj : 3 + (jj - NF);
-      float* dst = A.part + (((u * A.n_tiles + blockIdx.x) * 6 + slot) * 256 + s4);
+      float* dst = A.part + (((u * A.n_tiles + bx) * 6 + slot) * 256 + s4);
       *reinterpret_cast<float4*>(dst) = acc;
       continue;
     }

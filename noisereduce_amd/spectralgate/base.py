@@ -173,11 +173,14 @@ class SpectralGate:
             raise NotImplementedError
         is_np = isinstance(chunk, np.ndarray)
         dev = self._to_device(chunk)
-        with self._gate.lock:
+        def run():
             self._bind()
-            out = self._gate.filter_padded(dev, out_dtype=dev.dtype if dev.dtype.is_floating_point
-                                           else torch.float64)
-        return out.cpu().numpy() if is_np else out
+            return self._gate.filter_padded(dev, out_dtype=dev.dtype if dev.dtype.is_floating_point
+                                            else torch.float64)
+        if is_np:   # host array out: the call synchronises anyway -> deferred device errors are checked (and re-run)
+            return self._gate.run_checked(run).cpu().numpy()
+        with self._gate.lock:
+            return run()
 
     def _bind(self):
         """Load per-object state into the shared engine handle (stationary gate: its threshold)."""
@@ -193,8 +196,13 @@ class SpectralGate:
             end_frame = self.n_frames
         ydev = self._device_y()
         chunked = self._chunk_size is not None and end_frame - start_frame > self._chunk_size
-        with self._gate.lock:
+        def run():
             self._bind()
-            out = self._gate.process_chunks(ydev, out_dtype=ydev.dtype, start_frame=start_frame,
-                                            end_frame=end_frame, chunked=chunked)
+            return self._gate.process_chunks(ydev, out_dtype=ydev.dtype, start_frame=start_frame,
+                                             end_frame=end_frame, chunked=chunked)
+        if self._tensor_io:   # device tensor out: asynchronous, no host synchronisation (Gate.check_errors is the
+            with self._gate.lock:   # caller's to use; an unchecked failure surfaces at the next call on the handle)
+                out = run()
+        else:
+            out = self._gate.run_checked(run)
         return self._finish(out)

@@ -7,6 +7,7 @@ host<->device copy."""
 import numpy as np
 import torch
 
+from noisereduce_amd import _ffi
 from noisereduce_amd.spectralgate.base import SpectralGate
 from noisereduce_amd.torchgate import TorchGate as TG
 
@@ -57,7 +58,30 @@ class StreamedTorchGate(SpectralGate):
         return out.cpu().detach().numpy() if is_np else out
 
     def get_traces(self, start_frame=None, end_frame=None):
-        """The reference's chunk loop (base.py:167-226) with device-resident chunks."""
+        """The reference's chunk loop (base.py:167-226) with device-resident chunks.  Host arrays out: the call
+        synchronises anyway, so deferred device errors (a lost in-launch hand-off) are checked and the call is
+        re-run once on the kernels without hand-offs."""
+        if self._tensor_io:
+            return self._get_traces(start_frame, end_frame)
+        gates = lambda: list(self.tg._gates.values())
+        try:
+            out = self._get_traces(start_frame, end_frame)
+            for g in gates():
+                g.check_errors()
+            return out
+        except _ffi.HandoffTimeout:
+            for g in gates():
+                g.set_option(_ffi.SG_OPT_FORCE_NOLEAN, 1)
+            try:
+                out = self._get_traces(start_frame, end_frame)
+                for g in gates():
+                    g.check_errors()
+                return out
+            finally:
+                for g in gates():
+                    g.set_option(_ffi.SG_OPT_FORCE_NOLEAN, 0)
+
+    def _get_traces(self, start_frame=None, end_frame=None):
         if start_frame is None:
             start_frame = 0
         if end_frame is None:

@@ -151,3 +151,28 @@ def test_committed_bench_line_has_the_contract_fields():
     # value is consistent with ms_per_step and the workload size
     assert abs(line["value"] - line["config"]["samples_per_gpu"] * line["n_gpus"] / line["ms_per_step"] / 1e3) \
         < 0.01 * line["value"]
+
+
+def test_bench_launches_its_own_ranks(monkeypatch):
+    """`python bench.py --gpus N` started bare (no WORLD_SIZE) re-executes itself through torch.distributed.run with
+    one rank per GPU on 127.0.0.1 (the driver's first multi-GPU run must measure something)."""
+    import importlib
+    import subprocess
+    import sys
+    bench = importlib.import_module("bench")
+    cmd = bench.launcher_command(4, ["--gpus", "4", "--steps", "2"], port=29999)
+    assert cmd[:3] == [sys.executable, "-m", "torch.distributed.run"]
+    assert "--nproc-per-node" in cmd and cmd[cmd.index("--nproc-per-node") + 1] == "4"
+    assert cmd[cmd.index("--master-addr") + 1] == "127.0.0.1" and cmd[cmd.index("--master-port") + 1] == "29999"
+    assert cmd[-4:] == ["--gpus", "4", "--steps", "2"] and cmd[-5].endswith("bench.py")
+    calls = []
+    monkeypatch.delenv("WORLD_SIZE", raising=False)
+    monkeypatch.setattr(subprocess, "call", lambda c, env=None: calls.append((c, env)) or 0)
+    monkeypatch.setattr(sys, "argv", ["bench.py", "--gpus", "2", "--steps", "1", "--warmup", "0"])
+    bench.main()
+    assert len(calls) == 1 and calls[0][0][-6:] == ["--gpus", "2", "--steps", "1", "--warmup", "0"]
+    assert calls[0][1]["HSA_ENABLE_IPC_MODE_LEGACY"] == "0"
+    # under a launcher with another world size: a clear error, no silent mismatch
+    monkeypatch.setenv("WORLD_SIZE", "1")
+    with pytest.raises(SystemExit):
+        bench.main()

@@ -71,6 +71,21 @@ def test_torchgate_T_matches_reference(golden_dir, name):
     assert O.rel_err(out, g["out"]) < TOL_T
 
 
+@pytest.mark.parametrize("name", sorted(T_CASES))
+def test_torch_cpu_port_matches_reference(golden_dir, name):
+    """oracle/torchgate_torch_port.py (the torch-on-CPU restatement timed by bench.py's cpu_baseline leg for
+    configs[4]) against the same golden vectors of the live reference."""
+    import torch
+    from oracle.torchgate_torch_port import torchgate_cpu
+    case = T_CASES[name]
+    g = _load(golden_dir, "T_" + name)
+    x, xn = make_input_T(case)
+    out = torchgate_cpu(torch.from_numpy(x), case["sr"], xn=None if xn is None else torch.from_numpy(xn),
+                        **case["kwargs"]).numpy()
+    assert out.shape == g["out"].shape
+    assert O.rel_err(out, g["out"]) < TOL_T
+
+
 def test_conv_variants_agree():
     rng = np.random.default_rng(0)
     m = (rng.random((40, 60)) > 0.5) * 1.0
