@@ -95,6 +95,44 @@ def cpu_baseline(budget_s=25.0):
            "sample": "first 60 s (2.88 M samples, 5 chunks) of the workload, stationary, "
                      "oracle/spectralgate_oracle.py reduce_noise_S, float64, numpy single thread, "
                      "median of 3 after 1 warm-up; os.cpu_count()=%d" % (os.cpu_count() or 0)}
+    # configs[2] on one core: the same 60 s, non-stationary (filtfilt one-pole floor + sigmoid mask)
+    ts = []
+    for i in range(3):
+        t0 = time.perf_counter()
+        O.reduce_noise_S(y, SR, stationary=False, n_fft=NFFT, chunk_size=CHUNK, padding=PAD)
+        ts.append(time.perf_counter() - t0)
+    res["nonstationary"] = {"value": round(n / float(np.median(ts[1:])) / 1e6, 3), "unit": "Msamples/s", "cores": 1,
+                            "kind": "port", "sample": "configs[2]: the same 60 s, stationary=False, median of 2 after 1 warm-up"}
+    # configs[4] on the host cores: TorchGate restated with the torch primitives the reference calls, on CPU tensors
+    try:
+        from oracle.torchgate_torch_port import torchgate_cpu
+        torch.manual_seed(0)
+        tt = torch.arange(16000, dtype=torch.float64) / 16000
+        xc = (0.1 * torch.randn(256, 16000) + 0.5 * torch.sin(2 * np.pi * 440 * tt).float()).float()
+        ts = []
+        for i in range(4):
+            t0 = time.perf_counter()
+            torchgate_cpu(xc, 16000)
+            ts.append(time.perf_counter() - t0)
+        res["torchgate_cpu"] = {"value": round(xc.numel() / float(np.median(ts[1:])) / 1e6, 3), "unit": "Msamples/s",
+                                "cores": torch.get_num_threads(), "kind": "port",
+                                "sample": "configs[4]: 256 x 16000 float32 forward, oracle/torchgate_torch_port.py (torch.stft / "
+                                          "conv2d / istft on CPU tensors, torch's own thread pool), median of 3 after 1 warm-up"}
+    except Exception as e:
+        res["torchgate_cpu"] = {"error": repr(e)}
+    # how the port's speed relates to the LIVE reference (which cannot travel to the GPU box): measured side by side in
+    # the build container by tools/ref_vs_port.py, committed
+    try:
+        rv = json.load(open(os.path.join(ROOT, "profiles", "r03_ref_vs_port.json")))
+        res["port_vs_reference"] = {
+            "stationary_port_over_reference_speed": rv["stationary"]["port_over_reference_speed"],
+            "nonstationary_port_over_reference_speed": rv["nonstationary"]["port_over_reference_speed"],
+            "torchgate_port_over_reference_speed": rv["torchgate_256x16000_f32"]["torch_port_over_reference_speed"],
+            "source": "profiles/r03_ref_vs_port.json: live reference and port timed side by side on %d build-container cores "
+                      "(tools/ref_vs_port.py); > 1 means the port is FASTER than the reference it stands in for -- NOT measured "
+                      "in this run" % rv["host"]["cpu_count"]}
+    except Exception as e:
+        res["port_vs_reference"] = {"error": repr(e)}
     # multi-core leg
     try:
         n_chunks = N_PER_GPU // CHUNK
