@@ -61,7 +61,7 @@ extern "C" {
 typedef struct sg_params {
   int32_t variant;    /* SG_VARIANT_S | SG_VARIANT_T                                        */
   int32_t stationary; /* 1: stationary (threshold) mask, 0: non-stationary (sigmoid) mask   */
-  int32_t n_fft;      /* 4..4096, or a power of two up to 8192 (base.py:77; torchgate.py:55) */
+  int32_t n_fft;      /* 4..32768, or a power of two up to 65536 (base.py:77; torchgate.py:55) */
   int32_t win_length; /* <= n_fft (base.py:79-82)                                           */
   int32_t hop_length; /* >= 1    (base.py:83-86)                                            */
   int32_t n_grad_freq; /* mask-smoothing half width in bins  (base.py:104), >= 1            */

@@ -24,6 +24,7 @@
 #include "onepass.hpp"
 #include "nonstat.hpp"
 #include "fast64.hpp"
+#include "big.hpp"
 
 #ifndef SG_APPLY_WAVES
 #define SG_APPLY_WAVES 4  // wavefronts per workgroup of k_apply_fast: tile = 4*W frames -> 4*W-3 hops
@@ -80,6 +81,10 @@ struct sg_handle {
   bool dbg_xbits = false;            // the last batch's mask bits live in xbits (tile-blocked)
   int64_t dbg_tf0 = 0;               // first frame of tile 0 of that batch
   int dbg_ntt = 0;                   // tiles per unit incl. the two halo tiles
+  int big_M = 0;                     // > 0: long frames (n_fft > 8192, or > 4096 and not a power of two): four-step
+                                     // transform of size M through HBM (big.hpp); big_czt: chirp-z on top of it
+  int big_czt = 0;
+  DevBuf big_twM, big_tw2, big_ch, big_bh, big_W, big_W2;
   int czt_M = 0;                     // > 0: n_fft is not a power of two -> chirp-z kernels (czt.hpp) of size M
   DevBuf czt_tw64, czt_ch64, czt_bh64, czt_tw32, czt_ch32, czt_bh32;
   bool force_noseam = false;
@@ -430,10 +435,120 @@ static CztTabs<TC> czt_tabs(const sg_handle* h) {
   return {(const cx<TC>*)h->czt_tw32.p, (const cx<TC>*)h->czt_ch32.p, (const cx<TC>*)h->czt_bh32.p};
 }
 
+// ------------------------------------------------------------------------------------------
+// long frames (big.hpp): four-step transform through HBM, frames in batches of <= 256 MB of work buffer
+// ------------------------------------------------------------------------------------------
+static big::BigTabs big_tabs(const sg_handle* h) {
+  return big::BigTabs{(const big::cd*)h->big_twM.p, (const big::cd*)h->big_tw2.p, (const big::cd*)h->big_ch.p,
+                      (const big::cd*)h->big_bh.p, h->big_M, h->big_M / 16, h->big_czt};
+}
+
+template <int M2>
+static hipError_t big_rows_m2(big::cd* W, const big::BigTabs& tb, int64_t nf, int mode, hipStream_t st) {
+  const size_t lds = (size_t)lpn<double>(M2) * sizeof(big::cd);
+  auto go = [&](auto kern) -> hipError_t {
+    if (lds > 65536) {
+      hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize,
+                                         (int)lds);
+      if (e != hipSuccess) return e;
+    }
+    hipLaunchKernelGGL(kern, dim3((unsigned)(nf * 16)), dim3(256), lds, st, W, tb, nf);
+    return hipGetLastError();
+  };
+  if (mode == 0) return go(big::k_big_rows<M2, false, false>);
+  if (mode == 1) return go(big::k_big_rows<M2, true, false>);
+  return go(big::k_big_rows<M2, false, true>);
+}
+
+// mode 0: forward rows, 1: inverse rows, 2: forward rows x B then inverse rows (chirp-z)
+static hipError_t big_rows(big::cd* W, const big::BigTabs& tb, int64_t nf, int mode, hipStream_t st) {
+  switch (tb.M2) {
+    case 1024: return big_rows_m2<1024>(W, tb, nf, mode, st);
+    case 2048: return big_rows_m2<2048>(W, tb, nf, mode, st);
+    case 4096: return big_rows_m2<4096>(W, tb, nf, mode, st);
+  }
+  return hipErrorInvalidValue;
+}
+
+// the length-n DFT of the staged frames: natural order in; out = permuted bins (power of two) or the chirp-z
+// convolution in natural order
+static hipError_t big_dft(big::cd* W, const big::BigTabs& tb, int64_t nf, hipStream_t st) {
+  const dim3 gc((unsigned)((tb.M2 + 255) / 256), (unsigned)nf);
+  hipLaunchKernelGGL(big::k_big_cols<false>, gc, dim3(256), 0, st, W, tb, nf);
+  hipError_t e = hipGetLastError();
+  if (e != hipSuccess) return e;
+  if ((e = big_rows(W, tb, nf, tb.czt ? 2 : 0, st)) != hipSuccess) return e;
+  if (tb.czt) {
+    hipLaunchKernelGGL(big::k_big_cols<true>, gc, dim3(256), 0, st, W, tb, nf);
+    e = hipGetLastError();
+  }
+  return e;
+}
+
+static int64_t big_batch(const sg_handle* h, int64_t total) {
+  const int64_t per = (int64_t)h->big_M * (int64_t)sizeof(big::cd);
+  return std::max<int64_t>(1, std::min<int64_t>(std::min<int64_t>(total, 32768), ((int64_t)256 << 20) / per));
+}
+
+static int big_stft(sg_handle* h, const View& v, const Geom& g, int64_t units, double* P, float* mag, double* z,
+                    double zscale, hipStream_t st, unsigned long long* pmax_bits) {
+  const big::BigTabs tb = big_tabs(h);
+  const int64_t total = units * g.T, nb = big_batch(h, total);
+  int rc = ensure(h, h->big_W, (size_t)nb * tb.M * sizeof(big::cd));
+  if (rc) return rc;
+  big::cd* W = (big::cd*)h->big_W.p;
+  for (int64_t f0 = 0; f0 < total; f0 += nb) {
+    const int64_t nf = std::min(nb, total - f0);
+    hipLaunchKernelGGL(big::k_big_frames, dim3(64, (unsigned)nf), dim3(256), 0, st, v, g, tb, (const double*)h->wfull64.p,
+                       W, f0, nf);
+    HIPCHK(h, hipGetLastError());
+    HIPCHK(h, big_dft(W, tb, nf, st));
+    hipLaunchKernelGGL(big::k_big_out, dim3((unsigned)std::min<int64_t>(32, (g.F + 255) / 256), (unsigned)nf), dim3(256), 0,
+                       st, (const big::cd*)W, g, tb, f0, nf, P, mag, z, zscale, pmax_bits);
+    HIPCHK(h, hipGetLastError());
+  }
+  return SG_OK;
+}
+
+static int big_apply(sg_handle* h, const View& v, const Geom& g, int64_t units, const float* Mk, float* seg,
+                     hipStream_t st) {
+  const big::BigTabs tb = big_tabs(h);
+  const int64_t total = units * g.T, nb = big_batch(h, total);
+  int rc = ensure(h, h->big_W, (size_t)nb * tb.M * sizeof(big::cd));
+  if (!rc) rc = ensure(h, h->big_W2, (size_t)nb * tb.M * sizeof(big::cd));
+  if (rc) return rc;
+  big::cd *W = (big::cd*)h->big_W.p, *W2 = (big::cd*)h->big_W2.p;
+  for (int64_t f0 = 0; f0 < total; f0 += nb) {
+    const int64_t nf = std::min(nb, total - f0);
+    hipLaunchKernelGGL(big::k_big_frames, dim3(64, (unsigned)nf), dim3(256), 0, st, v, g, tb, (const double*)h->wfull64.p,
+                       W, f0, nf);
+    HIPCHK(h, hipGetLastError());
+    HIPCHK(h, big_dft(W, tb, nf, st));
+    hipLaunchKernelGGL(big::k_big_mask, dim3(64, (unsigned)nf), dim3(256), 0, st, (const big::cd*)W, W2, g, tb, f0, nf, Mk);
+    HIPCHK(h, hipGetLastError());
+    if (tb.czt) {
+      HIPCHK(h, big_dft(W2, tb, nf, st));   // inverse DFT = forward chirp-z of conj(Y), conjugated
+    } else {
+      HIPCHK(h, big_rows(W2, tb, nf, 1, st));
+      hipLaunchKernelGGL(big::k_big_cols<true>, dim3((unsigned)((tb.M2 + 255) / 256), (unsigned)nf), dim3(256), 0, st, W2,
+                         tb, nf);
+      HIPCHK(h, hipGetLastError());
+    }
+    hipLaunchKernelGGL(big::k_big_seg, dim3(64, (unsigned)nf), dim3(256), 0, st, (const big::cd*)W2, g, tb, f0, nf,
+                       (const double*)h->wfull64.p, seg);
+    HIPCHK(h, hipGetLastError());
+  }
+  return SG_OK;
+}
+
 // forward STFT of `units` units on the kernels that fit the handle's frame length
 template <typename TC>
 static hipError_t stft_any(const sg_handle* h, const View& v, const Geom& g, int64_t units, double* P, float* mag,
                            double* z, double zscale, hipStream_t st, unsigned long long* pmax_bits = nullptr) {
+  if (h->big_M) {
+    const int rc = big_stft(const_cast<sg_handle*>(h), v, g, units, P, mag, z, zscale, st, pmax_bits);
+    return rc == SG_OK ? hipSuccess : (rc == SG_E_NOMEM ? hipErrorOutOfMemory : hipErrorUnknown);
+  }
   const void* wfull = sizeof(TC) == 8 ? h->wfull64.p : h->wa32.p;
   if (sizeof(TC) == 8 && h->fast_ok && !h->force_nofast && P && !mag && !z && v.dtype == SG_F32 &&
       units * ((g.T + 15) / 16) >= 512) {
@@ -464,6 +579,10 @@ static hipError_t stft_any(const sg_handle* h, const View& v, const Geom& g, int
 
 static hipError_t apply_any(const sg_handle* h, const View& v, const Geom& g, int64_t units, const float* Mk,
                             float* seg, hipStream_t st) {
+  if (h->big_M) {
+    const int rc = big_apply(const_cast<sg_handle*>(h), v, g, units, Mk, seg, st);
+    return rc == SG_OK ? hipSuccess : (rc == SG_E_NOMEM ? hipErrorOutOfMemory : hipErrorUnknown);
+  }
   const float* wa = (const float*)h->wa32.p;
   const float* ws = (const float*)h->ws32.p;
   if (!h->czt_M) return launch_apply(h->N, v, g, units, h->tw32.p, wa, ws, Mk, seg, st);
@@ -567,6 +686,84 @@ static int build_czt(sg_handle* h) {
   return rc;
 }
 
+// Host radix-2 transform in long double (tables only)
+static void host_fft(std::vector<long double>& br, std::vector<long double>& bi) {
+  typedef long double ld;
+  const ld PI = 3.14159265358979323846264338327950288L;
+  const int M = (int)br.size();
+  for (int i = 1, j = 0; i < M; ++i) {
+    int bit = M >> 1;
+    for (; j & bit; bit >>= 1) j ^= bit;
+    j ^= bit;
+    if (i < j) {
+      std::swap(br[i], br[j]);
+      std::swap(bi[i], bi[j]);
+    }
+  }
+  for (int len = 2; len <= M; len <<= 1) {
+    for (int k = 0; k < len / 2; ++k) {
+      const ld a = -2.0L * PI * (ld)k / (ld)len;
+      const ld wr = cosl(a), wi = sinl(a);
+      for (int i = k; i < M; i += len) {
+        const int j = i + len / 2;
+        const ld xr = br[j] * wr - bi[j] * wi, xi = br[j] * wi + bi[j] * wr;
+        br[j] = br[i] - xr;
+        bi[j] = bi[i] - xi;
+        br[i] += xr;
+        bi[i] += xi;
+      }
+    }
+  }
+}
+
+// Tables of the long-frame kernels (big.hpp): w_M^j, the master twiddles of the M2-point row transform and, for a
+// frame length that is not a power of two, the chirp exp(-i pi j^2 / n) and B = FFT_M(b wrapped) / M in the PERMUTED
+// order pos(k) = (k & 15) * M2 + (k >> 4) the four-step transform leaves its output in.
+static int build_big(sg_handle* h, bool pow2) {
+  typedef long double ld;
+  const ld PI = 3.14159265358979323846264338327950288L;
+  const int n = h->n;
+  int M = n;
+  if (!pow2) {
+    M = 16384;
+    while (M < 2 * n - 1) M *= 2;
+  }
+  const int M2 = M / 16;
+  h->big_M = M;
+  h->big_czt = pow2 ? 0 : 1;
+  std::vector<cx<double>> twM(M), tw2(M2);
+  for (int j = 0; j < M; ++j) {
+    const ld a = -2.0L * PI * (ld)j / (ld)M;
+    twM[j] = {(double)cosl(a), (double)sinl(a)};
+  }
+  for (int k = 0; k < M2; ++k) {
+    const ld a = -PI * (ld)k / (ld)M2;
+    tw2[k] = {(double)cosl(a), (double)sinl(a)};
+  }
+  int rc = upload(h, h->big_twM, twM.data(), twM.size() * sizeof(cx<double>));
+  if (!rc) rc = upload(h, h->big_tw2, tw2.data(), tw2.size() * sizeof(cx<double>));
+  if (rc || pow2) return rc;
+  std::vector<ld> br(M, 0.0L), bi(M, 0.0L);
+  std::vector<cx<double>> ch(n), bh(M);
+  for (int j = 0; j < n; ++j) {
+    const int64_t q = ((int64_t)j * j) % (2 * (int64_t)n);
+    const ld a = PI * (ld)q / (ld)n;
+    ch[j] = {(double)cosl(a), (double)-sinl(a)};
+    br[j] = cosl(a);
+    bi[j] = sinl(a);
+    if (j) {
+      br[M - j] = br[j];
+      bi[M - j] = bi[j];
+    }
+  }
+  host_fft(br, bi);
+  for (int k = 0; k < M; ++k)
+    bh[(size_t)(k & 15) * M2 + (k >> 4)] = {(double)(br[k] / (ld)M), (double)(bi[k] / (ld)M)};
+  rc = upload(h, h->big_ch, ch.data(), ch.size() * sizeof(cx<double>));
+  if (!rc) rc = upload(h, h->big_bh, bh.data(), bh.size() * sizeof(cx<double>));
+  return rc;
+}
+
 extern "C" int sg_create(const sg_params* p, const double* window_host, sg_handle** out) {
   if (!p || !out) {
     g_create_error = "sg_create: null argument";
@@ -578,11 +775,13 @@ extern "C" int sg_create(const sg_params* p, const double* window_host, sg_handl
   };
   int n = p->n_fft;
   // powers of two 64..8192 run on the Stockham kernels; every other length 4..4096 on the chirp-z
-  // kernels (czt.hpp)
+  // kernels (czt.hpp); longer frames -- powers of two up to 65536, any other length up to 32768 -- on the
+  // four-step transform through HBM (big.hpp)
   const bool pow2 = n >= 64 && (n & (n - 1)) == 0;
-  if (n < 4 || (pow2 && n > 8192) || (!pow2 && n > 4096))
+  const bool bigf = (pow2 && n > 8192) || (!pow2 && n > 4096);
+  if (n < 4 || (pow2 && n > 65536) || (!pow2 && n > 32768))
     return bad(SG_E_UNSUPPORTED,
-               fmt("n_fft=%d unsupported: must be in [4, 4096], or a power of two up to 8192", n));
+               fmt("n_fft=%d unsupported: must be in [4, 32768], or a power of two up to 65536", n));
   if (p->win_length < 2 || p->win_length > n)
     return bad(SG_E_INVALID, fmt("win_length=%d must be in [2, n_fft=%d]", p->win_length, n));
   if (p->hop_length < 1 || p->hop_length > p->win_length)
@@ -670,7 +869,8 @@ extern "C" int sg_create(const sg_params* p, const double* window_host, sg_handl
   if (!rc) rc = upload(h, h->wa32, wa32.data(), wa32.size() * sizeof(float));
   if (!rc) rc = upload(h, h->ws32, ws32.data(), ws32.size() * sizeof(float));
   if (!rc) rc = upload(h, h->wsq32, wsq32.data(), wsq32.size() * sizeof(float));
-  if (!rc && !pow2) rc = build_czt(h);
+  if (!rc && bigf) rc = build_big(h, pow2);
+  else if (!rc && !pow2) rc = build_czt(h);
   if (!rc && p->smooth_mask) {
     auto vf = triangle(p->n_grad_freq), vt = triangle(p->n_grad_time);
     double sf = 0, stt = 0;
@@ -765,7 +965,8 @@ extern "C" int sg_destroy(sg_handle* h) {
                     &h->P, &h->pmax, &h->thr_rows, &h->raw, &h->M, &h->seg, &h->yn, &h->bits, &h->K16, &h->umax,
                     &h->need, &h->T2, &h->part, &h->tw512, &h->invn, &h->seam, &h->ftab, &h->xbits, &h->xpart,
                     &h->xticket, &h->xtick2, &h->ftab3, &h->xexp, &h->nsp, &h->nsc, &h->xin, &h->czt_tw64, &h->czt_ch64,
-                    &h->czt_bh64, &h->czt_tw32, &h->czt_ch32, &h->czt_bh32, &h->logtab})
+                    &h->czt_bh64, &h->czt_tw32, &h->czt_ch32, &h->czt_bh32, &h->logtab, &h->big_twM, &h->big_tw2,
+                    &h->big_ch, &h->big_bh, &h->big_W, &h->big_W2})
     free_buf(*b);
   delete h;
   return SG_OK;

@@ -65,6 +65,16 @@ S_CASES = {
                                            prop_decrease=0.7)),
     "stat_nfft8192": dict(sr=48000, n=70000, seed=28, kwargs=dict(stationary=True, n_fft=8192)),
     "nonstat_nfft8192": dict(sr=48000, n=70000, seed=29, kwargs=dict(stationary=False, n_fft=8192)),
+    # long frames (round 3: four-step transform through HBM): powers of two > 8192, other lengths > 4096
+    "stat_nfft16384": dict(sr=48000, n=100000, seed=61,
+                           kwargs=dict(stationary=True, n_fft=16384, time_mask_smooth_ms=200)),
+    "nonstat_nfft5000": dict(sr=48000, n=60000, seed=62, kwargs=dict(stationary=False, n_fft=5000)),
+    "stat_nfft32768_chunks": dict(sr=48000, n=130000, seed=63,
+                                  kwargs=dict(stationary=True, n_fft=32768, time_mask_smooth_ms=400, chunk_size=60000,
+                                              padding=20000, prop_decrease=0.9)),
+    "nonstat_nfft12000_geom": dict(sr=44100, n=80000, seed=64,
+                                   kwargs=dict(stationary=False, n_fft=12000, win_length=10000, hop_length=2500,
+                                               time_mask_smooth_ms=120)),
 }
 
 
@@ -103,6 +113,10 @@ T_CASES = {
     # odd n_fft with a length that is a multiple of the hop: torch.stft pads one sample less than a frame,
     # so there is one frame fewer than 1 + L // hop
     "stat_nfft601_hopmult": dict(sr=16000, B=2, L=9000, seed=41, kwargs=dict(n_fft=601, hop_length=150)),
+    # long frames
+    "stat_nfft16384": dict(sr=48000, B=2, L=40000, seed=42, kwargs=dict(n_fft=16384, time_mask_smooth_ms=200)),
+    "nonstat_nfft6000": dict(sr=48000, B=2, L=30000, seed=43,
+                             kwargs=dict(nonstationary=True, n_fft=6000, n_movemean_nonstationary=5)),
 }
 
 

@@ -363,9 +363,9 @@ def test_short_and_ragged_inputs(nr):
         assert O.rel_err(nr.reduce_noise(y=y, sr=48000, **kw), O.reduce_noise_S(y, 48000, **kw)) < TOL
     with pytest.raises(ValueError):
         nr.reduce_noise(y=np.zeros(500), sr=48000, stationary=True)      # shorter than win_length
-    for n_fft in (5000, 16384):   # beyond the chirp-z range (4096) / the largest Stockham size (8192)
+    for n_fft in (40000, 131072):   # beyond the long-frame kernels: any length <= 32768, powers of two <= 65536
         with pytest.raises(NotImplementedError):
-            nr.reduce_noise(y=np.zeros(40000), sr=48000, stationary=True, n_fft=n_fft, time_mask_smooth_ms=200)
+            nr.reduce_noise(y=np.zeros(300000), sr=48000, stationary=True, n_fft=n_fft, time_mask_smooth_ms=2000)
 
 
 def test_use_torch_routing(nr):

@@ -160,3 +160,51 @@ def test_workspace_regrow_is_zeroed(nr):
             got = nr.reduce_noise(y=y, sr=48000, stationary=stationary, chunk_size=50000, padding=4000)
             want = O.reduce_noise_S(y.astype(np.float64), 48000, stationary=stationary, chunk_size=50000, padding=4000)
             assert O.rel_err(got, want) < TOL
+
+
+# ---------------------------------------------------------------------------------------------
+# long frames: the four-step transform through HBM (big.hpp)
+# ---------------------------------------------------------------------------------------------
+@pytest.mark.parametrize("n_fft,kw", [
+    (4097, dict()),                                            # first length beyond the per-workgroup chirp-z kernels (M = 16384)
+    (8193, dict(time_mask_smooth_ms=100)),                     # M = 32768
+    (16384, dict(time_mask_smooth_ms=200)),                    # power of two, direct (M = n)
+    (20000, dict(time_mask_smooth_ms=300, win_length=16000, hop_length=3000)),   # M = 65536, window shorter than the frame
+    (32768, dict(time_mask_smooth_ms=400)),
+    (65536, dict(time_mask_smooth_ms=800, freq_mask_smooth_hz=None)),           # the largest frame
+])
+@pytest.mark.parametrize("stationary", [True, False])
+def test_long_frames_match_the_oracle(nr, n_fft, kw, stationary):
+    """reduce_noise with n_fft beyond 8192 (or beyond 4096 and not a power of two) against the oracle (base.py:77-86
+    accepts any n_fft; scipy.signal.stft/istft use rfft(n)/irfft(n))."""
+    n = max(6 * n_fft, 90000)
+    y = O.synth_signal(n, seed=n_fft).astype(np.float32)
+    args = dict(stationary=stationary, n_fft=n_fft, chunk_size=max(50000, 3 * n_fft), padding=max(6000, n_fft), **kw)
+    got = nr.reduce_noise(y=y, sr=48000, **args)
+    want = O.reduce_noise_S(y.astype(np.float64), 48000, **args)
+    assert got.shape == y.shape and got.dtype == y.dtype
+    assert O.rel_err(got, want) < TOL
+
+
+def test_long_frames_stft_tap(nr):
+    """The STFT tap (sg_stft) on a long chirp-z frame and a long power-of-two frame against scipy-style STFT of the oracle."""
+    from noisereduce_amd import _ffi
+    for n_fft in (5000, 16384):
+        x = O.synth_signal(4 * n_fft + 123, seed=3).astype(np.float64)
+        g = _ffi.Gate("cuda", variant=_ffi.SG_VARIANT_S, stationary=True, n_fft=n_fft, win_length=n_fft, hop_length=n_fft // 4)
+        Z = g.stft(torch.from_numpy(x)[None].cuda())[0].cpu().numpy().T     # (F, T)
+        Zo = O.stft_scipy(x, n_fft, n_fft, n_fft // 4)
+        assert Z.shape == Zo.shape
+        assert np.max(np.abs(Z - Zo)) < 1e-12 * max(1.0, np.max(np.abs(Zo)))
+        g.close()
+
+
+def test_torchgate_long_frames(nr):
+    from noisereduce_amd.torchgate import TorchGate
+    for n_fft, kw in ((16384, dict(time_mask_smooth_ms=200)), (6000, dict(nonstationary=True, n_movemean_nonstationary=5))):
+        x = np.stack([O.synth_signal(3 * n_fft + 777, sr=48000, seed=s) for s in range(3)]).astype(np.float64)
+        tg = TorchGate(sr=48000, n_fft=n_fft, **kw).cuda()
+        got = tg(torch.from_numpy(x).cuda()).cpu().numpy()
+        want = O.torchgate_T(x, 48000, n_fft=n_fft, window=torch.hann_window(n_fft).double().numpy(), **kw)
+        assert got.shape == want.shape
+        assert O.rel_err(got, want) < TOL
