@@ -1622,6 +1622,42 @@ static int stage_onepass(sg_handle* h, const View& v, const View& vx, const Geom
   P.inv_ktot = 1.0f / (float)h->ktot;
   P.mconst = (const unsigned long long*)h->ftab3.p;
   P.exp8 = (const unsigned long long*)h->xexp.p;
+#if OP_TRACE
+  {
+    // development builds: one process-wide device trace [workgroup][wave][16], overwritten by every launch, averaged at exit
+    static unsigned* tr = nullptr;
+    static size_t tr_slots = 0;
+    const size_t slots = (size_t)ub * ntt * 4;
+    if (!tr || tr_slots < slots) {
+      HIPCHK(h, hipMalloc((void**)&tr, slots * 64));
+      tr_slots = slots;
+      static unsigned** trp = &tr;
+      static size_t* trn = &tr_slots;
+      static bool reg = false;
+      if (!reg) {
+        reg = true;
+        atexit([] {
+          std::vector<unsigned> hst(*trn * 16);
+          if (hipMemcpy(hst.data(), *trp, hst.size() * 4, hipMemcpyDeviceToHost) != hipSuccess) return;
+          double sum[14] = {0}, w = 0, mx = 0;
+          for (size_t i = 0; i < *trn; ++i) {
+            if (hst[i * 16 + 15] != 1u) continue;
+            w += 1;
+            double tot = 0;
+            for (int k = 0; k < 14; ++k) { sum[k] += hst[i * 16 + k]; tot += hst[i * 16 + k]; }
+            mx = std::max(mx, tot);
+          }
+          fprintf(stderr, "[OP_TRACE] completed waves %.0f; average shader cycles per wave and phase:", w);
+          double tot = 0;
+          for (int k = 0; k < 14; ++k) { fprintf(stderr, " %d:%.0f", k, sum[k] / (w > 0 ? w : 1)); tot += sum[k] / (w > 0 ? w : 1); }
+          fprintf(stderr, "  sum %.0f  longest wave %.0f\n", tot, mx);
+        });
+      }
+    }
+    HIPCHK(h, hipMemsetAsync(tr, 0, slots * 64, st));
+    P.trace = tr;
+  }
+#endif
   {
     ProfScope ps(h, SG_STAGE_ONEPASS, st);
     const size_t lds = (size_t)(fast::FN + WAVES * fast::WAVE_CX_H) * sizeof(fast::cf) + (1024 + T2_FLOATS) * sizeof(float) +

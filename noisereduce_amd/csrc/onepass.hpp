@@ -38,6 +38,9 @@ constexpr int OP_TILE_WORDS = 16 * OP_XW * 2;  // payload of one tile: 288 tagge
 constexpr int OP_MAX_NT = 16;            // neighbours hold 16 frames each
 constexpr int OP_KP = 528;               // K row pitch (uint16 entries) of a wave's private K tile
 
+#ifndef OP_TRACE
+#define OP_TRACE 0
+#endif
 struct OnePassArgs {
   ApplyArgs A;              // view, geometry, output map, tables, seam buffer (A.K / A.Mf unused)
   View view_exact;          // the caller's samples in their own dtype (A.view may be a float32 copy): exact refinement
@@ -55,6 +58,9 @@ struct OnePassArgs {
   unsigned long long* part2;  // [units][n_tiles][3][256] trailing partial hops of every tile: granules {float, epoch}
   const unsigned long long* mconst;  // [3][64] per-lane MFMA operands: freq band B, time weights A (slots 0..31, 32..63)
   const unsigned long long* exp8;    // [256]: byte v -> 8 bytes (v >> e) & 1
+#if OP_TRACE
+  unsigned* trace;                   // [workgroups][4 waves][16] shader cycles per phase (slot 15 = 1: tile completed): development builds
+#endif
 };
 
 // exact float64 |X[f]|^2 of frame t (see k_decide_fast)
@@ -84,6 +90,21 @@ __device__ __forceinline__ double op_exact_power(const OnePassArgs& P, int64_t r
 #ifndef OP_ABLATE
 #define OP_ABLATE 0
 #endif
+// OP_TRACE (development only): per-phase shader-clock stamps of every non-halo wave, summed into P.trace (tools/
+// trace_onepass.sh): where a tile's lifetime goes
+#ifndef OP_TRACE
+#define OP_TRACE 0
+#endif
+#if OP_TRACE
+#define OP_STAMP(i)                                                                                   \
+  do {                                                                                                \
+    const long long t_now_ = clock64();                                                               \
+    if (lane == 0 && t_slot_) t_slot_[i] = (unsigned)(t_now_ - t_prev_);                              \
+    t_prev_ = t_now_;                                                                                 \
+  } while (0)
+#else
+#define OP_STAMP(i) do { } while (0)
+#endif
 
 // PROP: prop_decrease < 1 (stationary.py:108-114 applies it BEFORE the smoothing: mask = p K / ktot + (1 - p) edge,
 // edge = the smoothing filter's weight inside the spectrogram -- 1 except near its borders)
@@ -106,6 +127,10 @@ __global__ __launch_bounds__(WAVES * 64, 3) void k_gate_onepass(OnePassArgs P) {
   const int lane = tid & 63, wave = tid >> 6;
   const int g = lane >> 4, c = lane & 15;
   const int nt = P.nt;
+#if OP_TRACE
+  long long t_prev_ = clock64();
+  unsigned* t_slot_ = nullptr;   // known once the ticket is
+#endif
 
   double t2pre[3];   // compare constants of entries tid, tid + 256 and 512 (they do not depend on the ticket)
   {
@@ -135,6 +160,10 @@ __global__ __launch_bounds__(WAVES * 64, 3) void k_gate_onepass(OnePassArgs P) {
   __syncthreads();
   const int ntt = A.n_tiles + 2;                 // tiles per unit incl. one decide-only halo tile per side
   const unsigned ticket = s_misc[0];
+#if OP_TRACE
+  t_slot_ = P.trace + ((size_t)ticket * 4 + wave) * 16;
+#endif
+  OP_STAMP(0);   // tables + ticket
   const int64_t u = ticket / (unsigned)ntt;
   const int jt = (int)(ticket % (unsigned)ntt) - 1;   // -1 and n_tiles: halo tiles
   const bool halo_tile = jt < 0 || jt >= A.n_tiles;
@@ -204,6 +233,7 @@ __global__ __launch_bounds__(WAVES * 64, 3) void k_gate_onepass(OnePassArgs P) {
     }
   }
   __syncthreads();  // tables, compare constants and span staged
+  OP_STAMP(1);   // span + compare constants
 
   // ---- gather: v[r] = (x[2c + 32r], x[2c + 32r + 1]) * window ---------------------------------------
   cf v[32];
@@ -229,6 +259,7 @@ __global__ __launch_bounds__(WAVES * 64, 3) void k_gate_onepass(OnePassArgs P) {
     }
   }
   __syncthreads();  // every lane has its samples: the span may be overwritten by the exchanges
+  OP_STAMP(2);   // gather
   {
 #pragma unroll
     for (int r = 0; r < 32; ++r) nrm2 += v[r].x * v[r].x + v[r].y * v[r].y;
@@ -244,6 +275,7 @@ __global__ __launch_bounds__(WAVES * 64, 3) void k_gate_onepass(OnePassArgs P) {
     asm volatile("" : "+v"(z0));
     fft512_fwd_half(v, fb, tw512 + z0, c);
   }
+  OP_STAMP(3);   // forward transform
 
   // ---- decide (k_decide_fast): mask bits of this lane's 32 entries -----------------------------------
   // ---- real-FFT split, ONCE: conjugate pair (a, b) = (Zc[k], Zc[N-k]) -> X2[k] = E + w O, conj-pair value
@@ -273,6 +305,7 @@ __global__ __launch_bounds__(WAVES * 64, 3) void k_gate_onepass(OnePassArgs P) {
     }
   }
 
+  OP_STAMP(4);   // split
   // ---- decide (k_decide_fast): mask bits of this lane's 32 entries -----------------------------------
   unsigned long long myword;  // lane c < 9 of group g: word c of frame tq + g
   {
@@ -395,6 +428,7 @@ __global__ __launch_bounds__(WAVES * 64, 3) void k_gate_onepass(OnePassArgs P) {
     }
   }
 
+  OP_STAMP(5);   // decide (+ refinement) + transpose
   // ---- publish this tile's bits; the spectra stay in v[] ---------------------------------------------
   unsigned long long* xb_mine = P.xbits + ((size_t)u * ntt + (jt + 1)) * OP_TILE_WORDS;
   // data-tagged granules: every 8-byte store carries 32 mask bits and the launch epoch.  A consumer polls the
@@ -406,6 +440,7 @@ __global__ __launch_bounds__(WAVES * 64, 3) void k_gate_onepass(OnePassArgs P) {
   }
   __syncthreads();   // every wave is past its forward exchange: the slices are idle from here
   if (halo_tile) return;
+  OP_STAMP(6);   // publish + barrier
 
   // ---- smoothing on the matrix cores (exact integer arithmetic, v_mfma_i32_16x16x32_i8) ----------------
   // The separable triangle filter is two small dense contractions per 16-bin block:
@@ -453,6 +488,7 @@ __global__ __launch_bounds__(WAVES * 64, 3) void k_gate_onepass(OnePassArgs P) {
       }
     }
   }
+  OP_STAMP(7);   // zero fill + barrier + own rows on the matrix cores
   // neighbour rows: one 16-byte load per 64-bit word (2 nt x 9 words <= 288: at most two per thread), polled
   // until both tags are current
   for (int i = tid; i < 2 * nt * OP_XW; i += WAVES * 64) {
@@ -473,6 +509,7 @@ __global__ __launch_bounds__(WAVES * 64, 3) void k_gate_onepass(OnePassArgs P) {
     wb[(side ? nt + NF + rr : rr) * WP + 1 + w] = (unsigned long long)gr[0] | ((unsigned long long)gr[2] << 32);
   }
   __syncthreads();
+  OP_STAMP(8);   // neighbours' bits (poll) + barrier
   {
     const unsigned char* rp1 = wbb + r1 * WPB + 7 + q4;
     const unsigned char* rp2 = wbb + r2 * WPB + 7 + q4;
@@ -501,6 +538,7 @@ __global__ __launch_bounds__(WAVES * 64, 3) void k_gate_onepass(OnePassArgs P) {
     }
   }
   __syncthreads();  // K of all 16 frames complete; from here every wave touches only its own slice
+  OP_STAMP(9);   // smoothing on the matrix cores + barrier
 
   const unsigned short* kt = reinterpret_cast<const unsigned short*>(rbytes + wave * (SLICE_B + 64));
   // entry e of this lane = bin c + 32 e (e < 16) or (32 - c) + 32 (e - 16); lane 0 pairs its bins
@@ -567,6 +605,7 @@ __global__ __launch_bounds__(WAVES * 64, 3) void k_gate_onepass(OnePassArgs P) {
     v[31] = sel(pb[8], pb[0]);
   }
   wave_lds_sync();  // K tile consumed: the slice is reused by the inverse transform
+  OP_STAMP(10);  // mask + merge
 
   // ---- inverse transform, synthesis window, wave-private overlap-add (k_apply_fast<LEAN>) -------------
   {
@@ -576,6 +615,7 @@ __global__ __launch_bounds__(WAVES * 64, 3) void k_gate_onepass(OnePassArgs P) {
     asm volatile("" : "+v"(zi), "+v"(ci));
     fft512_inv_half(v, fb + zi, tw512 + zi, ci);
   }
+  OP_STAMP(11);  // inverse transform
   float* acc = reinterpret_cast<float*>(regions + wave * WAVE_CX_H);
   {
     const float2* wsrc2 = reinterpret_cast<const float2*>(swin + 2 * c);
@@ -597,6 +637,10 @@ __global__ __launch_bounds__(WAVES * 64, 3) void k_gate_onepass(OnePassArgs P) {
   }
   const float4 n4 = *reinterpret_cast<const float4*>(&A.invn[(tid & 63) * 4]);
   __syncthreads();
+  OP_STAMP(12);  // window + wave-private overlap-add + barrier
+#if OP_TRACE
+  if (lane == 0) t_slot_[15] = 1u;
+#endif
 
   // ---- cross-wave combine, normalise, store (seam mode: abutting tiles) -------------------------------
   const float* fr = reinterpret_cast<const float*>(regions);
@@ -626,6 +670,7 @@ __global__ __launch_bounds__(WAVES * 64, 3) void k_gate_onepass(OnePassArgs P) {
       if (wave == 3) {
 #pragma unroll
         for (int it = 0; it < 4; ++it) fin(ld4(it * R + 3 * HPITCH), 3 + 4 * it);
+        OP_STAMP(13);
         return;
       }
       {
@@ -664,6 +709,7 @@ __global__ __launch_bounds__(WAVES * 64, 3) void k_gate_onepass(OnePassArgs P) {
         a4.w = __uint_as_float(gb[2]) + a4.w;
         fin(a4, wave);
       }
+      OP_STAMP(13);  // cross-wave combine, hand-off of the straddling hops, stores
       return;
     }
   }
