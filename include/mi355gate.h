@@ -102,7 +102,9 @@ SG_API int sg_output_length(const sg_handle* h, int64_t L, int64_t* out_len);
 /* Workspace (bytes of HBM) the handle will own after an sg_process_chunks call on a (C, N) recording
  * (chunked as in sg_process_chunks) -- so that a caller can budget device memory next to the recording
  * (base.py:180-216 streams through a memmap instead; here units are processed in batches bounded by
- * sg_params.max_workspace_bytes).  Pure host arithmetic, no device work. */
+ * sg_params.max_workspace_bytes).  An upper bound: it includes the exchange buffers of the fused kernels and the
+ * float32 copy that a recording of another sample type (int16 / int32 / float64) costs on the default geometry --
+ * C * N * 4 bytes, which a float32 recording does not pay.  Pure host arithmetic, no device work. */
 SG_API int sg_workspace_bytes(const sg_handle* h, int64_t C, int64_t N, int32_t chunked, int64_t* bytes);
 
 /* ---- variant S -------------------------------------------------------------------- */
@@ -189,6 +191,10 @@ SG_API int sg_debug_fetch(sg_handle* h, int32_t what, void* host, int64_t bytes,
 #define SG_OPT_FORCE_NOSEAM 4   /* value != 0: overlapping apply tiles instead of abutting tiles + seam kernel */
 #define SG_OPT_FORCE_NOLEAN 5   /* value != 0: apply kernel with full-size LDS slices and stored frames */
 #define SG_OPT_FORCE_SPLIT 6    /* value != 0: default geometry: decide / smooth / apply as three kernels instead of the one-pass kernel */
+#define SG_OPT_FAST_INTEGER 8   /* value != 0: integer (SG_I16 / SG_I32) outputs from the fused float32 kernels: <= 1 LSB away from
+                                 * the reference on ~1 % of the samples.  Default: the float64 pipeline, whose truncated result IS
+                                 * the reference's (base.py:217-226 casts a float64 array), an order of magnitude slower */
+#define SG_OPT_FORCE_EXACT 9    /* value != 0: float64 pipeline for every output dtype (float64 recordings: float64-accurate results) */
 #define SG_OPT_INJECT_HANDOFF_FAULT 7 /* tests: the next launch with in-launch hand-offs reports `value` (bits 0..2) as lost hand-offs */
 #define SG_OPT_FORCE_NOFAST 2  /* value != 0: keep the bit-mask stages but use the general apply kernels */
 SG_API int sg_set_option(sg_handle* h, int32_t option, int64_t value);

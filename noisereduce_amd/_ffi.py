@@ -26,6 +26,8 @@ SG_OPT_FORCE_NOSEAM = 4
 SG_OPT_FORCE_NOLEAN = 5
 SG_OPT_FORCE_SPLIT = 6
 SG_OPT_INJECT_HANDOFF_FAULT = 7
+SG_OPT_FAST_INTEGER = 8
+SG_OPT_FORCE_EXACT = 9
 SG_OPT_FORCE_UNFUSED = 1
 SG_OPT_FORCE_NOFAST = 2
 
@@ -150,7 +152,7 @@ class Gate:
                  n_grad_freq=1, n_grad_time=1, smooth_mask=False, chunk_size=600000,
                  padding=30000, prop_decrease=1.0, n_std_thresh=1.5, top_db=80.0, ddof=0,
                  n_movemean=20, nonstat_thresh=2.0, nonstat_slope=10.0, iir_b=0.0,
-                 window=None, max_workspace_bytes=0):
+                 window=None, max_workspace_bytes=0, fast_integer=False):
         self.lib = load_library()
         self.device = resolve_device(device)
         p = SgParams(variant=variant, stationary=int(bool(stationary)), n_fft=int(n_fft),
@@ -182,6 +184,8 @@ class Gate:
             msg = self.lib.sg_last_error(None).decode()
             self._h = c_void_p()
             self._raise(rc, msg)
+        if fast_integer:   # integer outputs from the fused float32 kernels (<= 1 LSB off) instead of the float64 pipeline
+            self.set_option(SG_OPT_FAST_INTEGER, 1)
 
     # -- plumbing --------------------------------------------------------------------
     @staticmethod

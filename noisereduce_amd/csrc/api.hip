@@ -25,6 +25,7 @@
 #include "nonstat.hpp"
 #include "fast64.hpp"
 #include "big.hpp"
+#include "exact.hpp"
 
 #ifndef SG_APPLY_WAVES
 #define SG_APPLY_WAVES 4  // wavefronts per workgroup of k_apply_fast: tile = 4*W frames -> 4*W-3 hops
@@ -77,6 +78,9 @@ struct sg_handle {
   unsigned inject_fault = 0;         // SG_OPT_INJECT_HANDOFF_FAULT (tests): error bits the next hand-off launch reports
   unsigned ticket_base = 0;          // tickets handed out by all previous launches
   unsigned epoch = 0;                // launch counter: the value a tile's flag must carry to be current
+  bool fast_integer = false;         // SG_OPT_FAST_INTEGER: integer outputs from the float32 kernels (<= 1 LSB off)
+  bool force_exact = false;          // SG_OPT_FORCE_EXACT: float64 pipeline (exact.hpp) whatever the output dtype
+  DevBuf xP, xraw, xM, xtmp, xseg;   // fields of the exact path
   bool force_split = false;          // SG_OPT_FORCE_SPLIT: decide / smooth / apply as three kernels
   bool dbg_xbits = false;            // the last batch's mask bits live in xbits (tile-blocked)
   int64_t dbg_tf0 = 0;               // first frame of tile 0 of that batch
@@ -510,7 +514,8 @@ static int big_stft(sg_handle* h, const View& v, const Geom& g, int64_t units, d
   return SG_OK;
 }
 
-static int big_apply(sg_handle* h, const View& v, const Geom& g, int64_t units, const float* Mk, float* seg,
+template <typename TM, typename TS>
+static int big_apply(sg_handle* h, const View& v, const Geom& g, int64_t units, const TM* Mk, TS* seg,
                      hipStream_t st) {
   const big::BigTabs tb = big_tabs(h);
   const int64_t total = units * g.T, nb = big_batch(h, total);
@@ -524,7 +529,7 @@ static int big_apply(sg_handle* h, const View& v, const Geom& g, int64_t units, 
                        W, f0, nf);
     HIPCHK(h, hipGetLastError());
     HIPCHK(h, big_dft(W, tb, nf, st));
-    hipLaunchKernelGGL(big::k_big_mask, dim3(64, (unsigned)nf), dim3(256), 0, st, (const big::cd*)W, W2, g, tb, f0, nf, Mk);
+    hipLaunchKernelGGL(big::k_big_mask<TM>, dim3(64, (unsigned)nf), dim3(256), 0, st, (const big::cd*)W, W2, g, tb, f0, nf, Mk);
     HIPCHK(h, hipGetLastError());
     if (tb.czt) {
       HIPCHK(h, big_dft(W2, tb, nf, st));   // inverse DFT = forward chirp-z of conj(Y), conjugated
@@ -534,7 +539,7 @@ static int big_apply(sg_handle* h, const View& v, const Geom& g, int64_t units, 
                          tb, nf);
       HIPCHK(h, hipGetLastError());
     }
-    hipLaunchKernelGGL(big::k_big_seg, dim3(64, (unsigned)nf), dim3(256), 0, st, (const big::cd*)W2, g, tb, f0, nf,
+    hipLaunchKernelGGL(big::k_big_seg<TS>, dim3(64, (unsigned)nf), dim3(256), 0, st, (const big::cd*)W2, g, tb, f0, nf,
                        (const double*)h->wfull64.p, seg);
     HIPCHK(h, hipGetLastError());
   }
@@ -966,7 +971,7 @@ extern "C" int sg_destroy(sg_handle* h) {
                     &h->need, &h->T2, &h->part, &h->tw512, &h->invn, &h->seam, &h->ftab, &h->xbits, &h->xpart,
                     &h->xticket, &h->xtick2, &h->ftab3, &h->xexp, &h->nsp, &h->nsc, &h->xin, &h->czt_tw64, &h->czt_ch64,
                     &h->czt_bh64, &h->czt_tw32, &h->czt_ch32, &h->czt_bh32, &h->logtab, &h->big_twM, &h->big_tw2,
-                    &h->big_ch, &h->big_bh, &h->big_W, &h->big_W2})
+                    &h->big_ch, &h->big_bh, &h->big_W, &h->big_W2, &h->xP, &h->xraw, &h->xM, &h->xtmp, &h->xseg})
     free_buf(*b);
   delete h;
   return SG_OK;
@@ -1680,6 +1685,145 @@ static int stage_onepass(sg_handle* h, const View& v, const View& vx, const Geom
   return SG_OK;
 }
 
+// ------------------------------------------------------------------------------------------
+// exact path (exact.hpp): float64 fields, materialised -- integer outputs (base.py:217-226 truncates a float64 result)
+// ------------------------------------------------------------------------------------------
+template <int N>
+static hipError_t launch_xapply_n(const View& v, const Geom& g, int64_t units, const void* tw, const double* win,
+                                  const double* M, double* seg, hipStream_t st) {
+  constexpr int NT = N >= 4096 ? 256 : 64;
+  constexpr int WAVES = N >= 4096 ? 1 : ((N * sizeof(cx<double>) > 16384) ? 2 : 4);
+  constexpr int FPW = 4;
+  const size_t lds = (size_t)(N + WAVES * lpn<double>(N)) * sizeof(cx<double>);
+  auto kern = exact::kx_apply_istft<N, WAVES, FPW, NT>;
+  if (lds > 65536) {
+    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize,
+                                       (int)lds);
+    if (e != hipSuccess) return e;
+  }
+  dim3 grid((unsigned)((g.T + WAVES * FPW - 1) / (WAVES * FPW)), (unsigned)units);
+  hipLaunchKernelGGL(kern, grid, dim3(WAVES * NT), lds, st, v, g, (const cx<double>*)tw, win, M, seg);
+  return hipGetLastError();
+}
+
+template <int M>
+static hipError_t launch_xapply_czt_m(const View& v, const Geom& g, int64_t units, const CztTabs<double>& tb,
+                                      const double* win, const double* Mk, double* seg, hipStream_t st) {
+  constexpr int NT = CztShape<M>::NT, FR = CztShape<M>::FR;
+  const size_t lds = (size_t)FR * lpn<double>(M) * sizeof(cx<double>);
+  auto kern = exact::kx_apply_istft_czt<M, NT, FR>;
+  if (lds > 65536) {
+    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize,
+                                       (int)lds);
+    if (e != hipSuccess) return e;
+  }
+  const int fpb = 4;
+  dim3 grid((unsigned)((g.T + FR * fpb - 1) / (FR * fpb)), (unsigned)units);
+  hipLaunchKernelGGL(kern, grid, dim3(NT * FR), lds, st, v, g, tb, win, Mk, seg, fpb);
+  return hipGetLastError();
+}
+
+static hipError_t xapply_any(sg_handle* h, const View& v, const Geom& g, int64_t units, const double* Mk, double* seg,
+                             hipStream_t st) {
+  const double* win = (const double*)h->wfull64.p;
+  if (h->big_M) {
+    const int rc = big_apply<double, double>(h, v, g, units, Mk, seg, st);
+    return rc == SG_OK ? hipSuccess : (rc == SG_E_NOMEM ? hipErrorOutOfMemory : hipErrorUnknown);
+  }
+  if (h->czt_M) {
+    const CztTabs<double> tb = czt_tabs<double>(h);
+#define SG_CALL(M) launch_xapply_czt_m<M>(v, g, units, tb, win, Mk, seg, st)
+    SG_CZT_SWITCH(h->czt_M, SG_CALL);
+#undef SG_CALL
+  }
+  switch (h->N) {
+    case 32: return launch_xapply_n<32>(v, g, units, h->tw64.p, win, Mk, seg, st);
+    case 64: return launch_xapply_n<64>(v, g, units, h->tw64.p, win, Mk, seg, st);
+    case 128: return launch_xapply_n<128>(v, g, units, h->tw64.p, win, Mk, seg, st);
+    case 256: return launch_xapply_n<256>(v, g, units, h->tw64.p, win, Mk, seg, st);
+    case 512: return launch_xapply_n<512>(v, g, units, h->tw64.p, win, Mk, seg, st);
+    case 1024: return launch_xapply_n<1024>(v, g, units, h->tw64.p, win, Mk, seg, st);
+    case 2048: return launch_xapply_n<2048>(v, g, units, h->tw64.p, win, Mk, seg, st);
+    case 4096: return launch_xapply_n<4096>(v, g, units, h->tw64.p, win, Mk, seg, st);
+  }
+  return hipErrorInvalidValue;
+}
+
+static int run_S_exact(sg_handle* h, View v, int64_t total_units, const OutMap& om, hipStream_t st) {
+  const Geom g = make_geom(h, v.Lp);
+  const size_t cells1 = (size_t)g.T * g.FS;
+  // P, raw, M, tmp (8 B per cell each) + frames (8 B per sample of every frame) + the statistics rows
+  const size_t per_unit = cells1 * 32 + (size_t)g.T * g.n * 8 + (size_t)g.FS * 16;
+  int64_t ub = std::max<int64_t>(1, std::min<int64_t>(std::min<int64_t>(ws_budget(h) / (int64_t)per_unit, 32768), total_units));
+  int rc;
+  const size_t cells = (size_t)ub * cells1;
+  if ((rc = ensure(h, h->xP, cells * 8))) return rc;
+  if ((rc = ensure(h, h->xraw, cells * 8))) return rc;
+  if ((rc = ensure(h, h->xM, cells * 8))) return rc;
+  if ((rc = ensure(h, h->xtmp, cells * 8))) return rc;
+  if ((rc = ensure(h, h->xseg, (size_t)ub * g.T * g.n * 8))) return rc;
+  if ((rc = ensure(h, h->pmax, (size_t)ub * g.FS * 8))) return rc;
+  const int nf = h->p.n_grad_freq, nt = h->p.n_grad_time;
+  const double p = h->p.prop_decrease;
+  double* P = (double*)h->xP.p;
+  for (int64_t u0 = 0; u0 < total_units; u0 += ub) {
+    const int64_t nb = std::min(ub, total_units - u0);
+    v.unit0 = u0;
+    const int64_t ncell = nb * g.T * g.FS;
+    {
+      ProfScope ps(h, SG_STAGE_STFT_POWER, st);
+      if (h->p.stationary) HIPCHK(h, hipMemsetAsync(h->pmax.p, 0, (size_t)nb * g.FS * 8, st));
+      HIPCHK(h, stft_any<double>(h, v, g, nb, P, nullptr, nullptr, 1.0, st,
+                                 h->p.stationary ? (unsigned long long*)h->pmax.p : nullptr));
+    }
+    const int prop_before = h->p.stationary ? 1 : 0;
+    if (h->p.stationary) {
+      ProfScope ps(h, SG_STAGE_DECIDE, st);
+      hipLaunchKernelGGL(k_decide, dim3(grid_1d(ncell, 256)), dim3(256), 0, st, (const double*)P, g,
+                         (const double*)h->pmax.p, (const double*)h->thresh.p, (int64_t)0, h->mag_scale, h->p.top_db,
+                         (float*)h->xraw.p, nb);
+      HIPCHK(h, hipGetLastError());
+    } else {
+      ProfScope ps(h, SG_STAGE_NONSTAT_MASK, st);
+      hipLaunchKernelGGL(exact::kx_iir_sigmoid, dim3((unsigned)((g.F + 63) / 64), (unsigned)nb), dim3(64), 0, st,
+                         (const double*)P, g, h->p.iir_b, h->p.nonstat_thresh, h->p.nonstat_slope, (double*)h->xraw.p);
+      HIPCHK(h, hipGetLastError());
+    }
+    {
+      ProfScope ps(h, SG_STAGE_SMOOTH, st);
+      const dim3 gr(grid_1d(ncell, 256));
+      if (!h->p.smooth_mask) {
+        if (h->p.stationary)
+          hipLaunchKernelGGL(exact::kx_prop_only<float>, gr, dim3(256), 0, st, (const float*)h->xraw.p, g, p, (double*)h->xM.p, nb);
+        else
+          hipLaunchKernelGGL(exact::kx_prop_only<double>, gr, dim3(256), 0, st, (const double*)h->xraw.p, g, p, (double*)h->xM.p, nb);
+      } else {
+        if (h->p.stationary)
+          hipLaunchKernelGGL(exact::kx_smooth_f<float>, gr, dim3(256), 0, st, (const float*)h->xraw.p, g, nf, (double*)h->xtmp.p, nb);
+        else
+          hipLaunchKernelGGL(exact::kx_smooth_f<double>, gr, dim3(256), 0, st, (const double*)h->xraw.p, g, nf, (double*)h->xtmp.p, nb);
+        HIPCHK(h, hipGetLastError());
+        hipLaunchKernelGGL(exact::kx_smooth_t, gr, dim3(256), 0, st, (const double*)h->xtmp.p, g, nt, nf, p, prop_before,
+                           (double*)h->xM.p, nb);
+      }
+      HIPCHK(h, hipGetLastError());
+    }
+    {
+      ProfScope ps(h, SG_STAGE_APPLY_ISTFT, st);
+      HIPCHK(h, xapply_any(h, v, g, nb, (const double*)h->xM.p, (double*)h->xseg.p, st));
+    }
+    const int64_t np = om.p1 - om.p0;
+    if (np > 0) {
+      ProfScope ps(h, SG_STAGE_OLA, st);
+      hipLaunchKernelGGL(exact::kx_ola, dim3((unsigned)((np + 255) / 256), (unsigned)nb), dim3(256), 0, st, v, g, om,
+                         (const double*)h->xseg.p, (const double*)h->wfull64.p);
+      HIPCHK(h, hipGetLastError());
+    }
+    h->dbg_units = 0;   // the exact path keeps no debug fields
+  }
+  return SG_OK;
+}
+
 // Variant S over a set of units described by `v` (unit0 filled per batch).
 static int run_S(sg_handle* h, View v, int64_t total_units, const OutMap& om, hipStream_t st) {
   Geom g = make_geom(h, v.Lp);
@@ -1687,6 +1831,9 @@ static int run_S(sg_handle* h, View v, int64_t total_units, const OutMap& om, hi
                         (long long)v.Lp, h->W);
   if (h->p.stationary && !h->has_thresh)
     FAIL(h, SG_E_STATE, "stationary gate: call sg_noise_stats or sg_set_noise_threshold first");
+  // integer outputs are the TRUNCATED float64 result of the reference (base.py:217-226): float64 pipeline
+  if (h->force_exact || ((om.dtype == SG_I16 || om.dtype == SG_I32) && !h->fast_integer))
+    return run_S_exact(h, v, total_units, om, st);
   // one-pass gate (any prop_decrease) or, with prop_decrease == 1, the three-kernel bit-mask path: only bit /
   // count fields in the workspace
   const bool onepass = h->fused_ok && !h->force_unfused && h->fast_ok && !h->force_nofast && onepass_ok(h, g, om);
@@ -1773,10 +1920,29 @@ extern "C" int sg_workspace_bytes(const sg_handle* h, int64_t C, int64_t N, int3
   const int64_t units = chunked ? C * ((N + cs - 1) / cs) : C;
   if (Lp < h->W) return SG_E_INVALID;
   const Geom g = make_geom(h, Lp);
-  const bool lean = h->p.variant == SG_VARIANT_S && h->fused_ok && !h->force_unfused && h->fast_ok &&
-                    !h->force_nofast && h->p.prop_decrease == 1.0;
+  // the decisions of run_S: one-pass gate (any prop_decrease) or the three-kernel bit-mask path -> lean workspace
+  const bool geom_fast = h->fast_ok && !h->force_nofast;
+  const bool onepass = h->p.variant == SG_VARIANT_S && h->fused_ok && !h->force_unfused && geom_fast && !h->force_split &&
+                       !h->force_f64_decide && !h->force_noseam && !h->force_nolean && h->p.smooth_mask &&
+                       h->p.n_grad_freq <= 8 && h->p.n_grad_time <= fast::OP_MAX_NT && h->ftab3.p != nullptr;
+  const bool lean = h->p.variant == SG_VARIANT_S && h->fused_ok && !h->force_unfused && geom_fast &&
+                    (onepass || h->p.prop_decrease == 1.0);
   const int64_t ub = units_per_batch(h, g, units, lean);
-  *bytes = ub * (int64_t)unit_bytes(h, g, lean);
+  int64_t total = ub * (int64_t)unit_bytes(h, g, lean);
+  if (geom_fast) {
+    // exchange buffers of the in-launch hand-offs (tagged granules): mask bits (one-pass gate) and partial hops
+    const int64_t kept = chunked ? cs : N;
+    const int64_t n_tiles = (kept / 256 + 1 + 3 + 15) / 16 + 1;
+    total += ub * n_tiles * 3 * 256 * 8 + ub * 64;
+    if (onepass) total += ub * (n_tiles + 2) * (int64_t)fast::OP_TILE_WORDS * 8;
+    // a recording that is not float32 is converted once (UPPER bound: float32 recordings do not pay this)
+    total += C * N * (int64_t)sizeof(float);
+  }
+  if (h->big_M) {   // long frames: two work buffers of <= 256 MB (big.hpp)
+    const int64_t nb = big_batch(h, units * g.T);
+    total += 2 * nb * (int64_t)h->big_M * (int64_t)sizeof(big::cd);
+  }
+  *bytes = total;
   return SG_OK;
 }
 
@@ -2101,6 +2267,8 @@ extern "C" int sg_set_option(sg_handle* h, int32_t option, int64_t value) {
     case SG_OPT_FORCE_NOSEAM: h->force_noseam = value != 0; return SG_OK;
     case SG_OPT_FORCE_NOLEAN: h->force_nolean = value != 0; return SG_OK;
     case SG_OPT_FORCE_SPLIT: h->force_split = value != 0; return SG_OK;
+    case SG_OPT_FAST_INTEGER: h->fast_integer = value != 0; return SG_OK;
+    case SG_OPT_FORCE_EXACT: h->force_exact = value != 0; return SG_OK;
     case SG_OPT_INJECT_HANDOFF_FAULT: h->inject_fault = (unsigned)value & 7u; return SG_OK;
   }
   FAIL(h, SG_E_INVALID, "sg_set_option: unknown option %d", option);

@@ -166,14 +166,15 @@ __global__ __launch_bounds__(256) void k_big_out(const cd* __restrict__ W, Geom 
 // inverse transform.  Power-of-two frames: Y over all n bins in the permuted layout (bins above n/2 are the
 // conjugates of their mirror bins); chirp-z: conj(Y[k]) * chirp[k] in natural order, zero above n (the inverse DFT
 // is the forward chirp-z of conj(Y), conjugated).  In place except for the mirrored bins, hence the second buffer.
+template <typename TM>
 __global__ __launch_bounds__(256) void k_big_mask(const cd* __restrict__ W, cd* __restrict__ W2, Geom g, BigTabs tb,
-                                                  int64_t f0, int64_t nf, const float* __restrict__ Mk) {
+                                                  int64_t f0, int64_t nf, const TM* __restrict__ Mk) {
   const int64_t f = blockIdx.y;
   if (f >= nf) return;
   const int64_t fl = f0 + f;
   const cd* Wf = W + f * (int64_t)tb.M;
   cd* Of = W2 + f * (int64_t)tb.M;
-  const float* Mrow = Mk + fl * g.FS;
+  const TM* Mrow = Mk + fl * g.FS;
   for (int j = blockIdx.x * 256 + threadIdx.x; j < tb.M; j += gridDim.x * 256) {
     cd z = {0.0, 0.0};
     if (j < g.n) {
@@ -194,8 +195,9 @@ __global__ __launch_bounds__(256) void k_big_mask(const cd* __restrict__ W, cd* 
 }
 
 // time-domain frame * synthesis window (incl. 1 / n) -> seg[u][t][0..n) for k_ola
+template <typename TS>
 __global__ __launch_bounds__(256) void k_big_seg(const cd* __restrict__ W, Geom g, BigTabs tb, int64_t f0, int64_t nf,
-                                                 const double* __restrict__ wfull, float* __restrict__ seg) {
+                                                 const double* __restrict__ wfull, TS* __restrict__ seg) {
   const int64_t f = blockIdx.y;
   if (f >= nf) return;
   const int64_t fl = f0 + f;
@@ -205,7 +207,7 @@ __global__ __launch_bounds__(256) void k_big_seg(const cd* __restrict__ W, Geom 
     double y;
     if (tb.czt) y = cmul(Wf[j], tb.chirp[j]).x;   // Re conj(D) = Re D
     else y = Wf[j].x;
-    seg[fl * (int64_t)g.n + j] = (float)(y * wfull[j] * inv_n);
+    seg[fl * (int64_t)g.n + j] = (TS)(y * wfull[j] * inv_n);
   }
 }
 

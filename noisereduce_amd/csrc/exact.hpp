@@ -1,0 +1,269 @@
+// EXACT path (variant S): the whole gate evaluated in float64, field by field, like the reference does it
+// (spectralgate/base.py:140 allocates float64 chunks; stationary.py:83-127, nonstationary.py:47-97).
+//
+// Why it exists: the reference casts its float64 result to the input dtype (base.py:217-226) -- for int16 / int32
+// recordings (what scipy.io.wavfile.read returns) a TRUNCATION.  A float32 pipeline is accurate to ~2e-7 of peak,
+// which moves about 1 % of the samples of an int16 recording across an integer boundary (+-1 LSB).  Integer outputs
+// therefore take this path by default: float64 power field -> float64 decisions / floor / sigmoid -> float64
+// separable smoothing -> float64 masked inverse transform -> float64 overlap-add -> truncation: the integers of the
+// reference.  It is the materialised pipeline (every field through HBM, 8 bytes per cell): an order of magnitude
+// slower than the fused float32 kernels -- SG_OPT_FAST_INTEGER selects those (<= 1 LSB off on ~1 % of the samples).
+#pragma once
+#include "kernels.hpp"
+#include "czt.hpp"
+
+namespace sg {
+namespace exact {
+
+// (m + 1 - |a|) / (m + 1)^2: one axis of the reference's smoothing filter after its normalisation
+// (base.py:7-29: outer([1..m+1..1] / (m+1)) / sum)
+__device__ __forceinline__ double tap(int m, int a) {
+  const int aa = a < 0 ? -a : a;
+  return (double)(m + 1 - aa) / ((double)(m + 1) * (double)(m + 1));
+}
+
+// Non-stationary raw mask (nonstationary.py:59-76): A = |X| (any common scale cancels), S = filtfilt(one pole)(A)
+// along time, raw = 1 / (1 + exp(-((A - S) / S - thresh) * slope)).  One thread per (unit, band), float64 throughout;
+// the forward pass is parked in `raw`.
+__global__ void kx_iir_sigmoid(const double* __restrict__ P, Geom g, double b, double nthresh, double slope,
+                               double* __restrict__ raw) {
+  const int f = blockIdx.x * blockDim.x + threadIdx.x;
+  const int64_t u = blockIdx.y;
+  if (f >= g.F) return;
+  const double* p = P + u * g.T * g.FS + f;
+  double* r = raw + u * g.T * g.FS + f;
+  const double c = 1.0 - b;
+  double s = sqrt(p[0]);
+  for (int64_t t = 0; t < g.T; ++t) {
+    s = b * sqrt(p[t * g.FS]) + c * s;
+    r[t * g.FS] = s;
+  }
+  // backward pass over the forward output, seeded with its last value (scipy filtfilt, padtype=None)
+  for (int64_t t = g.T - 1; t >= 0; --t) {
+    s = b * r[t * g.FS] + c * s;
+    const double a = sqrt(p[t * g.FS]);
+    r[t * g.FS] = 1.0 / (1.0 + exp(-((a - s) / s - nthresh) * slope));
+  }
+}
+
+// separable triangle smoothing, zero padded ("same"), float64.  TIN: float (0/1 decisions) or double (sigmoid).
+template <typename TIN>
+__global__ void kx_smooth_f(const TIN* __restrict__ raw, Geom g, int nf, double* __restrict__ tmp, int64_t n_units) {
+  const int64_t cells = n_units * g.T * g.FS;
+  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < cells; i += (int64_t)gridDim.x * blockDim.x) {
+    const int f = (int)(i % g.FS);
+    if (f >= g.F) continue;
+    double acc = 0.0;
+    for (int a = -nf; a <= nf; ++a) {
+      const int ff = f + a;
+      if (ff >= 0 && ff < g.F) acc += tap(nf, a) * (double)raw[i + a];
+    }
+    tmp[i] = acc;
+  }
+}
+
+// final = p * conv(raw) + (1 - p) * edge: edge = conv(1) (zero padded) when prop_decrease is applied BEFORE the
+// smoothing (stationary.py:108-114), 1 when it is applied after (nonstationary.py:78-84)
+__global__ void kx_smooth_t(const double* __restrict__ tmp, Geom g, int nt, int nf, double p, int prop_before,
+                            double* __restrict__ M, int64_t n_units) {
+  const int64_t cells = n_units * g.T * g.FS;
+  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < cells; i += (int64_t)gridDim.x * blockDim.x) {
+    const int f = (int)(i % g.FS);
+    if (f >= g.F) continue;
+    const int64_t t = (i / g.FS) % g.T;
+    double acc = 0.0, et = 0.0;
+    for (int b = -nt; b <= nt; ++b) {
+      const int64_t tt = t + b;
+      if (tt >= 0 && tt < g.T) {
+        acc += tap(nt, b) * tmp[i + (int64_t)b * g.FS];
+        et += tap(nt, b);
+      }
+    }
+    double edge = 1.0;
+    if (prop_before) {
+      double ef = 0.0;
+      for (int a = -nf; a <= nf; ++a)
+        if (f + a >= 0 && f + a < g.F) ef += tap(nf, a);
+      edge = ef * et;
+    }
+    M[i] = p * acc + (1.0 - p) * edge;
+  }
+}
+
+template <typename TIN>
+__global__ void kx_prop_only(const TIN* __restrict__ raw, Geom g, double p, double* __restrict__ M, int64_t n_units) {
+  const int64_t cells = n_units * g.T * g.FS;
+  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < cells; i += (int64_t)gridDim.x * blockDim.x) {
+    const int f = (int)(i % g.FS);
+    if (f >= g.F) continue;
+    M[i] = p * (double)raw[i] + (1.0 - p);
+  }
+}
+
+// Apply + inverse in float64 (k_apply_istft of kernels.hpp with every type widened): frame -> FFT -> X * M[t][k] ->
+// inverse FFT -> synthesis window (win / N: the half-size complex core leaves a factor N = n / 2) -> seg[u][t][0..n).
+template <int N, int WAVES, int FPW, int NT = 64>
+__global__ __launch_bounds__(WAVES * NT) void kx_apply_istft(View view, Geom g, const cx<double>* __restrict__ tw_g,
+                                                             const double* __restrict__ win,
+                                                             const double* __restrict__ M, double* __restrict__ seg) {
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  typedef cx<double> cd;
+  cd* tw = reinterpret_cast<cd*>(smem);
+  cd* bufs = tw + N;
+  const int lane = threadIdx.x % NT;
+  const int wave = threadIdx.x / NT;
+  cd* buf = bufs + wave * lpn<double>(N);
+  for (int i = threadIdx.x; i < N; i += WAVES * NT) tw[i] = tw_g[i];
+  const int64_t u = blockIdx.y;
+  const int64_t row = (view.unit0 + u) / view.n_chunks;
+  const int64_t chunk = view.c0 + (view.unit0 + u) % view.n_chunks;
+  const double inv_n = 1.0 / (double)N;
+  __syncthreads();
+  for (int fi = 0; fi < FPW; ++fi) {
+    const int64_t t = ((int64_t)blockIdx.x * FPW + fi) * WAVES + wave;
+    const bool valid = t < g.T;
+    const int64_t s0 = t * g.H - g.padL;
+    for (int j = lane; j < N; j += NT) {
+      cd z = {0.0, 0.0};
+      if (valid) {
+        z.x = view_sample(view, row, chunk, s0 + 2 * j) * win[2 * j];
+        z.y = view_sample(view, row, chunk, s0 + 2 * j + 1) * win[2 * j + 1];
+      }
+      buf[lp<double>(j)] = z;
+    }
+    SG_PASS_SYNC();
+    wave_fft<double, N, false, NT>(buf, tw, lane);
+    if (valid) {
+      const double* Mrow = M + (u * g.T + t) * g.FS;
+      for (int k = lane; k <= N / 2; k += NT) {
+        if (k == 0) {
+          const cd a = buf[lp<double>(0)];
+          const double y0 = (a.x + a.y) * Mrow[0];
+          const double yN = (a.x - a.y) * Mrow[N];
+          buf[lp<double>(0)] = {0.5 * (y0 + yN), 0.5 * (y0 - yN)};
+        } else {
+          const cd a = buf[lp<double>(k)], b = buf[lp<double>(N - k)];
+          const cd w = tw[k];
+          const cd E = {(a.x + b.x) * 0.5, (a.y - b.y) * 0.5};
+          const cd O = {(a.y + b.y) * 0.5, (b.x - a.x) * 0.5};
+          const cd wO = cmul(w, O);
+          const double mk = Mrow[k], mn = Mrow[N - k];
+          const cd Yk = {(E.x + wO.x) * mk, (E.y + wO.y) * mk};
+          const cd Yn = {(E.x - wO.x) * mn, (-E.y + wO.y) * mn};
+          const cd Ep = {(Yk.x + Yn.x) * 0.5, (Yk.y - Yn.y) * 0.5};
+          const cd D = {(Yk.x - Yn.x) * 0.5, (Yk.y + Yn.y) * 0.5};
+          const cd wc = {w.x, -w.y};
+          const cd Op = cmul(D, wc);
+          buf[lp<double>(k)] = {Ep.x - Op.y, Ep.y + Op.x};
+          if (k != N - k) buf[lp<double>(N - k)] = {Ep.x + Op.y, -Ep.y + Op.x};
+        }
+      }
+    }
+    SG_PASS_SYNC();
+    wave_fft<double, N, true, NT>(buf, tw, lane);
+    if (valid) {
+      double* srow = seg + (u * g.T + t) * (int64_t)g.n;
+      for (int j = lane; j < N; j += NT) {
+        const cd z = buf[lp<double>(j)];
+        srow[2 * j] = z.x * win[2 * j] * inv_n;
+        srow[2 * j + 1] = z.y * win[2 * j + 1] * inv_n;
+      }
+    }
+    SG_PASS_SYNC();
+  }
+}
+
+// chirp-z form for frame lengths that are not a power of two (k_apply_istft_czt of czt.hpp in float64)
+template <int M, int NT, int FR>
+__global__ __launch_bounds__(NT* FR) void kx_apply_istft_czt(View view, Geom g, CztTabs<double> tb,
+                                                             const double* __restrict__ win,
+                                                             const double* __restrict__ Mk, double* __restrict__ seg,
+                                                             int fpb) {
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  typedef cx<double> cd;
+  const int tl = threadIdx.x % NT, fr = threadIdx.x / NT;
+  cd* buf = reinterpret_cast<cd*>(smem) + (size_t)fr * lpn<double>(M);
+  const int64_t u = blockIdx.y;
+  const int64_t row = (view.unit0 + u) / view.n_chunks;
+  const int64_t chunk = view.c0 + (view.unit0 + u) % view.n_chunks;
+  const double inv_n = 1.0 / (double)g.n;
+  for (int fi = 0; fi < fpb; ++fi) {
+    const int64_t t = ((int64_t)blockIdx.x * fpb + fi) * FR + fr;
+    const bool valid = t < g.T;
+    const int64_t s0 = t * g.H - g.padL;
+    for (int j = tl; j < M; j += NT) {
+      cd z = {0.0, 0.0};
+      if (valid && j < g.n) {
+        const double xw = view_sample(view, row, chunk, s0 + j) * win[j];
+        const cd c = tb.chirp[j];
+        z = {xw * c.x, xw * c.y};
+      }
+      buf[lp<double>(j)] = z;
+    }
+    czt_core<double, M, NT>(buf, tb, tl);
+    const double* Mrow = Mk + (u * g.T + (valid ? t : 0)) * g.FS;
+    for (int j = tl; j < M; j += NT) {
+      cd z = {0.0, 0.0};
+      if (valid && j < g.n) {
+        const cd c = tb.chirp[j];
+        cd X = cmul(buf[lp<double>(j)], c);
+        const int kk = j < g.F ? j : g.n - j;
+        const double m = Mrow[kk];
+        if (j == 0 || 2 * j == g.n) X.y = 0.0;
+        const cd Yc = {X.x * m, -X.y * m};
+        z = cmul(Yc, c);
+      }
+      buf[lp<double>(j)] = z;
+    }
+    czt_core<double, M, NT>(buf, tb, tl);
+    if (valid) {
+      double* srow = seg + (u * g.T + t) * (int64_t)g.n;
+      for (int j = tl; j < g.n; j += NT) {
+        const cd D = cmul(buf[lp<double>(j)], tb.chirp[j]);
+        srow[j] = D.x * win[j] * inv_n;
+      }
+    }
+    SG_PASS_SYNC();
+  }
+}
+
+// truncating store of a float64 value (ndarray.astype semantics, base.py:217-226)
+__device__ __forceinline__ void store_sample_f64(void* p, int dtype, int64_t idx, double val) {
+  switch (dtype) {
+    case 0: ((float*)p)[idx] = (float)val; break;
+    case 1: ((double*)p)[idx] = val; break;
+    case 2: ((int16_t*)p)[idx] = (int16_t)val; break;
+    default: ((int32_t*)p)[idx] = (int32_t)val; break;
+  }
+}
+
+// overlap-add gather in float64 (k_ola): out[p] = sum_t seg[t][e - tH] / sum_t w^2[e - tH], e = p + padL
+// (scipy/_spectral_py.py:1708-1725: norm > 1e-10 guard)
+__global__ void kx_ola(View view, Geom g, OutMap om, const double* __restrict__ seg, const double* __restrict__ win) {
+  const int64_t u = blockIdx.y;
+  const int64_t row = (view.unit0 + u) / view.n_chunks;
+  const int64_t chunk = view.c0 + (view.unit0 + u) % view.n_chunks;
+  const int64_t p = om.p0 + (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (p >= om.p1) return;
+  const int64_t gi = chunk * om.g_step + (p - om.p0);
+  if (gi < om.g_lo || gi >= om.g_hi) return;
+  double val = 0.0;
+  if (p < g.Lout) {
+    const int64_t e = p + g.padL;
+    int64_t t_hi = e / g.H;
+    if (t_hi > g.T - 1) t_hi = g.T - 1;
+    int64_t t_lo = (e - g.n + g.H) / g.H;
+    if (e - g.n + 1 <= 0) t_lo = 0;
+    double acc = 0.0, norm = 0.0;
+    for (int64_t t = t_lo; t <= t_hi; ++t) {
+      const int m = (int)(e - t * g.H);
+      acc += seg[(u * g.T + t) * (int64_t)g.n + m];
+      norm += win[m] * win[m];
+    }
+    val = acc / (norm > 1e-10 ? norm : 1.0);
+  }
+  store_sample_f64(om.out, om.dtype, row * om.stride + gi - om.g0, val);
+}
+
+}  // namespace exact
+}  // namespace sg

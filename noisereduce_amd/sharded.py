@@ -162,6 +162,10 @@ def _check_shard_lengths(lens, chunk_size, padding):
     every shard but the last non-empty one must be a positive multiple of chunk_size and at least
     `padding` long (its seams are real samples); the last one may be short (its missing seam samples lie
     beyond the end of the recording == the reference's zero padding, base.py:139-141)."""
+    if any(n < 0 for n in lens):    # a rank could not produce its contribution (rank 0: the noise statistics)
+        bad = [i for i, n in enumerate(lens) if n < 0]
+        raise ValueError(f"rank(s) {bad} failed before the seam exchange (noise statistics of the first chunk); "
+                         f"shard lengths {[n if n >= 0 else -n - 1 for n in lens]}")
     nonempty = [i for i, n in enumerate(lens) if n > 0]
     if not nonempty:
         return
@@ -186,9 +190,13 @@ def exchange_seams_and_threshold(y_local, padding, thr, n_bins, group=None, bufs
     (left_halo, right_halo, thr): halos (C, padding) in y_local's dtype, zeros at the ends of the
     recording; thr float64 (n_bins,).
     No rank raises BEFORE the collective (the others would block in it until the RCCL timeout): a shard
-    shorter than `padding` sends zero-filled seams, and the shard layout is validated from the gathered
-    lengths -- by every rank with the same verdict -- the first time this (length, world) is seen.
-    `bufs`: optional dict that keeps the send/receive buffers (and the validation memo) between calls."""
+    shorter than `padding` sends zero-filled seams, `thr=None` on rank 0 (its statistics failed) travels as a
+    negative length, and the shard layout is validated from the GATHERED lengths -- the same verdict on every rank.
+    `bufs`: optional dict that keeps the send/receive buffers between calls.  With it the gathered lengths of call k
+    are validated without a host synchronisation: copied to page-locked memory asynchronously and checked at the
+    START of call k + 1, before its collective -- by every rank, so a layout that turns bad on ONE rank (whose
+    own length the others cannot see) still makes every rank raise together, one call late; a rank whose own
+    length or layout key changed validates immediately (first call: always)."""
     ws, rank = dist.get_world_size(group), dist.get_rank(group)
     C, S = y_local.shape
     es = y_local.element_size()
@@ -197,6 +205,11 @@ def exchange_seams_and_threshold(y_local, padding, thr, n_bins, group=None, bufs
     sb = HDR + (seam_bytes + 7) // 8 * 8                # threshold slot 8-byte aligned
     total = sb + n_bins * 8
     key = (total, ws, y_local.device)
+    if bufs is not None and bufs.get("pending") is not None:
+        # verdict on the previous call's gathered lengths (arrived long ago: no stall); raised by every rank alike
+        host, ev, pcs, ppad = bufs.pop("pending")
+        ev.synchronize()
+        _check_shard_lengths(host.tolist(), pcs, ppad)
     if bufs is not None and bufs.get("key") == key:
         send, recv = bufs["send"], bufs["recv"]
     else:
@@ -204,10 +217,11 @@ def exchange_seams_and_threshold(y_local, padding, thr, n_bins, group=None, bufs
         recv = torch.empty(ws * total, dtype=torch.uint8, device=y_local.device)
         if bufs is not None:
             bufs.update(key=key, send=send, recv=recv, checked=None, len_dev=None)
-    if bufs is None or bufs.get("len_dev") != S:
-        send[:HDR].view(torch.int64).fill_(S)
+    S_hdr = S if (rank != 0 or thr is not None) else -S - 1      # rank 0 without a threshold: failure marker
+    if bufs is None or bufs.get("len_dev") != S_hdr:
+        send[:HDR].view(torch.int64).fill_(S_hdr)
         if bufs is not None:
-            bufs["len_dev"] = S
+            bufs["len_dev"] = S_hdr
     if padding:
         seams = send[HDR:HDR + seam_bytes].view(y_local.dtype).view(2, C, padding)
         if S >= padding:
@@ -218,15 +232,25 @@ def exchange_seams_and_threshold(y_local, padding, thr, n_bins, group=None, bufs
             if S:
                 seams[0][:, :S].copy_(y_local)
                 seams[1][:, padding - S:].copy_(y_local)
-    if rank == 0:
+    if rank == 0 and thr is not None:
         send[sb:].view(torch.float64).copy_(thr)
     dist.all_gather_into_tensor(recv, send, group=group)
     recv = recv.view(ws, total)
-    if bufs is None or bufs.get("checked") != (S, chunk_size, padding):
-        lens = recv[:, :HDR].contiguous().view(torch.int64).flatten().cpu().tolist()   # one host sync, first call only
-        _check_shard_lengths(lens, chunk_size, padding)
+    hdr = recv[:, :HDR].contiguous().view(torch.int64).flatten()
+    if bufs is None or bufs.get("checked") != (S_hdr, chunk_size, padding):
+        _check_shard_lengths(hdr.cpu().tolist(), chunk_size, padding)   # one host sync: first call / own layout changed
         if bufs is not None:
-            bufs["checked"] = (S, chunk_size, padding)
+            bufs["checked"] = (S_hdr, chunk_size, padding)
+    elif hdr.is_cuda:
+        host = bufs.get("hdr_host")
+        if host is None or host.numel() != ws:
+            host = bufs["hdr_host"] = torch.empty(ws, dtype=torch.int64).pin_memory()
+        host.copy_(hdr, non_blocking=True)
+        ev = torch.cuda.Event()
+        ev.record()
+        bufs["pending"] = (host, ev, chunk_size, padding)
+    else:
+        _check_shard_lengths(hdr.tolist(), chunk_size, padding)         # CPU tensors (gloo tests): nothing to defer
     thr_out = recv[0, sb:].view(torch.float64)
 
     def seam_of(r, which):
@@ -271,9 +295,19 @@ class TimeShardedStationary:
             if self.ws == 1:
                 self.backend.stats(y_local)
                 return self.backend.filter(y_local, y_local, 0, None, owner=True)
-            thr = self.backend.threshold(y_local) if self.rank == 0 else None
-            left, right, thr = exchange_seams_and_threshold(y_local, pad, thr, self.n_bins, self.group,
-                                                            self._bufs, chunk_size=cs)
+            thr, thr_err = None, None
+            if self.rank == 0:
+                try:        # never raise before the collective: a failure travels to every rank in the header
+                    thr = self.backend.threshold(y_local)
+                except Exception as e:      # noqa: BLE001 -- re-raised below, after the exchange
+                    thr_err = e
+            try:
+                left, right, thr = exchange_seams_and_threshold(y_local, pad, thr, self.n_bins, self.group,
+                                                                self._bufs, chunk_size=cs)
+            except ValueError:
+                if thr_err is not None:
+                    raise thr_err
+                raise
             if S == 0:      # more ranks than chunks: this rank took part in the exchange and has nothing to filter
                 return y_local.new_empty((y_local.shape[0], 0))
             if pad == 0:

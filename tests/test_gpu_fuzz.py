@@ -50,8 +50,10 @@ def test_random_configuration_matches_oracle(seed):
     got = nr.reduce_noise(y=y, sr=sr, **kw)
     assert got.shape == y.shape and got.dtype == y.dtype
     if dtype == "int16":
-        # truncation to int16 (base.py:218-226): off by at most one count from the truncated oracle
-        assert np.max(np.abs(got.astype(np.int64) - want.astype(np.int16).astype(np.int64))) <= 1
+        # truncation to int16 (base.py:218-226) of a float64 result: the truncated oracle, bit for bit (float64 pipeline).
+        # (A sample whose float64 value sits within ~1e-9 of an integer could still fall either way: allow a handful.)
+        diff = got.astype(np.int64) - want.astype(np.int16).astype(np.int64)
+        assert np.max(np.abs(diff)) <= 1 and np.count_nonzero(diff) <= 2, np.count_nonzero(diff)
     else:
         assert O.rel_err(got.astype(np.float64), want) < TOL, (kw, sr, C, n)
     # tensor input on the device: same numbers as the numpy path

@@ -208,3 +208,50 @@ def test_torchgate_long_frames(nr):
         want = O.torchgate_T(x, 48000, n_fft=n_fft, window=torch.hann_window(n_fft).double().numpy(), **kw)
         assert got.shape == want.shape
         assert O.rel_err(got, want) < TOL
+
+
+# ---------------------------------------------------------------------------------------------
+# integer recordings: the truncated float64 result of the reference, bit for bit (exact.hpp)
+# ---------------------------------------------------------------------------------------------
+@pytest.mark.parametrize("kw", [
+    dict(stationary=True),                                                 # default geometry (fused path when float)
+    dict(stationary=False),
+    dict(stationary=True, prop_decrease=0.7, chunk_size=30000, padding=3000),
+    dict(stationary=False, n_fft=512, chunk_size=30000, padding=3000),
+    dict(stationary=True, n_fft=1000),                                     # chirp-z frames
+    dict(stationary=False, n_fft=2048, win_length=1500, hop_length=300, time_mask_smooth_ms=None),
+    dict(stationary=True, n_fft=8192, freq_mask_smooth_hz=None),
+    dict(stationary=True, n_fft=5000, time_mask_smooth_ms=None, freq_mask_smooth_hz=None),   # long chirp-z frames, no smoothing
+])
+@pytest.mark.parametrize("dtype", [np.int16, np.int32])
+def test_integer_recordings_are_bit_exact(nr, kw, dtype):
+    """int16 / int32 in -> the same dtype out = trunc(float64 result) (base.py:217-226), for both gates and every
+    family of transform kernels, against the oracle's float64 result truncated the same way."""
+    n = 90000
+    scale = 20000 if dtype == np.int16 else 1.5e9
+    y = np.stack([np.round(O.synth_signal(n, seed=71 + c, tone_hz=500.0 * (c + 1)).astype(np.float64) * scale) for c in range(2)]).astype(dtype)
+    got = nr.reduce_noise(y=y, sr=48000, **kw)
+    want = O.reduce_noise_S(y.astype(np.float64), 48000, **kw).astype(dtype)
+    assert got.dtype == dtype and got.shape == y.shape
+    diff = got.astype(np.int64) - want.astype(np.int64)
+    # float64 evaluation order differs from numpy's (1e-16 relative): a value that sits within ~1e-9 of an integer
+    # may fall on the other side -- none expected in 180 000 samples of int16, at most a few of int32 at 1.5e9 scale
+    assert np.max(np.abs(diff)) <= 1 and np.count_nonzero(diff) <= (0 if dtype == np.int16 else 8), np.count_nonzero(diff)
+
+
+def test_force_exact_float64(nr):
+    """SG_OPT_FORCE_EXACT: float64 recordings get float64-accurate results (1e-12 of peak instead of 2e-7)."""
+    from noisereduce_amd import _ffi
+    from noisereduce_amd.spectralgate.stationary import SpectralGateStationary
+    y = O.synth_signal(120000, seed=9).astype(np.float64)
+    kw = dict(sr=48000, y_noise=None, prop_decrease=1.0, n_std_thresh_stationary=1.5, chunk_size=50000,
+              clip_noise_stationary=True, padding=4000, n_fft=1024, win_length=None, hop_length=None, time_constant_s=2.0,
+              freq_mask_smooth_hz=500, time_mask_smooth_ms=50, tmp_folder=None, use_tqdm=False, n_jobs=1)
+    sg = SpectralGateStationary(y=y, **kw)
+    want = O.reduce_noise_S(y, 48000, stationary=True, chunk_size=50000, padding=4000)
+    assert 1e-9 < O.rel_err(sg.get_traces(), want) < TOL
+    sg._gate.set_option(_ffi.SG_OPT_FORCE_EXACT, 1)
+    try:
+        assert O.rel_err(sg.get_traces(), want) < 1e-12
+    finally:
+        sg._gate.set_option(_ffi.SG_OPT_FORCE_EXACT, 0)

@@ -184,3 +184,61 @@ def test_time_sharded_bad_layout_raises_on_every_rank():
     res, _ = _run_layout(n, 2, bounds=[(0, CS + 17), (CS + 17, n)])
     assert [r[0] for r in res] == ["ValueError", "ValueError"], res
     assert "not chunk-aligned" in res[0][1] and res[0][1] == res[1][1]
+
+
+# ---- the verdict on a shard layout must be the same on every rank on EVERY call, and a rank that fails
+# before the collective must not strand the others ----
+def _worker_relayout(rank, world, port, y, ret):
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    from noisereduce_amd.sharded import TimeShardedStationary
+    be = OracleBackend()                       # ONE backend: the exchange buffers and the validation memo persist
+    log = []
+    # call 1: good layout; call 2: rank 0's shard loses its chunk alignment while rank 1's length stays the same
+    for b in ([(0, CS), (CS, 2 * CS)], [(0, CS - 40), (CS, 2 * CS)]):
+        s0, s1 = b[rank]
+        try:
+            TimeShardedStationary(be, NFFT // 2 + 1).run(y[:, s0:s1].contiguous())
+            log.append("ok")
+        except ValueError as e:
+            log.append("ValueError")
+    ret[rank] = log
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_layout_change_on_one_rank_raises_on_every_rank():
+    y = torch.from_numpy(np.stack([O.synth_signal(2 * CS, seed=16).astype(np.float64)]))
+    mgr = mp.Manager()
+    ret = mgr.dict()
+    mp.spawn(_worker_relayout, args=(2, _free_port(), y, ret), nprocs=2, join=True)
+    assert ret[0] == ["ok", "ValueError"] and ret[1] == ["ok", "ValueError"], dict(ret)
+
+
+def _worker_rank0_fails(rank, world, port, y, ret):
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    from noisereduce_amd.sharded import TimeShardedStationary
+
+    class Failing(OracleBackend):
+        def threshold(self, y_local):
+            raise RuntimeError("noise statistics failed on rank 0")
+    try:
+        TimeShardedStationary(Failing(), NFFT // 2 + 1).run(y[:, rank * CS:(rank + 1) * CS].contiguous())
+        ret[rank] = "ok"
+    except RuntimeError as e:
+        ret[rank] = "RuntimeError"       # rank 0: its own error, re-raised AFTER the collective
+    except ValueError as e:
+        ret[rank] = "ValueError"         # the others: told through the gathered header
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_rank0_statistics_failure_reaches_every_rank():
+    y = torch.from_numpy(np.stack([O.synth_signal(2 * CS, seed=17).astype(np.float64)]))
+    mgr = mp.Manager()
+    ret = mgr.dict()
+    mp.spawn(_worker_rank0_fails, args=(2, _free_port(), y, ret), nprocs=2, join=True)
+    assert ret[0] == "RuntimeError" and ret[1] == "ValueError", dict(ret)
