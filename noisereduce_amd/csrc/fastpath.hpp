@@ -74,6 +74,110 @@ __device__ __forceinline__ constexpr float tws(int k) {  // sin(2 pi k / R) >= 0
   return j <= 8 ? C32[8 - j] : C32[j - 8];
 }
 
+// ---------------------------------------------------------------------------------------------------------------
+// Packed float32 butterflies (SG_PK_FFT, v_pk_*_f32 through inline asm: the compiler's own packing shuffles register
+// pairs).  A complex value is one aligned VGPR pair (re, im); op_sel / neg modifiers do the swaps and sign flips of a
+// complex product inside the instruction, twiddle constants ride in SGPR pairs (cos, sin):
+//     p = e + w o      2 x v_pk_fma_f32        (scalar form: 4 x v_fma_f32)
+//     q = 2 e - p      1 x v_pk_fma_f32        (2)
+//     e +- o, e +- i o 1 x v_pk_add_f32 each   (2)
+//     a * w            v_pk_mul_f32 + v_pk_fma_f32   (4)
+// Every half of a packed operation is the IEEE operation the scalar form performs, in the same order: the results are
+// bit-identical (tools/ubench/pk_check.hip).  A packed instruction occupies the VALU for twice as long as a scalar one
+// (profiles/r03_valu_rate2.txt: the float32 rate of the pipe is the same either way) -- what is saved is ISSUE SLOTS: a
+// wave issues one instruction per ~4 cycles whatever it is, and the one-pass gate is bound by that.
+// ---------------------------------------------------------------------------------------------------------------
+#ifndef SG_PK_FFT
+#define SG_PK_FFT 0   // measured: no gain (profiles/r03_packed_fft_ab.txt); needs the packed-fp32-ops target feature (tools/ab_build.sh)
+#endif
+typedef float pf2 __attribute__((ext_vector_type(2)));
+__device__ __forceinline__ pf2 pk_of(cf a) { return pf2{a.x, a.y}; }
+__device__ __forceinline__ cf pk_to(pf2 a) { return cf{a.x, a.y}; }
+__device__ __forceinline__ pf2 pk_add(pf2 a, pf2 b) {
+  pf2 d;
+  asm("v_pk_add_f32 %0, %1, %2" : "=v"(d) : "v"(a), "v"(b));
+  return d;
+}
+__device__ __forceinline__ pf2 pk_sub(pf2 a, pf2 b) {
+  pf2 d;
+  asm("v_pk_add_f32 %0, %1, %2 neg_lo:[0,1] neg_hi:[0,1]" : "=v"(d) : "v"(a), "v"(b));
+  return d;
+}
+__device__ __forceinline__ pf2 pk_mul(pf2 a, pf2 b) {
+  pf2 d;
+  asm("v_pk_mul_f32 %0, %1, %2" : "=v"(d) : "v"(a), "v"(b));
+  return d;
+}
+// a + (b.y, -b.x)  /  a + (-b.y, b.x)
+__device__ __forceinline__ pf2 pk_add_mi(pf2 a, pf2 b) {   // a + (-i) b
+  pf2 d;
+  asm("v_pk_add_f32 %0, %1, %2 op_sel:[0,1] op_sel_hi:[1,0] neg_hi:[0,1]" : "=v"(d) : "v"(a), "v"(b));
+  return d;
+}
+__device__ __forceinline__ pf2 pk_add_pi(pf2 a, pf2 b) {   // a + (+i) b
+  pf2 d;
+  asm("v_pk_add_f32 %0, %1, %2 op_sel:[0,1] op_sel_hi:[1,0] neg_lo:[0,1]" : "=v"(d) : "v"(a), "v"(b));
+  return d;
+}
+// butterfly with the twiddle folded in: p = a + w b, q = 2 a - p;  w = c - i s (forward), c + i s (inverse); cs = (c, s)
+// uniform (SGPR pair).  p.x = fma(b.x, c, fma(b.y, +-s, a.x)), p.y = fma(b.y, c, fma(-+b.x, s, a.y)): as dft_reg's scalar form
+template <bool INV>
+__device__ __forceinline__ void pk_bfly_tw(pf2 a, pf2 b, pf2 cs, pf2& p, pf2& q) {
+  pf2 t;
+  if (INV) asm("v_pk_fma_f32 %0, %1, %2, %3 op_sel:[1,1,0] op_sel_hi:[0,1,1] neg_lo:[0,1,0]" : "=v"(t) : "v"(b), "s"(cs), "v"(a));
+  else asm("v_pk_fma_f32 %0, %1, %2, %3 op_sel:[1,1,0] op_sel_hi:[0,1,1] neg_hi:[0,1,0]" : "=v"(t) : "v"(b), "s"(cs), "v"(a));
+  asm("v_pk_fma_f32 %0, %1, %2, %3 op_sel:[0,0,0] op_sel_hi:[1,0,1]" : "=v"(p) : "v"(b), "s"(cs), "v"(t));
+  asm("v_pk_fma_f32 %0, %1, 2.0, %2 op_sel_hi:[1,0,1] neg_lo:[0,0,1] neg_hi:[0,0,1]" : "=v"(q) : "v"(a), "v"(p));
+}
+// a * w (CONJ: a * conj w), w a VGPR pair
+template <bool CONJ>
+__device__ __forceinline__ pf2 pk_cmul(pf2 a, pf2 w) {
+  pf2 t, r;
+  asm("v_pk_mul_f32 %0, %1, %2 op_sel_hi:[1,0]" : "=v"(t) : "v"(a), "v"(w));
+  if (CONJ) asm("v_pk_fma_f32 %0, %1, %2, %3 op_sel:[1,1,0] op_sel_hi:[0,1,1] neg_hi:[0,1,0]" : "=v"(r) : "v"(a), "v"(w), "v"(t));
+  else asm("v_pk_fma_f32 %0, %1, %2, %3 op_sel:[1,1,0] op_sel_hi:[0,1,1] neg_lo:[0,1,0]" : "=v"(r) : "v"(a), "v"(w), "v"(t));
+  return r;
+}
+
+// In-register DFT of R points on packed values, natural order in and out (decimation in time): dft_reg below, packed.
+template <int R, bool INV>
+__device__ __forceinline__ void dft_reg_pk(pf2* v) {
+  if constexpr (R == 2) {
+    const pf2 a = v[0], b = v[1];
+    v[0] = pk_add(a, b);
+    v[1] = pk_sub(a, b);
+  } else if constexpr (R == 4) {
+    const pf2 s02 = pk_add(v[0], v[2]), d02 = pk_sub(v[0], v[2]);
+    const pf2 s13 = pk_add(v[1], v[3]), d13 = pk_sub(v[1], v[3]);
+    v[0] = pk_add(s02, s13);
+    v[2] = pk_sub(s02, s13);
+    v[1] = INV ? pk_add_pi(d02, d13) : pk_add_mi(d02, d13);   // d02 + rot90(d13)
+    v[3] = INV ? pk_add_mi(d02, d13) : pk_add_pi(d02, d13);   // d02 - rot90(d13)
+  } else {
+    pf2 e[R / 2], o[R / 2];
+#pragma unroll
+    for (int k = 0; k < R / 2; ++k) {
+      e[k] = v[2 * k];
+      o[k] = v[2 * k + 1];
+    }
+    dft_reg_pk<R / 2, INV>(e);
+    dft_reg_pk<R / 2, INV>(o);
+#pragma unroll
+    for (int k = 0; k < R / 2; ++k) {
+      if (k == 0) {
+        v[k] = pk_add(e[k], o[k]);
+        v[k + R / 2] = pk_sub(e[k], o[k]);
+      } else if (k == R / 4) {
+        v[k] = INV ? pk_add_pi(e[k], o[k]) : pk_add_mi(e[k], o[k]);
+        v[k + R / 2] = INV ? pk_add_mi(e[k], o[k]) : pk_add_pi(e[k], o[k]);
+      } else {
+        const pf2 cs = {twc<R>(k), tws<R>(k)};
+        pk_bfly_tw<INV>(e[k], o[k], cs, v[k], v[k + R / 2]);
+      }
+    }
+  }
+}
+
 template <bool INV>
 __device__ __forceinline__ cf mul_tw(cf a, float c, float s) {
   // a * (c - i s) forward, a * (c + i s) inverse
@@ -118,6 +222,65 @@ __device__ __forceinline__ void dft_reg(cf* v) {
       }
     }
   }
+}
+
+// The three register stages of the 512-point transform, shared by every variant below (packed or scalar butterflies:
+// the same arithmetic in every kernel that uses them, so the kernels agree to the bit).
+//   forward: DFT32 over r, then the twiddle w_512^(c k1)
+__device__ __forceinline__ void stage_dft32_tw_fwd(cf* v, const cf* tw512, int c) {
+#if SG_PK_FFT
+  pf2 p[32];
+#pragma unroll
+  for (int r = 0; r < 32; ++r) p[r] = pk_of(v[r]);
+  dft_reg_pk<32, false>(p);
+  __builtin_amdgcn_sched_barrier(0);
+  v[0] = pk_to(p[0]);
+#pragma unroll
+  for (int k1 = 1; k1 < 32; ++k1) v[k1] = pk_to(pk_cmul<false>(p[k1], pk_of(tw512[k1 * 16 + c])));
+#else
+  dft_reg<32, false>(v);
+  __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+  for (int k1 = 1; k1 < 32; ++k1) v[k1] = cmul(v[k1], tw512[k1 * 16 + c]);
+#endif
+}
+//   inverse: conjugate twiddle, then DFT32 over k1
+__device__ __forceinline__ void stage_tw_dft32_inv(cf* v, const cf* tw512, int c) {
+#if SG_PK_FFT
+  pf2 p[32];
+  p[0] = pk_of(v[0]);
+#pragma unroll
+  for (int k1 = 1; k1 < 32; ++k1) p[k1] = pk_cmul<true>(pk_of(v[k1]), pk_of(tw512[k1 * 16 + c]));
+  __builtin_amdgcn_sched_barrier(0);
+  dft_reg_pk<32, true>(p);
+#pragma unroll
+  for (int r = 0; r < 32; ++r) v[r] = pk_to(p[r]);
+#else
+#pragma unroll
+  for (int k1 = 1; k1 < 32; ++k1) {
+    cf w = tw512[k1 * 16 + c];
+    w.y = -w.y;
+    v[k1] = cmul(v[k1], w);
+  }
+  __builtin_amdgcn_sched_barrier(0);
+  dft_reg<32, true>(v);
+#endif
+}
+//   both directions: the two DFT16 over the lane's rows
+template <bool INV>
+__device__ __forceinline__ void stage_dft16x2(cf* v) {
+#if SG_PK_FFT
+  pf2 p[32];
+#pragma unroll
+  for (int r = 0; r < 32; ++r) p[r] = pk_of(v[r]);
+  dft_reg_pk<16, INV>(p);
+  dft_reg_pk<16, INV>(p + 16);
+#pragma unroll
+  for (int r = 0; r < 32; ++r) v[r] = pk_to(p[r]);
+#else
+  dft_reg<16, INV>(v);
+  dft_reg<16, INV>(v + 16);
+#endif
 }
 
 __device__ __forceinline__ void wave_lds_sync() {
@@ -169,40 +332,28 @@ __device__ __forceinline__ void fft512_fwd(cf* v, cf* fb, const cf* tw512, int c
   // sched_barriers keep the phases apart: left alone, the scheduler overlaps the loads of one
   // phase with the arithmetic of the previous one and the live range balloons past 256 VGPRs.
   __builtin_amdgcn_sched_barrier(0);
-  dft_reg<32, false>(v);
-  __builtin_amdgcn_sched_barrier(0);
-#pragma unroll
-  for (int k1 = 1; k1 < 32; ++k1) v[k1] = cmul(v[k1], tw512[k1 * 16 + c]);
+  stage_dft32_tw_fwd(v, tw512, c);
   xchg_write_cols(fb, c, v);
   wave_lds_sync();
   __builtin_amdgcn_sched_barrier(0);
   xchg_read_row(fb, row1(c), v);
   xchg_read_row(fb, row2(c), v + 16);
   wave_lds_sync();
-  dft_reg<16, false>(v);
-  dft_reg<16, false>(v + 16);
+  stage_dft16x2<false>(v);
   __builtin_amdgcn_sched_barrier(0);
 }
 
 // Inverse (unnormalised): v[k2], v[16 + k2] as above  ->  v[r] = 512 * z[c + 16 r].
 __device__ __forceinline__ void fft512_inv(cf* v, cf* fb, const cf* tw512, int c) {
   __builtin_amdgcn_sched_barrier(0);
-  dft_reg<16, true>(v);
-  dft_reg<16, true>(v + 16);
+  stage_dft16x2<true>(v);
   xchg_write_row(fb, row1(c), v);
   xchg_write_row(fb, row2(c), v + 16);
   wave_lds_sync();
   __builtin_amdgcn_sched_barrier(0);
   xchg_read_cols(fb, c, v);
   wave_lds_sync();
-#pragma unroll
-  for (int k1 = 1; k1 < 32; ++k1) {
-    cf w = tw512[k1 * 16 + c];
-    w.y = -w.y;
-    v[k1] = cmul(v[k1], w);
-  }
-  __builtin_amdgcn_sched_barrier(0);
-  dft_reg<32, true>(v);
+  stage_tw_dft32_inv(v, tw512, c);
   __builtin_amdgcn_sched_barrier(0);
 }
 
@@ -217,10 +368,7 @@ __device__ __forceinline__ int frame_base_h(int g) { return g * FPITCH_H; }
 
 __device__ __forceinline__ void fft512_fwd_half(cf* v, cf* fb, const cf* tw512, int c) {
   __builtin_amdgcn_sched_barrier(0);
-  dft_reg<32, false>(v);
-  __builtin_amdgcn_sched_barrier(0);
-#pragma unroll
-  for (int k1 = 1; k1 < 32; ++k1) v[k1] = cmul(v[k1], tw512[k1 * 16 + c]);
+  stage_dft32_tw_fwd(v, tw512, c);
   // phase A: rows 0..15
 #pragma unroll
   for (int k1 = 0; k1 < 16; ++k1) fb[k1 * 16 + (c ^ (2 * ((k1 >> 1) & 7)))] = v[k1];
@@ -233,16 +381,14 @@ __device__ __forceinline__ void fft512_fwd_half(cf* v, cf* fb, const cf* tw512, 
   wave_lds_sync();
   xchg_read_row(fb, row2(c) - 16, v + 16);
   wave_lds_sync();
-  dft_reg<16, false>(v);
-  dft_reg<16, false>(v + 16);
+  stage_dft16x2<false>(v);
   __builtin_amdgcn_sched_barrier(0);
 }
 
 // Inverse transform with the half-size slice: row1 rows (0..15) travel first, then row2 rows.
 __device__ __forceinline__ void fft512_inv_half(cf* v, cf* fb, const cf* tw512, int c) {
   __builtin_amdgcn_sched_barrier(0);
-  dft_reg<16, true>(v);
-  dft_reg<16, true>(v + 16);
+  stage_dft16x2<true>(v);
   xchg_write_row(fb, row1(c), v);
   wave_lds_sync();
 #pragma unroll
@@ -253,14 +399,7 @@ __device__ __forceinline__ void fft512_inv_half(cf* v, cf* fb, const cf* tw512, 
 #pragma unroll
   for (int k1 = 16; k1 < 32; ++k1) v[k1] = fb[(k1 - 16) * 16 + (c ^ (2 * ((k1 >> 1) & 7)))];
   wave_lds_sync();
-#pragma unroll
-  for (int k1 = 1; k1 < 32; ++k1) {
-    cf w = tw512[k1 * 16 + c];
-    w.y = -w.y;
-    v[k1] = cmul(v[k1], w);
-  }
-  __builtin_amdgcn_sched_barrier(0);
-  dft_reg<32, true>(v);
+  stage_tw_dft32_inv(v, tw512, c);
   __builtin_amdgcn_sched_barrier(0);
 }
 
