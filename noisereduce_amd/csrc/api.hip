@@ -27,6 +27,12 @@
 #include "big.hpp"
 #include "exact.hpp"
 
+// complex transform length from which a whole 256-thread workgroup (instead of one wavefront) works on ONE frame in
+// the general LDS kernels: at N = 2048 (n_fft = 4096) a wavefront holds 4 radix-8 butterflies = 64 complex values per
+// lane -- 256 VGPRs and scratch, one wave per SIMD
+#ifndef SG_TEAM_N
+#define SG_TEAM_N 2048
+#endif
 #ifndef SG_APPLY_WAVES
 #define SG_APPLY_WAVES 4  // wavefronts per workgroup of k_apply_fast: tile = 4*W frames -> 4*W-3 hops
 #endif
@@ -234,8 +240,8 @@ static hipError_t launch_stft_n(const View& v, const Geom& g, int64_t units, con
                                 double* P, float* mag, double* z, double zscale, hipStream_t st,
                                 unsigned long long* pmax_bits) {
   // n_fft = 8192 (N = 4096): the whole workgroup cooperates on one frame
-  constexpr int NT = N >= 4096 ? 256 : 64;
-  constexpr int WAVES = N >= 4096 ? 1 : ((N * sizeof(cx<TC>) > 16384) ? 2 : 4);
+  constexpr int NT = N >= SG_TEAM_N ? 256 : 64;
+  constexpr int WAVES = N >= SG_TEAM_N ? 1 : ((N * sizeof(cx<TC>) > 16384) ? 2 : 4);
   size_t lds = (size_t)(N + WAVES * lpn<TC>(N)) * sizeof(cx<TC>);
   // few units (the noise clip): one frame per wave so that the grid still covers the chip
   const bool small = units * ((g.T + WAVES * 4 - 1) / (WAVES * 4)) < 1024;
@@ -343,8 +349,8 @@ static hipError_t launch_decide_lds(const sg_handle* h, const View& v, const Geo
 template <int N>
 static hipError_t launch_apply_n(const View& v, const Geom& g, int64_t units, const void* tw, const float* wa,
                                  const float* ws, const float* M, float* seg, hipStream_t st) {
-  constexpr int NT = N >= 4096 ? 256 : 64;
-  constexpr int WAVES = N >= 4096 ? 1 : ((N * sizeof(cx<float>) > 16384) ? 2 : 4);
+  constexpr int NT = N >= SG_TEAM_N ? 256 : 64;
+  constexpr int WAVES = N >= SG_TEAM_N ? 1 : ((N * sizeof(cx<float>) > 16384) ? 2 : 4);
   constexpr int FPW = 4;
   size_t lds = (size_t)(N + WAVES * lpn<float>(N)) * sizeof(cx<float>);
   auto kern = k_apply_istft<N, WAVES, FPW, NT>;
@@ -1691,8 +1697,8 @@ static int stage_onepass(sg_handle* h, const View& v, const View& vx, const Geom
 template <int N>
 static hipError_t launch_xapply_n(const View& v, const Geom& g, int64_t units, const void* tw, const double* win,
                                   const double* M, double* seg, hipStream_t st) {
-  constexpr int NT = N >= 4096 ? 256 : 64;
-  constexpr int WAVES = N >= 4096 ? 1 : ((N * sizeof(cx<double>) > 16384) ? 2 : 4);
+  constexpr int NT = N >= SG_TEAM_N ? 256 : 64;
+  constexpr int WAVES = N >= SG_TEAM_N ? 1 : ((N * sizeof(cx<double>) > 16384) ? 2 : 4);
   constexpr int FPW = 4;
   const size_t lds = (size_t)(N + WAVES * lpn<double>(N)) * sizeof(cx<double>);
   auto kern = exact::kx_apply_istft<N, WAVES, FPW, NT>;
