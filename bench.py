@@ -35,6 +35,23 @@ import torch.distributed as dist
 ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
+# CPython garbage-collector pauses on the enqueueing thread: a generation-2 collection of a process that has torch
+# imported takes ~35 ms (tools/stall_probe.py), during which the GPU idles -- the "40 ms repetition" of BENCH_r02's
+# configs[2] leg.  The collections are logged, and the objects that exist once the workload is set up are frozen
+# (gc.freeze) so that a full collection inside a timed leg only has the leg's own garbage to look at.
+import gc
+GC_PAUSES = []
+
+
+def _gc_cb(phase, info, _t=[0.0]):
+    if phase == "start":
+        _t[0] = time.perf_counter()
+    else:
+        GC_PAUSES.append((info["generation"], (time.perf_counter() - _t[0]) * 1e3))
+
+
+gc.callbacks.append(_gc_cb)
+
 SR = 48000
 SECONDS = 600
 N_PER_GPU = SR * SECONDS            # 28.8 M samples
@@ -313,6 +330,9 @@ def main():
 
     for _ in range(args.warmup):
         step()
+    gc.collect()
+    gc.freeze()
+    GC_PAUSES.clear()
     gate = engine_gate()
     # untimed survey pass: every kernel bracketed by HIP events -> per-kernel table + dominant kernel
     gate.profile_read(reset=True)
@@ -463,6 +483,9 @@ def main():
             line["distributed"] = distributed
         if world == 1 and not args.no_extras:
             line.update(extras(device, wl, out, y2d, gate, O))
+        line["host_gc"] = {"pauses_over_1ms": [(g_, round(ms_, 2)) for g_, ms_ in GC_PAUSES if ms_ > 1.0],
+                           "note": "CPython collector pauses on the enqueueing thread since the warm-up (generation, ms); "
+                                   "objects alive after the warm-up are frozen (gc.freeze)"}
         if world == 1 and not args.no_cpu_baseline:
             line["cpu_baseline"] = cpu_baseline()
         print(json.dumps(line))

@@ -452,6 +452,9 @@ def cached_gate(device, slot=0, **kw):
     """`slot` distinguishes handles with identical parameters: calls that are in flight at the same time
     on different streams must not share a handle (its workspace is per call)."""
     dev = resolve_device(device)
+    # integer recordings: the reference truncates a float64 result (base.py:217-226) -> float64 pipeline by default;
+    # NOISEREDUCE_AMD_FAST_INT=1 keeps the fused float32 kernels (<= 1 LSB off on ~1 % of the samples)
+    kw.setdefault("fast_integer", os.environ.get("NOISEREDUCE_AMD_FAST_INT", "0") == "1")
 
     def norm(v):
         if isinstance(v, np.ndarray):

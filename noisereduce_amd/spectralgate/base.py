@@ -8,8 +8,6 @@ once and the whole chunk grid of ``get_traces`` (base.py:167-226) -- every
 joblib pool and no memmap tempfile (``n_jobs``, ``tmp_folder`` and ``use_tqdm`` are
 accepted and ignored).  ``_do_filter`` stays the operator seam (base.py:158-160).
 """
-import os
-
 import numpy as np
 import torch
 
@@ -106,10 +104,7 @@ class SpectralGate:
                     hop_length=self._hop_length, n_grad_freq=self._n_grad_freq,
                     n_grad_time=self._n_grad_time, smooth_mask=self.smooth_mask,
                     chunk_size=self._chunk_size, padding=self.padding,
-                    prop_decrease=self._prop_decrease,
-                    # integer recordings: the reference truncates a float64 result (base.py:217-226) -> float64
-                    # pipeline by default; NOISEREDUCE_AMD_FAST_INT=1 keeps the fused float32 kernels (<= 1 LSB off)
-                    fast_integer=os.environ.get("NOISEREDUCE_AMD_FAST_INT", "0") == "1")
+                    prop_decrease=self._prop_decrease)
 
     def _to_device(self, a):
         """Upload a host array (or pass a tensor) as one of the dtypes the kernels read

@@ -33,19 +33,27 @@ kf = GiB / (max(cal_f) * 1024) if cal_f else None
 kw = GiB / (max(cal_w) * 1024) if cal_w else None
 print("calibration factors (true bytes / (counter*1024)): fetch", kf, "write", kw)
 names = {"k_gate_onepass": "k_gate_onepass (fft+decide+smooth+mask+ifft+ola)",
-         "k_apply_fast": "k_apply_fast (fft+mask+ifft+ola)", "k_decide_fast": "k_decide_fast (f32 stft + exact f64 refine)",
-         "k_smooth_bits2": "k_smooth_f+k_smooth_t", "k_unit_absmax": "k_unit_absmax+k_prep_thresh",
-         "k_stft<double": "noise statistics: k_stft<double>", "k_colstats1(": "noise statistics: k_colstats1"}
+         "k_unit_absmax": "k_unit_absmax+k_prep_thresh"}
 traffic = {}; detail = {}
-for short, stage in names.items():
-    fr = [v for k, v in res.get("FETCH_SIZE", {}).items() if short in k]
-    wr = [v for k, v in res.get("WRITE_SIZE", {}).items() if short in k]
+import re
+def short_name(k):
+    m = re.search(r"sg::(?:fast::|big::|exact::)?(k_[a-z0-9_]+(?:<[^(]*>)?)", k)
+    return m.group(1) if m else None
+allk = set(res.get("FETCH_SIZE", {})) | set(res.get("WRITE_SIZE", {}))
+for k in sorted(allk):
+    sn = short_name(k)
+    if not sn: continue
+    fr = res.get("FETCH_SIZE", {}).get(k); wr = res.get("WRITE_SIZE", {}).get(k)
     if not fr or not wr: continue
-    fb = fr[0][0] * 1024 * (kf or 1.0); wb = wr[0][0] * 1024 * (kw or 1.0)
-    traffic[stage] = int(fb + wb)
-    detail[short] = {"fetch_bytes": int(fb), "write_bytes": int(wb), "raw_FETCH_SIZE": fr[0][0], "raw_WRITE_SIZE": wr[0][0]}
+    fb = fr[0] * 1024 * (kf or 1.0); wb = wr[0] * 1024 * (kw or 1.0)
+    detail[sn] = {"launches": fr[1], "fetch_bytes": int(fb), "write_bytes": int(wb), "total_bytes": int(fb + wb),
+                  "raw_FETCH_SIZE": fr[0], "raw_WRITE_SIZE": wr[0]}
+    for short, stage in names.items():
+        if sn.startswith(short): traffic[stage] = int(fb + wb)
 json.dump(traffic, open(os.path.join(out, "traffic.json"), "w"), indent=1)
 json.dump({"calibration": {"fetch_factor": kf, "write_factor": kw, "method": "1 GiB torch clone in the same run"},
+           "workloads": "tools/traffic_probe.py: configs[1] stationary, configs[2] non-stationary (10 min mono each), "
+                        "configs[4] TorchGate 256 x 16000 forward; per-launch averages",
            "kernels": detail}, open(os.path.join(out, "traffic_detail.json"), "w"), indent=1)
 print(json.dumps(detail, indent=1))
 PY

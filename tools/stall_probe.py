@@ -12,6 +12,16 @@ import noisereduce_amd as nr
 from noisereduce_amd.torchgate import TorchGate
 
 reps = int(sys.argv[1]) if len(sys.argv) > 1 else 200
+# CPython garbage-collector pauses on the enqueueing thread (a full collection of a process that has torch imported
+# takes tens of milliseconds: the GPU idles meanwhile and the repetition looks like a 30-40 ms kernel)
+import gc
+GC_LOG = []
+def _gc_cb(phase, info, _t=[0.0]):
+    if phase == "start":
+        _t[0] = time.perf_counter()
+    else:
+        GC_LOG.append((info["generation"], (time.perf_counter() - _t[0]) * 1e3))
+gc.callbacks.append(_gc_cb)
 dev = torch.device("cuda", 0)
 SR = 48000
 g = torch.Generator(device=dev); g.manual_seed(1234)
@@ -35,7 +45,9 @@ def probe(name, fn, warm=3):
     out = {"name": name, "reps": reps, "median_ms": float(np.median(ts)), "mean_ms": float(ts.mean()), "max_ms": float(ts.max()),
            "outliers(rep, gpu_ms, host_enqueue_ms)": [(int(i), round(float(ts[i]), 3), round(float(host[i]), 3)) for i in np.argsort(-ts)[:6]],
            "first10_ms": [round(float(t), 3) for t in ts[:10]],
-           "host_enqueue_median_ms": float(np.median(host)), "host_enqueue_max_ms": float(host.max())}
+           "host_enqueue_median_ms": float(np.median(host)), "host_enqueue_max_ms": float(host.max()),
+           "gc_pauses_ms(generation, ms) over 1 ms": [(g_, round(ms_, 2)) for g_, ms_ in GC_LOG if ms_ > 1.0]}
+    GC_LOG.clear()
     print(json.dumps(out), flush=True)
 
 probe("config2 stationary reduce_noise", lambda: nr.reduce_noise(y=y, sr=SR, stationary=True))
@@ -43,3 +55,12 @@ probe("config3 non-stationary reduce_noise", lambda: nr.reduce_noise(y=y, sr=SR,
 tg = TorchGate(sr=16000).to(dev)
 x = (0.1 * torch.randn(256, 16000, device=dev)).float()
 probe("config5 TorchGate forward", lambda: tg(x), warm=10)
+
+xg = x.clone().requires_grad_()
+def fb():
+    xg.grad = None
+    tg(xg).sum().backward()
+probe("config5 TorchGate forward+backward", fb, warm=10)
+import gc
+gc.disable()
+probe("config5 TorchGate forward+backward (gc disabled)", fb, warm=10)

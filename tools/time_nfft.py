@@ -12,9 +12,9 @@ rng = np.random.default_rng(0)
 y = (0.1 * rng.standard_normal(n) + 0.5 * np.sin(2 * np.pi * 1000 * np.arange(n) / sr)).astype(np.float32)
 yd = torch.from_numpy(y).cuda()
 res = {}
-for n_fft in (256, 400, 512, 1000, 1024, 1536, 2048, 3000, 4096, 8192):
+for n_fft in (256, 400, 512, 1000, 1024, 1536, 2048, 3000, 4096, 8192, 5000, 16384, 32768):
     for stationary in (True, False):
-        kw = dict(stationary=stationary, n_fft=n_fft, time_mask_smooth_ms=200 if n_fft > 2048 else 50)
+        kw = dict(stationary=stationary, n_fft=n_fft, time_mask_smooth_ms=(400 if n_fft > 16384 else 200) if n_fft > 2048 else 50)
         for _ in range(2):
             nr.reduce_noise(y=yd, sr=sr, **kw)
         torch.cuda.synchronize()

@@ -12,5 +12,17 @@ for _ in range(3):
 torch.cuda.synchronize()
 y = bench.synth_on_device(bench.N_PER_GPU, 1234, dev)
 for _ in range(4):
-    out = nr.reduce_noise(y=y, sr=48000, stationary=True)
+    out = nr.reduce_noise(y=y, sr=48000, stationary=True)        # configs[1]
+torch.cuda.synchronize()
+for _ in range(4):
+    out = nr.reduce_noise(y=y, sr=48000, stationary=False)       # configs[2]
+torch.cuda.synchronize()
+import numpy as np
+from noisereduce_amd.torchgate import TorchGate
+torch.manual_seed(0)
+t = torch.arange(16000, device=dev, dtype=torch.float64) / 16000
+x = (0.1 * torch.randn(256, 16000, device=dev) + 0.5 * torch.sin(2 * np.pi * 440 * t).float()).float()
+tg = TorchGate(sr=16000).to(dev)
+for _ in range(4):
+    out = tg(x)                                                  # configs[4] forward
 torch.cuda.synchronize()
