@@ -52,8 +52,11 @@ def test_random_configuration_matches_oracle(seed):
     if dtype == "int16":
         # truncation to int16 (base.py:218-226) of a float64 result: the truncated oracle, bit for bit (float64 pipeline).
         # (A sample whose float64 value sits within ~1e-9 of an integer could still fall either way: allow a handful.)
+        # (samples whose float64 value lies within 1e-9 of an integer -- mask exactly 1: the integer input reconstructed to
+        # ~1e-12 -- fall on either side by the reference's own rounding noise: within one count there, equal elsewhere)
         diff = got.astype(np.int64) - want.astype(np.int16).astype(np.int64)
-        assert np.max(np.abs(diff)) <= 1 and np.count_nonzero(diff) <= 2, np.count_nonzero(diff)
+        decided = np.abs(want - np.round(want)) > 1e-9
+        assert np.max(np.abs(diff)) <= 1 and np.count_nonzero(diff[decided]) == 0, np.count_nonzero(diff[decided])
     else:
         assert O.rel_err(got.astype(np.float64), want) < TOL, (kw, sr, C, n)
     # tensor input on the device: same numbers as the numpy path

@@ -231,12 +231,16 @@ def test_integer_recordings_are_bit_exact(nr, kw, dtype):
     scale = 20000 if dtype == np.int16 else 1.5e9
     y = np.stack([np.round(O.synth_signal(n, seed=71 + c, tone_hz=500.0 * (c + 1)).astype(np.float64) * scale) for c in range(2)]).astype(dtype)
     got = nr.reduce_noise(y=y, sr=48000, **kw)
-    want = O.reduce_noise_S(y.astype(np.float64), 48000, **kw).astype(dtype)
+    want64 = O.reduce_noise_S(y.astype(np.float64), 48000, **kw)
+    want = want64.astype(dtype)
     assert got.dtype == dtype and got.shape == y.shape
     diff = got.astype(np.int64) - want.astype(np.int64)
-    # float64 evaluation order differs from numpy's (1e-16 relative): a value that sits within ~1e-9 of an integer
-    # may fall on the other side -- none expected in 180 000 samples of int16, at most a few of int32 at 1.5e9 scale
-    assert np.max(np.abs(diff)) <= 1 and np.count_nonzero(diff) <= (0 if dtype == np.int16 else 8), np.count_nonzero(diff)
+    # float64 evaluation order differs from numpy's (1e-16 relative): a value within 1e-9 (int16) / 1e-4 (int32 at 1.5e9:
+    # 1e-13 relative) of an integer may fall on the other side -- e.g. where the mask is exactly 1 and the gate reconstructs
+    # the integer input to ~1e-12, the reference's own truncation is rounding noise.  Everywhere else: equal.
+    decided = np.abs(want64 - np.round(want64)) > (1e-9 if dtype == np.int16 else 1e-4)
+    assert np.max(np.abs(diff)) <= 1 and np.count_nonzero(diff[decided]) == 0, np.count_nonzero(diff[decided])
+    assert np.count_nonzero(decided) > 0.9 * decided.size
 
 
 def test_force_exact_float64(nr):

@@ -13,13 +13,13 @@ STATS = dict(compared=0, valueerror=0, max_err_S=0.0, max_err_T=0.0)
 
 def case_S(seed):
     r = np.random.default_rng(77000 + seed)
-    n_fft = int(r.choice([64, 100, 128, 255, 256, 400, 512, 1000, 1024, 1024, 1536, 2048]))
+    n_fft = int(r.choice([64, 100, 128, 255, 256, 400, 512, 1000, 1024, 1024, 1536, 2048, 4096, 4500, 6000, 16384]))
     win = n_fft if r.random() < 0.5 else int(r.integers(max(8, n_fft // 3), n_fft + 1))
     hop = win // 4 if r.random() < 0.5 else int(r.integers(max(1, win // 10), max(2, win // 2) + 1))
     sr = int(r.choice([8000, 11025, 16000, 32000, 44100, 48000, 96000]))
     C = int(r.choice([1, 1, 2, 4]))
-    n = int(r.integers(3 * n_fft + 5, 50000))
-    cs = None if r.random() < 0.15 else int(r.integers(max(2 * n_fft, 500), 25000))
+    n = int(r.integers(3 * n_fft + 5, max(50000, 4 * n_fft)))
+    cs = None if r.random() < 0.15 else int(r.integers(max(2 * n_fft, 500), max(25000, 3 * n_fft)))
     pad = int(r.integers(0, 4 * n_fft))
     stationary = bool(r.random() < 0.55)
     kw = dict(stationary=stationary, n_fft=n_fft, win_length=win, hop_length=hop, chunk_size=cs, padding=pad,
@@ -42,7 +42,7 @@ def case_S(seed):
         kw.update(freq_mask_smooth_hz=f_hz, time_mask_smooth_ms=t_ms)
     noise = None
     if stationary and r.random() < 0.4:
-        nl = int(r.integers(max(win, 2 * n_fft), 30000))
+        nl = int(r.integers(max(win, 2 * n_fft), max(30000, 3 * n_fft)))
         noise = ("2d" if (C > 1 and r.random() < 0.5) else "1d", nl)
     dtype = str(r.choice(["float32", "float64", "float64", "int16"]))
     return sr, C, n, dtype, noise, kw
@@ -71,7 +71,15 @@ def run_S(seed):
     got = nr.reduce_noise(y=y, sr=sr, **kw)
     assert got.shape == y.shape and got.dtype == y.dtype
     if dtype == "int16":
-        assert np.max(np.abs(got.astype(np.int64) - np.trunc(want).astype(np.int64))) <= 1
+        # integer recordings: the truncated float64 result, bit for bit (a value within ~1e-9 of an integer may differ)
+        # Samples whose float64 value sits within 1e-9 of an integer are excluded: where the mask is exactly 1 the gate
+        # reconstructs the integer input to ~1e-12, and which side of the integer the REFERENCE lands on is its own
+        # rounding noise (pocketfft's summation order) -- there the engine must be within 1 count, elsewhere equal.
+        diff = got.astype(np.int64) - np.trunc(want).astype(np.int64)
+        decided = np.abs(want - np.round(want)) > 1e-9
+        assert np.max(np.abs(diff)) <= 1 and np.count_nonzero(diff[decided]) == 0, np.count_nonzero(diff[decided])
+        STATS["int_samples_decided"] = STATS.get("int_samples_decided", 0) + int(np.count_nonzero(decided))
+        STATS["int_samples_on_an_integer"] = STATS.get("int_samples_on_an_integer", 0) + int(np.count_nonzero(~decided))
     else:
         # relative to the larger of the output and (a millionth of) the input: a gate that removes
         # everything leaves fftconvolve dust (~1e-19) in the reference and exact zeros here
