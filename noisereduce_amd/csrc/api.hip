@@ -2,6 +2,7 @@
 // Builds tables, owns the workspace, batches (channel, chunk) units and enqueues the
 // kernels of kernels.hpp on the caller's HIP stream.  gfx950 only.
 #include <hip/hip_runtime.h>
+#include <dlfcn.h>
 
 #include <algorithm>
 #include <cmath>
@@ -112,6 +113,7 @@ struct sg_handle {
   int64_t dbg_db = 0, dbg_de = 0;  // frames whose mask bits were decided in the last batch
   bool force_unfused = false;  // sg_set_option(SG_OPT_FORCE_UNFUSED): materialised v1 path
   // per-kernel timing with HIP events on the launch stream (sg_profile_*)
+  bool roctx_on = false;       // SG_ROCTX=1: a roctx range around every stage's enqueue
   bool prof_on = false;
   uint64_t prof_mask = ~0ull;  // stages that get an event pair (sg_profile_select)
   int prof_override = -1;  // >= 0: book every launch under this stage (noise statistics)
@@ -124,6 +126,29 @@ struct sg_handle {
 };
 
 namespace {
+// Optional roctx ranges around every stage's enqueue (SG_ROCTX=1 in the environment at sg_create): the stages show
+// up by name in `rocprofv3 --marker-trace` next to the kernel trace.  libroctx64 is looked up at run time: the library
+// does not depend on it.
+struct Roctx {
+  int (*push)(const char*) = nullptr;
+  int (*pop)() = nullptr;
+  Roctx() {
+    // rocprofv3 listens to the rocprofiler-sdk flavour; libroctx64 is the roctracer one (older tools)
+    void* lib = dlopen("librocprofiler-sdk-roctx.so", RTLD_NOW | RTLD_GLOBAL);
+    if (!lib) lib = dlopen("librocprofiler-sdk-roctx.so.1", RTLD_NOW | RTLD_GLOBAL);
+    if (!lib) lib = dlopen("libroctx64.so", RTLD_NOW | RTLD_GLOBAL);
+    if (!lib) lib = dlopen("libroctx64.so.4", RTLD_NOW | RTLD_GLOBAL);
+    if (!lib) return;
+    push = reinterpret_cast<int (*)(const char*)>(dlsym(lib, "roctxRangePushA"));
+    pop = reinterpret_cast<int (*)()>(dlsym(lib, "roctxRangePop"));
+    if (!push || !pop) push = nullptr, pop = nullptr;
+  }
+};
+const Roctx& roctx() {
+  static const Roctx r;
+  return r;
+}
+
 // RAII: records an event pair around one kernel launch when profiling is enabled.
 struct ProfScope {
   sg_handle* h;
@@ -139,7 +164,12 @@ struct ProfScope {
     (void)hipEventCreate(&e);
     return e;
   }
+  bool ranged = false;
   ProfScope(sg_handle* h_, int stage, hipStream_t st_) : h(h_), st(st_) {
+    if (h->roctx_on && roctx().push) {
+      roctx().push(sg_stage_name(h->prof_override >= 0 ? h->prof_override : stage));
+      ranged = true;
+    }
     if (!h->prof_on) return;
     const int booked = h->prof_override >= 0 ? h->prof_override : stage;
     if (!((h->prof_mask >> booked) & 1ull)) return;
@@ -150,6 +180,7 @@ struct ProfScope {
   }
   ~ProfScope() {
     if (idx >= 0) (void)hipEventRecord(h->prof_live[idx].b, st);
+    if (ranged) roctx().pop();
   }
 };
 }  // namespace
@@ -807,6 +838,10 @@ extern "C" int sg_create(const sg_params* p, const double* window_host, sg_handl
 
   sg_handle* h = new sg_handle();
   h->p = *p;
+  {
+    const char* e = getenv("SG_ROCTX");
+    h->roctx_on = e && e[0] == '1';
+  }
   h->n = n;
   h->N = n / 2;
   h->W = p->win_length;
