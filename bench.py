@@ -39,7 +39,7 @@ sys.path.insert(0, ROOT)
 # imported takes ~35 ms (tools/stall_probe.py), during which the GPU idles -- the "40 ms repetition" of BENCH_r02's
 # configs[2] leg.  The collections are logged, and the objects that exist once the workload is set up are frozen
 # (gc.freeze) so that a full collection inside a timed leg only has the leg's own garbage to look at.
-import gc
+import gc as _gc
 GC_PAUSES = []
 
 
@@ -50,7 +50,7 @@ def _gc_cb(phase, info, _t=[0.0]):
         GC_PAUSES.append((info["generation"], (time.perf_counter() - _t[0]) * 1e3))
 
 
-gc.callbacks.append(_gc_cb)
+_gc.callbacks.append(_gc_cb)
 
 SR = 48000
 SECONDS = 600
@@ -330,8 +330,8 @@ def main():
 
     for _ in range(args.warmup):
         step()
-    gc.collect()
-    gc.freeze()
+    _gc.collect()
+    _gc.freeze()
     GC_PAUSES.clear()
     gate = engine_gate()
     # untimed survey pass: every kernel bracketed by HIP events -> per-kernel table + dominant kernel
