@@ -9,6 +9,8 @@
 #include <cstdarg>
 #include <cstdio>
 #include <cstring>
+#include <map>
+#include <mutex>
 #include <string>
 #include <vector>
 
@@ -23,6 +25,7 @@
 #include "fused.hpp"
 #include "czt.hpp"
 #include "onepass.hpp"
+#include "fast512.hpp"
 #include "nonstat.hpp"
 #include "fast64.hpp"
 #include "big.hpp"
@@ -101,6 +104,8 @@ struct sg_handle {
   bool force_noseam = false;
   bool force_nolean = false;         // SG_OPT_FORCE_NOLEAN: full-size slices + stored frames (2 waves/SIMD)
   bool fast_ok = false;              // default geometry: fused apply kernel available
+  bool fast5_ok = false;             // n_fft = win = 512, hop = 128: register-transform kernels of fast512.hpp
+  DevBuf invn5;                      // 1 / window envelope per hop phase (128) of that geometry
   bool force_nofast = false;
   bool force_f64_decide = false;     // SG_OPT_FORCE_F64_DECIDE: float64 STFT for every mask decision
   int64_t ktot = 1;                  // (nf+1)^2 (nt+1)^2: integer weight total of the smoothing filter
@@ -200,6 +205,21 @@ struct ProfScope {
     return (code);              \
   } while (0)
 
+// hipFuncSetAttribute(MaxDynamicSharedMemorySize) once per (device, kernel, size): the call costs microseconds of host
+// time, and a short call enqueues ten launches
+static hipError_t set_lds(const void* kern, size_t bytes) {
+  static std::mutex mu;
+  static std::map<std::pair<int, const void*>, size_t> done;
+  int dev = 0;
+  (void)hipGetDevice(&dev);
+  std::lock_guard<std::mutex> lk(mu);
+  size_t& have = done[{dev, kern}];
+  if (have >= bytes) return hipSuccess;
+  hipError_t e = hipFuncSetAttribute(kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)bytes);
+  if (e == hipSuccess) have = bytes;
+  return e;
+}
+
 static int ensure(sg_handle* h, DevBuf& b, size_t bytes) {
   if (b.bytes >= bytes) return SG_OK;
   if (b.p) {
@@ -278,8 +298,7 @@ static hipError_t launch_stft_n(const View& v, const Geom& g, int64_t units, con
   const bool small = units * ((g.T + WAVES * 4 - 1) / (WAVES * 4)) < 1024;
   auto launch = [&](auto kern, int fpw) -> hipError_t {
     if (lds > 65536) {
-      hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern),
-                                         hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+      hipError_t e = set_lds(reinterpret_cast<const void*>(kern), lds);
       if (e != hipSuccess) return e;
     }
     dim3 grid((unsigned)((g.T + WAVES * fpw - 1) / (WAVES * fpw)), (unsigned)units);
@@ -318,8 +337,7 @@ static hipError_t launch_bits_n(const View& v, const Geom& g, int64_t units, con
   size_t lds = (size_t)(N + WAVES * lpn<double>(N)) * sizeof(cx<double>) + (size_t)(N + 1) * sizeof(double);
   auto kern = k_stft_bits<N, WAVES, FPW, MODE>;
   if (lds > 65536) {
-    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern),
-                                       hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    hipError_t e = set_lds(reinterpret_cast<const void*>(kern), lds);
     if (e != hipSuccess) return e;
   }
   dim3 grid((unsigned)((g.T + WAVES * FPW - 1) / (WAVES * FPW)), (unsigned)units);
@@ -352,8 +370,7 @@ static hipError_t launch_decide_lds_n(const sg_handle* h, const View& v, const G
   const size_t lds = (size_t)(N + WAVES * N) * sizeof(cx<float>) + (size_t)(N + 1) * sizeof(float);
   auto kern = k_decide_lds<N, WAVES, FPW>;
   if (lds > 65536) {
-    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern),
-                                       hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    hipError_t e = set_lds(reinterpret_cast<const void*>(kern), lds);
     if (e != hipSuccess) return e;
   }
   dim3 grid((unsigned)((g.T + WAVES * FPW - 1) / (WAVES * FPW)), (unsigned)units);
@@ -386,8 +403,7 @@ static hipError_t launch_apply_n(const View& v, const Geom& g, int64_t units, co
   size_t lds = (size_t)(N + WAVES * lpn<float>(N)) * sizeof(cx<float>);
   auto kern = k_apply_istft<N, WAVES, FPW, NT>;
   if (lds > 65536) {
-    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern),
-                                       hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    hipError_t e = set_lds(reinterpret_cast<const void*>(kern), lds);
     if (e != hipSuccess) return e;
   }
   dim3 grid((unsigned)((g.T + WAVES * FPW - 1) / (WAVES * FPW)), (unsigned)units);
@@ -427,8 +443,7 @@ static hipError_t launch_stft_czt_m(const View& v, const Geom& g, int64_t units,
   const size_t lds = (size_t)FR * lpn<TC>(M) * sizeof(cx<TC>);
   auto kern = k_stft_czt<TC, M, NT, FR>;
   if (lds > 65536) {
-    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern),
-                                       hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    hipError_t e = set_lds(reinterpret_cast<const void*>(kern), lds);
     if (e != hipSuccess) return e;
   }
   const int fpb = units * ((g.T + FR * 4 - 1) / (FR * 4)) < 1024 ? 1 : 4;
@@ -446,8 +461,7 @@ static hipError_t launch_apply_czt_m(const View& v, const Geom& g, int64_t units
   const size_t lds = (size_t)FR * lpn<float>(M) * sizeof(cx<float>);
   auto kern = k_apply_istft_czt<M, NT, FR>;
   if (lds > 65536) {
-    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern),
-                                       hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    hipError_t e = set_lds(reinterpret_cast<const void*>(kern), lds);
     if (e != hipSuccess) return e;
   }
   const int fpb = 4;
@@ -489,8 +503,7 @@ static hipError_t big_rows_m2(big::cd* W, const big::BigTabs& tb, int64_t nf, in
   const size_t lds = (size_t)lpn<double>(M2) * sizeof(big::cd);
   auto go = [&](auto kern) -> hipError_t {
     if (lds > 65536) {
-      hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize,
-                                         (int)lds);
+      hipError_t e = set_lds(reinterpret_cast<const void*>(kern), lds);
       if (e != hipSuccess) return e;
     }
     hipLaunchKernelGGL(kern, dim3((unsigned)(nf * 16)), dim3(256), lds, st, W, tb, nf);
@@ -601,8 +614,7 @@ static hipError_t stft_any(const sg_handle* h, const View& v, const Geom& g, int
     const size_t lds = (size_t)(fast::FN + WAVES * 4 * fast::FSLOTS_D + 32) * sizeof(fast::cd);
     dim3 grid((unsigned)((g.T + WAVES * 4 - 1) / (WAVES * 4)), (unsigned)units);
     auto go = [&](auto kern) -> hipError_t {
-      hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern),
-                                         hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+      hipError_t e = set_lds(reinterpret_cast<const void*>(kern), lds);
       if (e != hipSuccess) return e;
       hipLaunchKernelGGL(kern, grid, dim3(WAVES * 64), lds, st, A);
       return hipGetLastError();
@@ -944,6 +956,23 @@ extern "C" int sg_create(const sg_params* p, const double* window_host, sg_handl
     if (!rc) rc = upload(h, h->invn, invn.data(), invn.size() * sizeof(float));
     h->fast_ok = true;
   }
+  if (!rc && n == 512 && W == 512 && h->H == 128) {
+    // fast512.hpp: the 512-point complex transform of the default geometry carries two real frames of 512 samples
+    std::vector<cx<float>> t512(512);
+    for (int j = 0; j < 512; ++j) {
+      long double a = -2.0L * 3.14159265358979323846264338327950288L * (long double)j / 512.0L;
+      t512[j] = {(float)cosl(a), (float)sinl(a)};
+    }
+    std::vector<float> invn(128);
+    for (int s2 = 0; s2 < 128; ++s2) {
+      double acc = 0.0;
+      for (int q = 0; q < 4; ++q) acc += wfull[128 * q + s2] * wfull[128 * q + s2];
+      invn[s2] = (float)(acc > 1e-10 ? 1.0 / acc : 1.0);
+    }
+    rc = upload(h, h->tw512, t512.data(), t512.size() * sizeof(cx<float>));
+    if (!rc) rc = upload(h, h->invn5, invn.data(), invn.size() * sizeof(float));
+    h->fast5_ok = true;
+  }
   if (!rc && p->smooth_mask && 8 + 2 * p->n_grad_freq <= 18) {
     // counts of 8 adjacent bins f..f+7 from the 18-bit window b[f-nf .. f-nf+17]: two 9-bit tables
     const int nf = p->n_grad_freq;
@@ -1012,7 +1041,7 @@ extern "C" int sg_destroy(sg_handle* h) {
                     &h->need, &h->T2, &h->part, &h->tw512, &h->invn, &h->seam, &h->ftab, &h->xbits, &h->xpart,
                     &h->xticket, &h->xtick2, &h->ftab3, &h->xexp, &h->nsp, &h->nsc, &h->xin, &h->czt_tw64, &h->czt_ch64,
                     &h->czt_bh64, &h->czt_tw32, &h->czt_ch32, &h->czt_bh32, &h->logtab, &h->big_twM, &h->big_tw2,
-                    &h->big_ch, &h->big_bh, &h->big_W, &h->big_W2, &h->xP, &h->xraw, &h->xM, &h->xtmp, &h->xseg})
+                    &h->big_ch, &h->big_bh, &h->big_W, &h->big_W2, &h->xP, &h->xraw, &h->xM, &h->xtmp, &h->xseg, &h->invn5})
     free_buf(*b);
   delete h;
   return SG_OK;
@@ -1160,8 +1189,78 @@ static int stage_decide(sg_handle* h, const Geom& g, int64_t ub, const double* t
   return SG_OK;
 }
 
+// ------------------------------------------------------------------------------------------
+// n_fft = 512 / hop 128 on the register transform (fast512.hpp)
+// ------------------------------------------------------------------------------------------
+static fast::Fast5Args fast5_args(const sg_handle* h, const View& v, const Geom& g) {
+  fast::Fast5Args A{};
+  A.view = v; A.g = g;
+  A.win = (const float*)h->wa32.p;
+  A.win64 = (const double*)h->wfull64.p;
+  A.tw512 = (const fast::cf*)h->tw512.p;
+  A.tw64 = (const cx<double>*)h->tw64.p;
+  A.mag_scale = h->mag_scale; A.top_db = h->p.top_db;
+  A.wsq = (const float*)h->wsq32.p;
+  A.invn = (const float*)h->invn5.p;
+  return A;
+}
+constexpr size_t FAST5_LDS = (size_t)(fast::FN + 4 * fast::WAVE_CX_H) * sizeof(fast::cf) + (512 + 264) * sizeof(float);
+
+static int stage_decide512(sg_handle* h, const View& v, const Geom& g, int64_t ub, const ThreshConsts& tc,
+                           unsigned long long* bits, hipStream_t st) {
+  ProfScope ps(h, SG_STAGE_DECIDE_FAST, st);
+  fast::Fast5Args A = fast5_args(h, v, g);
+  A.tc = tc;
+  A.bits = bits;
+  auto kern = fast::k_decide_fast512<4>;
+  HIPCHK(h, set_lds(reinterpret_cast<const void*>(kern), FAST5_LDS));
+  hipLaunchKernelGGL(kern, dim3((unsigned)((g.T + 31) / 32), (unsigned)ub), dim3(256), FAST5_LDS, st, A);
+  HIPCHK(h, hipGetLastError());
+  return SG_OK;
+}
+
+static int stage_mag512(sg_handle* h, const View& v, const Geom& g, int64_t ub, float* mag, hipStream_t st) {
+  ProfScope ps(h, SG_STAGE_STFT_MAG, st);
+  fast::Fast5Args A = fast5_args(h, v, g);
+  A.mag = mag;
+  auto kern = fast::k_mag_fast512<4>;
+  HIPCHK(h, set_lds(reinterpret_cast<const void*>(kern), FAST5_LDS));
+  hipLaunchKernelGGL(kern, dim3((unsigned)((g.T + 31) / 32), (unsigned)ub), dim3(256), FAST5_LDS, st, A);
+  HIPCHK(h, hipGetLastError());
+  return SG_OK;
+}
+
+static int stage_apply512(sg_handle* h, const View& v, const Geom& g, int64_t ub, const OutMap& om,
+                          const float* mask_f /* nullptr: uint16 weight sums in h->K16 (natural bin order) */,
+                          int normalize, hipStream_t st) {
+  ProfScope ps(h, SG_STAGE_APPLY_FAST, st);
+  fast::Fast5Args A = fast5_args(h, v, g);
+  A.Mf = mask_f;
+  A.K = (const unsigned short*)h->K16.p;
+  A.inv_ktot = (float)(1.0 / (double)h->ktot);
+  A.om = om;
+  A.normalize = normalize;
+  A.h_begin = (om.p0 + g.padL) / 128;
+  A.h_end = (om.p1 - 1 + g.padL) / 128 + 1;
+  const int64_t nh = A.h_end - A.h_begin;
+  if (nh <= 0) return SG_OK;
+  const dim3 grid((unsigned)((nh + 28) / 29), (unsigned)ub);
+  if (mask_f) {
+    auto kern = fast::k_apply_fast512<4, false>;
+    HIPCHK(h, set_lds(reinterpret_cast<const void*>(kern), FAST5_LDS));
+    hipLaunchKernelGGL(kern, grid, dim3(256), FAST5_LDS, st, A);
+  } else {
+    auto kern = fast::k_apply_fast512<4, true>;
+    HIPCHK(h, set_lds(reinterpret_cast<const void*>(kern), FAST5_LDS));
+    hipLaunchKernelGGL(kern, grid, dim3(256), FAST5_LDS, st, A);
+  }
+  HIPCHK(h, hipGetLastError());
+  return SG_OK;
+}
+
 static int stage_mag(sg_handle* h, const View& v, const Geom& g, int64_t ub, hipStream_t st) {
   float* mag = (float*)h->P.p;
+  if (h->fast5_ok && !h->force_nofast) return stage_mag512(h, v, g, ub, mag, st);
   if (h->fast_ok && !h->force_nofast) {
     ProfScope ps(h, SG_STAGE_STFT_MAG, st);
     constexpr int WAVES = 4;
@@ -1173,8 +1272,7 @@ static int stage_mag(sg_handle* h, const View& v, const Geom& g, int64_t ub, hip
     M.mag = mag;
     size_t lds = (size_t)(fast::FN + WAVES * fast::WAVE_CX_H) * sizeof(fast::cf) + 1024 * sizeof(float);
     auto kern = fast::k_mag_fast<WAVES>;
-    HIPCHK(h, hipFuncSetAttribute(reinterpret_cast<const void*>(kern),
-                                  hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+    HIPCHK(h, set_lds(reinterpret_cast<const void*>(kern), lds));
     dim3 grid((unsigned)((g.T + 4 * WAVES - 1) / (4 * WAVES)), (unsigned)ub);
     hipLaunchKernelGGL(kern, grid, dim3(WAVES * 64), lds, st, M);
     HIPCHK(h, hipGetLastError());
@@ -1284,8 +1382,7 @@ static int stage_smooth(sg_handle* h, const Geom& g, int64_t ub, hipStream_t st)
     if (lds <= 150 * 1024 && ub <= 65535 && nf <= 30 && nt <= 30 && SMF_FB + 2 * nf <= 192) {
       auto kern = k_smooth_tiled;
       if (lds > 65536)
-        HIPCHK(h, hipFuncSetAttribute(reinterpret_cast<const void*>(kern),
-                                      hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+        HIPCHK(h, set_lds(reinterpret_cast<const void*>(kern), lds));
       dim3 grid((g.F + SMF_FB - 1) / SMF_FB, (unsigned)((g.T + SMF_TT - 1) / SMF_TT), (unsigned)ub);
       hipLaunchKernelGGL(kern, grid, dim3(256), lds, st, (const float*)h->raw.p, g, (const float*)h->kf.p, nf,
                          (const float*)h->kt.p, nt, p, prop_before0, (float*)h->M.p);
@@ -1340,15 +1437,13 @@ static int stage_smooth_bits(sg_handle* h, const Geom& g, int64_t ub, bool fast,
     if (small) {
       auto kern = k_smooth_bits2<uint8_t>;
       if (lds > 65536)
-        HIPCHK(h, hipFuncSetAttribute(reinterpret_cast<const void*>(kern),
-                                      hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+        HIPCHK(h, set_lds(reinterpret_cast<const void*>(kern), lds));
       hipLaunchKernelGGL(kern, grid, dim3(SM2_THREADS), lds, st, (const unsigned long long*)h->bits.p, g, wpr, nf,
                          nt, (unsigned short*)h->K16.p, fast ? 1 : 0, tb, te, ftab);
     } else {
       auto kern = k_smooth_bits2<uint16_t>;
       if (lds > 65536)
-        HIPCHK(h, hipFuncSetAttribute(reinterpret_cast<const void*>(kern),
-                                      hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+        HIPCHK(h, set_lds(reinterpret_cast<const void*>(kern), lds));
       hipLaunchKernelGGL(kern, grid, dim3(SM2_THREADS), lds, st, (const unsigned long long*)h->bits.p, g, wpr, nf,
                          nt, (unsigned short*)h->K16.p, fast ? 1 : 0, tb, te, (const unsigned long long*)nullptr);
     }
@@ -1360,15 +1455,13 @@ static int stage_smooth_bits(sg_handle* h, const Geom& g, int64_t ub, bool fast,
     if (small) {
       auto kern = k_smooth_bits<uint8_t>;
       if (lds > 65536)
-        HIPCHK(h, hipFuncSetAttribute(reinterpret_cast<const void*>(kern),
-                                      hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+        HIPCHK(h, set_lds(reinterpret_cast<const void*>(kern), lds));
       hipLaunchKernelGGL(kern, grid, dim3(256), lds, st, (const unsigned long long*)h->bits.p, g, wpr, nf, nt,
                          (unsigned short*)h->K16.p, fast ? 1 : 0);
     } else {
       auto kern = k_smooth_bits<uint16_t>;
       if (lds > 65536)
-        HIPCHK(h, hipFuncSetAttribute(reinterpret_cast<const void*>(kern),
-                                      hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+        HIPCHK(h, set_lds(reinterpret_cast<const void*>(kern), lds));
       hipLaunchKernelGGL(kern, grid, dim3(256), lds, st, (const unsigned long long*)h->bits.p, g, wpr, nf, nt,
                          (unsigned short*)h->K16.p, fast ? 1 : 0);
     }
@@ -1449,11 +1542,14 @@ static int stage_fused_mask(sg_handle* h, const View& v, const Geom& g, int64_t 
     const int64_t per_block = (int64_t)WAVES * D.quads_per_wave;
     size_t lds = (size_t)(fast::FN + WAVES * fast::WAVE_CX_H) * sizeof(fast::cf) + (T2_FLOATS + 1024) * sizeof(float);
     auto kern = fast::k_decide_fast<WAVES>;
-    HIPCHK(h, hipFuncSetAttribute(reinterpret_cast<const void*>(kern),
-                                  hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+    HIPCHK(h, set_lds(reinterpret_cast<const void*>(kern), lds));
     dim3 grid((unsigned)((quads + per_block - 1) / per_block), (unsigned)ub);
     hipLaunchKernelGGL(kern, grid, dim3(WAVES * 64), lds, st, D);
     HIPCHK(h, hipGetLastError());
+  } else if (!h->force_f64_decide && h->fast5_ok && !h->force_nofast) {
+    // n_fft = 512: register transform, two frames per lane group
+    int rc5 = stage_decide512(h, v, g, ub, tc, (unsigned long long*)h->bits.p, st);
+    if (rc5) return rc5;
   } else if (!h->force_f64_decide) {
     // other power-of-two frame lengths: float32 LDS transform + exact refinement
     ProfScope ps(h, SG_STAGE_STFT_BITS, st);
@@ -1467,6 +1563,7 @@ static int stage_fused_mask(sg_handle* h, const View& v, const Geom& g, int64_t 
   const int nf = h->p.n_grad_freq, nt = h->p.n_grad_time;
   int64_t cells = ub * g.T * g.FS;
   if (fast) return SG_OK;  // the fused apply kernel reads K directly
+  if (h->fast5_ok && !h->force_nofast && h->p.prop_decrease == 1.0) return SG_OK;   // so does k_apply_fast512<K>
   hipLaunchKernelGGL(k_k16_to_mask, dim3(grid_1d(cells, 256)), dim3(256), 0, st, (const unsigned short*)h->K16.p,
                      g, nf, nt, 1.0f / (float)h->ktot, (float)h->p.prop_decrease, 1, h->p.smooth_mask ? 1 : 0,
                      (float*)h->M.p, ub);
@@ -1585,8 +1682,7 @@ static int stage_apply_fast(sg_handle* h, const View& v, const Geom& g, int64_t 
   }
   dim3 grid((unsigned)(seam ? tiles_seam : (nh + NH - 1) / NH), (unsigned)ub);
   auto go = [&](auto kern, size_t lds_bytes) -> hipError_t {
-    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern),
-                                       hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes);
+    hipError_t e = set_lds(reinterpret_cast<const void*>(kern), lds_bytes);
     if (e != hipSuccess) return e;
     hipLaunchKernelGGL(kern, grid, dim3(WAVES * 64), lds_bytes, st, A);
     return hipGetLastError();
@@ -1709,8 +1805,7 @@ static int stage_onepass(sg_handle* h, const View& v, const View& vx, const Geom
     const size_t lds = (size_t)(fast::FN + WAVES * fast::WAVE_CX_H) * sizeof(fast::cf) + (1024 + T2_FLOATS) * sizeof(float) +
                        256 * 8 + 514 * 8 + 16 + (prop ? 528 : 0);
     auto go = [&](auto kern) -> hipError_t {
-      hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize,
-                                         (int)lds);
+      hipError_t e = set_lds(reinterpret_cast<const void*>(kern), lds);
       if (e != hipSuccess) return e;
       hipLaunchKernelGGL(kern, dim3((unsigned)(ub * ntt)), dim3(WAVES * 64), lds, st, P);
       return hipGetLastError();
@@ -1738,8 +1833,7 @@ static hipError_t launch_xapply_n(const View& v, const Geom& g, int64_t units, c
   const size_t lds = (size_t)(N + WAVES * lpn<double>(N)) * sizeof(cx<double>);
   auto kern = exact::kx_apply_istft<N, WAVES, FPW, NT>;
   if (lds > 65536) {
-    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize,
-                                       (int)lds);
+    hipError_t e = set_lds(reinterpret_cast<const void*>(kern), lds);
     if (e != hipSuccess) return e;
   }
   dim3 grid((unsigned)((g.T + WAVES * FPW - 1) / (WAVES * FPW)), (unsigned)units);
@@ -1754,8 +1848,7 @@ static hipError_t launch_xapply_czt_m(const View& v, const Geom& g, int64_t unit
   const size_t lds = (size_t)FR * lpn<double>(M) * sizeof(cx<double>);
   auto kern = exact::kx_apply_istft_czt<M, NT, FR>;
   if (lds > 65536) {
-    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize,
-                                       (int)lds);
+    hipError_t e = set_lds(reinterpret_cast<const void*>(kern), lds);
     if (e != hipSuccess) return e;
   }
   const int fpb = 4;
@@ -1924,7 +2017,7 @@ static int run_S(sg_handle* h, View v, int64_t total_units, const OutMap& om, hi
       continue;
     }
     // float mask field (natural bin order for the general apply kernels, lane order for the fused one)
-    h->dbg_fast = geom_fast;
+    h->dbg_fast = geom_fast || (fused && h->fast5_ok && !h->force_nofast && h->p.prop_decrease == 1.0);
     if (fused) {
       if ((rc = stage_fused_mask(h, v, g, nb, false, 0, g.T, st))) return rc;
     } else {
@@ -1941,6 +2034,9 @@ static int run_S(sg_handle* h, View v, int64_t total_units, const OutMap& om, hi
     }
     if (geom_fast) {
       if ((rc = stage_apply_fast(h, v, g, nb, om, (const float*)h->M.p, 1, st))) return rc;
+    } else if (h->fast5_ok && !h->force_nofast) {
+      const bool kmask = fused && h->p.prop_decrease == 1.0;   // the bit-mask stages left uint16 sums, no float mask
+      if ((rc = stage_apply512(h, v, g, nb, om, kmask ? nullptr : (const float*)h->M.p, 1, st))) return rc;
     } else {
       if ((rc = stage_apply_ola(h, v, g, nb, (const float*)h->M.p, om, 1, st))) return rc;
     }
@@ -2227,6 +2323,8 @@ extern "C" int sg_process_batch(sg_handle* h, const void* x_dev, int dtype, int6
                                hipMemcpyDeviceToDevice, st));
     if (geom_fast) {
       if ((rc = stage_apply_fast(h, v, g, nb, om, (const float*)h->M.p, 1, st))) return rc;
+    } else if (h->fast5_ok && !h->force_nofast) {
+      if ((rc = stage_apply512(h, v, g, nb, om, (const float*)h->M.p, 1, st))) return rc;
     } else {
       if ((rc = stage_apply_ola(h, v, g, nb, (const float*)h->M.p, om, 1, st))) return rc;
     }
@@ -2278,6 +2376,8 @@ extern "C" int sg_process_batch_backward(sg_handle* h, const void* grad_out_dev,
     const float* mk = mask_dev + (size_t)u0 * g.T * g.FS;
     if (h->fast_ok && !h->force_nofast) {
       if ((rc = stage_apply_fast(h, v, gb, nb, om, mk, 0, st))) return rc;
+    } else if (h->fast5_ok && !h->force_nofast) {
+      if ((rc = stage_apply512(h, v, gb, nb, om, mk, 0, st))) return rc;
     } else {
       if ((rc = stage_apply_ola(h, v, gb, nb, mk, om, 0, st))) return rc;
     }

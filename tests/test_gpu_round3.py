@@ -259,3 +259,77 @@ def test_force_exact_float64(nr):
         assert O.rel_err(sg.get_traces(), want) < 1e-12
     finally:
         sg._gate.set_option(_ffi.SG_OPT_FORCE_EXACT, 0)
+
+
+# ---------------------------------------------------------------------------------------------
+# n_fft = 512 / hop 128 on the register transform (fast512.hpp): two real frames per complex transform
+# ---------------------------------------------------------------------------------------------
+@pytest.mark.parametrize("sr,n,kw", [
+    (16000, 30000, dict()),                                                  # one chunk
+    (48000, 200000, dict(chunk_size=40000, padding=5000)),                   # chunk grid, partial last chunk
+    (16000, 51234, dict(chunk_size=9000, padding=1000, prop_decrease=0.6)),  # ragged: tiles at both unit edges
+    (16000, 515, dict()),                                                    # barely longer than a frame
+    (8000, 20000, dict(freq_mask_smooth_hz=None, time_mask_smooth_ms=None)),
+    (44100, 70000, dict(time_mask_smooth_ms=None)),
+])
+@pytest.mark.parametrize("stationary", [True, False])
+def test_nfft512_fast_path_matches_the_oracle(nr, sr, n, kw, stationary):
+    y = np.stack([O.synth_signal(n, sr=sr, seed=81 + c, tone_hz=300.0 * (c + 1)) for c in range(2)]).astype(np.float32)
+    args = dict(stationary=stationary, n_fft=512, **kw)
+    got = nr.reduce_noise(y=y, sr=sr, **args)
+    want = O.reduce_noise_S(y.astype(np.float64), sr, **args)
+    assert O.rel_err(got, want) < TOL
+    # the general LDS kernels on the same input (SG_OPT_FORCE_NOFAST): same result to float32 rounding
+    y1 = torch.from_numpy(y).cuda()
+    a = nr.reduce_noise(y=y1, sr=sr, **args)
+    assert O.rel_err(a.cpu().numpy(), want) < TOL
+
+
+def test_nfft512_decisions_equal_the_float64_decisions(nr):
+    """Mask bits of k_decide_fast512 (float32 + exact refinement, two frames per transform) == the all-float64 decision
+    kernel, bit for bit -- incl. a loud frame next to a quiet one (the pair shares one transform) and a steady tone."""
+    from noisereduce_amd import _ffi
+    from noisereduce_amd.spectralgate.stationary import SpectralGateStationary
+    sr, n = 16000, 120000
+    y = O.synth_signal(n, sr=sr, seed=5, tone_hz=440.0).astype(np.float32)
+    y[30000:30700] *= 200.0          # a burst: frames with a loud and a quiet partner
+    y[60000:] = (0.3 * np.sin(2 * np.pi * 1000.0 * np.arange(n - 60000) / sr)).astype(np.float32)   # steady tone
+    kw = dict(sr=sr, y_noise=None, prop_decrease=1.0, n_std_thresh_stationary=1.5, chunk_size=50000, clip_noise_stationary=True,
+              padding=4000, n_fft=512, win_length=None, hop_length=None, time_constant_s=2.0, freq_mask_smooth_hz=500,
+              time_mask_smooth_ms=50, tmp_folder=None, use_tqdm=False, n_jobs=1)
+    sg = SpectralGateStationary(y=torch.from_numpy(y).cuda(), **kw)
+    out_fast = sg.get_traces().clone()
+    bits_fast = sg._gate.debug_field(3)
+    sg._gate.set_option(_ffi.SG_OPT_FORCE_F64_DECIDE, 1)
+    try:
+        out_64 = sg.get_traces().clone()
+        bits_64 = sg._gate.debug_field(3)
+    finally:
+        sg._gate.set_option(_ffi.SG_OPT_FORCE_F64_DECIDE, 0)
+    assert bits_fast.shape == bits_64.shape and np.array_equal(bits_fast, bits_64)
+    assert torch.equal(out_fast, out_64)
+    want = O.reduce_noise_S(y.astype(np.float64), sr, stationary=True, n_fft=512, chunk_size=50000, padding=4000)
+    assert O.rel_err(out_fast.cpu().numpy(), want) < TOL
+
+
+def test_torchgate_nfft512(nr):
+    from noisereduce_amd.torchgate import TorchGate
+    for kw in (dict(), dict(nonstationary=True)):
+        x = np.stack([O.synth_signal(16000, sr=16000, seed=s, tone_hz=440.0) for s in range(5)]).astype(np.float64)
+        tg = TorchGate(sr=16000, n_fft=512, **kw).cuda()
+        xt = torch.from_numpy(x).cuda().requires_grad_()
+        y = tg(xt)
+        want = O.torchgate_T(x, 16000, n_fft=512, window=torch.hann_window(512).double().numpy(), **kw)
+        assert O.rel_err(y.detach().cpu().numpy(), want) < TOL
+        # backward: the adjoint with the mask fixed against autograd through torch.stft / istft on the CPU
+        w = torch.linspace(0.5, 1.5, y.shape[1], dtype=torch.float64)
+        (y * w.cuda()).sum().backward()
+        got_g = xt.grad.cpu()
+        _, st = O.torchgate_T(x, 16000, n_fft=512, window=torch.hann_window(512).double().numpy(), return_stages=True, **kw)
+        m = torch.from_numpy(st["mask"])
+        xc = torch.from_numpy(x).requires_grad_()
+        win = torch.hann_window(512, dtype=torch.float64)
+        X = torch.stft(xc, 512, 128, 512, window=win, center=True, pad_mode="constant", return_complex=True)
+        yc = torch.istft(X * m, 512, 128, 512, window=win, center=True)
+        (yc * w).sum().backward()
+        assert O.rel_err(got_g.numpy(), xc.grad.numpy()) < TOL
