@@ -26,6 +26,7 @@
 #include "czt.hpp"
 #include "onepass.hpp"
 #include "fast512.hpp"
+#include "fast2048.hpp"
 #include "nonstat.hpp"
 #include "fast64.hpp"
 #include "big.hpp"
@@ -106,6 +107,8 @@ struct sg_handle {
   bool fast_ok = false;              // default geometry: fused apply kernel available
   bool fast5_ok = false;             // n_fft = win = 512, hop = 128: register-transform kernels of fast512.hpp
   DevBuf invn5;                      // 1 / window envelope per hop phase (128) of that geometry
+  bool fast20_ok = false;            // n_fft = win = 2048, hop = 512: register-transform kernels of fast2048.hpp
+  DevBuf invn20;                     // 1 / window envelope per hop phase (512)
   bool force_nofast = false;
   bool force_f64_decide = false;     // SG_OPT_FORCE_F64_DECIDE: float64 STFT for every mask decision
   int64_t ktot = 1;                  // (nf+1)^2 (nt+1)^2: integer weight total of the smoothing filter
@@ -973,6 +976,16 @@ extern "C" int sg_create(const sg_params* p, const double* window_host, sg_handl
     if (!rc) rc = upload(h, h->invn5, invn.data(), invn.size() * sizeof(float));
     h->fast5_ok = true;
   }
+  if (!rc && n == 2048 && W == 2048 && h->H == 512) {
+    std::vector<float> invn(512);
+    for (int s2 = 0; s2 < 512; ++s2) {
+      double acc = 0.0;
+      for (int q = 0; q < 4; ++q) acc += wfull[512 * q + s2] * wfull[512 * q + s2];
+      invn[s2] = (float)(acc > 1e-10 ? 1.0 / acc : 1.0);
+    }
+    rc = upload(h, h->invn20, invn.data(), invn.size() * sizeof(float));
+    h->fast20_ok = true;
+  }
   if (!rc && p->smooth_mask && 8 + 2 * p->n_grad_freq <= 18) {
     // counts of 8 adjacent bins f..f+7 from the 18-bit window b[f-nf .. f-nf+17]: two 9-bit tables
     const int nf = p->n_grad_freq;
@@ -1041,7 +1054,7 @@ extern "C" int sg_destroy(sg_handle* h) {
                     &h->need, &h->T2, &h->part, &h->tw512, &h->invn, &h->seam, &h->ftab, &h->xbits, &h->xpart,
                     &h->xticket, &h->xtick2, &h->ftab3, &h->xexp, &h->nsp, &h->nsc, &h->xin, &h->czt_tw64, &h->czt_ch64,
                     &h->czt_bh64, &h->czt_tw32, &h->czt_ch32, &h->czt_bh32, &h->logtab, &h->big_twM, &h->big_tw2,
-                    &h->big_ch, &h->big_bh, &h->big_W, &h->big_W2, &h->xP, &h->xraw, &h->xM, &h->xtmp, &h->xseg, &h->invn5})
+                    &h->big_ch, &h->big_bh, &h->big_W, &h->big_W2, &h->xP, &h->xraw, &h->xM, &h->xtmp, &h->xseg, &h->invn5, &h->invn20})
     free_buf(*b);
   delete h;
   return SG_OK;
@@ -1258,9 +1271,92 @@ static int stage_apply512(sg_handle* h, const View& v, const Geom& g, int64_t ub
   return SG_OK;
 }
 
+// ------------------------------------------------------------------------------------------
+// n_fft = 2048 / hop 512 on the register transform (fast2048.hpp)
+// ------------------------------------------------------------------------------------------
+static fast::Fast20Args fast20_args(const sg_handle* h, const View& v, const Geom& g) {
+  fast::Fast20Args A{};
+  A.view = v; A.g = g;
+  A.win = (const float*)h->wa32.p;
+  A.win64 = (const double*)h->wfull64.p;
+  A.tw2048 = (const fast::cf*)h->tw32.p;
+  A.tw64 = (const cx<double>*)h->tw64.p;
+  A.mag_scale = h->mag_scale; A.top_db = h->p.top_db;
+  A.wsq = (const float*)h->wsq32.p;
+  A.invn = (const float*)h->invn20.p;
+  return A;
+}
+constexpr size_t FAST20_LDS = (size_t)(1024 + 4 * fast::WAVE_CX_H) * sizeof(fast::cf) + 1028 * sizeof(float);
+
+static int stage_decide2048(sg_handle* h, const View& v, const Geom& g, int64_t ub, const ThreshConsts& tc,
+                            unsigned long long* bits, hipStream_t st) {
+  ProfScope ps(h, SG_STAGE_DECIDE_FAST, st);
+  fast::Fast20Args A = fast20_args(h, v, g);
+  A.tc = tc;
+  A.bits = bits;
+  auto kern = fast::k_decide_fast2048<4>;
+  HIPCHK(h, set_lds(reinterpret_cast<const void*>(kern), FAST20_LDS));
+  hipLaunchKernelGGL(kern, dim3((unsigned)((g.T + 7) / 8), (unsigned)ub), dim3(256), FAST20_LDS, st, A);
+  HIPCHK(h, hipGetLastError());
+  return SG_OK;
+}
+
+static int stage_mag2048(sg_handle* h, const View& v, const Geom& g, int64_t ub, float* mag, hipStream_t st) {
+  ProfScope ps(h, SG_STAGE_STFT_MAG, st);
+  fast::Fast20Args A = fast20_args(h, v, g);
+  A.mag = mag;
+  auto kern = fast::k_mag_fast2048<4>;
+  HIPCHK(h, set_lds(reinterpret_cast<const void*>(kern), FAST20_LDS));
+  hipLaunchKernelGGL(kern, dim3((unsigned)((g.T + 7) / 8), (unsigned)ub), dim3(256), FAST20_LDS, st, A);
+  HIPCHK(h, hipGetLastError());
+  return SG_OK;
+}
+
+static int stage_apply2048(sg_handle* h, const View& v, const Geom& g, int64_t ub, const OutMap& om,
+                           const float* mask_f /* nullptr: uint16 weight sums in h->K16 */, int normalize, hipStream_t st) {
+  ProfScope ps(h, SG_STAGE_APPLY_FAST, st);
+  fast::Fast20Args A = fast20_args(h, v, g);
+  A.Mf = mask_f;
+  A.K = (const unsigned short*)h->K16.p;
+  A.inv_ktot = (float)(1.0 / (double)h->ktot);
+  A.om = om;
+  A.normalize = normalize;
+  A.h_begin = (om.p0 + g.padL) / 512;
+  A.h_end = (om.p1 - 1 + g.padL) / 512 + 1;
+  const int64_t nh = A.h_end - A.h_begin;
+  if (nh <= 0) return SG_OK;
+  // abutting tiles of 8 frames; the 3 hops that straddle two tiles as partial sums + k_ola_seam2048
+  const int64_t tiles = (nh + 3 + 7) / 8;
+  const bool seam = tiles >= 2 && !h->force_noseam;
+  A.part = nullptr;
+  A.n_tiles = (int)tiles;
+  if (seam) {
+    int rc = ensure(h, h->seam, (size_t)ub * tiles * 6 * 512 * sizeof(float));
+    if (rc) return rc;
+    A.part = (float*)h->seam.p;
+  }
+  const dim3 grid((unsigned)(seam ? tiles : (nh + 4) / 5), (unsigned)ub);
+  if (mask_f) {
+    auto kern = fast::k_apply_fast2048<4, false>;
+    HIPCHK(h, set_lds(reinterpret_cast<const void*>(kern), FAST20_LDS));
+    hipLaunchKernelGGL(kern, grid, dim3(256), FAST20_LDS, st, A);
+  } else {
+    auto kern = fast::k_apply_fast2048<4, true>;
+    HIPCHK(h, set_lds(reinterpret_cast<const void*>(kern), FAST20_LDS));
+    hipLaunchKernelGGL(kern, grid, dim3(256), FAST20_LDS, st, A);
+  }
+  HIPCHK(h, hipGetLastError());
+  if (seam) {
+    hipLaunchKernelGGL(fast::k_ola_seam2048<8>, dim3((unsigned)(tiles - 1), (unsigned)ub), dim3(512), 0, st, A);
+    HIPCHK(h, hipGetLastError());
+  }
+  return SG_OK;
+}
+
 static int stage_mag(sg_handle* h, const View& v, const Geom& g, int64_t ub, hipStream_t st) {
   float* mag = (float*)h->P.p;
   if (h->fast5_ok && !h->force_nofast) return stage_mag512(h, v, g, ub, mag, st);
+  if (h->fast20_ok && !h->force_nofast) return stage_mag2048(h, v, g, ub, mag, st);
   if (h->fast_ok && !h->force_nofast) {
     ProfScope ps(h, SG_STAGE_STFT_MAG, st);
     constexpr int WAVES = 4;
@@ -1546,6 +1642,9 @@ static int stage_fused_mask(sg_handle* h, const View& v, const Geom& g, int64_t 
     dim3 grid((unsigned)((quads + per_block - 1) / per_block), (unsigned)ub);
     hipLaunchKernelGGL(kern, grid, dim3(WAVES * 64), lds, st, D);
     HIPCHK(h, hipGetLastError());
+  } else if (!h->force_f64_decide && h->fast20_ok && !h->force_nofast) {
+    int rc20 = stage_decide2048(h, v, g, ub, tc, (unsigned long long*)h->bits.p, st);
+    if (rc20) return rc20;
   } else if (!h->force_f64_decide && h->fast5_ok && !h->force_nofast) {
     // n_fft = 512: register transform, two frames per lane group
     int rc5 = stage_decide512(h, v, g, ub, tc, (unsigned long long*)h->bits.p, st);
@@ -1563,7 +1662,7 @@ static int stage_fused_mask(sg_handle* h, const View& v, const Geom& g, int64_t 
   const int nf = h->p.n_grad_freq, nt = h->p.n_grad_time;
   int64_t cells = ub * g.T * g.FS;
   if (fast) return SG_OK;  // the fused apply kernel reads K directly
-  if (h->fast5_ok && !h->force_nofast && h->p.prop_decrease == 1.0) return SG_OK;   // so does k_apply_fast512<K>
+  if ((h->fast5_ok || h->fast20_ok) && !h->force_nofast && h->p.prop_decrease == 1.0) return SG_OK;   // so do k_apply_fast512 / 2048<K>
   hipLaunchKernelGGL(k_k16_to_mask, dim3(grid_1d(cells, 256)), dim3(256), 0, st, (const unsigned short*)h->K16.p,
                      g, nf, nt, 1.0f / (float)h->ktot, (float)h->p.prop_decrease, 1, h->p.smooth_mask ? 1 : 0,
                      (float*)h->M.p, ub);
@@ -2017,7 +2116,7 @@ static int run_S(sg_handle* h, View v, int64_t total_units, const OutMap& om, hi
       continue;
     }
     // float mask field (natural bin order for the general apply kernels, lane order for the fused one)
-    h->dbg_fast = geom_fast || (fused && h->fast5_ok && !h->force_nofast && h->p.prop_decrease == 1.0);
+    h->dbg_fast = geom_fast || (fused && (h->fast5_ok || h->fast20_ok) && !h->force_nofast && h->p.prop_decrease == 1.0);
     if (fused) {
       if ((rc = stage_fused_mask(h, v, g, nb, false, 0, g.T, st))) return rc;
     } else {
@@ -2037,6 +2136,9 @@ static int run_S(sg_handle* h, View v, int64_t total_units, const OutMap& om, hi
     } else if (h->fast5_ok && !h->force_nofast) {
       const bool kmask = fused && h->p.prop_decrease == 1.0;   // the bit-mask stages left uint16 sums, no float mask
       if ((rc = stage_apply512(h, v, g, nb, om, kmask ? nullptr : (const float*)h->M.p, 1, st))) return rc;
+    } else if (h->fast20_ok && !h->force_nofast) {
+      const bool kmask = fused && h->p.prop_decrease == 1.0;
+      if ((rc = stage_apply2048(h, v, g, nb, om, kmask ? nullptr : (const float*)h->M.p, 1, st))) return rc;
     } else {
       if ((rc = stage_apply_ola(h, v, g, nb, (const float*)h->M.p, om, 1, st))) return rc;
     }
@@ -2325,6 +2427,8 @@ extern "C" int sg_process_batch(sg_handle* h, const void* x_dev, int dtype, int6
       if ((rc = stage_apply_fast(h, v, g, nb, om, (const float*)h->M.p, 1, st))) return rc;
     } else if (h->fast5_ok && !h->force_nofast) {
       if ((rc = stage_apply512(h, v, g, nb, om, (const float*)h->M.p, 1, st))) return rc;
+    } else if (h->fast20_ok && !h->force_nofast) {
+      if ((rc = stage_apply2048(h, v, g, nb, om, (const float*)h->M.p, 1, st))) return rc;
     } else {
       if ((rc = stage_apply_ola(h, v, g, nb, (const float*)h->M.p, om, 1, st))) return rc;
     }
@@ -2378,6 +2482,8 @@ extern "C" int sg_process_batch_backward(sg_handle* h, const void* grad_out_dev,
       if ((rc = stage_apply_fast(h, v, gb, nb, om, mk, 0, st))) return rc;
     } else if (h->fast5_ok && !h->force_nofast) {
       if ((rc = stage_apply512(h, v, gb, nb, om, mk, 0, st))) return rc;
+    } else if (h->fast20_ok && !h->force_nofast) {
+      if ((rc = stage_apply2048(h, v, gb, nb, om, mk, 0, st))) return rc;
     } else {
       if ((rc = stage_apply_ola(h, v, gb, nb, mk, om, 0, st))) return rc;
     }

@@ -333,3 +333,67 @@ def test_torchgate_nfft512(nr):
         yc = torch.istft(X * m, 512, 128, 512, window=win, center=True)
         (yc * w).sum().backward()
         assert O.rel_err(got_g.numpy(), xc.grad.numpy()) < TOL
+
+
+# ---------------------------------------------------------------------------------------------
+# n_fft = 2048 / hop 512 on the register transform (fast2048.hpp): 1024 complex points on 32 lanes
+# ---------------------------------------------------------------------------------------------
+@pytest.mark.parametrize("sr,n,kw", [
+    (44100, 50000, dict()),                                                   # one chunk
+    (48000, 300000, dict(chunk_size=70000, padding=9000)),                    # chunk grid, partial last chunk
+    (48000, 123457, dict(chunk_size=30000, padding=4100, prop_decrease=0.6)), # ragged: tiles at both unit edges
+    (48000, 2060, dict()),                                                    # barely longer than a frame
+    (96000, 90000, dict(freq_mask_smooth_hz=None, time_mask_smooth_ms=None)),
+])
+@pytest.mark.parametrize("stationary", [True, False])
+def test_nfft2048_fast_path_matches_the_oracle(nr, sr, n, kw, stationary):
+    y = np.stack([O.synth_signal(n, sr=sr, seed=91 + c, tone_hz=300.0 * (c + 1)) for c in range(2)]).astype(np.float32)
+    args = dict(stationary=stationary, n_fft=2048, **kw)
+    got = nr.reduce_noise(y=y, sr=sr, **args)
+    want = O.reduce_noise_S(y.astype(np.float64), sr, **args)
+    assert O.rel_err(got, want) < TOL
+
+
+def test_nfft2048_decisions_equal_the_float64_decisions(nr):
+    from noisereduce_amd import _ffi
+    from noisereduce_amd.spectralgate.stationary import SpectralGateStationary
+    sr, n = 48000, 400000
+    y = O.synth_signal(n, sr=sr, seed=6, tone_hz=440.0).astype(np.float32)
+    y[100000:102000] *= 200.0
+    y[250000:] = (0.3 * np.sin(2 * np.pi * 1000.0 * np.arange(n - 250000) / sr)).astype(np.float32)   # steady tone
+    kw = dict(sr=sr, y_noise=None, prop_decrease=1.0, n_std_thresh_stationary=1.5, chunk_size=150000, clip_noise_stationary=True,
+              padding=12000, n_fft=2048, win_length=None, hop_length=None, time_constant_s=2.0, freq_mask_smooth_hz=500,
+              time_mask_smooth_ms=50, tmp_folder=None, use_tqdm=False, n_jobs=1)
+    sg = SpectralGateStationary(y=torch.from_numpy(y).cuda(), **kw)
+    out_fast = sg.get_traces().clone()
+    bits_fast = sg._gate.debug_field(3)
+    sg._gate.set_option(_ffi.SG_OPT_FORCE_F64_DECIDE, 1)
+    try:
+        out_64 = sg.get_traces().clone()
+        bits_64 = sg._gate.debug_field(3)
+    finally:
+        sg._gate.set_option(_ffi.SG_OPT_FORCE_F64_DECIDE, 0)
+    assert bits_fast.shape == bits_64.shape and np.array_equal(bits_fast, bits_64)
+    assert torch.equal(out_fast, out_64)
+    want = O.reduce_noise_S(y.astype(np.float64), sr, stationary=True, n_fft=2048, chunk_size=150000, padding=12000)
+    assert O.rel_err(out_fast.cpu().numpy(), want) < TOL
+
+
+def test_torchgate_nfft2048(nr):
+    from noisereduce_amd.torchgate import TorchGate
+    for kw in (dict(), dict(nonstationary=True)):
+        x = np.stack([O.synth_signal(30000, sr=48000, seed=s, tone_hz=440.0) for s in range(3)]).astype(np.float64)
+        tg = TorchGate(sr=48000, n_fft=2048, **kw).cuda()
+        xt = torch.from_numpy(x).cuda().requires_grad_()
+        y = tg(xt)
+        want, st = O.torchgate_T(x, 48000, n_fft=2048, window=torch.hann_window(2048).double().numpy(), return_stages=True, **kw)
+        assert O.rel_err(y.detach().cpu().numpy(), want) < TOL
+        w = torch.linspace(0.5, 1.5, y.shape[1], dtype=torch.float64)
+        (y * w.cuda()).sum().backward()
+        m = torch.from_numpy(st["mask"])
+        xc = torch.from_numpy(x).requires_grad_()
+        win = torch.hann_window(2048, dtype=torch.float64)
+        X = torch.stft(xc, 2048, 512, 2048, window=win, center=True, pad_mode="constant", return_complex=True)
+        yc = torch.istft(X * m, 2048, 512, 2048, window=win, center=True)
+        (yc * w).sum().backward()
+        assert O.rel_err(xt.grad.cpu().numpy(), xc.grad.numpy()) < TOL
