@@ -8,8 +8,9 @@
 // so a frame needs a 32 x 16 slice (4 KB): two frames fit the wave slice of the 1024-path kernels, with the same
 // swizzle (16-byte chunk ^ ((row >> 1) & 7)).
 // Real-FFT split / merge: bins k and 1024 - k sit in DIFFERENT lanes here (one row per lane: row 32 - c', register
-// 31 - k2).  Every lane fetches its partners' values (ds_bpermute) and evaluates the pair for its OWN bin only --
-// twice the pair arithmetic of the 1024 path, no lane-0 special cases beyond DC / Nyquist.
+// 31 - k2).  A lane fetches the partner value of each of its registers 0..15 (ds_bpermute), evaluates that pair once
+// and hands the partner's half of the result back through a second shuffle -- the partner does the same for registers
+// 16..31.  Lane 0 (rows 0: bins 32 k2) pairs its own registers i <-> 32 - i; DC / Nyquist and bin 512 are explicit.
 // Tile = 4 waves = 8 frames, hop = 512 samples.  Tiles abut: the 3 hops that straddle two tiles are written as partial
 // sums and combined by k_ola_seam2048 (overlapping tiles would redo 3 of every 8 transforms).
 //
@@ -158,23 +159,8 @@ __device__ __forceinline__ void fft1k_inv(cf* v, cf* fb, const cf* tw, int c) {
   __builtin_amdgcn_sched_barrier(0);
 }
 
-// partner values b[k2] = Zc[1024 - (c + 32 k2)]: lane (32 - c) & 31 of the same frame, register 31 - k2 (lane 0: its
-// own register (32 - k2) & 31)
-__device__ __forceinline__ void f20_partners(const cf* v, cf* b, int lane, int c) {
-  const int src = (lane & 32) | ((32 - c) & 31);
-#pragma unroll
-  for (int k2 = 0; k2 < 32; ++k2) {
-    const cf s = v[31 - k2];
-    cf t;
-    t.x = __shfl(s.x, src);
-    t.y = __shfl(s.y, src);
-    const cf own = v[(32 - k2) & 31];
-    b[k2] = {c == 0 ? own.x : t.x, c == 0 ? own.y : t.y};
-  }
-}
-
 // w_2048^(c + 32 k2) = w_2048^c * w_64^k2   (cos / sin of 2 pi k2 / 64: compile-time constants after unrolling)
-__device__ constexpr float F20_C64[32] = {1.000000000e+00f, 9.951847267e-01f, 9.807852804e-01f, 9.569403357e-01f, 9.238795325e-01f, 8.819212643e-01f, 8.314696123e-01f, 7.730104534e-01f, 7.071067812e-01f, 6.343932842e-01f, 5.555702330e-01f, 4.713967368e-01f, 3.826834324e-01f, 2.902846773e-01f, 1.950903220e-01f, 9.801714033e-02f, 6.123233996e-17f, -9.801714033e-02f, -1.950903220e-01f, -2.902846773e-01f, -3.826834324e-01f, -4.713967368e-01f, -5.555702330e-01f, -6.343932842e-01f, -7.071067812e-01f, -7.730104534e-01f, -8.314696123e-01f, -8.819212643e-01f, -9.238795325e-01f, -9.569403357e-01f, -9.807852804e-01f, -9.951847267e-01f};
+__device__ constexpr float F20_C64[32] = {1.000000000e+00f, 9.951847267e-01f, 9.807852804e-01f, 9.569403357e-01f, 9.238795325e-01f, 8.819212643e-01f, 8.314696123e-01f, 7.730104534e-01f, 7.071067812e-01f, 6.343932842e-01f, 5.555702330e-01f, 4.713967368e-01f, 3.826834324e-01f, 2.902846773e-01f, 1.950903220e-01f, 9.801714033e-02f, 0.0f, -9.801714033e-02f, -1.950903220e-01f, -2.902846773e-01f, -3.826834324e-01f, -4.713967368e-01f, -5.555702330e-01f, -6.343932842e-01f, -7.071067812e-01f, -7.730104534e-01f, -8.314696123e-01f, -8.819212643e-01f, -9.238795325e-01f, -9.569403357e-01f, -9.807852804e-01f, -9.951847267e-01f};
 __device__ constexpr float F20_S64[32] = {0.000000000e+00f, 9.801714033e-02f, 1.950903220e-01f, 2.902846773e-01f, 3.826834324e-01f, 4.713967368e-01f, 5.555702330e-01f, 6.343932842e-01f, 7.071067812e-01f, 7.730104534e-01f, 8.314696123e-01f, 8.819212643e-01f, 9.238795325e-01f, 9.569403357e-01f, 9.807852804e-01f, 9.951847267e-01f, 1.000000000e+00f, 9.951847267e-01f, 9.807852804e-01f, 9.569403357e-01f, 9.238795325e-01f, 8.819212643e-01f, 8.314696123e-01f, 7.730104534e-01f, 7.071067812e-01f, 6.343932842e-01f, 5.555702330e-01f, 4.713967368e-01f, 3.826834324e-01f, 2.902846773e-01f, 1.950903220e-01f, 9.801714033e-02f};
 __device__ __forceinline__ cf f20_wk(cf wl, int k2) {
   const float cs = F20_C64[k2], sn = -F20_S64[k2];      // w_64^k2 = cos - i sin
@@ -248,22 +234,39 @@ __global__ __launch_bounds__(WAVES * 64, 3) void k_decide_fast2048(Fast20Args A)
   unsigned pred = 0, amb = 0;
   bool predN = false, ambN = false;     // bin 1024 (lane 0)
   {
-    cf b[32];
-    f20_partners(v, b, lane, c);
-#pragma unroll
-    for (int k2 = 0; k2 < 32; ++k2) {
-      cf xa, xb;
-      split_pair(v[k2], b[k2], f20_wk(wl, k2), xa, xb);
-      const float P = xa.x * xa.x + xa.y * xa.y;
-      const float T = s_t2[c + 32 * k2];
+    // One pair per iteration (see k_apply_fast2048): the split of (Zc[k], Zc[1024 - k]) yields 2 X[k] for the lane's own
+    // register i AND 2 X[1024 - k], whose power belongs to the partner's register 31 - i -- the powers are swapped
+    // through one shuffle instead of both lanes evaluating both pairs.  Lane 0 pairs its own registers i <-> 32 - i.
+    const int src = (lane & 32) | ((32 - c) & 31);
+    const bool l0 = c == 0;
+    auto decide = [&](float P, float T, int q) {
       const float diff = P - T;
-      pred |= (diff > 0.f ? 1u : 0u) << k2;
-      amb |= ((diff * diff <= d2 * (P + T)) ? 1u : 0u) << k2;
-      if (k2 == 0) {   // lane 0: the pair (Zc[0], Zc[0]) also yields bin 1024 (xb)
-        const float PN = xb.x * xb.x + xb.y * xb.y, TN = s_t2[1024], dN = PN - TN;
-        predN = c == 0 && dN > 0.f;
-        ambN = c == 0 && dN * dN <= d2 * (PN + TN);
-      }
+      pred |= (diff > 0.f ? 1u : 0u) << q;
+      amb |= ((diff * diff <= d2 * (P + T)) ? 1u : 0u) << q;
+    };
+    float Pp[16];
+#pragma unroll
+    for (int i = 0; i < 16; ++i) {
+      const cf ob = v[31 - i], own = v[(32 - i) & 31];
+      cf ta;
+      ta.x = __shfl(ob.x, src); ta.y = __shfl(ob.y, src);
+      const cf ba = {l0 ? own.x : ta.x, l0 ? own.y : ta.y};
+      cf xa, xb;
+      split_pair(v[i], ba, f20_wk(wl, i), xa, xb);
+      decide(xa.x * xa.x + xa.y * xa.y, s_t2[c + 32 * i], i);
+      Pp[i] = xb.x * xb.x + xb.y * xb.y;
+    }
+    {   // lane 0, i = 0: the pair (Zc[0], Zc[0]) also yields bin 1024
+      const float PN = Pp[0], TN = s_t2[1024], dN = PN - TN;
+      predN = l0 && dN > 0.f;
+      ambN = l0 && dN * dN <= d2 * (PN + TN);
+    }
+    const float P512 = 4.f * (v[16].x * v[16].x + v[16].y * v[16].y);   // lane 0: Zc[512] is its own partner, X = conj Zc
+#pragma unroll
+    for (int i = 0; i < 16; ++i) {
+      const float pu = __shfl(Pp[i], src);                       // generic: the partner evaluated OUR register 31 - i
+      const float p0 = i < 15 ? Pp[i + 1] : P512;               // lane 0: register 31 - i = 32 - (i + 1)
+      decide(l0 ? p0 : pu, s_t2[c + 32 * (31 - i)], 31 - i);
     }
   }
   if (need == 2) { pred = 0; amb = 0; predN = false; ambN = false; }
@@ -327,14 +330,27 @@ __global__ __launch_bounds__(WAVES * 64, 3) void k_mag_fast2048(Fast20Args A) {
   fft1k_fwd(v, fb, tw, c);
   const cf wl = A.tw2048[c];
   float* mrow = A.mag + (u * G.T + (valid ? tq + g : 0)) * (int64_t)G.FS;
-  cf b[32];
-  f20_partners(v, b, lane, c);
+  const int src = (lane & 32) | ((32 - c) & 31);
+  const bool l0 = c == 0;
+  float Pp[16];
 #pragma unroll
-  for (int k2 = 0; k2 < 32; ++k2) {
+  for (int i = 0; i < 16; ++i) {   // one pair per iteration, the partner's power handed over (see k_decide_fast2048)
+    const cf ob = v[31 - i], own = v[(32 - i) & 31];
+    cf ta;
+    ta.x = __shfl(ob.x, src); ta.y = __shfl(ob.y, src);
+    const cf ba = {l0 ? own.x : ta.x, l0 ? own.y : ta.y};
     cf xa, xb;
-    split_pair(v[k2], b[k2], f20_wk(wl, k2), xa, xb);
-    if (valid) mrow[c + 32 * k2] = 0.5f * sqrtf(xa.x * xa.x + xa.y * xa.y);
-    if (k2 == 0 && c == 0 && valid) mrow[1024] = 0.5f * sqrtf(xb.x * xb.x + xb.y * xb.y);
+    split_pair(v[i], ba, f20_wk(wl, i), xa, xb);
+    if (valid) mrow[c + 32 * i] = 0.5f * sqrtf(xa.x * xa.x + xa.y * xa.y);
+    Pp[i] = xb.x * xb.x + xb.y * xb.y;
+  }
+  if (l0 && valid) mrow[1024] = 0.5f * sqrtf(Pp[0]);
+  const float P512 = 4.f * (v[16].x * v[16].x + v[16].y * v[16].y);
+#pragma unroll
+  for (int i = 0; i < 16; ++i) {
+    const float pu = __shfl(Pp[i], src);
+    const float p0 = i < 15 ? Pp[i + 1] : P512;
+    if (valid) mrow[c + 32 * (31 - i)] = 0.5f * sqrtf(l0 ? p0 : pu);
   }
 }
 
@@ -374,33 +390,39 @@ __global__ __launch_bounds__(WAVES * 64, 3) void k_apply_fast2048(Fast20Args A) 
       else return A.Mf[moff + k] * ks;
     };
     {
-      // Registers j and 31 - j are each other's partner SOURCES (lane 32 - c reads them), so the pairs are processed two
-      // at a time, in place: all shuffles of an iteration read values no lane has overwritten yet.  Lane 0 pairs its
-      // own registers differently (j with 32 - j): the one original value it still needs from the previous
-      // iteration's overwritten register rides along in `carry`.
+      // One pair per iteration: the lane fetches the partner value of its register i (lane 32 - c, register 31 - i),
+      // runs split -> mask -> merge ONCE, keeps the merged value of its own bin and hands the other one -- the new
+      // Zc'[1024 - k], which belongs in the partner's register 31 - i -- back through a second shuffle (the partner
+      // does the same for us): half the pair arithmetic and half the mask loads of evaluating every bin separately.
+      // Lane 0 pairs its own registers i <-> 32 - i: the partner VALUE it needs was overwritten one iteration ago
+      // (carried along), and the merged partner value it produces belongs one register higher than where the generic
+      // hand-back puts it (shifted after the loop); its self-paired bin 512 and DC / Nyquist are set explicitly.
       const int src = (lane & 32) | ((32 - c) & 31);
       const bool l0 = c == 0;
-      const cf a0 = v[0];
+      const cf a0 = v[0], a16 = v[16];
       cf carry = v[0];
 #pragma unroll
       for (int i = 0; i < 16; ++i) {
         const cf oa = v[i], ob = v[31 - i];
-        cf ta, tb;
-        ta.x = __shfl(ob.x, src); ta.y = __shfl(ob.y, src);     // partner of register i:      lane 32 - c, register 31 - i
-        tb.x = __shfl(oa.x, src); tb.y = __shfl(oa.y, src);     // partner of register 31 - i: lane 32 - c, register i
-        const cf pa0 = i == 0 ? oa : carry;                     // lane 0: Zc[32 (32 - i)] (register 32 - i, original)
-        const cf pb0 = i == 15 ? ob : v[i + 1];                 // lane 0: Zc[32 (i + 1)]  (register i + 1, still original)
-        cf ba = {l0 ? pa0.x : ta.x, l0 ? pa0.y : ta.y};
-        cf bb = {l0 ? pb0.x : tb.x, l0 ? pb0.y : tb.y};
+        cf ta;
+        ta.x = __shfl(ob.x, src); ta.y = __shfl(ob.y, src);     // Zc[1024 - k]: lane 32 - c, register 31 - i
+        cf ba = {l0 ? carry.x : ta.x, l0 ? carry.y : ta.y};      // lane 0: original register 32 - i (i = 0: itself)
         carry = ob;
-        const int ka = c + 32 * i, kb = c + 32 * (31 - i);
-        cf xa = oa, xb = ob;
+        const int ka = c + 32 * i;
+        cf xa = oa;
         pair_mask(xa, ba, f20_wk(wl, i), mval(ka), mval(1024 - ka));          // (ka = 0: the second mask is bin 1024's)
-        pair_mask(xb, bb, f20_wk(wl, 31 - i), mval(kb), mval(1024 - kb));
         v[i] = xa;
-        v[31 - i] = xb;
+        v[31 - i].x = __shfl(ba.x, src);                          // the partner's merged value for OUR register 31 - i
+        v[31 - i].y = __shfl(ba.y, src);
       }
-      if (l0) {   // DC / Nyquist: Zc'[0] = ((X0 m0 + XN mN) / 2, (X0 m0 - XN mN) / 2), X0 = Re + Im, XN = Re - Im
+      if (l0) {
+        // lane 0 received its own hand-backs: register 31 - i holds Zc'[32 (32 - i)], which belongs in register 32 - i
+#pragma unroll
+        for (int j = 31; j >= 17; --j) v[j] = v[j - 1];
+        // bin 512 = Zc[512] is its own partner: Zc'[512] = Zc[512] m (irfft side: conj conj); DC / Nyquist:
+        // Zc'[0] = ((X0 m0 + XN mN) / 2, (X0 m0 - XN mN) / 2), X0 = Re + Im, XN = Re - Im
+        const float m16 = mval(512) * 4.0f;
+        v[16] = {a16.x * m16, a16.y * m16};
         const float y0 = (a0.x + a0.y) * mval(0) * 4.0f;
         const float yN = (a0.x - a0.y) * mval(1024) * 4.0f;
         v[0] = {0.5f * (y0 + yN), 0.5f * (y0 - yN)};
