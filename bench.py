@@ -330,6 +330,14 @@ def main():
 
     for _ in range(args.warmup):
         step()
+    # untimed settle loop on top of the W warm-up steps: ~0.1 s of back-to-back steps so that clock / power-state
+    # transitions of a GPU that was idle a moment ago happen BEFORE the timed region (one default run in ~20 showed a
+    # single 8 ms step among its 20 right after the box had been idle; per-step times are in `ms_per_step_all`)
+    # (a FIXED count: every rank must run the same number of collectives)
+    settle_steps = 20 if wl == "config4" else 200
+    for _ in range(settle_steps):
+        step()
+    torch.cuda.synchronize(device)
     _gc.collect()
     _gc.freeze()
     GC_PAUSES.clear()
@@ -349,10 +357,13 @@ def main():
     marks = [torch.cuda.Event(enable_timing=True) for _ in range(args.steps + 1)] if n_streams == 1 else None
     sync()
     t0 = time.perf_counter()
+    host_ms = []
     for i in range(args.steps):
         if marks:
             marks[i].record()
+        th0 = time.perf_counter()
         out = step()
+        host_ms.append((time.perf_counter() - th0) * 1e3)
     if marks:
         marks[args.steps].record()
     sync()
@@ -479,10 +490,13 @@ def main():
             line["ms_per_step_median"] = round(float(np.median(per_step)), 4)
             line["ms_per_step_min"] = round(float(np.min(per_step)), 4)
             line["value_at_median_step"] = round(samples_per_gpu * world / (float(np.median(per_step)) * 1e-3) / 1e6, 1)
+            line["ms_per_step_all"] = [round(float(t), 4) for t in per_step]
+            line["host_enqueue_ms_per_step"] = [round(t, 4) for t in host_ms]
         if distributed:
             line["distributed"] = distributed
         if world == 1 and not args.no_extras:
             line.update(extras(device, wl, out, y2d, gate, O))
+        line["settle_steps_untimed"] = settle_steps
         line["host_gc"] = {"pauses_over_1ms": [(g_, round(ms_, 2)) for g_, ms_ in GC_PAUSES if ms_ > 1.0],
                            "note": "CPython collector pauses on the enqueueing thread since the warm-up (generation, ms); "
                                    "objects alive after the warm-up are frozen (gc.freeze)"}
