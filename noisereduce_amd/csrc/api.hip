@@ -1085,7 +1085,7 @@ static size_t unit_bytes(const sg_handle* h, const Geom& g, bool lean) {
   if (lean) return (size_t)g.T * ((g.F + 63) / 64) * 8 + cells * 2 + (size_t)g.FS * 16 + 64 +
            (size_t)(g.T / 16 + 2) * 6 * 256 * 4;
   return cells * (8 + 4 + 4 + 2) + (size_t)g.T * g.n * 4 + (size_t)g.FS * 16 +
-         (size_t)(g.T / NS_TT + 1) * 3 * 2 * g.FS * 8 * 2;   // + partials and carries of the two-pass non-stationary mask
+         (size_t)(g.T / NS_TT + 1) * 2 * g.FS * 8 * 2;   // + partials and carries of the two-pass non-stationary mask
 }
 
 static int64_t units_per_batch(const sg_handle* h, const Geom& g, int64_t total, bool lean = false) {
@@ -1400,7 +1400,7 @@ static int stage_nonstat_mask2(sg_handle* h, const View& v, const Geom& g, int64
   const float* mag = (const float*)h->P.p;
   NsTiling tl{g.T, h->p.n_grad_time};
   const int64_t nk = tl.n_tiles();
-  const size_t bytes = (size_t)ub * nk * 3 * 2 * g.FS * sizeof(double);
+  const size_t bytes = (size_t)ub * nk * 2 * g.FS * sizeof(double);
   if ((rc = ensure(h, h->nsp, bytes))) return rc;
   if ((rc = ensure(h, h->nsc, bytes))) return rc;
   {
@@ -1408,7 +1408,7 @@ static int stage_nonstat_mask2(sg_handle* h, const View& v, const Geom& g, int64
     hipLaunchKernelGGL(k_iir_part, dim3((unsigned)((g.F + 63) / 64), (unsigned)((nk + 3) / 4), (unsigned)ub), dim3(256), 0,
                        st, mag, g, tl, h->p.iir_b, (double*)h->nsp.p);
     HIPCHK(h, hipGetLastError());
-    hipLaunchKernelGGL(k_iir_chain, dim3((unsigned)((ub * g.FS + 63) / 64)), dim3(64), (size_t)nk * 3 * 2 * sizeof(double), st, mag,
+    hipLaunchKernelGGL(k_iir_chain, dim3((unsigned)((ub * g.FS + 63) / 64)), dim3(64), (size_t)nk * 2 * sizeof(double), st, mag,
                        (const double*)h->nsp.p, g, tl, h->p.iir_b, (double*)h->nsc.p, ub);
     HIPCHK(h, hipGetLastError());
   }
