@@ -80,6 +80,7 @@ struct sg_handle {
   DevBuf tw512, invn;                // fast path tables (n_fft = 1024, hop = 256)
   DevBuf seam;                       // partial seam hops of abutting apply tiles
   DevBuf ftab;                       // k_smooth_bits2 phase-1 lookup tables (nf <= 5)
+  int sm2_tt = 64;                   // k_smooth_bits2 tile height (frames)
   // one-pass gate (onepass.hpp): published mask bits per tile, publication flags, work counter, tables
   DevBuf xbits, xpart, xticket, xtick2, ftab3, xexp;
   DevBuf xin;                        // float32 copy of a recording held in another sample dtype
@@ -881,10 +882,15 @@ extern "C" int sg_create(const sg_params* p, const double* window_host, sg_handl
     h->fused_ok = p->variant == SG_VARIANT_S && p->stationary && h->ktot <= 65535 && pow2 && n <= 4096 &&
                   (!p->smooth_mask || p->n_grad_time <= 96);
     if (h->fused_ok && p->smooth_mask) {
-      // the integer smoothing kernel holds (64 + 2 nt) rows of all F bins in LDS
-      const int rows = SM2_TT + 2 * p->n_grad_time, wpr = (h->F + 63) / 64;
+      // the integer smoothing kernel holds (tt + 2 nt) rows of all F bins in LDS: 64-frame tiles, lower ones for long rows
+      const int wpr = (h->F + 63) / 64;
       const bool small = (p->n_grad_freq + 1) * (p->n_grad_freq + 1) <= 255;
-      const size_t lds = smooth2_cf_bytes(rows + 2, h->F, small ? 1 : 2) + (size_t)rows * (wpr + 2) * 8 + 8192;
+      size_t lds = 0;
+      for (h->sm2_tt = SM2_TT; h->sm2_tt >= 16; h->sm2_tt >>= 1) {
+        const int rows = h->sm2_tt + 2 * p->n_grad_time;
+        lds = smooth2_cf_bytes(rows + 2, h->F, small ? 1 : 2) + (size_t)rows * (wpr + 2) * 8 + 8192;
+        if (lds <= 150 * 1024) break;
+      }
       if (lds > 150 * 1024 || p->n_grad_freq > 30) h->fused_ok = false;
     }
   }
@@ -1379,26 +1385,31 @@ static int stage_mag(sg_handle* h, const View& v, const Geom& g, int64_t ub, hip
   return SG_OK;
 }
 
-// Variant-S non-stationary mask in two passes over |X| (nonstat.hpp): partials -> chain -> IIR + sigmoid + smoothing.
-static bool nonstat2_ok(const sg_handle* h, const Geom& g) {
-  if (h->p.variant != SG_VARIANT_S || h->p.stationary || !h->p.smooth_mask || h->force_unfused) return false;
-  const int nf = h->p.n_grad_freq, nt = h->p.n_grad_time;
-  if (nf > NS_MAX_NF) return false;
-  switch (nt) {  // instantiated time half-widths (k_iir_mask keeps the tile column in registers)
-    case 1: case 2: case 3: case 4: case 5: case 6: case 7: case 8: case 9: case 10: case 12: case 16: case 18: break;
-    default: return false;
-  }
+// Variant-S non-stationary mask in two passes over |X| (nonstat.hpp): partials -> chain -> IIR + sigmoid (+ smoothing).
+//   nonstat2_chain_ok: the recurrence can run tile-parallel (k_iir_part / k_iir_chain / k_iir_mask)
+//   nonstat2_ok:       ... and k_iir_mask also smooths (nt instantiated, nf <= NS_MAX_NF): the mask in one kernel
+// Other smoothing widths take k_iir_mask<0> for the raw sigmoid field and the general smoothing kernels after it.
+static bool nonstat2_chain_ok(const sg_handle* h, const Geom& g) {
+  if (h->p.variant != SG_VARIANT_S || h->p.stationary || h->force_unfused) return false;
   const double b = h->p.iir_b, c = 1.0 - b;
   if (!(b > 0.0 && b < 1.0)) return false;
   // the backward sweep regenerates the forward values in reverse: error growth c^-rows must stay small
-  return std::pow(c, (double)(NS_TT + 2 * nt)) >= 1e-3 && g.T >= 1;
+  return std::pow(c, (double)(NS_TT + 2 * 20)) >= 1e-3 && g.T >= 1;
+}
+static bool nonstat2_ok(const sg_handle* h, const Geom& g) {
+  if (!nonstat2_chain_ok(h, g) || !h->p.smooth_mask) return false;
+  const int nf = h->p.n_grad_freq, nt = h->p.n_grad_time;
+  return nf <= NS_MAX_NF && nt >= 1 && nt <= 20;   // instantiated time half-widths (the tile column lives in registers)
 }
 
-static int stage_nonstat_mask2(sg_handle* h, const View& v, const Geom& g, int64_t ub, hipStream_t st) {
+// smooth: IIR + sigmoid + smoothing + prop_decrease -> M;  !smooth: the raw sigmoid field -> raw (smoothing follows),
+// or, without a smoothing filter, p * sigmoid + (1 - p) -> M
+static int stage_nonstat_mask2(sg_handle* h, const View& v, const Geom& g, int64_t ub, bool smooth, hipStream_t st) {
   int rc = stage_mag(h, v, g, ub, st);
   if (rc) return rc;
   const float* mag = (const float*)h->P.p;
-  NsTiling tl{g.T, h->p.n_grad_time};
+  const int nf = smooth ? h->p.n_grad_freq : 0, nt = smooth ? h->p.n_grad_time : 0;
+  NsTiling tl{g.T, nt};
   const int64_t nk = tl.n_tiles();
   const size_t bytes = (size_t)ub * nk * 2 * g.FS * sizeof(double);
   if ((rc = ensure(h, h->nsp, bytes))) return rc;
@@ -1413,20 +1424,21 @@ static int stage_nonstat_mask2(sg_handle* h, const View& v, const Geom& g, int64
     HIPCHK(h, hipGetLastError());
   }
   {
-    ProfScope ps(h, SG_STAGE_SMOOTH, st);
-    const int nf = h->p.n_grad_freq, nt = h->p.n_grad_time;
+    ProfScope ps(h, smooth ? SG_STAGE_SMOOTH : SG_STAGE_NONSTAT_MASK, st);
     const int BW = 64 - 2 * nf;
     const unsigned gx = (unsigned)(((g.F + BW - 1) / BW + 3) / 4);
+    const bool to_raw = !smooth && h->p.smooth_mask;
     auto launch = [&](auto kern) -> hipError_t {
       hipLaunchKernelGGL(kern, dim3(gx, (unsigned)nk, (unsigned)ub), dim3(256), 0, st, mag, (const double*)h->nsc.p, g, tl,
-                         h->p.iir_b, h->p.nonstat_thresh, h->p.nonstat_slope, (const float*)h->kf.p, nf,
-                         (float)h->p.prop_decrease, (float*)h->M.p);
+                         h->p.iir_b, h->p.nonstat_thresh, h->p.nonstat_slope, nf,
+                         to_raw ? 1.0f : (float)h->p.prop_decrease, to_raw ? (float*)h->raw.p : (float*)h->M.p);
       return hipGetLastError();
     };
     switch (nt) {
 #define SG_NS_CASE(NT_) case NT_: HIPCHK(h, launch(k_iir_mask<NT_>)); break;
-      SG_NS_CASE(1) SG_NS_CASE(2) SG_NS_CASE(3) SG_NS_CASE(4) SG_NS_CASE(5) SG_NS_CASE(6) SG_NS_CASE(7) SG_NS_CASE(8)
-      SG_NS_CASE(9) SG_NS_CASE(10) SG_NS_CASE(12) SG_NS_CASE(16) SG_NS_CASE(18)
+      SG_NS_CASE(0) SG_NS_CASE(1) SG_NS_CASE(2) SG_NS_CASE(3) SG_NS_CASE(4) SG_NS_CASE(5) SG_NS_CASE(6) SG_NS_CASE(7)
+      SG_NS_CASE(8) SG_NS_CASE(9) SG_NS_CASE(10) SG_NS_CASE(11) SG_NS_CASE(12) SG_NS_CASE(13) SG_NS_CASE(14)
+      SG_NS_CASE(15) SG_NS_CASE(16) SG_NS_CASE(17) SG_NS_CASE(18) SG_NS_CASE(19) SG_NS_CASE(20)
 #undef SG_NS_CASE
       default: FAIL(h, SG_E_UNSUPPORTED, "no k_iir_mask instantiation for n_grad_time=%d", nt);
     }
@@ -1525,23 +1537,24 @@ static int stage_smooth_bits(sg_handle* h, const Geom& g, int64_t ub, bool fast,
   const int nf = h->p.n_grad_freq, nt = h->p.n_grad_time;
   int64_t cells = ub * g.T * g.FS;
   if (h->p.smooth_mask && nf <= 30) {
-    const int rows = SM2_TT + 2 * nt;
+    const int tt = h->sm2_tt;
+    const int rows = tt + 2 * nt;
     const bool small = (nf + 1) * (nf + 1) <= 255;
     const unsigned long long* ftab = (small && h->ftab.p) ? (const unsigned long long*)h->ftab.p : nullptr;
     size_t lds = smooth2_cf_bytes(rows + 2, g.F, small ? 1 : 2) + (size_t)rows * (wpr + 2) * 8 + (ftab ? 8192 : 0);
-    dim3 grid((unsigned)((te - tb + SM2_TT - 1) / SM2_TT), (unsigned)ub);
+    dim3 grid((unsigned)((te - tb + tt - 1) / tt), (unsigned)ub);
     if (small) {
       auto kern = k_smooth_bits2<uint8_t>;
       if (lds > 65536)
         HIPCHK(h, set_lds(reinterpret_cast<const void*>(kern), lds));
       hipLaunchKernelGGL(kern, grid, dim3(SM2_THREADS), lds, st, (const unsigned long long*)h->bits.p, g, wpr, nf,
-                         nt, (unsigned short*)h->K16.p, fast ? 1 : 0, tb, te, ftab);
+                         nt, (unsigned short*)h->K16.p, fast ? 1 : 0, tb, te, ftab, tt);
     } else {
       auto kern = k_smooth_bits2<uint16_t>;
       if (lds > 65536)
         HIPCHK(h, set_lds(reinterpret_cast<const void*>(kern), lds));
       hipLaunchKernelGGL(kern, grid, dim3(SM2_THREADS), lds, st, (const unsigned long long*)h->bits.p, g, wpr, nf,
-                         nt, (unsigned short*)h->K16.p, fast ? 1 : 0, tb, te, (const unsigned long long*)nullptr);
+                         nt, (unsigned short*)h->K16.p, fast ? 1 : 0, tb, te, (const unsigned long long*)nullptr, tt);
     }
   } else if (h->p.smooth_mask) {
     const int rows = SM_TT + 2 * nt;
@@ -2124,11 +2137,13 @@ static int run_S(sg_handle* h, View v, int64_t total_units, const OutMap& om, hi
         if ((rc = stage_power(h, v, g, nb, st))) return rc;
         if ((rc = stage_decide(h, g, nb, (const double*)h->thresh.p, 0, st))) return rc;
       } else if (nonstat2_ok(h, g)) {
-        if ((rc = stage_nonstat_mask2(h, v, g, nb, st))) return rc;
+        if ((rc = stage_nonstat_mask2(h, v, g, nb, true, st))) return rc;
+      } else if (nonstat2_chain_ok(h, g)) {
+        if ((rc = stage_nonstat_mask2(h, v, g, nb, false, st))) return rc;
       } else {
         if ((rc = stage_nonstat_raw(h, v, g, nb, st))) return rc;
       }
-      if (h->p.stationary || !nonstat2_ok(h, g))
+      if (h->p.stationary || !(nonstat2_ok(h, g) || (nonstat2_chain_ok(h, g) && !h->p.smooth_mask)))
         if ((rc = stage_smooth(h, g, nb, st))) return rc;
     }
     if (geom_fast) {

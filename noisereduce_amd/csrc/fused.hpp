@@ -406,7 +406,8 @@ __global__ __launch_bounds__(256) void k_smooth_bits(const unsigned long long* _
 // Second-generation smoothing kernel (nf <= 30): phase 1 keeps a 128-bit sliding window of the
 // bit row in registers (no LDS reads in the recurrence) and stores 4 counts per LDS write;
 // phase 2 walks one output column per thread over the whole tile with batched LDS reads.
-// Frames outside [t_begin, t_end) are neither read as outputs nor written.
+// Frames outside [t_begin, t_end) are neither read as outputs nor written.  The tile height tt (<= SM2_TT frames) is a
+// launch parameter: long frames (n_fft = 4096: 2049 bins per row) take lower tiles so that the tile fits the LDS.
 constexpr int SM2_TT = 64;
 constexpr int SM2_THREADS = 576;
 
@@ -426,9 +427,9 @@ __global__ __launch_bounds__(SM2_THREADS) void k_smooth_bits2(const unsigned lon
                                                                int wpr, int nf, int nt,
                                                                unsigned short* __restrict__ K, int perm,
                                                                int64_t t_begin, int64_t t_end,
-                                                               const unsigned long long* __restrict__ ftab) {
+                                                               const unsigned long long* __restrict__ ftab, int tt) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
-  const int rows = SM2_TT + 2 * nt;
+  const int rows = tt + 2 * nt;
   // phase-1 counts are stored at column f + 4*(f/32): the phase-2 column walk visits bins 32 apart
   // with consecutive lanes (lane order of the apply kernel), which would be an 8-way bank conflict
   // on a dense row
@@ -439,7 +440,7 @@ __global__ __launch_bounds__(SM2_THREADS) void k_smooth_bits2(const unsigned lon
       reinterpret_cast<unsigned long long*>(smem + smooth2_cf_bytes(rows + 2, g.F, sizeof(CT)));
   for (int i = threadIdx.x; i < 2 * FP; i += SM2_THREADS) cf[(size_t)rows * FP + i] = (CT)0;
   const int64_t u = blockIdx.y;
-  const int64_t t0 = t_begin + (int64_t)blockIdx.x * SM2_TT;
+  const int64_t t0 = t_begin + (int64_t)blockIdx.x * tt;
   for (int i = threadIdx.x; i < rows * WP; i += SM2_THREADS) {
     const int r = i / WP, w = i - r * WP - 1;
     const int64_t t = t0 - nt + r;
@@ -513,7 +514,7 @@ __global__ __launch_bounds__(SM2_THREADS) void k_smooth_bits2(const unsigned lon
   __syncthreads();
   }
   // ---- phase 2: along t, one output position per thread ------------------------------------
-  // The walk reads rows r - nt .. r + nt + 2 for r = nt .. nt + 63: never below row 0, at most two
+  // The walk reads rows r - nt .. r + nt + 2 for r = nt .. nt + tt - 1: never below row 0, at most two
   // rows past the tile -- those two rows exist and are zero (cleared above), so no bounds checks
   // (they were scalar compares/selects per read: the CU's one scalar unit was the bottleneck).
   for (int pos = threadIdx.x; pos < g.F; pos += SM2_THREADS) {
@@ -527,7 +528,7 @@ __global__ __launch_bounds__(SM2_THREADS) void k_smooth_bits2(const unsigned lon
       if (b <= 0) L += x;
     }
     unsigned short* kout = K + (u * g.T + t0) * (int64_t)g.FS + pos;
-    const int n_out = (int)min<int64_t>(SM2_TT, min<int64_t>(t_end, g.T) - t0);
+    const int n_out = (int)min<int64_t>(tt, min<int64_t>(t_end, g.T) - t0);
     const CT* pa = col + (size_t)(2 * nt + 2) * FP;  // row r + nt + 2
     const CT* pb = col + (size_t)(nt + 1) * FP;      // row r + 1
     const CT* pc = col;                              // row r - nt

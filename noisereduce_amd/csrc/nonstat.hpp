@@ -31,7 +31,7 @@
 namespace sg {
 
 constexpr int NS_TT = 64;      // frames per time tile
-constexpr int NS_MAX_NF = 8;   // k_iir_mask: a wave holds 64 - 2 nf output bins
+constexpr int NS_MAX_NF = 24;  // k_iir_mask: a wave holds 64 - 2 nf output bins (the DPP boxcars cost 2 nf adds per value)
 
 struct NsTiling {
   int64_t T;
@@ -184,8 +184,7 @@ __device__ __forceinline__ float lane_shl1(float v) {
 template <int NT, bool EDGE>
 __device__ __forceinline__ void ns_mask_tile(const float* __restrict__ A, const double* __restrict__ carry,
                                              const Geom& g, const NsTiling& tl, double b, double nthresh, double slope,
-                                             const float* __restrict__ kf, int nf, float p, float* __restrict__ M,
-                                             int64_t k) {
+                                             int nf, float p, float* __restrict__ M, int64_t k) {
   constexpr int ROWS = NS_TT + 2 * NT;
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   const int BW = 64 - 2 * nf;
@@ -314,12 +313,11 @@ __device__ __forceinline__ void ns_mask_tile(const float* __restrict__ A, const 
 template <int NT>
 __global__ __launch_bounds__(256, (NT <= 9 ? 3 : 2)) void k_iir_mask(const float* __restrict__ A, const double* __restrict__ carry,
                                                      Geom g, NsTiling tl, double b, double nthresh, double slope,
-                                                     const float* __restrict__ kf, int nf, float p,
-                                                     float* __restrict__ M) {
+                                                     int nf, float p, float* __restrict__ M) {
   const int64_t k = blockIdx.y;
   const bool edge = k * NS_TT - NT < 0 || (k + 1) * NS_TT + NT > g.T;
-  if (edge) ns_mask_tile<NT, true>(A, carry, g, tl, b, nthresh, slope, kf, nf, p, M, k);
-  else ns_mask_tile<NT, false>(A, carry, g, tl, b, nthresh, slope, kf, nf, p, M, k);
+  if (edge) ns_mask_tile<NT, true>(A, carry, g, tl, b, nthresh, slope, nf, p, M, k);
+  else ns_mask_tile<NT, false>(A, carry, g, tl, b, nthresh, slope, nf, p, M, k);
 }
 
 }  // namespace sg
