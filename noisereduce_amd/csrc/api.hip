@@ -1394,12 +1394,12 @@ static bool nonstat2_chain_ok(const sg_handle* h, const Geom& g) {
   const double b = h->p.iir_b, c = 1.0 - b;
   if (!(b > 0.0 && b < 1.0)) return false;
   // the backward sweep regenerates the forward values in reverse: error growth c^-rows must stay small
-  return std::pow(c, (double)(NS_TT + 2 * 20)) >= 1e-3 && g.T >= 1;
+  return std::pow(c, (double)(NS_TT + 2 * NS_IIR_MAX_NT)) >= 1e-3 && g.T >= 1;
 }
 static bool nonstat2_ok(const sg_handle* h, const Geom& g) {
   if (!nonstat2_chain_ok(h, g) || !h->p.smooth_mask) return false;
   const int nf = h->p.n_grad_freq, nt = h->p.n_grad_time;
-  return nf <= NS_MAX_NF && nt >= 1 && nt <= 20;   // instantiated time half-widths (the tile column lives in registers)
+  return nf <= NS_MAX_NF && nt >= 1 && nt <= NS_IIR_MAX_NT;   // instantiated time half-widths (the tile column lives in registers)
 }
 
 // smooth: IIR + sigmoid + smoothing + prop_decrease -> M;  !smooth: the raw sigmoid field -> raw (smoothing follows),
@@ -1428,21 +1428,31 @@ static int stage_nonstat_mask2(sg_handle* h, const View& v, const Geom& g, int64
     const int BW = 64 - 2 * nf;
     const unsigned gx = (unsigned)(((g.F + BW - 1) / BW + 3) / 4);
     const bool to_raw = !smooth && h->p.smooth_mask;
-    auto launch = [&](auto kern) -> hipError_t {
-      hipLaunchKernelGGL(kern, dim3(gx, (unsigned)nk, (unsigned)ub), dim3(256), 0, st, mag, (const double*)h->nsc.p, g, tl,
-                         h->p.iir_b, h->p.nonstat_thresh, h->p.nonstat_slope, nf,
-                         to_raw ? 1.0f : (float)h->p.prop_decrease, to_raw ? (float*)h->raw.p : (float*)h->M.p);
-      return hipGetLastError();
-    };
-    switch (nt) {
-#define SG_NS_CASE(NT_) case NT_: HIPCHK(h, launch(k_iir_mask<NT_>)); break;
-      SG_NS_CASE(0) SG_NS_CASE(1) SG_NS_CASE(2) SG_NS_CASE(3) SG_NS_CASE(4) SG_NS_CASE(5) SG_NS_CASE(6) SG_NS_CASE(7)
-      SG_NS_CASE(8) SG_NS_CASE(9) SG_NS_CASE(10) SG_NS_CASE(11) SG_NS_CASE(12) SG_NS_CASE(13) SG_NS_CASE(14)
-      SG_NS_CASE(15) SG_NS_CASE(16) SG_NS_CASE(17) SG_NS_CASE(18) SG_NS_CASE(19) SG_NS_CASE(20)
-#undef SG_NS_CASE
-      default: FAIL(h, SG_E_UNSUPPORTED, "no k_iir_mask instantiation for n_grad_time=%d", nt);
-    }
+    HIPCHK(h, launch_iir_mask(nt, dim3(gx, (unsigned)nk, (unsigned)ub), st, mag, (const double*)h->nsc.p, g, tl, h->p.iir_b,
+                              h->p.nonstat_thresh, h->p.nonstat_slope, nf, to_raw ? 1.0f : (float)h->p.prop_decrease,
+                              to_raw ? (float*)h->raw.p : (float*)h->M.p));
   }
+  return SG_OK;
+}
+
+// Variant-T non-stationary mask in one kernel (nonstat.hpp: k_box_mask): the default moving-mean length and the
+// smoothing widths k_iir_mask also covers; other settings keep k_boxcar_sigmoid + the general smoothing kernels.
+static bool box_mask_ok(const sg_handle* h) {
+  if (h->p.variant != SG_VARIANT_T || h->p.stationary || h->force_unfused || h->p.n_movemean != NS_BOX_KB) return false;
+  if (!h->p.smooth_mask) return true;
+  return h->p.n_grad_freq <= NS_MAX_NF && h->p.n_grad_time >= 1 && h->p.n_grad_time <= NS_BOX_MAX_NT;
+}
+
+static int stage_box_mask(sg_handle* h, const View& v, const Geom& g, int64_t ub, hipStream_t st) {
+  int rc = stage_mag(h, v, g, ub, st);
+  if (rc) return rc;
+  ProfScope ps(h, SG_STAGE_NONSTAT_MASK, st);
+  const int nf = h->p.smooth_mask ? h->p.n_grad_freq : 0, nt = h->p.smooth_mask ? h->p.n_grad_time : 0;
+  const int BW = 64 - 2 * nf;
+  const unsigned gx = (unsigned)(((g.F + BW - 1) / BW + 3) / 4);
+  const unsigned nk = (unsigned)((g.T + NS_TT - 1) / NS_TT);
+  HIPCHK(h, launch_box_mask(nt, h->p.n_movemean, dim3(gx, nk, (unsigned)ub), st, (const float*)h->P.p, g,
+                            h->p.nonstat_thresh, h->p.nonstat_slope, nf, (float)h->p.prop_decrease, (float*)h->M.p));
   return SG_OK;
 }
 
@@ -2430,11 +2440,14 @@ extern "C" int sg_process_batch(sg_handle* h, const void* x_dev, int dtype, int6
         continue;
       }
       if ((rc = stage_decide(h, g, nb, th, ustride, st))) return rc;
+    } else if (box_mask_ok(h)) {
+      if ((rc = stage_box_mask(h, v, g, nb, st))) return rc;
     } else {
       if ((rc = stage_nonstat_raw(h, v, g, nb, st))) return rc;
     }
     const bool geom_fast = h->fast_ok && !h->force_nofast;
-    if ((rc = stage_smooth(h, g, nb, st))) return rc;
+    if (h->p.stationary || !box_mask_ok(h))
+      if ((rc = stage_smooth(h, g, nb, st))) return rc;
     if (mask_out_dev)
       HIPCHK(h, hipMemcpyAsync(mask_out_dev + (size_t)u0 * g.T * g.FS, h->M.p, (size_t)nb * g.T * g.FS * 4,
                                hipMemcpyDeviceToDevice, st));

@@ -11,7 +11,7 @@ RT=$(dirname "$($CLANG -print-file-name=libclang_rt.asan-x86_64.so)")
 if [ "${1:-build}" = build ]; then
   mkdir -p noisereduce_amd/_ab
   (cd noisereduce_amd/csrc && /opt/rocm/bin/hipcc --offload-arch=gfx950 -O1 -g -std=c++17 -fPIC -shared -fvisibility=hidden \
-     -Wl,--version-script=exports.map api.hip -o ../_ab/libmi355gate_asan.so -ldl \
+     -Wl,--version-script=exports.map api.hip nonstat_mask.hip -o ../_ab/libmi355gate_asan.so -ldl \
      -Xclang -target-feature -Xclang -packed-fp32-ops -Xarch_host -fsanitize=address -Xarch_host -fno-omit-frame-pointer \
      -shared-libasan 2>/dev/null)
   $CLANG -std=c99 -g -fsanitize=address -shared-libasan tests/c_abi/example.c -Iinclude -Lnoisereduce_amd/_ab -lmi355gate_asan \
