@@ -117,6 +117,7 @@ struct sg_handle {
   double sum_abs_w = 0.0;
   int64_t dbg_units = 0, dbg_T = 0;
   bool dbg_has_P = false;
+  bool dbg_has_raw = true;           // the unsmoothed mask field exists (not when k_iir_mask / k_box_mask produced the mask in one kernel)
   bool dbg_fused = false;
   bool dbg_fast = false;
   int64_t dbg_db = 0, dbg_de = 0;  // frames whose mask bits were decided in the last batch
@@ -2170,6 +2171,7 @@ static int run_S(sg_handle* h, View v, int64_t total_units, const OutMap& om, hi
     h->dbg_units = nb;
     h->dbg_T = g.T;
     h->dbg_has_P = h->p.stationary != 0 && !fused;
+    h->dbg_has_raw = h->p.stationary || !nonstat2_chain_ok(h, g) || (!nonstat2_ok(h, g) && h->p.smooth_mask);
     h->dbg_fused = fused;
   }
   return SG_OK;
@@ -2463,6 +2465,7 @@ extern "C" int sg_process_batch(sg_handle* h, const void* x_dev, int dtype, int6
     h->dbg_units = nb;
     h->dbg_T = g.T;
     h->dbg_has_P = h->p.stationary != 0;
+    h->dbg_has_raw = h->p.stationary || !box_mask_ok(h);
     h->dbg_fused = false;
     h->dbg_fast = geom_fast;
   }
@@ -2615,6 +2618,8 @@ extern "C" int sg_debug_fetch(sg_handle* h, int32_t what, void* host, int64_t by
   switch (what) {
     case 0:
       if (h->dbg_fused) FAIL(h, SG_E_STATE, "fused path keeps the raw mask as bits: fetch field 3");
+      if (!h->dbg_has_raw)
+        FAIL(h, SG_E_STATE, "the one-kernel non-stationary mask does not materialise the raw mask: set SG_OPT_FORCE_UNFUSED");
       src = h->raw.p; need = cells * 4; break;
     case 3:
       if (!h->dbg_fused) FAIL(h, SG_E_STATE, "bit field only exists on the fused path");

@@ -397,3 +397,62 @@ def test_torchgate_nfft2048(nr):
         yc = torch.istft(X * m, 2048, 512, 2048, window=win, center=True)
         (yc * w).sum().backward()
         assert O.rel_err(xt.grad.cpu().numpy(), xc.grad.numpy()) < TOL
+
+
+# ---------------------------------------------------------------------------------------------
+# one-kernel non-stationary masks (nonstat_mask.hpp): k_iir_mask<NT> (variant S), k_box_mask<NT, 20> (variant T)
+# ---------------------------------------------------------------------------------------------
+@pytest.mark.parametrize("sr,n_fft,tms,fhz", [
+    (44100, 512, 50, 500),        # nt = 17 (no instantiation before round 3), nf = 2
+    (48000, 2048, 50, 500),       # nt = 4, nf = 10 (> 8: the general kernels before round 3)
+    (48000, 4096, 100, 500),      # nt = 4, nf = 21
+    (48000, 1024, 110, 300),      # nt = 20, nf = 3: the widest instantiated time half-width
+    (48000, 256, 50, 500),        # nt = 37: chain-based raw sigmoid (k_iir_mask<0>) + general smoothing
+    (48000, 1024, None, 800),     # frequency smoothing only (the reference's 3-tap time filter)
+])
+def test_nonstationary_mask_widths(nr, sr, n_fft, tms, fhz):
+    y = O.synth_signal(sr * 2 + 777, sr=sr, seed=n_fft + (tms or 0)).astype(np.float32)
+    kw = dict(stationary=False, n_fft=n_fft, time_mask_smooth_ms=tms, freq_mask_smooth_hz=fhz, chunk_size=60000, padding=3000)
+    got = nr.reduce_noise(y=y, sr=sr, **kw)
+    want = O.reduce_noise_S(y.astype(np.float64), sr, **kw)
+    assert O.rel_err(got, want) < TOL
+
+
+def test_one_kernel_masks_equal_the_general_kernels(nr):
+    """k_iir_mask / k_box_mask against the materialised kernels behind SG_OPT_FORCE_UNFUSED: same mask up to float32
+    rounding of a different summation order; the raw field is only fetchable from the latter."""
+    from noisereduce_amd import _ffi
+    from noisereduce_amd.spectralgate.nonstationary import SpectralGateNonStationary
+    y = torch.from_numpy(O.synth_signal(48000 * 2, seed=5).astype(np.float32)).cuda()
+    kw = dict(NS_KW); kw.update(y=y, chunk_size=48000, padding=4000)
+    sg = SpectralGateNonStationary(**kw)
+    out = sg.get_traces().cpu().numpy()
+    M = sg._gate.debug_field(1)
+    with pytest.raises(RuntimeError, match="FORCE_UNFUSED"):
+        sg._gate.debug_field(0)
+    sg._gate.set_option(_ffi.SG_OPT_FORCE_UNFUSED, 1)
+    try:
+        out_u = SpectralGateNonStationary(**kw).get_traces().cpu().numpy()
+        M_u = sg._gate.debug_field(1)
+        raw = sg._gate.debug_field(0)
+    finally:
+        sg._gate.set_option(_ffi.SG_OPT_FORCE_UNFUSED, 0)
+    assert raw.shape == M.shape and np.isfinite(raw).all()
+    assert np.max(np.abs(M - M_u)) < 2e-5
+    assert np.max(np.abs(out - out_u)) < 1e-5 * np.max(np.abs(out_u))
+
+
+@pytest.mark.parametrize("sr,L,kw", [
+    (48000, 48000, dict()),                                          # nt = 9, nf = 5: interior and edge tiles
+    (16000, 16000, dict()),                                          # nt = 3, nf = 16: half of every wave is halo columns
+    (8000, 9000, dict(prop_decrease=0.7)),                           # nt = 1
+    (48000, 20000, dict(time_mask_smooth_ms=None)),                  # one-axis smoothing
+    (22050, 30000, dict(freq_mask_smooth_hz=None, time_mask_smooth_ms=None, prop_decrease=0.5)),   # no smoothing: NT = 0
+    (48000, 5000, dict(n_movemean_nonstationary=7)),                 # another moving-mean length: k_boxcar_sigmoid path
+])
+def test_torchgate_nonstationary_one_kernel_mask(nr, sr, L, kw):
+    from noisereduce_amd.torchgate import TorchGate
+    x = np.stack([O.synth_signal(L, sr=sr, seed=s + L, tone_hz=300.0 * (s + 1)) for s in range(3)]).astype(np.float64)
+    y = TorchGate(sr=sr, nonstationary=True, **kw).cuda()(torch.from_numpy(x).cuda()).cpu().numpy()
+    want = O.torchgate_T(x, sr, nonstationary=True, window=torch.hann_window(1024).double().numpy(), **kw)
+    assert O.rel_err(y, want) < TOL
