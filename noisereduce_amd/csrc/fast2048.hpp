@@ -341,16 +341,16 @@ __global__ __launch_bounds__(WAVES * 64, 3) void k_mag_fast2048(Fast20Args A) {
     const cf ba = {l0 ? own.x : ta.x, l0 ? own.y : ta.y};
     cf xa, xb;
     split_pair(v[i], ba, f20_wk(wl, i), xa, xb);
-    if (valid) mrow[c + 32 * i] = 0.5f * sqrtf(xa.x * xa.x + xa.y * xa.y);
+    if (valid) mrow[c + 32 * i] = half_sqrt(xa.x * xa.x + xa.y * xa.y);
     Pp[i] = xb.x * xb.x + xb.y * xb.y;
   }
-  if (l0 && valid) mrow[1024] = 0.5f * sqrtf(Pp[0]);
+  if (l0 && valid) mrow[1024] = half_sqrt(Pp[0]);
   const float P512 = 4.f * (v[16].x * v[16].x + v[16].y * v[16].y);
 #pragma unroll
   for (int i = 0; i < 16; ++i) {
     const float pu = __shfl(Pp[i], src);
     const float p0 = i < 15 ? Pp[i + 1] : P512;
-    if (valid) mrow[c + 32 * (31 - i)] = 0.5f * sqrtf(l0 ? p0 : pu);
+    if (valid) mrow[c + 32 * (31 - i)] = half_sqrt(l0 ? p0 : pu);
   }
 }
 

@@ -312,8 +312,8 @@ __global__ __launch_bounds__(WAVES * 64, 3) void k_mag_fast512(Fast5Args A) {
       PB = l0 ? xb * xb : PB;
     }
     const int f = bin5(c, sl);
-    if (validA) mA[f] = 0.5f * sqrtf(PA);
-    if (validB) mB[f] = 0.5f * sqrtf(PB);
+    if (validA) mA[f] = half_sqrt(PA);
+    if (validB) mB[f] = half_sqrt(PB);
   }
   if (l0) {
     if (validA) mA[256] = fabsf(v[8].x);
