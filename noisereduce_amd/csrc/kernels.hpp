@@ -724,10 +724,14 @@ __global__ __launch_bounds__(64 * STAT_TG) void k_row_decide(const double* __res
     const double mm = r1[i][l];
     m = (m != m || mm != mm) ? NAN : fmax(m, mm);
   }
-  const double mdb = cell_db(m, mag_scale);
-  double th;
+  // band-level quantities (two logarithms, a square root, an exp10: ~300 float64 instructions) are evaluated by ONE of
+  // the four thread groups and handed to the others through LDS -- they only depend on the band
+  __shared__ double s_band[2][64];   // [0] maximum in dB, [1] compare constant
+  if (tg == 0) s_band[0][l] = cell_db(m, mag_scale);
+  __syncthreads();  // (also: r1 is reused below)
+  const double mdb = s_band[0][l];
+  double th = 0.0;
   if (thresh_in == nullptr) {
-    __syncthreads();  // r1 is reused
     double s1 = 0.0, s2 = 0.0;
     for (int64_t t = tg; t < g.T; t += STAT_TG) {
       double d = db_fast(tile[t * 64 + l], s_tab, dbk, mag_scale) - mdb;  // <= 0
@@ -738,33 +742,40 @@ __global__ __launch_bounds__(64 * STAT_TG) void k_row_decide(const double* __res
     r1[tg][l] = s1;
     r2[tg][l] = s2;
     __syncthreads();
-    s1 = r1[0][l];
-    s2 = r2[0][l];
-    for (int i = 1; i < STAT_TG; ++i) {
-      s1 += r1[i][l];
-      s2 += r2[i][l];
+    if (tg == 0) {
+      s1 = r1[0][l];
+      s2 = r2[0][l];
+      for (int i = 1; i < STAT_TG; ++i) {
+        s1 += r1[i][l];
+        s2 += r2[i][l];
+      }
+      const double Tn = (double)g.T;
+      const double mean_d = s1 / Tn;
+      double var = (s2 - s1 * s1 / Tn) / (Tn - (double)ddof);
+      if (var < 0.0) var = 0.0;
+      th = (mdb + mean_d) + sqrt(var) * n_std;
     }
-    const double Tn = (double)g.T;
-    const double mean_d = s1 / Tn;
-    double var = (s2 - s1 * s1 / Tn) / (Tn - (double)ddof);
-    if (var < 0.0) var = 0.0;
-    th = (mdb + mean_d) + sqrt(var) * n_std;
-  } else {
+  } else if (tg == 0) {
     th = on ? thresh_in[u * thresh_ustride + f] : 0.0;
   }
   // compare constant in the power domain (see k_t2_rows)
   double t2 = 0.0;
-  if (on) {
-    const double fl = mdb - top_db;
-    if (th != th || fl != fl) {
-      t2 = 1e300;   // NaN threshold / NaN in the band: no cell passes (T2_NEVER)
-    } else if (fl > th || 20.0 * log10(eps) > th) {
-      t2 = -1.0;
-    } else {
-      const double tm = (exp10(th / 20.0) - eps) / mag_scale;
-      t2 = tm > 0.0 ? tm * tm : 0.0;
+  if (tg == 0) {
+    if (on) {
+      const double fl = mdb - top_db;
+      if (th != th || fl != fl) {
+        t2 = 1e300;   // NaN threshold / NaN in the band: no cell passes (T2_NEVER)
+      } else if (fl > th || 20.0 * log10(eps) > th) {
+        t2 = -1.0;
+      } else {
+        const double tm = (exp10(th / 20.0) - eps) / mag_scale;
+        t2 = tm > 0.0 ? tm * tm : 0.0;
+      }
     }
+    s_band[1][l] = t2;
   }
+  __syncthreads();
+  t2 = s_band[1][l];
   if (tg == 0 && f < g.FS) {
     pmax[u * g.FS + f] = on ? m : 0.0;
     if (thresh_out && on) thresh_out[u * g.FS + f] = th;
