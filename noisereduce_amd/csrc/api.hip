@@ -1429,9 +1429,12 @@ static int stage_nonstat_mask2(sg_handle* h, const View& v, const Geom& g, int64
     const int BW = 64 - 2 * nf;
     const unsigned gx = (unsigned)(((g.F + BW - 1) / BW + 3) / 4);
     const bool to_raw = !smooth && h->p.smooth_mask;
-    HIPCHK(h, launch_iir_mask(nt, dim3(gx, (unsigned)nk, (unsigned)ub), st, mag, (const double*)h->nsc.p, g, tl, h->p.iir_b,
-                              h->p.nonstat_thresh, h->p.nonstat_slope, nf, to_raw ? 1.0f : (float)h->p.prop_decrease,
-                              to_raw ? (float*)h->raw.p : (float*)h->M.p));
+    for (int64_t k0 = 0; k0 < nk; k0 += 65535) {   // grid.y <= 65535 tiles per launch (a 6-hour window has more)
+      tl.k0 = k0;
+      HIPCHK(h, launch_iir_mask(nt, dim3(gx, (unsigned)std::min<int64_t>(65535, nk - k0), (unsigned)ub), st, mag,
+                                (const double*)h->nsc.p, g, tl, h->p.iir_b, h->p.nonstat_thresh, h->p.nonstat_slope, nf,
+                                to_raw ? 1.0f : (float)h->p.prop_decrease, to_raw ? (float*)h->raw.p : (float*)h->M.p));
+    }
   }
   return SG_OK;
 }
@@ -1452,8 +1455,10 @@ static int stage_box_mask(sg_handle* h, const View& v, const Geom& g, int64_t ub
   const int BW = 64 - 2 * nf;
   const unsigned gx = (unsigned)(((g.F + BW - 1) / BW + 3) / 4);
   const unsigned nk = (unsigned)((g.T + NS_TT - 1) / NS_TT);
-  HIPCHK(h, launch_box_mask(nt, h->p.n_movemean, dim3(gx, nk, (unsigned)ub), st, (const float*)h->P.p, g,
-                            h->p.nonstat_thresh, h->p.nonstat_slope, nf, (float)h->p.prop_decrease, (float*)h->M.p));
+  for (int64_t k0 = 0; k0 < (int64_t)nk; k0 += 65535)   // grid.y <= 65535 tiles per launch
+    HIPCHK(h, launch_box_mask(nt, h->p.n_movemean, dim3(gx, (unsigned)std::min<int64_t>(65535, (int64_t)nk - k0), (unsigned)ub), st,
+                              (const float*)h->P.p, g, h->p.nonstat_thresh, h->p.nonstat_slope, nf, (float)h->p.prop_decrease,
+                              (float*)h->M.p, k0));
   return SG_OK;
 }
 

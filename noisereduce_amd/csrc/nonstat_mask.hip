@@ -20,12 +20,12 @@ hipError_t launch_iir_mask(int nt, dim3 grid, hipStream_t st, const float* mag, 
 }
 
 hipError_t launch_box_mask(int nt, int kbox, dim3 grid, hipStream_t st, const float* mag, Geom g, double nthresh,
-                           double slope, int nf, float p, float* M) {
+                           double slope, int nf, float p, float* M, int64_t k0) {
   if (kbox != NS_BOX_KB) return hipErrorInvalidValue;
   switch (nt) {
 #define SG_BOX_CASE(NT_)                                                                                             \
   case NT_:                                                                                                          \
-    hipLaunchKernelGGL((k_box_mask<NT_, NS_BOX_KB>), grid, dim3(256), 0, st, mag, g, nthresh, slope, nf, p, M);     \
+    hipLaunchKernelGGL((k_box_mask<NT_, NS_BOX_KB>), grid, dim3(256), 0, st, mag, g, nthresh, slope, nf, p, M, k0); \
     return hipGetLastError();
     SG_BOX_CASE(0) SG_BOX_CASE(1) SG_BOX_CASE(2) SG_BOX_CASE(3) SG_BOX_CASE(4) SG_BOX_CASE(5) SG_BOX_CASE(6)
     SG_BOX_CASE(7) SG_BOX_CASE(8) SG_BOX_CASE(9) SG_BOX_CASE(10) SG_BOX_CASE(11) SG_BOX_CASE(12)

@@ -15,6 +15,7 @@ constexpr int NS_MAX_NF = 24;  // k_iir_mask: a wave holds 64 - 2 nf output bins
 struct NsTiling {
   int64_t T;
   int nt;
+  int64_t k0 = 0;   // first tile of this launch (grid.y <= 65535: very long windows take several launches)
   __host__ __device__ int64_t n_tiles() const { return (T + NS_TT - 1) / NS_TT; }
 };
 
@@ -178,7 +179,7 @@ template <int NT>
 __global__ __launch_bounds__(256, (NT <= 9 ? 3 : 2)) void k_iir_mask(const float* __restrict__ A, const double* __restrict__ carry,
                                                      Geom g, NsTiling tl, double b, double nthresh, double slope,
                                                      int nf, float p, float* __restrict__ M) {
-  const int64_t k = blockIdx.y;
+  const int64_t k = tl.k0 + blockIdx.y;
   const bool edge = k * NS_TT - NT < 0 || (k + 1) * NS_TT + NT > g.T;
   if (edge) ns_mask_tile<NT, true>(A, carry, g, tl, b, nthresh, slope, nf, p, M, k);
   else ns_mask_tile<NT, false>(A, carry, g, tl, b, nthresh, slope, nf, p, M, k);
@@ -316,9 +317,9 @@ __device__ __forceinline__ void box_mask_tile(const float* __restrict__ A, const
 // grid (bin blocks, time tiles, units); interior tiles take the predicate-free instantiation
 template <int NT, int KB>
 __global__ __launch_bounds__(256, 2) void k_box_mask(const float* __restrict__ A, Geom g, double nthresh, double slope,
-                                                     int nf, float p, float* __restrict__ M) {
+                                                     int nf, float p, float* __restrict__ M, int64_t k0) {
   constexpr int LEFT = (KB - 1) / 2;
-  const int64_t k = blockIdx.y;
+  const int64_t k = k0 + blockIdx.y;
   const bool edge = k * NS_TT - NT - LEFT < 0 || (k + 1) * NS_TT + NT + (KB - 1 - LEFT) > g.T;
   if (edge) box_mask_tile<NT, KB, true>(A, g, nthresh, slope, nf, p, M, k);
   else box_mask_tile<NT, KB, false>(A, g, nthresh, slope, nf, p, M, k);
@@ -328,7 +329,7 @@ __global__ __launch_bounds__(256, 2) void k_box_mask(const float* __restrict__ A
 hipError_t launch_iir_mask(int nt, dim3 grid, hipStream_t st, const float* mag, const double* carry, Geom g, NsTiling tl,
                            double b, double nthresh, double slope, int nf, float p, float* M);
 hipError_t launch_box_mask(int nt, int kbox, dim3 grid, hipStream_t st, const float* mag, Geom g, double nthresh,
-                           double slope, int nf, float p, float* M);
+                           double slope, int nf, float p, float* M, int64_t k0);
 constexpr int NS_IIR_MAX_NT = 20;   // k_iir_mask<0 .. 20>
 constexpr int NS_BOX_MAX_NT = 12;   // k_box_mask<0 .. 12, 20>
 constexpr int NS_BOX_KB = 20;       // the moving-mean length k_box_mask is built for (TorchGate's default)
