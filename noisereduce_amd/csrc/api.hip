@@ -1420,7 +1420,7 @@ static int stage_nonstat_mask2(sg_handle* h, const View& v, const Geom& g, int64
     hipLaunchKernelGGL(k_iir_part, dim3((unsigned)((g.F + 63) / 64), (unsigned)((nk + 3) / 4), (unsigned)ub), dim3(256), 0,
                        st, mag, g, tl, h->p.iir_b, (double*)h->nsp.p);
     HIPCHK(h, hipGetLastError());
-    hipLaunchKernelGGL(k_iir_chain, dim3((unsigned)((ub * g.FS + 63) / 64)), dim3(64), (size_t)nk * 2 * sizeof(double), st, mag,
+    hipLaunchKernelGGL(k_iir_chain, dim3((unsigned)((ub * g.FS + 63) / 64)), dim3(64), 0, st, mag,
                        (const double*)h->nsp.p, g, tl, h->p.iir_b, (double*)h->nsc.p, ub);
     HIPCHK(h, hipGetLastError());
   }

@@ -65,19 +65,15 @@ __global__ __launch_bounds__(256) void k_iir_part(const float* __restrict__ A, G
 __global__ __launch_bounds__(64) void k_iir_chain(const float* __restrict__ A, const double* __restrict__ part,
                                                   Geom g, NsTiling tl, double b, double* __restrict__ carry,
                                                   int64_t n_units) {
-  extern __shared__ __attribute__((aligned(16))) char smem[];
-  double* pw1 = reinterpret_cast<double*>(smem);  // [nk] c^len
   const int64_t nk = tl.n_tiles();
   const int nj = (int)nk;
-  double* pw2 = pw1 + nj;                          // [nk] 1 - c^(2 len)
   const double c = 1.0 - b;
-  for (int j = threadIdx.x; j < nj; j += 64) {
-    const int64_t t0 = (int64_t)j * NS_TT, t1 = t0 + NS_TT < g.T ? t0 + NS_TT : g.T;
-    const double len = (double)(t1 - t0);
-    pw1[j] = pow(c, len);
-    pw2[j] = 1.0 - pow(c, 2.0 * len);
-  }
-  __syncthreads();
+  // c^len and 1 - c^(2 len): every tile has NS_TT frames but the last (no table: an hour in one window has 10 k tiles)
+  const double len_last = (double)(g.T - (nk - 1) * NS_TT);
+  const double pf1 = pow(c, (double)NS_TT), pf2 = 1.0 - pow(c, 2.0 * NS_TT);
+  const double pl1 = pow(c, len_last), pl2 = 1.0 - pow(c, 2.0 * len_last);
+  auto pw1 = [&](int j) { return j == nj - 1 ? pl1 : pf1; };
+  auto pw2 = [&](int j) { return j == nj - 1 ? pl2 : pf2; };
   const int64_t i = (int64_t)blockIdx.x * 64 + threadIdx.x;
   if (i >= n_units * g.FS) return;
   const int64_t u = i / g.FS;
@@ -101,7 +97,7 @@ __global__ __launch_bounds__(64) void k_iir_chain(const float* __restrict__ A, c
       for (int q = 0; q < CB; ++q)
         if (j0 + q < nj) {
           cb[(j0 + q) * st2] = s;
-          s = d[q] + pw1[j0 + q] * s;
+          s = d[q] + pw1(j0 + q) * s;
         }
     };
     fetch(0, e[0]);
@@ -132,7 +128,7 @@ __global__ __launch_bounds__(64) void k_iir_chain(const float* __restrict__ A, c
         const int j = j1 - q;
         if (j >= 0) {
           cb[j * st2 + g.FS] = S;
-          S = (d0[q] + d1[q] * gq * pw2[j]) + pw1[j] * S;
+          S = (d0[q] + d1[q] * gq * pw2(j)) + pw1(j) * S;
         }
       }
     };
