@@ -1,5 +1,5 @@
 """Device-resident throughput of reduce_noise (stationary / non-stationary) over n_fft, including
-frame lengths that run on the chirp-z kernels.  Usage: python tools/time_nfft.py"""
+frame lengths that run on the chirp-z kernels.  Usage: [MINUTES=2] [NFFT=512,1024,...] python tools/time_nfft.py"""
 import json
 import sys, os
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
@@ -7,12 +7,14 @@ import numpy as np
 import torch
 import noisereduce_amd as nr
 
-sr, n = 48000, 48000 * 120
+sr = 48000
+n = int(sr * 60 * float(os.environ.get("MINUTES", "2")))
 rng = np.random.default_rng(0)
 y = (0.1 * rng.standard_normal(n) + 0.5 * np.sin(2 * np.pi * 1000 * np.arange(n) / sr)).astype(np.float32)
 yd = torch.from_numpy(y).cuda()
 res = {}
-for n_fft in (256, 400, 512, 1000, 1024, 1536, 2048, 3000, 4096, 8192, 5000, 16384, 32768):
+NFFTS = [int(a) for a in os.environ["NFFT"].split(",")] if os.environ.get("NFFT") else (256, 400, 512, 1000, 1024, 1536, 2048, 3000, 4096, 8192, 5000, 16384, 32768)
+for n_fft in NFFTS:
     for stationary in (True, False):
         kw = dict(stationary=stationary, n_fft=n_fft, time_mask_smooth_ms=(400 if n_fft > 16384 else 200) if n_fft > 2048 else 50)
         for _ in range(2):
