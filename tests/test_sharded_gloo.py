@@ -178,6 +178,17 @@ def test_time_sharded_more_ranks_than_chunks():
         assert kind == "ok" and err < 1e-12, (kind, err)
 
 
+def test_time_sharded_eight_ranks():
+    # the node the scaling runs use: 8 ranks, 21 chunks (the last one partial) -> shards of 3, 3, 3, 3, 3, 2, 2, 2 chunks;
+    # every rank's result against the single-process oracle, seams exchanged in ONE all-gather
+    n = 20 * CS + 777
+    res, bounds = _run_layout(n, 8)
+    assert bounds[0][0] == 0 and bounds[-1][1] == n
+    assert all(bounds[r][1] == bounds[r + 1][0] and bounds[r][1] % CS == 0 for r in range(7))
+    for kind, err, shape in res:
+        assert kind == "ok" and err < 1e-12, (kind, err)
+
+
 def test_time_sharded_bad_layout_raises_on_every_rank():
     # rank 0's shard is not chunk-aligned: every rank must raise (none may hang in the all-gather)
     n = 2 * CS
