@@ -456,3 +456,25 @@ def test_torchgate_nonstationary_one_kernel_mask(nr, sr, L, kw):
     y = TorchGate(sr=sr, nonstationary=True, **kw).cuda()(torch.from_numpy(x).cuda()).cpu().numpy()
     want = O.torchgate_T(x, sr, nonstationary=True, window=torch.hann_window(1024).double().numpy(), **kw)
     assert O.rel_err(y, want) < TOL
+
+
+def test_nonstationary_window_of_24_minutes(nr):
+    """One window (chunk_size=None) of 24 min at 48 kHz = 270 k frames = 4219 time tiles: k_iir_chain used to keep
+    a per-tile table in LDS and did not launch beyond 4096 tiles (23 min).  Against the materialised kernels behind
+    SG_OPT_FORCE_UNFUSED (no chain), whole output; tests/tools/long_window_check.py holds an hour against the oracle."""
+    from noisereduce_amd import _ffi
+    from noisereduce_amd.spectralgate.nonstationary import SpectralGateNonStationary
+    sr, n = 48000, 48000 * 60 * 24
+    g = torch.Generator(device="cuda").manual_seed(3)
+    y = 0.05 * torch.randn(n, device="cuda", generator=g)
+    y += 0.3 * torch.sin(2 * np.pi * 700.0 * torch.arange(n, device="cuda", dtype=torch.float32) / sr)
+    kw = dict(NS_KW); kw.update(y=y, chunk_size=None, padding=30000)
+    sg = SpectralGateNonStationary(**kw)
+    a = sg.get_traces()
+    sg._gate.set_option(_ffi.SG_OPT_FORCE_UNFUSED, 1)
+    try:
+        b = SpectralGateNonStationary(**kw).get_traces()
+    finally:
+        sg._gate.set_option(_ffi.SG_OPT_FORCE_UNFUSED, 0)
+    assert bool(torch.isfinite(a).all())
+    assert float((a - b).abs().max()) < 1e-5 * float(b.abs().max())
