@@ -78,6 +78,19 @@ def test_channel_sharded_two_ranks_matches_single_process():
     assert ret[0] < 1e-9 and ret[1] < 1e-9
 
 
+def test_channel_sharded_eight_ranks_matches_single_process():
+    # configs[3]'s layout on the scaling node: 8 ranks, channels dealt 2 per rank (64 channels / 8 GPUs there); the only
+    # exchange is the all-reduce of the noise clip's channel sum
+    n = 2 * CS + 333
+    y = np.stack([O.synth_signal(n, seed=80 + c, tone_hz=120.0 * (c + 1)).astype(np.float64) for c in range(16)])
+    want = O.reduce_noise_S(y, SR, stationary=True, chunk_size=CS, padding=PAD, n_fft=NFFT)
+    mgr = mp.Manager()
+    ret = mgr.dict()
+    mp.spawn(_worker_channels, args=(8, _free_port(), torch.from_numpy(y), torch.from_numpy(want), ret),
+             nprocs=8, join=True)
+    assert all(ret[r] < 1e-9 for r in range(8)), dict(ret)
+
+
 def _free_port():
     s = socket.socket()
     s.bind(("127.0.0.1", 0))
