@@ -93,7 +93,54 @@ def _pool_chunk(args):
 _pool_chunk.cache = {}
 
 
+def cpu_baseline_reference(budget_s=40.0, timeout_s=240.0):
+    """The UNMODIFIED reference timed on this host's cores (oracle/time_reference.py in a subprocess: no HIP context,
+    none of this process's state), when oracle/make_ref.sh has staged it under the git-ignored oracle/_ref/ (it
+    travels with the gpurun snapshot like the built .so).  Returns None when it is not staged or fails."""
+    import subprocess
+    script = os.path.join(ROOT, "oracle", "time_reference.py")
+    if not os.path.isdir(os.path.join(ROOT, "oracle", "_ref", "noisereduce")):
+        return None
+    env = {k: v for k, v in os.environ.items() if k not in ("OMP_NUM_THREADS", "MKL_NUM_THREADS")}
+    try:
+        pr = subprocess.run([sys.executable, script, "--budget", str(budget_s)], capture_output=True, text=True,
+                            timeout=timeout_s, env=env, cwd=ROOT)
+        lines = [ln for ln in pr.stdout.splitlines() if ln.startswith("{")]
+        res = json.loads(lines[-1])
+        if "value" not in res:
+            return None
+        return res
+    except Exception as e:
+        print("bench.py: reference cpu_baseline failed (%r): falling back to the port" % (e,), file=sys.stderr)
+        return None
+
+
 def cpu_baseline(budget_s=25.0):
+    """`cpu_baseline` of the JSON line.  Preferred: "kind": "reference" -- the reference's own numpy/scipy path
+    (reduce_noise(use_torch=False), n_jobs=1 and n_jobs=os.cpu_count(), plus its TorchGate on CPU tensors), staged by
+    oracle/make_ref.sh, 1 warm-up + median of 5 (oracle/time_reference.py).  The numpy oracle ("port") is timed on the
+    same single-core sample beside it.  Without the staged reference: the port alone ("kind": "port")."""
+    ref = cpu_baseline_reference()
+    if ref is not None:
+        try:
+            from oracle import spectralgate_oracle as O
+            n = SR * 60
+            y = O.synth_signal(n, dtype=np.float32).astype(np.float64)
+            ts = []
+            for i in range(3):
+                t0 = time.perf_counter()
+                O.reduce_noise_S(y, SR, stationary=True, n_fft=NFFT, chunk_size=CHUNK, padding=PAD)
+                ts.append(time.perf_counter() - t0)
+            ref["port_same_sample"] = {"value": round(n / float(np.median(ts[1:])) / 1e6, 3), "unit": "Msamples/s", "cores": 1,
+                                       "kind": "port", "sample": "oracle/spectralgate_oracle.py reduce_noise_S on the same "
+                                       "60 s, median of 2 after 1 warm-up (the checker's own speed, for the record)"}
+        except Exception as e:
+            ref["port_same_sample"] = {"error": repr(e)}
+        return ref
+    return cpu_baseline_port(budget_s)
+
+
+def cpu_baseline_port(budget_s=25.0):
     """(a) 1 core: stationary reduce_noise of the first 60 s of the workload (5 chunks), 1 warm-up +
     median of 3.  (b) all cores: the 48 chunks of the full 10-min workload dealt to a process pool
     (one chunk per task = the reference's joblib n_jobs semantics, base.py:206-216), median of 3 after

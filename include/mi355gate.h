@@ -195,7 +195,10 @@ SG_API int sg_debug_fetch(sg_handle* h, int32_t what, void* host, int64_t bytes,
                                  * the reference on ~1 % of the samples.  Default: the float64 pipeline, whose truncated result IS
                                  * the reference's (base.py:217-226 casts a float64 array), an order of magnitude slower */
 #define SG_OPT_FORCE_EXACT 9    /* value != 0: float64 pipeline for every output dtype (float64 recordings: float64-accurate results) */
-#define SG_OPT_INJECT_HANDOFF_FAULT 7 /* tests: the next launch with in-launch hand-offs reports `value` (bits 0..2) as lost hand-offs */
+#define SG_OPT_INJECT_HANDOFF_FAULT 7 /* tests: the next launch with in-launch hand-offs reports `value` (bits 0..2) as lost hand-offs
+                                       * (the output is fine); bits 3..5 make the KERNEL lose its hand-offs (3 or 4: the one-pass
+                                       * gate, 5: the fused apply): the producers' tags are never accepted and the polls give up --
+                                       * the bounded-poll timeout path itself: error word set by the kernel, affected hops NaN */
 #define SG_OPT_FORCE_NOFAST 2  /* value != 0: keep the bit-mask stages but use the general apply kernels */
 SG_API int sg_set_option(sg_handle* h, int32_t option, int64_t value);
 
@@ -206,7 +209,8 @@ SG_API int sg_set_option(sg_handle* h, int32_t option, int64_t value);
  * call that enqueued the kernel.  sg_check_errors synchronises `stream` and returns SG_E_HANDOFF when a launch
  * enqueued on this handle since the previous check lost a hand-off: those calls' outputs are invalid and must
  * be re-run.  sg_get_noise_threshold and sg_debug_fetch (which synchronise anyway) report the same way; a caller
- * that never checks gets SG_E_HANDOFF from its NEXT compute call on the handle.  The Python layer checks after
+ * that never checks gets SG_E_HANDOFF from its NEXT compute call on the handle -- and never plausible-looking audio:
+ * a tile that lost a hand-off writes NaN to every output hop it could not finalise.  The Python layer checks after
  * every call that returns host arrays and re-runs a failed call on the kernels without in-launch hand-offs.
  * (No counterpart in the reference: base.py:206-216 joins its joblib workers.) */
 SG_API int sg_check_errors(sg_handle* h, void* stream);

@@ -88,6 +88,8 @@ struct sg_handle {
   unsigned* err_host = nullptr;      // host-mapped error word written by k_gate_onepass when a hand-off times out
   unsigned* err_dev = nullptr;
   unsigned inject_fault = 0;         // SG_OPT_INJECT_HANDOFF_FAULT (tests): error bits the next hand-off launch reports
+  unsigned lose_now = 0;             // bits 3..5 of the option, consumed by the next hand-off launch: the kernel itself treats
+                                     // the hand-off as lost (bounded-poll timeout path: error word + NaN-poisoned hops)
   unsigned ticket_base = 0;          // tickets handed out by all previous launches
   unsigned epoch = 0;                // launch counter: the value a tile's flag must carry to be current
   bool fast_integer = false;         // SG_OPT_FAST_INTEGER: integer outputs from the float32 kernels (<= 1 LSB off)
@@ -1724,8 +1726,10 @@ static int handoff_prepare(sg_handle* h, hipStream_t st) {
     FAIL(h, SG_E_HANDOFF, "a tile hand-off of an EARLIER call on this handle timed out (code %u): that call's output "
                           "is invalid (call sg_check_errors after a call to learn about it in time)", e);
   }
+  h->lose_now = 0;
   if (h->inject_fault) {  // test hook: this launch "loses" a hand-off
-    *h->err_host = h->inject_fault;
+    *h->err_host = h->inject_fault & 7u;          // bits 0..2: reported only (the output is fine)
+    h->lose_now = (h->inject_fault >> 3) & 7u;    // bits 3..5: lost INSIDE the kernel (the output is poisoned)
     h->inject_fault = 0;
   }
   if (++h->epoch == 0) {  // wrapped: tags of 2^32 launches ago could alias
@@ -1816,11 +1820,14 @@ static int stage_apply_fast(sg_handle* h, const View& v, const Geom& g, int64_t 
     return hipGetLastError();
   };
   const size_t lds_lean = (size_t)(fast::FN + WAVES * fast::WAVE_CX_H) * sizeof(fast::cf) + 1024 * sizeof(float) + 16;
+  const bool lose = inkernel && (h->lose_now & 4u);   // test hook: the instantiation whose hand-off polls give up at once
   if (mask_f) {
-    if (lean) HIPCHK(h, go(fast::k_apply_fast<WAVES, false, true>, lds_lean));
+    if (lose) HIPCHK(h, go(fast::k_apply_fast<WAVES, false, true, true>, lds_lean));
+    else if (lean) HIPCHK(h, go(fast::k_apply_fast<WAVES, false, true>, lds_lean));
     else HIPCHK(h, go(fast::k_apply_fast<WAVES, false, false>, lds));
   } else {
-    if (lean) HIPCHK(h, go(fast::k_apply_fast<WAVES, true, true>, lds_lean));
+    if (lose) HIPCHK(h, go(fast::k_apply_fast<WAVES, true, true, true>, lds_lean));
+    else if (lean) HIPCHK(h, go(fast::k_apply_fast<WAVES, true, true>, lds_lean));
     else HIPCHK(h, go(fast::k_apply_fast<WAVES, true, false>, lds));
   }
   HIPCHK(h, hipGetLastError());
@@ -1938,7 +1945,8 @@ static int stage_onepass(sg_handle* h, const View& v, const View& vx, const Geom
       hipLaunchKernelGGL(kern, dim3((unsigned)(ub * ntt)), dim3(WAVES * 64), lds, st, P);
       return hipGetLastError();
     };
-    if (prop) HIPCHK(h, go(fast::k_gate_onepass<WAVES, true>));
+    if (h->lose_now & 3u) HIPCHK(h, go(fast::k_gate_onepass<WAVES, false, true>));   // test hook (PROP-free shape only)
+    else if (prop) HIPCHK(h, go(fast::k_gate_onepass<WAVES, true>));
     else HIPCHK(h, go(fast::k_gate_onepass<WAVES, false>));
   }
   h->dbg_xbits = true;
@@ -2552,7 +2560,7 @@ extern "C" int sg_set_option(sg_handle* h, int32_t option, int64_t value) {
     case SG_OPT_FORCE_SPLIT: h->force_split = value != 0; return SG_OK;
     case SG_OPT_FAST_INTEGER: h->fast_integer = value != 0; return SG_OK;
     case SG_OPT_FORCE_EXACT: h->force_exact = value != 0; return SG_OK;
-    case SG_OPT_INJECT_HANDOFF_FAULT: h->inject_fault = (unsigned)value & 7u; return SG_OK;
+    case SG_OPT_INJECT_HANDOFF_FAULT: h->inject_fault = (unsigned)value & 63u; return SG_OK;
   }
   FAIL(h, SG_E_INVALID, "sg_set_option: unknown option %d", option);
 }

@@ -529,7 +529,8 @@ struct ApplyArgs {
 #ifndef SG_ABLATE
 #define SG_ABLATE 0
 #endif
-template <int WAVES, bool KMASK, bool LEAN>
+// LOSE (tests only, SG_OPT_INJECT_HANDOFF_FAULT bit 5): the in-launch hand-off polls give up at once (see k_gate_onepass).
+template <int WAVES, bool KMASK, bool LEAN, bool LOSE = false>
 __global__ __launch_bounds__(WAVES * 64, LEAN ? 3 : 2) void k_apply_fast(ApplyArgs A) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
   cf* tw512 = reinterpret_cast<cf*>(smem);
@@ -899,9 +900,12 @@ __global__ __launch_bounds__(WAVES * 64, LEAN ? 3 : 2) void k_apply_fast(ApplyAr
         asm volatile("global_load_dwordx4 %0, %2, off sc1\n\tglobal_load_dwordx4 %1, %2, off offset:16 sc1\n\ts_waitcnt vmcnt(0)"
                      : "=&v"(ga), "=&v"(gb) : "v"(src) : "memory");
         const unsigned e = A.epoch;
-        if (ga[1] == e && ga[3] == e && gb[1] == e && gb[3] == e) break;
-        if (spin >= OP_SPIN_MAX) {
+        if (!LOSE && ga[1] == e && ga[3] == e && gb[1] == e && gb[3] == e) break;
+        if (LOSE || spin >= OP_SPIN_MAX) {
           atomicOr_system(A.err, 4u);
+          // the previous tile's share never arrived: these hops become NaN (a device-tensor caller that does not
+          // check the error word must not receive a plausible partial sum)
+          ga[0] = ga[2] = gb[0] = gb[2] = 0x7fc00000u;
           break;
         }
         __builtin_amdgcn_s_sleep(1);

@@ -108,7 +108,10 @@ __device__ __forceinline__ double op_exact_power(const OnePassArgs& P, int64_t r
 
 // PROP: prop_decrease < 1 (stationary.py:108-114 applies it BEFORE the smoothing: mask = p K / ktot + (1 - p) edge,
 // edge = the smoothing filter's weight inside the spectrogram -- 1 except near its borders)
-template <int WAVES, bool PROP>
+// LOSE (tests only, SG_OPT_INJECT_HANDOFF_FAULT bits 3..4): an instantiation whose polls give up at once -- the timeout
+// branch of every hand-off (error word, NaN-poisoned hops) runs without a second of spinning and without a test
+// argument in the product kernel, whose register allocation sits at the 168-VGPR edge.
+template <int WAVES, bool PROP, bool LOSE = false>
 __global__ __launch_bounds__(WAVES * 64, 3) void k_gate_onepass(OnePassArgs P) {
   static_assert(WAVES == 4, "tile = 16 frames");
   extern __shared__ __attribute__((aligned(16))) char smem[];
@@ -143,7 +146,10 @@ __global__ __launch_bounds__(WAVES * 64, 3) void k_gate_onepass(OnePassArgs P) {
     t2pre[0] = P.tc.T2[perm_inv(tid)];
     t2pre[1] = P.tc.T2[perm_inv(tid + 256)];
     t2pre[2] = P.tc.T2[perm_inv(512)];
-    if (tid == 0) s_misc[0] = atomicAdd(P.ticket, 1u) - P.ticket_base;
+    if (tid == 0) {
+      s_misc[0] = atomicAdd(P.ticket, 1u) - P.ticket_base;
+      s_misc[1] = 0u;   // set when a hand-off of this tile is lost: its output hops are POISONED (NaN), never plausible garbage
+    }
     tw512[tid] = tw_a;
     tw512[tid + 256] = tw_b;
     reinterpret_cast<float4*>(swin)[tid] = w4;
@@ -498,9 +504,10 @@ __global__ __launch_bounds__(WAVES * 64, 3) void k_gate_onepass(OnePassArgs P) {
     const unsigned long long* src = side ? xb_mine + OP_TILE_WORDS + (rr * OP_XW + w) * 2
                                          : xb_mine - OP_TILE_WORDS + ((NF - nt + rr) * OP_XW + w) * 2;
     op_v4u gr = op_ld16_sc1(src);
-    for (int spin = 0; !(OP_ABLATE & 2) && (gr[1] != P.epoch || gr[3] != P.epoch); ++spin) {
-      if (spin >= OP_SPIN_MAX) {   // every spin is bounded: report instead of hanging the device
+    for (int spin = 0; !(OP_ABLATE & 2) && (LOSE || gr[1] != P.epoch || gr[3] != P.epoch); ++spin) {
+      if (LOSE || spin >= OP_SPIN_MAX) {   // every spin is bounded: report instead of hanging the device
         atomicOr_system(P.err, 1u);
+        s_misc[1] = 1u;            // the tile's mask is unknown: every hop it finalises or hands on becomes NaN
         break;
       }
       __builtin_amdgcn_s_sleep(1);
@@ -645,6 +652,10 @@ __global__ __launch_bounds__(WAVES * 64, 3) void k_gate_onepass(OnePassArgs P) {
   // ---- cross-wave combine, normalise, store (seam mode: abutting tiles) -------------------------------
   const float* fr = reinterpret_cast<const float*>(regions);
   const int s4 = (tid & 63) * 4;
+  // A lost hand-off must not look like audio: a tile whose neighbour bits never arrived writes NaN to every hop it
+  // finalises and publishes NaN partials (the next tile's straddling hops inherit them); a tile whose predecessor's
+  // partial hops never arrived writes NaN to those three hops.  The error word still reports it (sg_check_errors).
+  const float poison = s_misc[1] != 0u ? __uint_as_float(0x7fc00000u) : 0.f;
   // Hops that straddle two tiles: tile j publishes its three TRAILING partial hops (un-normalised sums) the
   // same way as the mask bits (write-through stores, drained, epoch flag per hop); tile j+1 adds its LEADING
   // partials and finalises them.  Per wave: trailing hop first (published early), interior hops, leading hop
@@ -664,7 +675,7 @@ __global__ __launch_bounds__(WAVES * 64, 3) void k_gate_onepass(OnePassArgs P) {
       constexpr int R = WAVE_CX_H * 2;
       auto ld4 = [&](int off) { return *reinterpret_cast<const float4*>(&fr[off + s4]); };
       auto fin = [&](float4 a, int jj) {
-        a.x *= n4.x; a.y *= n4.y; a.z *= n4.z; a.w *= n4.w;
+        a.x = (a.x + poison) * n4.x; a.y = (a.y + poison) * n4.y; a.z = (a.z + poison) * n4.z; a.w = (a.w + poison) * n4.w;
         *reinterpret_cast<float4*>(dst0 + jj * 256) = a;
       };
       if (wave == 3) {
@@ -676,8 +687,8 @@ __global__ __launch_bounds__(WAVES * 64, 3) void k_gate_onepass(OnePassArgs P) {
       {
         const float4 a4 = ld4((WAVES - 1) * R + (wave + 4) * HPITCH);
         unsigned long long* dst = P.part2 + (((size_t)u * A.n_tiles + jt) * 3 + wave) * 256 + s4;
-        const op_v4u ga = {__float_as_uint(a4.x), P.epoch, __float_as_uint(a4.y), P.epoch};
-        const op_v4u gb = {__float_as_uint(a4.z), P.epoch, __float_as_uint(a4.w), P.epoch};
+        const op_v4u ga = {__float_as_uint(a4.x + poison), P.epoch, __float_as_uint(a4.y + poison), P.epoch};
+        const op_v4u gb = {__float_as_uint(a4.z + poison), P.epoch, __float_as_uint(a4.w + poison), P.epoch};
         op_st16_sc1(dst, ga);
         op_st16_sc1(dst + 2, gb);
       }
@@ -696,9 +707,10 @@ __global__ __launch_bounds__(WAVES * 64, 3) void k_gate_onepass(OnePassArgs P) {
           asm volatile("global_load_dwordx4 %0, %2, off sc1\n\tglobal_load_dwordx4 %1, %2, off offset:16 sc1\n\ts_waitcnt vmcnt(0)"
                        : "=&v"(ga), "=&v"(gb) : "v"(src) : "memory");
           const unsigned e = P.epoch;
-          if ((OP_ABLATE & 16) || (ga[1] == e && ga[3] == e && gb[1] == e && gb[3] == e)) break;
-          if (spin >= OP_SPIN_MAX) {
+          if ((OP_ABLATE & 16) || (!LOSE && ga[1] == e && ga[3] == e && gb[1] == e && gb[3] == e)) break;
+          if (LOSE || spin >= OP_SPIN_MAX) {
             atomicOr_system(P.err, 2u);
+            ga[0] = ga[2] = gb[0] = gb[2] = 0x7fc00000u;   // the previous tile's share is unknown: NaN, not a partial sum
             break;
           }
           __builtin_amdgcn_s_sleep(1);
@@ -739,8 +751,8 @@ __global__ __launch_bounds__(WAVES * 64, 3) void k_gate_onepass(OnePassArgs P) {
       // trailing partial hop -> tagged granules {float, epoch}
       const int k = jj - NF;
       unsigned long long* dst = P.part2 + (((size_t)u * A.n_tiles + jt) * 3 + k) * 256 + s4;
-      const op_v4u ga = {__float_as_uint(a4.x), P.epoch, __float_as_uint(a4.y), P.epoch};
-      const op_v4u gb = {__float_as_uint(a4.z), P.epoch, __float_as_uint(a4.w), P.epoch};
+      const op_v4u ga = {__float_as_uint(a4.x + poison), P.epoch, __float_as_uint(a4.y + poison), P.epoch};
+      const op_v4u gb = {__float_as_uint(a4.z + poison), P.epoch, __float_as_uint(a4.w + poison), P.epoch};
       op_st16_sc1(dst, ga);
       op_st16_sc1(dst + 2, gb);
       continue;
@@ -753,9 +765,10 @@ __global__ __launch_bounds__(WAVES * 64, 3) void k_gate_onepass(OnePassArgs P) {
         asm volatile("global_load_dwordx4 %0, %2, off sc1\n\tglobal_load_dwordx4 %1, %2, off offset:16 sc1\n\ts_waitcnt vmcnt(0)"
                      : "=&v"(ga), "=&v"(gb) : "v"(src) : "memory");
         const unsigned e = P.epoch;
-        if ((OP_ABLATE & 16) || (ga[1] == e && ga[3] == e && gb[1] == e && gb[3] == e)) break;
-        if (spin >= OP_SPIN_MAX) {
+        if ((OP_ABLATE & 16) || (!LOSE && ga[1] == e && ga[3] == e && gb[1] == e && gb[3] == e)) break;
+        if (LOSE || spin >= OP_SPIN_MAX) {
           atomicOr_system(P.err, 2u);
+          ga[0] = ga[2] = gb[0] = gb[2] = 0x7fc00000u;
           break;
         }
         __builtin_amdgcn_s_sleep(1);
@@ -766,6 +779,7 @@ __global__ __launch_bounds__(WAVES * 64, 3) void k_gate_onepass(OnePassArgs P) {
       a4.z = __uint_as_float(gb[0]) + a4.z;
       a4.w = __uint_as_float(gb[2]) + a4.w;
     }
+    a4.x += poison; a4.y += poison; a4.z += poison; a4.w += poison;
     if (!A.normalize) {
     } else if (all_valid) {
       a4.x *= n4.x; a4.y *= n4.y; a4.z *= n4.z; a4.w *= n4.w;
