@@ -183,6 +183,10 @@ SG_API int sg_debug_dims(const sg_handle* h, int64_t dims[3]); /* units, T, FS *
 /* Frame range [t0, t1) for which field 3 (mask bits) was computed: the fast path only decides
  * the frames that reach the kept output samples (+- the smoothing half width). */
 SG_API int sg_debug_range(const sg_handle* h, int64_t range[2]);
+/* Diagnostic counters (synchronises `stream`).  which = 0: (row, band) pairs of the one-kernel TorchGate row gate that were
+ * re-evaluated in float64 since the handle was created (the float32 statistics could not decide them within their error
+ * bound); divide by rows x 513 for the rate. */
+SG_API int sg_debug_counter(sg_handle* h, int32_t which, int64_t* value, void* stream);
 SG_API int sg_debug_fetch(sg_handle* h, int32_t what, void* host, int64_t bytes, void* stream);
 
 /* ---- options ------------------------------------------------------------------------- */
@@ -199,6 +203,10 @@ SG_API int sg_debug_fetch(sg_handle* h, int32_t what, void* host, int64_t bytes,
                                        * (the output is fine); bits 3..5 make the KERNEL lose its hand-offs (3 or 4: the one-pass
                                        * gate, 5: the fused apply): the producers' tags are never accepted and the polls give up --
                                        * the bounded-poll timeout path itself: error word set by the kernel, affected hops NaN */
+#define SG_OPT_FORCE_NOROWGATE 10 /* value != 0: variant T, stationary, short rows: the four-kernel path (float64 transform of every
+                                   * frame, k_row_decide, k_smooth_bits2, k_apply_fast) instead of the one-kernel row gate */
+#define SG_OPT_ROWGATE_TAP 11     /* value != 0: the row gate also writes its float32 power tile (4 |X|^2, [rows][64][528]) for
+                                   * sg_debug_fetch(what = 4): measurements behind the decision margin */
 #define SG_OPT_FORCE_NOFAST 2  /* value != 0: keep the bit-mask stages but use the general apply kernels */
 SG_API int sg_set_option(sg_handle* h, int32_t option, int64_t value);
 
@@ -233,7 +241,8 @@ SG_API int sg_check_errors(sg_handle* h, void* stream);
 #define SG_STAGE_APPLY_FAST 14
 #define SG_STAGE_DECIDE_FAST 15
 #define SG_STAGE_ONEPASS 16
-#define SG_N_STAGES 17
+#define SG_STAGE_ROW_GATE 17   /* k_row_gate: TorchGate.forward of a whole row (<= 64 frames) in one kernel */
+#define SG_N_STAGES 18
 /* When enabled, every kernel launch is bracketed by a hipEvent pair recorded on the launch
  * stream.  sg_profile_read synchronises those events and returns accumulated milliseconds
  * and launch counts per stage (arrays of SG_N_STAGES); reset != 0 clears the accumulators. */

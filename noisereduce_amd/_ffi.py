@@ -20,7 +20,7 @@ LIB_PATH = os.path.join(_HERE, "libmi355gate.so")
 SG_F32, SG_F64, SG_I16, SG_I32 = 0, 1, 2, 3
 SG_VARIANT_S, SG_VARIANT_T = 0, 1
 SG_E_INVALID, SG_E_UNSUPPORTED, SG_E_HIP, SG_E_NOMEM, SG_E_STATE, SG_E_HANDOFF = -1, -2, -3, -4, -5, -6
-SG_N_STAGES = 17
+SG_N_STAGES = 18
 SG_OPT_FORCE_F64_DECIDE = 3
 SG_OPT_FORCE_NOSEAM = 4
 SG_OPT_FORCE_NOLEAN = 5
@@ -28,6 +28,8 @@ SG_OPT_FORCE_SPLIT = 6
 SG_OPT_INJECT_HANDOFF_FAULT = 7
 SG_OPT_FAST_INTEGER = 8
 SG_OPT_FORCE_EXACT = 9
+SG_OPT_FORCE_NOROWGATE = 10
+SG_OPT_ROWGATE_TAP = 11
 SG_OPT_FORCE_UNFUSED = 1
 SG_OPT_FORCE_NOFAST = 2
 
@@ -86,6 +88,7 @@ _PROTOTYPES = {
     "sg_stage_name": (c_char_p, [c_int32]),
     "sg_debug_dims": (c_int, [c_void_p, POINTER(c_int64)]),
     "sg_debug_range": (c_int, [c_void_p, POINTER(c_int64)]),
+    "sg_debug_counter": (c_int, [c_void_p, c_int32, POINTER(c_int64), c_void_p]),
     "sg_debug_fetch": (c_int, [c_void_p, c_int32, c_void_p, c_int64, c_void_p]),
 }
 
@@ -416,12 +419,25 @@ class Gate:
         self._check(self.lib.sg_debug_range(self._h, r))
         return int(r[0]), int(r[1])
 
+    def debug_counter(self, which=0):
+        """0: (row, band) pairs the row gate re-evaluated in float64 since the handle was created."""
+        v = c_int64(0)
+        with torch.cuda.device(self.device):
+            self._check(self.lib.sg_debug_counter(self._h, int(which), ctypes.byref(v), self._stream()))
+        return int(v.value)
+
     def debug_field(self, what):
         """0: raw mask, 1: final mask (float32); 2: power (float64) of the last unit batch,
         as (units, T, F) numpy arrays."""
         dims = (c_int64 * 3)()
         self._check(self.lib.sg_debug_dims(self._h, dims))
         units, T, FS = dims[0], dims[1], dims[2]
+        if what == 4:  # row gate: float32 power tile (4 |X|^2) of pass 1, (units, 64, 528); rows >= T are scratch
+            host = np.empty((units, 64, 528), dtype=np.float32)
+            with torch.cuda.device(self.device):
+                self._check(self.lib.sg_debug_fetch(self._h, 4, host.ctypes.data_as(c_void_p), host.nbytes,
+                                                    self._stream()))
+            return host[:, :T, :self.n_bins]
         if what == 3:  # bit field -> boolean (units, T, F)
             wpr = (self.n_bins + 63) // 64
             words = np.empty((units, T, wpr), dtype=np.uint64)

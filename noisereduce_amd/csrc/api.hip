@@ -25,6 +25,7 @@
 #include "fused.hpp"
 #include "czt.hpp"
 #include "onepass.hpp"
+#include "rowgate.hpp"
 #include "fast512.hpp"
 #include "fast2048.hpp"
 #include "nonstat.hpp"
@@ -96,6 +97,10 @@ struct sg_handle {
   bool force_exact = false;          // SG_OPT_FORCE_EXACT: float64 pipeline (exact.hpp) whatever the output dtype
   DevBuf xP, xraw, xM, xtmp, xseg;   // fields of the exact path
   bool force_split = false;          // SG_OPT_FORCE_SPLIT: decide / smooth / apply as three kernels
+  bool force_norowgate = false;      // SG_OPT_FORCE_NOROWGATE: variant T short rows on the four-kernel path
+  bool rg_tap = false;               // SG_OPT_ROWGATE_TAP: keep the row gate's float32 power tile (stage tap 4)
+  bool dbg_rg = false;               // the last batch ran on the row gate
+  DevBuf rg_count;                   // k_row_gate: number of (row, band) pairs that took the exact path (one counter, never reset)
   bool dbg_xbits = false;            // the last batch's mask bits live in xbits (tile-blocked)
   int64_t dbg_tf0 = 0;               // first frame of tile 0 of that batch
   int dbg_ntt = 0;                   // tiles per unit incl. the two halo tiles
@@ -1063,7 +1068,7 @@ extern "C" int sg_destroy(sg_handle* h) {
                     &h->need, &h->T2, &h->part, &h->tw512, &h->invn, &h->seam, &h->ftab, &h->xbits, &h->xpart,
                     &h->xticket, &h->xtick2, &h->ftab3, &h->xexp, &h->nsp, &h->nsc, &h->xin, &h->czt_tw64, &h->czt_ch64,
                     &h->czt_bh64, &h->czt_tw32, &h->czt_ch32, &h->czt_bh32, &h->logtab, &h->big_twM, &h->big_tw2,
-                    &h->big_ch, &h->big_bh, &h->big_W, &h->big_W2, &h->xP, &h->xraw, &h->xM, &h->xtmp, &h->xseg, &h->invn5, &h->invn20})
+                    &h->big_ch, &h->big_bh, &h->big_W, &h->big_W2, &h->xP, &h->xraw, &h->xM, &h->xtmp, &h->xseg, &h->invn5, &h->invn20, &h->rg_count})
     free_buf(*b);
   delete h;
   return SG_OK;
@@ -2190,6 +2195,87 @@ static int run_S(sg_handle* h, View v, int64_t total_units, const OutMap& om, hi
   return SG_OK;
 }
 
+// TorchGate.forward of whole rows in one kernel (rowgate.hpp): variant T, stationary, statistics from the row itself,
+// default geometry, rows of at most 64 frames (1 s clips at 16 kHz: 63), full reduction, smoothing filter within the
+// kernel's sliding-window limits.
+static bool rowgate_ok(const sg_handle* h, const Geom& g) {
+  return h->fast_ok && !h->force_nofast && !h->force_unfused && !h->force_norowgate && h->p.stationary &&
+         h->p.prop_decrease == 1.0 && h->p.smooth_mask && h->ktot <= 65535 && g.F == 513 && g.T >= 1 &&
+         g.T <= 4 * fast::RG_WAVES && h->p.n_grad_freq >= 1 && h->p.n_grad_freq <= fast::RG_NFMAX &&
+         h->p.n_grad_time >= 1 && h->p.n_grad_time <= fast::RG_NTMAX;
+}
+
+static int stage_row_gate(sg_handle* h, const View& v, const Geom& g, int64_t nb, const OutMap& om, float* mask_out,
+                          hipStream_t st) {
+  int rc;
+  if ((rc = ensure(h, h->bits, (size_t)nb * g.T * 9 * 8))) return rc;
+  if ((rc = ensure_zeroed(h, h->rg_count, 64, st))) return rc;
+  fast::RowGateArgs A;
+  A.view = v; A.g = g; A.om = om;
+  A.win = (const float*)h->wa32.p;
+  A.wsq = (const float*)h->wsq32.p;
+  A.invn = (const float*)h->invn.p;
+  A.tw512 = (const fast::cf*)h->tw512.p;
+  A.tw1024 = (const fast::cf*)h->tw32.p;
+  A.win64 = (const double*)h->wfull64.p;
+  A.tw64 = (const cx<double>*)h->tw64.p;
+  A.mag_scale = h->mag_scale; A.top_db = h->p.top_db; A.n_std = h->p.n_std_thresh; A.ddof = h->p.ddof;
+  A.nf = h->p.n_grad_freq; A.nt = h->p.n_grad_time;
+  A.kscale = (float)(1.0 / ((double)h->ktot * 512.0));
+  A.inv_ktot = 1.0f / (float)h->ktot;
+  A.mask_out = mask_out;
+  A.bits_out = (unsigned long long*)h->bits.p;
+  A.n_exact = (unsigned*)h->rg_count.p;
+  A.ptile_out = nullptr;
+  if (h->rg_tap) {   // SG_OPT_ROWGATE_TAP: float32 powers of pass 1 -> h->M ([rows][64][528] floats), fetched with sg_debug_fetch(4)
+    if ((rc = ensure(h, h->M, (size_t)nb * 64 * fast::RG_PP * 4))) return rc;
+    A.ptile_out = (float*)h->M.p;
+  }
+#if RG_TRACE
+  {
+    // development builds: [rows][16] stamps of the LAST launch, averaged per phase at exit
+    static unsigned long long* tr = nullptr;
+    static size_t tr_rows = 0;
+    if (!tr || tr_rows < (size_t)nb) {
+      HIPCHK(h, hipMalloc((void**)&tr, (size_t)nb * 128));
+      tr_rows = (size_t)nb;
+      static unsigned long long** trp = &tr;
+      static size_t* trn = &tr_rows;
+      static bool reg = false;
+      if (!reg) {
+        reg = true;
+        atexit([] {
+          std::vector<unsigned long long> hst(*trn * 16);
+          if (hipMemcpy(hst.data(), *trp, hst.size() * 8, hipMemcpyDeviceToHost) != hipSuccess) return;
+          double sum[12] = {0};
+          for (size_t i = 0; i < *trn; ++i)
+            for (int k = 1; k < 12; ++k) sum[k] += (double)(hst[i * 16 + k] - hst[i * 16 + k - 1]);
+          {
+            double a = 0, b = 0, c = 0;
+            for (size_t i = 0; i < *trn; ++i) {
+              a += (double)(hst[i * 16 + 12] - hst[i * 16 + 6]); b += (double)(hst[i * 16 + 13] - hst[i * 16 + 12]);
+              c += (double)(hst[i * 16 + 7] - hst[i * 16 + 13]);
+            }
+            fprintf(stderr, "[RG_TRACE] phase 7 of wave 0: zero fill %.0f, tasks %.0f, barrier wait %.0f\n", a / *trn, b / *trn, c / *trn);
+          }
+          fprintf(stderr, "[RG_TRACE] rows %zu; average shader cycles per phase:", *trn);
+          double tot = 0;
+          for (int k = 1; k < 12; ++k) { fprintf(stderr, " %d:%.0f", k, sum[k] / *trn); tot += sum[k] / *trn; }
+          fprintf(stderr, "  sum %.0f\n", tot);
+        });
+      }
+    }
+    A.trace = tr;
+  }
+#endif
+  ProfScope ps(h, SG_STAGE_ROW_GATE, st);
+  const size_t lds = fast::rowgate_lds_bytes();
+  HIPCHK(h, set_lds(reinterpret_cast<const void*>(fast::k_row_gate), lds));
+  hipLaunchKernelGGL(fast::k_row_gate, dim3((unsigned)nb), dim3(fast::RG_THREADS), lds, st, A);
+  HIPCHK(h, hipGetLastError());
+  return SG_OK;
+}
+
 static bool dtype_ok(int d) { return d >= SG_F32 && d <= SG_I32; }
 
 extern "C" int sg_workspace_bytes(const sg_handle* h, int64_t C, int64_t N, int32_t chunked, int64_t* bytes) {
@@ -2365,6 +2451,7 @@ extern "C" int sg_process_batch(sg_handle* h, const void* x_dev, int dtype, int6
     if (Bn != 1 && Bn != B) FAIL(h, SG_E_INVALID, "xn rows (%lld) must be 1 or the batch size", (long long)Bn);
   }
   hipStream_t st = (hipStream_t)stream;
+  h->dbg_rg = false;
   View v{};
   v.x = x_dev; v.dtype = dtype; v.stride = x_stride; v.N = L; v.lo = 0; v.hi = L; v.cs = 0; v.pad = 0; v.Lp = L; v.n_chunks = 1;
   Geom g = make_geom(h, L);
@@ -2401,6 +2488,18 @@ extern "C" int sg_process_batch(sg_handle* h, const void* x_dev, int dtype, int6
         th = thr; ustride = g.FS;
       } else {
         th = nullptr; ustride = g.FS;
+      }
+      if (!xn_dev && rowgate_ok(h, g)) {
+        // one kernel per call: a workgroup per row (rowgate.hpp)
+        v.unit0 = 0;
+        View vr = v;
+        vr.unit0 = u0;
+        if ((rc = stage_row_gate(h, vr, g, nb, om, mask_out_dev ? mask_out_dev + (size_t)u0 * g.T * g.FS : nullptr, st)))
+          return rc;
+        h->dbg_units = nb; h->dbg_T = g.T; h->dbg_has_P = false; h->dbg_fused = true; h->dbg_fast = true;
+        h->dbg_has_raw = false; h->dbg_xbits = false; h->dbg_rg = true;
+        h->dbg_db = 0; h->dbg_de = g.T;
+        continue;
       }
       // default geometry, full reduction: decisions as bits -> exact integer smoothing -> uint16 sums
       // read by the fused apply kernel (same stages as the variant-S fused path)
@@ -2560,6 +2659,8 @@ extern "C" int sg_set_option(sg_handle* h, int32_t option, int64_t value) {
     case SG_OPT_FORCE_SPLIT: h->force_split = value != 0; return SG_OK;
     case SG_OPT_FAST_INTEGER: h->fast_integer = value != 0; return SG_OK;
     case SG_OPT_FORCE_EXACT: h->force_exact = value != 0; return SG_OK;
+    case SG_OPT_FORCE_NOROWGATE: h->force_norowgate = value != 0; return SG_OK;
+    case SG_OPT_ROWGATE_TAP: h->rg_tap = value != 0; return SG_OK;
     case SG_OPT_INJECT_HANDOFF_FAULT: h->inject_fault = (unsigned)value & 63u; return SG_OK;
   }
   FAIL(h, SG_E_INVALID, "sg_set_option: unknown option %d", option);
@@ -2606,7 +2707,8 @@ extern "C" const char* sg_stage_name(int32_t stage) {
                                            "k_stft_bits<max> (floor pre-pass)", "k_stft_bits<decide>",
                                            "k_apply_fast (fft+mask+ifft+ola)",
                                            "k_decide_fast (f32 stft + exact f64 refine)",
-                                           "k_gate_onepass (fft+decide+smooth+mask+ifft+ola)"};
+                                           "k_gate_onepass (fft+decide+smooth+mask+ifft+ola)",
+                                           "k_row_gate (fft+row stats+decide+smooth+mask+ifft+ola)"};
   return (stage >= 0 && stage < SG_N_STAGES) ? names[stage] : "?";
 }
 
@@ -2619,6 +2721,18 @@ extern "C" int sg_debug_dims(const sg_handle* h, int64_t dims[3]) {
 extern "C" int sg_debug_range(const sg_handle* h, int64_t range[2]) {
   if (!h || !range) return SG_E_INVALID;
   range[0] = h->dbg_db; range[1] = h->dbg_de;
+  return SG_OK;
+}
+
+extern "C" int sg_debug_counter(sg_handle* h, int32_t which, int64_t* value, void* stream) {
+  if (!h || !value) return SG_E_INVALID;
+  if (which != 0) FAIL(h, SG_E_INVALID, "sg_debug_counter: unknown counter %d", which);
+  *value = 0;
+  if (!h->rg_count.p) return SG_OK;
+  HIPCHK(h, hipStreamSynchronize((hipStream_t)stream));
+  unsigned v = 0;
+  HIPCHK(h, hipMemcpy(&v, h->rg_count.p, sizeof(v), hipMemcpyDeviceToHost));
+  *value = (int64_t)v;
   return SG_OK;
 }
 
@@ -2644,6 +2758,9 @@ extern "C" int sg_debug_fetch(sg_handle* h, int32_t what, void* host, int64_t by
     case 2:
       if (!h->dbg_has_P) FAIL(h, SG_E_STATE, "power field only exists for stationary gates");
       src = h->P.p; need = cells * 8; break;
+    case 4:
+      if (!h->dbg_rg || !h->rg_tap) FAIL(h, SG_E_STATE, "row-gate power tile: set SG_OPT_ROWGATE_TAP and run TorchGate.forward");
+      src = h->M.p; need = (size_t)h->dbg_units * 64 * fast::RG_PP * 4; break;
     default: FAIL(h, SG_E_INVALID, "sg_debug_fetch: unknown field %d", what);
   }
   if ((size_t)bytes != need) FAIL(h, SG_E_INVALID, "sg_debug_fetch: need %zu bytes, got %lld", need, (long long)bytes);

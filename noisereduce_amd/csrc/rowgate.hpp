@@ -1,0 +1,786 @@
+// TorchGate.forward (variant T, stationary, statistics from the row itself) at the default geometry in ONE kernel:
+// one workgroup = one batch row (clip) of at most 64 frames.
+//
+//   k_power_fast64 (float64 transform of every frame) -> k_row_decide (68 MB of float64 powers re-read)
+//   -> k_smooth_bits2 -> k_apply_fast (forward transform again, K field through HBM)        4 launches, 8.0 x algorithmic
+//     ->  k_row_gate                                                                        1 launch, samples in / out
+//
+// 16 wavefronts, wave w = frames 4w .. 4w+3 (the register FFT of fastpath.hpp).  The float32 spectra of the WHOLE row
+// stay in registers (64 per lane) from the forward transform to the inverse one; everything in between lives in LDS:
+//
+//   1. stage the row's samples, gather + window, forward transform, real-FFT split (once)
+//   2. |2X|^2 (float32) of all 64 x 513 cells -> LDS tile; one thread pair per band walks its column: maximum, then
+//      floored dB values relative to the maximum (torchgate/utils.py:5-23: top_db = 40 under the band's maximum over time),
+//      mean and standard deviation (ddof = 1, torchgate.py:158-160) accumulated in float64, threshold -> compare constant
+//      in the power domain -- together with a BOUND on its error (below)
+//   3. every lane decides its own 33 cells against the band constants; a cell closer to the threshold than the bound
+//      makes its (row, band) AMBIGUOUS
+//   4. ambiguous bands (a few per row) are re-evaluated EXACTLY: the 63 float64 DFT sums of that band (1024 terms each),
+//      float64 statistics with the reference's formulas, float64 compare -- their bits replace the float32 ones
+//   5. exact integer separable triangle smoothing of the bit tile in LDS (the arithmetic of k_smooth_bits2)
+//   6. x mask -> merge -> inverse transform -> window -> overlap-add inside the workgroup -> output.  No tiles, no
+//      hand-offs between workgroups, no tickets: a row is one workgroup.
+//
+// Error bound of step 2 (why float32 is enough).  Measured on this kernel's own transform (tools/rowgate_margin.py,
+// profiles/r04_rowgate_margin.json: 7 signal families, 7 M cells): the float32 |X| is off by 0.0068 (RMS) / 0.047 (max) x
+// 2^-16 ||x w||_2 on noise-like bins, and by <= 3 ulp of |X| itself on the bins of a strong tone.  The kernel assumes
+//   | |2X|_f32 - |2X| |  <=  d_t + RG_REL |2X|,   d_t = 2 * 2^-18 ||x w||_2 (5 x the largest error seen, 37 x RMS),
+//                                                  RG_REL = 2^-21 (8 ulp)
+// In dB a cell is off by at most  e_i = (20 / ln 10) x (1 + 2 x),  x = d_t / |2X_i| + RG_REL  (x <= 1/2; deeper nulls that
+// are not surely floored make the band ambiguous at once); cells surely below the floor contribute -top_db exactly (no
+// error), the band maximum is off by e_M.  Mean and standard deviation are Lipschitz in their inputs:
+//   |d thresh| <= sum(e) / n + |n_std| sqrt(sum(e^2) / (n - ddof))            (worst case: all errors conspire)
+// plus 2e-5 dB for the float32 logarithm / exponential and the effect of the reference's eps = 2.2e-16 inside the
+// logarithm (computed per band; bands whose maximum is below 1e-8 are ambiguous unless the row is digital silence).
+// Sums run in float64, so their own rounding does not count.  Ambiguous: ~0.3 % of the (row, band) pairs of noise + tone.
+#pragma once
+#include "fastpath.hpp"
+#include "fused.hpp"   // funnel_r
+
+namespace sg {
+namespace fast {
+
+constexpr int RG_WAVES = 16;             // 64 frames per row at most
+constexpr int RG_THREADS = RG_WAVES * 64;
+constexpr int RG_NTMAX = 16;             // time half-width of the smoothing filter
+constexpr int RG_NFMAX = 30;             // frequency half-width (128-bit sliding window)
+constexpr int RG_PP = 528;               // float pitch of the power tile: rows 4w+g of a wave land on disjoint bank quarters
+constexpr int RG_WP = 11;                // 64-bit words per bit row: 9 + one zero word on each side
+constexpr int RG_FP = 584;               // uint16 pitch of the count / K tile: column(f) = f + 4 (f / 32)  (smooth2_pitch(513))
+constexpr int RG_ROWS_MAX = 64 + 2 * RG_NTMAX;
+constexpr float RG_REL = 4.7683716e-7f;  // 2^-21: relative part of the float32 transform's error bound
+// LDS map of the exact phase inside the tile region: samples (hop pitch 288) | float64 window | w_1024^j | exact powers
+constexpr int RG_EX_W64 = 77312, RG_EX_TW = RG_EX_W64 + 8192, RG_EX_PW = RG_EX_TW + 8192, RG_EX_BANDS = 64;
+static_assert(67 * 288 * 4 <= RG_EX_W64 && RG_EX_PW + RG_EX_BANDS * 64 * 8 <= RG_WAVES * WAVE_CX_H * 8, "exact-phase LDS map");
+
+#ifndef RG_TRACE
+#define RG_TRACE 0   // development only: per-phase shader-clock stamps (tools/rowgate_trace.sh)
+#endif
+struct RowGateArgs {
+  View view;
+  Geom g;
+  OutMap om;
+  const float* win;          // analysis == synthesis window (1024)
+  const float* wsq;          // window squared (1024)
+  const float* invn;         // 1 / sum_q wsq[256 q + s]
+  const cf* tw512;
+  const cf* tw1024;
+  const double* win64;       // exact path
+  const cx<double>* tw64;    // w_1024^j float64
+  double mag_scale, top_db, n_std;
+  int ddof;
+  int nf, nt;
+  float kscale;              // 1 / (ktot * 512)
+  float inv_ktot;
+  float* mask_out;           // optional [rows][T][FS] float mask (natural bin order) for the backward pass
+  unsigned long long* bits_out;   // optional [rows][T][9] decisions (stage tap)
+  unsigned* n_exact;         // optional counter: (row, band) pairs that took the exact path
+  float* ptile_out;          // optional [rows][64][RG_PP] float32 powers (4x) of pass 1 (stage tap: error-margin measurements)
+#if RG_TRACE
+  unsigned long long* trace; // [rows][16] shader-clock stamps of wave 0 at the phase boundaries (development builds)
+#endif
+};
+
+#if RG_TRACE
+#define RG_STAMP(i) do { if (tid == 0) A.trace[(size_t)blockIdx.x * 16 + (i)] = (unsigned long long)clock64(); } while (0)
+#else
+#define RG_STAMP(i) do { } while (0)
+#endif
+
+__host__ __device__ constexpr size_t rowgate_lds_bytes() {
+  return (size_t)FN * 8 + (size_t)RG_WAVES * WAVE_CX_H * 8 + 1024 * 4 + (size_t)RG_ROWS_MAX * RG_WP * 8 +
+         2 * T2_FLOATS * 4 + 2 * 64 * 4 + 64 * 8 + 520 + 520 * 2 + 64;
+}
+
+// exact float64 |X[f]|^2 (UNSCALED transform, like k_power_fast64's) of frame t of a row: the whole wave cooperates
+__device__ __forceinline__ double rg_exact_power(const RowGateArgs& A, int64_t row, int64_t t, int f, int lane) {
+  const int64_t s0 = t * 256 - A.g.padL;
+  double re = 0.0, im = 0.0;
+#pragma unroll 4
+  for (int i = 0; i < 16; ++i) {
+    const int m = lane + 64 * i;
+    const double xv = view_sample(A.view, row, 0, s0 + m) * A.win64[m];
+    const int j = (f * m) & 1023;
+    cx<double> w = A.tw64[j & 511];
+    if (j >= 512) { w.x = -w.x; w.y = -w.y; }
+    re += xv * w.x;
+    im += xv * w.y;
+  }
+  for (int off = 32; off > 0; off >>= 1) {
+    re += __shfl_xor(re, off);
+    im += __shfl_xor(im, off);
+  }
+  return re * re + im * im;
+}
+
+// Lane 0 of a frame owns the self-paired rows 0 and 16 of the transform (fastpath.hpp): its conjugate pairs sit in other
+// registers than the (s, 31 - s) pairs of lanes 1..15.  Instead of selecting operands per pair (which keeps both the
+// transform's 64 registers and the 64 split values alive: 56 spills at the 128-register budget of a 16-wave workgroup),
+// lane 0 PERMUTES its registers once -- one 24-cycle walked in place with a single temporary -- so that afterwards
+// register index == entry index in every lane (bin_of_entry) and split / merge run in place on (v[s], v[31 - s]):
+//   new[1..7] = old[1..7], new[8..15] = old[16..23], new[16..23] = old[24..31], new[24..30] = old[9..15],
+//   new[31] = old[8] (bin 256), new[0] = old[0] (bins 0 / 512)
+__host__ __device__ constexpr int rg_cyc(int i) {   // position i of the cycle 8 <- 16 <- 24 <- 9 <- 17 <- 25 <- 10 ...
+  return (i % 3 == 0) ? 8 + i / 3 : ((i % 3 == 1) ? 16 + i / 3 : 24 + i / 3);
+}
+__device__ __forceinline__ void rg_lane0_to_entries(cf* v, bool l0) {
+  const cf t = v[rg_cyc(0)];
+#pragma unroll
+  for (int i = 0; i < 23; ++i) {
+    const cf s = v[rg_cyc(i + 1)], d = v[rg_cyc(i)];
+    v[rg_cyc(i)] = {l0 ? s.x : d.x, l0 ? s.y : d.y};
+  }
+  const cf d = v[rg_cyc(23)];
+  v[rg_cyc(23)] = {l0 ? t.x : d.x, l0 ? t.y : d.y};
+}
+__device__ __forceinline__ void rg_lane0_from_entries(cf* v, bool l0) {
+  const cf t = v[rg_cyc(23)];
+#pragma unroll
+  for (int i = 23; i >= 1; --i) {
+    const cf s = v[rg_cyc(i - 1)], d = v[rg_cyc(i)];
+    v[rg_cyc(i)] = {l0 ? s.x : d.x, l0 ? s.y : d.y};
+  }
+  const cf d = v[rg_cyc(0)];
+  v[rg_cyc(0)] = {l0 ? t.x : d.x, l0 ? t.y : d.y};
+}
+
+__global__ __launch_bounds__(RG_THREADS, 1) void k_row_gate(RowGateArgs A) {
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  cf* tw512 = reinterpret_cast<cf*>(smem);
+  cf* regions = tw512 + FN;
+  float* swin = reinterpret_cast<float*>(regions + RG_WAVES * WAVE_CX_H);
+  unsigned long long* wb = reinterpret_cast<unsigned long long*>(swin + 1024);          // bit rows [2 nt + 64][RG_WP]
+  float* s_t2 = reinterpret_cast<float*>(wb + RG_ROWS_MAX * RG_WP);                      // [513] compare constants (4x power)
+  float* s_cb = s_t2 + T2_FLOATS;                                                        // [513] ambiguity widths 4 eta^2 T^2
+  float* s_d2 = s_cb + T2_FLOATS;                                                        // [64] per frame: 2 (2 delta_t)^2
+  float* s_dl = s_d2 + 64;                                                               // [64] per frame: 2 delta_t
+  double* s_ex = reinterpret_cast<double*>(s_dl + 64);                                   // [64] exact powers of one band (slow path)
+  unsigned char* s_flag = reinterpret_cast<unsigned char*>(s_ex + 64);                   // [520] band is ambiguous
+  unsigned short* s_list = reinterpret_cast<unsigned short*>(s_flag + 520);              // [520] compacted
+  unsigned* s_misc = reinterpret_cast<unsigned*>(s_list + 520);                          // [0] list length  [1] row has a sample
+  const Geom& G = A.g;
+  const int tid = threadIdx.x;
+  const int lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);   // (uniform: an SGPR)
+  const int g = lane >> 4, c = lane & 15;
+  const int nt = A.nt, nf = A.nf;
+  const int T = (int)G.T;
+  const int64_t row = A.view.unit0 + blockIdx.x;
+  const int t = 4 * wave + g;                 // this lane group's frame
+  const bool fvalid = t < T;
+  const bool l0 = c == 0;
+  float* tile = reinterpret_cast<float*>(regions);   // power tile [64][RG_PP] (between the transforms)
+  cf* fb = regions + wave * WAVE_CX_H + frame_base_h(g);
+  constexpr int XPITCH = 288;
+  const int span = (T - 1) * 256 + 1024;       // samples covered by the row's frames, from position -padL
+  static_assert((63 * 256 + 1024) / 256 * XPITCH * 4 <= RG_WAVES * WAVE_CX_H * 8, "span must fit the exchange slices");
+
+  // the row's samples -> LDS (hops of 256 samples, pitch 288 floats), zero outside the row
+  auto stage_span = [&](bool note) {
+    float* xs = reinterpret_cast<float*>(regions);
+    const float* sp = (const float*)A.view.x + row * A.view.stride;
+    const bool vec_ok = A.view.dtype == 0 && (reinterpret_cast<uintptr_t>(sp) & 15) == 0 && A.view.lo <= 0 &&
+                        A.view.hi >= A.view.Lp;
+    bool any = false;
+    for (int i4 = tid; i4 < span / 4; i4 += RG_THREADS) {
+      const int e = 4 * i4;
+      const int64_t s = (int64_t)e - G.padL;      // multiple of 4 (padL = 512)
+      float4 q;
+      if (vec_ok && s >= 0 && s + 4 <= A.view.Lp) {
+        q = *reinterpret_cast<const float4*>(sp + s);
+      } else {
+        q.x = (float)view_sample(A.view, row, 0, s);
+        q.y = (float)view_sample(A.view, row, 0, s + 1);
+        q.z = (float)view_sample(A.view, row, 0, s + 2);
+        q.w = (float)view_sample(A.view, row, 0, s + 3);
+      }
+      any = any || q.x != 0.f || q.y != 0.f || q.z != 0.f || q.w != 0.f;
+      *reinterpret_cast<float4*>(&xs[(e >> 8) * XPITCH + (e & 255)]) = q;
+    }
+    if (note && any) s_misc[1] = 1u;     // (benign race: every writer stores 1)  0: digital silence; NaN counts as a sample
+  };
+  // gather (window x frame) -> forward transform -> split in place: v[e] = 2 X[bin_of_entry(c, e)]; lane 0 keeps its two
+  // unpaired registers raw: v[0] = Zc[0] (bins 0 / 512), v[31] = Zc[256] (bin 256).  Returns 2 (2 delta_t)^2.
+  cf wlo, whi;
+  auto forward = [&](cf* v) -> float {
+    // fresh (opaque) lane arithmetic per call: shared between the two passes (CSE), the 32 swizzled exchange addresses
+    // and the gather addresses would stay live -- and be spilled -- across the whole statistics phase
+    int c = lane & 15, zo = 0;
+    asm volatile("" : "+v"(c), "+v"(zo));
+    const bool l0 = c == 0;
+    cf* fb = regions + wave * WAVE_CX_H + frame_base_h(g) + zo;
+    {
+      const float* xs = reinterpret_cast<const float*>(regions) + t * XPITCH + 2 * c + zo;
+      const float2* wl = reinterpret_cast<const float2*>(swin + 2 * c + zo);
+#pragma unroll
+      for (int r = 0; r < 32; ++r) {
+        float2 x2 = *reinterpret_cast<const float2*>(xs + (r >> 3) * XPITCH + 32 * (r & 7));
+        if (!fvalid) x2 = make_float2(0.f, 0.f);
+        const float2 w2 = wl[16 * r];
+        v[r] = {x2.x * w2.x, x2.y * w2.y};
+      }
+    }
+    __syncthreads();   // every lane has its samples: the span may be overwritten by the exchanges
+    float nrm2 = 0.f;
+#pragma unroll
+    for (int r = 0; r < 32; ++r) nrm2 += v[r].x * v[r].x + v[r].y * v[r].y;
+    nrm2 += __shfl_xor(nrm2, 1);
+    nrm2 += __shfl_xor(nrm2, 2);
+    nrm2 += __shfl_xor(nrm2, 4);
+    nrm2 += __shfl_xor(nrm2, 8);
+    fft512_fwd_half(v, fb, tw512 + zo, c);
+    wlo = A.tw1024[c];
+    asm volatile("" : "+v"(wlo.x), "+v"(wlo.y));
+    whi = wlo;
+    {
+      const cf w16 = A.tw1024[16];
+      if (l0) whi = {-w16.y, w16.x};  // i * w_1024^16
+    }
+    rg_lane0_to_entries(v, l0);
+    {
+      const cf r0 = v[0], r31 = v[31];
+      cf xa, xb;
+      split_pair(r0, r31, wlo, xa, xb);
+      v[0] = {l0 ? r0.x : xa.x, l0 ? r0.y : xa.y};
+      v[31] = {l0 ? r31.x : xb.x, l0 ? r31.y : xb.y};
+#pragma unroll
+      for (int sl = 1; sl < 16; ++sl) {
+        const cf w = mul_tw<false>(sl < 8 ? wlo : whi, twc<32>(sl), tws<32>(sl));
+        cf ya, yb;
+        split_pair(v[sl], v[31 - sl], w, ya, yb);
+        v[sl] = ya;
+        v[31 - sl] = yb;
+      }
+    }
+    return 8.0f * 1.4551915e-11f * nrm2;   // 2 (2 delta_t)^2 with delta_t = 2^-18 ||x w||_2 (see RG_REL)
+  };
+
+  // ---- tables, zero-filled bit rows, the row's samples ------------------------------------------------------------------
+  for (int i = tid; i < FN; i += RG_THREADS) tw512[i] = A.tw512[(i >> 4) * (i & 15)];
+  if (tid < 256) reinterpret_cast<float4*>(swin)[tid] = reinterpret_cast<const float4*>(A.win)[tid];
+  for (int i = tid; i < (T + 2 * nt) * RG_WP; i += RG_THREADS) wb[i] = 0ull;
+  if (tid < 520) s_flag[tid] = 0;
+  if (tid == 0) { s_misc[0] = 0u; s_misc[1] = 0u; }
+  __syncthreads();
+  RG_STAMP(0);
+  stage_span(true);
+  __syncthreads();
+  RG_STAMP(1);   // tables + span
+
+  // ---- pass 1: powers (4x) of all cells -> LDS tile --------------------------------------------------------------------
+  {
+    cf v[32];
+    const float d2 = forward(v);
+    float pw[32];
+#pragma unroll
+    for (int e = 0; e < 32; ++e) pw[e] = v[e].x * v[e].x + v[e].y * v[e].y;
+    const float x0 = 2.f * (v[0].x + v[0].y), xN = 2.f * (v[0].x - v[0].y);   // lane 0: 2 X[0], 2 X[512]
+    pw[0] = l0 ? x0 * x0 : pw[0];
+    pw[31] = l0 ? 4.f * pw[31] : pw[31];
+    __syncthreads();   // all forward exchanges done: the slices become the power tile
+    if (fvalid) {
+      float* trow = tile + t * RG_PP;
+#pragma unroll
+      for (int e = 0; e < 32; ++e) trow[bin_of_entry(c, e)] = pw[e];
+      if (l0) {
+        trow[512] = xN * xN;
+        s_d2[t] = d2;
+        s_dl[t] = __builtin_amdgcn_sqrtf(0.5f * d2);
+      }
+    }
+  }
+  __syncthreads();
+  RG_STAMP(2);   // pass 1: gather, forward transform, power tile
+  if (A.ptile_out) {
+    float* po = A.ptile_out + (size_t)blockIdx.x * 64 * RG_PP;
+    for (int i = tid; i < T * RG_PP; i += RG_THREADS) po[i] = tile[i];
+  }
+
+  // ---- band statistics: thread pair (2j, 2j+1) = band j < 512 (frames of equal parity), then band 512 ---------------------
+  {
+  const float kDb = 3.01029995663981195f;      // 10 log10(2)
+  const float E_LOG = 2e-5f;                   // float32 log2 / exp2 evaluation (see header)
+  const float top = (float)A.top_db;
+  const bool has_sample = s_misc[1] != 0u;
+  auto band_stats = [&](int f, int par, int npar) {
+    // pass 1: maximum (NaN-sticky, like torch.max)
+    float M = 0.f, dM = 0.f;
+    for (int tt = par; tt < T; tt += npar) {
+      const float p = tile[tt * RG_PP + f];
+      const bool gt = p > M;
+      dM = gt ? s_dl[tt] : dM;
+      M = (M != M || p != p) ? __uint_as_float(0x7fc00000u) : (gt ? p : M);
+    }
+    if (npar == 2) {
+      const float Mo = __shfl_xor(M, 1), dMo = __shfl_xor(dM, 1);
+      const bool gt = Mo > M;
+      dM = gt ? dMo : dM;
+      M = (M != M || Mo != Mo) ? __uint_as_float(0x7fc00000u) : (gt ? Mo : M);
+    }
+    // amplitude of the maximum and its absolute error
+    const float aM = __builtin_amdgcn_sqrtf(M);
+    const float delM = dM + RG_REL * aM;
+    bool exact = false;
+    float t2 = 3.0e38f, cb = 0.f;              // default: no cell passes (NaN in the band)
+    if (M != M) {
+      // keep the default
+    } else if (!(M < 3.0e38f)) {
+      exact = true;                            // overflow of the float32 power: float64 decides
+    } else if (!(aM * 0.5f * (float)A.mag_scale >= 1e-8f)) {
+      // very quiet band: the reference's eps matters.  Digital silence (every sample 0): all cells equal, `>` is
+      // False everywhere (t2 = 0: P > 0 never holds for P = 0); anything else is left to float64
+      if (has_sample) exact = true;
+      else { t2 = 0.f; cb = 0.f; }
+    } else {
+      const float xM = delM / aM;
+      if (xM > 0.25f) exact = true;
+      const float eM = 8.6858896f * xM * (1.f + 2.f * xM);
+      // the reference's eps inside the logarithm moves an unfloored cell (>= 10^(-top/20) of the maximum) by at most
+      const float E_FIX = E_LOG + 8.6858896f * 2.220446e-16f / (0.0099f * aM * 0.5f * (float)A.mag_scale);
+      // surely floored:  |2X_i| + 2 delta_i < 10^(-top/20) (aM - delM) (1 - 2^-20)
+      const float Famp = __builtin_amdgcn_exp2f(-top * (1.f / 6.0205999f)) * (aM - delM) * 0.999999f;
+      const float rM = 1.0f / M;
+      // pass 2: floored dB relative to the maximum, float64 sums; error sums in float32
+      double S1 = 0.0, S2 = 0.0;
+      float E1 = 0.f, E2 = 0.f;
+      for (int tt = par; tt < T; tt += npar) {
+        const float p = tile[tt * RG_PP + f];
+        const float dl = s_dl[tt];                          // 2 delta_t
+        const float rs = __builtin_amdgcn_rsqf(p);
+        const float a = p * rs;                             // |2X| (p = 0: NaN, handled by the floor test below)
+        float d = kDb * __builtin_amdgcn_logf(p * rM);      // <= 0 (up to rounding)
+        float e = 0.f;
+        if (!(p > 0.f) || fmaf(a, RG_REL, a) + dl < Famp) {
+          d = -top;                                         // surely floored: exact
+        } else {
+          const float x = fmaf(dl, rs, RG_REL);
+          if (x > 0.5f) exact = true;                       // a deep null that may or may not be floored
+          e = 8.6858896f * x * (1.f + 2.f * x) + eM + E_FIX;
+          d = fmaxf(d, -top);
+          d = fminf(d, 0.f);
+        }
+        S1 += (double)d;
+        S2 += (double)d * (double)d;
+        E1 += e;
+        E2 = fmaf(e, e, E2);
+      }
+      if (npar == 2) {
+        S1 += __shfl_xor(S1, 1);
+        S2 += __shfl_xor(S2, 1);
+        E1 += __shfl_xor(E1, 1);
+        E2 += __shfl_xor(E2, 1);
+        exact = exact || (__shfl_xor((int)exact, 1) != 0);
+      }
+      const double Tn = (double)T;
+      const double mean_d = S1 / Tn;
+      double var = (S2 - S1 * S1 / Tn) / (Tn - (double)A.ddof);
+      if (var < 0.0) var = 0.0;
+      const float th = (float)(mean_d + sqrt(var) * A.n_std);            // threshold relative to the maximum, dB
+      const float Eth = E1 / (float)T + fabsf((float)A.n_std) * __builtin_amdgcn_sqrtf(E2 / (float)(T - A.ddof)) + E_FIX;
+      // (the threshold also inherits the maximum's relative error: covered by e_M inside every e)
+      if (-top > th + Eth) {
+        t2 = -3.0e38f;                           // the floor lifts every cell above the threshold: all pass
+      } else if (-top > th - Eth || !(Eth < 1.0f) || !(th == th)) {
+        exact = true;
+      } else {
+        // compare constant in the (4x) power domain: T^2 = M * 2^(th / (10 log10 2)); ambiguity width 4 eta^2 T^2,
+        // eta = Eth ln(10) / 20 (relative error of the amplitude threshold)
+        t2 = M * __builtin_amdgcn_exp2f(th * (1.f / kDb));
+        const float eta = Eth * 0.11512925f + 1.01f * RG_REL;    // + the cell's own relative error near the threshold
+        cb = 4.f * eta * eta * t2;
+      }
+    }
+    if (par == 0) {
+      s_t2[f] = t2;
+      s_cb[f] = cb;
+      if (exact) s_flag[f] = 1;
+    }
+  };
+  band_stats(tid >> 1, tid & 1, 2);
+  if (tid < 64) band_stats(512, 0, 1);         // (the whole first wave runs it; the lanes agree)
+  }
+  __syncthreads();
+  RG_STAMP(3);   // band statistics
+
+  // ---- decisions (float32) from the tile: one wave per (frame, 64-bin word), the ballot IS the word ----------------------
+  //   passes     <=>  P > T                                   (False for a NaN power, like the reference's compare)
+  //   ambiguous  <=>  (P - T)^2 <= (2 d2_t + cb)(P + T)       (implied by | |2X| - T | <= 2 delta_t + eta T)
+  // group q = (word w, third of the rows): the band constants of a lane do not depend on the row
+  {
+    const int rpp = (T + 2) / 3;
+    for (int q = wave; q < 27; q += RG_WAVES) {
+      const int w = q % 9, r0 = (q / 9) * rpp, r1 = min(T, r0 + rpp);
+      const int f = 64 * w + lane;
+      const bool on = f < 513;
+      const float Tv = on ? s_t2[f] : 3.0e38f;
+      const float cbv = on ? s_cb[f] : 0.f;
+      bool ambacc = false;
+#pragma unroll 4
+      for (int r = r0; r < r1; ++r) {
+        const float P = on ? tile[r * RG_PP + f] : 0.f;
+        const float wd = 2.f * s_d2[r] + cbv;
+        const float nd = Tv - P;
+        ambacc = ambacc || (wd > 0.f && nd * nd <= wd * (P + Tv));   // "never" / "always" constants: nd^2 overflows -> false
+        const unsigned long long word = __ballot(on && P > Tv);
+        if (lane == 0) wb[(nt + r) * RG_WP + 1 + w] = word;
+      }
+      if (on && ambacc) s_flag[f] = 1;
+    }
+  }
+  __syncthreads();
+  RG_STAMP(4);   // decisions
+
+  // ---- exact re-evaluation of the ambiguous bands ---------------------------------------------------------------------
+  if (tid < 513 && s_flag[tid]) {
+    const unsigned idx = atomicAdd(&s_misc[0], 1u);
+    s_list[idx] = (unsigned short)tid;
+  }
+  __syncthreads();
+  const int n_amb = (int)s_misc[0];
+  // float32-exact sample types (float32, int16): the samples are staged in LDS and 16 lanes share one (frame, band) sum
+  const bool lds_x = A.view.dtype == 0 || A.view.dtype == 2;
+  if (n_amb > 0) {
+    if (tid == 0 && A.n_exact) atomicAdd(A.n_exact, (unsigned)n_amb);
+    // float64 statistics of one band with the reference's formulas (k_row_decide), lane = frame; patches the bit rows
+    auto band_exact = [&](int f, double Pe, bool on) {
+      const double eps = 2.220446049250313e-16;
+      double m = Pe;
+      for (int off = 32; off > 0; off >>= 1) {
+        const double o = __shfl_xor(m, off);
+        m = (m != m || o != o) ? (double)NAN : fmax(m, o);
+      }
+      const double mdb = cell_db(m, A.mag_scale);
+      double d = 0.0, dsq = 0.0;
+      if (on) {
+        d = cell_db(Pe, A.mag_scale) - mdb;
+        d = (d != d) ? d : fmax(d, -A.top_db);
+        dsq = d * d;
+      }
+      for (int off = 32; off > 0; off >>= 1) {
+        d += __shfl_xor(d, off);
+        dsq += __shfl_xor(dsq, off);
+      }
+      const double Tn = (double)T;
+      double var = (dsq - d * d / Tn) / (Tn - (double)A.ddof);
+      if (var < 0.0) var = 0.0;
+      const double th = (mdb + d / Tn) + sqrt(var) * A.n_std;
+      const double fl = mdb - A.top_db;
+      double t2e;
+      if (th != th || fl != fl) {
+        t2e = 1e300;
+      } else if (fl > th || 20.0 * log10(eps) > th) {
+        t2e = -1.0;
+      } else {
+        const double tm = (exp10(th / 20.0) - eps) / A.mag_scale;
+        t2e = tm > 0.0 ? tm * tm : 0.0;
+      }
+      if (on) {   // (bands that share a 64-bit word may be patched by different waves at once: LDS atomics)
+        unsigned long long* wp = &wb[(nt + lane) * RG_WP + 1 + (f >> 6)];
+        const unsigned long long bit = 1ull << (f & 63);
+        if (Pe > t2e) atomicOr(wp, bit);
+        else atomicAnd(wp, ~bit);
+      }
+    };
+    if (lds_x) {
+      char* rb = reinterpret_cast<char*>(regions);
+      const float* xs = reinterpret_cast<const float*>(rb);
+      double* w64s = reinterpret_cast<double*>(rb + RG_EX_W64);
+      cx<double>* tws = reinterpret_cast<cx<double>*>(rb + RG_EX_TW);
+      double* exb = reinterpret_cast<double*>(rb + RG_EX_PW);
+      stage_span(false);
+      w64s[tid] = A.win64[tid];
+      if (tid < 512) tws[tid] = A.tw64[tid];
+      __syncthreads();
+      const int tq = tid >> 4, p = tid & 15;       // 16 lanes per frame, lane p sums the terms m = p + 16 i
+      const float* xq = xs + tq * 288 + p;
+      const double* wq = w64s + p;
+      for (int k0 = 0; k0 < n_amb; k0 += RG_EX_BANDS) {
+        const int nbk = min(RG_EX_BANDS, n_amb - k0);
+        for (int k = 0; k < nbk; ++k) {
+          const int f = (int)s_list[k0 + k];
+          double re = 0.0, im = 0.0;
+          if (tq < T) {
+            int j = (f * p) & 1023;
+            const int dj = (16 * f) & 1023;
+#pragma unroll 1
+            for (int q = 0; q < 4; ++q) {
+#pragma unroll 4
+              for (int r = 0; r < 16; ++r) {
+                const double xv = (double)xq[q * 288 + 16 * r] * wq[256 * q + 16 * r];
+                cx<double> w = tws[j & 511];
+                if (j & 512) { w.x = -w.x; w.y = -w.y; }
+                re += xv * w.x;
+                im += xv * w.y;
+                j = (j + dj) & 1023;
+              }
+            }
+          }
+          re += __shfl_xor(re, 1); im += __shfl_xor(im, 1);
+          re += __shfl_xor(re, 2); im += __shfl_xor(im, 2);
+          re += __shfl_xor(re, 4); im += __shfl_xor(im, 4);
+          re += __shfl_xor(re, 8); im += __shfl_xor(im, 8);
+          if (p == 0 && tq < T) exb[k * 64 + tq] = re * re + im * im;
+        }
+        __syncthreads();
+        for (int k = wave; k < nbk; k += RG_WAVES) {
+          const bool on = lane < T;
+          band_exact((int)s_list[k0 + k], on ? exb[k * 64 + lane] : 0.0, on);
+        }
+        __syncthreads();
+      }
+    } else {
+      // other sample types (float64, int32: not exact in float32): one wave per (frame, band) sum, samples from memory
+      for (int k = 0; k < n_amb; ++k) {
+        const int f = (int)s_list[k];
+#pragma unroll 1
+        for (int q = 0; q < 4; ++q) {
+          const int tq = 4 * wave + q;
+          if (tq < T) {
+            const double Pe = rg_exact_power(A, row, tq, f, lane);
+            if (lane == 0) s_ex[tq] = Pe;
+          }
+        }
+        __syncthreads();
+        if (wave == 0) {
+          const bool on = lane < T;
+          band_exact(f, on ? s_ex[lane] : 0.0, on);
+        }
+        __syncthreads();
+      }
+    }
+  }
+  if (A.bits_out) {
+    for (int i = tid; i < T * 9; i += RG_THREADS) {
+      const int r = i / 9, w = i - 9 * r;
+      A.bits_out[((int64_t)blockIdx.x * T + r) * 9 + w] = wb[(nt + r) * RG_WP + 1 + w];
+    }
+  }
+
+  RG_STAMP(5);   // exact re-evaluation (+ stage tap)
+  // ---- pass 2: the row's spectra again (they stay in registers from here to the inverse transform) -----------------------
+  if (!(n_amb > 0 && lds_x)) stage_span(false);   // (the exact phase has staged the samples already)
+  __syncthreads();
+  cf v[32];
+  (void)forward(v);
+  __syncthreads();   // all forward exchanges done: the slices become the count / K tile
+  RG_STAMP(6);   // pass 2: span, gather, forward transform, split
+
+  // ---- smoothing, exact integer arithmetic (k_smooth_bits2's): K[t][f] = sum_a sum_b vf[a] vt[b] bit[t+b][f+a] ------------
+  unsigned short* cfp = reinterpret_cast<unsigned short*>(regions);   // [rows + 2][RG_FP] counts along f, then K in place
+  const int rows = T + 2 * nt;
+  for (int i = tid; i < 2 * RG_FP; i += RG_THREADS) cfp[(size_t)rows * RG_FP + i] = 0;
+  // rows outside the spectrogram are zero
+  for (int i = tid; i < 2 * nt * (RG_FP / 4); i += RG_THREADS) {
+    const int r = i / (RG_FP / 4), q = i - r * (RG_FP / 4);
+    reinterpret_cast<unsigned long long*>(cfp + (size_t)(r < nt ? r : T + r) * RG_FP)[q] = 0ull;
+  }
+  RG_STAMP(12);
+  {
+    // one thread = one (frame, 64-bin word): c[f] = sum_a (nf + 1 - |a|) bit[f + a] by the recurrence c += R - L of
+    // k_smooth_bits2 (R / L = set bits in the nf + 1 bins right of / left of and including f).  The three bit streams the
+    // recurrence reads -- bit(f + 1), bit(f + nf + 2), bit(f - nf) -- are the 128-bit window shifted ONCE per task, so
+    // the unrolled loop extracts every bit with one v_bfe at a compile-time position (64-bit shifts are quarter rate).
+    const unsigned long long m1 = (1ull << (nf + 1)) - 1ull;
+    for (int task = tid; task < T * 9; task += RG_THREADS) {
+      const int r = nt + task / 9, w = task % 9;
+      const unsigned long long* rb = wb + (size_t)r * RG_WP + 1 + w;
+      const unsigned long long lo = funnel_r(rb[-1], rb[0], 64 - nf);      // bins 64 w - nf ...
+      const unsigned long long hi = funnel_r(rb[0], rb[1], 64 - nf);       // bins 64 w - nf + 64 ...
+      int cnt = 0;
+      for (int i = 0; i <= 2 * nf; ++i) cnt += (nf + 1 - (i < nf ? nf - i : i - nf)) * (int)((lo >> i) & 1ull);
+      int R = __popcll((lo >> (nf + 1)) & m1);
+      int L = __popcll(lo & m1);
+      const unsigned long long sA = funnel_r(lo, hi, nf + 1);              // bit i = bit(f + 1),      f = 64 w + i
+      const unsigned long long sB = funnel_r(lo, hi, 2 * nf + 2 >= 64 ? 63 : 2 * nf + 2) >> (2 * nf + 2 >= 64 ? 2 * nf + 2 - 63 : 0);
+      // (2 nf + 2 <= 62 for nf <= 30, so the second shift is 0: kept for the general form)
+      const unsigned long long sC = lo;                                     // bit i = bit(f - nf)
+      const unsigned a0 = (unsigned)sA, a1 = (unsigned)(sA >> 32), b0 = (unsigned)sB, b1 = (unsigned)(sB >> 32);
+      const unsigned c0 = (unsigned)sC, c1 = (unsigned)(sC >> 32);
+      unsigned short* out = cfp + (size_t)r * RG_FP + 72 * w;   // column(f) = f + 4 (f / 32)
+      if (w == 8) {                                                         // bin 512 only (+ 3 scratch columns)
+        out[0] = (unsigned short)cnt;
+        continue;
+      }
+      // rolled: 16 groups of 4 bins (the bit positions are scalar); the held spectra leave this loop ~40 registers
+#pragma unroll 1
+      for (int i4 = 0; i4 < 64; i4 += 4) {
+        const unsigned av = i4 & 32 ? a1 : a0, bv = i4 & 32 ? b1 : b0, cv = i4 & 32 ? c1 : c0;
+        unsigned v4[4];
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+          const int i = (i4 & 31) + e;
+          v4[e] = (unsigned)cnt;
+          cnt += R - L;
+          const int bA = (int)((av >> i) & 1u);
+          R += (int)((bv >> i) & 1u) - bA;
+          L += bA - (int)((cv >> i) & 1u);
+        }
+        const unsigned long long pk = (unsigned long long)(v4[0] | (v4[1] << 16)) | ((unsigned long long)(v4[2] | (v4[3] << 16)) << 32);
+        *reinterpret_cast<unsigned long long*>(out + i4 + ((i4 >> 5) << 2)) = pk;
+      }
+    }
+  }
+  RG_STAMP(13);
+  __syncthreads();
+  RG_STAMP(7);   // smoothing along f
+  if (tid < 513) {
+    // along t, one column per thread, IN PLACE: output row i overwrites count row i (dead once it has been read)
+    const int f = tid;
+    unsigned short* col = cfp + f + ((f >> 5) << 2);
+    int cnt = 0, R = 0, L = 0;
+    for (int b = -nt; b <= nt + 1; ++b) {
+      const int x = (int)col[(size_t)(nt + b) * RG_FP];
+      if (b <= nt) cnt += (nt + 1 - (b < 0 ? -b : b)) * x;
+      if (b >= 1) R += x;
+      if (b <= 0) L += x;
+    }
+    const unsigned short* pa2 = col + (size_t)(2 * nt + 2) * RG_FP;
+    const unsigned short* pb2 = col + (size_t)(nt + 1) * RG_FP;
+    unsigned short* pc2 = col;
+#pragma unroll 4
+    for (int i = 0; i < T; ++i) {
+      const int xa = (int)*pa2, xb = (int)*pb2, xc = (int)*pc2;
+      *pc2 = (unsigned short)cnt;
+      pa2 += RG_FP; pb2 += RG_FP; pc2 += RG_FP;
+      cnt += R - L;
+      R += xa - xb;
+      L += xb - xc;
+    }
+  }
+  __syncthreads();
+  RG_STAMP(8);   // smoothing along t
+  if (A.mask_out) {
+    float* mo = A.mask_out + (int64_t)blockIdx.x * T * G.FS;
+    for (int i = tid; i < T * 513; i += RG_THREADS) {
+      const int r = i / 513, f = i - 513 * r;
+      mo[(int64_t)r * G.FS + f] = (float)cfp[(size_t)r * RG_FP + f + ((f >> 5) << 2)] * A.inv_ktot;
+    }
+  }
+
+  // ---- x mask -> merge (second half of pair_mask), in place ------------------------------------------------------------
+  {
+    const unsigned short* krow = cfp + (size_t)(fvalid ? t : 0) * RG_FP;
+    const unsigned short* k_lo = krow + c;                 // lanes c >= 1: entry e < 16 = bin c + 32 e -> column c + 36 e
+    const unsigned short* k_hi = krow + (32 - c);          // entry e >= 16 = bin (32 - c) + 32 (e - 16)
+    auto mval = [&](int q, float scale) -> float {
+      const int b0 = bin_of_entry(0, q);                   // lane 0 (compile-time)
+      const unsigned short kv = c == 0 ? krow[b0 + ((b0 >> 5) << 2)] : (q < 16 ? k_lo[36 * q] : k_hi[36 * (q - 16)]);
+      return (float)kv * scale;
+    };
+    const float k512 = (float)krow[512 + 64] * A.kscale;
+    const float ks = A.kscale * 0.25f;
+    {
+      // slot 0: lanes >= 1 merge the pair (v[0], v[31]); lane 0: bins 0 / 512 from v[0], bin 256 = v[31] scaled
+      const cf r0 = v[0], r31 = v[31];
+      cf xa = r0, xb = r31;
+      merge_pair(xa, xb, wlo, mval(0, ks), mval(31, ks));
+      const float y0 = (r0.x + r0.y) * mval(0, A.kscale);
+      const float yN = (r0.x - r0.y) * k512;
+      const cf z0 = {0.5f * (y0 + yN), 0.5f * (y0 - yN)};
+      const float m8 = mval(31, A.kscale);  // entry 31 of lane 0 = bin 256
+      const cf z8 = {r31.x * m8, r31.y * m8};
+      v[0] = {l0 ? z0.x : xa.x, l0 ? z0.y : xa.y};
+      v[31] = {l0 ? z8.x : xb.x, l0 ? z8.y : xb.y};
+    }
+#pragma unroll
+    for (int sl = 1; sl < 16; ++sl) {
+      const cf w = mul_tw<false>(sl < 8 ? wlo : whi, twc<32>(sl), tws<32>(sl));
+      merge_pair(v[sl], v[31 - sl], w, mval(sl, ks), mval(31 - sl, ks));
+    }
+    rg_lane0_from_entries(v, l0);   // back to the transform's register order
+    if (!fvalid) {
+#pragma unroll
+      for (int i = 0; i < 32; ++i) v[i] = {0.f, 0.f};
+    }
+  }
+  __syncthreads();   // every lane has read its K values: the slices are reused by the inverse transforms
+  RG_STAMP(9);   // mask + merge
+
+  // ---- inverse transform, synthesis window, wave-private overlap-add (k_apply_fast<LEAN>) -------------------------------
+  {
+    int zi = 0, ci = c;
+    asm volatile("" : "+v"(zi), "+v"(ci));
+    fft512_inv_half(v, fb + zi, tw512 + zi, ci);
+  }
+  float* acc = reinterpret_cast<float*>(regions + wave * WAVE_CX_H);
+  {
+    const float2* wsrc2 = reinterpret_cast<const float2*>(swin + 2 * c);
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      const bool first = (j == 0) || (g == 3);
+#pragma unroll
+      for (int rr = 0; rr < 8; ++rr) {
+        const int r = 8 * j + rr;
+        float2* dst = reinterpret_cast<float2*>(acc + (g + j) * HPITCH + 2 * c + 32 * rr);
+        const float2 old = *dst;
+        const float2 ws = wsrc2[16 * r];
+        float2 nw = {v[r].x * ws.x, v[r].y * ws.y};
+        if (!first) { nw.x += old.x; nw.y += old.y; }
+        *dst = nw;
+      }
+      wave_lds_sync();
+    }
+  }
+  const float4 n4 = *reinterpret_cast<const float4*>(&A.invn[(tid & 63) * 4]);
+  __syncthreads();
+  RG_STAMP(10);  // inverse transform, window, wave-private overlap-add
+
+  // ---- cross-wave combine, normalise, store: ext hop jj (256 samples from position 256 jj - padL) -----------------------
+  const float* fr = reinterpret_cast<const float*>(regions);
+  const int s4 = (tid & 63) * 4;
+  const int64_t h_begin = (A.om.p0 + G.padL) / 256, h_end = (A.om.p1 - 1 + G.padL) / 256 + 1;
+  for (int jj = (int)h_begin + wave; jj < (int)h_end && jj < 4 * RG_WAVES + 3; jj += RG_WAVES) {
+    float4 a4 = make_float4(0.f, 0.f, 0.f, 0.f);
+    const int wh = jj >> 2, lh = jj & 3;
+    if (wh >= 1 && lh <= 2) a4 = *reinterpret_cast<const float4*>(&fr[(wh - 1) * WAVE_CX_H * 2 + (lh + 4) * HPITCH + s4]);
+    if (wh < RG_WAVES) {
+      const float4 f4 = *reinterpret_cast<const float4*>(&fr[wh * WAVE_CX_H * 2 + lh * HPITCH + s4]);
+      a4.x += f4.x; a4.y += f4.y; a4.z += f4.z; a4.w += f4.w;
+    }
+    bool all_valid = true;
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+      const int ti = jj - q;
+      if (ti < 0 || ti >= T) all_valid = false;
+    }
+    if (all_valid) {
+      a4.x *= n4.x; a4.y *= n4.y; a4.z *= n4.z; a4.w *= n4.w;
+    } else {
+      float4 nrm = make_float4(0.f, 0.f, 0.f, 0.f);
+#pragma unroll
+      for (int q = 0; q < 4; ++q) {
+        const int ti = jj - q;
+        if (ti >= 0 && ti < T) {
+          const float4 w4 = *reinterpret_cast<const float4*>(&A.wsq[256 * q + s4]);
+          nrm.x += w4.x; nrm.y += w4.y; nrm.z += w4.z; nrm.w += w4.w;
+        }
+      }
+      a4.x /= (nrm.x > 1e-10f ? nrm.x : 1.f);
+      a4.y /= (nrm.y > 1e-10f ? nrm.y : 1.f);
+      a4.z /= (nrm.z > 1e-10f ? nrm.z : 1.f);
+      a4.w /= (nrm.w > 1e-10f ? nrm.w : 1.f);
+    }
+    const int64_t pbs = (int64_t)jj * 256 - G.padL;
+    const int64_t gi0 = pbs - A.om.p0;
+    if (A.om.dtype == 0 && pbs >= A.om.p0 && pbs + 256 <= A.om.p1 && pbs + 256 <= G.Lout && gi0 >= A.om.g_lo &&
+        gi0 + 256 <= A.om.g_hi) {
+      float* dst = (float*)A.om.out + (row * A.om.stride + gi0 - A.om.g0 + s4);
+      if ((reinterpret_cast<uintptr_t>(dst) & 15) == 0) {
+        *reinterpret_cast<float4*>(dst) = a4;
+        continue;
+      }
+    }
+    const float vals[4] = {a4.x, a4.y, a4.z, a4.w};
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {
+      const int64_t p = (int64_t)jj * 256 + s4 + e - G.padL;
+      if (p < A.om.p0 || p >= A.om.p1) continue;
+      const int64_t gi = p - A.om.p0;
+      if (gi < A.om.g_lo || gi >= A.om.g_hi) continue;
+      store_sample(A.om.out, A.om.dtype, row * A.om.stride + gi - A.om.g0, p < G.Lout ? vals[e] : 0.f);
+    }
+  }
+  RG_STAMP(11);  // combine, normalise, store
+}
+
+}  // namespace fast
+}  // namespace sg
