@@ -207,6 +207,8 @@ SG_API int sg_debug_fetch(sg_handle* h, int32_t what, void* host, int64_t bytes,
                                    * frame, k_row_decide, k_smooth_bits2, k_apply_fast) instead of the one-kernel row gate */
 #define SG_OPT_ROWGATE_TAP 11     /* value != 0: the row gate also writes its float32 power tile (4 |X|^2, [rows][64][528]) for
                                    * sg_debug_fetch(what = 4): measurements behind the decision margin */
+#define SG_OPT_ROWGATE_SHAPE 12   /* value = 16 (default) or 8: wavefronts per workgroup of the row gate (16 x one quad of frames at 128
+                                   * VGPRs, or 8 x two quads at 256 VGPRs without scratch): A/B measurements */
 #define SG_OPT_FORCE_NOFAST 2  /* value != 0: keep the bit-mask stages but use the general apply kernels */
 SG_API int sg_set_option(sg_handle* h, int32_t option, int64_t value);
 

@@ -30,6 +30,7 @@ SG_OPT_FAST_INTEGER = 8
 SG_OPT_FORCE_EXACT = 9
 SG_OPT_FORCE_NOROWGATE = 10
 SG_OPT_ROWGATE_TAP = 11
+SG_OPT_ROWGATE_SHAPE = 12
 SG_OPT_FORCE_UNFUSED = 1
 SG_OPT_FORCE_NOFAST = 2
 

@@ -98,6 +98,7 @@ struct sg_handle {
   DevBuf xP, xraw, xM, xtmp, xseg;   // fields of the exact path
   bool force_split = false;          // SG_OPT_FORCE_SPLIT: decide / smooth / apply as three kernels
   bool force_norowgate = false;      // SG_OPT_FORCE_NOROWGATE: variant T short rows on the four-kernel path
+  int rg_shape = 16;                 // SG_OPT_ROWGATE_SHAPE: waves per workgroup of the row gate (16 x 1 quad, or 8 x 2 quads)
   bool rg_tap = false;               // SG_OPT_ROWGATE_TAP: keep the row gate's float32 power tile (stage tap 4)
   bool dbg_rg = false;               // the last batch ran on the row gate
   DevBuf rg_count;                   // k_row_gate: number of (row, band) pairs that took the exact path (one counter, never reset)
@@ -2201,7 +2202,7 @@ static int run_S(sg_handle* h, View v, int64_t total_units, const OutMap& om, hi
 static bool rowgate_ok(const sg_handle* h, const Geom& g) {
   return h->fast_ok && !h->force_nofast && !h->force_unfused && !h->force_norowgate && h->p.stationary &&
          h->p.prop_decrease == 1.0 && h->p.smooth_mask && h->ktot <= 65535 && g.F == 513 && g.T >= 1 &&
-         g.T <= 4 * fast::RG_WAVES && h->p.n_grad_freq >= 1 && h->p.n_grad_freq <= fast::RG_NFMAX &&
+         g.T <= fast::RG_FRAMES && h->p.n_grad_freq >= 1 && h->p.n_grad_freq <= fast::RG_NFMAX &&
          h->p.n_grad_time >= 1 && h->p.n_grad_time <= fast::RG_NTMAX;
 }
 
@@ -2251,12 +2252,13 @@ static int stage_row_gate(sg_handle* h, const View& v, const Geom& g, int64_t nb
           for (size_t i = 0; i < *trn; ++i)
             for (int k = 1; k < 12; ++k) sum[k] += (double)(hst[i * 16 + k] - hst[i * 16 + k - 1]);
           {
-            double a = 0, b = 0, c = 0;
+            double a = 0, b = 0, c = 0, d = 0;
             for (size_t i = 0; i < *trn; ++i) {
-              a += (double)(hst[i * 16 + 12] - hst[i * 16 + 6]); b += (double)(hst[i * 16 + 13] - hst[i * 16 + 12]);
+              d += (double)(hst[i * 16 + 14] - hst[i * 16 + 6]);
+              a += (double)(hst[i * 16 + 12] - hst[i * 16 + 14]); b += (double)(hst[i * 16 + 13] - hst[i * 16 + 12]);
               c += (double)(hst[i * 16 + 7] - hst[i * 16 + 13]);
             }
-            fprintf(stderr, "[RG_TRACE] phase 7 of wave 0: zero fill %.0f, tasks %.0f, barrier wait %.0f\n", a / *trn, b / *trn, c / *trn);
+            fprintf(stderr, "[RG_TRACE] phase 7 of wave 0: after barrier %.0f, zero fill %.0f, tasks %.0f, barrier wait %.0f\n", d / *trn, a / *trn, b / *trn, c / *trn);
           }
           fprintf(stderr, "[RG_TRACE] rows %zu; average shader cycles per phase:", *trn);
           double tot = 0;
@@ -2270,8 +2272,13 @@ static int stage_row_gate(sg_handle* h, const View& v, const Geom& g, int64_t nb
 #endif
   ProfScope ps(h, SG_STAGE_ROW_GATE, st);
   const size_t lds = fast::rowgate_lds_bytes();
-  HIPCHK(h, set_lds(reinterpret_cast<const void*>(fast::k_row_gate), lds));
-  hipLaunchKernelGGL(fast::k_row_gate, dim3((unsigned)nb), dim3(fast::RG_THREADS), lds, st, A);
+  if (h->rg_shape == 8) {     // SG_OPT_ROWGATE_SHAPE: 8 waves x 2 quads (256 VGPRs, no scratch)
+    HIPCHK(h, set_lds(reinterpret_cast<const void*>(fast::k_row_gate<8, 2>), lds));
+    hipLaunchKernelGGL((fast::k_row_gate<8, 2>), dim3((unsigned)nb), dim3(512), lds, st, A);
+  } else {                    // default: 16 waves x 1 quad
+    HIPCHK(h, set_lds(reinterpret_cast<const void*>(fast::k_row_gate<16, 1>), lds));
+    hipLaunchKernelGGL((fast::k_row_gate<16, 1>), dim3((unsigned)nb), dim3(1024), lds, st, A);
+  }
   HIPCHK(h, hipGetLastError());
   return SG_OK;
 }
@@ -2661,6 +2668,10 @@ extern "C" int sg_set_option(sg_handle* h, int32_t option, int64_t value) {
     case SG_OPT_FORCE_EXACT: h->force_exact = value != 0; return SG_OK;
     case SG_OPT_FORCE_NOROWGATE: h->force_norowgate = value != 0; return SG_OK;
     case SG_OPT_ROWGATE_TAP: h->rg_tap = value != 0; return SG_OK;
+    case SG_OPT_ROWGATE_SHAPE:
+      if (value != 8 && value != 16) FAIL(h, SG_E_INVALID, "SG_OPT_ROWGATE_SHAPE: 8 or 16 waves");
+      h->rg_shape = (int)value;
+      return SG_OK;
     case SG_OPT_INJECT_HANDOFF_FAULT: h->inject_fault = (unsigned)value & 63u; return SG_OK;
   }
   FAIL(h, SG_E_INVALID, "sg_set_option: unknown option %d", option);

@@ -40,8 +40,12 @@
 namespace sg {
 namespace fast {
 
-constexpr int RG_WAVES = 16;             // 64 frames per row at most
-constexpr int RG_THREADS = RG_WAVES * 64;
+// Two shapes of the workgroup (template parameters WAVES x QUADS, 64 frames per row at most either way):
+//   16 x 1: every wave transforms one quad of frames; 4 waves per SIMD, 128 VGPRs (the compiler spills ~30 around the
+//           transforms), the exchange slices alias the staged samples;
+//    8 x 2: every wave transforms two quads one after the other; 2 waves per SIMD, 256 VGPRs, no scratch, the slices sit
+//           behind the samples.  Measured on 256 x 16000: 16 x 1 is the faster one (tools/rowgate_scale.py).
+constexpr int RG_FRAMES = 64;
 constexpr int RG_NTMAX = 16;             // time half-width of the smoothing filter
 constexpr int RG_NFMAX = 30;             // frequency half-width (128-bit sliding window)
 constexpr int RG_PP = 528;               // float pitch of the power tile: rows 4w+g of a wave land on disjoint bank quarters
@@ -49,9 +53,15 @@ constexpr int RG_WP = 11;                // 64-bit words per bit row: 9 + one ze
 constexpr int RG_FP = 584;               // uint16 pitch of the count / K tile: column(f) = f + 4 (f / 32)  (smooth2_pitch(513))
 constexpr int RG_ROWS_MAX = 64 + 2 * RG_NTMAX;
 constexpr float RG_REL = 4.7683716e-7f;  // 2^-21: relative part of the float32 transform's error bound
-// LDS map of the exact phase inside the tile region: samples (hop pitch 288) | float64 window | w_1024^j | exact powers
-constexpr int RG_EX_W64 = 77312, RG_EX_TW = RG_EX_W64 + 8192, RG_EX_PW = RG_EX_TW + 8192, RG_EX_BANDS = 64;
-static_assert(67 * 288 * 4 <= RG_EX_W64 && RG_EX_PW + RG_EX_BANDS * 64 * 8 <= RG_WAVES * WAVE_CX_H * 8, "exact-phase LDS map");
+// The tile region (RG_REGION bytes) over time: samples (67 hops of 256) + exchange slices behind them | power tile |
+// samples + float64 window + w_1024^j + exact powers | samples + slices | count / K tile | slices + hop accumulators
+constexpr int RG_REGION = 16 * WAVE_CX_H * 8;          // 139264
+constexpr int RG_SPAN_BYTES = 67 * 256 * 4;            // 68608: hop pitch 256 (8 x 2: the slices must fit behind the samples)
+constexpr int RG_SPAN_BYTES_P = 67 * 288 * 4;          // 77184: hop pitch 288 (16 x 1: conflict-free gather, see k_apply_fast)
+__host__ __device__ constexpr int rg_slices(int waves) { return RG_REGION - waves * WAVE_CX_H * 8; }   // the slices sit at the END of the region
+constexpr int RG_EX_W64 = 77312, RG_EX_TW = RG_EX_W64 + 8192, RG_EX_PW = RG_EX_TW + 16384, RG_EX_BANDS = 64;
+static_assert(RG_SPAN_BYTES <= rg_slices(8) && RG_SPAN_BYTES_P <= RG_EX_W64 && RG_EX_PW + RG_EX_BANDS * 64 * 8 <= RG_REGION,
+              "tile-region LDS map");
 
 #ifndef RG_TRACE
 #define RG_TRACE 0   // development only: per-phase shader-clock stamps (tools/rowgate_trace.sh)
@@ -88,7 +98,7 @@ struct RowGateArgs {
 #endif
 
 __host__ __device__ constexpr size_t rowgate_lds_bytes() {
-  return (size_t)FN * 8 + (size_t)RG_WAVES * WAVE_CX_H * 8 + 1024 * 4 + (size_t)RG_ROWS_MAX * RG_WP * 8 +
+  return (size_t)FN * 8 + (size_t)RG_REGION + 1024 * 4 + (size_t)RG_ROWS_MAX * RG_WP * 8 +
          2 * T2_FLOATS * 4 + 2 * 64 * 4 + 64 * 8 + 520 + 520 * 2 + 64;
 }
 
@@ -144,11 +154,17 @@ __device__ __forceinline__ void rg_lane0_from_entries(cf* v, bool l0) {
   v[rg_cyc(0)] = {l0 ? t.x : d.x, l0 ? t.y : d.y};
 }
 
-__global__ __launch_bounds__(RG_THREADS, 1) void k_row_gate(RowGateArgs A) {
+template <int RG_WAVES, int RG_QUADS>
+__global__ __launch_bounds__(RG_WAVES * 64, 1) void k_row_gate(RowGateArgs A) {
+  static_assert(RG_WAVES * RG_QUADS * 4 == RG_FRAMES, "64 frames per row");
+  constexpr int RG_THREADS = RG_WAVES * 64;
+  constexpr int RG_SLICES = rg_slices(RG_WAVES);
+  constexpr bool ALIASED = RG_SLICES < RG_SPAN_BYTES;    // (16 x 1) the exchanges overwrite the staged samples
+  constexpr int XP = ALIASED ? 288 : 256;                // floats between hops of the staged samples
   extern __shared__ __attribute__((aligned(16))) char smem[];
   cf* tw512 = reinterpret_cast<cf*>(smem);
-  cf* regions = tw512 + FN;
-  float* swin = reinterpret_cast<float*>(regions + RG_WAVES * WAVE_CX_H);
+  char* region = reinterpret_cast<char*>(tw512 + FN);
+  float* swin = reinterpret_cast<float*>(region + RG_REGION);
   unsigned long long* wb = reinterpret_cast<unsigned long long*>(swin + 1024);          // bit rows [2 nt + 64][RG_WP]
   float* s_t2 = reinterpret_cast<float*>(wb + RG_ROWS_MAX * RG_WP);                      // [513] compare constants (4x power)
   float* s_cb = s_t2 + T2_FLOATS;                                                        // [513] ambiguity widths 4 eta^2 T^2
@@ -165,18 +181,16 @@ __global__ __launch_bounds__(RG_THREADS, 1) void k_row_gate(RowGateArgs A) {
   const int nt = A.nt, nf = A.nf;
   const int T = (int)G.T;
   const int64_t row = A.view.unit0 + blockIdx.x;
-  const int t = 4 * wave + g;                 // this lane group's frame
-  const bool fvalid = t < T;
   const bool l0 = c == 0;
-  float* tile = reinterpret_cast<float*>(regions);   // power tile [64][RG_PP] (between the transforms)
-  cf* fb = regions + wave * WAVE_CX_H + frame_base_h(g);
-  constexpr int XPITCH = 288;
+  float* tile = reinterpret_cast<float*>(region);                    // power tile [64][RG_PP] (between the transforms)
+  float* xs = reinterpret_cast<float*>(region);                      // the row's samples: hop h at xs + 256 h
+  cf* slices = reinterpret_cast<cf*>(region + RG_SLICES);            // 8 exchange slices, behind the samples
   const int span = (T - 1) * 256 + 1024;       // samples covered by the row's frames, from position -padL
-  static_assert((63 * 256 + 1024) / 256 * XPITCH * 4 <= RG_WAVES * WAVE_CX_H * 8, "span must fit the exchange slices");
+  // frame of this lane group in quad q: wave w transforms frames 4 (w + 8 q) .. + 3
+  auto frame_of = [&](int q) { return 4 * (wave + RG_WAVES * q) + g; };
 
-  // the row's samples -> LDS (hops of 256 samples, pitch 288 floats), zero outside the row
+  // the row's samples -> LDS, zero outside the row
   auto stage_span = [&](bool note) {
-    float* xs = reinterpret_cast<float*>(regions);
     const float* sp = (const float*)A.view.x + row * A.view.stride;
     const bool vec_ok = A.view.dtype == 0 && (reinterpret_cast<uintptr_t>(sp) & 15) == 0 && A.view.lo <= 0 &&
                         A.view.hi >= A.view.Lp;
@@ -194,32 +208,34 @@ __global__ __launch_bounds__(RG_THREADS, 1) void k_row_gate(RowGateArgs A) {
         q.w = (float)view_sample(A.view, row, 0, s + 3);
       }
       any = any || q.x != 0.f || q.y != 0.f || q.z != 0.f || q.w != 0.f;
-      *reinterpret_cast<float4*>(&xs[(e >> 8) * XPITCH + (e & 255)]) = q;
+      *reinterpret_cast<float4*>(&xs[(e >> 8) * XP + (e & 255)]) = q;
     }
     if (note && any) s_misc[1] = 1u;     // (benign race: every writer stores 1)  0: digital silence; NaN counts as a sample
   };
-  // gather (window x frame) -> forward transform -> split in place: v[e] = 2 X[bin_of_entry(c, e)]; lane 0 keeps its two
+  // gather (window x frame t) -> forward transform -> split in place: v[e] = 2 X[bin_of_entry(c, e)]; lane 0 keeps its two
   // unpaired registers raw: v[0] = Zc[0] (bins 0 / 512), v[31] = Zc[256] (bin 256).  Returns 2 (2 delta_t)^2.
+  // The exchange slices lie behind the samples, so the transforms of one quad do not disturb the gather of the other.
   cf wlo, whi;
-  auto forward = [&](cf* v) -> float {
-    // fresh (opaque) lane arithmetic per call: shared between the two passes (CSE), the 32 swizzled exchange addresses
-    // and the gather addresses would stay live -- and be spilled -- across the whole statistics phase
+  auto forward = [&](cf* v, int t) -> float {
+    // fresh (opaque) lane arithmetic per call: shared between the calls (CSE), the 32 swizzled exchange addresses and the
+    // gather addresses would stay live across everything in between
     int c = lane & 15, zo = 0;
     asm volatile("" : "+v"(c), "+v"(zo));
     const bool l0 = c == 0;
-    cf* fb = regions + wave * WAVE_CX_H + frame_base_h(g) + zo;
+    const bool fvalid = t < T;
+    cf* fb = slices + wave * WAVE_CX_H + frame_base_h(g) + zo;
     {
-      const float* xs = reinterpret_cast<const float*>(regions) + t * XPITCH + 2 * c + zo;
+      const float* xp = xs + t * XP + 2 * c + zo;
       const float2* wl = reinterpret_cast<const float2*>(swin + 2 * c + zo);
 #pragma unroll
       for (int r = 0; r < 32; ++r) {
-        float2 x2 = *reinterpret_cast<const float2*>(xs + (r >> 3) * XPITCH + 32 * (r & 7));
+        float2 x2 = *reinterpret_cast<const float2*>(xp + (r >> 3) * XP + 32 * (r & 7));
         if (!fvalid) x2 = make_float2(0.f, 0.f);
         const float2 w2 = wl[16 * r];
         v[r] = {x2.x * w2.x, x2.y * w2.y};
       }
     }
-    __syncthreads();   // every lane has its samples: the span may be overwritten by the exchanges
+    if constexpr (ALIASED) __syncthreads();   // every lane has its samples: the exchanges may overwrite them
     float nrm2 = 0.f;
 #pragma unroll
     for (int r = 0; r < 32; ++r) nrm2 += v[r].x * v[r].x + v[r].y * v[r].y;
@@ -258,7 +274,7 @@ __global__ __launch_bounds__(RG_THREADS, 1) void k_row_gate(RowGateArgs A) {
   for (int i = tid; i < FN; i += RG_THREADS) tw512[i] = A.tw512[(i >> 4) * (i & 15)];
   if (tid < 256) reinterpret_cast<float4*>(swin)[tid] = reinterpret_cast<const float4*>(A.win)[tid];
   for (int i = tid; i < (T + 2 * nt) * RG_WP; i += RG_THREADS) wb[i] = 0ull;
-  if (tid < 520) s_flag[tid] = 0;
+  for (int i = tid; i < 520; i += RG_THREADS) s_flag[i] = 0;
   if (tid == 0) { s_misc[0] = 0u; s_misc[1] = 0u; }
   __syncthreads();
   RG_STAMP(0);
@@ -268,23 +284,38 @@ __global__ __launch_bounds__(RG_THREADS, 1) void k_row_gate(RowGateArgs A) {
 
   // ---- pass 1: powers (4x) of all cells -> LDS tile --------------------------------------------------------------------
   {
-    cf v[32];
-    const float d2 = forward(v);
-    float pw[32];
+    float pw[RG_QUADS][32], p512[RG_QUADS], d2q[RG_QUADS];
 #pragma unroll
-    for (int e = 0; e < 32; ++e) pw[e] = v[e].x * v[e].x + v[e].y * v[e].y;
-    const float x0 = 2.f * (v[0].x + v[0].y), xN = 2.f * (v[0].x - v[0].y);   // lane 0: 2 X[0], 2 X[512]
-    pw[0] = l0 ? x0 * x0 : pw[0];
-    pw[31] = l0 ? 4.f * pw[31] : pw[31];
-    __syncthreads();   // all forward exchanges done: the slices become the power tile
-    if (fvalid) {
-      float* trow = tile + t * RG_PP;
+    for (int q = 0; q < RG_QUADS; ++q) {
+      cf v[32];
+      d2q[q] = forward(v, frame_of(q));
 #pragma unroll
-      for (int e = 0; e < 32; ++e) trow[bin_of_entry(c, e)] = pw[e];
-      if (l0) {
-        trow[512] = xN * xN;
-        s_d2[t] = d2;
-        s_dl[t] = __builtin_amdgcn_sqrtf(0.5f * d2);
+      for (int e = 0; e < 32; ++e) pw[q][e] = v[e].x * v[e].x + v[e].y * v[e].y;
+      const float x0 = 2.f * (v[0].x + v[0].y), xN = 2.f * (v[0].x - v[0].y);   // lane 0: 2 X[0], 2 X[512]
+      pw[q][0] = l0 ? x0 * x0 : pw[q][0];
+      pw[q][31] = l0 ? 4.f * pw[q][31] : pw[q][31];
+      p512[q] = xN * xN;
+    }
+    __syncthreads();   // all gathers and forward exchanges done: samples and slices become the power tile
+    // tile columns of this lane's entries: lanes c >= 1: entry e < 16 = bin c + 32 e, entry e >= 16 = bin (32 - c) + 32 (e - 16)
+#pragma unroll
+    for (int q = 0; q < RG_QUADS; ++q) {
+      const int t = frame_of(q);
+      if (t < T) {
+        float* trow = tile + t * RG_PP;
+        float* t_lo = trow + c;
+        float* t_hi = trow + (32 - c);
+#pragma unroll
+        for (int e = 0; e < 32; ++e) {
+          const int b0 = bin_of_entry(0, e);   // lane 0 (compile-time)
+          float* dst = l0 ? trow + b0 : (e < 16 ? t_lo + 32 * e : t_hi + 32 * (e - 16));
+          *dst = pw[q][e];
+        }
+        if (l0) {
+          trow[512] = p512[q];
+          s_d2[t] = d2q[q];
+          s_dl[t] = __builtin_amdgcn_sqrtf(0.5f * d2q[q]);
+        }
       }
     }
   }
@@ -295,22 +326,23 @@ __global__ __launch_bounds__(RG_THREADS, 1) void k_row_gate(RowGateArgs A) {
     for (int i = tid; i < T * RG_PP; i += RG_THREADS) po[i] = tile[i];
   }
 
-  // ---- band statistics: thread pair (2j, 2j+1) = band j < 512 (frames of equal parity), then band 512 ---------------------
+  // ---- band statistics: thread pair (2j, 2j+1) = band j (frames of equal parity), 256 bands per round ---------------------
   {
   const float kDb = 3.01029995663981195f;      // 10 log10(2)
   const float E_LOG = 2e-5f;                   // float32 log2 / exp2 evaluation (see header)
   const float top = (float)A.top_db;
   const bool has_sample = s_misc[1] != 0u;
-  auto band_stats = [&](int f, int par, int npar) {
+  const int par = tid & 1;
+  for (int f = tid >> 1; f < 513; f += RG_THREADS / 2) {
     // pass 1: maximum (NaN-sticky, like torch.max)
     float M = 0.f, dM = 0.f;
-    for (int tt = par; tt < T; tt += npar) {
+    for (int tt = par; tt < T; tt += 2) {
       const float p = tile[tt * RG_PP + f];
       const bool gt = p > M;
       dM = gt ? s_dl[tt] : dM;
       M = (M != M || p != p) ? __uint_as_float(0x7fc00000u) : (gt ? p : M);
     }
-    if (npar == 2) {
+    {
       const float Mo = __shfl_xor(M, 1), dMo = __shfl_xor(dM, 1);
       const bool gt = Mo > M;
       dM = gt ? dMo : dM;
@@ -336,13 +368,13 @@ __global__ __launch_bounds__(RG_THREADS, 1) void k_row_gate(RowGateArgs A) {
       const float eM = 8.6858896f * xM * (1.f + 2.f * xM);
       // the reference's eps inside the logarithm moves an unfloored cell (>= 10^(-top/20) of the maximum) by at most
       const float E_FIX = E_LOG + 8.6858896f * 2.220446e-16f / (0.0099f * aM * 0.5f * (float)A.mag_scale);
-      // surely floored:  |2X_i| + 2 delta_i < 10^(-top/20) (aM - delM) (1 - 2^-20)
+      // surely floored:  |2X_i| (1 + rel) + 2 delta_i < 10^(-top/20) (aM - delM) (1 - 2^-20)
       const float Famp = __builtin_amdgcn_exp2f(-top * (1.f / 6.0205999f)) * (aM - delM) * 0.999999f;
       const float rM = 1.0f / M;
       // pass 2: floored dB relative to the maximum, float64 sums; error sums in float32
       double S1 = 0.0, S2 = 0.0;
       float E1 = 0.f, E2 = 0.f;
-      for (int tt = par; tt < T; tt += npar) {
+      for (int tt = par; tt < T; tt += 2) {
         const float p = tile[tt * RG_PP + f];
         const float dl = s_dl[tt];                          // 2 delta_t
         const float rs = __builtin_amdgcn_rsqf(p);
@@ -363,29 +395,26 @@ __global__ __launch_bounds__(RG_THREADS, 1) void k_row_gate(RowGateArgs A) {
         E1 += e;
         E2 = fmaf(e, e, E2);
       }
-      if (npar == 2) {
-        S1 += __shfl_xor(S1, 1);
-        S2 += __shfl_xor(S2, 1);
-        E1 += __shfl_xor(E1, 1);
-        E2 += __shfl_xor(E2, 1);
-        exact = exact || (__shfl_xor((int)exact, 1) != 0);
-      }
+      S1 += __shfl_xor(S1, 1);
+      S2 += __shfl_xor(S2, 1);
+      E1 += __shfl_xor(E1, 1);
+      E2 += __shfl_xor(E2, 1);
+      exact = exact || (__shfl_xor((int)exact, 1) != 0);
       const double Tn = (double)T;
       const double mean_d = S1 / Tn;
       double var = (S2 - S1 * S1 / Tn) / (Tn - (double)A.ddof);
       if (var < 0.0) var = 0.0;
       const float th = (float)(mean_d + sqrt(var) * A.n_std);            // threshold relative to the maximum, dB
       const float Eth = E1 / (float)T + fabsf((float)A.n_std) * __builtin_amdgcn_sqrtf(E2 / (float)(T - A.ddof)) + E_FIX;
-      // (the threshold also inherits the maximum's relative error: covered by e_M inside every e)
       if (-top > th + Eth) {
         t2 = -3.0e38f;                           // the floor lifts every cell above the threshold: all pass
       } else if (-top > th - Eth || !(Eth < 1.0f) || !(th == th)) {
         exact = true;
       } else {
         // compare constant in the (4x) power domain: T^2 = M * 2^(th / (10 log10 2)); ambiguity width 4 eta^2 T^2,
-        // eta = Eth ln(10) / 20 (relative error of the amplitude threshold)
+        // eta = Eth ln(10) / 20 (relative error of the amplitude threshold) + the cell's own relative error
         t2 = M * __builtin_amdgcn_exp2f(th * (1.f / kDb));
-        const float eta = Eth * 0.11512925f + 1.01f * RG_REL;    // + the cell's own relative error near the threshold
+        const float eta = Eth * 0.11512925f + 1.01f * RG_REL;
         cb = 4.f * eta * eta * t2;
       }
     }
@@ -394,9 +423,7 @@ __global__ __launch_bounds__(RG_THREADS, 1) void k_row_gate(RowGateArgs A) {
       s_cb[f] = cb;
       if (exact) s_flag[f] = 1;
     }
-  };
-  band_stats(tid >> 1, tid & 1, 2);
-  if (tid < 64) band_stats(512, 0, 1);         // (the whole first wave runs it; the lanes agree)
+  }
   }
   __syncthreads();
   RG_STAMP(3);   // band statistics
@@ -430,9 +457,11 @@ __global__ __launch_bounds__(RG_THREADS, 1) void k_row_gate(RowGateArgs A) {
   RG_STAMP(4);   // decisions
 
   // ---- exact re-evaluation of the ambiguous bands ---------------------------------------------------------------------
-  if (tid < 513 && s_flag[tid]) {
-    const unsigned idx = atomicAdd(&s_misc[0], 1u);
-    s_list[idx] = (unsigned short)tid;
+  for (int f = tid; f < 513; f += RG_THREADS) {
+    if (s_flag[f]) {
+      const unsigned idx = atomicAdd(&s_misc[0], 1u);
+      s_list[idx] = (unsigned short)f;
+    }
   }
   __syncthreads();
   const int n_amb = (int)s_misc[0];
@@ -481,44 +510,57 @@ __global__ __launch_bounds__(RG_THREADS, 1) void k_row_gate(RowGateArgs A) {
       }
     };
     if (lds_x) {
-      char* rb = reinterpret_cast<char*>(regions);
-      const float* xs = reinterpret_cast<const float*>(rb);
-      double* w64s = reinterpret_cast<double*>(rb + RG_EX_W64);
-      cx<double>* tws = reinterpret_cast<cx<double>*>(rb + RG_EX_TW);
-      double* exb = reinterpret_cast<double*>(rb + RG_EX_PW);
+      double* w64s = reinterpret_cast<double*>(region + RG_EX_W64);
+      cx<double>* tws = reinterpret_cast<cx<double>*>(region + RG_EX_TW);
+      double* exb = reinterpret_cast<double*>(region + RG_EX_PW);
       stage_span(false);
-      w64s[tid] = A.win64[tid];
-      if (tid < 512) tws[tid] = A.tw64[tid];
+      for (int i = tid; i < 1024; i += RG_THREADS) w64s[i] = A.win64[i];
+      for (int i = tid; i < 1024; i += RG_THREADS) {     // w_1024^i for every i: no sign logic in the inner loop
+        cx<double> w = A.tw64[i & 511];
+        if (i & 512) { w.x = -w.x; w.y = -w.y; }
+        tws[i] = w;
+      }
       __syncthreads();
-      const int tq = tid >> 4, p = tid & 15;       // 16 lanes per frame, lane p sums the terms m = p + 16 i
-      const float* xq = xs + tq * 288 + p;
+      const int p = tid & 15;                       // 16 lanes per frame, lane p sums the terms m = p + 16 i
       const double* wq = w64s + p;
       for (int k0 = 0; k0 < n_amb; k0 += RG_EX_BANDS) {
         const int nbk = min(RG_EX_BANDS, n_amb - k0);
         for (int k = 0; k < nbk; ++k) {
           const int f = (int)s_list[k0 + k];
-          double re = 0.0, im = 0.0;
-          if (tq < T) {
-            int j = (f * p) & 1023;
-            const int dj = (16 * f) & 1023;
+          const int dj = (16 * f) & 1023;
+          // radix-4 split of the 1024-term sum: with y_k[m] = (x w)[m + 256 k], m < 256, and w^(256 f) = (-i)^f
+          //   X[f] = sum_m ( (y0 + s y2) + (-i)^f (y1 + s y3) ) w^(f m),  s = (-1)^f
+          // -- a quarter of the twiddle reads (the LDS pipe bounds this loop) and 4 instead of 8 multiply-adds per 4 terms
+          const double sg2 = (f & 1) ? -1.0 : 1.0;
+          const double cr = (f & 1) ? 0.0 : ((f & 2) ? -1.0 : 1.0);      // (-i)^f = cr + i ci
+          const double ci = (f & 1) ? ((f & 2) ? 1.0 : -1.0) : 0.0;
 #pragma unroll 1
-            for (int q = 0; q < 4; ++q) {
+          for (int hq = 0; hq < RG_FRAMES / (RG_THREADS / 16); ++hq) {
+            const int tq = (tid >> 4) + (RG_THREADS / 16) * hq;
+            double re = 0.0, im = 0.0;
+            if (tq < T) {
+              const float* xq = xs + tq * XP + p;
+              int j = (f * p) & 1023;
 #pragma unroll 4
-              for (int r = 0; r < 16; ++r) {
-                const double xv = (double)xq[q * 288 + 16 * r] * wq[256 * q + 16 * r];
-                cx<double> w = tws[j & 511];
-                if (j & 512) { w.x = -w.x; w.y = -w.y; }
-                re += xv * w.x;
-                im += xv * w.y;
+              for (int i = 0; i < 16; ++i) {
+                const double y0 = (double)xq[16 * i] * wq[16 * i];
+                const double y1 = (double)xq[XP + 16 * i] * wq[256 + 16 * i];
+                const double y2 = (double)xq[2 * XP + 16 * i] * wq[512 + 16 * i];
+                const double y3 = (double)xq[3 * XP + 16 * i] * wq[768 + 16 * i];
+                const double a = fma(sg2, y2, y0), b = fma(sg2, y3, y1);
+                const double Cr = fma(cr, b, a), Ci = ci * b;
+                const cx<double> w = tws[j];
+                re = fma(Cr, w.x, fma(-Ci, w.y, re));
+                im = fma(Cr, w.y, fma(Ci, w.x, im));
                 j = (j + dj) & 1023;
               }
             }
+            re += __shfl_xor(re, 1); im += __shfl_xor(im, 1);
+            re += __shfl_xor(re, 2); im += __shfl_xor(im, 2);
+            re += __shfl_xor(re, 4); im += __shfl_xor(im, 4);
+            re += __shfl_xor(re, 8); im += __shfl_xor(im, 8);
+            if (p == 0 && tq < T) exb[k * 64 + tq] = re * re + im * im;
           }
-          re += __shfl_xor(re, 1); im += __shfl_xor(im, 1);
-          re += __shfl_xor(re, 2); im += __shfl_xor(im, 2);
-          re += __shfl_xor(re, 4); im += __shfl_xor(im, 4);
-          re += __shfl_xor(re, 8); im += __shfl_xor(im, 8);
-          if (p == 0 && tq < T) exb[k * 64 + tq] = re * re + im * im;
         }
         __syncthreads();
         for (int k = wave; k < nbk; k += RG_WAVES) {
@@ -532,8 +574,8 @@ __global__ __launch_bounds__(RG_THREADS, 1) void k_row_gate(RowGateArgs A) {
       for (int k = 0; k < n_amb; ++k) {
         const int f = (int)s_list[k];
 #pragma unroll 1
-        for (int q = 0; q < 4; ++q) {
-          const int tq = 4 * wave + q;
+        for (int q = 0; q < 64 / RG_WAVES; ++q) {
+          const int tq = (64 / RG_WAVES) * wave + q;
           if (tq < T) {
             const double Pe = rg_exact_power(A, row, tq, f, lane);
             if (lane == 0) s_ex[tq] = Pe;
@@ -554,34 +596,38 @@ __global__ __launch_bounds__(RG_THREADS, 1) void k_row_gate(RowGateArgs A) {
       A.bits_out[((int64_t)blockIdx.x * T + r) * 9 + w] = wb[(nt + r) * RG_WP + 1 + w];
     }
   }
-
   RG_STAMP(5);   // exact re-evaluation (+ stage tap)
-  // ---- pass 2: the row's spectra again (they stay in registers from here to the inverse transform) -----------------------
+
+  // ---- pass 2: the row's spectra again (they stay in registers from here to the inverse transforms) ----------------------
   if (!(n_amb > 0 && lds_x)) stage_span(false);   // (the exact phase has staged the samples already)
   __syncthreads();
-  cf v[32];
-  (void)forward(v);
-  __syncthreads();   // all forward exchanges done: the slices become the count / K tile
+  cf v[RG_QUADS][32];
+#pragma unroll
+  for (int q = 0; q < RG_QUADS; ++q) (void)forward(v[q], frame_of(q));
+  __syncthreads();   // all gathers and forward exchanges done: the region becomes the count / K tile
   RG_STAMP(6);   // pass 2: span, gather, forward transform, split
 
   // ---- smoothing, exact integer arithmetic (k_smooth_bits2's): K[t][f] = sum_a sum_b vf[a] vt[b] bit[t+b][f+a] ------------
-  unsigned short* cfp = reinterpret_cast<unsigned short*>(regions);   // [rows + 2][RG_FP] counts along f, then K in place
+  unsigned short* cfp = reinterpret_cast<unsigned short*>(region);   // [rows + 2][RG_FP] counts along f, then K in place
   const int rows = T + 2 * nt;
-  for (int i = tid; i < 2 * RG_FP; i += RG_THREADS) cfp[(size_t)rows * RG_FP + i] = 0;
-  // rows outside the spectrogram are zero
-  for (int i = tid; i < 2 * nt * (RG_FP / 4); i += RG_THREADS) {
-    const int r = i / (RG_FP / 4), q = i - r * (RG_FP / 4);
-    reinterpret_cast<unsigned long long*>(cfp + (size_t)(r < nt ? r : T + r) * RG_FP)[q] = 0ull;
+  RG_STAMP(14);
+  {
+    // rows outside the spectrogram are zero: [0, nt) in front, [nt + T, nt + T + nt + 2) behind (two more than the tile:
+    // the walk along t reads them)
+    unsigned long long* z0 = reinterpret_cast<unsigned long long*>(cfp);
+    unsigned long long* z1 = reinterpret_cast<unsigned long long*>(cfp + (size_t)(nt + T) * RG_FP);
+    for (int i = tid; i < nt * (RG_FP / 4); i += RG_THREADS) z0[i] = 0ull;
+    for (int i = tid; i < (nt + 2) * (RG_FP / 4); i += RG_THREADS) z1[i] = 0ull;
   }
   RG_STAMP(12);
   {
-    // one thread = one (frame, 64-bin word): c[f] = sum_a (nf + 1 - |a|) bit[f + a] by the recurrence c += R - L of
-    // k_smooth_bits2 (R / L = set bits in the nf + 1 bins right of / left of and including f).  The three bit streams the
-    // recurrence reads -- bit(f + 1), bit(f + nf + 2), bit(f - nf) -- are the 128-bit window shifted ONCE per task, so
-    // the unrolled loop extracts every bit with one v_bfe at a compile-time position (64-bit shifts are quarter rate).
+    // one thread = one (frame, 64-bin word), 63 x 8 = 504 tasks: c[f] = sum_a (nf + 1 - |a|) bit[f + a] by the recurrence
+    // c += R - L of k_smooth_bits2 (R / L = set bits in the nf + 1 bins right of / left of and including f).  The three bit
+    // streams the recurrence reads -- bit(f + 1), bit(f + nf + 2), bit(f - nf) -- are the 128-bit window shifted ONCE per
+    // task (64-bit shifts are quarter rate); word 7's thread also leaves the count of bin 512, the recurrence's next value.
     const unsigned long long m1 = (1ull << (nf + 1)) - 1ull;
-    for (int task = tid; task < T * 9; task += RG_THREADS) {
-      const int r = nt + task / 9, w = task % 9;
+    for (int task = tid; task < T * 8; task += RG_THREADS) {
+      const int r = nt + (task >> 3), w = task & 7;
       const unsigned long long* rb = wb + (size_t)r * RG_WP + 1 + w;
       const unsigned long long lo = funnel_r(rb[-1], rb[0], 64 - nf);      // bins 64 w - nf ...
       const unsigned long long hi = funnel_r(rb[0], rb[1], 64 - nf);       // bins 64 w - nf + 64 ...
@@ -590,17 +636,10 @@ __global__ __launch_bounds__(RG_THREADS, 1) void k_row_gate(RowGateArgs A) {
       int R = __popcll((lo >> (nf + 1)) & m1);
       int L = __popcll(lo & m1);
       const unsigned long long sA = funnel_r(lo, hi, nf + 1);              // bit i = bit(f + 1),      f = 64 w + i
-      const unsigned long long sB = funnel_r(lo, hi, 2 * nf + 2 >= 64 ? 63 : 2 * nf + 2) >> (2 * nf + 2 >= 64 ? 2 * nf + 2 - 63 : 0);
-      // (2 nf + 2 <= 62 for nf <= 30, so the second shift is 0: kept for the general form)
-      const unsigned long long sC = lo;                                     // bit i = bit(f - nf)
+      const unsigned long long sB = funnel_r(lo, hi, 2 * nf + 2);          // bit i = bit(f + nf + 2)  (2 nf + 2 <= 62)
       const unsigned a0 = (unsigned)sA, a1 = (unsigned)(sA >> 32), b0 = (unsigned)sB, b1 = (unsigned)(sB >> 32);
-      const unsigned c0 = (unsigned)sC, c1 = (unsigned)(sC >> 32);
+      const unsigned c0 = (unsigned)lo, c1 = (unsigned)(lo >> 32);         // bit i = bit(f - nf)
       unsigned short* out = cfp + (size_t)r * RG_FP + 72 * w;   // column(f) = f + 4 (f / 32)
-      if (w == 8) {                                                         // bin 512 only (+ 3 scratch columns)
-        out[0] = (unsigned short)cnt;
-        continue;
-      }
-      // rolled: 16 groups of 4 bins (the bit positions are scalar); the held spectra leave this loop ~40 registers
 #pragma unroll 1
       for (int i4 = 0; i4 < 64; i4 += 4) {
         const unsigned av = i4 & 32 ? a1 : a0, bv = i4 & 32 ? b1 : b0, cv = i4 & 32 ? c1 : c0;
@@ -617,14 +656,15 @@ __global__ __launch_bounds__(RG_THREADS, 1) void k_row_gate(RowGateArgs A) {
         const unsigned long long pk = (unsigned long long)(v4[0] | (v4[1] << 16)) | ((unsigned long long)(v4[2] | (v4[3] << 16)) << 32);
         *reinterpret_cast<unsigned long long*>(out + i4 + ((i4 >> 5) << 2)) = pk;
       }
+      if (w == 7) out[72] = (unsigned short)cnt;    // bin 512 = column 576
     }
   }
   RG_STAMP(13);
   __syncthreads();
   RG_STAMP(7);   // smoothing along f
-  if (tid < 513) {
+  if (tid < 512) {
     // along t, one column per thread, IN PLACE: output row i overwrites count row i (dead once it has been read)
-    const int f = tid;
+    const int f = tid;    // columns 0..511
     unsigned short* col = cfp + f + ((f >> 5) << 2);
     int cnt = 0, R = 0, L = 0;
     for (int b = -nt; b <= nt + 1; ++b) {
@@ -646,6 +686,15 @@ __global__ __launch_bounds__(RG_THREADS, 1) void k_row_gate(RowGateArgs A) {
       L += xb - xc;
     }
   }
+  if (wave == 0) {
+    // column 512 (bin 512): lane = frame, direct sum over the 2 nt + 1 rows; every lane reads before any lane writes
+    const unsigned short* col = cfp + 576;
+    int acc = 0;
+    if (lane < T)
+      for (int b = -nt; b <= nt; ++b) acc += (nt + 1 - (b < 0 ? -b : b)) * (int)col[(size_t)(lane + nt + b) * RG_FP];
+    wave_lds_sync();
+    if (lane < T) cfp[(size_t)lane * RG_FP + 576] = (unsigned short)acc;
+  }
   __syncthreads();
   RG_STAMP(8);   // smoothing along t
   if (A.mask_out) {
@@ -656,21 +705,25 @@ __global__ __launch_bounds__(RG_THREADS, 1) void k_row_gate(RowGateArgs A) {
     }
   }
 
-  // ---- x mask -> merge (second half of pair_mask), in place ------------------------------------------------------------
-  {
+  // ---- x mask -> merge (second half of pair_mask), in place, both quads ------------------------------------------------
+#pragma unroll
+  for (int q = 0; q < RG_QUADS; ++q) {
+    const int t = frame_of(q);
+    const bool fvalid = t < T;
+    cf* vq = v[q];
     const unsigned short* krow = cfp + (size_t)(fvalid ? t : 0) * RG_FP;
     const unsigned short* k_lo = krow + c;                 // lanes c >= 1: entry e < 16 = bin c + 32 e -> column c + 36 e
     const unsigned short* k_hi = krow + (32 - c);          // entry e >= 16 = bin (32 - c) + 32 (e - 16)
-    auto mval = [&](int q, float scale) -> float {
-      const int b0 = bin_of_entry(0, q);                   // lane 0 (compile-time)
-      const unsigned short kv = c == 0 ? krow[b0 + ((b0 >> 5) << 2)] : (q < 16 ? k_lo[36 * q] : k_hi[36 * (q - 16)]);
+    auto mval = [&](int e, float scale) -> float {
+      const int b0 = bin_of_entry(0, e);                   // lane 0 (compile-time)
+      const unsigned short kv = c == 0 ? krow[b0 + ((b0 >> 5) << 2)] : (e < 16 ? k_lo[36 * e] : k_hi[36 * (e - 16)]);
       return (float)kv * scale;
     };
     const float k512 = (float)krow[512 + 64] * A.kscale;
     const float ks = A.kscale * 0.25f;
     {
       // slot 0: lanes >= 1 merge the pair (v[0], v[31]); lane 0: bins 0 / 512 from v[0], bin 256 = v[31] scaled
-      const cf r0 = v[0], r31 = v[31];
+      const cf r0 = vq[0], r31 = vq[31];
       cf xa = r0, xb = r31;
       merge_pair(xa, xb, wlo, mval(0, ks), mval(31, ks));
       const float y0 = (r0.x + r0.y) * mval(0, A.kscale);
@@ -678,108 +731,125 @@ __global__ __launch_bounds__(RG_THREADS, 1) void k_row_gate(RowGateArgs A) {
       const cf z0 = {0.5f * (y0 + yN), 0.5f * (y0 - yN)};
       const float m8 = mval(31, A.kscale);  // entry 31 of lane 0 = bin 256
       const cf z8 = {r31.x * m8, r31.y * m8};
-      v[0] = {l0 ? z0.x : xa.x, l0 ? z0.y : xa.y};
-      v[31] = {l0 ? z8.x : xb.x, l0 ? z8.y : xb.y};
+      vq[0] = {l0 ? z0.x : xa.x, l0 ? z0.y : xa.y};
+      vq[31] = {l0 ? z8.x : xb.x, l0 ? z8.y : xb.y};
     }
 #pragma unroll
     for (int sl = 1; sl < 16; ++sl) {
       const cf w = mul_tw<false>(sl < 8 ? wlo : whi, twc<32>(sl), tws<32>(sl));
-      merge_pair(v[sl], v[31 - sl], w, mval(sl, ks), mval(31 - sl, ks));
+      merge_pair(vq[sl], vq[31 - sl], w, mval(sl, ks), mval(31 - sl, ks));
     }
-    rg_lane0_from_entries(v, l0);   // back to the transform's register order
+    rg_lane0_from_entries(vq, l0);   // back to the transform's register order
     if (!fvalid) {
 #pragma unroll
-      for (int i = 0; i < 32; ++i) v[i] = {0.f, 0.f};
-    }
-  }
-  __syncthreads();   // every lane has read its K values: the slices are reused by the inverse transforms
-  RG_STAMP(9);   // mask + merge
-
-  // ---- inverse transform, synthesis window, wave-private overlap-add (k_apply_fast<LEAN>) -------------------------------
-  {
-    int zi = 0, ci = c;
-    asm volatile("" : "+v"(zi), "+v"(ci));
-    fft512_inv_half(v, fb + zi, tw512 + zi, ci);
-  }
-  float* acc = reinterpret_cast<float*>(regions + wave * WAVE_CX_H);
-  {
-    const float2* wsrc2 = reinterpret_cast<const float2*>(swin + 2 * c);
-#pragma unroll
-    for (int j = 0; j < 4; ++j) {
-      const bool first = (j == 0) || (g == 3);
-#pragma unroll
-      for (int rr = 0; rr < 8; ++rr) {
-        const int r = 8 * j + rr;
-        float2* dst = reinterpret_cast<float2*>(acc + (g + j) * HPITCH + 2 * c + 32 * rr);
-        const float2 old = *dst;
-        const float2 ws = wsrc2[16 * r];
-        float2 nw = {v[r].x * ws.x, v[r].y * ws.y};
-        if (!first) { nw.x += old.x; nw.y += old.y; }
-        *dst = nw;
-      }
-      wave_lds_sync();
+      for (int i = 0; i < 32; ++i) vq[i] = {0.f, 0.f};
     }
   }
   const float4 n4 = *reinterpret_cast<const float4*>(&A.invn[(tid & 63) * 4]);
-  __syncthreads();
-  RG_STAMP(10);  // inverse transform, window, wave-private overlap-add
+  __syncthreads();   // every lane has read its K values: the region is reused by the inverse transforms
+  RG_STAMP(9);   // mask + merge
 
-  // ---- cross-wave combine, normalise, store: ext hop jj (256 samples from position 256 jj - padL) -----------------------
-  const float* fr = reinterpret_cast<const float*>(regions);
+  // ---- per quad: inverse transform, synthesis window, wave-private overlap-add (k_apply_fast<LEAN>), then the cross-wave
+  // combine of the 32 frames' hops.  Quad 0 = frames 0..31 -> hops 0..34; hops 32..34 also receive frames 32..34 of quad 1:
+  // their partial sums wait in `carry` (the dead compare-constant tables).  Quad 1 = frames 32..63 -> hops 32..66.
+  float* carry = s_t2;    // [3][256]
+  static_assert(2 * T2_FLOATS >= 3 * 256, "carry buffer");
   const int s4 = (tid & 63) * 4;
   const int64_t h_begin = (A.om.p0 + G.padL) / 256, h_end = (A.om.p1 - 1 + G.padL) / 256 + 1;
-  for (int jj = (int)h_begin + wave; jj < (int)h_end && jj < 4 * RG_WAVES + 3; jj += RG_WAVES) {
-    float4 a4 = make_float4(0.f, 0.f, 0.f, 0.f);
-    const int wh = jj >> 2, lh = jj & 3;
-    if (wh >= 1 && lh <= 2) a4 = *reinterpret_cast<const float4*>(&fr[(wh - 1) * WAVE_CX_H * 2 + (lh + 4) * HPITCH + s4]);
-    if (wh < RG_WAVES) {
-      const float4 f4 = *reinterpret_cast<const float4*>(&fr[wh * WAVE_CX_H * 2 + lh * HPITCH + s4]);
-      a4.x += f4.x; a4.y += f4.y; a4.z += f4.z; a4.w += f4.w;
-    }
-    bool all_valid = true;
 #pragma unroll
-    for (int q = 0; q < 4; ++q) {
-      const int ti = jj - q;
-      if (ti < 0 || ti >= T) all_valid = false;
+  for (int q = 0; q < RG_QUADS; ++q) {
+    cf* vq = v[q];
+    {
+      int zi = 0, ci = c;
+      asm volatile("" : "+v"(zi), "+v"(ci));
+      fft512_inv_half(vq, slices + wave * WAVE_CX_H + frame_base_h(g) + zi, tw512 + zi, ci);
     }
-    if (all_valid) {
-      a4.x *= n4.x; a4.y *= n4.y; a4.z *= n4.z; a4.w *= n4.w;
-    } else {
-      float4 nrm = make_float4(0.f, 0.f, 0.f, 0.f);
+    float* acc = reinterpret_cast<float*>(slices + wave * WAVE_CX_H);
+    {
+      const float2* wsrc2 = reinterpret_cast<const float2*>(swin + 2 * c);
 #pragma unroll
-      for (int q = 0; q < 4; ++q) {
-        const int ti = jj - q;
-        if (ti >= 0 && ti < T) {
-          const float4 w4 = *reinterpret_cast<const float4*>(&A.wsq[256 * q + s4]);
-          nrm.x += w4.x; nrm.y += w4.y; nrm.z += w4.z; nrm.w += w4.w;
+      for (int j = 0; j < 4; ++j) {
+        const bool first = (j == 0) || (g == 3);
+#pragma unroll
+        for (int rr = 0; rr < 8; ++rr) {
+          const int r = 8 * j + rr;
+          float2* dst = reinterpret_cast<float2*>(acc + (g + j) * HPITCH + 2 * c + 32 * rr);
+          const float2 old = *dst;
+          const float2 ws = wsrc2[16 * r];
+          float2 nw = {vq[r].x * ws.x, vq[r].y * ws.y};
+          if (!first) { nw.x += old.x; nw.y += old.y; }
+          *dst = nw;
         }
+        wave_lds_sync();
       }
-      a4.x /= (nrm.x > 1e-10f ? nrm.x : 1.f);
-      a4.y /= (nrm.y > 1e-10f ? nrm.y : 1.f);
-      a4.z /= (nrm.z > 1e-10f ? nrm.z : 1.f);
-      a4.w /= (nrm.w > 1e-10f ? nrm.w : 1.f);
     }
-    const int64_t pbs = (int64_t)jj * 256 - G.padL;
-    const int64_t gi0 = pbs - A.om.p0;
-    if (A.om.dtype == 0 && pbs >= A.om.p0 && pbs + 256 <= A.om.p1 && pbs + 256 <= G.Lout && gi0 >= A.om.g_lo &&
-        gi0 + 256 <= A.om.g_hi) {
-      float* dst = (float*)A.om.out + (row * A.om.stride + gi0 - A.om.g0 + s4);
-      if ((reinterpret_cast<uintptr_t>(dst) & 15) == 0) {
-        *reinterpret_cast<float4*>(dst) = a4;
+    __syncthreads();
+    // combine: local hop lj = 0..34 of this quad (ext hop jj = 32 q + lj): wave lj / 4 (hop lj % 4) + wave lj / 4 - 1 (hop lj % 4 + 4)
+    const float* fr = reinterpret_cast<const float*>(slices);
+    for (int lj = wave; lj < 4 * RG_WAVES + 3; lj += RG_WAVES) {
+      const int jj = 4 * RG_WAVES * q + lj;
+      float4 a4 = make_float4(0.f, 0.f, 0.f, 0.f);
+      const int wh = lj >> 2, lh = lj & 3;
+      if (wh >= 1 && lh <= 2) a4 = *reinterpret_cast<const float4*>(&fr[(wh - 1) * WAVE_CX_H * 2 + (lh + 4) * HPITCH + s4]);
+      if (wh < RG_WAVES) {
+        const float4 f4 = *reinterpret_cast<const float4*>(&fr[wh * WAVE_CX_H * 2 + lh * HPITCH + s4]);
+        a4.x += f4.x; a4.y += f4.y; a4.z += f4.z; a4.w += f4.w;
+      }
+      if (RG_QUADS == 2 && q == 0 && lj >= 4 * RG_WAVES) {          // frames 32.. have not contributed yet
+        *reinterpret_cast<float4*>(&carry[(lj - 4 * RG_WAVES) * 256 + s4]) = a4;
         continue;
       }
-    }
-    const float vals[4] = {a4.x, a4.y, a4.z, a4.w};
+      if (RG_QUADS == 2 && q == 1 && lj < 3) {
+        const float4 f4 = *reinterpret_cast<const float4*>(&carry[lj * 256 + s4]);
+        a4.x += f4.x; a4.y += f4.y; a4.z += f4.z; a4.w += f4.w;
+      }
+      if (jj < (int)h_begin || jj >= (int)h_end) continue;
+      bool all_valid = true;
 #pragma unroll
-    for (int e = 0; e < 4; ++e) {
-      const int64_t p = (int64_t)jj * 256 + s4 + e - G.padL;
-      if (p < A.om.p0 || p >= A.om.p1) continue;
-      const int64_t gi = p - A.om.p0;
-      if (gi < A.om.g_lo || gi >= A.om.g_hi) continue;
-      store_sample(A.om.out, A.om.dtype, row * A.om.stride + gi - A.om.g0, p < G.Lout ? vals[e] : 0.f);
+      for (int k = 0; k < 4; ++k) {
+        const int ti = jj - k;
+        if (ti < 0 || ti >= T) all_valid = false;
+      }
+      if (all_valid) {
+        a4.x *= n4.x; a4.y *= n4.y; a4.z *= n4.z; a4.w *= n4.w;
+      } else {
+        float4 nrm = make_float4(0.f, 0.f, 0.f, 0.f);
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+          const int ti = jj - k;
+          if (ti >= 0 && ti < T) {
+            const float4 w4 = *reinterpret_cast<const float4*>(&A.wsq[256 * k + s4]);
+            nrm.x += w4.x; nrm.y += w4.y; nrm.z += w4.z; nrm.w += w4.w;
+          }
+        }
+        a4.x /= (nrm.x > 1e-10f ? nrm.x : 1.f);
+        a4.y /= (nrm.y > 1e-10f ? nrm.y : 1.f);
+        a4.z /= (nrm.z > 1e-10f ? nrm.z : 1.f);
+        a4.w /= (nrm.w > 1e-10f ? nrm.w : 1.f);
+      }
+      const int64_t pbs = (int64_t)jj * 256 - G.padL;
+      const int64_t gi0 = pbs - A.om.p0;
+      if (A.om.dtype == 0 && pbs >= A.om.p0 && pbs + 256 <= A.om.p1 && pbs + 256 <= G.Lout && gi0 >= A.om.g_lo &&
+          gi0 + 256 <= A.om.g_hi) {
+        float* dst = (float*)A.om.out + (row * A.om.stride + gi0 - A.om.g0 + s4);
+        if ((reinterpret_cast<uintptr_t>(dst) & 15) == 0) {
+          *reinterpret_cast<float4*>(dst) = a4;
+          continue;
+        }
+      }
+      const float vals[4] = {a4.x, a4.y, a4.z, a4.w};
+#pragma unroll
+      for (int e = 0; e < 4; ++e) {
+        const int64_t p = (int64_t)jj * 256 + s4 + e - G.padL;
+        if (p < A.om.p0 || p >= A.om.p1) continue;
+        const int64_t gi = p - A.om.p0;
+        if (gi < A.om.g_lo || gi >= A.om.g_hi) continue;
+        store_sample(A.om.out, A.om.dtype, row * A.om.stride + gi - A.om.g0, p < G.Lout ? vals[e] : 0.f);
+      }
     }
+    __syncthreads();   // the accumulators are consumed: the next quad's inverse exchange may overwrite them
+    RG_STAMP(10 + q);  // inverse transform, window, overlap-add, combine, store
   }
-  RG_STAMP(11);  // combine, normalise, store
 }
 
 }  // namespace fast

@@ -13,14 +13,13 @@ res = {}
 for B in (64, 128, 256, 512, 1024, 2048):
     torch.manual_seed(0)
     x = (0.1 * torch.randn(B, 16000, device=dev) + 0.5 * torch.sin(2 * np.pi * 440 * t16).float()).float()
-    for mode in ("rowgate", "four"):
-        (g,) = list(tg._gates.values()) if tg._gates else (None,)
-        if g is not None:
-            g.set_option(_ffi.SG_OPT_FORCE_NOROWGATE, 1 if mode == "four" else 0)
-        for _ in range(10):
-            tg(x)
+    for mode in ("rowgate16", "rowgate8", "four"):
+        tg(x)
         (g,) = list(tg._gates.values())
         g.set_option(_ffi.SG_OPT_FORCE_NOROWGATE, 1 if mode == "four" else 0)
+        g.set_option(_ffi.SG_OPT_ROWGATE_SHAPE, 8 if mode == "rowgate8" else 16)
+        for _ in range(10):
+            tg(x)
         ev = [torch.cuda.Event(enable_timing=True) for _ in range(31)]
         for i in range(30):
             ev[i].record(); tg(x)
@@ -29,6 +28,7 @@ for B in (64, 128, 256, 512, 1024, 2048):
         res["%s B=%d" % (mode, B)] = round(ts[15], 4)
         print(mode, B, ts[15], flush=True)
     g.set_option(_ffi.SG_OPT_FORCE_NOROWGATE, 0)
+    g.set_option(_ffi.SG_OPT_ROWGATE_SHAPE, 16)
 json.dump(res, open(os.path.join(ROOT, "gpurun_out", "rowgate_scale.json"), "w"), indent=1)
 
 # host enqueue cost per call (asynchronous loop, no synchronisation inside) and the kernel's own time (HIP events around the launch)
