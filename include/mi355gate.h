@@ -203,8 +203,9 @@ SG_API int sg_debug_fetch(sg_handle* h, int32_t what, void* host, int64_t bytes,
                                        * (the output is fine); bits 3..5 make the KERNEL lose its hand-offs (3 or 4: the one-pass
                                        * gate, 5: the fused apply): the producers' tags are never accepted and the polls give up --
                                        * the bounded-poll timeout path itself: error word set by the kernel, affected hops NaN */
-#define SG_OPT_FORCE_NOROWGATE 10 /* value != 0: variant T, stationary, short rows: the four-kernel path (float64 transform of every
-                                   * frame, k_row_decide, k_smooth_bits2, k_apply_fast) instead of the one-kernel row gate */
+#define SG_OPT_FORCE_NOROWGATE 10 /* variant T, stationary, rows of <= 64 frames: 0 (default) = the one-kernel row gate for calls of >= 160
+                                   * rows, the four-kernel path (float64 transform of every frame, k_row_decide, k_smooth_bits2,
+                                   * k_apply_fast) below; 1 = never the row gate; 2 = the row gate whenever the shape is eligible */
 #define SG_OPT_ROWGATE_TAP 11     /* value != 0: the row gate also writes its float32 power tile (4 |X|^2, [rows][64][528]) for
                                    * sg_debug_fetch(what = 4): measurements behind the decision margin */
 #define SG_OPT_ROWGATE_SHAPE 12   /* value = 16 (default) or 8: wavefronts per workgroup of the row gate (16 x one quad of frames at 128

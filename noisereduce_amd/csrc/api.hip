@@ -97,7 +97,7 @@ struct sg_handle {
   bool force_exact = false;          // SG_OPT_FORCE_EXACT: float64 pipeline (exact.hpp) whatever the output dtype
   DevBuf xP, xraw, xM, xtmp, xseg;   // fields of the exact path
   bool force_split = false;          // SG_OPT_FORCE_SPLIT: decide / smooth / apply as three kernels
-  bool force_norowgate = false;      // SG_OPT_FORCE_NOROWGATE: variant T short rows on the four-kernel path
+  int rowgate_mode = 0;              // SG_OPT_FORCE_NOROWGATE: 0 = by batch size, 1 = never, 2 = whenever the shape is eligible
   int rg_shape = 16;                 // SG_OPT_ROWGATE_SHAPE: waves per workgroup of the row gate (16 x 1 quad, or 8 x 2 quads)
   bool rg_tap = false;               // SG_OPT_ROWGATE_TAP: keep the row gate's float32 power tile (stage tap 4)
   bool dbg_rg = false;               // the last batch ran on the row gate
@@ -2199,8 +2199,13 @@ static int run_S(sg_handle* h, View v, int64_t total_units, const OutMap& om, hi
 // TorchGate.forward of whole rows in one kernel (rowgate.hpp): variant T, stationary, statistics from the row itself,
 // default geometry, rows of at most 64 frames (1 s clips at 16 kHz: 63), full reduction, smoothing filter within the
 // kernel's sliding-window limits.
-static bool rowgate_ok(const sg_handle* h, const Geom& g) {
-  return h->fast_ok && !h->force_nofast && !h->force_unfused && !h->force_norowgate && h->p.stationary &&
+// One workgroup per row and one workgroup per CU at a time: a call of fewer rows than ~2/3 of the CUs is faster on the
+// four-kernel path, which spreads a row over 5 workgroups (256 x 16000: 0.110 vs 0.146 ms; 128 rows: ~0.105 vs 0.097;
+// 1024 rows: 0.45 vs 0.52; profiles/r04_rowgate_scale.json).
+constexpr int64_t RG_MIN_ROWS = 160;
+static bool rowgate_ok(const sg_handle* h, const Geom& g, int64_t rows) {
+  if (h->rowgate_mode == 1 || (h->rowgate_mode == 0 && rows < RG_MIN_ROWS)) return false;
+  return h->fast_ok && !h->force_nofast && !h->force_unfused && h->p.stationary &&
          h->p.prop_decrease == 1.0 && h->p.smooth_mask && h->ktot <= 65535 && g.F == 513 && g.T >= 1 &&
          g.T <= fast::RG_FRAMES && h->p.n_grad_freq >= 1 && h->p.n_grad_freq <= fast::RG_NFMAX &&
          h->p.n_grad_time >= 1 && h->p.n_grad_time <= fast::RG_NTMAX;
@@ -2496,7 +2501,7 @@ extern "C" int sg_process_batch(sg_handle* h, const void* x_dev, int dtype, int6
       } else {
         th = nullptr; ustride = g.FS;
       }
-      if (!xn_dev && rowgate_ok(h, g)) {
+      if (!xn_dev && rowgate_ok(h, g, B)) {
         // one kernel per call: a workgroup per row (rowgate.hpp)
         v.unit0 = 0;
         View vr = v;
@@ -2666,7 +2671,10 @@ extern "C" int sg_set_option(sg_handle* h, int32_t option, int64_t value) {
     case SG_OPT_FORCE_SPLIT: h->force_split = value != 0; return SG_OK;
     case SG_OPT_FAST_INTEGER: h->fast_integer = value != 0; return SG_OK;
     case SG_OPT_FORCE_EXACT: h->force_exact = value != 0; return SG_OK;
-    case SG_OPT_FORCE_NOROWGATE: h->force_norowgate = value != 0; return SG_OK;
+    case SG_OPT_FORCE_NOROWGATE:
+      if (value < 0 || value > 2) FAIL(h, SG_E_INVALID, "SG_OPT_FORCE_NOROWGATE: 0 (auto), 1 (never) or 2 (always)");
+      h->rowgate_mode = (int)value;
+      return SG_OK;
     case SG_OPT_ROWGATE_TAP: h->rg_tap = value != 0; return SG_OK;
     case SG_OPT_ROWGATE_SHAPE:
       if (value != 8 && value != 16) FAIL(h, SG_E_INVALID, "SG_OPT_ROWGATE_SHAPE: 8 or 16 waves");

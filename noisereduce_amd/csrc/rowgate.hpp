@@ -190,7 +190,7 @@ __global__ __launch_bounds__(RG_WAVES * 64, 1) void k_row_gate(RowGateArgs A) {
   auto frame_of = [&](int q) { return 4 * (wave + RG_WAVES * q) + g; };
 
   // the row's samples -> LDS, zero outside the row
-  auto stage_span = [&](bool note) {
+  auto stage_span = [&]() -> bool {
     const float* sp = (const float*)A.view.x + row * A.view.stride;
     const bool vec_ok = A.view.dtype == 0 && (reinterpret_cast<uintptr_t>(sp) & 15) == 0 && A.view.lo <= 0 &&
                         A.view.hi >= A.view.Lp;
@@ -210,7 +210,7 @@ __global__ __launch_bounds__(RG_WAVES * 64, 1) void k_row_gate(RowGateArgs A) {
       any = any || q.x != 0.f || q.y != 0.f || q.z != 0.f || q.w != 0.f;
       *reinterpret_cast<float4*>(&xs[(e >> 8) * XP + (e & 255)]) = q;
     }
-    if (note && any) s_misc[1] = 1u;     // (benign race: every writer stores 1)  0: digital silence; NaN counts as a sample
+    return any;     // this thread staged a non-zero sample (NaN counts as one)
   };
   // gather (window x frame t) -> forward transform -> split in place: v[e] = 2 X[bin_of_entry(c, e)]; lane 0 keeps its two
   // unpaired registers raw: v[0] = Zc[0] (bins 0 / 512), v[31] = Zc[256] (bin 256).  Returns 2 (2 delta_t)^2.
@@ -275,11 +275,13 @@ __global__ __launch_bounds__(RG_WAVES * 64, 1) void k_row_gate(RowGateArgs A) {
   if (tid < 256) reinterpret_cast<float4*>(swin)[tid] = reinterpret_cast<const float4*>(A.win)[tid];
   for (int i = tid; i < (T + 2 * nt) * RG_WP; i += RG_THREADS) wb[i] = 0ull;
   for (int i = tid; i < 520; i += RG_THREADS) s_flag[i] = 0;
-  if (tid == 0) { s_misc[0] = 0u; s_misc[1] = 0u; }
-  __syncthreads();
+  unsigned* s_maxu = reinterpret_cast<unsigned*>(s_cb);   // band maxima (bit patterns) until the statistics replace them by cb
+  for (int i = tid; i < 513; i += RG_THREADS) s_maxu[i] = 0u;
+  if (tid == 0) { s_misc[0] = 0u; s_misc[1] = 0u; s_misc[2] = 0u; }
   RG_STAMP(0);
-  stage_span(true);
+  const bool any_sample = stage_span();
   __syncthreads();
+  if (any_sample) s_misc[1] = 1u;     // (every writer stores 1)  0: digital silence
   RG_STAMP(1);   // tables + span
 
   // ---- pass 1: powers (4x) of all cells -> LDS tile --------------------------------------------------------------------
@@ -310,11 +312,17 @@ __global__ __launch_bounds__(RG_WAVES * 64, 1) void k_row_gate(RowGateArgs A) {
           const int b0 = bin_of_entry(0, e);   // lane 0 (compile-time)
           float* dst = l0 ? trow + b0 : (e < 16 ? t_lo + 32 * e : t_hi + 32 * (e - 16));
           *dst = pw[q][e];
+          // band maximum over the frames: LDS atomic on the bit pattern (powers are >= 0; a NaN pattern beats every
+          // number, so the maximum is NaN-sticky like torch.max)
+          atomicMax(s_maxu + (dst - trow), __float_as_uint(pw[q][e]));
         }
         if (l0) {
           trow[512] = p512[q];
+          atomicMax(s_maxu + 512, __float_as_uint(p512[q]));
           s_d2[t] = d2q[q];
-          s_dl[t] = __builtin_amdgcn_sqrtf(0.5f * d2q[q]);
+          const float dl = __builtin_amdgcn_sqrtf(0.5f * d2q[q]);
+          s_dl[t] = dl;
+          atomicMax(&s_misc[2], __float_as_uint(dl));     // largest 2 delta_t of the row (NaN-sticky too)
         }
       }
     }
@@ -334,20 +342,9 @@ __global__ __launch_bounds__(RG_WAVES * 64, 1) void k_row_gate(RowGateArgs A) {
   const bool has_sample = s_misc[1] != 0u;
   const int par = tid & 1;
   for (int f = tid >> 1; f < 513; f += RG_THREADS / 2) {
-    // pass 1: maximum (NaN-sticky, like torch.max)
-    float M = 0.f, dM = 0.f;
-    for (int tt = par; tt < T; tt += 2) {
-      const float p = tile[tt * RG_PP + f];
-      const bool gt = p > M;
-      dM = gt ? s_dl[tt] : dM;
-      M = (M != M || p != p) ? __uint_as_float(0x7fc00000u) : (gt ? p : M);
-    }
-    {
-      const float Mo = __shfl_xor(M, 1), dMo = __shfl_xor(dM, 1);
-      const bool gt = Mo > M;
-      dM = gt ? dMo : dM;
-      M = (M != M || Mo != Mo) ? __uint_as_float(0x7fc00000u) : (gt ? Mo : M);
-    }
+    // the band's maximum was gathered while the tile was written; its error: the row's largest 2 delta_t (conservative)
+    const float M = __uint_as_float(s_maxu[f]);
+    const float dM = __uint_as_float(s_misc[2]);
     // amplitude of the maximum and its absolute error
     const float aM = __builtin_amdgcn_sqrtf(M);
     const float delM = dM + RG_REL * aM;
@@ -513,7 +510,7 @@ __global__ __launch_bounds__(RG_WAVES * 64, 1) void k_row_gate(RowGateArgs A) {
       double* w64s = reinterpret_cast<double*>(region + RG_EX_W64);
       cx<double>* tws = reinterpret_cast<cx<double>*>(region + RG_EX_TW);
       double* exb = reinterpret_cast<double*>(region + RG_EX_PW);
-      stage_span(false);
+      (void)stage_span();
       for (int i = tid; i < 1024; i += RG_THREADS) w64s[i] = A.win64[i];
       for (int i = tid; i < 1024; i += RG_THREADS) {     // w_1024^i for every i: no sign logic in the inner loop
         cx<double> w = A.tw64[i & 511];
@@ -599,7 +596,7 @@ __global__ __launch_bounds__(RG_WAVES * 64, 1) void k_row_gate(RowGateArgs A) {
   RG_STAMP(5);   // exact re-evaluation (+ stage tap)
 
   // ---- pass 2: the row's spectra again (they stay in registers from here to the inverse transforms) ----------------------
-  if (!(n_amb > 0 && lds_x)) stage_span(false);   // (the exact phase has staged the samples already)
+  if (!(n_amb > 0 && lds_x)) (void)stage_span();   // (the exact phase has staged the samples already)
   __syncthreads();
   cf v[RG_QUADS][32];
 #pragma unroll

@@ -3,6 +3,8 @@
 * item 7: a lost hand-off POISONS the output (NaN), it never looks like audio -- driven through the kernels' own
   bounded-poll timeout path (SG_OPT_INJECT_HANDOFF_FAULT bits 3..5), without the caller ever checking the error word;
 """
+import os
+
 import numpy as np
 import pytest
 import torch
@@ -91,3 +93,132 @@ def test_lost_handoff_poisons_torchgate_forward(nr):
     with pytest.raises(_ffi.HandoffTimeout):
         gate.check_errors()
     assert torch.equal(tg(x), good)
+
+
+# ---------------------------------------------------------------------------------------------------------------------
+# TorchGate.forward of a row in one kernel (k_row_gate: float32 statistics with an error bound,
+# exact float64 re-evaluation of the (row, band) pairs the bound cannot decide)
+# ---------------------------------------------------------------------------------------------------------------------
+def _tg_gate(tg):
+    (g,) = list(tg._gates.values())
+    return g
+
+
+def _rowgate_vs_float64(x, sr=16000, shape=16):
+    """forward on the row gate and on the four-kernel float64 path: (y_rowgate, bits_rowgate, y_f64, bits_f64)."""
+    from noisereduce_amd import _ffi
+    from noisereduce_amd.torchgate import TorchGate
+    tg = TorchGate(sr=sr).cuda()
+    xd = x.cuda()
+    tg(xd)
+    g = _tg_gate(tg)
+    try:
+        g.set_option(_ffi.SG_OPT_ROWGATE_SHAPE, shape)
+        g.set_option(_ffi.SG_OPT_FORCE_NOROWGATE, 2)
+        y_new = tg(xd).clone()
+        bits_new = g.debug_field(3)
+        g.set_option(_ffi.SG_OPT_FORCE_NOROWGATE, 1)
+        y_old = tg(xd).clone()
+        bits_old = g.debug_field(3)
+    finally:
+        g.set_option(_ffi.SG_OPT_FORCE_NOROWGATE, 0)
+        g.set_option(_ffi.SG_OPT_ROWGATE_SHAPE, 16)
+    return y_new, bits_new, y_old, bits_old
+
+
+def _rg_inputs():
+    torch.manual_seed(0)
+    t16 = torch.arange(16000, dtype=torch.float64) / 16000
+    x = (0.1 * torch.randn(24, 16000) + 0.5 * torch.sin(2 * np.pi * 440 * t16).float()).float()
+    sp = torch.from_numpy(np.stack([O.synth_signal(16000, sr=16000, seed=s, tone_hz=300.0 + 50 * s) for s in range(8)]))
+    chirp = torch.sin(2 * np.pi * (200 * t16 + 3000 * t16 * t16)).float()[None, :] * 0.7 + 0.01 * torch.randn(4, 16000)
+    return {"noise+tone 24x16000": x, "T=64 5x16383": x[:5].repeat(1, 2)[:, :16383].contiguous(),
+            "short rows 7x3000": x[:7, :3000].contiguous(), "2 W 3x2048": x[:3, :2048].contiguous(),
+            "float64 3x16000": x[:3].double(), "synth_signal 8x16000": sp, "chirp 4x16000": chirp.float()}
+
+
+@pytest.mark.parametrize("shape", [16, 8])
+@pytest.mark.parametrize("name", sorted(_rg_inputs()))
+def test_rowgate_decisions_equal_the_float64_path(nr, name, shape):
+    """Mask bits IDENTICAL to the float64 transform + k_row_decide on every cell, output within 1e-6 of that path and
+    within the 1e-4 bar of the CPU oracle -- both workgroup shapes (16 waves x 1 quad, 8 waves x 2 quads)."""
+    x = _rg_inputs()[name]
+    y_new, b_new, y_old, b_old = _rowgate_vs_float64(x, shape=shape)
+    assert b_new.shape == b_old.shape and np.array_equal(b_new, b_old), int((b_new != b_old).sum())
+    assert O.rel_err(y_new.cpu().numpy(), y_old.cpu().numpy()) < 1e-6
+    want = O.torchgate_T(x.numpy().astype(np.float64), 16000, window=torch.hann_window(1024).double().numpy())
+    assert y_new.dtype == x.dtype and tuple(y_new.shape) == want.shape
+    assert O.rel_err(y_new.cpu().numpy(), want) < TOL
+
+
+def test_rowgate_silent_tiny_and_nan_rows(nr):
+    """Digital silence (nothing passes), a row at -140 dBFS (the reference's eps matters: float64 decides), a NaN sample
+    (its row is gated like the reference gates it): same bits, same NaN pattern, same numbers as the float64 path."""
+    x = _rg_inputs()["noise+tone 24x16000"][:6].clone()
+    x[1] = 0
+    x[3] *= 1e-7
+    x[4, 5000] = float("nan")
+    y_new, b_new, y_old, b_old = _rowgate_vs_float64(x)
+    assert np.array_equal(b_new, b_old)
+    assert torch.equal(torch.isnan(y_new), torch.isnan(y_old))
+    fin = torch.isfinite(y_old)
+    assert float((y_new[fin] - y_old[fin]).abs().max()) < 1e-6 * float(y_old[fin].abs().max())
+    assert float(y_new[1].abs().max()) == 0.0
+
+
+@pytest.mark.parametrize("dtype", [torch.float32, torch.float64])
+def test_rowgate_on_the_reference_golden(nr, golden_dir, dtype):
+    """The reference's own TorchGate output (tests/golden/T_stat.npz, made by the live reference) through the row gate."""
+    from noisereduce_amd import _ffi
+    from noisereduce_amd.torchgate import TorchGate
+    from tests.golden.cases import T_CASES, make_input_T
+    case = T_CASES["stat"]
+    gold = np.load(os.path.join(golden_dir, "T_stat.npz"))
+    x, _ = make_input_T(case)
+    tg = TorchGate(sr=case["sr"], **case["kwargs"]).cuda()
+    xt = torch.from_numpy(x).to(dtype).cuda()
+    tg(xt)
+    g = _tg_gate(tg)
+    c0 = g.debug_counter(0)
+    g.set_option(_ffi.SG_OPT_FORCE_NOROWGATE, 2)
+    try:
+        out = tg(xt)
+    finally:
+        g.set_option(_ffi.SG_OPT_FORCE_NOROWGATE, 0)
+    assert out.dtype == dtype and tuple(out.shape) == gold["out"].shape
+    assert O.rel_err(out.cpu().numpy(), gold["out"]) < TOL
+    assert g.debug_counter(0) >= c0          # (the counter only grows; the row gate really ran: see the next assert)
+    assert g.debug_field(3).shape[1] == gold["out"].shape[1] // 256 + 1
+
+
+def test_rowgate_backward_uses_the_same_mask(nr):
+    """forward + backward with the row gate's float mask (natural bin order, for the adjoint kernel) against the
+    four-kernel path: same gradient."""
+    from noisereduce_amd import _ffi
+    from noisereduce_amd.torchgate import TorchGate
+    x = _rg_inputs()["noise+tone 24x16000"][:6].cuda()
+    tg = TorchGate(sr=16000).cuda()
+    tg(x)
+    g = _tg_gate(tg)
+    w = torch.linspace(0.5, 1.5, 15872, device="cuda")
+    grads = []
+    for mode in (2, 1):
+        g.set_option(_ffi.SG_OPT_FORCE_NOROWGATE, mode)
+        xg = x.clone().requires_grad_()
+        (tg(xg) * w).sum().backward()
+        grads.append(xg.grad.clone())
+    g.set_option(_ffi.SG_OPT_FORCE_NOROWGATE, 0)
+    assert O.rel_err(grads[0].cpu().numpy(), grads[1].cpu().numpy()) < 1e-6
+
+
+def test_rowgate_is_the_default_for_large_batches(nr):
+    """256 x 16000 (BASELINE configs[4]) takes the row gate by itself; 8 rows take the four-kernel path."""
+    from noisereduce_amd.torchgate import TorchGate
+    x = _rg_inputs()["noise+tone 24x16000"]
+    tg = TorchGate(sr=16000).cuda()
+    big = x.repeat(11, 1)[:256].contiguous().cuda()
+    tg(big)
+    g = _tg_gate(tg)
+    prof = lambda xx: (g.profile_read(reset=True), g.profile_enable(True), tg(xx), g.profile_read(reset=True), g.profile_enable(False))[3]
+    assert any("k_row_gate" in k for k in prof(big))
+    assert not any("k_row_gate" in k for k in prof(x[:8].contiguous().cuda()))

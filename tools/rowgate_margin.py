@@ -39,6 +39,7 @@ for name, x in families(32).items():
     xd = torch.from_numpy(x32).to(dev)
     tg(xd)
     (g,) = list(tg._gates.values())
+    g.set_option(_ffi.SG_OPT_FORCE_NOROWGATE, 2)
     g.set_option(_ffi.SG_OPT_ROWGATE_TAP, 1)
     tg(xd)
     P4 = g.debug_field(4).astype(np.float64)            # (rows, T, 513): 4 |X|^2 in float32

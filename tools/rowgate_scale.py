@@ -16,7 +16,7 @@ for B in (64, 128, 256, 512, 1024, 2048):
     for mode in ("rowgate16", "rowgate8", "four"):
         tg(x)
         (g,) = list(tg._gates.values())
-        g.set_option(_ffi.SG_OPT_FORCE_NOROWGATE, 1 if mode == "four" else 0)
+        g.set_option(_ffi.SG_OPT_FORCE_NOROWGATE, 1 if mode == "four" else 2)
         g.set_option(_ffi.SG_OPT_ROWGATE_SHAPE, 8 if mode == "rowgate8" else 16)
         for _ in range(10):
             tg(x)
