@@ -295,8 +295,8 @@ def main():
         __graft_entry__.build()
     if world > 1:
         dist.barrier()
-    from noisereduce_amd.sharded import (ChannelShardedStationary, HipStationaryBackend, TimeShardedStationary,
-                                         alloc_shard, with_halos)
+    from noisereduce_amd.sharded import (ChannelShardedStationary, HipStationaryBackend, TimeShardedNonStationary,
+                                         TimeShardedStationary, alloc_shard, hip_nonstationary_filter, with_halos)
     from noisereduce_amd.spectralgate.nonstationary import SpectralGateNonStationary, iir_coefficient
     from oracle import spectralgate_oracle as O   # checker only, never inside the timed region
 
@@ -348,6 +348,9 @@ def main():
             thresh_n_mult_nonstationary=2, sigmoid_slope_nonstationary=10, tmp_folder=None,
             prop_decrease=1.0, use_tqdm=False, n_jobs=1, device=device)._gate
 
+    tsn = TimeShardedNonStationary(hip_nonstationary_filter(nonstat_gate, CHUNK), CHUNK, PAD) if wl == "config3" else None
+    ts_objs = [TimeShardedStationary(b, NFFT // 2 + 1) for b in backends] if wl == "config2" else []
+
     def engine_gate():
         return nonstat_gate if wl == "config3" else backend._gate()
 
@@ -359,16 +362,15 @@ def main():
         if wl == "config2":
             i = step_no[0] % n_streams
             step_no[0] += 1
+            # (defer_check: the gathered shard layout of step k is validated at the start of step k + 1 -- by every rank --
+            # and after the last step by finish(): no host synchronisation inside a step)
             if n_streams > 1:
                 with torch.cuda.stream(streams[i]):
-                    return TimeShardedStationary(backends[i], NFFT // 2 + 1).run(
-                        y2d if i == 0 or world == 1 else exts[i][:, PAD:PAD + N_PER_GPU],
-                        ext=exts[i] if world > 1 else None)
-            return TimeShardedStationary(backend, NFFT // 2 + 1).run(y2d, ext=y_ext if world > 1 else None)
-        ext = with_halos(y2d, PAD, ext=y_ext) if world > 1 else None
-        if ext is None:
-            return nonstat_gate.process_chunks(y2d, chunked=True)
-        return nonstat_gate.process_chunks(ext, out_dtype=y.dtype, chunked=True, halo_left=PAD, halo_right=PAD)
+                    return ts_objs[i].run(y2d if i == 0 or world == 1 else exts[i][:, PAD:PAD + N_PER_GPU],
+                                          ext=exts[i] if world > 1 else None, defer_check=True)
+            return ts_objs[0].run(y2d, ext=y_ext if world > 1 else None, defer_check=True)
+        # configs[2]: the non-stationary gate, time-sharded: the seam all-gather is its only exchange
+        return tsn.run(y2d, ext=y_ext if world > 1 else None, defer_check=True)
 
     def sync():
         if world > 1:
@@ -427,6 +429,8 @@ def main():
         marks[args.steps].record()
     sync()
     elapsed = time.perf_counter() - t0
+    for o in ts_objs + ([tsn] if tsn is not None else []):
+        o.finish()          # the deferred verdict on the last step's shard layout (outside the timed region)
     profs = [gate.profile_read(reset=True)]
     gate.profile_enable(False)
     gate.profile_select(None)

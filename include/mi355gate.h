@@ -104,7 +104,11 @@ SG_API int sg_output_length(const sg_handle* h, int64_t L, int64_t* out_len);
  * (base.py:180-216 streams through a memmap instead; here units are processed in batches bounded by
  * sg_params.max_workspace_bytes).  An upper bound: it includes the exchange buffers of the fused kernels and the
  * float32 copy that a recording of another sample type (int16 / int32 / float64) costs on the default geometry --
- * C * N * 4 bytes, which a float32 recording does not pay.  Pure host arithmetic, no device work. */
+ * C * N * 4 bytes, which a float32 recording does not pay.  The entry point does not know the sample type of the call
+ * to come: unless SG_OPT_FAST_INTEGER is set (and SG_OPT_FORCE_EXACT clear) it reports the LARGER of the fused float32
+ * pipeline and the float64 pipeline that integer outputs take by default (32 bytes per time-frequency cell plus float64
+ * frames, batched under max_workspace_bytes / the 8 GiB default); with SG_OPT_FORCE_EXACT, the float64 figure.
+ * Pure host arithmetic, no device work. */
 SG_API int sg_workspace_bytes(const sg_handle* h, int64_t C, int64_t N, int32_t chunked, int64_t* bytes);
 
 /* ---- variant S -------------------------------------------------------------------- */

@@ -5,6 +5,7 @@ PyTorch-ROCm tensors are only the I/O container: this module passes
 fallback: if the shared library is missing, or no MI355X/HIP device is visible, the
 calls raise.
 """
+import contextlib
 import ctypes
 import os
 import threading
@@ -353,6 +354,24 @@ class Gate:
 
     def set_option(self, option, value):
         self._check(self.lib.sg_set_option(self._h, int(option), int(value)))
+        self.__dict__.setdefault("_opts", {})[int(option)] = int(value)
+
+    def get_option(self, option):
+        """The value last set through set_option on this (shared, cached) handle; 0 if never set."""
+        return self.__dict__.get("_opts", {}).get(int(option), 0)
+
+    @contextlib.contextmanager
+    def with_options(self, pairs):
+        """`with g.with_options([(SG_OPT_X, 1), ...]):` -- sets the options and RESTORES their previous values (the
+        handle is shared between objects: a user's or a test's setting must survive somebody else's retry)."""
+        prev = [(o, self.get_option(o)) for o, _ in pairs]
+        try:
+            for o, v in pairs:
+                self.set_option(o, v)
+            yield self
+        finally:
+            for o, v in prev:
+                self.set_option(o, v)
 
     def check_errors(self):
         """Synchronise the current stream and raise HandoffTimeout if a launch enqueued on this handle since the
@@ -365,20 +384,22 @@ class Gate:
         without in-launch hand-offs (three-kernel gate, apply + seam kernel).  For callers that synchronise
         anyway (host arrays out); holds the handle's lock."""
         with self.lock:
+            # an error left behind by an EARLIER unchecked (tensor-in / tensor-out) call on this shared handle belongs to
+            # that call: report it as such instead of "fixing" it with a retry of this one
+            try:
+                self.check_errors()
+            except HandoffTimeout as e:
+                raise HandoffTimeout("an earlier, unchecked call on this engine handle lost a tile hand-off (its output "
+                                     "is invalid); this call has not run: " + str(e)) from None
             try:
                 out = fn()
                 self.check_errors()
                 return out
             except HandoffTimeout:
-                self.set_option(SG_OPT_FORCE_SPLIT, 1)
-                self.set_option(SG_OPT_FORCE_NOLEAN, 1)
-                try:
+                with self.with_options([(SG_OPT_FORCE_SPLIT, 1), (SG_OPT_FORCE_NOLEAN, 1)]):
                     out = fn()
                     self.check_errors()
                     return out
-                finally:
-                    self.set_option(SG_OPT_FORCE_SPLIT, 0)
-                    self.set_option(SG_OPT_FORCE_NOLEAN, 0)
 
     # -- per-kernel timing -----------------------------------------------------------
     def profile_enable(self, on=True):

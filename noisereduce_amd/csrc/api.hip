@@ -2025,12 +2025,19 @@ static hipError_t xapply_any(sg_handle* h, const View& v, const Geom& g, int64_t
   return hipErrorInvalidValue;
 }
 
+// float64 pipeline (exact.hpp): bytes per unit -- P, raw, M, tmp (8 B per cell each) + frames (8 B per sample of every
+// frame) + the statistics rows -- and units per batch.  Shared with sg_workspace_bytes.
+static size_t exact_unit_bytes(const Geom& g) {
+  return (size_t)g.T * g.FS * 32 + (size_t)g.T * g.n * 8 + (size_t)g.FS * 16;
+}
+static int64_t exact_units_per_batch(const sg_handle* h, const Geom& g, int64_t total_units) {
+  return std::max<int64_t>(1, std::min<int64_t>(std::min<int64_t>(ws_budget(h) / (int64_t)exact_unit_bytes(g), 32768), total_units));
+}
+
 static int run_S_exact(sg_handle* h, View v, int64_t total_units, const OutMap& om, hipStream_t st) {
   const Geom g = make_geom(h, v.Lp);
   const size_t cells1 = (size_t)g.T * g.FS;
-  // P, raw, M, tmp (8 B per cell each) + frames (8 B per sample of every frame) + the statistics rows
-  const size_t per_unit = cells1 * 32 + (size_t)g.T * g.n * 8 + (size_t)g.FS * 16;
-  int64_t ub = std::max<int64_t>(1, std::min<int64_t>(std::min<int64_t>(ws_budget(h) / (int64_t)per_unit, 32768), total_units));
+  int64_t ub = exact_units_per_batch(h, g, total_units);
   int rc;
   const size_t cells = (size_t)ub * cells1;
   if ((rc = ensure(h, h->xP, cells * 8))) return rc;
@@ -2318,6 +2325,16 @@ extern "C" int sg_workspace_bytes(const sg_handle* h, int64_t C, int64_t N, int3
   if (h->big_M) {   // long frames: two work buffers of <= 256 MB (big.hpp)
     const int64_t nb = big_batch(h, units * g.T);
     total += 2 * nb * (int64_t)h->big_M * (int64_t)sizeof(big::cd);
+  }
+  // Integer (SG_I16 / SG_I32) outputs take the float64 pipeline by default, SG_OPT_FORCE_EXACT selects it for every dtype
+  // (run_S_exact: 32 B per cell + float64 frames).  The entry point has no dtype argument, so the figure is the LARGER
+  // of the two pipelines unless the handle can never take the float64 one for this call (SG_OPT_FAST_INTEGER set and
+  // SG_OPT_FORCE_EXACT clear) -- an upper bound, as documented in the header.
+  if (h->p.variant == SG_VARIANT_S && (h->force_exact || !h->fast_integer)) {
+    int64_t ex = exact_units_per_batch(h, g, units) * (int64_t)exact_unit_bytes(g);
+    if (h->big_M) ex += 2 * big_batch(h, units * g.T) * (int64_t)h->big_M * (int64_t)sizeof(big::cd);
+    if (h->force_exact) total = ex;
+    else total = std::max(total, ex);
   }
   *bytes = total;
   return SG_OK;

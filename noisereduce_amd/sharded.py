@@ -183,7 +183,16 @@ def _check_shard_lengths(lens, chunk_size, padding):
                              f"({padding})")
 
 
-def exchange_seams_and_threshold(y_local, padding, thr, n_bins, group=None, bufs=None, chunk_size=None):
+def flush_pending(bufs):
+    """Deferred mode: raise the verdict on the LAST call's gathered shard lengths (every rank alike).  Call it after the
+    last `exchange_seams_and_threshold(..., defer=True)` of a loop; a no-op when nothing is pending."""
+    if bufs is not None and bufs.get("pending") is not None:
+        host, ev, pcs, ppad = bufs.pop("pending")
+        ev.synchronize()
+        _check_shard_lengths(host.tolist(), pcs, ppad)
+
+
+def exchange_seams_and_threshold(y_local, padding, thr, n_bins, group=None, bufs=None, chunk_size=None, defer=False):
     """ONE all-gather carrying every rank's shard length, seam samples and rank 0's threshold.
     Each rank contributes [int64 shard length | first `padding` | last `padding` samples of every channel
     | n_bins float64] as raw bytes (only rank 0's threshold slot is meaningful).  Returns
@@ -191,12 +200,17 @@ def exchange_seams_and_threshold(y_local, padding, thr, n_bins, group=None, bufs
     recording; thr float64 (n_bins,).
     No rank raises BEFORE the collective (the others would block in it until the RCCL timeout): a shard
     shorter than `padding` sends zero-filled seams, `thr=None` on rank 0 (its statistics failed) travels as a
-    negative length, and the shard layout is validated from the GATHERED lengths -- the same verdict on every rank.
-    `bufs`: optional dict that keeps the send/receive buffers between calls.  With it the gathered lengths of call k
-    are validated without a host synchronisation: copied to page-locked memory asynchronously and checked at the
-    START of call k + 1, before its collective -- by every rank, so a layout that turns bad on ONE rank (whose
-    own length the others cannot see) still makes every rank raise together, one call late; a rank whose own
-    length or layout key changed validates immediately (first call: always)."""
+    negative length AND a NaN threshold (a NaN threshold gates everything: no rank can filter with a stale one), and
+    the shard layout is validated from the GATHERED lengths.  The verdict is SYMMETRIC: every rank takes the same
+    branch, which depends on `defer` only (never on what a single rank knows about its own shard):
+      * defer=False (default): every rank reads the gathered lengths back (one small device-to-host copy) and
+        validates them in THIS call -- every rank raises in the same call, or none does;
+      * defer=True (hot loops; needs `bufs`): the lengths go to page-locked memory asynchronously and are validated by
+        every rank at the START of its next call, before that call's collective, or by `flush_pending(bufs)` after the
+        last one -- every rank raises one call late, together.  The call with the bad layout has already produced its
+        (wrong) output by then: callers that use `defer` treat the result of call k as valid once call k + 1 or the
+        flush has returned.
+    `bufs`: optional dict that keeps the send/receive buffers between calls."""
     ws, rank = dist.get_world_size(group), dist.get_rank(group)
     C, S = y_local.shape
     es = y_local.element_size()
@@ -205,18 +219,14 @@ def exchange_seams_and_threshold(y_local, padding, thr, n_bins, group=None, bufs
     sb = HDR + (seam_bytes + 7) // 8 * 8                # threshold slot 8-byte aligned
     total = sb + n_bins * 8
     key = (total, ws, y_local.device)
-    if bufs is not None and bufs.get("pending") is not None:
-        # verdict on the previous call's gathered lengths (arrived long ago: no stall); raised by every rank alike
-        host, ev, pcs, ppad = bufs.pop("pending")
-        ev.synchronize()
-        _check_shard_lengths(host.tolist(), pcs, ppad)
+    flush_pending(bufs)     # verdict on the previous deferred call (arrived long ago: no stall); every rank alike
     if bufs is not None and bufs.get("key") == key:
         send, recv = bufs["send"], bufs["recv"]
     else:
         send = torch.zeros(total, dtype=torch.uint8, device=y_local.device)
         recv = torch.empty(ws * total, dtype=torch.uint8, device=y_local.device)
         if bufs is not None:
-            bufs.update(key=key, send=send, recv=recv, checked=None, len_dev=None)
+            bufs.update(key=key, send=send, recv=recv, len_dev=None)
     S_hdr = S if (rank != 0 or thr is not None) else -S - 1      # rank 0 without a threshold: failure marker
     if bufs is None or bufs.get("len_dev") != S_hdr:
         send[:HDR].view(torch.int64).fill_(S_hdr)
@@ -232,16 +242,15 @@ def exchange_seams_and_threshold(y_local, padding, thr, n_bins, group=None, bufs
             if S:
                 seams[0][:, :S].copy_(y_local)
                 seams[1][:, padding - S:].copy_(y_local)
-    if rank == 0 and thr is not None:
-        send[sb:].view(torch.float64).copy_(thr)
+    if rank == 0:
+        if thr is not None:
+            send[sb:].view(torch.float64).copy_(thr)
+        else:
+            send[sb:].view(torch.float64).fill_(float("nan"))    # never a stale threshold from an earlier call
     dist.all_gather_into_tensor(recv, send, group=group)
     recv = recv.view(ws, total)
     hdr = recv[:, :HDR].contiguous().view(torch.int64).flatten()
-    if bufs is None or bufs.get("checked") != (S_hdr, chunk_size, padding):
-        _check_shard_lengths(hdr.cpu().tolist(), chunk_size, padding)   # one host sync: first call / own layout changed
-        if bufs is not None:
-            bufs["checked"] = (S_hdr, chunk_size, padding)
-    elif hdr.is_cuda:
+    if defer and bufs is not None and hdr.is_cuda:
         host = bufs.get("hdr_host")
         if host is None or host.numel() != ws:
             host = bufs["hdr_host"] = torch.empty(ws, dtype=torch.int64).pin_memory()
@@ -250,7 +259,7 @@ def exchange_seams_and_threshold(y_local, padding, thr, n_bins, group=None, bufs
         ev.record()
         bufs["pending"] = (host, ev, chunk_size, padding)
     else:
-        _check_shard_lengths(hdr.tolist(), chunk_size, padding)         # CPU tensors (gloo tests): nothing to defer
+        _check_shard_lengths(hdr.cpu().tolist(), chunk_size, padding)   # every rank, this call
     thr_out = recv[0, sb:].view(torch.float64)
 
     def seam_of(r, which):
@@ -277,9 +286,15 @@ class TimeShardedStationary:
         # per-call object
         self._bufs = backend.__dict__.setdefault("_xchg_bufs", {})
 
-    def run(self, y_local, ext=None):
+    def finish(self):
+        """After a loop of run(..., defer_check=True): the verdict on the last call's shard layout (every rank)."""
+        flush_pending(self._bufs)
+
+    def run(self, y_local, ext=None, defer_check=False):
         """y_local: this rank's (C, S) shard.  ext: optional halo-extended buffer that already
-        holds the shard in its middle (alloc_shard) -- avoids copying the shard every call."""
+        holds the shard in its middle (alloc_shard) -- avoids copying the shard every call.
+        defer_check: validate the gathered shard layout one call late (no host synchronisation in this call; see
+        exchange_seams_and_threshold) -- for hot loops that end with finish()."""
         if y_local.dim() == 1:
             y_local = y_local[None, :]
         pad, cs = self.backend.padding, self.backend.chunk_size
@@ -303,7 +318,7 @@ class TimeShardedStationary:
                     thr_err = e
             try:
                 left, right, thr = exchange_seams_and_threshold(y_local, pad, thr, self.n_bins, self.group,
-                                                                self._bufs, chunk_size=cs)
+                                                                self._bufs, chunk_size=cs, defer=defer_check)
             except ValueError:
                 if thr_err is not None:
                     raise thr_err
@@ -318,6 +333,57 @@ class TimeShardedStationary:
                 ext[:, :pad].copy_(left)
                 ext[:, pad + S:].copy_(right)
             return self.backend.filter(y_local, ext, pad, thr, owner=self.rank == 0)
+
+
+class TimeShardedNonStationary:
+    """reduce_noise(stationary=False) of a recording that is time-sharded over the ranks of `group`.  The gate has no
+    state shared between chunks (nonstationary.py:47-97: floor, sigmoid mask and smoothing are per chunk window), so
+    the ONLY exchange is the seam all-gather that lets chunk windows reach `padding` samples into the neighbouring
+    shards (base.py:144-156) -- no threshold, nothing else.  `filter_fn(ext, halo, out_dtype) -> (C, S)` is the
+    compute step: the HIP engine's `process_chunks` in production (hip_nonstationary_filter), the oracle in the CPU
+    tests.  The shard layout is validated like the stationary gate's (same header, same verdict on every rank)."""
+
+    def __init__(self, filter_fn, chunk_size, padding, group=None):
+        self.filter_fn = filter_fn
+        self.chunk_size, self.padding = chunk_size, padding
+        self.group = group
+        self.ws = dist.get_world_size(group) if dist.is_initialized() else 1
+        self.rank = dist.get_rank(group) if dist.is_initialized() else 0
+        self._bufs = {}
+
+    def finish(self):
+        flush_pending(self._bufs)
+
+    def run(self, y_local, ext=None, defer_check=False):
+        if y_local.dim() == 1:
+            y_local = y_local[None, :]
+        pad, S = self.padding, y_local.shape[1]
+        if self.ws == 1:
+            return self.filter_fn(y_local, 0, y_local.dtype)
+        # the threshold slot of the shared exchange stays empty (0 bins); rank 0 "has" its (non-existent) threshold
+        left, right, _ = exchange_seams_and_threshold(y_local, pad, torch.empty(0, dtype=torch.float64, device=y_local.device),
+                                                      0, self.group, self._bufs, chunk_size=self.chunk_size,
+                                                      defer=defer_check)
+        if S == 0:
+            return y_local.new_empty((y_local.shape[0], 0))
+        if pad == 0:
+            return self.filter_fn(y_local, 0, y_local.dtype)
+        if ext is None:
+            ext = torch.cat([left, y_local, right], dim=1)
+        else:
+            ext[:, :pad].copy_(left)
+            ext[:, pad + S:].copy_(right)
+        return self.filter_fn(ext, pad, y_local.dtype)
+
+
+def hip_nonstationary_filter(gate, chunk_size):
+    """filter_fn of TimeShardedNonStationary on the HIP engine: `gate` is the _ffi.Gate of a SpectralGateNonStationary
+    (its chunk grid reads the halos as real neighbour samples)."""
+    def fn(ext, halo, out_dtype):
+        if halo == 0:
+            return gate.process_chunks(ext, chunked=chunk_size is not None and ext.shape[1] > chunk_size)
+        return gate.process_chunks(ext, out_dtype=out_dtype, chunked=True, halo_left=halo, halo_right=halo)
+    return fn
 
 
 class ChannelShardedStationary:

@@ -4,6 +4,8 @@ streamer feeding each (C, chunk+2*padding) float64 window to ``TorchGate`` as a 
 (streamed_torch_gate.py:81-87).  Here the recording stays in HBM: each padded chunk is a
 strided view of the uploaded signal (zero-extended once), so there is no per-chunk
 host<->device copy."""
+import contextlib
+
 import numpy as np
 import torch
 
@@ -64,22 +66,24 @@ class StreamedTorchGate(SpectralGate):
         if self._tensor_io:
             return self._get_traces(start_frame, end_frame)
         gates = lambda: list(self.tg._gates.values())
-        try:
-            out = self._get_traces(start_frame, end_frame)
+        with contextlib.ExitStack() as held:
+            # the cached engine handles are shared between objects: run -> check -> (retry with other options) is one
+            # critical section per handle, and the options a user or a test had set are restored afterwards
             for g in gates():
-                g.check_errors()
-            return out
-        except _ffi.HandoffTimeout:
-            for g in gates():
-                g.set_option(_ffi.SG_OPT_FORCE_NOLEAN, 1)
+                held.enter_context(g.lock)
             try:
                 out = self._get_traces(start_frame, end_frame)
                 for g in gates():
                     g.check_errors()
                 return out
-            finally:
-                for g in gates():
-                    g.set_option(_ffi.SG_OPT_FORCE_NOLEAN, 0)
+            except _ffi.HandoffTimeout:
+                with contextlib.ExitStack() as opts:
+                    for g in gates():
+                        opts.enter_context(g.with_options([(_ffi.SG_OPT_FORCE_NOLEAN, 1)]))
+                    out = self._get_traces(start_frame, end_frame)
+                    for g in gates():
+                        g.check_errors()
+                    return out
 
     def _get_traces(self, start_frame=None, end_frame=None):
         if start_frame is None:

@@ -222,3 +222,25 @@ def test_rowgate_is_the_default_for_large_batches(nr):
     prof = lambda xx: (g.profile_read(reset=True), g.profile_enable(True), tg(xx), g.profile_read(reset=True), g.profile_enable(False))[3]
     assert any("k_row_gate" in k for k in prof(big))
     assert not any("k_row_gate" in k for k in prof(x[:8].contiguous().cuda()))
+
+
+def test_workspace_bytes_covers_the_float64_pipeline(nr):
+    """sg_workspace_bytes is an upper bound for EVERY sample type of the call to come -- an int16 recording
+    takes the float64 pipeline (32 B per cell + float64 frames); the figure must not be the few MB of the bit-mask path."""
+    from noisereduce_amd import _ffi
+    from noisereduce_amd.spectralgate.stationary import SpectralGateStationary
+    y16 = (O.synth_signal(300000, seed=9) * 20000).astype(np.int16)
+    kw = dict(sr=48000, y_noise=None, n_std_thresh_stationary=1.5, clip_noise_stationary=True, prop_decrease=1.0,
+              chunk_size=100000, padding=8000, n_fft=1024, win_length=None, hop_length=None, time_constant_s=2.0,
+              freq_mask_smooth_hz=500, time_mask_smooth_ms=50, tmp_folder=None, use_tqdm=False, n_jobs=1)
+    sg = SpectralGateStationary(y=torch.from_numpy(y16).cuda(), **kw)
+    est = sg._gate.workspace_bytes(1, 300000, chunked=True)
+    T, FS, units = 116000 // 256 + 1, 528, 3
+    exact = units * (T * FS * 32 + T * 1024 * 8 + FS * 16)
+    assert est >= exact, (est, exact)
+    free0 = torch.cuda.mem_get_info()[0]
+    out = sg.get_traces()
+    torch.cuda.synchronize()
+    used = free0 - torch.cuda.mem_get_info()[0]
+    assert out.dtype == torch.int16
+    assert used <= est + (64 << 20), (used, est)      # what the call really allocated (allocator granularity aside)
