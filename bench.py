@@ -58,6 +58,9 @@ N_PER_GPU = SR * SECONDS            # 28.8 M samples
 CHUNK, PAD, NFFT, HOP = 600000, 30000, 1024, 256
 ALGO_BYTES_PER_SAMPLE = 8           # 4 B float32 read + 4 B float32 written
 HBM_PEAK_GBS = 8000.0               # MI355X_MICROARCH.md: 8 TB/s spec
+VALU_PEAK_TFLOPS = 157.3            # MI355X_MICROARCH.md: float32 vector peak (2.4 GHz)
+ALGO_FLOPS_PER_SAMPLE = 450         # two 1024-point real transforms per 256-sample hop, smoothing, log / compare / window / overlap-add
+TRAFFIC_DETAIL = "profiles/r04_traffic_detail.json"   # rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes (tools/gpu_traffic.sh), committed
 C4_CHANNELS, C4_SAMPLES = 8, SR * 1800   # configs[3]: one GPU's share
 
 
@@ -545,7 +548,14 @@ def main():
                          "traffic_source": traffic_src,
                          "avg_launch_ms": round(avg_ms, 4), "algorithmic_bytes_per_launch": int(algo_bytes),
                          "whole_step_frac": round(value * 1e6 / world * ALGO_BYTES_PER_SAMPLE / 1e9
-                                                  / HBM_PEAK_GBS, 5)},
+                                                  / HBM_PEAK_GBS, 5),
+                         # the binding resource of this kernel is the float32 vector pipe, not HBM:
+                         "valu": {"achieved": round(ALGO_FLOPS_PER_SAMPLE * samples_per_gpu / launches_per_step / (avg_ms * 1e-3) / 1e12, 2),
+                                  "peak": VALU_PEAK_TFLOPS, "unit": "TFLOP/s",
+                                  "frac": round(ALGO_FLOPS_PER_SAMPLE * samples_per_gpu / launches_per_step / (avg_ms * 1e-3) / 1e12
+                                                / VALU_PEAK_TFLOPS, 4),
+                                  "basis": "algorithmic flops (%d per sample, SURVEY.md 8(d)) / dominant-kernel time"
+                                           % ALGO_FLOPS_PER_SAMPLE}},
             "kernel_ms_per_step": {k: round(v[0] / survey_steps, 4) for k, v in
                                    sorted(survey.items(), key=lambda kv: -kv[1][0])},
         }
@@ -569,6 +579,47 @@ def main():
     if world > 1:
         dist.barrier()
         dist.destroy_process_group()
+
+
+def _roofline_of(gate, fn, samples, ms_median, traffic_keys):
+    """`roofline` of one of the other configs: algorithmic bytes / median call time against the HBM peak, the dominant
+    kernel of the call (HIP events around every launch of 5 calls), the float32-vector fraction of that kernel, and the
+    committed PMC traffic of the call's kernels (TRAFFIC_DETAIL: NOT measured in this run)."""
+    gate.profile_read(reset=True)
+    gate.profile_select(None)
+    gate.profile_enable(True)
+    for _ in range(5):
+        fn()
+    pr = gate.profile_read(reset=True)
+    gate.profile_enable(False)
+    dom = max(pr, key=lambda k: pr[k][0])
+    dom_ms = pr[dom][0] / max(pr[dom][1], 1)
+    algo = ALGO_BYTES_PER_SAMPLE * samples
+    r = {"bound": "hbm", "achieved": round(algo / (ms_median * 1e-3) / 1e9, 2), "peak": HBM_PEAK_GBS, "unit": "GB/s",
+         "frac": round(algo / (ms_median * 1e-3) / 1e9 / HBM_PEAK_GBS, 5), "basis": "whole call (median of the HIP-event-timed "
+         "repetitions): this config runs several kernels per call", "algorithmic_bytes_per_call": int(algo),
+         "kernel": dom, "kernel_avg_launch_ms": round(dom_ms, 4),
+         "kernel_ms_per_call": {k: round(v[0] / 5, 4) for k, v in sorted(pr.items(), key=lambda kv: -kv[1][0])},
+         "valu": {"achieved": round(ALGO_FLOPS_PER_SAMPLE * samples / (ms_median * 1e-3) / 1e12, 2), "peak": VALU_PEAK_TFLOPS,
+                  "unit": "TFLOP/s", "frac": round(ALGO_FLOPS_PER_SAMPLE * samples / (ms_median * 1e-3) / 1e12 / VALU_PEAK_TFLOPS, 4),
+                  "basis": "algorithmic flops (%d per sample, SURVEY.md 8(d)) / whole call" % ALGO_FLOPS_PER_SAMPLE},
+         "traffic": None, "traffic_source": None}
+    try:
+        td = json.load(open(os.path.join(ROOT, TRAFFIC_DETAIL)))["kernels"]
+        tot, used = 0, []
+        for key in traffic_keys:
+            for kn, v in td.items():
+                if kn.startswith(key):
+                    tot += v["total_bytes"]
+                    used.append(kn)
+        if used:
+            r["traffic"] = int(tot)
+            r["traffic_over_algorithmic"] = round(tot / algo, 2)
+            r["traffic_source"] = TRAFFIC_DETAIL + ": per-launch FETCH_SIZE (x2 corrected) + WRITE_SIZE of " + ", ".join(used) + \
+                " -- committed rocprofv3 --pmc passes, NOT measured in this run"
+    except Exception:
+        pass
+    return r
 
 
 def _time_events(fn, warm, reps):
@@ -619,6 +670,17 @@ def extras(device, wl, out, y2d, gate, O):
     oc["config3_nonstationary"] = {"ms_median": round(med, 4), "ms_mean": round(mean, 4), "ms_per_rep": reps3,
                                    "Msamples_s": round(y.numel() / (med * 1e-3) / 1e6, 1),
                                    "what": "configs[2]: same recording, stationary=False, device-resident"}
+    try:
+        from noisereduce_amd.spectralgate.nonstationary import SpectralGateNonStationary
+        ns = SpectralGateNonStationary(y=y, sr=SR, chunk_size=CHUNK, padding=PAD, n_fft=NFFT, win_length=None, hop_length=None,
+                                       time_constant_s=2.0, freq_mask_smooth_hz=500, time_mask_smooth_ms=50,
+                                       thresh_n_mult_nonstationary=2, sigmoid_slope_nonstationary=10, tmp_folder=None,
+                                       prop_decrease=1.0, use_tqdm=False, n_jobs=1, device=device)
+        oc["config3_nonstationary"]["roofline"] = _roofline_of(
+            ns._gate, lambda: nr.reduce_noise(y=y, sr=SR, stationary=False), y.numel(), med,
+            ["k_mag_fast", "k_iir_part", "k_iir_chain", "k_iir_mask", "k_apply_fast<4, false, true>"])
+    except Exception as e:
+        oc["config3_nonstationary"]["roofline"] = {"error": repr(e)}
     torch.manual_seed(0)
     t = torch.arange(16000, device=device, dtype=torch.float64) / 16000
     x = (0.1 * torch.randn(256, 16000, device=device) + 0.5 * torch.sin(2 * np.pi * 440 * t).float()).float()
@@ -628,6 +690,12 @@ def extras(device, wl, out, y2d, gate, O):
                                        "ms_max": max(reps5),
                                        "Msamples_s": round(x.numel() / (med * 1e-3) / 1e6, 1),
                                        "what": "configs[4]: TorchGate(sr=16000) on 256 x 16000 float32"}
+    try:
+        (tgate,) = list(tg._gates.values())
+        oc["config5_torchgate_forward"]["roofline"] = _roofline_of(tgate, lambda: tg(x), x.numel(), med, ["k_row_gate"])
+        oc["config5_torchgate_forward"]["exact_pairs_per_call"] = (lambda c0: (tg(x), tgate.debug_counter(0) - c0)[1])(tgate.debug_counter(0))
+    except Exception as e:
+        oc["config5_torchgate_forward"]["roofline"] = {"error": repr(e)}
     xg = x.clone().requires_grad_()
 
     def fb():

@@ -149,6 +149,26 @@ T_NAN_CASES = {
 }
 
 
+# ---- an Inf sample.  The reference's result depends on which bins of its FFT come out Inf (the
+# band's chunk maximum is Inf: floor = Inf, the whole band PASSES in that chunk) and which NaN (np.max keeps the NaN:
+# the band is gated) -- pocketfft's butterfly order decides.  The oracle calls the same FFT and reproduces it; the
+# engine gates an Inf sample like a NaN (stated deviation): the goldens pin what is equal (the non-finite
+# output samples, every chunk the Inf does not reach) and what is not (the finite rest of the affected chunk).
+S_INF_CASES = {
+    "signal_chunks": dict(sr=48000, n=90000, seed=51, inf_at=40000, value=np.inf,
+                          kwargs=dict(stationary=True, chunk_size=25000, padding=4000)),
+    "signal_chunks_neg": dict(sr=48000, n=90000, seed=57, inf_at=61000, value=-np.inf,
+                              kwargs=dict(stationary=True, chunk_size=25000, padding=4000)),
+}
+
+
+def make_input_S_inf(case):
+    y, y_noise = make_input_S(case)
+    y = y.copy()
+    y[..., case["inf_at"]] = case["value"]
+    return y, y_noise
+
+
 def make_input_S_nan(case):
     y, y_noise = make_input_S(case)
     if "nan_at" in case:

@@ -173,3 +173,18 @@ def test_nan_sample_T_matches_reference(golden_dir, name):
     with np.errstate(all="ignore"):
         out = O.torchgate_T(x, case["sr"], xn=xn, window=g["window"], **case["kwargs"])
     assert nonfinite_agree(out, g["out"], TOL_T) is None, nonfinite_agree(out, g["out"], TOL_T)
+
+
+# ---- an Inf sample: the oracle calls the reference's own FFT, so it reproduces the reference's Inf / NaN pattern ----
+from tests.golden.cases import S_INF_CASES, make_input_S_inf  # noqa: E402
+
+
+@pytest.mark.parametrize("name", sorted(S_INF_CASES))
+def test_inf_sample_S_matches_reference(golden_dir, name):
+    case = S_INF_CASES[name]
+    g = _load(golden_dir, "S_inf_" + name)
+    y, y_noise = make_input_S_inf(case)
+    assert sha(y) == str(g["in_sha"])
+    with np.errstate(all="ignore"):
+        out = O.reduce_noise_S(y, case["sr"], y_noise=y_noise, **case["kwargs"])
+    assert nonfinite_agree(out, g["out"], 1e-9) is None, nonfinite_agree(out, g["out"], 1e-9)
