@@ -469,6 +469,37 @@ __host__ __device__ constexpr int reg0_of_entry(int e) {
   return e < 8 ? e : (e < 24 ? e + 8 : (e < 31 ? e - 15 : 8));
 }
 
+// Lane 0 of a frame owns the self-paired rows 0 and 16 of the transform (fastpath.hpp): its conjugate pairs sit in other
+// registers than the (s, 31 - s) pairs of lanes 1..15.  Instead of selecting operands per pair (which keeps both the
+// transform's 64 registers and the 64 split values alive),
+// lane 0 PERMUTES its registers once -- one 24-cycle walked in place with a single temporary -- so that afterwards
+// register index == entry index in every lane (bin_of_entry) and split / merge run in place on (v[s], v[31 - s]):
+//   new[1..7] = old[1..7], new[8..15] = old[16..23], new[16..23] = old[24..31], new[24..30] = old[9..15],
+//   new[31] = old[8] (bin 256), new[0] = old[0] (bins 0 / 512)
+__host__ __device__ constexpr int rg_cyc(int i) {   // position i of the cycle 8 <- 16 <- 24 <- 9 <- 17 <- 25 <- 10 ...
+  return (i % 3 == 0) ? 8 + i / 3 : ((i % 3 == 1) ? 16 + i / 3 : 24 + i / 3);
+}
+__device__ __forceinline__ void rg_lane0_to_entries(cf* v, bool l0) {
+  const cf t = v[rg_cyc(0)];
+#pragma unroll
+  for (int i = 0; i < 23; ++i) {
+    const cf s = v[rg_cyc(i + 1)], d = v[rg_cyc(i)];
+    v[rg_cyc(i)] = {l0 ? s.x : d.x, l0 ? s.y : d.y};
+  }
+  const cf d = v[rg_cyc(23)];
+  v[rg_cyc(23)] = {l0 ? t.x : d.x, l0 ? t.y : d.y};
+}
+__device__ __forceinline__ void rg_lane0_from_entries(cf* v, bool l0) {
+  const cf t = v[rg_cyc(23)];
+#pragma unroll
+  for (int i = 23; i >= 1; --i) {
+    const cf s = v[rg_cyc(i - 1)], d = v[rg_cyc(i)];
+    v[rg_cyc(i)] = {l0 ? s.x : d.x, l0 ? s.y : d.y};
+  }
+  const cf d = v[rg_cyc(0)];
+  v[rg_cyc(0)] = {l0 ? t.x : d.x, l0 ? t.y : d.y};
+}
+
 constexpr int OP_SPIN_MAX = 1 << 20;     // polls before a hand-off is declared lost (~1 s): no unbounded spin
 typedef unsigned short op_us2 __attribute__((ext_vector_type(2)));
 typedef unsigned op_v4u __attribute__((ext_vector_type(4)));

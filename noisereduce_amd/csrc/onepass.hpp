@@ -41,6 +41,11 @@ constexpr int OP_KP = 528;               // K row pitch (uint16 entries) of a wa
 #ifndef OP_TRACE
 #define OP_TRACE 0
 #endif
+#ifndef OP_INPLACE
+#define OP_INPLACE 0   // 1: split / merge in place after a one-off permutation of lane 0's registers (k_row_gate's formulation)
+                       // instead of operand selects per pair.  Round 4: same instruction count (96 + 8 v_cndmask either way),
+                       // same 168 VGPRs and SGPR spills in this kernel -- no gain here, kept for A/B builds
+#endif
 struct OnePassArgs {
   ApplyArgs A;              // view, geometry, output map, tables, seam buffer (A.K / A.Mf unused)
   View view_exact;          // the caller's samples in their own dtype (A.view may be a float32 copy): exact refinement
@@ -288,6 +293,40 @@ __global__ __launch_bounds__(WAVES * 64, 3) void k_gate_onepass(OnePassArgs P) {
   // X2n = E - w O (both 2x the spectrum; E = a + conj b, O = (a - conj b)/i).  Slot order (see k_apply_fast):
   // lanes >= 1 pair registers (sl, 31 - sl); lane 0 pairs its self-conjugate rows differently, handled by
   // selects on the way in HERE only -- the decision stage and the mask stage both read pa/pb in slot order.
+#if OP_INPLACE
+  // In place (rowgate.hpp's formulation): lane 0 permutes its registers ONCE so that register index == entry index in
+  // every lane, then split / merge work on (v[s], v[31 - s]) without operand selects -- ~100 v_cndmask fewer per wave
+  // and the 64 registers of the transform are the 64 split values (no second array alive beside them).
+  // pa[sl] / pb[sl] below are v[sl] / v[31 - sl]; lane 0 keeps its unpaired registers raw in v[0] (bins 0 / 512) and
+  // v[31] (bin 256).  Same split_pair / merge_pair arithmetic in the same order: bit-identical results.
+  const bool l0 = c == 0;
+  cf wlo = A.tw1024[c];
+  asm volatile("" : "+v"(wlo.x), "+v"(wlo.y));
+  cf whi = wlo;
+  {
+    const cf w16 = A.tw1024[16];
+    if (l0) whi = {-w16.y, w16.x};  // i * w_1024^16
+  }
+  rg_lane0_to_entries(v, l0);
+  {
+    const cf r0 = v[0], r31 = v[31];
+    cf xa, xb;
+    split_pair(r0, r31, wlo, xa, xb);
+    v[0] = {l0 ? r0.x : xa.x, l0 ? r0.y : xa.y};
+    v[31] = {l0 ? r31.x : xb.x, l0 ? r31.y : xb.y};
+#pragma unroll
+    for (int sl = 1; sl < 16; ++sl) {
+      const cf w = mul_tw<false>(sl < 8 ? wlo : whi, twc<32>(sl), tws<32>(sl));
+      cf ya, yb;
+      split_pair(v[sl], v[31 - sl], w, ya, yb);
+      v[sl] = ya;
+      v[31 - sl] = yb;
+    }
+  }
+#define OP_PA(sl) v[sl]
+#define OP_PB(sl) v[31 - (sl)]
+  const cf raw0 = v[0], raw8 = v[31];   // (lane 0 only: the same registers)
+#else
   cf pa[16], pb[16];
   const cf raw0 = v[0], raw8 = v[8];   // lane 0: bins 0 / 512 and bin 256 are not part of a pair
   const bool l0 = c == 0;
@@ -311,6 +350,9 @@ __global__ __launch_bounds__(WAVES * 64, 3) void k_gate_onepass(OnePassArgs P) {
     }
   }
 
+#define OP_PA(sl) pa[sl]
+#define OP_PB(sl) pb[sl]
+#endif
   OP_STAMP(4);   // split
   // ---- decide (k_decide_fast): mask bits of this lane's 32 entries -----------------------------------
   unsigned long long myword;  // lane c < 9 of group g: word c of frame tq + g
@@ -342,8 +384,8 @@ __global__ __launch_bounds__(WAVES * 64, 3) void k_gate_onepass(OnePassArgs P) {
     };
     bool pred512 = false, amb512 = false;
     {
-      const float Pk = pa[0].x * pa[0].x + pa[0].y * pa[0].y;
-      const float Pn = pb[0].x * pb[0].x + pb[0].y * pb[0].y;
+      const float Pk = OP_PA(0).x * OP_PA(0).x + OP_PA(0).y * OP_PA(0).y;
+      const float Pn = OP_PB(0).x * OP_PB(0).x + OP_PB(0).y * OP_PB(0).y;
       const float x0 = 2.f * (raw0.x + raw0.y), xN = 2.f * (raw0.x - raw0.y);
       const float P256 = 4.f * (raw8.x * raw8.x + raw8.y * raw8.y);
       decideA(l0 ? x0 * x0 : Pk, t2[0]);
@@ -355,8 +397,8 @@ __global__ __launch_bounds__(WAVES * 64, 3) void k_gate_onepass(OnePassArgs P) {
 #pragma unroll
     for (int sl = 1; sl < 16; ++sl) {
       if ((sl & 3) == 0) __builtin_amdgcn_sched_barrier(0);  // keep the constant loads next to their use
-      decideA(pa[sl].x * pa[sl].x + pa[sl].y * pa[sl].y, t2[sl]);
-      decideB(pb[sl].x * pb[sl].x + pb[sl].y * pb[sl].y, t2[31 - sl]);
+      decideA(OP_PA(sl).x * OP_PA(sl).x + OP_PA(sl).y * OP_PA(sl).y, t2[sl]);
+      decideB(OP_PB(sl).x * OP_PB(sl).x + OP_PB(sl).y * OP_PB(sl).y, t2[31 - sl]);
     }
     __builtin_amdgcn_sched_barrier(0);
     unsigned pred = (__brev(pA) >> 16) | (pB << 16);
@@ -372,8 +414,8 @@ __global__ __launch_bounds__(WAVES * 64, 3) void k_gate_onepass(OnePassArgs P) {
       static_assert(64 * 32 * 4 <= WAVE_CX_H * 8, "parked registers must fit the wave's slice");
 #pragma unroll
       for (int i = 0; i < 16; ++i) {
-        park[(2 * i) * 64] = pb[i].x;
-        park[(2 * i + 1) * 64] = pb[i].y;
+        park[(2 * i) * 64] = OP_PB(i).x;
+        park[(2 * i + 1) * 64] = OP_PB(i).y;
       }
       while (true) {
         const unsigned long long pending = __ballot(amb != 0 || amb512);
@@ -398,8 +440,8 @@ __global__ __launch_bounds__(WAVES * 64, 3) void k_gate_onepass(OnePassArgs P) {
       wave_lds_sync();
 #pragma unroll
       for (int i = 0; i < 16; ++i) {
-        pb[i].x = park[(2 * i) * 64];
-        pb[i].y = park[(2 * i + 1) * 64];
+        OP_PB(i).x = park[(2 * i) * 64];
+        OP_PB(i).y = park[(2 * i + 1) * 64];
       }
       wave_lds_sync();
     }
@@ -582,6 +624,28 @@ __global__ __launch_bounds__(WAVES * 64, 3) void k_gate_onepass(OnePassArgs P) {
     // mask -> merge (the second half of pair_mask): Yk = X2[k] mk, Yn = conj-pair value x mn, then back to the
     // half-size complex spectrum.  The four 1/2 factors of split and merge ride in the mask scale.
     const float ks = A.kscale * 0.25f;
+#if OP_INPLACE
+    {
+      // slot 0: lanes >= 1 merge the pair (v[0], v[31]); lane 0: bins 0 / 512 from v[0], bin 256 = v[31] scaled
+      const cf r0 = v[0], r31 = v[31];
+      cf xa = r0, xb = r31;
+      merge_pair(xa, xb, wlo, mval(0, ks), mval(31, ks));
+      const float y0 = (r0.x + r0.y) * mval(0, A.kscale);
+      const float yN = (r0.x - r0.y) * k512;
+      const cf z0 = {0.5f * (y0 + yN), 0.5f * (y0 - yN)};
+      const float m8 = mval(31, A.kscale);  // entry 31 of lane 0 = bin 256
+      const cf z8 = {r31.x * m8, r31.y * m8};
+      v[0] = {l0 ? z0.x : xa.x, l0 ? z0.y : xa.y};
+      v[31] = {l0 ? z8.x : xb.x, l0 ? z8.y : xb.y};
+    }
+#pragma unroll
+    for (int sl = 1; sl < 16; ++sl) {
+      const cf w = mul_tw<false>(sl < 8 ? wlo : whi, twc<32>(sl), tws<32>(sl));
+      merge_pair(v[sl], v[31 - sl], w, mval(sl, ks), mval(31 - sl, ks));
+    }
+    rg_lane0_from_entries(v, l0);   // back to the transform's register order
+  }
+#else
     auto sel = [&](cf a0, cf a1) -> cf { return {l0 ? a0.x : a1.x, l0 ? a0.y : a1.y}; };
     auto merge = [&](cf& xa, cf& xb, cf w, float mk, float mn) { merge_pair(xa, xb, w, mk, mn); };
     merge(pa[0], pb[0], wlo, mval(0, ks), mval(31, ks));
@@ -611,6 +675,7 @@ __global__ __launch_bounds__(WAVES * 64, 3) void k_gate_onepass(OnePassArgs P) {
     for (int i = 24; i < 31; ++i) v[i] = sel(pb[39 - i], pb[31 - i]);
     v[31] = sel(pb[8], pb[0]);
   }
+#endif
   wave_lds_sync();  // K tile consumed: the slice is reused by the inverse transform
   OP_STAMP(10);  // mask + merge
 

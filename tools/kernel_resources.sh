@@ -29,7 +29,7 @@ for f in sorted(glob.glob(sys.argv[1] + "/*.log")):
             cur[m.group(1).strip()] = m.group(2)
 names = [r["name"] for r in rows]
 try:
-    dem = subprocess.run(["/opt/rocm/lib/llvm/bin/llvm-cxxfilt"] + names, capture_output=True, text=True).stdout.splitlines()
+    dem = subprocess.run(["c++filt"], input="\n".join(names), capture_output=True, text=True).stdout.splitlines()
 except Exception:
     dem = names
 with open(sys.argv[2], "w") as o:

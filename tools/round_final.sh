@@ -1,9 +1,9 @@
 #!/bin/bash
 # Final measurements of a round, one gpurun call: GPU test suite, bench lines (configs[1], [2], [3]-share), rocprofv3
 # kernel stats of the bench command, PMC HBM traffic (configs[1], [2], [4]), throughput over n_fft and sample dtypes.
-# usage (on the GPU box): tools/r03_final.sh <tag>      -> gpurun_out/<tag>/
+# usage (on the GPU box): tools/round_final.sh <tag>      -> gpurun_out/<tag>/
 set -u
-TAG=${1:-r03}
+TAG=${1:-r04}
 REPO=${GRAFT_REPO_ROOT:-/root/repo}
 OUT=$REPO/gpurun_out/$TAG
 mkdir -p "$OUT"
@@ -22,3 +22,6 @@ python tools/time_nfft.py > "$OUT/time_nfft.json" 2>&1
 python tools/time_dtypes.py > "$OUT/time_dtypes.txt" 2>&1
 python tools/prof_torchgate.py > "$OUT/prof_torchgate.txt" 2>&1
 cat "$OUT/pytest_gpu.txt"; head -c 300 "$OUT/bench.json"; echo; tail -3 "$OUT/traffic.log"
+python tools/rowgate_scale.py > "$OUT/rowgate_scale.txt" 2>&1; cp gpurun_out/rowgate_scale.json "$OUT/" 2>/dev/null
+python tools/rowgate_probe.py > "$OUT/rowgate_probe.txt" 2>&1; cp gpurun_out/rowgate_probe.json "$OUT/" 2>/dev/null
+tools/step_timeline.sh $TAG > "$OUT/step_timeline.log" 2>&1; cp gpurun_out/timeline_$TAG.txt "$OUT/" 2>/dev/null
