@@ -83,7 +83,7 @@ struct sg_handle {
   DevBuf ftab;                       // k_smooth_bits2 phase-1 lookup tables (nf <= 5)
   int sm2_tt = 64;                   // k_smooth_bits2 tile height (frames)
   // one-pass gate (onepass.hpp): published mask bits per tile, publication flags, work counter, tables
-  DevBuf xbits, xpart, xticket, xtick2, ftab3, xexp;
+  DevBuf xbits, xpart, xticket, xtick2, ftab3, xexp, optab;
   DevBuf xin;                        // float32 copy of a recording held in another sample dtype
   DevBuf nsp, nsc;                   // non-stationary mask: per-sub-tile partials / carries (nonstat.hpp)  // ftab3: per-lane MFMA operands, xexp: bit -> byte table
   unsigned* err_host = nullptr;      // host-mapped error word written by k_gate_onepass when a hand-off times out
@@ -1047,6 +1047,20 @@ extern "C" int sg_create(const sg_params* p, const double* window_host, sg_handl
       for (int e = 0; e < 8; ++e) ex[v] |= (unsigned long long)((v >> e) & 1) << (8 * e);
     rc = upload(h, h->ftab3, mc.data(), mc.size() * 8);
     if (!rc) rc = upload(h, h->xexp, ex.data(), ex.size() * 8);
+    // the one-pass kernel reads all of its constant tables through ONE base pointer (onepass.hpp: OP_TAB_*)
+    if (!rc) rc = ensure(h, h->optab, fast::OP_TAB_BYTES);
+    if (!rc) {
+      struct { const DevBuf* b; int off; size_t bytes; } parts[] = {
+          {&h->wa32, fast::OP_TAB_WIN, 4096}, {&h->wsq32, fast::OP_TAB_WSQ, 4096}, {&h->invn, fast::OP_TAB_INVN, 1024},
+          {&h->tw512, fast::OP_TAB_TW512, 4096}, {&h->tw32, fast::OP_TAB_TW1024, 4096}, {&h->wfull64, fast::OP_TAB_WIN64, 8192},
+          {&h->tw64, fast::OP_TAB_TW64, 8192}, {&h->ftab3, fast::OP_TAB_MCONST, 1536}, {&h->xexp, fast::OP_TAB_EXP8, 2048}};
+      for (const auto& pt : parts) {
+        if (!pt.b->p || pt.b->bytes < pt.bytes) { h->err = "one-pass table arena: a source table is missing"; rc = SG_E_STATE; break; }
+        if (hipMemcpy((char*)h->optab.p + pt.off, pt.b->p, pt.bytes, hipMemcpyDeviceToDevice) != hipSuccess) {
+          h->err = "one-pass table arena: hipMemcpy failed"; rc = SG_E_HIP; break;
+        }
+      }
+    }
   }
   if (!rc) rc = ensure(h, h->thresh, (size_t)h->FS * sizeof(double));
   if (rc) {
@@ -1067,7 +1081,7 @@ extern "C" int sg_destroy(sg_handle* h) {
   for (DevBuf* b : {&h->tw64, &h->tw32, &h->wfull64, &h->wa32, &h->ws32, &h->wsq32, &h->kf, &h->kt, &h->thresh,
                     &h->P, &h->pmax, &h->thr_rows, &h->raw, &h->M, &h->seg, &h->yn, &h->bits, &h->K16, &h->umax,
                     &h->need, &h->T2, &h->part, &h->tw512, &h->invn, &h->seam, &h->ftab, &h->xbits, &h->xpart,
-                    &h->xticket, &h->xtick2, &h->ftab3, &h->xexp, &h->nsp, &h->nsc, &h->xin, &h->czt_tw64, &h->czt_ch64,
+                    &h->xticket, &h->xtick2, &h->ftab3, &h->xexp, &h->optab, &h->nsp, &h->nsc, &h->xin, &h->czt_tw64, &h->czt_ch64,
                     &h->czt_bh64, &h->czt_tw32, &h->czt_ch32, &h->czt_bh32, &h->logtab, &h->big_twM, &h->big_tw2,
                     &h->big_ch, &h->big_bh, &h->big_W, &h->big_W2, &h->xP, &h->xraw, &h->xM, &h->xtmp, &h->xseg, &h->invn5, &h->invn20, &h->rg_count})
     free_buf(*b);
@@ -1850,7 +1864,7 @@ static int stage_apply_fast(sg_handle* h, const View& v, const Geom& g, int64_t 
 // (the caller then runs the three-kernel path).
 static bool onepass_ok(const sg_handle* h, const Geom& g, const OutMap& om) {
   if (h->force_split || h->force_f64_decide || h->force_noseam || h->force_nolean) return false;
-  if (!h->p.smooth_mask || h->p.n_grad_freq > 8 || h->p.n_grad_time > fast::OP_MAX_NT || !h->ftab3.p) return false;
+  if (!h->p.smooth_mask || h->p.n_grad_freq > 8 || h->p.n_grad_time > fast::OP_MAX_NT || !h->ftab3.p || !h->optab.p) return false;
   if (g.F != 513) return false;
   const int64_t hb = (om.p0 + g.padL) / 256, he = (om.p1 - 1 + g.padL) / 256 + 1;
   return (he - hb + 3 + 15) / 16 >= 2;  // at least two abutting tiles (seam mode)
@@ -1863,7 +1877,7 @@ static int stage_onepass(sg_handle* h, const View& v, const View& vx, const Geom
   ThreshConsts tc{};
   if ((rc = stage_prep_floor(h, v, g, ub, &tc, st, &vx))) return rc;
   fast::OnePassArgs P;
-  P.view_exact = vx;
+  P.x_exact = vx.x; P.stride_exact = vx.stride; P.dtype_exact = vx.dtype;
   fast::ApplyArgs& A = P.A;
   A.view = v; A.g = g; A.om = om;
   A.K = nullptr; A.Mf = nullptr;
@@ -1889,8 +1903,7 @@ static int stage_onepass(sg_handle* h, const View& v, const View& vx, const Geom
   if ((rc = ensure_zeroed(h, h->xbits, (size_t)ub * ntt * fast::OP_TILE_WORDS * 8, st))) return rc;
   // granule buffers are zero when (re)allocated and the epoch only grows: a fresh granule never carries it
   if ((rc = handoff_prepare(h, st))) return rc;
-  P.win64 = (const double*)h->wfull64.p;
-  P.tw64 = (const cx<double>*)h->tw64.p;
+  P.tab = (const char*)h->optab.p;
   P.tc = tc;
   P.mag_scale = h->mag_scale; P.top_db = h->p.top_db;
   P.xbits = (unsigned long long*)h->xbits.p;
@@ -1903,8 +1916,6 @@ static int stage_onepass(sg_handle* h, const View& v, const View& vx, const Geom
   P.nf = h->p.n_grad_freq; P.nt = h->p.n_grad_time;
   P.prop = (float)h->p.prop_decrease;
   P.inv_ktot = 1.0f / (float)h->ktot;
-  P.mconst = (const unsigned long long*)h->ftab3.p;
-  P.exp8 = (const unsigned long long*)h->xexp.p;
 #if OP_TRACE
   {
     // development builds: one process-wide device trace [workgroup][wave][16], overwritten by every launch, averaged at exit

@@ -37,6 +37,10 @@ constexpr int OP_XW = 9;                 // 64-bit words per frame row (513 bins
 constexpr int OP_TILE_WORDS = 16 * OP_XW * 2;  // payload of one tile: 288 tagged granules = 2304 B (18 x 128 B)
 constexpr int OP_MAX_NT = 16;            // neighbours hold 16 frames each
 constexpr int OP_KP = 528;               // K row pitch (uint16 entries) of a wave's private K tile
+// The kernel's nine constant tables live in ONE device buffer at fixed offsets (OnePassArgs::tab): one base pointer in the
+// kernel arguments instead of nine -- 16 scalar registers fewer in a kernel that spilled 44 of them.
+constexpr int OP_TAB_WIN = 0, OP_TAB_WSQ = 4096, OP_TAB_INVN = 8192, OP_TAB_TW512 = 9216, OP_TAB_TW1024 = 13312,
+              OP_TAB_WIN64 = 17408, OP_TAB_TW64 = 25600, OP_TAB_MCONST = 33792, OP_TAB_EXP8 = 35328, OP_TAB_BYTES = 37376;
 
 #ifndef OP_TRACE
 #define OP_TRACE 0
@@ -48,9 +52,13 @@ constexpr int OP_KP = 528;               // K row pitch (uint16 entries) of a wa
 #endif
 struct OnePassArgs {
   ApplyArgs A;              // view, geometry, output map, tables, seam buffer (A.K / A.Mf unused)
-  View view_exact;          // the caller's samples in their own dtype (A.view may be a float32 copy): exact refinement
-  const double* win64;      // analysis window, float64 (exact refinement)
-  const cx<double>* tw64;   // w_1024^j float64
+  // the caller's samples in their own dtype (A.view may be a float32 copy): exact refinement.  Only these three fields
+  // differ from A.view (96 bytes of kernel arguments fewer than a second View)
+  const void* x_exact;
+  int64_t stride_exact;
+  int dtype_exact;
+  const char* tab;          // the constant tables (OP_TAB_*): float32 window, window^2, 1/envelope, w_512^(k1 c), w_1024^j,
+                            // float64 window and w_1024^j (exact refinement), MFMA operands, byte -> 8 bytes expansion
   ThreshConsts tc;
   double mag_scale, top_db;
   unsigned long long* xbits;  // [units][n_tiles + 2][16][OP_XW][2] published mask bits: granules {32 bits, epoch}
@@ -61,8 +69,6 @@ struct OnePassArgs {
   int nf, nt;
   float prop, inv_ktot;       // PROP instantiation: prop_decrease and 1 / ktot (A.kscale = 1/512 then)
   unsigned long long* part2;  // [units][n_tiles][3][256] trailing partial hops of every tile: granules {float, epoch}
-  const unsigned long long* mconst;  // [3][64] per-lane MFMA operands: freq band B, time weights A (slots 0..31, 32..63)
-  const unsigned long long* exp8;    // [256]: byte v -> 8 bytes (v >> e) & 1
 #if OP_TRACE
   unsigned* trace;                   // [workgroups][4 waves][16] shader cycles per phase (slot 15 = 1: tile completed): development builds
 #endif
@@ -76,9 +82,17 @@ __device__ __forceinline__ double op_exact_power(const OnePassArgs& P, int64_t r
 #pragma unroll 4
   for (int i = 0; i < 16; ++i) {
     const int m = lane + 64 * i;
-    const double xv = view_sample(P.view_exact, row, chunk, s0 + m) * P.win64[m];   // the ORIGINAL samples
+    // the ORIGINAL samples: view_sample on A.view's geometry with the caller's pointer / dtype / stride
+    double xs = 0.0;
+    {
+      const View& V = P.A.view;
+      const int64_t sp = s0 + m;
+      const int64_t gi = chunk * V.cs - V.pad + sp;
+      if (sp >= 0 && sp < V.Lp && gi >= V.lo && gi < V.hi) xs = load_sample(P.x_exact, P.dtype_exact, row * P.stride_exact + gi);
+    }
+    const double xv = xs * reinterpret_cast<const double*>(P.tab + OP_TAB_WIN64)[m];
     const int j = (f * m) & 1023;
-    cx<double> w = P.tw64[j & 511];
+    cx<double> w = reinterpret_cast<const cx<double>*>(P.tab + OP_TAB_TW64)[j & 511];
     if (j >= 512) { w.x = -w.x; w.y = -w.y; }
     re += xv * w.x;
     im += xv * w.y;
@@ -144,10 +158,10 @@ __global__ __launch_bounds__(WAVES * 64, 3) void k_gate_onepass(OnePassArgs P) {
   {
     // table loads first, the ticket's atomic behind them in the same queue: one memory round trip, not two
     static_assert(FN == 2 * WAVES * 64 && WAVES * 64 == 256, "one pass of the prologue loads per thread");
-    const cf tw_a = A.tw512[(tid >> 4) * (tid & 15)];
-    const cf tw_b = A.tw512[((tid + 256) >> 4) * (tid & 15)];
-    const float4 w4 = reinterpret_cast<const float4*>(A.win)[tid];
-    const unsigned long long e8 = P.exp8[tid];
+    const cf tw_a = reinterpret_cast<const cf*>(P.tab + OP_TAB_TW512)[(tid >> 4) * (tid & 15)];
+    const cf tw_b = reinterpret_cast<const cf*>(P.tab + OP_TAB_TW512)[((tid + 256) >> 4) * (tid & 15)];
+    const float4 w4 = reinterpret_cast<const float4*>(P.tab + OP_TAB_WIN)[tid];
+    const unsigned long long e8 = reinterpret_cast<const unsigned long long*>(P.tab + OP_TAB_EXP8)[tid];
     t2pre[0] = P.tc.T2[perm_inv(tid)];
     t2pre[1] = P.tc.T2[perm_inv(tid + 256)];
     t2pre[2] = P.tc.T2[perm_inv(512)];
@@ -300,11 +314,11 @@ __global__ __launch_bounds__(WAVES * 64, 3) void k_gate_onepass(OnePassArgs P) {
   // pa[sl] / pb[sl] below are v[sl] / v[31 - sl]; lane 0 keeps its unpaired registers raw in v[0] (bins 0 / 512) and
   // v[31] (bin 256).  Same split_pair / merge_pair arithmetic in the same order: bit-identical results.
   const bool l0 = c == 0;
-  cf wlo = A.tw1024[c];
+  cf wlo = reinterpret_cast<const cf*>(P.tab + OP_TAB_TW1024)[c];
   asm volatile("" : "+v"(wlo.x), "+v"(wlo.y));
   cf whi = wlo;
   {
-    const cf w16 = A.tw1024[16];
+    const cf w16 = reinterpret_cast<const cf*>(P.tab + OP_TAB_TW1024)[16];
     if (l0) whi = {-w16.y, w16.x};  // i * w_1024^16
   }
   rg_lane0_to_entries(v, l0);
@@ -330,11 +344,11 @@ __global__ __launch_bounds__(WAVES * 64, 3) void k_gate_onepass(OnePassArgs P) {
   cf pa[16], pb[16];
   const cf raw0 = v[0], raw8 = v[8];   // lane 0: bins 0 / 512 and bin 256 are not part of a pair
   const bool l0 = c == 0;
-  cf wlo = A.tw1024[c];
+  cf wlo = reinterpret_cast<const cf*>(P.tab + OP_TAB_TW1024)[c];
   asm volatile("" : "+v"(wlo.x), "+v"(wlo.y));
   cf whi = wlo;
   {
-    const cf w16 = A.tw1024[16];
+    const cf w16 = reinterpret_cast<const cf*>(P.tab + OP_TAB_TW1024)[16];
     if (l0) whi = {-w16.y, w16.x};  // i * w_1024^16
   }
   {
@@ -513,7 +527,7 @@ __global__ __launch_bounds__(WAVES * 64, 3) void k_gate_onepass(OnePassArgs P) {
     wb[r * WP + WP - 1] = 0ull;
   }
   const int q4 = lane >> 4, j16 = lane & 15;
-  const long Bf = (long)P.mconst[lane], At1 = (long)P.mconst[64 + lane], At2 = (long)P.mconst[128 + lane];
+  const long Bf = (long)reinterpret_cast<const unsigned long long*>(P.tab + OP_TAB_MCONST)[lane], At1 = (long)reinterpret_cast<const unsigned long long*>(P.tab + OP_TAB_MCONST)[64 + lane], At2 = (long)reinterpret_cast<const unsigned long long*>(P.tab + OP_TAB_MCONST)[128 + lane];
   const bool three = 2 * nt > 16;      // a third row block (wave-uniform)
   // neighbour-list index m -> tile row: m < nt: row m (previous tile), else row nt + 16 + (m - nt) (next tile)
   const int m1 = j16, m2 = 16 + j16;
@@ -707,7 +721,7 @@ __global__ __launch_bounds__(WAVES * 64, 3) void k_gate_onepass(OnePassArgs P) {
       wave_lds_sync();
     }
   }
-  const float4 n4 = *reinterpret_cast<const float4*>(&A.invn[(tid & 63) * 4]);
+  const float4 n4 = *reinterpret_cast<const float4*>(&reinterpret_cast<const float*>(P.tab + OP_TAB_INVN)[(tid & 63) * 4]);
   __syncthreads();
   OP_STAMP(12);  // window + wave-private overlap-add + barrier
 #if OP_TRACE
@@ -854,7 +868,7 @@ __global__ __launch_bounds__(WAVES * 64, 3) void k_gate_onepass(OnePassArgs P) {
       for (int q = 0; q < 4; ++q) {
         const int64_t ti = h - q;
         if (ti >= 0 && ti < G.T) {
-          const float4 w4 = *reinterpret_cast<const float4*>(&A.wsq[256 * q + s4]);
+          const float4 w4 = *reinterpret_cast<const float4*>(&reinterpret_cast<const float*>(P.tab + OP_TAB_WSQ)[256 * q + s4]);
           nrm.x += w4.x; nrm.y += w4.y; nrm.z += w4.z; nrm.w += w4.w;
         }
       }
