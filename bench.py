@@ -475,6 +475,15 @@ def main():
             chunk = y2d[c, s0 - PAD:s0 + CHUNK + PAD].cpu().numpy().astype(np.float64)[None, :]
             ref = O.gate_stationary_S(chunk, thr_t, NFFT, NFFT, HOP, 1.0, O.smoothing_filter(5, 9))[0, PAD:PAD + CHUNK]
             info["rel_err_unit"] = O.rel_err(out[c, s0:s0 + CHUNK].cpu().numpy(), ref)
+        # (2b) configs[1]: how long a rank's stream sits in the exchange INSIDE a step (CUDA events around it, 20 steps):
+        # rank 0 enters after its noise statistics, the others at once -- their time in it is the exposed wait
+        if wl == "config2":
+            evs = []
+            for _ in range(20):
+                ts_objs[0].run(y2d, ext=y_ext, defer_check=True, timing=evs)
+            torch.cuda.synchronize(device)
+            ts_objs[0].finish()
+            info["exchange_in_step_ms"] = float(np.median([a.elapsed_time(b) for a, b in evs])) if evs else None
         # (3) collective time per step: the exchange alone, same payload, 20 repetitions
         torch.cuda.synchronize(device)
         dist.barrier()
@@ -494,6 +503,9 @@ def main():
                        "collective": ("all_reduce(sum) of the noise clip's channel sum, %d float64" % CHUNK)
                        if wl == "config4" else "all_gather of [shard length | 2*padding seam samples | threshold] per rank",
                        "collective_ms_per_step_max": round(max(g["collective_ms"] for g in gathered), 4),
+                       # time ranks > 0 spend in the in-step exchange beyond rank 0's own: waiting for its statistics
+                       "exposed_wait_ms": (round(max(g["exchange_in_step_ms"] for g in gathered[1:]) - gathered[0]["exchange_in_step_ms"], 4)
+                                           if all(g.get("exchange_in_step_ms") is not None for g in gathered) and len(gathered) > 1 else None),
                        "per_rank": gathered}
         bad = [g for g in gathered if g.get("halo_ok") is False or max(g.get("rel_err_chunk0", 0), g.get("rel_err_unit", 0)) > 1e-4]
         if bad and rank == 0:

@@ -290,11 +290,14 @@ class TimeShardedStationary:
         """After a loop of run(..., defer_check=True): the verdict on the last call's shard layout (every rank)."""
         flush_pending(self._bufs)
 
-    def run(self, y_local, ext=None, defer_check=False):
+    def run(self, y_local, ext=None, defer_check=False, timing=None):
         """y_local: this rank's (C, S) shard.  ext: optional halo-extended buffer that already
         holds the shard in its middle (alloc_shard) -- avoids copying the shard every call.
         defer_check: validate the gathered shard layout one call late (no host synchronisation in this call; see
-        exchange_seams_and_threshold) -- for hot loops that end with finish()."""
+        exchange_seams_and_threshold) -- for hot loops that end with finish().
+        timing: optional list; a (start, end) pair of CUDA events around the exchange is appended per call (measurement
+        of the time a rank's stream spends in / waiting for the collective: rank 0 enters it after its statistics, the
+        other ranks at once -- their time in it is the exposed wait for rank 0)."""
         if y_local.dim() == 1:
             y_local = y_local[None, :]
         pad, cs = self.backend.padding, self.backend.chunk_size
@@ -316,6 +319,10 @@ class TimeShardedStationary:
                     thr = self.backend.threshold(y_local)
                 except Exception as e:      # noqa: BLE001 -- re-raised below, after the exchange
                     thr_err = e
+            ev = None
+            if timing is not None and y_local.is_cuda:
+                ev = (torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True))
+                ev[0].record()
             try:
                 left, right, thr = exchange_seams_and_threshold(y_local, pad, thr, self.n_bins, self.group,
                                                                 self._bufs, chunk_size=cs, defer=defer_check)
@@ -323,6 +330,9 @@ class TimeShardedStationary:
                 if thr_err is not None:
                     raise thr_err
                 raise
+            if ev is not None:
+                ev[1].record()
+                timing.append(ev)
             if S == 0:      # more ranks than chunks: this rank took part in the exchange and has nothing to filter
                 return y_local.new_empty((y_local.shape[0], 0))
             if pad == 0:
