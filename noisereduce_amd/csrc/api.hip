@@ -345,16 +345,19 @@ static hipError_t launch_bits_n(const View& v, const Geom& g, int64_t units, con
                                 const ThreshConsts& tc, double mag_scale, double top_db,
                                 unsigned long long* pmax_bits, unsigned long long* bits, int wpr,
                                 hipStream_t st) {
-  constexpr int WAVES = (N * sizeof(cx<double>) > 16384) ? 2 : 4;
+  // from N = 2048 (n_fft = 4096) on the 256 threads of a workgroup share one frame (k_stft does the same): a single wave's
+  // 2048-point float64 pass held 512 registers and 476 B of scratch
+  constexpr int NT = N >= SG_TEAM_N ? 256 : 64;
+  constexpr int WAVES = N >= SG_TEAM_N ? 1 : ((N * sizeof(cx<double>) > 16384) ? 2 : 4);
   constexpr int FPW = 4;
   size_t lds = (size_t)(N + WAVES * lpn<double>(N)) * sizeof(cx<double>) + (size_t)(N + 1) * sizeof(double);
-  auto kern = k_stft_bits<N, WAVES, FPW, MODE>;
+  auto kern = k_stft_bits<N, WAVES, FPW, MODE, NT>;
   if (lds > 65536) {
     hipError_t e = set_lds(reinterpret_cast<const void*>(kern), lds);
     if (e != hipSuccess) return e;
   }
   dim3 grid((unsigned)((g.T + WAVES * FPW - 1) / (WAVES * FPW)), (unsigned)units);
-  hipLaunchKernelGGL(kern, grid, dim3(WAVES * 64), lds, st, v, g, (const cx<double>*)tw, (const double*)wfull, tc,
+  hipLaunchKernelGGL(kern, grid, dim3(WAVES * NT), lds, st, v, g, (const cx<double>*)tw, (const double*)wfull, tc,
                      mag_scale, top_db, pmax_bits, bits, wpr);
   return hipGetLastError();
 }

@@ -123,8 +123,10 @@ __global__ void k_prep_thresh(const double* __restrict__ thresh, int F, double m
 // MODE 0 (max): only for units with need_floor: atomic max of the raw power per band.
 // MODE 1 (decide): bits[u][t][w] (64 bins per word) = |X|^2 > T2[f]  ||  floor lifts the band.
 // ---------------------------------------------------------------------------------------
-template <int N, int WAVES, int FPW, int MODE>
-__global__ __launch_bounds__(WAVES * 64) void k_stft_bits(View view, Geom g, const cx<double>* __restrict__ tw_g,
+// NT: threads per frame (64: one wavefront; 256: the whole workgroup shares a frame -- from N = 2048 on, where a single
+// wave's 32 float64 points per pass cost 256 VGPRs + scratch).  WAVES = frames in flight per workgroup.
+template <int N, int WAVES, int FPW, int MODE, int NT = 64>
+__global__ __launch_bounds__(WAVES * NT) void k_stft_bits(View view, Geom g, const cx<double>* __restrict__ tw_g,
                                                           const double* __restrict__ wfull, ThreshConsts tc,
                                                           double mag_scale, double top_db,
                                                           unsigned long long* __restrict__ pmax_bits,
@@ -133,16 +135,16 @@ __global__ __launch_bounds__(WAVES * 64) void k_stft_bits(View view, Geom g, con
   cx<double>* tw = reinterpret_cast<cx<double>*>(smem);
   cx<double>* bufs = tw + N;
   double* sT2 = reinterpret_cast<double*>(bufs + WAVES * lpn<double>(N));  // [N+1] compare constants
-  const int lane = threadIdx.x & 63;
-  const int wave = threadIdx.x >> 6;
+  const int lane = threadIdx.x % NT;   // thread within the frame's team
+  const int wave = threadIdx.x / NT;
   cx<double>* buf = bufs + wave * lpn<double>(N);
   const int64_t u = blockIdx.y;
   const int need = tc.need_floor[u];
   const bool floor_live = need == 1;
   if (MODE == 0 && !floor_live) return;  // whole block: uniform
-  for (int i = threadIdx.x; i < N; i += WAVES * 64) tw[i] = tw_g[i];
+  for (int i = threadIdx.x; i < N; i += WAVES * NT) tw[i] = tw_g[i];
   if (MODE == 1) {
-    for (int i = threadIdx.x; i <= N; i += WAVES * 64) {
+    for (int i = threadIdx.x; i <= N; i += WAVES * NT) {
       double t2 = tc.T2[i];
       if (floor_live) {
         // band lifted by the floor: rowmax_dB - top_db > thresh  =>  every cell passes
@@ -156,14 +158,14 @@ __global__ __launch_bounds__(WAVES * 64) void k_stft_bits(View view, Geom g, con
   const int64_t row = (view.unit0 + u) / view.n_chunks;
   const int64_t chunk = view.c0 + (view.unit0 + u) % view.n_chunks;
   __syncthreads();
-  double vmax[N / 64 + 1];
+  double vmax[N / NT + 1];
 #pragma unroll
-  for (int m = 0; m <= N / 64; ++m) vmax[m] = 0.0;
+  for (int m = 0; m <= N / NT; ++m) vmax[m] = 0.0;
   for (int fi = 0; fi < FPW; ++fi) {
     const int64_t t = ((int64_t)blockIdx.x * FPW + fi) * WAVES + wave;
     const bool valid = t < g.T;
     const int64_t s0 = t * g.H - g.padL;
-    for (int j = lane; j < N; j += 64) {
+    for (int j = lane; j < N; j += NT) {
       cx<double> z = {0.0, 0.0};
       if (valid) {
         z.x = view_sample(view, row, chunk, s0 + 2 * j) * wfull[2 * j];
@@ -172,11 +174,11 @@ __global__ __launch_bounds__(WAVES * 64) void k_stft_bits(View view, Geom g, con
       buf[lp<double>(j)] = z;
     }
     SG_PASS_SYNC();
-    wave_fft<double, N, false>(buf, tw, lane);
+    wave_fft<double, N, false, NT>(buf, tw, lane);
     unsigned long long* brow = bits + ((u * g.T + t) * (int64_t)wpr);
 #pragma unroll
-    for (int m = 0; m <= N / 64; ++m) {
-      const int k = lane + 64 * m;
+    for (int m = 0; m <= N / NT; ++m) {
+      const int k = lane + NT * m;
       bool pred = false;
       if (k <= N) {
         cx<double> a = buf[lp<double>(k == N ? 0 : k)];
@@ -188,16 +190,17 @@ __global__ __launch_bounds__(WAVES * 64) void k_stft_bits(View view, Geom g, con
         else pred = P > sT2[k];
       }
       if (MODE == 1) {
+        // a hardware wave covers 64 consecutive bins: its ballot is word k / 64 of the frame's row
         unsigned long long word = __ballot(pred);
-        if (valid && lane == 0) brow[m] = word;
+        if (valid && (lane & 63) == 0 && k <= N) brow[k >> 6] = word;
       }
     }
     SG_PASS_SYNC();
   }
   if (MODE == 0) {
 #pragma unroll
-    for (int m = 0; m <= N / 64; ++m) {
-      const int k = lane + 64 * m;
+    for (int m = 0; m <= N / NT; ++m) {
+      const int k = lane + NT * m;
       if (k <= N) atomicMax(&pmax_bits[u * g.FS + k], (unsigned long long)__double_as_longlong(vmax[m]));
     }
   }
