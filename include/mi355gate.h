@@ -189,7 +189,8 @@ SG_API int sg_debug_dims(const sg_handle* h, int64_t dims[3]); /* units, T, FS *
 SG_API int sg_debug_range(const sg_handle* h, int64_t range[2]);
 /* Diagnostic counters (synchronises `stream`).  which = 0: (row, band) pairs of the one-kernel TorchGate row gate that were
  * re-evaluated in float64 since the handle was created (the float32 statistics could not decide them within their error
- * bound); divide by rows x 513 for the rate. */
+ * bound); divide by rows x 513 for the rate.  which = 1 / 2: batches of the one-pass gate that took the in-kernel / the a-priori
+ * floor test (SG_OPT_FLOOR_TEST) since the handle was created (host counters, no synchronisation). */
 SG_API int sg_debug_counter(sg_handle* h, int32_t which, int64_t* value, void* stream);
 SG_API int sg_debug_fetch(sg_handle* h, int32_t what, void* host, int64_t bytes, void* stream);
 
@@ -214,6 +215,11 @@ SG_API int sg_debug_fetch(sg_handle* h, int32_t what, void* host, int64_t bytes,
                                    * sg_debug_fetch(what = 4): measurements behind the decision margin */
 #define SG_OPT_ROWGATE_SHAPE 12   /* value = 16 (default) or 8: wavefronts per workgroup of the row gate (16 x one quad of frames at 128
                                    * VGPRs, or 8 x two quads at 256 VGPRs without scratch): A/B measurements */
+#define SG_OPT_FLOOR_TEST 13      /* one-pass gate (k_gate_onepass): how "can _amp_to_db's -top_db floor lift a band of this chunk over its
+                                   * threshold?" is answered.  1 = a priori (k_unit_absmax reads the recording once more before the gate);
+                                   * 2 = by the gate kernel on the samples it stages -- free unless a chunk reports, which is then gated a
+                                   * second time with its float64 band maxima; 0 (default) = predicted from what recent calls on the handle
+                                   * found (no synchronisation).  Same result either way: exact band maxima decide */
 #define SG_OPT_FORCE_NOFAST 2  /* value != 0: keep the bit-mask stages but use the general apply kernels */
 SG_API int sg_set_option(sg_handle* h, int32_t option, int64_t value);
 

@@ -32,6 +32,7 @@ SG_OPT_FORCE_EXACT = 9
 SG_OPT_FORCE_NOROWGATE = 10
 SG_OPT_ROWGATE_TAP = 11
 SG_OPT_ROWGATE_SHAPE = 12
+SG_OPT_FLOOR_TEST = 13
 SG_OPT_FORCE_UNFUSED = 1
 SG_OPT_FORCE_NOFAST = 2
 
@@ -442,7 +443,8 @@ class Gate:
         return int(r[0]), int(r[1])
 
     def debug_counter(self, which=0):
-        """0: (row, band) pairs the row gate re-evaluated in float64 since the handle was created."""
+        """0: (row, band) pairs the row gate re-evaluated in float64 since the handle was created; 1 / 2: batches of the
+        one-pass gate that took the in-kernel / the a-priori floor test (SG_OPT_FLOOR_TEST)."""
         v = c_int64(0)
         with torch.cuda.device(self.device):
             self._check(self.lib.sg_debug_counter(self._h, int(which), ctypes.byref(v), self._stream()))

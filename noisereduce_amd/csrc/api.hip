@@ -76,6 +76,7 @@ struct sg_handle {
   // workspace
   DevBuf P, pmax, thr_rows, raw, M, seg, yn;
   DevBuf bits, K16, umax, need, T2;  // fused stationary path
+  DevBuf alim;                       // one-pass gate, in-kernel floor test: compare constant on max|x| (k_prep_thresh_lazy)
   DevBuf logtab;                     // db_fast (kernels.hpp): {rd(1 / c_i), -log2 of it} for 128 mantissa centres
   DevBuf part;                       // partial reductions of the column statistics
   DevBuf tw512, invn;                // fast path tables (n_fft = 1024, hop = 256)
@@ -98,6 +99,8 @@ struct sg_handle {
   DevBuf xP, xraw, xM, xtmp, xseg;   // fields of the exact path
   bool force_split = false;          // SG_OPT_FORCE_SPLIT: decide / smooth / apply as three kernels
   int rowgate_mode = 0;              // SG_OPT_FORCE_NOROWGATE: 0 = by batch size, 1 = never, 2 = whenever the shape is eligible
+  int64_t n_floor_lazy = 0, n_floor_apriori = 0;   // sg_debug_counter 1 / 2
+  int floor_test = 0;                // SG_OPT_FLOOR_TEST: one-pass gate's floor test 0 = predicted, 1 = a priori, 2 = in the gate kernel
   int rg_shape = 16;                 // SG_OPT_ROWGATE_SHAPE: waves per workgroup of the row gate (16 x 1 quad, or 8 x 2 quads)
   bool rg_tap = false;               // SG_OPT_ROWGATE_TAP: keep the row gate's float32 power tile (stage tap 4)
   bool dbg_rg = false;               // the last batch ran on the row gate
@@ -1086,7 +1089,7 @@ extern "C" int sg_destroy(sg_handle* h) {
                     &h->need, &h->T2, &h->part, &h->tw512, &h->invn, &h->seam, &h->ftab, &h->xbits, &h->xpart,
                     &h->xticket, &h->xtick2, &h->ftab3, &h->xexp, &h->optab, &h->nsp, &h->nsc, &h->xin, &h->czt_tw64, &h->czt_ch64,
                     &h->czt_bh64, &h->czt_tw32, &h->czt_ch32, &h->czt_bh32, &h->logtab, &h->big_twM, &h->big_tw2,
-                    &h->big_ch, &h->big_bh, &h->big_W, &h->big_W2, &h->xP, &h->xraw, &h->xM, &h->xtmp, &h->xseg, &h->invn5, &h->invn20, &h->rg_count})
+                    &h->big_ch, &h->big_bh, &h->big_W, &h->big_W2, &h->xP, &h->xraw, &h->xM, &h->xtmp, &h->xseg, &h->invn5, &h->invn20, &h->rg_count, &h->alim})
     free_buf(*b);
   delete h;
   return SG_OK;
@@ -1626,7 +1629,8 @@ static int stage_smooth_bits(sg_handle* h, const Geom& g, int64_t ub, bool fast,
 // Compare constants + per-unit floor flags + (rare) float64 floor pre-pass: what every decision kernel of
 // the fused stationary path needs before it can run.
 static int stage_prep_floor(sg_handle* h, const View& v, const Geom& g, int64_t ub, ThreshConsts* tc_out,
-                            hipStream_t st, const View* v_exact = nullptr) {
+                            hipStream_t st, const View* v_exact = nullptr, unsigned* live_host = nullptr,
+                            unsigned stamp = 0) {
   const int wpr = (g.F + 63) / 64;
   int rc;
   if ((rc = ensure(h, h->bits, (size_t)ub * g.T * wpr * 8))) return rc;
@@ -1643,7 +1647,8 @@ static int stage_prep_floor(sg_handle* h, const View& v, const Geom& g, int64_t 
     HIPCHK(h, hipGetLastError());
     hipLaunchKernelGGL(k_prep_thresh, dim3((unsigned)((ub + 255) / 256)), dim3(256), 0, st,
                        (const double*)h->thresh.p, g.F, h->mag_scale, h->sum_abs_w, h->p.top_db,
-                       (unsigned*)h->umax.p, ub, (double*)h->T2.p, (int*)h->need.p, (double*)h->pmax.p, g.FS);
+                       (unsigned*)h->umax.p, ub, (double*)h->T2.p, (int*)h->need.p, (double*)h->pmax.p, g.FS, live_host,
+                       stamp);
     HIPCHK(h, hipGetLastError());
   }
   ThreshConsts tc{(const double*)h->T2.p, (const double*)h->thresh.p, (const double*)h->pmax.p,
@@ -1727,6 +1732,17 @@ static int stage_fused_mask(sg_handle* h, const View& v, const Geom& g, int64_t 
 // Hand-offs between workgroups of one launch (tagged granules, bounded polls): the host-mapped error word, the
 // verdict on earlier launches, a fresh epoch.  Granule buffers are zero when (re)allocated and the epoch only grows:
 // a fresh granule never carries it.
+// A new tag for the granules of the next hand-off launch (a call that launches twice takes two).
+static int handoff_next_epoch(sg_handle* h, hipStream_t st) {
+  if (++h->epoch == 0) {  // wrapped: tags of 2^32 launches ago could alias
+    if (h->xbits.p) HIPCHK(h, hipMemsetAsync(h->xbits.p, 0, h->xbits.bytes, st));
+    if (h->xpart.p) HIPCHK(h, hipMemsetAsync(h->xpart.p, 0, h->xpart.bytes, st));
+    h->epoch = 1;
+    if (h->err_host) h->err_host[1] = 0u;   // the floor-test stamp is an epoch too
+  }
+  return SG_OK;
+}
+
 static int handoff_prepare(sg_handle* h, hipStream_t st) {
   {
     // The work counter is never reset: every launch takes exactly its grid size in tickets, the kernels subtract
@@ -1739,6 +1755,7 @@ static int handoff_prepare(sg_handle* h, hipStream_t st) {
   if (!h->err_host) {
     HIPCHK(h, hipHostMalloc((void**)&h->err_host, 64, hipHostMallocMapped));
     *h->err_host = 0u;
+    h->err_host[1] = 0u;   // floor-test stamp (stage_onepass)
     HIPCHK(h, hipHostGetDevicePointer((void**)&h->err_dev, h->err_host, 0));
   }
   if (*h->err_host != 0u) {
@@ -1755,12 +1772,7 @@ static int handoff_prepare(sg_handle* h, hipStream_t st) {
     h->lose_now = (h->inject_fault >> 3) & 7u;    // bits 3..5: lost INSIDE the kernel (the output is poisoned)
     h->inject_fault = 0;
   }
-  if (++h->epoch == 0) {  // wrapped: tags of 2^32 launches ago could alias
-    if (h->xbits.p) HIPCHK(h, hipMemsetAsync(h->xbits.p, 0, h->xbits.bytes, st));
-    if (h->xpart.p) HIPCHK(h, hipMemsetAsync(h->xpart.p, 0, h->xpart.bytes, st));
-    h->epoch = 1;
-  }
-  return SG_OK;
+  return handoff_next_epoch(h, st);
 }
 
 // After the stream has been synchronised: did a hand-off of the work just completed time out?
@@ -1877,8 +1889,32 @@ static int stage_onepass(sg_handle* h, const View& v, const View& vx, const Geom
                          hipStream_t st) {
   constexpr int WAVES = 4, NF = 16;
   int rc;
+  // (first: the floor test stamps err_host[1] with this launch's epoch)
+  if ((rc = handoff_prepare(h, st))) return rc;
+  // Floor test (is some band's -top_db floor possibly live?): a priori -- k_unit_absmax reads the recording once more, 26 us
+  // of a 345 us call at 10 minutes of 48 kHz -- or by the gate kernel on the samples it stages (onepass.hpp "floor test"),
+  // which costs nothing unless a unit reports; then that unit is gated twice.  Both are exact; the choice is a
+  // prediction from the host-mapped stamp "a unit of launch <epoch> reported / had its flag set", read WITHOUT
+  // synchronising (it may lag by the calls still queued): recent -> a priori.
+  const unsigned live_stamp = h->err_host[1];
+  const bool lazy = h->floor_test == 2 || (h->floor_test == 0 && !(live_stamp != 0u && h->epoch - live_stamp <= 16u));
   ThreshConsts tc{};
-  if ((rc = stage_prep_floor(h, v, g, ub, &tc, st, &vx))) return rc;
+  ++(lazy ? h->n_floor_lazy : h->n_floor_apriori);
+  if (!lazy) {
+    if ((rc = stage_prep_floor(h, v, g, ub, &tc, st, &vx, h->err_dev + 1, h->epoch))) return rc;
+  } else {
+    const int wpr = (g.F + 63) / 64;
+    if ((rc = ensure(h, h->bits, (size_t)ub * g.T * wpr * 8))) return rc;
+    if ((rc = ensure(h, h->need, (size_t)ub * 4))) return rc;
+    if ((rc = ensure(h, h->T2, (size_t)g.FS * 8))) return rc;
+    if ((rc = ensure(h, h->alim, 64))) return rc;
+    ProfScope ps(h, SG_STAGE_PREP, st);
+    hipLaunchKernelGGL(k_prep_thresh_lazy, dim3(1), dim3(256), 0, st, (const double*)h->thresh.p, g.F, h->mag_scale,
+                       h->sum_abs_w, h->p.top_db, ub, (double*)h->T2.p, (int*)h->need.p, (unsigned*)h->alim.p,
+                       (unsigned*)h->xticket.p + 8);
+    HIPCHK(h, hipGetLastError());
+    tc = ThreshConsts{(const double*)h->T2.p, (const double*)h->thresh.p, (const double*)h->pmax.p, (const int*)h->need.p};
+  }
   fast::OnePassArgs P;
   P.x_exact = vx.x; P.stride_exact = vx.stride; P.dtype_exact = vx.dtype;
   fast::ApplyArgs& A = P.A;
@@ -1905,7 +1941,17 @@ static int stage_onepass(sg_handle* h, const View& v, const View& vx, const Geom
   A.n_tiles = (int)n_tiles;
   if ((rc = ensure_zeroed(h, h->xbits, (size_t)ub * ntt * fast::OP_TILE_WORDS * 8, st))) return rc;
   // granule buffers are zero when (re)allocated and the epoch only grows: a fresh granule never carries it
-  if ((rc = handoff_prepare(h, st))) return rc;
+  P.alim = lazy ? (unsigned*)h->alim.p : nullptr;
+  P.redo = 0;
+  {
+    // the part of a unit's window outside its tiles' spans, dealt evenly to the unit's tiles (onepass.hpp "floor test")
+    constexpr int64_t SPAN = (NF - 1) * 256 + 1024;
+    const int64_t sp0 = (A.h_begin - 3 - NF) * 256 - g.padL, sp1 = (A.h_begin - 3 + n_tiles * NF) * 256 - g.padL + SPAN;
+    const int64_t inside = std::max<int64_t>(0, std::min<int64_t>(v.Lp, sp1) - std::max<int64_t>(0, sp0));
+    const int64_t q = (v.Lp - inside + ntt - 1) / ntt;
+    if (q > 0x7fffffff) FAIL(h, SG_E_UNSUPPORTED, "one-pass gate: window of %lld samples", (long long)v.Lp);
+    P.scan_q = (int)q;
+  }
   P.tab = (const char*)h->optab.p;
   P.tc = tc;
   P.mag_scale = h->mag_scale; P.top_db = h->p.top_db;
@@ -1968,6 +2014,24 @@ static int stage_onepass(sg_handle* h, const View& v, const View& vx, const Geom
     if (h->lose_now & 3u) HIPCHK(h, go(fast::k_gate_onepass<WAVES, false, true>));   // test hook (PROP-free shape only)
     else if (prop) HIPCHK(h, go(fast::k_gate_onepass<WAVES, true>));
     else HIPCHK(h, go(fast::k_gate_onepass<WAVES, false>));
+  }
+  if (lazy) {
+    // the units whose floor test fired: float64 band maxima, then the gate again with them.  Both launches exit at once
+    // when no unit reported (the common case)
+    ProfScope ps(h, SG_STAGE_STFT_MAX, st);
+    const int wpr = (g.F + 63) / 64;
+    HIPCHK(h, launch_bits<0>(h->N, vx, g, ub, h->tw64.p, h->wfull64.p, tc, h->mag_scale, h->p.top_db,
+                             (unsigned long long*)h->pmax.p, (unsigned long long*)h->bits.p, wpr, st));
+    if ((rc = handoff_next_epoch(h, st))) return rc;
+    P.epoch = h->epoch;
+    P.ticket = (unsigned*)h->xticket.p + 8;   // its own counter (zeroed by k_prep_thresh_lazy): it takes tickets only if a unit reported
+    P.ticket_base = 0;
+    P.redo = 1;
+    const size_t lds = (size_t)(fast::FN + WAVES * fast::WAVE_CX_H) * sizeof(fast::cf) + (1024 + T2_FLOATS) * sizeof(float) +
+                       256 * 8 + 514 * 8 + 16 + (prop ? 528 : 0);
+    if (prop) hipLaunchKernelGGL((fast::k_gate_onepass<WAVES, true>), dim3((unsigned)(ub * ntt)), dim3(WAVES * 64), lds, st, P);
+    else hipLaunchKernelGGL((fast::k_gate_onepass<WAVES, false>), dim3((unsigned)(ub * ntt)), dim3(WAVES * 64), lds, st, P);
+    HIPCHK(h, hipGetLastError());
   }
   h->dbg_xbits = true;
   h->dbg_tf0 = A.h_begin - 3;
@@ -2712,6 +2776,10 @@ extern "C" int sg_set_option(sg_handle* h, int32_t option, int64_t value) {
       h->rg_shape = (int)value;
       return SG_OK;
     case SG_OPT_INJECT_HANDOFF_FAULT: h->inject_fault = (unsigned)value & 63u; return SG_OK;
+    case SG_OPT_FLOOR_TEST:
+      if (value < 0 || value > 2) FAIL(h, SG_E_INVALID, "SG_OPT_FLOOR_TEST: 0 (predicted), 1 (a priori) or 2 (in the gate kernel)");
+      h->floor_test = (int)value;
+      return SG_OK;
   }
   FAIL(h, SG_E_INVALID, "sg_set_option: unknown option %d", option);
 }
@@ -2776,6 +2844,10 @@ extern "C" int sg_debug_range(const sg_handle* h, int64_t range[2]) {
 
 extern "C" int sg_debug_counter(sg_handle* h, int32_t which, int64_t* value, void* stream) {
   if (!h || !value) return SG_E_INVALID;
+  if (which == 1 || which == 2) {   // host counters: one-pass gate calls with the in-kernel (1) / a-priori (2) floor test
+    *value = which == 1 ? h->n_floor_lazy : h->n_floor_apriori;
+    return SG_OK;
+  }
   if (which != 0) FAIL(h, SG_E_INVALID, "sg_debug_counter: unknown counter %d", which);
   *value = 0;
   if (!h->rg_count.p) return SG_OK;

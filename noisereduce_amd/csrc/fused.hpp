@@ -73,10 +73,13 @@ __global__ void k_unit_absmax(View view, int64_t n_units, unsigned* __restrict__
 // Also keeps two buffers clean so that no memset launch sits on the critical path: umax_bits (zeroed after it
 // was read: k_unit_absmax of the NEXT call accumulates into it with atomicMax) and the pmax rows of the units
 // whose floor can be live (the floor pre-pass accumulates into them; nobody reads the other rows).
+// live_host (host-mapped, may be null): set to `stamp` when some unit's floor may be live -- the one-pass gate's host
+// side reads it (without synchronising) to choose between this a-priori test and the in-kernel one, see
+// k_prep_thresh_lazy.
 __global__ void k_prep_thresh(const double* __restrict__ thresh, int F, double mag_scale, double sum_abs_w,
                               double top_db, unsigned* __restrict__ umax_bits, int64_t n_units,
                               double* __restrict__ T2, int* __restrict__ need_floor, double* __restrict__ pmax,
-                              int FS) {
+                              int FS, unsigned* __restrict__ live_host, unsigned stamp) {
   const double eps = 2.220446049250313e-16;
   __shared__ double s_min[256];
   double mn = 1e300;
@@ -113,8 +116,64 @@ __global__ void k_prep_thresh(const double* __restrict__ thresh, int F, double m
     // 2: a NaN / Inf sample in the unit -- every band's maximum is NaN, no cell passes (T2_NEVER)
     const int need = mbits >= 0x7f800000u ? 2 : ((ub_db - top_db > min_thresh) ? 1 : 0);
     need_floor[u] = need;
-    if (need)
+    if (need) {
       for (int f = 0; f < FS; ++f) pmax[u * (int64_t)FS + f] = 0.0;
+      if (live_host) *live_host = stamp;
+    }
+  }
+}
+
+// The one-pass gate's variant (onepass.hpp): k_unit_absmax reads the whole recording once more (26 us of a 345 us
+// call at 10 minutes of 48 kHz) only to learn that no unit's floor can be live.  Here the gate kernel makes that test
+// itself on the samples it stages anyway: this kernel turns the dB test of k_prep_thresh into ONE compare constant on
+// max|x|,
+//   20 log10(max|x| sum|w| mag_scale + eps) + 1e-6 - top_db > min_f thresh[f]   <=>   max|x| > a_lim,
+// published as the bit pattern of a float a little BELOW a_lim (non-negative floats order like their bit patterns; a
+// test that fires too often only costs time: a flagged unit takes the exact floor path).  need_floor[], the "some unit
+// reported" word and the second launch's work counter are cleared: the gate's tiles OR their verdicts into the flags.
+__global__ void k_prep_thresh_lazy(const double* __restrict__ thresh, int F, double mag_scale, double sum_abs_w,
+                                   double top_db, int64_t n_units, double* __restrict__ T2,
+                                   int* __restrict__ need_floor, unsigned* __restrict__ alim_bits,
+                                   unsigned* __restrict__ ticket2) {
+  const double eps = 2.220446049250313e-16;
+  __shared__ double s_min[256];
+  double mn = 1e300;
+  const double zero_db = 20.0 * log10(eps);
+  for (int f = threadIdx.x; f < F; f += blockDim.x) {
+    const double th = thresh[f];
+    mn = fmin(mn, th);
+    double t2;
+    if (th != th) {
+      t2 = T2_NEVER;
+    } else if (zero_db > th) {
+      t2 = -1.0;
+    } else {
+      const double tm = (exp10(th / 20.0) - eps) / mag_scale;
+      t2 = tm > 0.0 ? tm * tm : 0.0;
+    }
+    T2[f] = t2;
+  }
+  for (int64_t u = threadIdx.x; u < n_units; u += blockDim.x) need_floor[u] = 0;
+  s_min[threadIdx.x] = mn;
+  __syncthreads();
+  for (int o = blockDim.x / 2; o > 0; o >>= 1) {
+    if ((int)threadIdx.x < o) s_min[threadIdx.x] = fmin(s_min[threadIdx.x], s_min[threadIdx.x + o]);
+    __syncthreads();
+  }
+  if (threadIdx.x == 0) {
+    // k_prep_thresh: ub = float(max|x| (1 + 2^-22)) sum|w| mag_scale;  need <=> 20 log10(ub + eps) + 1e-6 - top_db > min
+    const double lim = (exp10((s_min[0] + top_db - 1e-6) / 20.0) - eps) / (sum_abs_w * mag_scale);
+    unsigned bits;
+    if (!(lim > 0.0)) {
+      bits = 0u;                               // (or NaN) every tile reports: the floor path is exact for every unit
+    } else {
+      // 1e-6 relative slack covers the float rounding of max|x| (k_unit_absmax inflates by an ulp) and exp10's error
+      const float lf = __double2float_rd(lim * (1.0 - 1e-6));
+      bits = __float_as_uint(lf);              // +Inf (limit beyond float): only non-finite samples report
+    }
+    alim_bits[0] = bits;
+    alim_bits[1] = 0u;     // "some unit reported"
+    *ticket2 = 0u;         // work counter of the gate's second launch (it only counts when a unit reported)
   }
 }
 

@@ -69,6 +69,14 @@ struct OnePassArgs {
   int nf, nt;
   float prop, inv_ktot;       // PROP instantiation: prop_decrease and 1 / ktot (A.kscale = 1/512 then)
   unsigned long long* part2;  // [units][n_tiles][3][256] trailing partial hops of every tile: granules {float, epoch}
+  // In-kernel floor test (see "floor test" in the kernel): alim = bit pattern of the largest max|x| for which no band's
+  // -top_db floor can be live (k_prep_thresh_lazy), null when the flags in tc.need_floor were computed up front
+  // (k_unit_absmax + k_prep_thresh).  redo = 1: the second launch of such a call -- only the units whose test fired run.
+  // alim[1]: "some unit reported" (cleared by k_prep_thresh_lazy): the second launch returns at once -- before tables and
+  // ticket -- when it is 0 (2064 workgroups that only took their ticket and left cost 83 us: tools/ubench/ticket_atomic.hip)
+  unsigned* alim;
+  int redo;
+  int scan_q;                 // in-kernel floor test: samples of the unit window's unstaged part that each tile scans
 #if OP_TRACE
   unsigned* trace;                   // [workgroups][4 waves][16] shader cycles per phase (slot 15 = 1: tile completed): development builds
 #endif
@@ -154,7 +162,9 @@ __global__ __launch_bounds__(WAVES * 64, 3) void k_gate_onepass(OnePassArgs P) {
   unsigned* t_slot_ = nullptr;   // known once the ticket is
 #endif
 
+  if (P.redo && P.alim[1] == 0u) return;   // second launch of a call none of whose units reported (the common case)
   double t2pre[3];   // compare constants of entries tid, tid + 256 and 512 (they do not depend on the ticket)
+  unsigned alim_v = 0u;
   {
     // table loads first, the ticket's atomic behind them in the same queue: one memory round trip, not two
     static_assert(FN == 2 * WAVES * 64 && WAVES * 64 == 256, "one pass of the prologue loads per thread");
@@ -165,6 +175,13 @@ __global__ __launch_bounds__(WAVES * 64, 3) void k_gate_onepass(OnePassArgs P) {
     t2pre[0] = P.tc.T2[perm_inv(tid)];
     t2pre[1] = P.tc.T2[perm_inv(tid + 256)];
     t2pre[2] = P.tc.T2[perm_inv(512)];
+    if (P.alim != nullptr && !P.redo) {
+      // the floor test's compare constant: a VECTOR load behind the table loads (as a scalar load the compiler places it
+      // at its use, after the span has landed: one more exposed round trip per tile, 5 us of the kernel)
+      int z = 0;
+      asm volatile("" : "+v"(z));
+      alim_v = P.alim[z];
+    }
     if (tid == 0) {
       s_misc[0] = atomicAdd(P.ticket, 1u) - P.ticket_base;
       s_misc[1] = 0u;   // set when a hand-off of this tile is lost: its output hops are POISONED (NaN), never plausible garbage
@@ -196,7 +213,11 @@ __global__ __launch_bounds__(WAVES * 64, 3) void k_gate_onepass(OnePassArgs P) {
   const unsigned gu = (unsigned)(A.view.unit0 + u), nch = (unsigned)A.view.n_chunks;
   const int64_t row = gu / nch;
   const int64_t chunk = A.view.c0 + gu % nch;
-  const int need = P.tc.need_floor[u];
+  // Floor flags of the unit.  lazy (P.alim set): the first launch assumes "not live" and runs the floor test on the
+  // samples it stages (below); the second launch (P.redo) serves exactly the units whose test fired.
+  const bool lazy = P.alim != nullptr;
+  const int need = (lazy && !P.redo) ? 0 : P.tc.need_floor[u];
+  if (P.redo && need == 0) return;   // whole workgroup (the ticket is taken: the counter stays in step with the grid)
   const bool floor_live = need == 1;
 
   // compare constants (x4: the split works on 2X), permuted like the lanes' entries -- see k_decide_fast
@@ -205,7 +226,7 @@ __global__ __launch_bounds__(WAVES * 64, 3) void k_gate_onepass(OnePassArgs P) {
       double fl = cell_db(P.tc.pmax[u * G.FS + f], P.mag_scale) - P.top_db;
       if (fl > P.tc.thresh[f]) v = -1.0;
     }
-    if (need == 2) v = T2_NEVER;   // non-finite sample in the unit
+    if (need & 2) v = T2_NEVER;   // non-finite sample in the unit (wins over 1: lazy tiles OR their verdicts together)
     return v;
   };
   const int64_t tf_tile = A.h_begin - 3 + (int64_t)jt * NF;  // first frame of the tile (abutting tiles)
@@ -236,6 +257,45 @@ __global__ __launch_bounds__(WAVES * 64, 3) void k_gate_onepass(OnePassArgs P) {
       }
     };
     float* xs = reinterpret_cast<float*>(regions);
+    // ---- floor test (lazy, first launch).  k_unit_absmax + k_prep_thresh read the whole recording before the gate to
+    // decide, per unit, whether _amp_to_db's floor max(dB, band max - top_db) (spectralgate/utils.py:16) can lift a band
+    // over its threshold: max|x| sum|w| bounds every |X|.  The tiles of a unit stage nearly all of its window anyway:
+    // each compares the largest sample it staged with the same bound (alim).  The rest of the window -- the chunk's
+    // padding, which no tile of THIS unit transforms: A = [s_lo, first span) and B = [last span's end, s_hi) -- is dealt
+    // to the unit's tiles in slices of P.scan_q samples of A ++ B (~1200 at the default chunking: five loads per thread,
+    // in flight with the span's).  A tile whose test fires reports its unit: need_floor[u] |= 1 (2: a non-finite
+    // sample), the unit's band maxima cleared for the float64 pre-pass that follows.  This launch's result for a reported
+    // unit is overwritten by the second (P.redo).
+    const bool test = lazy && !P.redo;
+    unsigned mi = 0u;   // max |x| seen by this thread, as a bit pattern (sign cleared: NaN / Inf order above every finite value)
+    auto ab = [](float x) -> unsigned { return __float_as_uint(x) & 0x7fffffffu; };
+    constexpr int SCAN_REG = 5;                     // slices up to 5 x 256 samples ride in registers
+    int64_t sc_lo = 0, sc_last = 0, sc_lenA = 0, sc_c0 = 0, sc_c1 = 0;
+    const float* sc_base = nullptr;                 // float32 samples, slice inside A or inside B: its first sample
+    if (test) {
+      const int64_t g0 = chunk * A.view.cs - A.view.pad;
+      const int64_t s_lo = max<int64_t>(0, A.view.lo - g0), s_hi = min<int64_t>(A.view.Lp, A.view.hi - g0);
+      const int64_t sp0 = (A.h_begin - 3 - NF) * 256 - G.padL;                                   // tile -1's span begins
+      const int64_t sp1 = (A.h_begin - 3 + (int64_t)A.n_tiles * NF) * 256 - G.padL + SPAN;       // tile n_tiles' span ends
+      const int64_t first = min(s_hi, max(s_lo, sp0));
+      sc_lo = s_lo;
+      sc_last = max(s_lo, min(s_hi, sp1));
+      sc_lenA = first - s_lo;
+      sc_c0 = (int64_t)(jt + 1) * P.scan_q;
+      sc_c1 = min(sc_c0 + P.scan_q, sc_lenA + (s_hi - sc_last));
+      if (A.view.dtype == 0 && sc_c1 > sc_c0 && sc_c1 - sc_c0 <= SCAN_REG * WAVES * 64 && (sc_c1 <= sc_lenA || sc_c0 >= sc_lenA))
+        sc_base = (const float*)A.view.x + row * A.view.stride + g0 + (sc_c1 <= sc_lenA ? s_lo + sc_c0 : sc_last + (sc_c0 - sc_lenA));
+    }
+    float sc[SCAN_REG];
+    // issued BEHIND the span's loads (every later phase waits for the span), consumed after them.  One scalar base + a
+    // clamped lane offset: the slice's tail re-reads its last sample (a predicated load is a branch and a copy)
+    auto scan_issue = [&]() {
+      if (sc_base != nullptr) {
+        const int n1 = (int)(sc_c1 - sc_c0) - 1;
+#pragma unroll
+        for (int k = 0; k < SCAN_REG; ++k) sc[k] = sc_base[min(tid + k * WAVES * 64, n1)];
+      }
+    };
     if (blk_vec) {
       // span loads in flight while the compare constants are built
       constexpr int NQ = (SPAN / 4 + WAVES * 64 - 1) / (WAVES * 64);
@@ -243,18 +303,48 @@ __global__ __launch_bounds__(WAVES * 64, 3) void k_gate_onepass(OnePassArgs P) {
 #pragma unroll
       for (int k = 0; k < NQ; ++k) {
         const int i = tid + k * WAVES * 64;
-        q[k] = i < SPAN / 4 ? reinterpret_cast<const float4*>(sp)[i] : make_float4(0.f, 0.f, 0.f, 0.f);
+        // (clamped, not predicated: a predicated load is a branch + a copy of its result, and that copy waited for every
+        // load in flight -- before the compare constants, which were meant to be built under the loads)
+        q[k] = reinterpret_cast<const float4*>(sp)[min(i, SPAN / 4 - 1)];
       }
+      scan_issue();
       fill_t2();
 #pragma unroll
       for (int k = 0; k < NQ; ++k) {
         const int e = 4 * (tid + k * WAVES * 64);
-        if (e < SPAN) *reinterpret_cast<float4*>(&xs[(e >> 8) * XPITCH + (e & 255)]) = q[k];
+        if ((k + 1) * WAVES * 64 <= SPAN / 4 || e < SPAN) *reinterpret_cast<float4*>(&xs[(e >> 8) * XPITCH + (e & 255)]) = q[k];
+        mi = max(max(mi, max(ab(q[k].x), ab(q[k].y))), max(ab(q[k].z), ab(q[k].w)));
       }
     } else {
+      scan_issue();
       fill_t2();
-      for (int i = tid; i < SPAN; i += WAVES * 64)
-        xs[(i >> 8) * XPITCH + (i & 255)] = (float)view_sample(A.view, row, chunk, s0b + i);
+      for (int i = tid; i < SPAN; i += WAVES * 64) {
+        const float xv = (float)view_sample(A.view, row, chunk, s0b + i);
+        xs[(i >> 8) * XPITCH + (i & 255)] = xv;
+        mi = max(mi, ab(xv));
+      }
+    }
+    if (test) {
+      if (sc_base != nullptr) {
+#pragma unroll
+        for (int k = 0; k < SCAN_REG; ++k) mi = max(mi, ab(sc[k]));
+      } else {
+        // the slice that straddles A | B, long slices (padding much longer than the kept part), other sample types: a
+        // loop after the span
+        for (int64_t i = sc_c0 + tid; i < sc_c1; i += WAVES * 64)
+          mi = max(mi, ab((float)view_sample(A.view, row, chunk, i < sc_lenA ? sc_lo + i : sc_last + (i - sc_lenA))));
+      }
+      const bool hit = mi >= alim_v;
+      if (__any(hit)) {   // wave-uniform, rare
+        const bool nonfinite = __any(mi >= 0x7f800000u);
+        double* pm = const_cast<double*>(P.tc.pmax) + u * G.FS;
+        for (int f = lane; f < G.FS; f += 64) pm[f] = 0.0;
+        if (lane == 0) {
+          atomicOr(const_cast<int*>(P.tc.need_floor) + u, nonfinite ? 2 : 1);
+          P.alim[1] = 1u;
+          P.err[1] = P.epoch;   // host-mapped: "a unit of launch `epoch` reported" (the host picks the a-priori test next time)
+        }
+      }
     }
   }
   __syncthreads();  // tables, compare constants and span staged

@@ -279,3 +279,100 @@ def test_inf_sample_against_the_reference_golden(nr, golden_dir, name):
     inside = fin & ~other
     dev = np.abs(out[inside] - gold[inside]).max() / peak
     assert dev > TOL, dev         # if this ever fails the engine has started to match the reference: update DESIGN.md
+
+
+# ---- one-pass gate: floor test a priori (k_unit_absmax) vs in the gate kernel (SG_OPT_FLOOR_TEST) -------------------
+def _floor_inputs(kind):
+    rng = np.random.default_rng(1234)
+    n, cs, pad = 150000, 40000, 6000
+    y = (0.05 * rng.standard_normal(n)).astype(np.float32)
+    y_noise = (0.05 * rng.standard_normal(30000)).astype(np.float32)
+    if kind == "benign":
+        pass
+    elif kind == "live":              # loud half next to digital silence, very quiet noise clip: bands lifted by the floor
+        y[: n // 2] = 0.0
+        y[n // 2:] *= 10.0
+        y_noise = (1e-7 * rng.standard_normal(30000)).astype(np.float32)
+    elif kind == "loud_in_padding":   # the only loud samples of chunk 1's window sit in its left padding (chunk 0's tail)
+        y[:] = (1e-6 * rng.standard_normal(n)).astype(np.float32)
+        y[cs - pad + 200: cs - pad + 1500] = (0.9 * rng.standard_normal(1300)).astype(np.float32)
+        y_noise = (1e-7 * rng.standard_normal(30000)).astype(np.float32)
+    elif kind == "nan_in_padding":    # a NaN that only chunk 2's right padding sees (and chunk 3's body)
+        y[3 * cs + 4000] = np.nan
+    elif kind == "inf_far_padding":   # an Inf near the far end of chunk 0's right padding
+        y[cs + pad - 3] = np.inf
+    return y, y_noise, cs, pad
+
+
+@pytest.mark.parametrize("prop", [1.0, 0.8])
+@pytest.mark.parametrize("kind", ["benign", "live", "loud_in_padding", "nan_in_padding", "inf_far_padding"])
+def test_onepass_floor_test_in_kernel_equals_a_priori(kind, prop):
+    """SG_OPT_FLOOR_TEST: the gate kernel's own floor test (+ second launch for the chunks that report) gives the output
+    of the a-priori test, bit for bit, also when the samples that matter sit in a chunk's PADDING (staged by no tile of
+    that chunk: the halo tiles scan it), and the oracle's result."""
+    from noisereduce_amd import _ffi
+    from noisereduce_amd.spectralgate.stationary import SpectralGateStationary
+    y, y_noise, cs, pad = _floor_inputs(kind)
+    kw = dict(sr=48000, y_noise=y_noise, prop_decrease=prop, n_std_thresh_stationary=1.5, chunk_size=cs,
+              clip_noise_stationary=True, padding=pad, n_fft=1024, win_length=None, hop_length=None,
+              time_constant_s=2.0, freq_mask_smooth_hz=500, time_mask_smooth_ms=50, tmp_folder=None, use_tqdm=False,
+              n_jobs=1)
+    sg = SpectralGateStationary(y=y, **kw)
+    outs = {}
+    try:
+        for mode in (1, 2, 0, 0):
+            sg._gate.set_option(_ffi.SG_OPT_FLOOR_TEST, mode)
+            outs.setdefault(mode, []).append(sg.get_traces())
+    finally:
+        sg._gate.set_option(_ffi.SG_OPT_FLOOR_TEST, 0)
+    ref = outs[1][0]
+    for mode, lst in outs.items():
+        for o in lst:
+            assert np.array_equal(o, ref, equal_nan=True), (kind, mode)
+    if kind in ("benign", "live", "loud_in_padding"):
+        want = O.reduce_noise_S(y.astype(np.float64), 48000, stationary=True, y_noise=y_noise.astype(np.float64),
+                                prop_decrease=prop, chunk_size=cs, padding=pad)
+        assert O.rel_err(ref, want) < TOL
+    else:
+        # the reference's behaviour for a non-finite sample (golden vectors: test_nan_sample_golden): the chunk windows
+        # that hold it come back NaN where its frames reach and gated to zero elsewhere; here: the two modes agree (above)
+        assert np.isnan(ref).any()
+
+
+def test_onepass_floor_test_prediction_follows_the_data():
+    """Default mode: after a call whose chunks reported (floor possibly live) the handle takes the a-priori test, after
+    calls that did not it returns to the in-kernel one (sg_debug_counter 1 / 2 count the batches of either kind)."""
+    from noisereduce_amd import _ffi
+    from noisereduce_amd.spectralgate.stationary import SpectralGateStationary
+    kw = dict(sr=48000, prop_decrease=1.0, n_std_thresh_stationary=1.5, clip_noise_stationary=True, n_fft=1024,
+              win_length=None, hop_length=None, time_constant_s=2.0, freq_mask_smooth_hz=500, time_mask_smooth_ms=50,
+              tmp_folder=None, use_tqdm=False, n_jobs=1)
+    yb, nb, cs, pad = _floor_inputs("benign")
+    yl, nl, _, _ = _floor_inputs("live")
+    sb = SpectralGateStationary(y=yb, y_noise=nb, chunk_size=cs, padding=pad, **kw)
+    sl = SpectralGateStationary(y=yl, y_noise=nl, chunk_size=cs, padding=pad, **kw)
+    assert sb._gate is sl._gate            # same geometry -> same cached handle
+    gate = sb._gate
+    gate.set_option(_ffi.SG_OPT_FLOOR_TEST, 0)
+
+    def run(sg):
+        a0, b0 = gate.debug_counter(1), gate.debug_counter(2)
+        out = sg.get_traces()
+        torch.cuda.synchronize()            # the stamp of this call is visible to the next one
+        return (gate.debug_counter(1) - a0, gate.debug_counter(2) - b0), out
+
+    for _ in range(20):                     # whatever earlier tests left in the handle's history has aged out
+        sb.get_traces()
+    torch.cuda.synchronize()
+    n_chunks = -(-len(yb) // cs)
+    how, out_b = run(sb)
+    assert how == (1, 0)                    # benign history: in-kernel test (one batch)
+    how1, out_l1 = run(sl)                  # first live call: still in-kernel (its chunks report) ...
+    how2, out_l2 = run(sl)                  # ... the next one takes the a-priori test
+    assert how1 == (1, 0) and how2 == (0, 1)
+    assert np.array_equal(out_l1, out_l2, equal_nan=True)
+    for _ in range(20):
+        sb.get_traces()
+    torch.cuda.synchronize()
+    how3, out_b2 = run(sb)
+    assert how3 == (1, 0) and np.array_equal(out_b, out_b2)
