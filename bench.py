@@ -260,6 +260,10 @@ def main():
     ap.add_argument("--steps", type=int, default=20)
     ap.add_argument("--warmup", type=int, default=5)
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--event-every", type=int, default=4,
+                    help="HIP events around the dominant kernel (and a step-boundary event) on every E-th step of the timed "
+                         "region: each event pair is ~6 us of queue time around a 0.25 ms kernel, 4 %% of a step when every "
+                         "step carries them (1 = every step)")
     ap.add_argument("--no-extras", action="store_true", help="skip other_configs / parity legs")
     ap.add_argument("--workload", choices=["config2", "config3", "config4"], default="config2")
     ap.add_argument("--nonstationary", action="store_true", help="alias of --workload config3")
@@ -389,13 +393,6 @@ def main():
 
     for _ in range(args.warmup):
         step()
-    # untimed settle loop on top of the W warm-up steps: ~0.1 s of back-to-back steps so that clock / power-state
-    # transitions of a GPU that was idle a moment ago happen BEFORE the timed region (one default run in ~20 showed a
-    # single 8 ms step among its 20 right after the box had been idle; per-step times are in `ms_per_step_all`)
-    # (a FIXED count: every rank must run the same number of collectives)
-    settle_steps = 20 if wl == "config4" else 200
-    for _ in range(settle_steps):
-        step()
     torch.cuda.synchronize(device)
     _gc.collect()
     _gc.freeze()
@@ -409,22 +406,40 @@ def main():
     for _ in range(survey_steps):
         step()
     survey = gate.profile_read(reset=True)
+    gate.profile_enable(False)
     dom = max(survey, key=lambda k: survey[k][0])
+    # untimed settle loop on top of the W warm-up steps, DIRECTLY before the timed region: ~0.1 s of back-to-back steps
+    # so that clock / power-state transitions of a GPU that was idle a moment ago happen BEFORE the timed steps.  (Up to
+    # round 4 the survey pass and a gc.collect() sat between this loop and the timed region: the queue ran dry for
+    # milliseconds and the first timed steps ran 10 % slower than the last -- `ms_per_step_all` fell monotonically.
+    # One default run in ~20 of round 2 showed a single 8 ms step right after the box had been idle.)
+    # (a FIXED count: every rank must run the same number of collectives)
+    settle_steps = 20 if wl == "config4" else 200
+    for _ in range(settle_steps):
+        step()
     # timed region: HIP events (on the launch stream) only around the dominant kernel, plus one event per
     # step boundary (median of the per-step times next to the mean)
     gate.profile_select([dom])
-    marks = [torch.cuda.Event(enable_timing=True) for _ in range(args.steps + 1)] if n_streams == 1 else None
+    gate.profile_enable(False)
+    # (events on every E-th step only: the kernel's average duration over those launches is the roofline's; the steps
+    # between run as a caller's would, without instrumentation in the queue)
+    E = max(1, args.event_every) * n_streams
+    sampled = [i for i in range(args.steps) if i % E == 0]
+    mark_at = sampled + [args.steps]
+    marks = {i: torch.cuda.Event(enable_timing=True) for i in mark_at} if n_streams == 1 else None
     if marks:
         # torch creates the HIP event at the first record(): do that here, not inside the timed region (right after the
         # opening barrier the GPU queue is empty, so host time of the first step is exposed: one run showed 0.43 ms)
-        for m in marks:
+        for m in marks.values():
             m.record()
     sync()
     t0 = time.perf_counter()
     host_ms = []
     for i in range(args.steps):
-        if marks:
+        on = i % E == 0
+        if on and marks:
             marks[i].record()
+        gate.profile_enable(on)          # a host flag of the handle: no queue traffic
         th0 = time.perf_counter()
         out = step()
         host_ms.append((time.perf_counter() - th0) * 1e3)
@@ -437,7 +452,12 @@ def main():
     profs = [gate.profile_read(reset=True)]
     gate.profile_enable(False)
     gate.profile_select(None)
-    per_step = [marks[i].elapsed_time(marks[i + 1]) for i in range(args.steps)] if marks else None
+    # per-step times between consecutive step-boundary events (E steps apart: their mean)
+    per_step = None
+    if marks:
+        per_step = []
+        for a, b in zip(mark_at, mark_at[1:]):
+            per_step += [marks[a].elapsed_time(marks[b]) / (b - a)] * (b - a)
     if world > 1:
         tt = torch.tensor([elapsed], device=device, dtype=torch.float64)
         dist.all_reduce(tt, op=dist.ReduceOp.MAX)
@@ -524,7 +544,7 @@ def main():
                 a[1] += cnt
         avg_ms = agg[dom][0] / agg[dom][1]
         # the event pairs live in the handle of stream 0: it ran every n_streams-th step
-        steps_profiled = (args.steps + n_streams - 1) // n_streams
+        steps_profiled = len(sampled)
         launches_per_step = agg[dom][1] / steps_profiled
         algo_bytes = ALGO_BYTES_PER_SAMPLE * samples_per_gpu / launches_per_step
         achieved = algo_bytes / (avg_ms * 1e-3) / 1e9
@@ -559,6 +579,8 @@ def main():
                          "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBS, 5), "traffic": traffic,
                          "traffic_source": traffic_src,
                          "avg_launch_ms": round(avg_ms, 4), "algorithmic_bytes_per_launch": int(algo_bytes),
+                         "events": "HIP events around this kernel on every %d-th step of the timed region (%d launches)"
+                                   % (E, agg[dom][1]),
                          "whole_step_frac": round(value * 1e6 / world * ALGO_BYTES_PER_SAMPLE / 1e9
                                                   / HBM_PEAK_GBS, 5),
                          # the binding resource of this kernel is the float32 vector pipe, not HBM:

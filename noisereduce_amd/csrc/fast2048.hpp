@@ -69,7 +69,21 @@ __device__ __forceinline__ void f20_gather(const Fast20Args& A, cf* tw, cf* regi
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, g = lane >> 5, c = lane & 31;
   constexpr int NF = 2 * WAVES, ROWS = NF - 1 + 4, SPAN = ROWS * F20_H;
   static_assert(ROWS * F20_XP * 4 <= WAVES * WAVE_CX_H * 8, "span must fit the exchange slices");
-  for (int i = tid; i < 1024; i += WAVES * 64) tw[i] = f20_w1024(A.tw2048, (i >> 5) * (i & 31));
+  {
+    // (all table loads issued before the first store: see stage_tables in fastpath.hpp)
+    constexpr int K = (1024 + WAVES * 64 - 1) / (WAVES * 64);
+    cf t[K];
+#pragma unroll
+    for (int k = 0; k < K; ++k) {
+      const int i = min(tid + k * WAVES * 64, 1023);
+      t[k] = f20_w1024(A.tw2048, (i >> 5) * (i & 31));
+    }
+#pragma unroll
+    for (int k = 0; k < K; ++k) {
+      const int i = tid + k * WAVES * 64;
+      if (i < 1024) tw[i] = t[k];
+    }
+  }
   const Geom& G = A.g;
   const int64_t s0b = tf0 * F20_H - G.padL;
   const int64_t gb = chunk * A.view.cs - A.view.pad + s0b;
@@ -78,11 +92,7 @@ __device__ __forceinline__ void f20_gather(const Fast20Args& A, cf* tw, cf* regi
                    gb >= A.view.lo && gb + SPAN <= A.view.hi && (reinterpret_cast<uintptr_t>(sp) & 15) == 0;
   float* xs = reinterpret_cast<float*>(regions);
   if (vec) {
-    for (int i = tid; i < SPAN / 4; i += WAVES * 64) {
-      const float4 q = reinterpret_cast<const float4*>(sp)[i];
-      const int e = 4 * i;
-      *reinterpret_cast<float4*>(&xs[(e >> 9) * F20_XP + (e & 511)]) = q;
-    }
+    stage_span_vec<WAVES * 64, SPAN, F20_XP, 512>(xs, sp, tid);
   } else {
     for (int i = tid; i < SPAN; i += WAVES * 64)
       xs[(i >> 9) * F20_XP + (i & 511)] = (float)view_sample(A.view, row, chunk, s0b + i);

@@ -60,8 +60,7 @@ __device__ __forceinline__ void f5_gather(const Fast5Args& A, cf* tw512, cf* reg
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, g = lane >> 4, c = lane & 15;
   constexpr int NF = F5_FPW * WAVES, ROWS = NF - 1 + 4, SPAN = ROWS * F5_H;
   static_assert(ROWS * F5_XP * 4 <= WAVES * WAVE_CX_H * 8, "span must fit the exchange slices");
-  for (int i = tid; i < FN; i += WAVES * 64) tw512[i] = A.tw512[(i >> 4) * (i & 15)];
-  for (int i = tid; i < 128; i += WAVES * 64) reinterpret_cast<float4*>(swin)[i] = reinterpret_cast<const float4*>(A.win)[i];
+  stage_tables<WAVES * 64, 128>(tw512, A.tw512, swin, A.win, tid);
   const Geom& G = A.g;
   const int64_t s0b = tf0 * F5_H - G.padL;
   const int64_t gb = chunk * A.view.cs - A.view.pad + s0b;
@@ -70,11 +69,7 @@ __device__ __forceinline__ void f5_gather(const Fast5Args& A, cf* tw512, cf* reg
                    gb >= A.view.lo && gb + SPAN <= A.view.hi && (reinterpret_cast<uintptr_t>(sp) & 15) == 0;
   float* xs = reinterpret_cast<float*>(regions);
   if (vec) {
-    for (int i = tid; i < SPAN / 4; i += WAVES * 64) {
-      const float4 q = reinterpret_cast<const float4*>(sp)[i];
-      const int e = 4 * i;
-      *reinterpret_cast<float4*>(&xs[(e >> 7) * F5_XP + (e & 127)]) = q;
-    }
+    stage_span_vec<WAVES * 64, SPAN, F5_XP, 128>(xs, sp, tid);
   } else {
     for (int i = tid; i < SPAN; i += WAVES * 64)
       xs[(i >> 7) * F5_XP + (i & 127)] = (float)view_sample(A.view, row, chunk, s0b + i);

@@ -133,12 +133,24 @@ __global__ __launch_bounds__(WAVES * 64, 2) void k_power_fast64(Pow64Args A) {
   const int tid = threadIdx.x;
   const int lane = tid & 63, wave = tid >> 6;
   const int g = lane >> 4, c = lane & 15;
-  if (tid < 17) tw_lo[tid] = A.tw1024[tid];
-  for (int i = tid; i < FN; i += WAVES * 64) {
-    const int idx = 2 * (i >> 4) * (i & 15);   // w_512^j = w_1024^(2 j), 2 j < 1024
-    cd w = A.tw1024[idx & 511];
-    if (idx >= 512) w = {-w.x, -w.y};
-    tw512[i] = w;
+  {
+    // (every load of the prologue issued before the first store: see stage_tables in fastpath.hpp)
+    constexpr int K = (FN + WAVES * 64 - 1) / (WAVES * 64);
+    cd t[K];
+    const cd tl = A.tw1024[min(tid, 16)];
+#pragma unroll
+    for (int k = 0; k < K; ++k) {
+      const int i = min(tid + k * WAVES * 64, FN - 1);
+      const int idx = 2 * (i >> 4) * (i & 15);   // w_512^j = w_1024^(2 j), 2 j < 1024
+      t[k] = A.tw1024[idx & 511];
+      if (idx >= 512) t[k] = {-t[k].x, -t[k].y};
+    }
+    if (tid < 17) tw_lo[tid] = tl;
+#pragma unroll
+    for (int k = 0; k < K; ++k) {
+      const int i = tid + k * WAVES * 64;
+      if (i < FN) tw512[i] = t[k];
+    }
   }
   const Geom& G = A.g;
   const int64_t u = blockIdx.y;
@@ -158,18 +170,23 @@ __global__ __launch_bounds__(WAVES * 64, 2) void k_power_fast64(Pow64Args A) {
     const bool blk_in = A.view.dtype == 0 && s0b >= 0 && s0b + SPAN <= A.view.Lp && gb >= A.view.lo &&
                         gb + SPAN <= A.view.hi;
     const float* sp = (const float*)A.view.x + row * A.view.stride + gb;
-    if (blk_in && (reinterpret_cast<uintptr_t>(sp) & 15) == 0) {
-      for (int i = tid; i < SPAN / 4; i += WAVES * 64) {
-        const float4 q = reinterpret_cast<const float4*>(sp)[i];
-        const int e = 4 * i;
-        *reinterpret_cast<float4*>(&xs[(e >> 8) * XPITCH + (e & 255)]) = q;
+    {
+      constexpr int KW = (512 + WAVES * 64 - 1) / (WAVES * 64);
+      double2 w2[KW];
+#pragma unroll
+      for (int k = 0; k < KW; ++k) w2[k] = reinterpret_cast<const double2*>(A.win)[min(tid + k * WAVES * 64, 511)];
+      if (blk_in && (reinterpret_cast<uintptr_t>(sp) & 15) == 0) {
+        stage_span_vec<WAVES * 64, SPAN, XPITCH>(xs, sp, tid);
+      } else {
+        for (int i = tid; i < SPAN; i += WAVES * 64)
+          xs[(i >> 8) * XPITCH + (i & 255)] = (float)view_sample(A.view, row, chunk, s0b + i);
       }
-    } else {
-      for (int i = tid; i < SPAN; i += WAVES * 64)
-        xs[(i >> 8) * XPITCH + (i & 255)] = (float)view_sample(A.view, row, chunk, s0b + i);
+#pragma unroll
+      for (int k = 0; k < KW; ++k) {
+        const int i = tid + k * WAVES * 64;
+        if (i < 512) reinterpret_cast<double2*>(wl)[i] = w2[k];
+      }
     }
-    for (int i = tid; i < 512; i += WAVES * 64)
-      reinterpret_cast<double2*>(wl)[i] = reinterpret_cast<const double2*>(A.win)[i];
   }
   const int64_t tq = tqb + wave * 4;
   __syncthreads();

@@ -51,6 +51,56 @@ constexpr int FSK = 528;          // mask row pitch (entries) of the permuted K 
 
 typedef cx<float> cf;
 
+// Prologue loads of the register-FFT kernels: twiddle table, window table and the tile's sample span go to LDS.  Written
+// as rolled loops (load, store, next index) the compiler keeps them rolled and waits for every load before its store --
+// s_waitcnt vmcnt(0) per iteration: eight dependent memory round trips per tile in k_mag_fast / k_apply_fast /
+// k_decide_fast, whose tiles live 13 - 30 us (round 4, ISA of those loops).  Here every load of a group is issued before
+// the first store; indices are CLAMPED, not predicated (a predicated load is a branch and a copy of its result that
+// waits for all loads in flight).
+template <int NTHR, int WIN4>   // WIN4: float4 entries of the window table (0: the kernel keeps no window in LDS)
+__device__ __forceinline__ void stage_tables(cf* tw512, const cf* __restrict__ tw_src, float* swin,
+                                             const float* __restrict__ win_src, int tid) {
+  constexpr bool WIN = WIN4 > 0;
+  constexpr int K = (FN + NTHR - 1) / NTHR, KW = WIN ? (WIN4 + NTHR - 1) / NTHR : 1;
+  cf t[K];
+  float4 w[KW];
+#pragma unroll
+  for (int k = 0; k < K; ++k) {
+    const int i = min(tid + k * NTHR, FN - 1);
+    t[k] = tw_src[(i >> 4) * (i & 15)];
+  }
+  if constexpr (WIN) {
+#pragma unroll
+    for (int k = 0; k < KW; ++k) w[k] = reinterpret_cast<const float4*>(win_src)[min(tid + k * NTHR, WIN4 - 1)];
+  }
+#pragma unroll
+  for (int k = 0; k < K; ++k) {
+    const int i = tid + k * NTHR;
+    if ((k + 1) * NTHR <= FN || i < FN) tw512[i] = t[k];
+  }
+  if constexpr (WIN) {
+#pragma unroll
+    for (int k = 0; k < KW; ++k) {
+      const int i = tid + k * NTHR;
+      if ((k + 1) * NTHR <= WIN4 || i < WIN4) reinterpret_cast<float4*>(swin)[i] = w[k];
+    }
+  }
+}
+// SPAN contiguous float32 samples at sp (16-byte aligned) -> xs, rows of ROW samples at a pitch of XPITCH floats
+template <int NTHR, int SPAN, int XPITCH, int ROW = 256>
+__device__ __forceinline__ void stage_span_vec(float* xs, const float* __restrict__ sp, int tid) {
+  static_assert(SPAN % 4 == 0, "16-byte loads");
+  constexpr int N4 = SPAN / 4, NQ = (N4 + NTHR - 1) / NTHR;
+  float4 q[NQ];
+#pragma unroll
+  for (int k = 0; k < NQ; ++k) q[k] = reinterpret_cast<const float4*>(sp)[min(tid + k * NTHR, N4 - 1)];
+#pragma unroll
+  for (int k = 0; k < NQ; ++k) {
+    const int e = 4 * (tid + k * NTHR);
+    if ((k + 1) * NTHR <= N4 || e < SPAN) *reinterpret_cast<float4*>(&xs[(e / ROW) * XPITCH + (e % ROW)]) = q[k];
+  }
+}
+
 // cos(2 pi k / 32), k = 0..8
 __device__ constexpr float C32[9] = {1.0f,
                                      0.98078528040323044913f,
@@ -571,14 +621,10 @@ __global__ __launch_bounds__(WAVES * 64, LEAN ? 3 : 2) void k_apply_fast(ApplyAr
   const int tid = threadIdx.x;
   const int lane = tid & 63, wave = tid >> 6;
   const int g = lane >> 4, c = lane & 15;
-  for (int i = tid; i < FN; i += WAVES * 64) tw512[i] = A.tw512[(i >> 4) * (i & 15)];
   // LEAN: the window table (4 KB) lives in LDS behind the exchange slices: both window passes read it
   // with ds_read_b64 instead of 64 global loads per lane
   float* swin = reinterpret_cast<float*>(regions + WAVES * (LEAN ? WAVE_CX_H : WAVE_CX));
-  if constexpr (LEAN) {
-    for (int i = tid; i < 256; i += WAVES * 64)
-      reinterpret_cast<float4*>(swin)[i] = reinterpret_cast<const float4*>(A.win)[i];
-  }
+  stage_tables<WAVES * 64, LEAN ? 256 : 0>(tw512, A.tw512, swin, A.win, tid);
   const Geom& G = A.g;
   // which tile: the grid position, or -- when hops are handed from tile to tile inside the launch -- a ticket
   unsigned bx = blockIdx.x, by = blockIdx.y;
@@ -671,11 +717,7 @@ __global__ __launch_bounds__(WAVES * 64, LEAN ? 3 : 2) void k_apply_fast(ApplyAr
               (reinterpret_cast<uintptr_t>(sp) & 15) == 0;
     float* xs = reinterpret_cast<float*>(regions);
     if (blk_vec) {
-      for (int i = tid; i < SPAN / 4; i += WAVES * 64) {
-        const float4 q = reinterpret_cast<const float4*>(sp)[i];
-        const int e = 4 * i;
-        *reinterpret_cast<float4*>(&xs[(e >> 8) * XPITCH + (e & 255)]) = q;
-      }
+      stage_span_vec<WAVES * 64, SPAN, XPITCH>(xs, sp, tid);
     } else {
       for (int i = tid; i < SPAN; i += WAVES * 64)
         xs[(i >> 8) * XPITCH + (i & 255)] = (float)view_sample(A.view, row, chunk, s0b + i);
@@ -1101,7 +1143,6 @@ __global__ __launch_bounds__(WAVES * 64, 3) void k_decide_fast(DecideArgs A) {
   const int tid = threadIdx.x;
   const int lane = tid & 63, wave = tid >> 6;
   const int g = lane >> 4, c = lane & 15;
-  for (int i = tid; i < FN; i += WAVES * 64) tw512[i] = A.tw512[(i >> 4) * (i & 15)];
   const Geom& G = A.g;
   const int64_t u = blockIdx.y;
   const int64_t row = (A.view.unit0 + u) / A.view.n_chunks;
@@ -1133,8 +1174,7 @@ __global__ __launch_bounds__(WAVES * 64, 3) void k_decide_fast(DecideArgs A) {
   // the contiguous sample span of their 4*WAVES frames in the (still idle) exchange slices -- see
   // k_apply_fast
   float* swin = s_t2 + T2_FLOATS;
-  for (int i = tid; i < 256; i += WAVES * 64)
-    reinterpret_cast<float4*>(swin)[i] = reinterpret_cast<const float4*>(A.win)[i];
+  stage_tables<WAVES * 64, 256>(tw512, A.tw512, swin, A.win, tid);
   constexpr int NFB = 4 * WAVES, SPAN = (NFB - 1) * 256 + 1024, XPITCH = 288;
   static_assert((SPAN / 256) * XPITCH <= WAVES * WAVE_CX_H * 2, "span must fit the exchange slices");
   const int64_t tqb = A.t_begin + (int64_t)blockIdx.x * NFB;  // first frame of the workgroup
@@ -1149,11 +1189,7 @@ __global__ __launch_bounds__(WAVES * 64, 3) void k_decide_fast(DecideArgs A) {
               (reinterpret_cast<uintptr_t>(sp) & 15) == 0;
     float* xs = reinterpret_cast<float*>(regions);
     if (blk_vec) {
-      for (int i = tid; i < SPAN / 4; i += WAVES * 64) {
-        const float4 q = reinterpret_cast<const float4*>(sp)[i];
-        const int e = 4 * i;
-        *reinterpret_cast<float4*>(&xs[(e >> 8) * XPITCH + (e & 255)]) = q;
-      }
+      stage_span_vec<WAVES * 64, SPAN, XPITCH>(xs, sp, tid);
     } else {
       for (int i = tid; i < SPAN; i += WAVES * 64)
         xs[(i >> 8) * XPITCH + (i & 255)] = (float)view_sample(A.view, row, chunk, s0b + i);
@@ -1373,7 +1409,6 @@ __global__ __launch_bounds__(WAVES * 64, 3) void k_mag_fast(MagArgs A) {
   const int tid = threadIdx.x;
   const int lane = tid & 63, wave = tid >> 6;
   const int g = lane >> 4, c = lane & 15;
-  for (int i = tid; i < FN; i += WAVES * 64) tw512[i] = A.tw512[(i >> 4) * (i & 15)];
   const Geom& G = A.g;
   const int64_t u = blockIdx.y;
   const int64_t row = (A.view.unit0 + u) / A.view.n_chunks;
@@ -1382,8 +1417,7 @@ __global__ __launch_bounds__(WAVES * 64, 3) void k_mag_fast(MagArgs A) {
   // window table and (interior blocks of float32 input) the block's contiguous sample span in LDS, as
   // in k_apply_fast / k_decide_fast
   float* swin = reinterpret_cast<float*>(regions + WAVES * WAVE_CX_H);
-  for (int i = tid; i < 256; i += WAVES * 64)
-    reinterpret_cast<float4*>(swin)[i] = reinterpret_cast<const float4*>(A.win)[i];
+  stage_tables<WAVES * 64, 256>(tw512, A.tw512, swin, A.win, tid);
   constexpr int NFB = 4 * WAVES, SPAN = (NFB - 1) * 256 + 1024, XPITCH = 288;
   const int64_t tqb = (int64_t)blockIdx.x * NFB;
   // Every block stages its span: interior blocks of float32 input with 16-byte loads, the others (row edges,
@@ -1399,11 +1433,7 @@ __global__ __launch_bounds__(WAVES * 64, 3) void k_mag_fast(MagArgs A) {
               gb >= A.view.lo && gb + SPAN <= A.view.hi && (reinterpret_cast<uintptr_t>(sp) & 15) == 0;
     float* xs = reinterpret_cast<float*>(regions);
     if (blk_vec) {
-      for (int i = tid; i < SPAN / 4; i += WAVES * 64) {
-        const float4 q = reinterpret_cast<const float4*>(sp)[i];
-        const int e = 4 * i;
-        *reinterpret_cast<float4*>(&xs[(e >> 8) * XPITCH + (e & 255)]) = q;
-      }
+      stage_span_vec<WAVES * 64, SPAN, XPITCH>(xs, sp, tid);
     } else {
       for (int i = tid; i < SPAN; i += WAVES * 64)
         xs[(i >> 8) * XPITCH + (i & 255)] = (float)view_sample(A.view, row, chunk, s0b + i);
