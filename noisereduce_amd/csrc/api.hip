@@ -1445,7 +1445,7 @@ static int stage_nonstat_mask2(sg_handle* h, const View& v, const Geom& g, int64
   if ((rc = ensure(h, h->nsc, bytes))) return rc;
   {
     ProfScope ps(h, SG_STAGE_NONSTAT_MASK, st);
-    hipLaunchKernelGGL(k_iir_part, dim3((unsigned)((g.F + 63) / 64), (unsigned)((nk + 3) / 4), (unsigned)ub), dim3(256), 0,
+    hipLaunchKernelGGL(k_iir_part, dim3((unsigned)((nk * (g.FS / 4) + 255) / 256), (unsigned)ub), dim3(256), 0,
                        st, mag, g, tl, h->p.iir_b, (double*)h->nsp.p);
     HIPCHK(h, hipGetLastError());
     hipLaunchKernelGGL(k_iir_chain, dim3((unsigned)((ub * g.FS + 63) / 64)), dim3(64), 0, st, mag,
