@@ -77,6 +77,7 @@ struct sg_handle {
   DevBuf P, pmax, thr_rows, raw, M, seg, yn;
   DevBuf bits, K16, umax, need, T2;  // fused stationary path
   DevBuf alim;                       // one-pass gate, in-kernel floor test: compare constant on max|x| (k_prep_thresh_lazy)
+  bool t2_ready = false;             // T2 / alim hold the compare constants of the CURRENT threshold (any writer of thresh clears it)
   DevBuf logtab;                     // db_fast (kernels.hpp): {rd(1 / c_i), -log2 of it} for 128 mantissa centres
   DevBuf part;                       // partial reductions of the column statistics
   DevBuf tw512, invn;                // fast path tables (n_fft = 1024, hop = 256)
@@ -1201,7 +1202,8 @@ static int stage_colstats(sg_handle* h, const Geom& g, int64_t ub, double* thres
 }
 
 // power field + band statistics -> threshold
-static int stage_stats(sg_handle* h, const View& v, const Geom& g, int64_t ub, double* thresh_out, hipStream_t st) {
+static int stage_stats(sg_handle* h, const View& v, const Geom& g, int64_t ub, double* thresh_out, hipStream_t st,
+                       bool gate_consts = false) {
   if (ub < 16) {
     // few units (the noise clip): STFT -> one pass over the power field -> final (3 launches instead of 5)
     {
@@ -1216,10 +1218,19 @@ static int stage_stats(sg_handle* h, const View& v, const Geom& g, int64_t ub, d
     hipLaunchKernelGGL(k_colstats1, grid, dim3(64 * STAT_TG), 0, st, (const double*)h->P.p, g, h->mag_scale,
                        (double*)h->part.p, db_fast_consts(h));
     HIPCHK(h, hipGetLastError());
+    // (for the stationary gate's noise statistics the final kernel also derives the gate's compare constants: no
+    // k_prep_thresh_lazy launch in the calls that follow)
+    GateConsts gc{};
+    if (gate_consts && ub == 1 && grid.x == OP_ALIM_BLOCKS) {
+      if ((rc = ensure(h, h->T2, (size_t)g.FS * 8))) return rc;
+      if ((rc = ensure_zeroed(h, h->alim, 64, st))) return rc;
+      gc.T2 = (double*)h->T2.p; gc.alim_b = (unsigned*)h->alim.p + 2; gc.sum_abs_w = h->sum_abs_w;
+    }
     hipLaunchKernelGGL(k_colstats1_final, dim3((unsigned)((g.FS + 63) / 64), (unsigned)ub), dim3(64 * STAT_TG), 0, st,
                        (const double*)h->part.p, (const double*)h->P.p, g, nts, h->mag_scale, h->p.top_db,
-                       h->p.n_std_thresh, h->p.ddof, (double*)h->pmax.p, thresh_out);
+                       h->p.n_std_thresh, h->p.ddof, (double*)h->pmax.p, thresh_out, gc);
     HIPCHK(h, hipGetLastError());
+    if (gc.T2 != nullptr) h->t2_ready = true;
     return SG_OK;
   }
   int rc = stage_power(h, v, g, ub, st);
@@ -1638,7 +1649,7 @@ static int stage_prep_floor(sg_handle* h, const View& v, const Geom& g, int64_t 
   // k_prep_thresh for exactly the units whose floor can be live (the only rows anybody reads): no memset
   // launches on the critical path
   if ((rc = ensure_zeroed(h, h->umax, (size_t)ub * 4, st))) return rc;
-  if ((rc = ensure(h, h->need, (size_t)ub * 4))) return rc;
+  if ((rc = ensure_zeroed(h, h->need, (size_t)ub * 4, st))) return rc;
   if ((rc = ensure(h, h->T2, (size_t)g.FS * 8))) return rc;
   {
     ProfScope ps(h, SG_STAGE_PREP, st);
@@ -1897,7 +1908,14 @@ static int stage_onepass(sg_handle* h, const View& v, const View& vx, const Geom
   // prediction from the host-mapped stamp "a unit of launch <epoch> reported / had its flag set", read WITHOUT
   // synchronising (it may lag by the calls still queued): recent -> a priori.
   const unsigned live_stamp = h->err_host[1];
-  const bool lazy = h->floor_test == 2 || (h->floor_test == 0 && !(live_stamp != 0u && h->epoch - live_stamp <= 16u));
+  // the flags the tiles raise are tagged with this launch's epoch (30 bits; 0 = untagged): nothing to clear per call
+  const unsigned need_tag = h->epoch & 0x3fffffffu;
+  if (need_tag == 0u) {   // once per 2^30 launches: leftovers of the previous era could alias
+    if (h->need.p) HIPCHK(h, hipMemsetAsync(h->need.p, 0, h->need.bytes, st));
+    if (h->alim.p) HIPCHK(h, hipMemsetAsync((char*)h->alim.p + 4, 0, 4, st));
+  }
+  const bool lazy = need_tag != 0u &&
+                    (h->floor_test == 2 || (h->floor_test == 0 && !(live_stamp != 0u && h->epoch - live_stamp <= 16u)));
   ThreshConsts tc{};
   ++(lazy ? h->n_floor_lazy : h->n_floor_apriori);
   if (!lazy) {
@@ -1905,15 +1923,19 @@ static int stage_onepass(sg_handle* h, const View& v, const View& vx, const Geom
   } else {
     const int wpr = (g.F + 63) / 64;
     if ((rc = ensure(h, h->bits, (size_t)ub * g.T * wpr * 8))) return rc;
-    if ((rc = ensure(h, h->need, (size_t)ub * 4))) return rc;
+    if ((rc = ensure_zeroed(h, h->need, (size_t)ub * 4, st))) return rc;
     if ((rc = ensure(h, h->T2, (size_t)g.FS * 8))) return rc;
-    if ((rc = ensure(h, h->alim, 64))) return rc;
-    ProfScope ps(h, SG_STAGE_PREP, st);
-    hipLaunchKernelGGL(k_prep_thresh_lazy, dim3(1), dim3(256), 0, st, (const double*)h->thresh.p, g.F, h->mag_scale,
-                       h->sum_abs_w, h->p.top_db, ub, (double*)h->T2.p, (int*)h->need.p, (unsigned*)h->alim.p,
-                       (unsigned*)h->xticket.p + 8);
-    HIPCHK(h, hipGetLastError());
-    tc = ThreshConsts{(const double*)h->T2.p, (const double*)h->thresh.p, (const double*)h->pmax.p, (const int*)h->need.p};
+    if ((rc = ensure_zeroed(h, h->alim, 64, st))) return rc;
+    if (!h->t2_ready) {
+      // the threshold did not come from sg_noise_stats (whose last kernel derives T2 / alim itself): one small launch
+      ProfScope ps(h, SG_STAGE_PREP, st);
+      hipLaunchKernelGGL(k_prep_thresh_lazy, dim3(1), dim3(256), 0, st, (const double*)h->thresh.p, g.F, h->mag_scale,
+                         h->sum_abs_w, h->p.top_db, (double*)h->T2.p, (unsigned*)h->alim.p);
+      HIPCHK(h, hipGetLastError());
+      h->t2_ready = true;
+    }
+    tc = ThreshConsts{(const double*)h->T2.p, (const double*)h->thresh.p, (const double*)h->pmax.p, (const int*)h->need.p,
+                      need_tag};
   }
   fast::OnePassArgs P;
   P.x_exact = vx.x; P.stride_exact = vx.stride; P.dtype_exact = vx.dtype;
@@ -2447,7 +2469,8 @@ extern "C" int sg_noise_stats(sg_handle* h, const void* noise_dev, int dtype, in
   v.N = n; v.lo = 0; v.hi = n; v.cs = 0; v.pad = 0; v.Lp = n; v.n_chunks = 1; v.unit0 = 0;
   Geom g = make_geom(h, n);
   if ((rc = ensure_ws(h, g, 1))) return rc;
-  if ((rc = stage_stats(h, v, g, 1, (double*)h->thresh.p, st))) return rc;
+  h->t2_ready = false;
+  if ((rc = stage_stats(h, v, g, 1, (double*)h->thresh.p, st, /*gate_consts=*/h->fast_ok))) return rc;
   h->has_thresh = true;
   return SG_OK;
 }
@@ -2465,6 +2488,7 @@ extern "C" int sg_get_noise_threshold(sg_handle* h, double* thresh_host, int32_t
 extern "C" int sg_set_noise_threshold(sg_handle* h, const double* thresh_host, int32_t n_bins, void* stream) {
   if (!h) return SG_E_INVALID;
   if (!thresh_host || n_bins != h->F) FAIL(h, SG_E_INVALID, "sg_set_noise_threshold: n_bins must be %d", h->F);
+  h->t2_ready = false;
   HIPCHK(h, hipMemcpyAsync(h->thresh.p, thresh_host, (size_t)h->F * sizeof(double), hipMemcpyHostToDevice,
                            (hipStream_t)stream));
   HIPCHK(h, hipStreamSynchronize((hipStream_t)stream));
@@ -2484,6 +2508,7 @@ extern "C" int sg_get_noise_threshold_dev(sg_handle* h, double* thresh_dev, int3
 extern "C" int sg_set_noise_threshold_dev(sg_handle* h, const double* thresh_dev, int32_t n_bins, void* stream) {
   if (!h) return SG_E_INVALID;
   if (!thresh_dev || n_bins != h->F) FAIL(h, SG_E_INVALID, "sg_set_noise_threshold_dev: n_bins must be %d", h->F);
+  h->t2_ready = false;
   HIPCHK(h, hipMemcpyAsync(h->thresh.p, thresh_dev, (size_t)h->F * sizeof(double), hipMemcpyDeviceToDevice,
                            (hipStream_t)stream));
   h->has_thresh = true;

@@ -25,7 +25,20 @@ struct ThreshConsts {
   const double* pmax;      // [units][FS] per-(unit, band) max raw power, 0 where not computed
   const int* need_floor;   // [units] 1: this unit's -top_db floor may be live -> pmax is valid;
                            //         2: the unit holds a non-finite sample -> no cell of it passes (T2_NEVER)
+  // need_tag != 0 (one-pass gate, in-kernel floor test): the words are TAGGED, (tag << 2) | flags, raised with atomicMax
+  // by the gate's tiles (2 beats 1) -- a word with another tag is a leftover of an earlier call and reads as 0, so
+  // nobody has to clear the array between calls
+  unsigned need_tag = 0;
 };
+// The one-pass gate's floor test reads its bound on max|x| as OP_ALIM_BLOCKS bit patterns (one per 64-band block of the
+// noise statistics' final kernel, which derives them without a cross-block reduction) and takes their minimum:
+// alim[2 .. 2 + OP_ALIM_BLOCKS); alim[1] is the tag of the last call in which a unit reported.
+constexpr int OP_ALIM_BLOCKS = 9;
+__device__ __forceinline__ int need_of(const ThreshConsts& tc, int64_t u) {
+  const unsigned w = (unsigned)tc.need_floor[u];
+  if (tc.need_tag == 0u) return (int)w;
+  return (w >> 2) == tc.need_tag ? (int)(w & 3u) : 0;
+}
 
 // Compare constant meaning "no cell passes".  A band with a NaN threshold (NaN in the noise clip: stationary.py:75-81
 // give mean(NaN) = NaN, and `dB > NaN` is False) and every band of a unit with a non-finite sample (np.max over a

@@ -129,12 +129,10 @@ __global__ void k_prep_thresh(const double* __restrict__ thresh, int F, double m
 // max|x|,
 //   20 log10(max|x| sum|w| mag_scale + eps) + 1e-6 - top_db > min_f thresh[f]   <=>   max|x| > a_lim,
 // published as the bit pattern of a float a little BELOW a_lim (non-negative floats order like their bit patterns; a
-// test that fires too often only costs time: a flagged unit takes the exact floor path).  need_floor[], the "some unit
-// reported" word and the second launch's work counter are cleared: the gate's tiles OR their verdicts into the flags.
+// test that fires too often only costs time: a flagged unit takes the exact floor path).  Only needed when the threshold
+// did not come from sg_noise_stats, whose last kernel (k_colstats1, Colstats1Fin) derives the same constants itself.
 __global__ void k_prep_thresh_lazy(const double* __restrict__ thresh, int F, double mag_scale, double sum_abs_w,
-                                   double top_db, int64_t n_units, double* __restrict__ T2,
-                                   int* __restrict__ need_floor, unsigned* __restrict__ alim_bits,
-                                   unsigned* __restrict__ ticket2) {
+                                   double top_db, double* __restrict__ T2, unsigned* __restrict__ alim_bits) {
   const double eps = 2.220446049250313e-16;
   __shared__ double s_min[256];
   double mn = 1e300;
@@ -153,7 +151,6 @@ __global__ void k_prep_thresh_lazy(const double* __restrict__ thresh, int F, dou
     }
     T2[f] = t2;
   }
-  for (int64_t u = threadIdx.x; u < n_units; u += blockDim.x) need_floor[u] = 0;
   s_min[threadIdx.x] = mn;
   __syncthreads();
   for (int o = blockDim.x / 2; o > 0; o >>= 1) {
@@ -171,9 +168,7 @@ __global__ void k_prep_thresh_lazy(const double* __restrict__ thresh, int F, dou
       const float lf = __double2float_rd(lim * (1.0 - 1e-6));
       bits = __float_as_uint(lf);              // +Inf (limit beyond float): only non-finite samples report
     }
-    alim_bits[0] = bits;
-    alim_bits[1] = 0u;     // "some unit reported"
-    *ticket2 = 0u;         // work counter of the gate's second launch (it only counts when a unit reported)
+    for (int b = 0; b < OP_ALIM_BLOCKS; ++b) alim_bits[2 + b] = bits;   // (the gate takes the minimum of the block bounds)
   }
 }
 
@@ -198,7 +193,7 @@ __global__ __launch_bounds__(WAVES * NT) void k_stft_bits(View view, Geom g, con
   const int wave = threadIdx.x / NT;
   cx<double>* buf = bufs + wave * lpn<double>(N);
   const int64_t u = blockIdx.y;
-  const int need = tc.need_floor[u];
+  const int need = need_of(tc, u);
   const bool floor_live = need == 1;
   if (MODE == 0 && !floor_live) return;  // whole block: uniform
   for (int i = threadIdx.x; i < N; i += WAVES * NT) tw[i] = tw_g[i];

@@ -493,11 +493,20 @@ __global__ __launch_bounds__(64 * STAT_TG) void k_colstats1(const double* __rest
 
 // one workgroup = 64 bands of one unit; the STAT_TG thread groups split the slices
 constexpr int STAT1_MAXS = 16;  // slices per thread group (nts <= STAT_TG * STAT1_MAXS)
+// gc (variant S noise statistics, unit 0 only): the stationary gate's compare constants ride along instead of taking
+// a launch of their own (k_prep_thresh_lazy, fused.hpp: same arithmetic) -- T2[f] per band, and per BAND BLOCK the floor
+// test's bound on max|x| from that block's minimum threshold: alim_b[block].  The gate takes the minimum of the blocks'
+// bounds itself (the bound is monotone in the threshold), so no block waits for another here.
+struct GateConsts {
+  double* T2;           // [F] or nullptr
+  unsigned* alim_b;     // [band blocks] bit patterns of the bounds
+  double sum_abs_w;
+};
 __global__ __launch_bounds__(64 * STAT_TG) void k_colstats1_final(const double* __restrict__ part,
                                                                   const double* __restrict__ P, Geom g, int nts,
                                                                   double mag_scale, double top_db, double n_std,
                                                                   int ddof, double* __restrict__ pmax,
-                                                                  double* __restrict__ thresh) {
+                                                                  double* __restrict__ thresh, GateConsts gc) {
   __shared__ double r[3][STAT_TG][64];
   __shared__ int r_exact[STAT_TG][64];
   const int l = threadIdx.x & 63, tg = threadIdx.x >> 6;
@@ -569,6 +578,7 @@ __global__ __launch_bounds__(64 * STAT_TG) void k_colstats1_final(const double* 
   r[1][tg][l] = s1; r[2][tg][l] = s2; r_exact[tg][l] = exact ? 1 : 0;
   __syncthreads();
   if (tg != 0) return;
+  double thr_out = (double)NAN;
   s1 = 0.0; s2 = 0.0; exact = false;
 #pragma unroll
   for (int k = 0; k < STAT_TG; ++k) {  // fixed order: deterministic
@@ -580,7 +590,8 @@ __global__ __launch_bounds__(64 * STAT_TG) void k_colstats1_final(const double* 
     pmax[i] = mx;
     double var = (s2 - s1 * s1 / Tn) / (Tn - (double)ddof);
     if (var < 0.0) var = 0.0;
-    thresh[i] = (pivot + s1 / Tn) + sqrt(var) * n_std;
+    thr_out = (pivot + s1 / Tn) + sqrt(var) * n_std;
+    thresh[i] = thr_out;
   } else if (f < g.FS) {
     pmax[i] = 0.0;
   }
@@ -605,8 +616,35 @@ __global__ __launch_bounds__(64 * STAT_TG) void k_colstats1_final(const double* 
     if (l == src) {
       double var = (a2 - a1 * a1 / Tn) / (Tn - (double)ddof);
       if (var < 0.0) var = 0.0;
-      thresh[i] = (mb + a1 / Tn) + sqrt(var) * n_std;
+      thr_out = (mb + a1 / Tn) + sqrt(var) * n_std;
+      thresh[i] = thr_out;
     }
+  }
+  if (gc.T2 == nullptr || u != 0) return;
+  // ---- the gate's compare constants for these 64 bands (wave 0 holds their thresholds) ----
+  const double eps = 2.220446049250313e-16;
+  double mn = 1e300;
+  if (live) {
+    const double zero_db = 20.0 * log10(eps);
+    double t2;
+    if (thr_out != thr_out) {
+      t2 = 1e300;   // T2_NEVER (fastpath.hpp): NaN threshold, no cell of the band passes
+    } else if (zero_db > thr_out) {
+      t2 = -1.0;    // a zero cell already passes: every cell does
+    } else {
+      const double tm = (exp10(thr_out / 20.0) - eps) / mag_scale;
+      t2 = tm > 0.0 ? tm * tm : 0.0;
+    }
+    gc.T2[f] = t2;
+    mn = fmin(mn, thr_out);
+  }
+  for (int off = 32; off > 0; off >>= 1) mn = fmin(mn, __shfl_xor(mn, off));
+  if (l == 0) {
+    // need  <=>  20 log10(max|x| sum|w| mag_scale + eps) + 1e-6 - top_db > min thresh   <=>   max|x| > lim
+    const double lim = (exp10((mn + top_db - 1e-6) / 20.0) - eps) / (gc.sum_abs_w * mag_scale);
+    unsigned bits = 0u;                        // lim <= 0 or NaN: every tile reports (the floor path is exact for every unit)
+    if (lim > 0.0) bits = __float_as_uint(__double2float_rd(lim * (1.0 - 1e-6)));   // +Inf: only non-finite samples report
+    gc.alim_b[blockIdx.x] = bits;
   }
 }
 

@@ -72,8 +72,9 @@ struct OnePassArgs {
   // In-kernel floor test (see "floor test" in the kernel): alim = bit pattern of the largest max|x| for which no band's
   // -top_db floor can be live (k_prep_thresh_lazy), null when the flags in tc.need_floor were computed up front
   // (k_unit_absmax + k_prep_thresh).  redo = 1: the second launch of such a call -- only the units whose test fired run.
-  // alim[1]: "some unit reported" (cleared by k_prep_thresh_lazy): the second launch returns at once -- before tables and
-  // ticket -- when it is 0 (2064 workgroups that only took their ticket and left cost 83 us: tools/ubench/ticket_atomic.hip)
+  // alim[1]: tc.need_tag of the last call in which some unit reported: the second launch returns at once -- before tables
+  // and ticket -- when it is another call's (2064 workgroups that only took their ticket and left cost 83 us:
+  // tools/ubench/ticket_atomic.hip)
   unsigned* alim;
   int redo;
   int scan_q;                 // in-kernel floor test: samples of the unit window's unstaged part that each tile scans
@@ -162,7 +163,7 @@ __global__ __launch_bounds__(WAVES * 64, 3) void k_gate_onepass(OnePassArgs P) {
   unsigned* t_slot_ = nullptr;   // known once the ticket is
 #endif
 
-  if (P.redo && P.alim[1] == 0u) return;   // second launch of a call none of whose units reported (the common case)
+  if (P.redo && P.alim[1] != P.tc.need_tag) return;   // second launch of a call none of whose units reported (the common case)
   double t2pre[3];   // compare constants of entries tid, tid + 256 and 512 (they do not depend on the ticket)
   unsigned alim_v = 0u;
   {
@@ -178,7 +179,7 @@ __global__ __launch_bounds__(WAVES * 64, 3) void k_gate_onepass(OnePassArgs P) {
     if (P.alim != nullptr && !P.redo) {
       // the floor test's compare constant: a VECTOR load behind the table loads (as a scalar load the compiler places it
       // at its use, after the span has landed: one more exposed round trip per tile, 5 us of the kernel)
-      int z = 0;
+      int z = 2 + min(lane & 15, OP_ALIM_BLOCKS - 1);   // one bound per band block of the noise statistics: minimum below
       asm volatile("" : "+v"(z));
       alim_v = P.alim[z];
     }
@@ -216,8 +217,10 @@ __global__ __launch_bounds__(WAVES * 64, 3) void k_gate_onepass(OnePassArgs P) {
   // Floor flags of the unit.  lazy (P.alim set): the first launch assumes "not live" and runs the floor test on the
   // samples it stages (below); the second launch (P.redo) serves exactly the units whose test fired.
   const bool lazy = P.alim != nullptr;
-  const int need = (lazy && !P.redo) ? 0 : P.tc.need_floor[u];
-  if (P.redo && need == 0) return;   // whole workgroup (the ticket is taken: the counter stays in step with the grid)
+  const int need = (lazy && !P.redo) ? 0 : need_of(P.tc, u);
+  if (P.redo && need == 0) return;   // whole workgroup
+  // (first launch: the second launch's work counter -- it only counts when a unit reported -- starts from zero)
+  if (lazy && !P.redo && ticket == 0u && tid == 0) P.ticket[8] = 0u;
   const bool floor_live = need == 1;
 
   // compare constants (x4: the split works on 2X), permuted like the lanes' entries -- see k_decide_fast
@@ -334,14 +337,15 @@ __global__ __launch_bounds__(WAVES * 64, 3) void k_gate_onepass(OnePassArgs P) {
         for (int64_t i = sc_c0 + tid; i < sc_c1; i += WAVES * 64)
           mi = max(mi, ab((float)view_sample(A.view, row, chunk, i < sc_lenA ? sc_lo + i : sc_last + (i - sc_lenA))));
       }
+      for (int off = 1; off < 16; off <<= 1) alim_v = min(alim_v, (unsigned)__shfl_xor((int)alim_v, off));
       const bool hit = mi >= alim_v;
       if (__any(hit)) {   // wave-uniform, rare
         const bool nonfinite = __any(mi >= 0x7f800000u);
         double* pm = const_cast<double*>(P.tc.pmax) + u * G.FS;
         for (int f = lane; f < G.FS; f += 64) pm[f] = 0.0;
         if (lane == 0) {
-          atomicOr(const_cast<int*>(P.tc.need_floor) + u, nonfinite ? 2 : 1);
-          P.alim[1] = 1u;
+          atomicMax(reinterpret_cast<unsigned*>(const_cast<int*>(P.tc.need_floor)) + u, (P.tc.need_tag << 2) | (nonfinite ? 2u : 1u));
+          P.alim[1] = P.tc.need_tag;
           P.err[1] = P.epoch;   // host-mapped: "a unit of launch `epoch` reported" (the host picks the a-priori test next time)
         }
       }
