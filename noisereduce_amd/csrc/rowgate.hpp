@@ -99,7 +99,7 @@ struct RowGateArgs {
 
 __host__ __device__ constexpr size_t rowgate_lds_bytes() {
   return (size_t)FN * 8 + (size_t)RG_REGION + 1024 * 4 + (size_t)RG_ROWS_MAX * RG_WP * 8 +
-         2 * T2_FLOATS * 4 + 2 * 64 * 4 + 64 * 8 + 520 + 520 * 2 + 64;
+         2 * T2_FLOATS * 4 + 2 * 64 * 4 + 64 * 8 + 520 + 520 * 2 + 64 + 144;
 }
 
 // exact float64 |X[f]|^2 (UNSCALED transform, like k_power_fast64's) of frame t of a row: the whole wave cooperates
@@ -143,6 +143,7 @@ __global__ __launch_bounds__(RG_WAVES * 64, 1) void k_row_gate(RowGateArgs A) {
   unsigned char* s_flag = reinterpret_cast<unsigned char*>(s_ex + 64);                   // [520] band is ambiguous
   unsigned short* s_list = reinterpret_cast<unsigned short*>(s_flag + 520);              // [520] compacted
   unsigned* s_misc = reinterpret_cast<unsigned*>(s_list + 520);                          // [0] list length  [1] row has a sample
+  cf* s_tw1024 = reinterpret_cast<cf*>(s_misc + 16);                                     // [17] w_1024^0..16 (the split's twiddles)
   const Geom& G = A.g;
   const int tid = threadIdx.x;
   const int lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);   // (uniform: an SGPR)
@@ -158,28 +159,64 @@ __global__ __launch_bounds__(RG_WAVES * 64, 1) void k_row_gate(RowGateArgs A) {
   // frame of this lane group in quad q: wave w transforms frames 4 (w + 8 q) .. + 3
   auto frame_of = [&](int q) { return 4 * (wave + RG_WAVES * q) + g; };
 
-  // the row's samples -> LDS, zero outside the row
-  auto stage_span = [&]() -> bool {
-    const float* sp = (const float*)A.view.x + row * A.view.stride;
-    const bool vec_ok = A.view.dtype == 0 && (reinterpret_cast<uintptr_t>(sp) & 15) == 0 && A.view.lo <= 0 &&
-                        A.view.hi >= A.view.Lp;
+  // the row's samples -> LDS, zero outside the row.  float32 rows: every 16-byte load of the thread is issued before the
+  // first LDS store (span_issue / span_commit; a rolled load-store loop is serialised by the compiler: s_waitcnt vmcnt(0)
+  // per iteration, four to five dependent round trips with nothing else on the CU to hide them), indices clamped into
+  // the row, the zero padding and the row's ragged end patched at the store.
+  constexpr int SPAN_K = (((RG_FRAMES - 1) * 256 + 1024) / 4 + RG_THREADS - 1) / RG_THREADS;
+  const float* sp_row = (const float*)A.view.x + row * A.view.stride;
+  const bool span_vec = A.view.dtype == 0 && (reinterpret_cast<uintptr_t>(sp_row) & 15) == 0 && A.view.lo <= 0 &&
+                        A.view.hi >= A.view.Lp && A.view.Lp >= 8;
+  auto span_issue = [&](float4 (&q)[SPAN_K]) __attribute__((always_inline)) {
+    if (!span_vec) {
+#pragma unroll
+      for (int k = 0; k < SPAN_K; ++k) q[k] = make_float4(0.f, 0.f, 0.f, 0.f);
+      return;
+    }
+    const int64_t last4 = (A.view.Lp & ~(int64_t)3) - 4;
+#pragma unroll
+    for (int k = 0; k < SPAN_K; ++k) {
+      const int64_t s = (int64_t)4 * (tid + k * RG_THREADS) - G.padL;      // multiple of 4 (padL = 512)
+      q[k] = *reinterpret_cast<const float4*>(sp_row + min(max(s, (int64_t)0), last4));
+    }
+  };
+  auto span_commit = [&](float4 (&q)[SPAN_K]) __attribute__((always_inline)) -> bool {
     bool any = false;
-    for (int i4 = tid; i4 < span / 4; i4 += RG_THREADS) {
-      const int e = 4 * i4;
-      const int64_t s = (int64_t)e - G.padL;      // multiple of 4 (padL = 512)
-      float4 q;
-      if (vec_ok && s >= 0 && s + 4 <= A.view.Lp) {
-        q = *reinterpret_cast<const float4*>(sp + s);
-      } else {
-        q.x = (float)view_sample(A.view, row, 0, s);
-        q.y = (float)view_sample(A.view, row, 0, s + 1);
-        q.z = (float)view_sample(A.view, row, 0, s + 2);
-        q.w = (float)view_sample(A.view, row, 0, s + 3);
+    if (span_vec) {
+#pragma unroll
+      for (int k = 0; k < SPAN_K; ++k) {
+        const int i4 = tid + k * RG_THREADS;
+        if (i4 < span / 4) {
+          const int e = 4 * i4;
+          const int64_t s = (int64_t)e - G.padL;
+          float4 v4 = q[k];
+          if (!(s >= 0 && s + 4 <= A.view.Lp)) {   // zero padding before / behind the row, or the row's ragged last samples
+            auto at = [&](int64_t sj) -> float { return (sj >= 0 && sj < A.view.Lp) ? sp_row[sj] : 0.f; };
+            v4 = make_float4(at(s), at(s + 1), at(s + 2), at(s + 3));
+          }
+          any = any || v4.x != 0.f || v4.y != 0.f || v4.z != 0.f || v4.w != 0.f;
+          *reinterpret_cast<float4*>(&xs[(e >> 8) * XP + (e & 255)]) = v4;
+        }
       }
-      any = any || q.x != 0.f || q.y != 0.f || q.z != 0.f || q.w != 0.f;
-      *reinterpret_cast<float4*>(&xs[(e >> 8) * XP + (e & 255)]) = q;
+    } else {
+      for (int i4 = tid; i4 < span / 4; i4 += RG_THREADS) {
+        const int e = 4 * i4;
+        const int64_t s = (int64_t)e - G.padL;
+        float4 v4;
+        v4.x = (float)view_sample(A.view, row, 0, s);
+        v4.y = (float)view_sample(A.view, row, 0, s + 1);
+        v4.z = (float)view_sample(A.view, row, 0, s + 2);
+        v4.w = (float)view_sample(A.view, row, 0, s + 3);
+        any = any || v4.x != 0.f || v4.y != 0.f || v4.z != 0.f || v4.w != 0.f;
+        *reinterpret_cast<float4*>(&xs[(e >> 8) * XP + (e & 255)]) = v4;
+      }
     }
     return any;     // this thread staged a non-zero sample (NaN counts as one)
+  };
+  auto stage_span = [&]() __attribute__((always_inline)) -> bool {
+    float4 q[SPAN_K];
+    span_issue(q);
+    return span_commit(q);
   };
   // gather (window x frame t) -> forward transform -> split in place: v[e] = 2 X[bin_of_entry(c, e)]; lane 0 keeps its two
   // unpaired registers raw: v[0] = Zc[0] (bins 0 / 512), v[31] = Zc[256] (bin 256).  Returns 2 (2 delta_t)^2.
@@ -213,11 +250,11 @@ __global__ __launch_bounds__(RG_WAVES * 64, 1) void k_row_gate(RowGateArgs A) {
     nrm2 += __shfl_xor(nrm2, 4);
     nrm2 += __shfl_xor(nrm2, 8);
     fft512_fwd_half(v, fb, tw512 + zo, c);
-    wlo = A.tw1024[c];
+    wlo = s_tw1024[c];
     asm volatile("" : "+v"(wlo.x), "+v"(wlo.y));
     whi = wlo;
     {
-      const cf w16 = A.tw1024[16];
+      const cf w16 = s_tw1024[16];
       if (l0) whi = {-w16.y, w16.x};  // i * w_1024^16
     }
     rg_lane0_to_entries(v, l0);
@@ -240,15 +277,28 @@ __global__ __launch_bounds__(RG_WAVES * 64, 1) void k_row_gate(RowGateArgs A) {
   };
 
   // ---- tables, zero-filled bit rows, the row's samples ------------------------------------------------------------------
-  for (int i = tid; i < FN; i += RG_THREADS) tw512[i] = A.tw512[(i >> 4) * (i & 15)];
-  if (tid < 256) reinterpret_cast<float4*>(swin)[tid] = reinterpret_cast<const float4*>(A.win)[tid];
-  for (int i = tid; i < (T + 2 * nt) * RG_WP; i += RG_THREADS) wb[i] = 0ull;
-  for (int i = tid; i < 520; i += RG_THREADS) s_flag[i] = 0;
+  // (all global loads of the prologue -- tables and span -- in flight before the first store)
+  static_assert(RG_THREADS >= FN && RG_THREADS >= 256, "one table load per thread");
+  bool any_sample;
+  {
+    const int it = min(tid, FN - 1);
+    const cf tw_v = A.tw512[(it >> 4) * (it & 15)];
+    const float4 w4 = reinterpret_cast<const float4*>(A.win)[min(tid, 255)];
+    const cf t10 = A.tw1024[min(tid, 16)];
+    float4 q[SPAN_K];
+    span_issue(q);
+    for (int i = tid; i < (T + 2 * nt) * RG_WP; i += RG_THREADS) wb[i] = 0ull;
+    for (int i = tid; i < 520; i += RG_THREADS) s_flag[i] = 0;
+    unsigned* s_maxu0 = reinterpret_cast<unsigned*>(s_cb);
+    for (int i = tid; i < 513; i += RG_THREADS) s_maxu0[i] = 0u;
+    if (tid == 0) { s_misc[0] = 0u; s_misc[1] = 0u; s_misc[2] = 0u; }
+    if (tid < FN) tw512[tid] = tw_v;
+    if (tid < 256) reinterpret_cast<float4*>(swin)[tid] = w4;
+    if (tid < 17) s_tw1024[tid] = t10;
+    RG_STAMP(0);
+    any_sample = span_commit(q);
+  }
   unsigned* s_maxu = reinterpret_cast<unsigned*>(s_cb);   // band maxima (bit patterns) until the statistics replace them by cb
-  for (int i = tid; i < 513; i += RG_THREADS) s_maxu[i] = 0u;
-  if (tid == 0) { s_misc[0] = 0u; s_misc[1] = 0u; s_misc[2] = 0u; }
-  RG_STAMP(0);
-  const bool any_sample = stage_span();
   __syncthreads();
   if (any_sample) s_misc[1] = 1u;     // (every writer stores 1)  0: digital silence
   RG_STAMP(1);   // tables + span

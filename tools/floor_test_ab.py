@@ -56,7 +56,8 @@ def main():
             t, n = prof["k_gate_onepass (fft+decide+smooth+mask+ifft+ola)"]
             rows[mode]["gate_ms"].append(t / n)
     gate.set_option(_ffi.SG_OPT_FLOOR_TEST, 0)
-    same = all((torch.equal(outs[1], outs[m]) if torch.is_tensor(outs[1]) else np.array_equal(outs[1], outs[m])) for m in outs)
+    first = outs[MODES[0]]
+    same = all((torch.equal(first, outs[m]) if torch.is_tensor(first) else np.array_equal(first, outs[m])) for m in outs)
     print(json.dumps({"workload": "configs[1]: 28.8 M samples, chunk 600000, padding 30000, n_fft 1024",
                       "outputs_identical": bool(same),
                       "modes": {{1: "a_priori", 2: "in_kernel", 0: "predicted"}[m]:
