@@ -1964,7 +1964,6 @@ static int stage_onepass(sg_handle* h, const View& v, const View& vx, const Geom
   if ((rc = ensure_zeroed(h, h->xbits, (size_t)ub * ntt * fast::OP_TILE_WORDS * 8, st))) return rc;
   // granule buffers are zero when (re)allocated and the epoch only grows: a fresh granule never carries it
   P.alim = lazy ? (unsigned*)h->alim.p : nullptr;
-  P.redo = 0;
   {
     // the part of a unit's window outside its tiles' spans, dealt evenly to the unit's tiles (onepass.hpp "floor test")
     constexpr int64_t SPAN = (NF - 1) * 256 + 1024;
@@ -2048,11 +2047,16 @@ static int stage_onepass(sg_handle* h, const View& v, const View& vx, const Geom
     P.epoch = h->epoch;
     P.ticket = (unsigned*)h->xticket.p + 8;   // its own counter (zeroed by k_prep_thresh_lazy): it takes tickets only if a unit reported
     P.ticket_base = 0;
-    P.redo = 1;
     const size_t lds = (size_t)(fast::FN + WAVES * fast::WAVE_CX_H) * sizeof(fast::cf) + (1024 + T2_FLOATS) * sizeof(float) +
                        256 * 8 + 514 * 8 + 16 + (prop ? 528 : 0);
-    if (prop) hipLaunchKernelGGL((fast::k_gate_onepass<WAVES, true>), dim3((unsigned)(ub * ntt)), dim3(WAVES * 64), lds, st, P);
-    else hipLaunchKernelGGL((fast::k_gate_onepass<WAVES, false>), dim3((unsigned)(ub * ntt)), dim3(WAVES * 64), lds, st, P);
+    auto redo = [&](auto kern) -> hipError_t {
+      hipError_t e = set_lds(reinterpret_cast<const void*>(kern), lds);
+      if (e != hipSuccess) return e;
+      hipLaunchKernelGGL(kern, dim3((unsigned)(ub * ntt)), dim3(WAVES * 64), lds, st, P);
+      return hipGetLastError();
+    };
+    if (prop) HIPCHK(h, redo(fast::k_gate_onepass<WAVES, true, false, true>));
+    else HIPCHK(h, redo(fast::k_gate_onepass<WAVES, false, false, true>));
     HIPCHK(h, hipGetLastError());
   }
   h->dbg_xbits = true;

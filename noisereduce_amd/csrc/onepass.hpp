@@ -71,12 +71,12 @@ struct OnePassArgs {
   unsigned long long* part2;  // [units][n_tiles][3][256] trailing partial hops of every tile: granules {float, epoch}
   // In-kernel floor test (see "floor test" in the kernel): alim = bit pattern of the largest max|x| for which no band's
   // -top_db floor can be live (k_prep_thresh_lazy), null when the flags in tc.need_floor were computed up front
-  // (k_unit_absmax + k_prep_thresh).  redo = 1: the second launch of such a call -- only the units whose test fired run.
+  // (k_unit_absmax + k_prep_thresh).  The REDO instantiation is the second launch of such a call: only the units whose
+  // test fired run.
   // alim[1]: tc.need_tag of the last call in which some unit reported: the second launch returns at once -- before tables
   // and ticket -- when it is another call's (2064 workgroups that only took their ticket and left cost 83 us:
   // tools/ubench/ticket_atomic.hip)
   unsigned* alim;
-  int redo;
   int scan_q;                 // in-kernel floor test: samples of the unit window's unstaged part that each tile scans
 #if OP_TRACE
   unsigned* trace;                   // [workgroups][4 waves][16] shader cycles per phase (slot 15 = 1: tile completed): development builds
@@ -139,7 +139,10 @@ __device__ __forceinline__ double op_exact_power(const OnePassArgs& P, int64_t r
 // LOSE (tests only, SG_OPT_INJECT_HANDOFF_FAULT bits 3..4): an instantiation whose polls give up at once -- the timeout
 // branch of every hand-off (error word, NaN-poisoned hops) runs without a second of spinning and without a test
 // argument in the product kernel, whose register allocation sits at the 168-VGPR edge.
-template <int WAVES, bool PROP, bool LOSE = false>
+// REDO: the second launch of a call with the in-kernel floor test (its own instantiation: its launches are their own row in
+// a profile -- when no chunk reported they return at once, and would halve the gate's average duration -- and the first
+// launch carries no test for it).
+template <int WAVES, bool PROP, bool LOSE = false, bool REDO = false>
 __global__ __launch_bounds__(WAVES * 64, 3) void k_gate_onepass(OnePassArgs P) {
   static_assert(WAVES == 4, "tile = 16 frames");
   extern __shared__ __attribute__((aligned(16))) char smem[];
@@ -163,7 +166,7 @@ __global__ __launch_bounds__(WAVES * 64, 3) void k_gate_onepass(OnePassArgs P) {
   unsigned* t_slot_ = nullptr;   // known once the ticket is
 #endif
 
-  if (P.redo && P.alim[1] != P.tc.need_tag) return;   // second launch of a call none of whose units reported (the common case)
+  if (REDO && P.alim[1] != P.tc.need_tag) return;   // second launch of a call none of whose units reported (the common case)
   double t2pre[3];   // compare constants of entries tid, tid + 256 and 512 (they do not depend on the ticket)
   unsigned alim_v = 0u;
   {
@@ -176,7 +179,7 @@ __global__ __launch_bounds__(WAVES * 64, 3) void k_gate_onepass(OnePassArgs P) {
     t2pre[0] = P.tc.T2[perm_inv(tid)];
     t2pre[1] = P.tc.T2[perm_inv(tid + 256)];
     t2pre[2] = P.tc.T2[perm_inv(512)];
-    if (P.alim != nullptr && !P.redo) {
+    if (!REDO && P.alim != nullptr) {
       // the floor test's compare constant: a VECTOR load behind the table loads (as a scalar load the compiler places it
       // at its use, after the span has landed: one more exposed round trip per tile, 5 us of the kernel)
       int z = 2 + min(lane & 15, OP_ALIM_BLOCKS - 1);   // one bound per band block of the noise statistics: minimum below
@@ -215,12 +218,12 @@ __global__ __launch_bounds__(WAVES * 64, 3) void k_gate_onepass(OnePassArgs P) {
   const int64_t row = gu / nch;
   const int64_t chunk = A.view.c0 + gu % nch;
   // Floor flags of the unit.  lazy (P.alim set): the first launch assumes "not live" and runs the floor test on the
-  // samples it stages (below); the second launch (P.redo) serves exactly the units whose test fired.
+  // samples it stages (below); the second launch (REDO) serves exactly the units whose test fired.
   const bool lazy = P.alim != nullptr;
-  const int need = (lazy && !P.redo) ? 0 : need_of(P.tc, u);
-  if (P.redo && need == 0) return;   // whole workgroup
+  const int need = (lazy && !REDO) ? 0 : need_of(P.tc, u);
+  if (REDO && need == 0) return;   // whole workgroup
   // (first launch: the second launch's work counter -- it only counts when a unit reported -- starts from zero)
-  if (lazy && !P.redo && ticket == 0u && tid == 0) P.ticket[8] = 0u;
+  if (!REDO && lazy && ticket == 0u && tid == 0) P.ticket[8] = 0u;
   const bool floor_live = need == 1;
 
   // compare constants (x4: the split works on 2X), permuted like the lanes' entries -- see k_decide_fast
@@ -268,8 +271,8 @@ __global__ __launch_bounds__(WAVES * 64, 3) void k_gate_onepass(OnePassArgs P) {
     // to the unit's tiles in slices of P.scan_q samples of A ++ B (~1200 at the default chunking: five loads per thread,
     // in flight with the span's).  A tile whose test fires reports its unit: need_floor[u] |= 1 (2: a non-finite
     // sample), the unit's band maxima cleared for the float64 pre-pass that follows.  This launch's result for a reported
-    // unit is overwritten by the second (P.redo).
-    const bool test = lazy && !P.redo;
+    // unit is overwritten by the second (REDO).
+    const bool test = !REDO && lazy;
     unsigned mi = 0u;   // max |x| seen by this thread, as a bit pattern (sign cleared: NaN / Inf order above every finite value)
     auto ab = [](float x) -> unsigned { return __float_as_uint(x) & 0x7fffffffu; };
     constexpr int SCAN_REG = 5;                     // slices up to 5 x 256 samples ride in registers
