@@ -76,6 +76,7 @@ struct sg_handle {
   // workspace
   DevBuf P, pmax, thr_rows, raw, M, seg, yn;
   DevBuf bits, K16, umax, need, T2;  // fused stationary path
+  DevBuf nss;                        // non-stationary gate: recurrence partials of k_mag_fast's 16-frame blocks
   DevBuf alim;                       // one-pass gate, in-kernel floor test: compare constant on max|x| (k_prep_thresh_lazy)
   bool t2_ready = false;             // T2 / alim hold the compare constants of the CURRENT threshold (any writer of thresh clears it)
   DevBuf logtab;                     // db_fast (kernels.hpp): {rd(1 / c_i), -log2 of it} for 128 mantissa centres
@@ -1090,7 +1091,7 @@ extern "C" int sg_destroy(sg_handle* h) {
                     &h->need, &h->T2, &h->part, &h->tw512, &h->invn, &h->seam, &h->ftab, &h->xbits, &h->xpart,
                     &h->xticket, &h->xtick2, &h->ftab3, &h->xexp, &h->optab, &h->nsp, &h->nsc, &h->xin, &h->czt_tw64, &h->czt_ch64,
                     &h->czt_bh64, &h->czt_tw32, &h->czt_ch32, &h->czt_bh32, &h->logtab, &h->big_twM, &h->big_tw2,
-                    &h->big_ch, &h->big_bh, &h->big_W, &h->big_W2, &h->xP, &h->xraw, &h->xM, &h->xtmp, &h->xseg, &h->invn5, &h->invn20, &h->rg_count, &h->alim})
+                    &h->big_ch, &h->big_bh, &h->big_W, &h->big_W2, &h->xP, &h->xraw, &h->xM, &h->xtmp, &h->xseg, &h->invn5, &h->invn20, &h->rg_count, &h->alim, &h->nss})
     free_buf(*b);
   delete h;
   return SG_OK;
@@ -1121,7 +1122,8 @@ static size_t unit_bytes(const sg_handle* h, const Geom& g, bool lean) {
   if (lean) return (size_t)g.T * ((g.F + 63) / 64) * 8 + cells * 2 + (size_t)g.FS * 16 + 64 +
            (size_t)(g.T / 16 + 2) * 6 * 256 * 4;
   return cells * (8 + 4 + 4 + 2) + (size_t)g.T * g.n * 4 + (size_t)g.FS * 16 +
-         (size_t)(g.T / NS_TT + 1) * 2 * g.FS * 8 * 2;   // + partials and carries of the two-pass non-stationary mask
+         (size_t)(g.T / NS_TT + 1) * 2 * g.FS * 8 * 2 +  // + partials and carries of the two-pass non-stationary mask
+         (size_t)(g.T / 16 + 1) * 2 * g.FS * 8;          // + k_mag_fast's per-block partials
 }
 
 static int64_t units_per_batch(const sg_handle* h, const Geom& g, int64_t total, bool lean = false) {
@@ -1399,7 +1401,8 @@ static int stage_apply2048(sg_handle* h, const View& v, const Geom& g, int64_t u
   return SG_OK;
 }
 
-static int stage_mag(sg_handle* h, const View& v, const Geom& g, int64_t ub, hipStream_t st) {
+static int stage_mag(sg_handle* h, const View& v, const Geom& g, int64_t ub, hipStream_t st, double iir_b = 0.0,
+                     double* sub = nullptr /* default geometry only: recurrence partials per 16-frame block (k_mag_fast) */) {
   float* mag = (float*)h->P.p;
   if (h->fast5_ok && !h->force_nofast) return stage_mag512(h, v, g, ub, mag, st);
   if (h->fast20_ok && !h->force_nofast) return stage_mag2048(h, v, g, ub, mag, st);
@@ -1412,6 +1415,7 @@ static int stage_mag(sg_handle* h, const View& v, const Geom& g, int64_t ub, hip
     M.tw512 = (const fast::cf*)h->tw512.p;
     M.tw1024 = (const fast::cf*)h->tw32.p;
     M.mag = mag;
+    M.iir_b = iir_b; M.sub = sub;
     size_t lds = (size_t)(fast::FN + WAVES * fast::WAVE_CX_H) * sizeof(fast::cf) + 1024 * sizeof(float);
     auto kern = fast::k_mag_fast<WAVES>;
     HIPCHK(h, set_lds(reinterpret_cast<const void*>(kern), lds));
@@ -1445,7 +1449,12 @@ static bool nonstat2_ok(const sg_handle* h, const Geom& g) {
 // smooth: IIR + sigmoid + smoothing + prop_decrease -> M;  !smooth: the raw sigmoid field -> raw (smoothing follows),
 // or, without a smoothing filter, p * sigmoid + (1 - p) -> M
 static int stage_nonstat_mask2(sg_handle* h, const View& v, const Geom& g, int64_t ub, bool smooth, hipStream_t st) {
-  int rc = stage_mag(h, v, g, ub, st);
+  // default geometry: k_mag_fast also leaves the recurrence partials of its 16-frame blocks (no second pass over |X|)
+  const bool sub_ok = h->fast_ok && !h->force_nofast && !(h->fast5_ok || h->fast20_ok);
+  const int64_t nsub = (g.T + 15) / 16;
+  int rc;
+  if (sub_ok && (rc = ensure(h, h->nss, (size_t)ub * nsub * 2 * g.FS * sizeof(double)))) return rc;
+  rc = stage_mag(h, v, g, ub, st, h->p.iir_b, sub_ok ? (double*)h->nss.p : nullptr);
   if (rc) return rc;
   const float* mag = (const float*)h->P.p;
   const int nf = smooth ? h->p.n_grad_freq : 0, nt = smooth ? h->p.n_grad_time : 0;
@@ -1456,8 +1465,12 @@ static int stage_nonstat_mask2(sg_handle* h, const View& v, const Geom& g, int64
   if ((rc = ensure(h, h->nsc, bytes))) return rc;
   {
     ProfScope ps(h, SG_STAGE_NONSTAT_MASK, st);
-    hipLaunchKernelGGL(k_iir_part, dim3((unsigned)((nk * (g.FS / 4) + 255) / 256), (unsigned)ub), dim3(256), 0,
-                       st, mag, g, tl, h->p.iir_b, (double*)h->nsp.p);
+    if (sub_ok)
+      hipLaunchKernelGGL(k_iir_comb, dim3((unsigned)((nk * g.FS + 255) / 256), (unsigned)ub), dim3(256), 0, st,
+                         (const double*)h->nss.p, g, tl, h->p.iir_b, (double*)h->nsp.p, (int)nsub);
+    else
+      hipLaunchKernelGGL(k_iir_part, dim3((unsigned)((nk * (g.FS / 4) + 255) / 256), (unsigned)ub), dim3(256), 0,
+                         st, mag, g, tl, h->p.iir_b, (double*)h->nsp.p);
     HIPCHK(h, hipGetLastError());
     hipLaunchKernelGGL(k_iir_chain, dim3((unsigned)((ub * g.FS + 63) / 64)), dim3(64), 0, st, mag,
                        (const double*)h->nsp.p, g, tl, h->p.iir_b, (double*)h->nsc.p, ub);

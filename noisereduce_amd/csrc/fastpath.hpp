@@ -1412,7 +1412,12 @@ struct MagArgs {
   const cf* tw512;
   const cf* tw1024;
   float* mag;  // [units][T][FS]
+  // non-stationary gate: the recurrence partials of nonstat.hpp for this block's 16 frames ride along (k_iir_part read the
+  // whole |X| field once more for them: 57 us and 287 MB of a 10-minute call).  sub == nullptr: magnitudes only.
+  double iir_b;
+  double* sub;  // [units][blocks][2][FS]: e = sum_t b c^(end-1-t) A[t],  E0 = sum_t b c^(t-start) s0[t]  (zero-state forward response s0)
 };
+constexpr int MAG_TILE_PITCH = 520;   // floats per frame row of the block's |X| tile in LDS (4 rows in each wave's exchange slice)
 
 template <int WAVES>
 __global__ __launch_bounds__(WAVES * 64, 3) void k_mag_fast(MagArgs A) {
@@ -1478,7 +1483,10 @@ __global__ __launch_bounds__(WAVES * 64, 3) void k_mag_fast(MagArgs A) {
     }
   }
   __syncthreads();  // the span may now be overwritten by the exchanges
-  if (tq >= G.T) return;
+  static_assert(4 * MAG_TILE_PITCH * sizeof(float) <= WAVE_CX_H * sizeof(cf), "four tile rows per exchange slice");
+  float* trow = reinterpret_cast<float*>(regions + wave * WAVE_CX_H) + g * MAG_TILE_PITCH;   // this frame's row of the |X| tile
+  const bool with_sub = A.sub != nullptr;
+  if (tq < G.T) {
   fft512_fwd_half(v, fb, tw512, c);
   const bool l0 = c == 0;
   const cf wlo = A.tw1024[c];
@@ -1490,7 +1498,9 @@ __global__ __launch_bounds__(WAVES * 64, 3) void k_mag_fast(MagArgs A) {
   auto sel = [&](cf a0, cf a1) -> cf { return {l0 ? a0.x : a1.x, l0 ? a0.y : a1.y}; };
   float* mrow = A.mag + (u * G.T + (fvalid ? t : 0)) * (int64_t)G.FS;
   auto put = [&](int e, float P4) {  // |X| = sqrt(P4) / 2 at the bin of entry e
-    if (fvalid) mrow[bin_of_entry(c, e)] = half_sqrt(P4);
+    const float m = half_sqrt(P4);
+    if (fvalid) mrow[bin_of_entry(c, e)] = m;
+    if (with_sub) trow[bin_of_entry(c, e)] = m;   // (the wave's own exchange slice: its transform is done)
   };
   auto pair_power = [&](cf a, cf b, cf w, float& Pk, float& Pn) {
     cf p, q;
@@ -1507,6 +1517,7 @@ __global__ __launch_bounds__(WAVES * 64, 3) void k_mag_fast(MagArgs A) {
     put(0, l0 ? x0 * x0 : Pk);
     put(31, l0 ? P256 : Pn);
     if (l0 && fvalid) mrow[512] = 0.5f * fabsf(xN);
+    if (l0 && with_sub) trow[512] = 0.5f * fabsf(xN);
   }
 #pragma unroll
   for (int sl = 1; sl < 16; ++sl) {
@@ -1517,6 +1528,41 @@ __global__ __launch_bounds__(WAVES * 64, 3) void k_mag_fast(MagArgs A) {
     pair_power(a, b, w, Pk, Pn);
     put(sl, Pk);
     put(31 - sl, Pn);
+  }
+  }   // tq < G.T
+  if (!with_sub) return;
+  // ---- the block's frames as one sub-tile of the time recurrence: float64 like k_iir_part ----
+  __syncthreads();
+  {
+    const int n = (int)min<int64_t>((int64_t)NFB, G.T - tqb);   // frames of this block inside the unit
+    const double b = A.iir_b, cc = 1.0 - b;
+    static_assert(WAVES * 64 == 256, "bins tid, tid + 256 and (thread 0) 512");
+    // three independent chains per thread, interleaved (the recurrence is serial in t, float64 fma latency ~8 cycles)
+    const bool third = tid == 0;
+    double e0 = 0.0, e1 = 0.0, e2 = 0.0, E00 = 0.0, E01 = 0.0, E02 = 0.0, pw = b;
+    auto step = [&](int r) {
+      const float* rowp = reinterpret_cast<const float*>(regions + (r >> 2) * WAVE_CX_H) + (r & 3) * MAG_TILE_PITCH;
+      const double a0 = (double)rowp[tid], a1 = (double)rowp[tid + 256], a2 = third ? (double)rowp[512] : 0.0;
+      e0 = b * a0 + cc * e0;
+      e1 = b * a1 + cc * e1;
+      e2 = b * a2 + cc * e2;
+      E00 += pw * e0;
+      E01 += pw * e1;
+      E02 += pw * e2;
+      pw *= cc;
+    };
+    if (n == NFB) {   // every block but a unit's last: straight-line (all 48 LDS reads up front)
+#pragma unroll
+      for (int r = 0; r < NFB; ++r) step(r);
+    } else {
+      for (int r = 0; r < n; ++r) step(r);
+    }
+    double* o = A.sub + ((u * gridDim.x + blockIdx.x) * 2) * (int64_t)G.FS;
+    o[tid] = e0;
+    o[tid + 256] = e1;
+    o[G.FS + tid] = E00;
+    o[G.FS + tid + 256] = E01;
+    if (third) { o[512] = e2; o[G.FS + 512] = E02; }
   }
 }
 

@@ -72,6 +72,53 @@ __global__ __launch_bounds__(256) void k_iir_part(const float* __restrict__ A, G
   }
 }
 
+// The same partials from k_mag_fast's 16-frame sub-tiles (fastpath.hpp: MagArgs::sub), four per time tile.  For
+// consecutive pieces A (entering state 0, length L_A) and B: the state entering B is e_A, so
+//   e_AB = e_B + c^L_B e_A,    E0_AB = E0_A + c^L_A (E0_B + e_A b c (1 - c^(2 L_B)) / (1 - c^2))
+// (the bracket is k_iir_chain's E_b with s_in = e_A).  One thread per (tile, bin); every sub-tile has 16 frames but the
+// unit's last.
+__global__ __launch_bounds__(256) void k_iir_comb(const double* __restrict__ sub, Geom g, NsTiling tl, double b,
+                                                  double* __restrict__ part, int nsub) {
+  constexpr int SUBS = NS_TT / 16;
+  const unsigned FSu = (unsigned)g.FS;
+  const unsigned idx = blockIdx.x * 256u + threadIdx.x;
+  const int64_t nk = tl.n_tiles();
+  if (idx >= (unsigned)nk * FSu) return;
+  const int64_t k = idx / FSu;
+  const int f = (int)(idx % FSu);
+  if (f >= g.F) return;
+  const int64_t u = blockIdx.y;
+  const double c = 1.0 - b, gq = b * c / (1.0 - c * c);
+  const double c16 = pow(c, 16.0), q16 = 1.0 - pow(c, 32.0);
+  const double* sp = sub + ((u * nsub + k * SUBS) * 2) * (int64_t)g.FS + f;
+  const int ns = (int)min<int64_t>(SUBS, nsub - k * SUBS);
+  double ev[SUBS], Ev[SUBS];
+#pragma unroll
+  for (int j = 0; j < SUBS; ++j) {
+    const int jj = j < ns ? j : ns - 1;
+    ev[j] = sp[jj * 2 * (int64_t)g.FS];
+    Ev[j] = sp[jj * 2 * (int64_t)g.FS + g.FS];
+  }
+  auto clen = [&](int j, double& cl, double& ql) {   // c^len and 1 - c^(2 len) of sub-tile j of this tile
+    const int64_t len = min<int64_t>(16, g.T - (k * SUBS + j) * 16);
+    if (len == 16) { cl = c16; ql = q16; } else { cl = pow(c, (double)len); ql = 1.0 - pow(c, 2.0 * (double)len); }
+  };
+  double e = ev[0], E0 = Ev[0], cL, q0;
+  clen(0, cL, q0);
+#pragma unroll
+  for (int j = 1; j < SUBS; ++j)
+    if (j < ns) {
+      double cl, ql;
+      clen(j, cl, ql);
+      E0 += cL * (Ev[j] + e * gq * ql);
+      e = ev[j] + cl * e;
+      cL *= cl;
+    }
+  double* o = part + ((u * nk + k) * 2) * (int64_t)g.FS + f;
+  o[0] = e;
+  o[g.FS] = E0;
+}
+
 // carries [unit][tile][2][FS]: [0] forward state before the tile's first frame (s_f[ts - 1]; s_f[-1] := A[0], the
 // lfilter_zi steady state), [1] backward state at its end (S[te]; S[T] := s_f[T - 1], the seed of the backward pass)
 __global__ __launch_bounds__(64) void k_iir_chain(const float* __restrict__ A, const double* __restrict__ part,
