@@ -728,7 +728,7 @@ def extras(device, wl, out, y2d, gate, O):
                                        prop_decrease=1.0, use_tqdm=False, n_jobs=1, device=device)
         oc["config3_nonstationary"]["roofline"] = _roofline_of(
             ns._gate, lambda: nr.reduce_noise(y=y, sr=SR, stationary=False), y.numel(), med,
-            ["k_mag_fast", "k_iir_part", "k_iir_chain", "k_iir_mask", "k_apply_fast<4, false, true"])
+            ["k_mag_fast", "k_iir_comb", "k_iir_chain", "k_iir_mask", "k_apply_fast<4, false, true"])
     except Exception as e:
         oc["config3_nonstationary"]["roofline"] = {"error": repr(e)}
     torch.manual_seed(0)
