@@ -29,6 +29,20 @@ __device__ __forceinline__ float sigmoid_ratio_rcp(double av, double s, float nt
   return __builtin_amdgcn_rcpf(1.0f + __expf(-(ratio - nthresh) * slope));
 }
 
+// XCD-aware tile order (see k_iir_mask): a bijection of the grid's linear index, x fastest
+constexpr unsigned SG_XCDS = 8;
+__device__ __forceinline__ void xcd_remap(unsigned& bx, unsigned& by, unsigned& bz) {
+  const unsigned gx = gridDim.x, gy = gridDim.y;
+  const unsigned total = gx * gy * gridDim.z;
+  const unsigned L = bx + gx * (by + gy * bz);
+  const unsigned xcd = L % SG_XCDS, slot = L / SG_XCDS;
+  const unsigned q = total / SG_XCDS, r = total % SG_XCDS;
+  const unsigned P = xcd * q + (xcd < r ? xcd : r) + slot;   // XCD j owns q + (j < r) positions
+  bx = P % gx;
+  by = (P / gx) % gy;
+  bz = P / (gx * gy);
+}
+
 // lane l <- lane l -/+ 1 of the whole wavefront, 0 at the end (DPP wave_shr:1 / wave_shl:1, bound_ctrl): folded into the
 // consuming VALU instruction by the compiler (v_add_f32_dpp)
 __device__ __forceinline__ float lane_shr1(float v) {
@@ -49,14 +63,13 @@ __device__ __forceinline__ float lane_shl1(float v) {
 template <int NT, bool EDGE>
 __device__ __forceinline__ void ns_mask_tile(const float* __restrict__ A, const double* __restrict__ carry,
                                              const Geom& g, const NsTiling& tl, double b, double nthresh, double slope,
-                                             int nf, float p, float* __restrict__ M, int64_t k) {
+                                             int nf, float p, float* __restrict__ M, int64_t k, int bx, int64_t u) {
   constexpr int ROWS = NS_TT + 2 * NT;
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   const int BW = 64 - 2 * nf;
-  const int f = (blockIdx.x * 4 + wave) * BW - nf + lane;
+  const int f = (bx * 4 + wave) * BW - nf + lane;
   const int64_t nk = tl.n_tiles();
-  const int64_t u = blockIdx.z;
-  if ((blockIdx.x * 4 + wave) * BW >= g.F) return;   // wave-uniform
+  if ((bx * 4 + wave) * BW >= g.F) return;   // wave-uniform
   const int64_t ts = k * NS_TT, te = ts + NS_TT < g.T ? ts + NS_TT : g.T;
   const bool col_on = f >= 0 && f < g.F;
   const int fc = f < 0 ? 0 : (f >= g.F ? g.F - 1 : f);
@@ -179,10 +192,16 @@ template <int NT>
 __global__ __launch_bounds__(256, (NT <= 9 ? 3 : 2)) void k_iir_mask(const float* __restrict__ A, const double* __restrict__ carry,
                                                      Geom g, NsTiling tl, double b, double nthresh, double slope,
                                                      int nf, float p, float* __restrict__ M) {
-  const int64_t k = tl.k0 + blockIdx.y;
+  // Which tile: workgroups are dispatched round-robin over the 8 XCDs, each with its own L2, and neighbouring tiles
+  // share their halos (nt rows of the next time tile, nf columns of the next bin block: 40 % of what a tile loads).  Deal
+  // every XCD a CONTIGUOUS run of the launch's tiles (bin block fastest, then time, then unit) so that those re-reads hit
+  // its L2: dispatch index L -> XCD L % 8, its (L / 8)-th workgroup -> position off(L % 8) + L / 8.
+  unsigned bx = blockIdx.x, by = blockIdx.y, bz = blockIdx.z;
+  xcd_remap(bx, by, bz);
+  const int64_t k = tl.k0 + by;
   const bool edge = k * NS_TT - NT < 0 || (k + 1) * NS_TT + NT > g.T;
-  if (edge) ns_mask_tile<NT, true>(A, carry, g, tl, b, nthresh, slope, nf, p, M, k);
-  else ns_mask_tile<NT, false>(A, carry, g, tl, b, nthresh, slope, nf, p, M, k);
+  if (edge) ns_mask_tile<NT, true>(A, carry, g, tl, b, nthresh, slope, nf, p, M, k, (int)bx, (int64_t)bz);
+  else ns_mask_tile<NT, false>(A, carry, g, tl, b, nthresh, slope, nf, p, M, k, (int)bx, (int64_t)bz);
 }
 
 // ------------------------------------------------------------------------------------------------------------
