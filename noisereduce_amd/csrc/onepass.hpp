@@ -74,7 +74,7 @@ struct OnePassArgs {
   // (k_unit_absmax + k_prep_thresh).  The REDO instantiation is the second launch of such a call: only the units whose
   // test fired run.
   // alim[1]: tc.need_tag of the last call in which some unit reported: the second launch returns at once -- before tables
-  // and ticket -- when it is another call's (2064 workgroups that only took their ticket and left cost 83 us:
+  // and ticket -- when it is another call's (7152 workgroups that only took their ticket and left cost 83 us:
   // tools/ubench/ticket_atomic.hip)
   unsigned* alim;
   int scan_q;                 // in-kernel floor test: samples of the unit window's unstaged part that each tile scans

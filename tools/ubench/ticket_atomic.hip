@@ -1,6 +1,6 @@
 // Micro-benchmark: what does the work ticket of k_gate_onepass cost?  Every workgroup of that kernel takes its tile with one
-// returning atomicAdd on ONE device word (dispatch-order independence of the tile hand-offs).  A launch of 2064 workgroups
-// whose only work is that atomic took 83 us (round 4, the "second launch" of the in-kernel floor test) -- 40 ns per
+// returning atomicAdd on ONE device word (dispatch-order independence of the tile hand-offs).  A launch of 7152 workgroups (configs[1])
+// whose only work is that atomic took 83 us (round 4, the "second launch" of the in-kernel floor test) -- about 11 ns per
 // same-address atomic, serialised.  This program times a grid of G workgroups of 256 threads, 50 KB of dynamic LDS each
 // (three per CU, as the gate), that
 //   mode 0  exit at once
