@@ -220,6 +220,11 @@ SG_API int sg_debug_fetch(sg_handle* h, int32_t what, void* host, int64_t bytes,
                                    * 2 = by the gate kernel on the samples it stages -- free unless a chunk reports, which is then gated a
                                    * second time with its float64 band maxima; 0 (default) = predicted from what recent calls on the handle
                                    * found (no synchronisation).  Same result either way: exact band maxima decide */
+#define SG_OPT_TILE_ORDER 15      /* one-pass gate: 0 (default) = a workgroup takes its tile with an atomic ticket (a tile only ever waits for
+                                   * tiles of RUNNING workgroups, whatever order the hardware starts them in); 1 = tile = block index -- no
+                                   * atomic on every tile's critical path (gate kernel -4.4 %), at the price of assuming that the dispatcher
+                                   * starts workgroups in index order (it does on gfx950; HIP does not promise it).  Waits stay bounded and
+                                   * reported either way */
 #define SG_OPT_FORCE_NOFAST 2  /* value != 0: keep the bit-mask stages but use the general apply kernels */
 SG_API int sg_set_option(sg_handle* h, int32_t option, int64_t value);
 

@@ -102,6 +102,7 @@ struct sg_handle {
   bool force_split = false;          // SG_OPT_FORCE_SPLIT: decide / smooth / apply as three kernels
   int rowgate_mode = 0;              // SG_OPT_FORCE_NOROWGATE: 0 = by batch size, 1 = never, 2 = whenever the shape is eligible
   int64_t n_floor_lazy = 0, n_floor_apriori = 0;   // sg_debug_counter 1 / 2
+  int tile_order = 0;                // SG_OPT_TILE_ORDER: 1 = the gate's tiles by block index instead of tickets
   int floor_test = 0;                // SG_OPT_FLOOR_TEST: one-pass gate's floor test 0 = predicted, 1 = a priori, 2 = in the gate kernel
   int rg_shape = 16;                 // SG_OPT_ROWGATE_SHAPE: waves per workgroup of the row gate (16 x 1 quad, or 8 x 2 quads)
   bool rg_tap = false;               // SG_OPT_ROWGATE_TAP: keep the row gate's float32 power tile (stage tap 4)
@@ -1995,7 +1996,8 @@ static int stage_onepass(sg_handle* h, const View& v, const View& vx, const Geom
   P.epoch = h->epoch;
   P.err = h->err_dev;
   P.ticket_base = h->ticket_base;
-  h->ticket_base += (unsigned)(ub * ntt);
+  if (h->tile_order == 1) P.ticket_base = 0xffffffffu;   // SG_OPT_TILE_ORDER 1: tile = block index (no ticket)
+  else h->ticket_base += (unsigned)(ub * ntt);
   P.nf = h->p.n_grad_freq; P.nt = h->p.n_grad_time;
   P.prop = (float)h->p.prop_decrease;
   P.inv_ktot = 1.0f / (float)h->ktot;
@@ -2818,6 +2820,7 @@ extern "C" int sg_set_option(sg_handle* h, int32_t option, int64_t value) {
       h->rg_shape = (int)value;
       return SG_OK;
     case SG_OPT_INJECT_HANDOFF_FAULT: h->inject_fault = (unsigned)value & 63u; return SG_OK;
+    case SG_OPT_TILE_ORDER: h->tile_order = value != 0; return SG_OK;
     case SG_OPT_FLOOR_TEST:
       if (value < 0 || value > 2) FAIL(h, SG_E_INVALID, "SG_OPT_FLOOR_TEST: 0 (predicted), 1 (a priori) or 2 (in the gate kernel)");
       h->floor_test = (int)value;

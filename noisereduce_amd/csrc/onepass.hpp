@@ -187,7 +187,8 @@ __global__ __launch_bounds__(WAVES * 64, 3) void k_gate_onepass(OnePassArgs P) {
       alim_v = P.alim[z];
     }
     if (tid == 0) {
-      s_misc[0] = atomicAdd(P.ticket, 1u) - P.ticket_base;
+      // (ticket_base == 0xffffffff: SG_OPT_TILE_ORDER 1, the block index instead of a ticket)
+      s_misc[0] = P.ticket_base == 0xffffffffu ? blockIdx.x : atomicAdd(P.ticket, 1u) - P.ticket_base;
       s_misc[1] = 0u;   // set when a hand-off of this tile is lost: its output hops are POISONED (NaN), never plausible garbage
     }
     tw512[tid] = tw_a;

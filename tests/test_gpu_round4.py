@@ -376,3 +376,24 @@ def test_onepass_floor_test_prediction_follows_the_data():
     torch.cuda.synchronize()
     how3, out_b2 = run(sb)
     assert how3 == (1, 0) and np.array_equal(out_b, out_b2)
+
+
+def test_onepass_tile_order_option_same_output():
+    """SG_OPT_TILE_ORDER 1 (tile = block index, no atomic ticket) is an ordering choice only: bit-identical output."""
+    from noisereduce_amd import _ffi
+    from noisereduce_amd.spectralgate.stationary import SpectralGateStationary
+    y, y_noise, cs, pad = _floor_inputs("benign")
+    kw = dict(sr=48000, y_noise=y_noise, prop_decrease=1.0, n_std_thresh_stationary=1.5, chunk_size=cs,
+              clip_noise_stationary=True, padding=pad, n_fft=1024, win_length=None, hop_length=None,
+              time_constant_s=2.0, freq_mask_smooth_hz=500, time_mask_smooth_ms=50, tmp_folder=None, use_tqdm=False,
+              n_jobs=1)
+    sg = SpectralGateStationary(y=y, **kw)
+    a = sg.get_traces()
+    try:
+        sg._gate.set_option(_ffi.SG_OPT_TILE_ORDER, 1)
+        b = sg.get_traces()
+        c = sg.get_traces()
+    finally:
+        sg._gate.set_option(_ffi.SG_OPT_TILE_ORDER, 0)
+    d = sg.get_traces()
+    assert np.array_equal(a, b) and np.array_equal(a, c) and np.array_equal(a, d)

@@ -33,7 +33,8 @@ def main():
     rows = {m: {"ms": [], "gate_ms": []} for m in MODES}
     for rnd in range(4):
         for mode in MODES:
-            gate.set_option(_ffi.SG_OPT_FLOOR_TEST, mode)
+            gate.set_option(_ffi.SG_OPT_FLOOR_TEST, mode % 10)
+            gate.set_option(_ffi.SG_OPT_TILE_ORDER, mode // 10)   # modes 1x: tiles by block index instead of tickets
             for _ in range(30):
                 o = sg.get_traces()
             torch.cuda.synchronize()
@@ -60,7 +61,7 @@ def main():
     same = all((torch.equal(first, outs[m]) if torch.is_tensor(first) else np.array_equal(first, outs[m])) for m in outs)
     print(json.dumps({"workload": "configs[1]: 28.8 M samples, chunk 600000, padding 30000, n_fft 1024",
                       "outputs_identical": bool(same),
-                      "modes": {{1: "a_priori", 2: "in_kernel", 0: "predicted"}[m]:
+                      "modes": {{1: "a_priori", 2: "in_kernel", 0: "predicted", 12: "in_kernel_blockidx"}[m]:
                                 {"ms_per_call_rounds": [round(v, 4) for v in r["ms"]], "ms_per_call_median": round(float(np.median(r["ms"])), 4),
                                  "gate_kernel_ms_rounds": [round(v, 4) for v in r["gate_ms"]]} for m, r in rows.items()},
                       "counters": {"in_kernel_batches": gate.debug_counter(1), "a_priori_batches": gate.debug_counter(2)}}, indent=1))
