@@ -77,7 +77,7 @@ struct sg_handle {
   DevBuf P, pmax, thr_rows, raw, M, seg, yn;
   DevBuf bits, K16, umax, need, T2;  // fused stationary path
   DevBuf nss;                        // non-stationary gate: recurrence partials of k_mag_fast's 16-frame blocks
-  DevBuf alim;                       // one-pass gate, in-kernel floor test: compare constant on max|x| (k_prep_thresh_lazy)
+  DevBuf alim;                       // one-pass gate, in-kernel floor test: [1] tag of the last call that reported, [2..11) bounds on max|x| (k_colstats1_final / k_prep_thresh_lazy)
   bool t2_ready = false;             // T2 / alim hold the compare constants of the CURRENT threshold (any writer of thresh clears it)
   DevBuf logtab;                     // db_fast (kernels.hpp): {rd(1 / c_i), -log2 of it} for 128 mantissa centres
   DevBuf part;                       // partial reductions of the column statistics
@@ -2060,7 +2060,7 @@ static int stage_onepass(sg_handle* h, const View& v, const View& vx, const Geom
                              (unsigned long long*)h->pmax.p, (unsigned long long*)h->bits.p, wpr, st));
     if ((rc = handoff_next_epoch(h, st))) return rc;
     P.epoch = h->epoch;
-    P.ticket = (unsigned*)h->xticket.p + 8;   // its own counter (zeroed by k_prep_thresh_lazy): it takes tickets only if a unit reported
+    P.ticket = (unsigned*)h->xticket.p + 8;   // its own counter (zeroed by the first launch's ticket-0 workgroup): it takes tickets only if a unit reported
     P.ticket_base = 0;
     const size_t lds = (size_t)(fast::FN + WAVES * fast::WAVE_CX_H) * sizeof(fast::cf) + (1024 + T2_FLOATS) * sizeof(float) +
                        256 * 8 + 514 * 8 + 16 + (prop ? 528 : 0);

@@ -70,7 +70,7 @@ struct OnePassArgs {
   float prop, inv_ktot;       // PROP instantiation: prop_decrease and 1 / ktot (A.kscale = 1/512 then)
   unsigned long long* part2;  // [units][n_tiles][3][256] trailing partial hops of every tile: granules {float, epoch}
   // In-kernel floor test (see "floor test" in the kernel): alim = bit pattern of the largest max|x| for which no band's
-  // -top_db floor can be live (k_prep_thresh_lazy), null when the flags in tc.need_floor were computed up front
+  // -top_db floor can be live (alim[2 .. 2 + OP_ALIM_BLOCKS), see fastpath.hpp), null when the flags in tc.need_floor were computed up front
   // (k_unit_absmax + k_prep_thresh).  The REDO instantiation is the second launch of such a call: only the units whose
   // test fired run.
   // alim[1]: tc.need_tag of the last call in which some unit reported: the second launch returns at once -- before tables
