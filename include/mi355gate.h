@@ -190,7 +190,8 @@ SG_API int sg_debug_range(const sg_handle* h, int64_t range[2]);
 /* Diagnostic counters (synchronises `stream`).  which = 0: (row, band) pairs of the one-kernel TorchGate row gate that were
  * re-evaluated in float64 since the handle was created (the float32 statistics could not decide them within their error
  * bound); divide by rows x 513 for the rate.  which = 1 / 2: batches of the one-pass gate that took the in-kernel / the a-priori
- * floor test (SG_OPT_FLOOR_TEST) since the handle was created (host counters, no synchronisation). */
+ * floor test (SG_OPT_FLOOR_TEST) since the handle was created (host counters, no synchronisation); which = 3: launch epoch of the
+ * last gate call in which some chunk's floor test fired (0: never; synchronises). */
 SG_API int sg_debug_counter(sg_handle* h, int32_t which, int64_t* value, void* stream);
 SG_API int sg_debug_fetch(sg_handle* h, int32_t what, void* host, int64_t bytes, void* stream);
 

@@ -445,7 +445,8 @@ class Gate:
 
     def debug_counter(self, which=0):
         """0: (row, band) pairs the row gate re-evaluated in float64 since the handle was created; 1 / 2: batches of the
-        one-pass gate that took the in-kernel / the a-priori floor test (SG_OPT_FLOOR_TEST)."""
+        one-pass gate that took the in-kernel / the a-priori floor test (SG_OPT_FLOOR_TEST); 3: launch epoch of the last gate
+        call in which a chunk's floor test fired."""
         v = c_int64(0)
         with torch.cuda.device(self.device):
             self._check(self.lib.sg_debug_counter(self._h, int(which), ctypes.byref(v), self._stream()))

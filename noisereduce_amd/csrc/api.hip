@@ -2893,6 +2893,11 @@ extern "C" int sg_debug_counter(sg_handle* h, int32_t which, int64_t* value, voi
     *value = which == 1 ? h->n_floor_lazy : h->n_floor_apriori;
     return SG_OK;
   }
+  if (which == 3) {   // launch epoch of the last gate call in which a chunk's floor test fired / flag was set (0: never)
+    HIPCHK(h, hipStreamSynchronize((hipStream_t)stream));
+    *value = h->err_host ? (int64_t)h->err_host[1] : 0;
+    return SG_OK;
+  }
   if (which != 0) FAIL(h, SG_E_INVALID, "sg_debug_counter: unknown counter %d", which);
   *value = 0;
   if (!h->rg_count.p) return SG_OK;
