@@ -178,56 +178,16 @@ SG_API int sg_process_batch_backward(sg_handle* h, const void* grad_out_dev, int
  * scaling as the variant's reference call (S: 1/sum(w), scipy stft; T: unscaled). */
 SG_API int sg_stft(sg_handle* h, const void* x_dev, int dtype, int64_t B, int64_t L, int64_t stride,
             double* z_dev, void* stream);
-/* Fields of the last processed unit batch, copied to the host (synchronises):
- * what = 0: raw mask  float[units][T][FS];  1: final mask float[units][T][FS];
- *        2: power     double[units][T][FS] (stationary, materialised path only);
- *        3: raw mask as bits uint64[units][T][ceil(F/64)] (fused stationary path only).
- * FS = third entry of sg_debug_dims. */
-SG_API int sg_debug_dims(const sg_handle* h, int64_t dims[3]); /* units, T, FS */
-/* Frame range [t0, t1) for which field 3 (mask bits) was computed: the fast path only decides
- * the frames that reach the kept output samples (+- the smoothing half width). */
-SG_API int sg_debug_range(const sg_handle* h, int64_t range[2]);
-/* Diagnostic counters (synchronises `stream`).  which = 0: (row, band) pairs of the one-kernel TorchGate row gate that were
- * re-evaluated in float64 since the handle was created (the float32 statistics could not decide them within their error
- * bound); divide by rows x 513 for the rate.  which = 1 / 2: batches of the one-pass gate that took the in-kernel / the a-priori
- * floor test (SG_OPT_FLOOR_TEST) since the handle was created (host counters, no synchronisation); which = 3: launch epoch of the
- * last gate call in which some chunk's floor test fired (0: never; synchronises). */
-SG_API int sg_debug_counter(sg_handle* h, int32_t which, int64_t* value, void* stream);
-SG_API int sg_debug_fetch(sg_handle* h, int32_t what, void* host, int64_t bytes, void* stream);
-
 /* ---- options ------------------------------------------------------------------------- */
-#define SG_OPT_FORCE_UNFUSED 1 /* value != 0: use the materialised (v1) kernels everywhere */
-#define SG_OPT_FORCE_F64_DECIDE 3 /* value != 0: decide every mask cell from a float64 STFT */
-#define SG_OPT_FORCE_NOSEAM 4   /* value != 0: overlapping apply tiles instead of abutting tiles + seam kernel */
-#define SG_OPT_FORCE_NOLEAN 5   /* value != 0: apply kernel with full-size LDS slices and stored frames */
-#define SG_OPT_FORCE_SPLIT 6    /* value != 0: default geometry: decide / smooth / apply as three kernels instead of the one-pass kernel */
+/* Product options.  The A/B, fault-injection and profiling switches the tests and tools use live in
+ * mi355gate_debug.h (same library, same sg_set_option). */
 #define SG_OPT_FAST_INTEGER 8   /* value != 0: integer (SG_I16 / SG_I32) outputs from the fused float32 kernels: <= 1 LSB away from
                                  * the reference on ~1 % of the samples.  Default: the float64 pipeline, whose truncated result IS
                                  * the reference's (base.py:217-226 casts a float64 array), an order of magnitude slower */
 #define SG_OPT_FORCE_EXACT 9    /* value != 0: float64 pipeline for every output dtype (float64 recordings: float64-accurate results) */
-#define SG_OPT_INJECT_HANDOFF_FAULT 7 /* tests: the next launch with in-launch hand-offs reports `value` (bits 0..2) as lost hand-offs
-                                       * (the output is fine); bits 3..5 make the KERNEL lose its hand-offs (3 or 4: the one-pass
-                                       * gate, 5: the fused apply): the producers' tags are never accepted and the polls give up --
-                                       * the bounded-poll timeout path itself: error word set by the kernel, affected hops NaN */
-#define SG_OPT_FORCE_NOROWGATE 10 /* variant T, stationary, rows of <= 64 frames: 0 (default) = the one-kernel row gate for calls of >= 160
-                                   * rows, the four-kernel path (float64 transform of every frame, k_row_decide, k_smooth_bits2,
-                                   * k_apply_fast) below; 1 = never the row gate; 2 = the row gate whenever the shape is eligible */
-#define SG_OPT_ROWGATE_TAP 11     /* value != 0: the row gate also writes its float32 power tile (4 |X|^2, [rows][64][528]) for
-                                   * sg_debug_fetch(what = 4): measurements behind the decision margin */
-#define SG_OPT_ROWGATE_SHAPE 12   /* value = 16 (default) or 8: wavefronts per workgroup of the row gate (16 x one quad of frames at 128
-                                   * VGPRs, or 8 x two quads at 256 VGPRs without scratch): A/B measurements */
-#define SG_OPT_FLOOR_TEST 13      /* one-pass gate (k_gate_onepass): how "can _amp_to_db's -top_db floor lift a band of this chunk over its
-                                   * threshold?" is answered.  1 = a priori (k_unit_absmax reads the recording once more before the gate);
-                                   * 2 = by the gate kernel on the samples it stages -- free unless a chunk reports, which is then gated a
-                                   * second time with its float64 band maxima; 0 (default) = predicted from what recent calls on the handle
-                                   * found (no synchronisation).  Same result either way: exact band maxima decide */
-#define SG_OPT_TILE_ORDER 15      /* one-pass gate: 0 (default) = a workgroup takes its tile with an atomic ticket (a tile only ever waits for
-                                   * tiles of RUNNING workgroups, whatever order the hardware starts them in); 1 = tile = block index -- no
-                                   * atomic on every tile's critical path (gate kernel -4.4 %), at the price of assuming that the dispatcher
-                                   * starts workgroups in index order (it does on gfx950; HIP does not promise it).  Waits stay bounded and
-                                   * reported either way */
-#define SG_OPT_FORCE_NOFAST 2  /* value != 0: keep the bit-mask stages but use the general apply kernels */
 SG_API int sg_set_option(sg_handle* h, int32_t option, int64_t value);
+/* Current value of an option (the library's default if it was never set). */
+SG_API int sg_get_option(const sg_handle* h, int32_t option, int64_t* value);
 
 /* ---- deferred device-side errors -------------------------------------------------------- */
 /* The fused kernels of the default geometry hand data from workgroup to workgroup INSIDE a launch (mask bits,
@@ -235,42 +195,13 @@ SG_API int sg_set_option(sg_handle* h, int32_t option, int64_t value);
  * times out -- the device was preempted or time-sliced for that long -- cannot be reported by the asynchronous
  * call that enqueued the kernel.  sg_check_errors synchronises `stream` and returns SG_E_HANDOFF when a launch
  * enqueued on this handle since the previous check lost a hand-off: those calls' outputs are invalid and must
- * be re-run.  sg_get_noise_threshold and sg_debug_fetch (which synchronise anyway) report the same way; a caller
+ * be re-run.  Entry points that synchronise anyway (sg_get_noise_threshold; the stage taps of mi355gate_debug.h) report
+ * the same way; a caller
  * that never checks gets SG_E_HANDOFF from its NEXT compute call on the handle -- and never plausible-looking audio:
  * a tile that lost a hand-off writes NaN to every output hop it could not finalise.  The Python layer checks after
  * every call that returns host arrays and re-runs a failed call on the kernels without in-launch hand-offs.
  * (No counterpart in the reference: base.py:206-216 joins its joblib workers.) */
 SG_API int sg_check_errors(sg_handle* h, void* stream);
-
-/* ---- per-kernel timing (bench.py's roofline leg) ------------------------------------- */
-#define SG_STAGE_CHANNEL_MEAN 0
-#define SG_STAGE_STFT_POWER 1
-#define SG_STAGE_COLMAX 2
-#define SG_STAGE_COLSTATS 3
-#define SG_STAGE_DECIDE 4
-#define SG_STAGE_STFT_MAG 5
-#define SG_STAGE_NONSTAT_MASK 6
-#define SG_STAGE_SMOOTH 7
-#define SG_STAGE_APPLY_ISTFT 8
-#define SG_STAGE_OLA 9
-#define SG_STAGE_NOISE_STATS 10 /* every launch of sg_noise_stats */
-#define SG_STAGE_PREP 11
-#define SG_STAGE_STFT_MAX 12
-#define SG_STAGE_STFT_BITS 13
-#define SG_STAGE_APPLY_FAST 14
-#define SG_STAGE_DECIDE_FAST 15
-#define SG_STAGE_ONEPASS 16
-#define SG_STAGE_ROW_GATE 17   /* k_row_gate: TorchGate.forward of a whole row (<= 64 frames) in one kernel */
-#define SG_N_STAGES 18
-/* When enabled, every kernel launch is bracketed by a hipEvent pair recorded on the launch
- * stream.  sg_profile_read synchronises those events and returns accumulated milliseconds
- * and launch counts per stage (arrays of SG_N_STAGES); reset != 0 clears the accumulators. */
-SG_API int sg_profile_enable(sg_handle* h, int32_t on);
-/* Restrict the event pairs to the stages whose bit (1 << SG_STAGE_*) is set; 0 = all stages.  Timing
- * one kernel costs two event records per step instead of ~30. */
-SG_API int sg_profile_select(sg_handle* h, int64_t stage_mask);
-SG_API int sg_profile_read(sg_handle* h, double* ms, int64_t* counts, int32_t n_stages, int32_t reset);
-SG_API const char* sg_stage_name(int32_t stage);
 
 #ifdef __cplusplus
 }

@@ -1,4 +1,5 @@
-"""ctypes binding of libmi355gate.so (C ABI: include/mi355gate.h).
+"""ctypes binding of libmi355gate.so (C ABI: include/mi355gate.h; stage taps, development options and
+per-kernel timing: include/mi355gate_debug.h).
 
 PyTorch-ROCm tensors are only the I/O container: this module passes
 ``tensor.data_ptr()`` and the current HIP stream to the library.  There is no CPU
@@ -59,7 +60,7 @@ class SgParams(Structure):
     ]
 
 
-# every symbol include/mi355gate.h declares: name -> (restype, argtypes)
+# every symbol include/mi355gate.h and include/mi355gate_debug.h declare: name -> (restype, argtypes)
 _PROTOTYPES = {
     "sg_version": (c_int, []),
     "sg_last_error": (c_char_p, [c_void_p]),
@@ -85,6 +86,7 @@ _PROTOTYPES = {
                                           c_void_p, c_void_p, c_int64, c_void_p]),
     "sg_stft": (c_int, [c_void_p, c_void_p, c_int, c_int64, c_int64, c_int64, c_void_p, c_void_p]),
     "sg_set_option": (c_int, [c_void_p, c_int32, c_int64]),
+    "sg_get_option": (c_int, [c_void_p, c_int32, POINTER(c_int64)]),
     "sg_check_errors": (c_int, [c_void_p, c_void_p]),
     "sg_profile_enable": (c_int, [c_void_p, c_int32]),
     "sg_profile_select": (c_int, [c_void_p, c_int64]),
@@ -159,7 +161,7 @@ class Gate:
                  n_grad_freq=1, n_grad_time=1, smooth_mask=False, chunk_size=600000,
                  padding=30000, prop_decrease=1.0, n_std_thresh=1.5, top_db=80.0, ddof=0,
                  n_movemean=20, nonstat_thresh=2.0, nonstat_slope=10.0, iir_b=0.0,
-                 window=None, max_workspace_bytes=0, fast_integer=False):
+                 window=None, max_workspace_bytes=0, fast_integer=False, exact=False):
         self.lib = load_library()
         self.device = resolve_device(device)
         p = SgParams(variant=variant, stationary=int(bool(stationary)), n_fft=int(n_fft),
@@ -193,6 +195,8 @@ class Gate:
             self._raise(rc, msg)
         if fast_integer:   # integer outputs from the fused float32 kernels (<= 1 LSB off) instead of the float64 pipeline
             self.set_option(SG_OPT_FAST_INTEGER, 1)
+        if exact:          # float64 pipeline for every sample type (precision="float64": float64-accurate results)
+            self.set_option(SG_OPT_FORCE_EXACT, 1)
 
     # -- plumbing --------------------------------------------------------------------
     @staticmethod
@@ -356,11 +360,15 @@ class Gate:
 
     def set_option(self, option, value):
         self._check(self.lib.sg_set_option(self._h, int(option), int(value)))
-        self.__dict__.setdefault("_opts", {})[int(option)] = int(value)
 
     def get_option(self, option):
-        """The value last set through set_option on this (shared, cached) handle; 0 if never set."""
-        return self.__dict__.get("_opts", {}).get(int(option), 0)
+        """The option's current value on this (shared, cached) handle, read from the handle itself (sg_get_option):
+        the library's default if it was never set -- not every default is 0 (SG_OPT_ROWGATE_SHAPE: 16)."""
+        v = c_int64(0)
+        rc = self.lib.sg_get_option(self._h, int(option), byref(v))
+        if rc != 0:
+            raise ValueError(f"sg_get_option: unknown option {int(option)}")
+        return int(v.value)
 
     @contextlib.contextmanager
     def with_options(self, pairs):
@@ -497,6 +505,11 @@ def cached_gate(device, slot=0, **kw):
     # integer recordings: the reference truncates a float64 result (base.py:217-226) -> float64 pipeline by default;
     # NOISEREDUCE_AMD_FAST_INT=1 keeps the fused float32 kernels (<= 1 LSB off on ~1 % of the samples)
     kw.setdefault("fast_integer", os.environ.get("NOISEREDUCE_AMD_FAST_INT", "0") == "1")
+    # precision="float64" / NOISEREDUCE_AMD_EXACT=1: the float64 pipeline for every sample type -- a float64 recording then
+    # gets float64-accurate results like the reference's (base.py:140 computes every dtype in float64) instead of
+    # float32-accurate ones in a float64 container (the default: 14 x faster, 2e-7 of peak off)
+    if kw.get("exact") is None:
+        kw["exact"] = os.environ.get("NOISEREDUCE_AMD_EXACT", "0") == "1"
 
     def norm(v):
         if isinstance(v, np.ndarray):

@@ -14,7 +14,7 @@
 #include <string>
 #include <vector>
 
-#include "../../include/mi355gate.h"
+#include "../../include/mi355gate_debug.h"
 // Floating-point contraction only INSIDE a source expression (the language rule), never across statements: with the
 // compiler's default (fast) the back end fuses a product into whichever neighbouring add it meets first, and that
 // choice changes with unrelated edits -- two kernels that share a formula then round differently in the cells where
@@ -98,6 +98,7 @@ struct sg_handle {
   unsigned epoch = 0;                // launch counter: the value a tile's flag must carry to be current
   bool fast_integer = false;         // SG_OPT_FAST_INTEGER: integer outputs from the float32 kernels (<= 1 LSB off)
   bool force_exact = false;          // SG_OPT_FORCE_EXACT: float64 pipeline (exact.hpp) whatever the output dtype
+  unsigned need_era = 0;             // epoch >> 30 of the last one-pass gate call (tagged floor-test flags, stage_onepass)
   DevBuf xP, xraw, xM, xtmp, xseg;   // fields of the exact path
   bool force_split = false;          // SG_OPT_FORCE_SPLIT: decide / smooth / apply as three kernels
   int rowgate_mode = 0;              // SG_OPT_FORCE_NOROWGATE: 0 = by batch size, 1 = never, 2 = whenever the shape is eligible
@@ -1924,9 +1925,14 @@ static int stage_onepass(sg_handle* h, const View& v, const View& vx, const Geom
   const unsigned live_stamp = h->err_host[1];
   // the flags the tiles raise are tagged with this launch's epoch (30 bits; 0 = untagged): nothing to clear per call
   const unsigned need_tag = h->epoch & 0x3fffffffu;
-  if (need_tag == 0u) {   // once per 2^30 launches: leftovers of the previous era could alias
+  // Once per 2^30 launches the tag wraps: flags of the previous era carry LARGER tags, which atomicMax would keep.  Not
+  // every epoch reaches this function (a lazy call takes two, stage_apply_fast takes its own), so the crossing is
+  // detected by the era (epoch >> 30) changing between two calls here, not by need_tag == 0.
+  const unsigned era = h->epoch >> 30;
+  if (era != h->need_era || need_tag == 0u) {
     if (h->need.p) HIPCHK(h, hipMemsetAsync(h->need.p, 0, h->need.bytes, st));
     if (h->alim.p) HIPCHK(h, hipMemsetAsync((char*)h->alim.p + 4, 0, 4, st));
+    h->need_era = era;
   }
   const bool lazy = need_tag != 0u &&
                     (h->floor_test == 2 || (h->floor_test == 0 && !(live_stamp != 0u && h->epoch - live_stamp <= 16u)));
@@ -2827,6 +2833,27 @@ extern "C" int sg_set_option(sg_handle* h, int32_t option, int64_t value) {
       return SG_OK;
   }
   FAIL(h, SG_E_INVALID, "sg_set_option: unknown option %d", option);
+}
+
+extern "C" int sg_get_option(const sg_handle* h, int32_t option, int64_t* value) {
+  if (!h || !value) return SG_E_INVALID;
+  switch (option) {
+    case SG_OPT_FORCE_UNFUSED: *value = h->force_unfused; return SG_OK;
+    case SG_OPT_FORCE_NOFAST: *value = h->force_nofast; return SG_OK;
+    case SG_OPT_FORCE_F64_DECIDE: *value = h->force_f64_decide; return SG_OK;
+    case SG_OPT_FORCE_NOSEAM: *value = h->force_noseam; return SG_OK;
+    case SG_OPT_FORCE_NOLEAN: *value = h->force_nolean; return SG_OK;
+    case SG_OPT_FORCE_SPLIT: *value = h->force_split; return SG_OK;
+    case SG_OPT_FAST_INTEGER: *value = h->fast_integer; return SG_OK;
+    case SG_OPT_FORCE_EXACT: *value = h->force_exact; return SG_OK;
+    case SG_OPT_FORCE_NOROWGATE: *value = h->rowgate_mode; return SG_OK;
+    case SG_OPT_ROWGATE_TAP: *value = h->rg_tap; return SG_OK;
+    case SG_OPT_ROWGATE_SHAPE: *value = h->rg_shape; return SG_OK;
+    case SG_OPT_INJECT_HANDOFF_FAULT: *value = h->inject_fault; return SG_OK;
+    case SG_OPT_TILE_ORDER: *value = h->tile_order; return SG_OK;
+    case SG_OPT_FLOOR_TEST: *value = h->floor_test; return SG_OK;
+  }
+  return SG_E_INVALID;   // (no message: the handle is const here)
 }
 
 extern "C" int sg_profile_enable(sg_handle* h, int32_t on) {

@@ -421,16 +421,19 @@ __global__ __launch_bounds__(RG_WAVES * 64, 1) void k_row_gate(RowGateArgs A) {
       double var = (S2 - S1 * S1 / Tn) / (Tn - (double)A.ddof);
       if (var < 0.0) var = 0.0;
       const float th = (float)(mean_d + sqrt(var) * A.n_std);            // threshold relative to the maximum, dB
-      const float Eth = E1 / (float)T + fabsf((float)A.n_std) * __builtin_amdgcn_sqrtf(E2 / (float)(T - A.ddof)) + E_FIX;
+      // (+ eM outside the sums: th is relative to the ESTIMATED maximum and t2 below multiplies by it again -- in absolute dB
+      // the floored cells, exact relative to the maximum, carry the maximum's own error; a band where almost every frame is
+      // floored would otherwise see only the unfloored cells' share of it)
+      const float Eth = E1 / (float)T + fabsf((float)A.n_std) * __builtin_amdgcn_sqrtf(E2 / (float)(T - A.ddof)) + E_FIX + eM;
       if (-top > th + Eth) {
         t2 = -3.0e38f;                           // the floor lifts every cell above the threshold: all pass
       } else if (-top > th - Eth || !(Eth < 1.0f) || !(th == th)) {
         exact = true;
       } else {
         // compare constant in the (4x) power domain: T^2 = M * 2^(th / (10 log10 2)); ambiguity width 4 eta^2 T^2,
-        // eta = Eth ln(10) / 20 (relative error of the amplitude threshold) + the cell's own relative error
+        // eta = 10^(Eth / 20) - 1 (relative error of the amplitude threshold) + the cell's own relative error
         t2 = M * __builtin_amdgcn_exp2f(th * (1.f / kDb));
-        const float eta = Eth * 0.11512925f + 1.01f * RG_REL;
+        const float eta = expm1f(Eth * 0.11512925f) + 1.01f * RG_REL;   // 10^(Eth / 20) - 1, not its first-order term (Eth < 1 dB)
         cb = 4.f * eta * eta * t2;
       }
     }

@@ -14,9 +14,15 @@ def reduce_noise(y, sr, stationary=False, y_noise=None, prop_decrease=1.0, time_
                  sigmoid_slope_nonstationary=10, n_std_thresh_stationary=1.5, tmp_folder=None,
                  chunk_size=600000, padding=30000, n_fft=1024, win_length=None, hop_length=None,
                  clip_noise_stationary=True, use_tqdm=False, n_jobs=1, use_torch=False,
-                 device="cuda"):
+                 device="cuda", precision=None):
     """Reduce noise via spectral gating (see the reference docstring,
     noisereduce.py:37-109, for the meaning of every argument).
+
+    ``precision`` (not in the reference, ``use_torch=False`` only): ``"float32"`` -- the fused float32 kernels (mask
+    decisions exact, output within 2e-7 of peak of the reference's float64 arithmetic, whatever the container dtype);
+    ``"float64"`` -- the float64 pipeline (the reference computes every dtype in float64, base.py:140: a float64
+    recording then matches it to ~1e-13; about 14 x slower); ``None`` (default) -- ``"float64"`` if the environment
+    holds ``NOISEREDUCE_AMD_EXACT=1``, else ``"float32"``.  Integer recordings are bit-exact either way.
 
     ``use_torch=False`` evaluates the numpy/scipy "spectralgate" algorithm,
     ``use_torch=True`` the "torchgate" algorithm (the two differ)."""
@@ -40,7 +46,7 @@ def reduce_noise(y, sr, stationary=False, y_noise=None, prop_decrease=1.0, time_
             clip_noise_stationary=clip_noise_stationary, padding=padding, n_fft=n_fft,
             win_length=win_length, hop_length=hop_length, time_constant_s=time_constant_s,
             freq_mask_smooth_hz=freq_mask_smooth_hz, time_mask_smooth_ms=time_mask_smooth_ms,
-            tmp_folder=tmp_folder, use_tqdm=use_tqdm, n_jobs=n_jobs, device=device)
+            tmp_folder=tmp_folder, use_tqdm=use_tqdm, n_jobs=n_jobs, device=device, precision=precision)
     else:
         sg = SpectralGateNonStationary(
             y=y, sr=sr, chunk_size=chunk_size, padding=padding, prop_decrease=prop_decrease,
@@ -49,5 +55,5 @@ def reduce_noise(y, sr, stationary=False, y_noise=None, prop_decrease=1.0, time_
             time_mask_smooth_ms=time_mask_smooth_ms,
             thresh_n_mult_nonstationary=thresh_n_mult_nonstationary,
             sigmoid_slope_nonstationary=sigmoid_slope_nonstationary, tmp_folder=tmp_folder,
-            use_tqdm=use_tqdm, n_jobs=n_jobs, device=device)
+            use_tqdm=use_tqdm, n_jobs=n_jobs, device=device, precision=precision)
     return sg.get_traces()

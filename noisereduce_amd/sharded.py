@@ -188,8 +188,14 @@ def flush_pending(bufs):
     last `exchange_seams_and_threshold(..., defer=True)` of a loop; a no-op when nothing is pending."""
     if bufs is not None and bufs.get("pending") is not None:
         host, ev, pcs, ppad = bufs.pop("pending")
+        cause = bufs.pop("pending_cause", None)   # rank 0: the exception its statistics raised in the deferred call
         ev.synchronize()
-        _check_shard_lengths(host.tolist(), pcs, ppad)
+        try:
+            _check_shard_lengths(host.tolist(), pcs, ppad)
+        except ValueError as e:
+            if cause is not None:
+                raise e from cause
+            raise
 
 
 def exchange_seams_and_threshold(y_local, padding, thr, n_bins, group=None, bufs=None, chunk_size=None, defer=False):
@@ -330,6 +336,10 @@ class TimeShardedStationary:
                 if thr_err is not None:
                     raise thr_err
                 raise
+            if thr_err is not None and defer_check:
+                # deferred verdict: this call returns output gated with the NaN threshold (everything gated) and every
+                # rank raises at its next call / finish(); rank 0 keeps the original exception to chain it there
+                self._bufs["pending_cause"] = thr_err
             if ev is not None:
                 ev[1].record()
                 timing.append(ev)

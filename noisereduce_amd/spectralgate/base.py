@@ -35,8 +35,12 @@ _DEVICE_DTYPES = {
 class SpectralGate:
     def __init__(self, y, sr, prop_decrease, chunk_size, padding, n_fft, win_length,
                  hop_length, time_constant_s, freq_mask_smooth_hz, time_mask_smooth_ms,
-                 tmp_folder, use_tqdm, n_jobs, device="cuda"):
+                 tmp_folder, use_tqdm, n_jobs, device="cuda", precision=None):
         self.sr = sr
+        if precision not in (None, "float32", "float64"):
+            raise ValueError('precision must be None, "float32" or "float64"')
+        # None: NOISEREDUCE_AMD_EXACT decides (default: the fused float32 kernels); "float64": the float64 pipeline
+        self._exact = None if precision is None else precision == "float64"
         self.flat = False
         self._tensor_io = isinstance(y, torch.Tensor)
         if not self._tensor_io:
@@ -104,7 +108,7 @@ class SpectralGate:
                     hop_length=self._hop_length, n_grad_freq=self._n_grad_freq,
                     n_grad_time=self._n_grad_time, smooth_mask=self.smooth_mask,
                     chunk_size=self._chunk_size, padding=self.padding,
-                    prop_decrease=self._prop_decrease)
+                    prop_decrease=self._prop_decrease, exact=self._exact)
 
     def _to_device(self, a):
         """Upload a host array (or pass a tensor) as one of the dtypes the kernels read

@@ -16,7 +16,7 @@ class SpectralGateNonStationary(SpectralGate):
     def __init__(self, y, sr, chunk_size, padding, n_fft, win_length, hop_length,
                  time_constant_s, freq_mask_smooth_hz, time_mask_smooth_ms,
                  thresh_n_mult_nonstationary, sigmoid_slope_nonstationary, tmp_folder,
-                 prop_decrease, use_tqdm, n_jobs, device="cuda"):
+                 prop_decrease, use_tqdm, n_jobs, device="cuda", precision=None):
         self._thresh_n_mult_nonstationary = thresh_n_mult_nonstationary
         self._sigmoid_slope_nonstationary = sigmoid_slope_nonstationary
         super().__init__(y=y, sr=sr, chunk_size=chunk_size, padding=padding, n_fft=n_fft,
@@ -25,7 +25,7 @@ class SpectralGateNonStationary(SpectralGate):
                          freq_mask_smooth_hz=freq_mask_smooth_hz,
                          time_mask_smooth_ms=time_mask_smooth_ms, tmp_folder=tmp_folder,
                          prop_decrease=prop_decrease, use_tqdm=use_tqdm, n_jobs=n_jobs,
-                         device=device)
+                         device=device, precision=precision)
         b = iir_coefficient(self._time_constant_s, self.sr, self._hop_length)
         self._gate = _ffi.cached_gate(self.device, stationary=False, iir_b=b,
                                nonstat_thresh=thresh_n_mult_nonstationary,

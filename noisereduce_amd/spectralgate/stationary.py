@@ -11,14 +11,14 @@ class SpectralGateStationary(SpectralGate):
     def __init__(self, y, sr, y_noise, n_std_thresh_stationary, chunk_size,
                  clip_noise_stationary, padding, n_fft, win_length, hop_length, time_constant_s,
                  freq_mask_smooth_hz, time_mask_smooth_ms, tmp_folder, prop_decrease, use_tqdm,
-                 n_jobs, device="cuda", slot=0):
+                 n_jobs, device="cuda", slot=0, precision=None):
         super().__init__(y=y, sr=sr, chunk_size=chunk_size, padding=padding, n_fft=n_fft,
                          win_length=win_length, hop_length=hop_length,
                          time_constant_s=time_constant_s,
                          freq_mask_smooth_hz=freq_mask_smooth_hz,
                          time_mask_smooth_ms=time_mask_smooth_ms, tmp_folder=tmp_folder,
                          prop_decrease=prop_decrease, use_tqdm=use_tqdm, n_jobs=n_jobs,
-                         device=device)
+                         device=device, precision=precision)
         self.n_std_thresh_stationary = n_std_thresh_stationary
 
         # noise clip, (channels, frames)  (stationary.py:47-58)

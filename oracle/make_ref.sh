@@ -17,8 +17,11 @@ if [ ! -d "$src/noisereduce" ]; then
   echo "make_ref.sh: $src/noisereduce not found (nothing staged)" >&2
   exit 3
 fi
-rm -rf "$dst"
-mkdir -p "$dst"
+# staged into a scratch directory next to the target, then swapped in: concurrent callers (several processes running
+# build() at once) never see a half-copied tree, and a failed copy leaves the previous staging in place
+final="$dst"
+dst="$(mktemp -d "$here/_ref.tmp.XXXXXX")"
+trap 'rm -rf "$dst"' EXIT
 # python sources only (no __pycache__, no notebooks / assets)
 (cd "$src" && find noisereduce -name '*.py' -print0 | sort -z | xargs -0 -I{} cp --parents {} "$dst/")
 (cd "$dst" && find noisereduce -name '*.py' -print0 | sort -z | xargs -0 sha256sum > MANIFEST.sha256)
@@ -28,4 +31,9 @@ mkdir -p "$dst"
   grep -m1 -E '^\s*version' "$src/setup.py" 2>/dev/null | sed 's/^\s*/setup.py /' || true
   echo "files: $(wc -l < "$dst/MANIFEST.sha256")"
 } > "$dst/SOURCE.txt"
-echo "make_ref.sh: staged $(wc -l < "$dst/MANIFEST.sha256") files under $dst"
+n="$(wc -l < "$dst/MANIFEST.sha256")"
+old="$(mktemp -d "$here/_ref.old.XXXXXX")"
+if [ -d "$final" ]; then mv "$final" "$old/_ref"; fi
+mv "$dst" "$final"
+rm -rf "$old"
+echo "make_ref.sh: staged $n files under $final"

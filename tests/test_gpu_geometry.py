@@ -1,0 +1,200 @@
+"""STFT geometry generality (row f3): n_fft 512 / 2048 fast paths, long frames (four-step / chirp-z), TorchGate on them.
+(grouped by subject in round 5; the tests themselves date from rounds 2-4)"""
+import threading
+
+import numpy as np
+import pytest
+import torch
+
+from oracle import spectralgate_oracle as O
+
+pytestmark = pytest.mark.gpu
+
+TOL = 1e-4
+
+NS_KW = dict(sr=48000, prop_decrease=1.0, chunk_size=100000, padding=8000, n_fft=1024, win_length=None,
+             hop_length=None, time_constant_s=2.0, freq_mask_smooth_hz=500, time_mask_smooth_ms=50,
+             thresh_n_mult_nonstationary=2, sigmoid_slope_nonstationary=10, tmp_folder=None, use_tqdm=False, n_jobs=1)
+
+
+@pytest.fixture(scope="module")
+def nr():
+    import noisereduce_amd
+    return noisereduce_amd
+
+
+@pytest.mark.parametrize("n_fft,kw", [
+    (4097, dict()),                                            # first length beyond the per-workgroup chirp-z kernels (M = 16384)
+    (8193, dict(time_mask_smooth_ms=100)),                     # M = 32768
+    (16384, dict(time_mask_smooth_ms=200)),                    # power of two, direct (M = n)
+    (20000, dict(time_mask_smooth_ms=300, win_length=16000, hop_length=3000)),   # M = 65536, window shorter than the frame
+    (32768, dict(time_mask_smooth_ms=400)),
+    (65536, dict(time_mask_smooth_ms=800, freq_mask_smooth_hz=None)),           # the largest frame
+])
+@pytest.mark.parametrize("stationary", [True, False])
+def test_long_frames_match_the_oracle(nr, n_fft, kw, stationary):
+    """reduce_noise with n_fft beyond 8192 (or beyond 4096 and not a power of two) against the oracle (base.py:77-86
+    accepts any n_fft; scipy.signal.stft/istft use rfft(n)/irfft(n))."""
+    n = max(6 * n_fft, 90000)
+    y = O.synth_signal(n, seed=n_fft).astype(np.float32)
+    args = dict(stationary=stationary, n_fft=n_fft, chunk_size=max(50000, 3 * n_fft), padding=max(6000, n_fft), **kw)
+    got = nr.reduce_noise(y=y, sr=48000, **args)
+    want = O.reduce_noise_S(y.astype(np.float64), 48000, **args)
+    assert got.shape == y.shape and got.dtype == y.dtype
+    assert O.rel_err(got, want) < TOL
+
+
+def test_long_frames_stft_tap(nr):
+    """The STFT tap (sg_stft) on a long chirp-z frame and a long power-of-two frame against scipy-style STFT of the oracle."""
+    from noisereduce_amd import _ffi
+    for n_fft in (5000, 16384):
+        x = O.synth_signal(4 * n_fft + 123, seed=3).astype(np.float64)
+        g = _ffi.Gate("cuda", variant=_ffi.SG_VARIANT_S, stationary=True, n_fft=n_fft, win_length=n_fft, hop_length=n_fft // 4)
+        Z = g.stft(torch.from_numpy(x)[None].cuda())[0].cpu().numpy().T     # (F, T)
+        Zo = O.stft_scipy(x, n_fft, n_fft, n_fft // 4)
+        assert Z.shape == Zo.shape
+        assert np.max(np.abs(Z - Zo)) < 1e-12 * max(1.0, np.max(np.abs(Zo)))
+        g.close()
+
+
+def test_torchgate_long_frames(nr):
+    from noisereduce_amd.torchgate import TorchGate
+    for n_fft, kw in ((16384, dict(time_mask_smooth_ms=200)), (6000, dict(nonstationary=True, n_movemean_nonstationary=5))):
+        x = np.stack([O.synth_signal(3 * n_fft + 777, sr=48000, seed=s) for s in range(3)]).astype(np.float64)
+        tg = TorchGate(sr=48000, n_fft=n_fft, **kw).cuda()
+        got = tg(torch.from_numpy(x).cuda()).cpu().numpy()
+        want = O.torchgate_T(x, 48000, n_fft=n_fft, window=torch.hann_window(n_fft).double().numpy(), **kw)
+        assert got.shape == want.shape
+        assert O.rel_err(got, want) < TOL
+
+
+@pytest.mark.parametrize("sr,n,kw", [
+    (16000, 30000, dict()),                                                  # one chunk
+    (48000, 200000, dict(chunk_size=40000, padding=5000)),                   # chunk grid, partial last chunk
+    (16000, 51234, dict(chunk_size=9000, padding=1000, prop_decrease=0.6)),  # ragged: tiles at both unit edges
+    (16000, 515, dict()),                                                    # barely longer than a frame
+    (8000, 20000, dict(freq_mask_smooth_hz=None, time_mask_smooth_ms=None)),
+    (44100, 70000, dict(time_mask_smooth_ms=None)),
+])
+@pytest.mark.parametrize("stationary", [True, False])
+def test_nfft512_fast_path_matches_the_oracle(nr, sr, n, kw, stationary):
+    y = np.stack([O.synth_signal(n, sr=sr, seed=81 + c, tone_hz=300.0 * (c + 1)) for c in range(2)]).astype(np.float32)
+    args = dict(stationary=stationary, n_fft=512, **kw)
+    got = nr.reduce_noise(y=y, sr=sr, **args)
+    want = O.reduce_noise_S(y.astype(np.float64), sr, **args)
+    assert O.rel_err(got, want) < TOL
+    # the general LDS kernels on the same input (SG_OPT_FORCE_NOFAST): same result to float32 rounding
+    y1 = torch.from_numpy(y).cuda()
+    a = nr.reduce_noise(y=y1, sr=sr, **args)
+    assert O.rel_err(a.cpu().numpy(), want) < TOL
+
+
+def test_nfft512_decisions_equal_the_float64_decisions(nr):
+    """Mask bits of k_decide_fast512 (float32 + exact refinement, two frames per transform) == the all-float64 decision
+    kernel, bit for bit -- incl. a loud frame next to a quiet one (the pair shares one transform) and a steady tone."""
+    from noisereduce_amd import _ffi
+    from noisereduce_amd.spectralgate.stationary import SpectralGateStationary
+    sr, n = 16000, 120000
+    y = O.synth_signal(n, sr=sr, seed=5, tone_hz=440.0).astype(np.float32)
+    y[30000:30700] *= 200.0          # a burst: frames with a loud and a quiet partner
+    y[60000:] = (0.3 * np.sin(2 * np.pi * 1000.0 * np.arange(n - 60000) / sr)).astype(np.float32)   # steady tone
+    kw = dict(sr=sr, y_noise=None, prop_decrease=1.0, n_std_thresh_stationary=1.5, chunk_size=50000, clip_noise_stationary=True,
+              padding=4000, n_fft=512, win_length=None, hop_length=None, time_constant_s=2.0, freq_mask_smooth_hz=500,
+              time_mask_smooth_ms=50, tmp_folder=None, use_tqdm=False, n_jobs=1)
+    sg = SpectralGateStationary(y=torch.from_numpy(y).cuda(), **kw)
+    out_fast = sg.get_traces().clone()
+    bits_fast = sg._gate.debug_field(3)
+    sg._gate.set_option(_ffi.SG_OPT_FORCE_F64_DECIDE, 1)
+    try:
+        out_64 = sg.get_traces().clone()
+        bits_64 = sg._gate.debug_field(3)
+    finally:
+        sg._gate.set_option(_ffi.SG_OPT_FORCE_F64_DECIDE, 0)
+    assert bits_fast.shape == bits_64.shape and np.array_equal(bits_fast, bits_64)
+    assert torch.equal(out_fast, out_64)
+    want = O.reduce_noise_S(y.astype(np.float64), sr, stationary=True, n_fft=512, chunk_size=50000, padding=4000)
+    assert O.rel_err(out_fast.cpu().numpy(), want) < TOL
+
+
+def test_torchgate_nfft512(nr):
+    from noisereduce_amd.torchgate import TorchGate
+    for kw in (dict(), dict(nonstationary=True)):
+        x = np.stack([O.synth_signal(16000, sr=16000, seed=s, tone_hz=440.0) for s in range(5)]).astype(np.float64)
+        tg = TorchGate(sr=16000, n_fft=512, **kw).cuda()
+        xt = torch.from_numpy(x).cuda().requires_grad_()
+        y = tg(xt)
+        want = O.torchgate_T(x, 16000, n_fft=512, window=torch.hann_window(512).double().numpy(), **kw)
+        assert O.rel_err(y.detach().cpu().numpy(), want) < TOL
+        # backward: the adjoint with the mask fixed against autograd through torch.stft / istft on the CPU
+        w = torch.linspace(0.5, 1.5, y.shape[1], dtype=torch.float64)
+        (y * w.cuda()).sum().backward()
+        got_g = xt.grad.cpu()
+        _, st = O.torchgate_T(x, 16000, n_fft=512, window=torch.hann_window(512).double().numpy(), return_stages=True, **kw)
+        m = torch.from_numpy(st["mask"])
+        xc = torch.from_numpy(x).requires_grad_()
+        win = torch.hann_window(512, dtype=torch.float64)
+        X = torch.stft(xc, 512, 128, 512, window=win, center=True, pad_mode="constant", return_complex=True)
+        yc = torch.istft(X * m, 512, 128, 512, window=win, center=True)
+        (yc * w).sum().backward()
+        assert O.rel_err(got_g.numpy(), xc.grad.numpy()) < TOL
+
+
+@pytest.mark.parametrize("sr,n,kw", [
+    (44100, 50000, dict()),                                                   # one chunk
+    (48000, 300000, dict(chunk_size=70000, padding=9000)),                    # chunk grid, partial last chunk
+    (48000, 123457, dict(chunk_size=30000, padding=4100, prop_decrease=0.6)), # ragged: tiles at both unit edges
+    (48000, 2060, dict()),                                                    # barely longer than a frame
+    (96000, 90000, dict(freq_mask_smooth_hz=None, time_mask_smooth_ms=None)),
+])
+@pytest.mark.parametrize("stationary", [True, False])
+def test_nfft2048_fast_path_matches_the_oracle(nr, sr, n, kw, stationary):
+    y = np.stack([O.synth_signal(n, sr=sr, seed=91 + c, tone_hz=300.0 * (c + 1)) for c in range(2)]).astype(np.float32)
+    args = dict(stationary=stationary, n_fft=2048, **kw)
+    got = nr.reduce_noise(y=y, sr=sr, **args)
+    want = O.reduce_noise_S(y.astype(np.float64), sr, **args)
+    assert O.rel_err(got, want) < TOL
+
+
+def test_nfft2048_decisions_equal_the_float64_decisions(nr):
+    from noisereduce_amd import _ffi
+    from noisereduce_amd.spectralgate.stationary import SpectralGateStationary
+    sr, n = 48000, 400000
+    y = O.synth_signal(n, sr=sr, seed=6, tone_hz=440.0).astype(np.float32)
+    y[100000:102000] *= 200.0
+    y[250000:] = (0.3 * np.sin(2 * np.pi * 1000.0 * np.arange(n - 250000) / sr)).astype(np.float32)   # steady tone
+    kw = dict(sr=sr, y_noise=None, prop_decrease=1.0, n_std_thresh_stationary=1.5, chunk_size=150000, clip_noise_stationary=True,
+              padding=12000, n_fft=2048, win_length=None, hop_length=None, time_constant_s=2.0, freq_mask_smooth_hz=500,
+              time_mask_smooth_ms=50, tmp_folder=None, use_tqdm=False, n_jobs=1)
+    sg = SpectralGateStationary(y=torch.from_numpy(y).cuda(), **kw)
+    out_fast = sg.get_traces().clone()
+    bits_fast = sg._gate.debug_field(3)
+    sg._gate.set_option(_ffi.SG_OPT_FORCE_F64_DECIDE, 1)
+    try:
+        out_64 = sg.get_traces().clone()
+        bits_64 = sg._gate.debug_field(3)
+    finally:
+        sg._gate.set_option(_ffi.SG_OPT_FORCE_F64_DECIDE, 0)
+    assert bits_fast.shape == bits_64.shape and np.array_equal(bits_fast, bits_64)
+    assert torch.equal(out_fast, out_64)
+    want = O.reduce_noise_S(y.astype(np.float64), sr, stationary=True, n_fft=2048, chunk_size=150000, padding=12000)
+    assert O.rel_err(out_fast.cpu().numpy(), want) < TOL
+
+
+def test_torchgate_nfft2048(nr):
+    from noisereduce_amd.torchgate import TorchGate
+    for kw in (dict(), dict(nonstationary=True)):
+        x = np.stack([O.synth_signal(30000, sr=48000, seed=s, tone_hz=440.0) for s in range(3)]).astype(np.float64)
+        tg = TorchGate(sr=48000, n_fft=2048, **kw).cuda()
+        xt = torch.from_numpy(x).cuda().requires_grad_()
+        y = tg(xt)
+        want, st = O.torchgate_T(x, 48000, n_fft=2048, window=torch.hann_window(2048).double().numpy(), return_stages=True, **kw)
+        assert O.rel_err(y.detach().cpu().numpy(), want) < TOL
+        w = torch.linspace(0.5, 1.5, y.shape[1], dtype=torch.float64)
+        (y * w.cuda()).sum().backward()
+        m = torch.from_numpy(st["mask"])
+        xc = torch.from_numpy(x).requires_grad_()
+        win = torch.hann_window(2048, dtype=torch.float64)
+        X = torch.stft(xc, 2048, 512, 2048, window=win, center=True, pad_mode="constant", return_complex=True)
+        yc = torch.istft(X * m, 2048, 512, 2048, window=win, center=True)
+        (yc * w).sum().backward()
+        assert O.rel_err(xt.grad.cpu().numpy(), xc.grad.numpy()) < TOL

@@ -18,9 +18,15 @@ def test_cabi_library_exports_every_declared_symbol():
     import __graft_entry__
     __graft_entry__.build()
     from noisereduce_amd import _ffi
+    # product ABI + the development surface (stage taps, A/B options, per-kernel timing): same library
     header = open(os.path.join(ROOT, "include", "mi355gate.h")).read()
-    declared = set(re.findall(r"\b(sg_[a-z_0-9]+)\s*\(", header))
-    declared.discard("sg_debug_dims()")
+    debug_header = open(os.path.join(ROOT, "include", "mi355gate_debug.h")).read()
+    product = set(re.findall(r"\b(sg_[a-z_0-9]+)\s*\(", header))
+    # the product header carries no development switches, taps or profiling entry points
+    assert not [n for n in product if n.startswith(("sg_debug_", "sg_profile_", "sg_stage_"))], product
+    assert set(re.findall(r"#define (SG_OPT_\w+)", header)) == {"SG_OPT_FAST_INTEGER", "SG_OPT_FORCE_EXACT"}
+    assert "SG_STAGE_" not in header
+    declared = product | set(re.findall(r"\b(sg_[a-z_0-9]+)\s*\(", debug_header))
     lib = _ffi.load_library()
     assert declared == set(_ffi.exported_symbols()), declared ^ set(_ffi.exported_symbols())
     for name in declared:
@@ -119,10 +125,11 @@ def test_header_is_plain_c_and_c_example_links(tmp_path):
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
     if shutil.which("gcc") is None:
         pytest.skip("gcc not available")
-    hdr = os.path.join(root, "include", "mi355gate.h")
-    subprocess.run(["gcc", "-std=c99", "-Wall", "-Wextra", "-pedantic", "-Werror", "-fsyntax-only", "-x", "c", hdr],
-                   check=True)
-    subprocess.run(["g++", "-std=c++11", "-fsyntax-only", "-x", "c++", hdr], check=True)
+    for name in ("mi355gate.h", "mi355gate_debug.h"):
+        hdr = os.path.join(root, "include", name)
+        subprocess.run(["gcc", "-std=c99", "-Wall", "-Wextra", "-pedantic", "-Werror", "-fsyntax-only", "-x", "c", hdr],
+                       check=True)
+        subprocess.run(["g++", "-std=c++11", "-fsyntax-only", "-x", "c++", hdr], check=True)
     assert os.path.exists(_build_c_example(tmp_path))
 
 
