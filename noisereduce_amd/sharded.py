@@ -36,6 +36,15 @@ def shard_bounds(n_total, chunk_size, world_size, rank):
     return min(c0 * chunk_size, n_total), min(c1 * chunk_size, n_total)
 
 
+def channel_bounds(c_total, world_size, rank):
+    """Channels [c0, c1) of rank `rank` when C channels are dealt to the ranks in contiguous runs (the first
+    c_total % world_size ranks hold one more; with fewer channels than ranks the last ranks hold none -- they still take
+    part in the all-reduce of ChannelShardedStationary)."""
+    q, r = divmod(int(c_total), int(world_size))
+    c0 = rank * q + min(rank, r)
+    return c0, c0 + q + (1 if rank < r else 0)
+
+
 def exchange_seams(y_local, padding, group=None):
     """All-gather the seam samples and return (left_halo, right_halo), each (C, padding):
     the previous rank's last / the next rank's first `padding` samples, zeros at the ends of
@@ -352,7 +361,8 @@ class TimeShardedStationary:
             else:
                 ext[:, :pad].copy_(left)
                 ext[:, pad + S:].copy_(right)
-            return self.backend.filter(y_local, ext, pad, thr, owner=self.rank == 0)
+            # (rank 0 after a failed statistics pass does not "own" a threshold: it loads the NaN one it sent, like the others)
+            return self.backend.filter(y_local, ext, pad, thr, owner=self.rank == 0 and thr_err is None)
 
 
 class TimeShardedNonStationary:
@@ -418,26 +428,56 @@ class ChannelShardedStationary:
         self.group = group
         self.ws = dist.get_world_size(group) if dist.is_initialized() else 1
 
-    def run(self, y_local, c_total=None):
+    def run(self, y_local, c_total=None, timing=None):
+        """y_local: this rank's (C_local, N) channels -- C_local may differ between ranks and may be 0 (more ranks than
+        channels): the channel COUNT rides in the same all-reduce as the clip sum (one extra element), so the mean is
+        over the true total whatever the split.  `c_total`, when given, must equal that total (checked on every rank
+        alike, after the collective).  `timing`: list that receives a (start, end) CUDA-event pair around the
+        all-reduce (bench.py: time a rank's stream spends in the exchange)."""
         if y_local.dim() == 1:
             y_local = y_local[None, :]
         C_local, N = y_local.shape
-        c_total = C_local * self.ws if c_total is None else c_total
         kw = getattr(self.backend, "kw", {})
         y_noise = kw.get("y_noise")
         if y_noise is not None:
             # an explicit noise clip is the same on every rank (stationary.py:47-58): no exchange at all
+            if C_local == 0:
+                return y_local.new_empty((0, N))
             noise = y_noise if y_noise.dim() == 2 else y_noise[None, :]
             return self.backend.filter_with_noise(y_local, noise, clip=kw.get("clip_noise_stationary", True))
         # y_noise=None: the recording itself, clipped to chunk_size unless clip_noise_stationary=False
         # or chunk_size=None (stationary.py:61-64)
         cs = self.backend.chunk_size
         n_clip = min(N, cs) if (kw.get("clip_noise_stationary", True) and cs is not None) else N
-        clip_sum = y_local[:, :n_clip].to(torch.float64).sum(dim=0)
+        buf = torch.empty(n_clip + 1, dtype=torch.float64, device=y_local.device)
+        buf[:n_clip] = y_local[:, :n_clip].to(torch.float64).sum(dim=0)
+        buf[n_clip] = float(C_local)
         if self.ws > 1:
-            dist.all_reduce(clip_sum, op=dist.ReduceOp.SUM, group=self.group)
-        clip_mean = (clip_sum / float(c_total)).unsqueeze(0)      # (1, n_clip): its own "channel mean"
+            ev = None
+            if timing is not None and y_local.is_cuda:
+                ev = (torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True))
+                ev[0].record()
+            dist.all_reduce(buf, op=dist.ReduceOp.SUM, group=self.group)
+            if ev is not None:
+                ev[1].record()
+                timing.append(ev)
+        if c_total is None:
+            clip_mean = (buf[:n_clip] / buf[n_clip]).unsqueeze(0)     # (1, n_clip): its own "channel mean"; no host sync
+        else:
+            # the caller's count is used for the mean (identical on every rank by contract); the all-reduced count is
+            # NOT read back here (a device-to-host sync per call) -- check_channel_total() does that on demand
+            clip_mean = (buf[:n_clip] / float(c_total)).unsqueeze(0)
+        self._last_count = buf[n_clip:]
+        if C_local == 0:
+            return y_local.new_empty((0, N))
         return self.backend.filter_with_noise(y_local, clip_mean)
+
+    def check_channel_total(self, c_total):
+        """After run(): the all-reduced channel count of the last call equals `c_total` (synchronises; every rank reads
+        the same number, so every rank raises -- or none does)."""
+        got = int(round(float(self._last_count.item())))
+        if got != int(c_total):
+            raise ValueError(f"channel-sharded gate: the ranks hold {got} channels in total, caller said {c_total}")
 
 
 def _hip_filter_with_noise(self, y_local, noise, clip=False):

@@ -91,6 +91,60 @@ def test_channel_sharded_eight_ranks_matches_single_process():
     assert all(ret[r] < 1e-9 for r in range(8)), dict(ret)
 
 
+def _worker_channels_uneven(rank, world, port, y, want, ret):
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    from noisereduce_amd.sharded import ChannelShardedStationary, channel_bounds
+
+    class Backend:
+        chunk_size, padding = CS, PAD
+
+        def filter_with_noise(self, y_local, noise):
+            out = O.reduce_noise_S(y_local.numpy().astype(np.float64), SR, stationary=True,
+                                   y_noise=noise.numpy(), chunk_size=CS, padding=PAD, n_fft=NFFT)
+            return torch.from_numpy(out)
+
+    c0, c1 = channel_bounds(y.shape[0], world, rank)
+    y_local = y[c0:c1].contiguous()
+    cs = ChannelShardedStationary(Backend())
+    out = cs.run(y_local)                      # the channel count rides in the all-reduce: no c_total needed
+    assert out.shape == (c1 - c0, y.shape[1])
+    err = float((out - want[c0:c1]).abs().max() / want.abs().max()) if c1 > c0 else 0.0
+    cs.check_channel_total(y.shape[0])
+    out2 = cs.run(y_local, c_total=y.shape[0])  # an explicit (correct) total gives the same result
+    same = bool(torch.equal(out, out2))
+    try:
+        cs.check_channel_total(y.shape[0] + 1)
+        wrong = "no error"
+    except ValueError:
+        wrong = "ValueError"
+    ret[rank] = (c1 - c0, err, same, wrong)
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("channels,world", [(5, 2), (3, 2), (2, 3), (7, 3)])
+def test_channel_sharded_uneven_channel_counts(channels, world):
+    """C not divisible by the world size: channels are dealt in contiguous runs, the first C % world
+    ranks hold one more, ranks beyond the channel count hold none and still take part in the all-reduce; the channel mean
+    of the noise clip is over the TRUE total (stationary.py:61-64)."""
+    from noisereduce_amd.sharded import channel_bounds
+    bounds = [channel_bounds(channels, world, r) for r in range(world)]
+    assert bounds[0][0] == 0 and bounds[-1][1] == channels and all(a[1] == b[0] for a, b in zip(bounds, bounds[1:]))
+    assert max(b - a for a, b in bounds) - min(b - a for a, b in bounds) <= 1
+    n = CS + 555
+    y = np.stack([O.synth_signal(n, seed=90 + c, tone_hz=170.0 * (c + 1)).astype(np.float64) for c in range(channels)])
+    want = O.reduce_noise_S(y, SR, stationary=True, chunk_size=CS, padding=PAD, n_fft=NFFT)
+    mgr = mp.Manager()
+    ret = mgr.dict()
+    mp.spawn(_worker_channels_uneven, args=(world, _free_port(), torch.from_numpy(y), torch.from_numpy(want), ret),
+             nprocs=world, join=True)
+    assert sum(ret[r][0] for r in range(world)) == channels
+    for r in range(world):
+        assert ret[r][1] < 1e-9 and ret[r][2] and ret[r][3] == "ValueError", dict(ret)
+
+
 def _free_port():
     s = socket.socket()
     s.bind(("127.0.0.1", 0))

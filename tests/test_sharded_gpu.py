@@ -98,3 +98,62 @@ def test_rccl_single_rank_collectives():
     res = subprocess.run([sys.executable, os.path.join(root, "tests", "tools", "nccl_single_rank.py")], env=env,
                          capture_output=True, text=True, timeout=300)
     assert res.returncode == 0 and "collectives ok" in res.stdout, res.stdout[-2000:] + res.stderr[-2000:]
+
+
+def _worker_deferred_failure(rank, world, port, y, ret):
+    dev = _init(rank, world, port)
+    from noisereduce_amd.sharded import HipStationaryBackend, TimeShardedStationary, alloc_shard, shard_bounds
+
+    class Failing(HipStationaryBackend):
+        def threshold(self, y_local):
+            raise RuntimeError("noise statistics failed on rank 0")
+    s0, s1 = shard_bounds(y.shape[1], CS, world, rank)
+    ext, shard = alloc_shard(1, s1 - s0, PAD, torch.float32, dev)
+    shard.copy_(y[:, s0:s1].float())
+    gate = TimeShardedStationary(Failing(SR, dev, chunk_size=CS, padding=PAD, n_fft=NFFT), NFFT // 2 + 1)
+    out = gate.run(shard, ext=ext, defer_check=True)      # deferred verdict: no rank raises in the failing call
+    gated = bool((out == 0).all() or torch.isnan(out).all())   # filtered with the NaN threshold: nothing passes
+    try:
+        gate.finish()
+        res = ("no error", None)
+    except ValueError as e:
+        res = ("ValueError", type(e.__cause__).__name__ if e.__cause__ is not None else None)
+    ret[rank] = (gated,) + res
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_deferred_statistics_failure_keeps_its_cause():
+    """with defer_check=True a failure of rank 0's noise statistics surfaces one call late on EVERY rank (a
+    ValueError from the gathered header) -- and on rank 0 the original exception is chained to it instead of being lost."""
+    y = torch.from_numpy(np.stack([O.synth_signal(4 * CS, seed=19).astype(np.float64)]))
+    ret = mp.Manager().dict()
+    mp.spawn(_worker_deferred_failure, args=(2, _free_port(), y, ret), nprocs=2, join=True)
+    assert ret[0][1:] == ("ValueError", "RuntimeError"), dict(ret)
+    assert ret[1][1:] == ("ValueError", None), dict(ret)
+    assert ret[0][0] and ret[1][0], dict(ret)
+
+
+def _worker_channels_uneven(rank, world, port, y, want, ret):
+    dev = _init(rank, world, port)
+    from noisereduce_amd.sharded import ChannelShardedStationary, HipStationaryBackend, channel_bounds
+    c0, c1 = channel_bounds(y.shape[0], world, rank)
+    y_local = y[c0:c1].to(torch.float32).to(dev)
+    cs = ChannelShardedStationary(HipStationaryBackend(SR, dev, chunk_size=CS, padding=PAD, n_fft=NFFT))
+    ev = []
+    out = cs.run(y_local, timing=ev)
+    cs.check_channel_total(y.shape[0])
+    ret[rank] = (float((out.double().cpu() - want[c0:c1]).abs().max() / want.abs().max()), len(ev))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_channel_sharded_hip_uneven_channels():
+    """3 channels on 2 ranks (2 + 1): the channel mean of the noise clip is over all 3 (the count rides in the all-reduce)."""
+    n = 2 * CS + 999
+    y = np.stack([O.synth_signal(n, seed=75 + c, tone_hz=210.0 * (c + 1)).astype(np.float64) for c in range(3)])
+    want = O.reduce_noise_S(y, SR, stationary=True, chunk_size=CS, padding=PAD, n_fft=NFFT)
+    ret = mp.Manager().dict()
+    mp.spawn(_worker_channels_uneven, args=(2, _free_port(), torch.from_numpy(y), torch.from_numpy(want), ret),
+             nprocs=2, join=True)
+    assert ret[0][0] < TOL and ret[1][0] < TOL and ret[0][1] == 1 and ret[1][1] == 1, dict(ret)
