@@ -35,6 +35,7 @@ SG_OPT_ROWGATE_TAP = 11
 SG_OPT_ROWGATE_SHAPE = 12
 SG_OPT_FLOOR_TEST = 13
 SG_OPT_TILE_ORDER = 15
+SG_OPT_EXACT_MATERIALISED = 16
 SG_OPT_FORCE_UNFUSED = 1
 SG_OPT_FORCE_NOFAST = 2
 

@@ -32,6 +32,7 @@
 #include "fast64.hpp"
 #include "big.hpp"
 #include "exact.hpp"
+#include "apply64.hpp"
 
 // complex transform length from which a whole 256-thread workgroup (instead of one wavefront) works on ONE frame in
 // the general LDS kernels: at N = 2048 (n_fft = 4096) a wavefront holds 4 radix-8 butterflies = 64 complex values per
@@ -98,6 +99,8 @@ struct sg_handle {
   unsigned epoch = 0;                // launch counter: the value a tile's flag must carry to be current
   bool fast_integer = false;         // SG_OPT_FAST_INTEGER: integer outputs from the float32 kernels (<= 1 LSB off)
   bool force_exact = false;          // SG_OPT_FORCE_EXACT: float64 pipeline (exact.hpp) whatever the output dtype
+  bool exact_materialised = false;   // SG_OPT_EXACT_MATERIALISED: the float64 pipeline always through exact.hpp's materialised fields
+  DevBuf norm64;                     // sum_q win^2[256 q + s] as doubles (default geometry: k_apply_fast64's window envelope)
   unsigned need_era = 0;             // epoch >> 30 of the last one-pass gate call (tagged floor-test flags, stage_onepass)
   DevBuf xP, xraw, xM, xtmp, xseg;   // fields of the exact path
   bool force_split = false;          // SG_OPT_FORCE_SPLIT: decide / smooth / apply as three kernels
@@ -980,8 +983,15 @@ extern "C" int sg_create(const sg_params* p, const double* window_host, sg_handl
       for (int q = 0; q < 4; ++q) acc += wfull[256 * q + s2] * wfull[256 * q + s2];
       invn[s2] = (float)(acc > 1e-10 ? 1.0 / acc : 1.0);
     }
+    std::vector<double> norm64(256);
+    for (int s2 = 0; s2 < 256; ++s2) {
+      double acc = 0.0;
+      for (int q = 0; q < 4; ++q) acc += wfull[256 * q + s2] * wfull[256 * q + s2];   // frames t-3 .. t in scipy's order
+      norm64[s2] = acc;
+    }
     rc = upload(h, h->tw512, t512.data(), t512.size() * sizeof(cx<float>));
     if (!rc) rc = upload(h, h->invn, invn.data(), invn.size() * sizeof(float));
+    if (!rc) rc = upload(h, h->norm64, norm64.data(), norm64.size() * sizeof(double));
     h->fast_ok = true;
   }
   if (!rc && n == 512 && W == 512 && h->H == 128) {
@@ -2088,6 +2098,70 @@ static int stage_onepass(sg_handle* h, const View& v, const View& vx, const Geom
   return SG_OK;
 }
 
+// float64 fused apply (apply64.hpp): K counts of stage_fused_mask -> output samples, everything in double
+template <int WAVES>
+static hipError_t launch_apply_fast64(fast::Apply64Args& A, int64_t nh, int64_t ub, hipStream_t st) {
+  constexpr int NH = 4 * WAVES - 3;
+  const size_t lds = (size_t)(fast::FN + WAVES * 4 * fast::FSLOTS_D + 17) * sizeof(fast::cd);
+  auto kern = fast::k_apply_fast64<WAVES>;
+  hipError_t e = set_lds(reinterpret_cast<const void*>(kern), lds);
+  if (e != hipSuccess) return e;
+  hipLaunchKernelGGL(kern, dim3((unsigned)((nh + NH - 1) / NH), (unsigned)ub), dim3(WAVES * 64), lds, st, A);
+  return hipGetLastError();
+}
+
+static int stage_apply_fast64(sg_handle* h, const View& v, const Geom& g, int64_t ub, const OutMap& om, hipStream_t st) {
+  ProfScope ps(h, SG_STAGE_APPLY_FAST, st);
+  fast::Apply64Args A;
+  A.view = v; A.g = g; A.om = om;
+  A.K = (const unsigned short*)h->K16.p;
+  A.win = (const double*)h->wfull64.p;
+  A.norm = (const double*)h->norm64.p;
+  A.tw1024 = (const fast::cd*)h->tw64.p;
+  A.kscale = 1.0 / ((double)h->ktot * 512.0);
+  A.h_begin = (om.p0 + g.padL) / 256;
+  A.h_end = (om.p1 - 1 + g.padL) / 256 + 1;
+  const int64_t nh = A.h_end - A.h_begin;
+  if (nh <= 0) return SG_OK;
+  // tiles overlap by three frames: 8 wavefronts (32 frames -> 29 hops, 10 % of the transforms redone) unless the rows are
+  // short; either way two wavefronts per SIMD (256 VGPRs) and one (8) or two (4) workgroups per CU
+  static const int waves_env = getenv("SG_APPLY64_WAVES") ? atoi(getenv("SG_APPLY64_WAVES")) : 0;
+  const bool wide = waves_env ? waves_env == 8 : nh >= 64;
+  if (wide) HIPCHK(h, launch_apply_fast64<8>(A, nh, ub, st));
+  else HIPCHK(h, launch_apply_fast64<4>(A, nh, ub, st));
+  return SG_OK;
+}
+
+// The stationary gate in float64 WITHOUT materialised float64 fields (default geometry, full reduction): the mask comes
+// from the fused bit path -- decisions bit-identical to float64 decisions (k_decide_fast: float32 transform + exact
+// refinement of ambiguous cells on the ORIGINAL samples), integer smoothing -- and k_apply_fast64 does the transforms,
+// the mask multiply and the overlap-add in double.  Integer outputs (trunc(float64 result), base.py:217-226) and
+// precision="float64" take it; everything else of the float64 contract stays on run_S_exact.
+static bool exact_fused_ok(const sg_handle* h, const Geom& g) {
+  return h->p.stationary && h->fused_ok && !h->force_unfused && h->fast_ok && !h->force_nofast && !h->force_f64_decide &&
+         h->p.prop_decrease == 1.0 && g.F == 513 && h->norm64.p != nullptr && !h->exact_materialised;
+}
+
+static int run_S_exact_fused(sg_handle* h, View v, int64_t total_units, const OutMap& om, hipStream_t st) {
+  const Geom g = make_geom(h, v.Lp);
+  int64_t ub = units_per_batch(h, g, total_units, true);
+  int rc = ensure_ws(h, g, ub, true);
+  if (rc) return rc;
+  // (other sample types than float32 are NOT converted to a float32 copy here: k_decide_fast stages (float)sample per tile
+  // anyway, and its exact refinement and the float64 apply must read the ORIGINAL samples -- an int32 or float64 sample
+  // has no exact float32 copy)
+  for (int64_t u0 = 0; u0 < total_units; u0 += ub) {
+    const int64_t nb = std::min(ub, total_units - u0);
+    v.unit0 = u0;
+    const int64_t hb = (om.p0 + g.padL) / 256, he = (om.p1 - 1 + g.padL) / 256 + 1;
+    const int64_t tb = std::max<int64_t>(0, hb - 3), te = std::min<int64_t>(g.T, he);
+    if ((rc = stage_fused_mask(h, v, g, nb, true, tb, std::max(te, tb + 1), st))) return rc;
+    if ((rc = stage_apply_fast64(h, v, g, nb, om, st))) return rc;
+    h->dbg_units = nb; h->dbg_T = g.T; h->dbg_has_P = false; h->dbg_fused = true; h->dbg_fast = true;
+  }
+  return SG_OK;
+}
+
 // ------------------------------------------------------------------------------------------
 // exact path (exact.hpp): float64 fields, materialised -- integer outputs (base.py:217-226 truncates a float64 result)
 // ------------------------------------------------------------------------------------------
@@ -2241,7 +2315,7 @@ static int run_S(sg_handle* h, View v, int64_t total_units, const OutMap& om, hi
     FAIL(h, SG_E_STATE, "stationary gate: call sg_noise_stats or sg_set_noise_threshold first");
   // integer outputs are the TRUNCATED float64 result of the reference (base.py:217-226): float64 pipeline
   if (h->force_exact || ((om.dtype == SG_I16 || om.dtype == SG_I32) && !h->fast_integer))
-    return run_S_exact(h, v, total_units, om, st);
+    return exact_fused_ok(h, g) ? run_S_exact_fused(h, v, total_units, om, st) : run_S_exact(h, v, total_units, om, st);
   // one-pass gate (any prop_decrease) or, with prop_decrease == 1, the three-kernel bit-mask path: only bit /
   // count fields in the workspace
   const bool onepass = h->fused_ok && !h->force_unfused && h->fast_ok && !h->force_nofast && onepass_ok(h, g, om);
@@ -2827,6 +2901,7 @@ extern "C" int sg_set_option(sg_handle* h, int32_t option, int64_t value) {
       return SG_OK;
     case SG_OPT_INJECT_HANDOFF_FAULT: h->inject_fault = (unsigned)value & 63u; return SG_OK;
     case SG_OPT_TILE_ORDER: h->tile_order = value != 0; return SG_OK;
+    case SG_OPT_EXACT_MATERIALISED: h->exact_materialised = value != 0; return SG_OK;
     case SG_OPT_FLOOR_TEST:
       if (value < 0 || value > 2) FAIL(h, SG_E_INVALID, "SG_OPT_FLOOR_TEST: 0 (predicted), 1 (a priori) or 2 (in the gate kernel)");
       h->floor_test = (int)value;
@@ -2851,6 +2926,7 @@ extern "C" int sg_get_option(const sg_handle* h, int32_t option, int64_t* value)
     case SG_OPT_ROWGATE_SHAPE: *value = h->rg_shape; return SG_OK;
     case SG_OPT_INJECT_HANDOFF_FAULT: *value = h->inject_fault; return SG_OK;
     case SG_OPT_TILE_ORDER: *value = h->tile_order; return SG_OK;
+    case SG_OPT_EXACT_MATERIALISED: *value = h->exact_materialised; return SG_OK;
     case SG_OPT_FLOOR_TEST: *value = h->floor_test; return SG_OK;
   }
   return SG_E_INVALID;   // (no message: the handle is const here)

@@ -111,3 +111,61 @@ def test_with_options_restores_non_zero_defaults(nr):
     assert g.get_option(_ffi.SG_OPT_ROWGATE_SHAPE) == 16 and g.get_option(_ffi.SG_OPT_FORCE_NOROWGATE) == 0
     with pytest.raises(ValueError):
         g.get_option(9999)
+
+
+@pytest.mark.parametrize("dtype", [np.int16, np.int32, np.float64])
+@pytest.mark.parametrize("kw", [
+    dict(),                                                   # one window
+    dict(chunk_size=30000, padding=3000),                     # chunk grid, last chunk partial
+    dict(chunk_size=25000, padding=4000, n_std_thresh_stationary=0.5, freq_mask_smooth_hz=1000, time_mask_smooth_ms=20),
+])
+def test_fused_float64_apply_equals_the_materialised_float64_pipeline(nr, kw, dtype):
+    """Round 5: the stationary gate's float64 pipeline at the default geometry is mask bits (exact on the fused path) +
+    k_apply_fast64 (transforms, mask multiply and overlap-add in double) instead of five float64 fields through HBM.  Same
+    numbers as the materialised pipeline (exact.hpp, SG_OPT_EXACT_MATERIALISED) to float64 rounding, and -- for integer
+    recordings -- the same truncated samples wherever the float64 value is not within 1e-9 of an integer."""
+    from noisereduce_amd import _ffi
+    from noisereduce_amd.spectralgate.stationary import SpectralGateStationary
+    n = 70000
+    scale = {np.int16: 20000, np.int32: 1.5e9, np.float64: 1.0}[dtype]
+    y = np.stack([O.synth_signal(n, seed=81 + c, tone_hz=700.0 * (c + 1)).astype(np.float64) * scale for c in range(2)])
+    y = (np.round(y) if dtype != np.float64 else y).astype(dtype)
+    base = dict(sr=48000, y_noise=None, prop_decrease=1.0, n_std_thresh_stationary=1.5, chunk_size=600000,
+                clip_noise_stationary=True, padding=30000, n_fft=1024, win_length=None, hop_length=None, time_constant_s=2.0,
+                freq_mask_smooth_hz=500, time_mask_smooth_ms=50, tmp_folder=None, use_tqdm=False, n_jobs=1)
+    base.update(kw)
+    sg = SpectralGateStationary(y=y, precision="float64", **base)
+    fused = sg.get_traces()
+    with sg._gate.with_options([(_ffi.SG_OPT_EXACT_MATERIALISED, 1)]):
+        mat = sg.get_traces()
+    assert fused.dtype == dtype and fused.shape == y.shape
+    okw = {k: base[k] for k in ("chunk_size", "padding", "n_std_thresh_stationary", "freq_mask_smooth_hz", "time_mask_smooth_ms")}
+    want64 = O.reduce_noise_S(y.astype(np.float64), 48000, stationary=True, **okw)
+    if dtype == np.float64:
+        peak = np.abs(want64).max()
+        assert np.abs(fused - mat).max() <= 1e-13 * peak
+        assert np.abs(fused - want64).max() <= 1e-12 * peak
+    else:
+        tol = 1e-9 if dtype == np.int16 else 1e-4
+        decided = np.abs(want64 - np.round(want64)) > tol
+        d = fused.astype(np.int64) - want64.astype(dtype).astype(np.int64)
+        assert np.abs(d).max() <= 1 and np.count_nonzero(d[decided]) == 0
+        dm = fused.astype(np.int64) - mat.astype(np.int64)
+        assert np.abs(dm).max() <= 1 and np.count_nonzero(dm[decided]) == 0
+
+
+def test_fused_float64_apply_sub_range(nr):
+    """get_traces(start_frame, end_frame) on the float64 path: only the requested samples, equal to the same slice of the
+    whole result (chunk grid anchored at start_frame like base.py:175-216)."""
+    from noisereduce_amd.spectralgate.stationary import SpectralGateStationary
+    y = np.round(O.synth_signal(120000, seed=5).astype(np.float64) * 15000).astype(np.int16)
+    kw = dict(sr=48000, y_noise=None, prop_decrease=1.0, n_std_thresh_stationary=1.5, chunk_size=20000,
+              clip_noise_stationary=True, padding=3000, n_fft=1024, win_length=None, hop_length=None, time_constant_s=2.0,
+              freq_mask_smooth_hz=500, time_mask_smooth_ms=50, tmp_folder=None, use_tqdm=False, n_jobs=1)
+    sg = SpectralGateStationary(y=y, **kw)
+    part = sg.get_traces(start_frame=20000, end_frame=95000)
+    want64 = O.reduce_noise_S(y.astype(np.float64), 48000, stationary=True, chunk_size=20000, padding=3000)[20000:95000]
+    assert part.shape == (75000,) and part.dtype == np.int16
+    decided = np.abs(want64 - np.round(want64)) > 1e-9
+    d = part.astype(np.int64) - want64.astype(np.int16).astype(np.int64)
+    assert np.abs(d).max() <= 1 and np.count_nonzero(d[decided]) == 0
