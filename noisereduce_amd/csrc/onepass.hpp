@@ -42,6 +42,9 @@ constexpr int OP_KP = 528;               // K row pitch (uint16 entries) of a wa
 constexpr int OP_TAB_WIN = 0, OP_TAB_WSQ = 4096, OP_TAB_INVN = 8192, OP_TAB_TW512 = 9216, OP_TAB_TW1024 = 13312,
               OP_TAB_WIN64 = 17408, OP_TAB_TW64 = 25600, OP_TAB_MCONST = 33792, OP_TAB_EXP8 = 35328, OP_TAB_BYTES = 37376;
 
+#ifndef OP_LATE_ARGS
+#define OP_LATE_ARGS 1   // 1: the epilogue re-reads its arguments from the kernel-argument segment (see "LATE ARGUMENTS" in the kernel)
+#endif
 #ifndef OP_TRACE
 #define OP_TRACE 0
 #endif
@@ -83,10 +86,26 @@ struct OnePassArgs {
 #endif
 };
 
-// exact float64 |X[f]|^2 of frame t (see k_decide_fast)
+// exact float64 |X[f]|^2 of frame t (see k_decide_fast).  A rare path (about one wave in fifty): with OP_LATE_ARGS its
+// arguments -- a dozen 64-bit values of the view -- are read from the kernel-argument segment HERE (scalar loads through an
+// opaque pointer) instead of staying live in scalar registers from the entry block to the decision stage.
+#if OP_LATE_ARGS
+#define OP_XARG(type, member) (*(const __attribute__((address_space(4))) type*)(kp4 + __builtin_offsetof(OnePassArgs, member)))
+#else
+#define OP_XARG(type, member) (P.member)
+#endif
 __device__ __forceinline__ double op_exact_power(const OnePassArgs& P, int64_t row, int64_t chunk, int64_t t, int f,
                                                  int lane) {
-  const int64_t s0 = t * P.A.g.H - P.A.g.padL;
+#if OP_LATE_ARGS
+  const __attribute__((address_space(4))) char* kp4 = (const __attribute__((address_space(4))) char*)__builtin_amdgcn_kernarg_segment_ptr();
+  asm volatile("" : "+s"(kp4));
+#endif
+  const int64_t s0 = t * OP_XARG(int32_t, A.g.H) - OP_XARG(int32_t, A.g.padL);
+  const int64_t v_cs = OP_XARG(int64_t, A.view.cs), v_pad = OP_XARG(int64_t, A.view.pad), v_Lp = OP_XARG(int64_t, A.view.Lp),
+                v_lo = OP_XARG(int64_t, A.view.lo), v_hi = OP_XARG(int64_t, A.view.hi), x_stride = OP_XARG(int64_t, stride_exact);
+  const void* const x_exact = (const void*)(uintptr_t)OP_XARG(unsigned long long, x_exact);
+  const int x_dtype = OP_XARG(int, dtype_exact);
+  const char* const tab = (const char*)(uintptr_t)OP_XARG(unsigned long long, tab);
   double re = 0.0, im = 0.0;
 #pragma unroll 4
   for (int i = 0; i < 16; ++i) {
@@ -94,14 +113,13 @@ __device__ __forceinline__ double op_exact_power(const OnePassArgs& P, int64_t r
     // the ORIGINAL samples: view_sample on A.view's geometry with the caller's pointer / dtype / stride
     double xs = 0.0;
     {
-      const View& V = P.A.view;
       const int64_t sp = s0 + m;
-      const int64_t gi = chunk * V.cs - V.pad + sp;
-      if (sp >= 0 && sp < V.Lp && gi >= V.lo && gi < V.hi) xs = load_sample(P.x_exact, P.dtype_exact, row * P.stride_exact + gi);
+      const int64_t gi = chunk * v_cs - v_pad + sp;
+      if (sp >= 0 && sp < v_Lp && gi >= v_lo && gi < v_hi) xs = load_sample(x_exact, x_dtype, row * x_stride + gi);
     }
-    const double xv = xs * reinterpret_cast<const double*>(P.tab + OP_TAB_WIN64)[m];
+    const double xv = xs * reinterpret_cast<const double*>(tab + OP_TAB_WIN64)[m];
     const int j = (f * m) & 1023;
-    cx<double> w = reinterpret_cast<const cx<double>*>(P.tab + OP_TAB_TW64)[j & 511];
+    cx<double> w = reinterpret_cast<const cx<double>*>(tab + OP_TAB_TW64)[j & 511];
     if (j >= 512) { w.x = -w.x; w.y = -w.y; }
     re += xv * w.x;
     im += xv * w.y;
@@ -160,7 +178,6 @@ __global__ __launch_bounds__(WAVES * 64, 3) void k_gate_onepass(OnePassArgs P) {
   const int tid = threadIdx.x;
   const int lane = tid & 63, wave = tid >> 6;
   const int g = lane >> 4, c = lane & 15;
-  const int nt = P.nt;
 #if OP_TRACE
   long long t_prev_ = clock64();
   unsigned* t_slot_ = nullptr;   // known once the ticket is
@@ -590,12 +607,36 @@ __global__ __launch_bounds__(WAVES * 64, 3) void k_gate_onepass(OnePassArgs P) {
 
   OP_STAMP(5);   // decide (+ refinement) + transpose
   // ---- publish this tile's bits; the spectra stay in v[] ---------------------------------------------
-  unsigned long long* xb_mine = P.xbits + ((size_t)u * ntt + (jt + 1)) * OP_TILE_WORDS;
+  // (LATE ARGUMENTS, see the epilogue: what the middle of the kernel needs -- exchange buffer, epoch, error word, tables,
+  // mask scale, smoothing width -- is read from the kernel-argument segment here, after the prologue's peak of live scalars)
+#if OP_LATE_ARGS
+  typedef const __attribute__((address_space(4))) char* op_kpm_t;
+  op_kpm_t kpm = (op_kpm_t)__builtin_amdgcn_kernarg_segment_ptr();
+  asm volatile("" : "+s"(kpm));
+#define OP_MARG(type, member) (*(const __attribute__((address_space(4))) type*)(kpm + __builtin_offsetof(OnePassArgs, member)))
+  const unsigned m_ticket = (unsigned)__builtin_amdgcn_readfirstlane((int)s_misc[0]);
+  const unsigned m_ntt = (unsigned)(OP_MARG(int, A.n_tiles) + 2);
+  const int64_t m_u = m_ticket / m_ntt;
+  const int m_jt = (int)(m_ticket % m_ntt) - 1;
+#else
+#define OP_MARG(type, member) (P.member)
+  const unsigned m_ntt = (unsigned)ntt;
+  const int64_t m_u = u;
+  const int m_jt = jt;
+#endif
+  unsigned long long* const m_xbits = (unsigned long long*)(uintptr_t)OP_MARG(unsigned long long, xbits);
+  const unsigned m_epoch = OP_MARG(unsigned, epoch);
+  unsigned* const m_err = (unsigned*)(uintptr_t)OP_MARG(unsigned long long, err);
+  const char* const m_tab = (const char*)(uintptr_t)OP_MARG(unsigned long long, tab);
+  const float m_kscale = OP_MARG(float, A.kscale);
+  const int m_nt = OP_MARG(int, nt);
+  [[maybe_unused]] const float m_inv_ktot = OP_MARG(float, inv_ktot), m_prop = OP_MARG(float, prop);
+  unsigned long long* xb_mine = m_xbits + ((size_t)m_u * m_ntt + (m_jt + 1)) * OP_TILE_WORDS;
   // data-tagged granules: every 8-byte store carries 32 mask bits and the launch epoch.  A consumer polls the
   // granules it needs until their tags are current: no separate flag, no drain of the stores, one write-through
   // and one read on the critical path instead of two of each.
   if (c < OP_XW) {
-    const op_v4u gr = {(unsigned)myword, P.epoch, (unsigned)(myword >> 32), P.epoch};
+    const op_v4u gr = {(unsigned)myword, m_epoch, (unsigned)(myword >> 32), m_epoch};
     op_st16_sc1(&xb_mine[((4 * wave + g) * OP_XW + c) * 2], gr);
   }
   __syncthreads();   // every wave is past its forward exchange: the slices are idle from here
@@ -606,12 +647,12 @@ __global__ __launch_bounds__(WAVES * 64, 3) void k_gate_onepass(OnePassArgs P) {
   // The separable triangle filter is two small dense contractions per 16-bin block:
   //   H[row][bin]  = sum_k  bit[row][16 b - 8 + k] * vf[k - 8 - j]        (A = 16 rows x 32 bins of 0/1 bytes,
   //                                                                          B = 32 x 16 band matrix, constant)
-  //   K[frame][bin] = sum_row vt[row - frame - nt] * H[row][bin]           (A = 16 frames x 32 row slots, constant,
+  //   K[frame][bin] = sum_row vt[row - frame - m_nt] * H[row][bin]           (A = 16 frames x 32 row slots, constant,
   //                                                                          B = H as bytes: H <= (nf+1)^2 <= 81)
   // The first product's result layout (lane = bin column, 4 consecutive rows per lane group) IS the second
   // product's B layout once its k slots are numbered accordingly, so H never leaves the registers.  Row block 0
   // = the tile's OWN 16 rows: its H is computed before the neighbours' flags are polled (the hand-off latency
-  // hides behind it); row blocks 1, 2 = the 2 nt neighbour rows.
+  // hides behind it); row blocks 1, 2 = the 2 m_nt neighbour rows.
   constexpr int WP = OP_XW + 2;        // one zero word on each side of every bit row
   constexpr int WPB = WP * 8;          // bytes per row
   constexpr int SLICE_B = WAVE_CX_H * 8;
@@ -619,24 +660,24 @@ __global__ __launch_bounds__(WAVES * 64, 3) void k_gate_onepass(OnePassArgs P) {
   unsigned long long* wb = reinterpret_cast<unsigned long long*>(rbytes + 4 * OP_KP * 2);  // tail of slice 0: 48 rows
   static_assert(4 * OP_KP * 2 + 48 * WPB <= SLICE_B, "bit rows must fit behind wave 0's K rows");
   const unsigned char* wbb = reinterpret_cast<const unsigned char*>(wb);
-  if (c < OP_XW) wb[(nt + 4 * wave + g) * WP + 1 + c] = myword;
+  if (c < OP_XW) wb[(m_nt + 4 * wave + g) * WP + 1 + c] = myword;
   for (int r = tid; r < 48; r += WAVES * 64) {
     wb[r * WP] = 0ull;
     wb[r * WP + WP - 1] = 0ull;
   }
   const int q4 = lane >> 4, j16 = lane & 15;
-  const long Bf = (long)reinterpret_cast<const unsigned long long*>(P.tab + OP_TAB_MCONST)[lane], At1 = (long)reinterpret_cast<const unsigned long long*>(P.tab + OP_TAB_MCONST)[64 + lane], At2 = (long)reinterpret_cast<const unsigned long long*>(P.tab + OP_TAB_MCONST)[128 + lane];
-  const bool three = 2 * nt > 16;      // a third row block (wave-uniform)
-  // neighbour-list index m -> tile row: m < nt: row m (previous tile), else row nt + 16 + (m - nt) (next tile)
+  const long Bf = (long)reinterpret_cast<const unsigned long long*>(m_tab + OP_TAB_MCONST)[lane], At1 = (long)reinterpret_cast<const unsigned long long*>(m_tab + OP_TAB_MCONST)[64 + lane], At2 = (long)reinterpret_cast<const unsigned long long*>(m_tab + OP_TAB_MCONST)[128 + lane];
+  const bool three = 2 * m_nt > 16;      // a third row block (wave-uniform)
+  // neighbour-list index m -> tile row: m < m_nt: row m (previous tile), else row m_nt + 16 + (m - m_nt) (next tile)
   const int m1 = j16, m2 = 16 + j16;
-  const int r1 = m1 < 2 * nt ? (m1 < nt ? m1 : 16 + m1) : 0;
-  const int r2 = m2 < 2 * nt ? (m2 < nt ? m2 : 16 + m2) : 0;
+  const int r1 = m1 < 2 * m_nt ? (m1 < m_nt ? m1 : 16 + m1) : 0;
+  const int r2 = m2 < 2 * m_nt ? (m2 < m_nt ? m2 : 16 + m2) : 0;
   __syncthreads();
   typedef int op_v4i __attribute__((ext_vector_type(4)));
   const op_v4i zero4 = {0, 0, 0, 0};
   unsigned hown[9];   // H of the own rows, 4 bytes per 16-bin block
   {
-    const unsigned char* rp = wbb + (nt + j16) * WPB + 7 + q4;
+    const unsigned char* rp = wbb + (m_nt + j16) * WPB + 7 + q4;
 #pragma unroll
     for (int nb = 0; nb < 9; ++nb) {
       const int b = wave + 4 * nb;
@@ -649,25 +690,25 @@ __global__ __launch_bounds__(WAVES * 64, 3) void k_gate_onepass(OnePassArgs P) {
     }
   }
   OP_STAMP(7);   // zero fill + barrier + own rows on the matrix cores
-  // neighbour rows: one 16-byte load per 64-bit word (2 nt x 9 words <= 288: at most two per thread), polled
+  // neighbour rows: one 16-byte load per 64-bit word (2 m_nt x 9 words <= 288: at most two per thread), polled
   // until both tags are current
-  for (int i = tid; i < 2 * nt * OP_XW; i += WAVES * 64) {
-    const int side = i >= nt * OP_XW;
-    const int rem = i - side * nt * OP_XW;
+  for (int i = tid; i < 2 * m_nt * OP_XW; i += WAVES * 64) {
+    const int side = i >= m_nt * OP_XW;
+    const int rem = i - side * m_nt * OP_XW;
     const int rr = rem / OP_XW, w = rem - rr * OP_XW;
     const unsigned long long* src = side ? xb_mine + OP_TILE_WORDS + (rr * OP_XW + w) * 2
-                                         : xb_mine - OP_TILE_WORDS + ((NF - nt + rr) * OP_XW + w) * 2;
+                                         : xb_mine - OP_TILE_WORDS + ((NF - m_nt + rr) * OP_XW + w) * 2;
     op_v4u gr = op_ld16_sc1(src);
-    for (int spin = 0; !(OP_ABLATE & 2) && (LOSE || gr[1] != P.epoch || gr[3] != P.epoch); ++spin) {
+    for (int spin = 0; !(OP_ABLATE & 2) && (LOSE || gr[1] != m_epoch || gr[3] != m_epoch); ++spin) {
       if (LOSE || spin >= OP_SPIN_MAX) {   // every spin is bounded: report instead of hanging the device
-        atomicOr_system(P.err, 1u);
+        atomicOr_system(m_err, 1u);
         s_misc[1] = 1u;            // the tile's mask is unknown: every hop it finalises or hands on becomes NaN
         break;
       }
       __builtin_amdgcn_s_sleep(1);
       gr = op_ld16_sc1(src);
     }
-    wb[(side ? nt + NF + rr : rr) * WP + 1 + w] = (unsigned long long)gr[0] | ((unsigned long long)gr[2] << 32);
+    wb[(side ? m_nt + NF + rr : rr) * WP + 1 + w] = (unsigned long long)gr[0] | ((unsigned long long)gr[2] << 32);
   }
   __syncthreads();
   OP_STAMP(8);   // neighbours' bits (poll) + barrier
@@ -710,17 +751,17 @@ __global__ __launch_bounds__(WAVES * 64, 3) void k_gate_onepass(OnePassArgs P) {
   // PROP: weight of the valid taps along t for this lane group's frame (closed form of the triangle's tails)
   float tt = 0.f;
   if constexpr (PROP) {
-    const int64_t tl_ = t < nt ? nt - t : 0, tr_ = (G.T - 1 - t) < nt ? nt - (G.T - 1 - t) : 0;
-    tt = (float)((int64_t)(nt + 1) * (nt + 1) - tl_ * (tl_ + 1) / 2 - tr_ * (tr_ + 1) / 2);
+    const int64_t tl_ = t < m_nt ? m_nt - t : 0, tr_ = (G.T - 1 - t) < m_nt ? m_nt - (G.T - 1 - t) : 0;
+    tt = (float)((int64_t)(m_nt + 1) * (m_nt + 1) - tl_ * (tl_ + 1) / 2 - tr_ * (tr_ + 1) / 2);
   }
   const unsigned char* e_lo = s_ef + (c == 0 ? 0 : c);
   const unsigned char* e_hi = s_ef + (c == 0 ? 0 : 32 - c);
   // the float mask exactly as k_k16_to_mask writes it: p * (K / ktot) + (1 - p) * edge, edge = tf * tt / ktot
   auto mfull = [&](unsigned short kv, float tf) -> float {
-    const float edge = tf * tt * P.inv_ktot;
-    return P.prop * ((float)kv * P.inv_ktot) + (1.0f - P.prop) * edge;
+    const float edge = tf * tt * m_inv_ktot;
+    return m_prop * ((float)kv * m_inv_ktot) + (1.0f - m_prop) * edge;
   };
-  const float k512 = PROP ? mfull(krow[512], (float)s_ef[512]) * A.kscale : (float)krow[512] * A.kscale;
+  const float k512 = PROP ? mfull(krow[512], (float)s_ef[512]) * m_kscale : (float)krow[512] * m_kscale;
   auto mval = [&](int q, float scale) -> float {
     const int b0 = bin_of_entry(0, q);                         // lane 0 (compile-time)
     const unsigned short* pl = q < 16 ? k_lo : k_hi;
@@ -735,17 +776,17 @@ __global__ __launch_bounds__(WAVES * 64, 3) void k_gate_onepass(OnePassArgs P) {
   {
     // mask -> merge (the second half of pair_mask): Yk = X2[k] mk, Yn = conj-pair value x mn, then back to the
     // half-size complex spectrum.  The four 1/2 factors of split and merge ride in the mask scale.
-    const float ks = A.kscale * 0.25f;
+    const float ks = m_kscale * 0.25f;
 #if OP_INPLACE
     {
       // slot 0: lanes >= 1 merge the pair (v[0], v[31]); lane 0: bins 0 / 512 from v[0], bin 256 = v[31] scaled
       const cf r0 = v[0], r31 = v[31];
       cf xa = r0, xb = r31;
       merge_pair(xa, xb, wlo, mval(0, ks), mval(31, ks));
-      const float y0 = (r0.x + r0.y) * mval(0, A.kscale);
+      const float y0 = (r0.x + r0.y) * mval(0, m_kscale);
       const float yN = (r0.x - r0.y) * k512;
       const cf z0 = {0.5f * (y0 + yN), 0.5f * (y0 - yN)};
-      const float m8 = mval(31, A.kscale);  // entry 31 of lane 0 = bin 256
+      const float m8 = mval(31, m_kscale);  // entry 31 of lane 0 = bin 256
       const cf z8 = {r31.x * m8, r31.y * m8};
       v[0] = {l0 ? z0.x : xa.x, l0 ? z0.y : xa.y};
       v[31] = {l0 ? z8.x : xb.x, l0 ? z8.y : xb.y};
@@ -763,10 +804,10 @@ __global__ __launch_bounds__(WAVES * 64, 3) void k_gate_onepass(OnePassArgs P) {
     merge(pa[0], pb[0], wlo, mval(0, ks), mval(31, ks));
     cf z0, z8;
     {
-      const float y0 = (raw0.x + raw0.y) * mval(0, A.kscale);
+      const float y0 = (raw0.x + raw0.y) * mval(0, m_kscale);
       const float yN = (raw0.x - raw0.y) * k512;
       z0 = {0.5f * (y0 + yN), 0.5f * (y0 - yN)};
-      const float m8 = mval(31, A.kscale);  // entry 31 of lane 0 = bin 256
+      const float m8 = mval(31, m_kscale);  // entry 31 of lane 0 = bin 256
       z8 = {raw8.x * m8, raw8.y * m8};
     }
 #pragma unroll
@@ -819,7 +860,7 @@ __global__ __launch_bounds__(WAVES * 64, 3) void k_gate_onepass(OnePassArgs P) {
       wave_lds_sync();
     }
   }
-  const float4 n4 = *reinterpret_cast<const float4*>(&reinterpret_cast<const float*>(P.tab + OP_TAB_INVN)[(tid & 63) * 4]);
+  const float4 n4 = *reinterpret_cast<const float4*>(&reinterpret_cast<const float*>(m_tab + OP_TAB_INVN)[(tid & 63) * 4]);
   __syncthreads();
   OP_STAMP(12);  // window + wave-private overlap-add + barrier
 #if OP_TRACE
@@ -827,6 +868,47 @@ __global__ __launch_bounds__(WAVES * 64, 3) void k_gate_onepass(OnePassArgs P) {
 #endif
 
   // ---- cross-wave combine, normalise, store (seam mode: abutting tiles) -------------------------------
+  // LATE ARGUMENTS (round 5).  The output map, hop range, seam buffer and the tile's coordinates are only needed from here
+  // on, but as ordinary kernel arguments they are loaded in the entry block and stay live through every phase: the
+  // kernel ran out of scalar registers and parked them in VGPR lanes (v_writelane / 329 v_readlane -- each a 4-cycle slot
+  // of the vector pipe, the kernel's binding resource: profiles/r05_valu_classes.txt).  Here they are read again from the
+  // kernel-argument segment through an OPAQUE pointer (scalar loads, off the vector pipe; not mergeable with the entry
+  // block's loads), and the tile's coordinates are recomputed from the ticket, which is still in LDS.
+#if OP_LATE_ARGS
+  typedef const __attribute__((address_space(4))) char* op_kp_t;
+  op_kp_t kp4 = (op_kp_t)__builtin_amdgcn_kernarg_segment_ptr();
+  asm volatile("" : "+s"(kp4));
+#define OP_KARG(type, member) (*(const __attribute__((address_space(4))) type*)(kp4 + __builtin_offsetof(OnePassArgs, member)))
+#define OP_KPTR(type, member) ((type)(uintptr_t)OP_KARG(unsigned long long, member))
+#else
+#define OP_KARG(type, member) (P.member)
+#define OP_KPTR(type, member) ((type)P.member)
+#endif
+  const int64_t e_gstep = OP_KARG(int64_t, A.om.g_step), e_p0 = OP_KARG(int64_t, A.om.p0), e_p1 = OP_KARG(int64_t, A.om.p1);
+  void* const e_out = OP_KPTR(void*, A.om.out);
+  const int64_t e_ostride = OP_KARG(int64_t, A.om.stride), e_g0 = OP_KARG(int64_t, A.om.g0), e_glo = OP_KARG(int64_t, A.om.g_lo),
+                e_ghi = OP_KARG(int64_t, A.om.g_hi);
+  const int e_odtype = OP_KARG(int, A.om.dtype), e_normalize = OP_KARG(int, A.normalize), e_ntiles = OP_KARG(int, A.n_tiles);
+  const int64_t e_hbegin = OP_KARG(int64_t, A.h_begin), e_hend = OP_KARG(int64_t, A.h_end);
+  unsigned long long* const e_part2 = OP_KPTR(unsigned long long*, part2);
+  const unsigned e_epoch = OP_KARG(unsigned, epoch);
+  unsigned* const e_err = OP_KPTR(unsigned*, err);
+  const char* const e_tab = OP_KPTR(const char*, tab);
+  const int e_padL = OP_KARG(int32_t, A.g.padL);
+  const int64_t e_T = OP_KARG(int64_t, A.g.T), e_Lout = OP_KARG(int64_t, A.g.Lout);
+#if OP_LATE_ARGS
+  const unsigned e_ticket = (unsigned)__builtin_amdgcn_readfirstlane((int)s_misc[0]);
+  const unsigned e_ntt = (unsigned)(e_ntiles + 2);
+  const int64_t e_u = e_ticket / e_ntt;
+  const int e_jt = (int)(e_ticket % e_ntt) - 1;
+  const unsigned e_gu = (unsigned)(OP_KARG(int64_t, A.view.unit0) + e_u), e_nch = (unsigned)OP_KARG(int32_t, A.view.n_chunks);
+  const int64_t e_row = e_gu / e_nch;
+  const int64_t e_chunk = OP_KARG(int64_t, A.view.c0) + e_gu % e_nch;
+  const int64_t e_tf = e_hbegin - 3 + (int64_t)e_jt * NF;
+#else
+  const int64_t e_u = u, e_row = row, e_chunk = chunk, e_tf = tf_tile;
+  const int e_jt = jt;
+#endif
   const float* fr = reinterpret_cast<const float*>(regions);
   const int s4 = (tid & 63) * 4;
   // A lost hand-off must not look like audio: a tile whose neighbour bits never arrived writes NaN to every hop it
@@ -840,14 +922,14 @@ __global__ __launch_bounds__(WAVES * 64, 3) void k_gate_onepass(OnePassArgs P) {
   // Interior tiles (every hop inside the output range, all four frames of each hop present, float32 output,
   // aligned rows): straight-line version of the loop below, same sums in the same order.
   {
-    const int64_t pb0 = tf_tile * 256 - G.padL;
-    const int64_t gi00 = chunk * A.om.g_step + (pb0 - A.om.p0);
-    float* dbase = (float*)A.om.out + (row * A.om.stride + gi00 - A.om.g0);
+    const int64_t pb0 = e_tf * 256 - e_padL;
+    const int64_t gi00 = e_chunk * e_gstep + (pb0 - e_p0);
+    float* dbase = (float*)e_out + (e_row * e_ostride + gi00 - e_g0);
     float* dst0 = dbase + s4;
-    const bool tile_fast = A.om.dtype == 0 && A.normalize && tf_tile >= 3 && tf_tile + NF + 2 < G.T &&
-                           tf_tile >= A.h_begin && tf_tile + NF + 2 < A.h_end && pb0 >= A.om.p0 &&
-                           pb0 + NF * 256 <= A.om.p1 && pb0 + NF * 256 <= G.Lout && gi00 >= A.om.g_lo &&
-                           gi00 + NF * 256 <= A.om.g_hi && (reinterpret_cast<uintptr_t>(dbase) & 15) == 0 && WAVES == 4;
+    const bool tile_fast = e_odtype == 0 && e_normalize && e_tf >= 3 && e_tf + NF + 2 < e_T &&
+                           e_tf >= e_hbegin && e_tf + NF + 2 < e_hend && pb0 >= e_p0 &&
+                           pb0 + NF * 256 <= e_p1 && pb0 + NF * 256 <= e_Lout && gi00 >= e_glo &&
+                           gi00 + NF * 256 <= e_ghi && (reinterpret_cast<uintptr_t>(dbase) & 15) == 0 && WAVES == 4;
     if (tile_fast) {
       constexpr int R = WAVE_CX_H * 2;
       auto ld4 = [&](int off) { return *reinterpret_cast<const float4*>(&fr[off + s4]); };
@@ -863,9 +945,9 @@ __global__ __launch_bounds__(WAVES * 64, 3) void k_gate_onepass(OnePassArgs P) {
       }
       {
         const float4 a4 = ld4((WAVES - 1) * R + (wave + 4) * HPITCH);
-        unsigned long long* dst = P.part2 + (((size_t)u * A.n_tiles + jt) * 3 + wave) * 256 + s4;
-        const op_v4u ga = {__float_as_uint(a4.x + poison), P.epoch, __float_as_uint(a4.y + poison), P.epoch};
-        const op_v4u gb = {__float_as_uint(a4.z + poison), P.epoch, __float_as_uint(a4.w + poison), P.epoch};
+        unsigned long long* dst = e_part2 + (((size_t)e_u * e_ntiles + e_jt) * 3 + wave) * 256 + s4;
+        const op_v4u ga = {__float_as_uint(a4.x + poison), e_epoch, __float_as_uint(a4.y + poison), e_epoch};
+        const op_v4u gb = {__float_as_uint(a4.z + poison), e_epoch, __float_as_uint(a4.w + poison), e_epoch};
         op_st16_sc1(dst, ga);
         op_st16_sc1(dst + 2, gb);
       }
@@ -878,15 +960,15 @@ __global__ __launch_bounds__(WAVES * 64, 3) void k_gate_onepass(OnePassArgs P) {
       }
       {
         float4 a4 = ld4(wave * HPITCH);
-        const unsigned long long* src = P.part2 + (((size_t)u * A.n_tiles + jt - 1) * 3 + wave) * 256 + s4;
+        const unsigned long long* src = e_part2 + (((size_t)e_u * e_ntiles + e_jt - 1) * 3 + wave) * 256 + s4;
         op_v4u ga, gb;
         for (int spin = 0;; ++spin) {
           asm volatile("global_load_dwordx4 %0, %2, off sc1\n\tglobal_load_dwordx4 %1, %2, off offset:16 sc1\n\ts_waitcnt vmcnt(0)"
                        : "=&v"(ga), "=&v"(gb) : "v"(src) : "memory");
-          const unsigned e = P.epoch;
+          const unsigned e = e_epoch;
           if ((OP_ABLATE & 16) || (!LOSE && ga[1] == e && ga[3] == e && gb[1] == e && gb[3] == e)) break;
           if (LOSE || spin >= OP_SPIN_MAX) {
-            atomicOr_system(P.err, 2u);
+            atomicOr_system(e_err, 2u);
             ga[0] = ga[2] = gb[0] = gb[2] = 0x7fc00000u;   // the previous tile's share is unknown: NaN, not a partial sum
             break;
           }
@@ -905,14 +987,14 @@ __global__ __launch_bounds__(WAVES * 64, 3) void k_gate_onepass(OnePassArgs P) {
   for (int it = 0; it < 5; ++it) {
     const int jj = wave < 3 ? (it == 0 ? NF + wave : (it == 4 ? wave : wave + 4 * it)) : (it < 4 ? 3 + 4 * it : -1);
     if (jj < 0) break;
-    const int64_t h = tf_tile + jj;
-    if (h >= A.h_end || h < A.h_begin) continue;
+    const int64_t h = e_tf + jj;
+    if (h >= e_hend || h < e_hbegin) continue;
     float4 a4 = make_float4(0.f, 0.f, 0.f, 0.f);
     bool all_valid = true;
 #pragma unroll
     for (int q = 0; q < 4; ++q) {
-      const int64_t ti = tf_tile + jj - q;
-      if (ti < 0 || ti >= G.T) all_valid = false;
+      const int64_t ti = e_tf + jj - q;
+      if (ti < 0 || ti >= e_T) all_valid = false;
     }
     {
       const int wh = jj >> 2, lh = jj & 3;
@@ -927,24 +1009,24 @@ __global__ __launch_bounds__(WAVES * 64, 3) void k_gate_onepass(OnePassArgs P) {
     if (jj >= NF) {
       // trailing partial hop -> tagged granules {float, epoch}
       const int k = jj - NF;
-      unsigned long long* dst = P.part2 + (((size_t)u * A.n_tiles + jt) * 3 + k) * 256 + s4;
-      const op_v4u ga = {__float_as_uint(a4.x + poison), P.epoch, __float_as_uint(a4.y + poison), P.epoch};
-      const op_v4u gb = {__float_as_uint(a4.z + poison), P.epoch, __float_as_uint(a4.w + poison), P.epoch};
+      unsigned long long* dst = e_part2 + (((size_t)e_u * e_ntiles + e_jt) * 3 + k) * 256 + s4;
+      const op_v4u ga = {__float_as_uint(a4.x + poison), e_epoch, __float_as_uint(a4.y + poison), e_epoch};
+      const op_v4u gb = {__float_as_uint(a4.z + poison), e_epoch, __float_as_uint(a4.w + poison), e_epoch};
       op_st16_sc1(dst, ga);
       op_st16_sc1(dst + 2, gb);
       continue;
     }
     if (jj < 3) {
-      // h >= h_begin implies jt >= 1: the previous tile exists
-      const unsigned long long* src = P.part2 + (((size_t)u * A.n_tiles + jt - 1) * 3 + jj) * 256 + s4;
+      // h >= h_begin implies e_jt >= 1: the previous tile exists
+      const unsigned long long* src = e_part2 + (((size_t)e_u * e_ntiles + e_jt - 1) * 3 + jj) * 256 + s4;
       op_v4u ga, gb;
       for (int spin = 0;; ++spin) {
         asm volatile("global_load_dwordx4 %0, %2, off sc1\n\tglobal_load_dwordx4 %1, %2, off offset:16 sc1\n\ts_waitcnt vmcnt(0)"
                      : "=&v"(ga), "=&v"(gb) : "v"(src) : "memory");
-        const unsigned e = P.epoch;
+        const unsigned e = e_epoch;
         if ((OP_ABLATE & 16) || (!LOSE && ga[1] == e && ga[3] == e && gb[1] == e && gb[3] == e)) break;
         if (LOSE || spin >= OP_SPIN_MAX) {
-          atomicOr_system(P.err, 2u);
+          atomicOr_system(e_err, 2u);
           ga[0] = ga[2] = gb[0] = gb[2] = 0x7fc00000u;
           break;
         }
@@ -957,7 +1039,7 @@ __global__ __launch_bounds__(WAVES * 64, 3) void k_gate_onepass(OnePassArgs P) {
       a4.w = __uint_as_float(gb[2]) + a4.w;
     }
     a4.x += poison; a4.y += poison; a4.z += poison; a4.w += poison;
-    if (!A.normalize) {
+    if (!e_normalize) {
     } else if (all_valid) {
       a4.x *= n4.x; a4.y *= n4.y; a4.z *= n4.z; a4.w *= n4.w;
     } else {
@@ -965,8 +1047,8 @@ __global__ __launch_bounds__(WAVES * 64, 3) void k_gate_onepass(OnePassArgs P) {
 #pragma unroll
       for (int q = 0; q < 4; ++q) {
         const int64_t ti = h - q;
-        if (ti >= 0 && ti < G.T) {
-          const float4 w4 = *reinterpret_cast<const float4*>(&reinterpret_cast<const float*>(P.tab + OP_TAB_WSQ)[256 * q + s4]);
+        if (ti >= 0 && ti < e_T) {
+          const float4 w4 = *reinterpret_cast<const float4*>(&reinterpret_cast<const float*>(e_tab + OP_TAB_WSQ)[256 * q + s4]);
           nrm.x += w4.x; nrm.y += w4.y; nrm.z += w4.z; nrm.w += w4.w;
         }
       }
@@ -976,11 +1058,11 @@ __global__ __launch_bounds__(WAVES * 64, 3) void k_gate_onepass(OnePassArgs P) {
       a4.w /= (nrm.w > 1e-10f ? nrm.w : 1.f);
     }
     {
-      const int64_t pb = h * 256 - G.padL;
-      const int64_t gi0 = chunk * A.om.g_step + (pb - A.om.p0);
-      if (A.om.dtype == 0 && pb >= A.om.p0 && pb + 256 <= A.om.p1 && pb + 256 <= G.Lout && gi0 >= A.om.g_lo &&
-          gi0 + 256 <= A.om.g_hi) {
-        float* dst = (float*)A.om.out + (row * A.om.stride + gi0 - A.om.g0 + s4);
+      const int64_t pb = h * 256 - e_padL;
+      const int64_t gi0 = e_chunk * e_gstep + (pb - e_p0);
+      if (e_odtype == 0 && pb >= e_p0 && pb + 256 <= e_p1 && pb + 256 <= e_Lout && gi0 >= e_glo &&
+          gi0 + 256 <= e_ghi) {
+        float* dst = (float*)e_out + (e_row * e_ostride + gi0 - e_g0 + s4);
         if ((reinterpret_cast<uintptr_t>(dst) & 15) == 0) {
           *reinterpret_cast<float4*>(dst) = a4;
           continue;
@@ -990,11 +1072,11 @@ __global__ __launch_bounds__(WAVES * 64, 3) void k_gate_onepass(OnePassArgs P) {
     const float vals[4] = {a4.x, a4.y, a4.z, a4.w};
 #pragma unroll
     for (int e = 0; e < 4; ++e) {
-      const int64_t p = h * 256 + s4 + e - G.padL;
-      if (p < A.om.p0 || p >= A.om.p1) continue;
-      const int64_t gi = chunk * A.om.g_step + (p - A.om.p0);
-      if (gi < A.om.g_lo || gi >= A.om.g_hi) continue;
-      store_sample(A.om.out, A.om.dtype, row * A.om.stride + gi - A.om.g0, p < G.Lout ? vals[e] : 0.f);
+      const int64_t p = h * 256 + s4 + e - e_padL;
+      if (p < e_p0 || p >= e_p1) continue;
+      const int64_t gi = e_chunk * e_gstep + (p - e_p0);
+      if (gi < e_glo || gi >= e_ghi) continue;
+      store_sample(e_out, e_odtype, e_row * e_ostride + gi - e_g0, p < e_Lout ? vals[e] : 0.f);
     }
   }
 }
