@@ -26,6 +26,7 @@
 #include "czt.hpp"
 #include "onepass.hpp"
 #include "rowgate.hpp"
+#include "rowbwd.hpp"
 #include "fast512.hpp"
 #include "fast2048.hpp"
 #include "nonstat.hpp"
@@ -2829,8 +2830,37 @@ extern "C" int sg_process_batch_backward(sg_handle* h, const void* grad_out_dev,
   hipStream_t st = (hipStream_t)stream;
   Geom g = make_geom(h, L);
   const int64_t Lq = g.Lout;
+  int rc;
+  if (h->fast_ok && !h->force_nofast && h->rowgate_mode != 1 && g.F == 513 && g.T >= 1 && g.T <= fast::RG_FRAMES) {
+    // rows of at most 64 frames: the whole backward of a row in one workgroup (rowbwd.hpp) -- no grad_out / envelope copy,
+    // no tiles, no hand-offs
+    ProfScope ps(h, SG_STAGE_APPLY_FAST, st);
+    fast::RowBwdArgs A;
+    View v{};
+    v.x = grad_out_dev; v.dtype = dtype; v.stride = go_stride; v.N = Lq; v.lo = 0; v.hi = Lq; v.cs = 0; v.pad = 0; v.Lp = Lq;
+    v.n_chunks = 1; v.unit0 = 0;
+    A.view = v;
+    A.g = g;
+    A.g.Lout = L;   // the adjoint scatters back onto all L input samples
+    OutMap om{};
+    om.out = grad_x_dev; om.dtype = dtype; om.stride = gx_stride;
+    om.p0 = 0; om.p1 = L; om.g_step = 0; om.g0 = 0; om.g_lo = 0; om.g_hi = L;
+    A.om = om;
+    A.win = (const float*)h->wa32.p;
+    A.wsq = (const float*)h->wsq32.p;
+    A.invn = (const float*)h->invn.p;
+    A.tw512 = (const fast::cf*)h->tw512.p;
+    A.tw1024 = (const fast::cf*)h->tw32.p;
+    A.mask = mask_dev;
+    A.kscale = (float)(1.0 / 512.0);
+    const size_t lds = fast::rowbwd_lds_bytes();
+    HIPCHK(h, set_lds(reinterpret_cast<const void*>(fast::k_row_backward), lds));
+    hipLaunchKernelGGL(fast::k_row_backward, dim3((unsigned)B), dim3(1024), lds, st, A);
+    HIPCHK(h, hipGetLastError());
+    return SG_OK;
+  }
   int64_t ub = units_per_batch(h, g, B);
-  int rc = ensure_ws(h, g, ub);
+  rc = ensure_ws(h, g, ub);
   if (rc) return rc;
   if ((rc = ensure(h, h->yn, (size_t)ub * Lq * sizeof(float)))) return rc;
   for (int64_t u0 = 0; u0 < B; u0 += ub) {

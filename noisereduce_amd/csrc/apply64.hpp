@@ -291,7 +291,6 @@ __global__ __launch_bounds__(WAVES * 64, 2) void k_apply_fast64(Apply64Args A) {
     const double2* wsrc = reinterpret_cast<const double2*>(A.win + 2 * c);
 #pragma unroll
     for (int j = 0; j < 4; ++j) {
-      const bool first = (j == 0) || (g == 3);
 #pragma unroll
       for (int rr = 0; rr < 8; ++rr) {
         const int r = 8 * j + rr;
@@ -299,10 +298,10 @@ __global__ __launch_bounds__(WAVES * 64, 2) void k_apply_fast64(Apply64Args A) {
         const double2 w2 = wsrc[16 * r];
         double2 nw = make_double2(v[r].x * w2.x, v[r].y * w2.y);
         if (!wave_live) nw = make_double2(0.0, 0.0);
-        if (!first) {
+        if (j != 0) {   // (frame g == 3 is the first to touch hops 4..6: plain store; sel_s: fastpath.hpp)
           const double2 old = *dst;
-          nw.x += old.x;
-          nw.y += old.y;
+          nw.x = sel_s(OLA_KEEP, nw.x + old.x, nw.x);
+          nw.y = sel_s(OLA_KEEP, nw.y + old.y, nw.y);
         }
         *dst = nw;
       }

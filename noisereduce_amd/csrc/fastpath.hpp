@@ -346,6 +346,30 @@ __device__ __forceinline__ void stage_dft16x2(cf* v) {
 #endif
 }
 
+// Per-lane select with the condition in an SGPR PAIR (v_cndmask_b32_e64): bit l of `m` set -> a, else b.  A v_cndmask_b32
+// that reads VCC -- what the compiler emits for `c ? a : b` next to its compare -- holds the vector pipe of a gfx950 SIMD
+// for ~20 cycles, the SGPR-pair form for 4 (tools/ubench/valu_classes.hip, profiles/r05_valu_classes.txt).  The
+// wave-private overlap-add below selects "first contribution to this hop: store, else add" per float: 48 selects per wave
+// and tile.  OLA_KEEP: lanes of frames g = 0..2 add to what is there (frame 3 is the first to touch hops 4..6).
+constexpr unsigned long long OLA_KEEP = 0x0000ffffffffffffull;
+__device__ __forceinline__ float sel_s(unsigned long long m, float a, float b) {
+  float d;
+  asm("v_cndmask_b32_e64 %0, %1, %2, %3" : "=v"(d) : "v"(b), "v"(a), "s"(m));
+  return d;
+}
+__device__ __forceinline__ unsigned sel_s(unsigned long long m, unsigned a, unsigned b) {
+  unsigned d;
+  asm("v_cndmask_b32_e64 %0, %1, %2, %3" : "=v"(d) : "v"(b), "v"(a), "s"(m));
+  return d;
+}
+__device__ __forceinline__ double sel_s(unsigned long long m, double a, double b) {
+  const unsigned long long ua = (unsigned long long)__double_as_longlong(a), ub = (unsigned long long)__double_as_longlong(b);
+  unsigned lo, hi;
+  asm("v_cndmask_b32_e64 %0, %1, %2, %3" : "=v"(lo) : "v"((unsigned)ub), "v"((unsigned)ua), "s"(m));
+  asm("v_cndmask_b32_e64 %0, %1, %2, %3" : "=v"(hi) : "v"((unsigned)(ub >> 32)), "v"((unsigned)(ua >> 32)), "s"(m));
+  return __longlong_as_double((long long)(((unsigned long long)hi << 32) | lo));
+}
+
 __device__ __forceinline__ void wave_lds_sync() {
   // LDS operations of one wavefront execute in order; this only pins the compiler.
   __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
@@ -904,14 +928,17 @@ __global__ __launch_bounds__(WAVES * 64, LEAN ? 3 : 2) void k_apply_fast(ApplyAr
     static_assert(7 * HPITCH <= WAVE_CX_H * 2, "hop accumulators must fit the wave's exchange slices");
 #pragma unroll
     for (int j = 0; j < ((SG_ABLATE & 64) ? 0 : 4); ++j) {
-      const bool first = (j == 0) || (g == 3);  // first contribution to hop g + j: plain store
+      // (first contribution to hop g + j -- j == 0, or frame g == 3 -- is a plain store)
 #pragma unroll
       for (int rr = 0; rr < 8; ++rr) {
         const int r = 8 * j + rr;
         float2* dst = reinterpret_cast<float2*>(acc + (g + j) * HPITCH + 2 * c + 32 * rr);
-        float2 old = *dst;
         float2 nw = {v[r].x * wsyn[r].x, v[r].y * wsyn[r].y};
-        if (!first) { nw.x += old.x; nw.y += old.y; }
+        if (j != 0) {
+          const float2 old = *dst;
+          nw.x = sel_s(OLA_KEEP, nw.x + old.x, nw.x);
+          nw.y = sel_s(OLA_KEEP, nw.y + old.y, nw.y);
+        }
         *dst = nw;
       }
       wave_lds_sync();

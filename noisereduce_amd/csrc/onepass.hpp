@@ -581,17 +581,17 @@ __global__ __launch_bounds__(WAVES * 64, 3) void k_gate_onepass(OnePassArgs P) {
     // xor-shuffle steps, each swapping the off-diagonal s x s blocks -- leaves in lane k: low half = entry k of lanes
     // 0..15, high half = entry 16 + k.  (32 wave ballots + per-lane selects did the same in ~200 instructions.)
     unsigned tr = pred;
-    auto tstep = [&](int sft, unsigned msk) {
+    // (`up` = lanes whose column index has bit `sft` set: a compile-time lane mask -> SGPR-pair selects, sel_s of fastpath.hpp)
+    auto tstep = [&](int sft, unsigned msk, unsigned long long up) {
       const unsigned y = (unsigned)__shfl_xor((int)tr, sft);
-      const bool up = (c & sft) != 0;
-      const unsigned ysh = up ? (y >> sft) : (y << sft);
-      const unsigned mk = up ? msk : ~msk;
+      const unsigned ysh = sel_s(up, y >> sft, y << sft);
+      const unsigned mk = sel_s(up, msk, ~msk);
       tr = (tr & ~mk) | (ysh & mk);
     };
-    tstep(8, 0x00ff00ffu);
-    tstep(4, 0x0f0f0f0fu);
-    tstep(2, 0x33333333u);
-    tstep(1, 0x55555555u);
+    tstep(8, 0x00ff00ffu, 0xff00ff00ff00ff00ull);
+    tstep(4, 0x0f0f0f0fu, 0xf0f0f0f0f0f0f0f0ull);
+    tstep(2, 0x33333333u, 0xccccccccccccccccull);
+    tstep(1, 0x55555555u, 0xaaaaaaaaaaaaaaaaull);
     const unsigned long long b8 = __ballot(pred512);
     {
       const int sh = 16 * g;
@@ -846,15 +846,18 @@ __global__ __launch_bounds__(WAVES * 64, 3) void k_gate_onepass(OnePassArgs P) {
     const float2* wsrc2 = reinterpret_cast<const float2*>(swin + 2 * c);
 #pragma unroll
     for (int j = 0; j < 4; ++j) {
-      const bool first = (j == 0) || (g == 3);
+      // (first contribution to hop g + j -- j == 0, or frame g == 3 -- is a plain store; sel_s: fastpath.hpp)
 #pragma unroll
       for (int rr = 0; rr < 8; ++rr) {
         const int r = 8 * j + rr;
         float2* dst = reinterpret_cast<float2*>(acc + (g + j) * HPITCH + 2 * c + 32 * rr);
-        const float2 old = *dst;
         const float2 ws = wsrc2[16 * r];
         float2 nw = {v[r].x * ws.x, v[r].y * ws.y};
-        if (!first) { nw.x += old.x; nw.y += old.y; }
+        if (j != 0) {
+          const float2 old = *dst;
+          nw.x = sel_s(OLA_KEEP, nw.x + old.x, nw.x);
+          nw.y = sel_s(OLA_KEEP, nw.y + old.y, nw.y);
+        }
         *dst = nw;
       }
       wave_lds_sync();

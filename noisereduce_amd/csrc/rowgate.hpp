@@ -221,8 +221,8 @@ __global__ __launch_bounds__(RG_WAVES * 64, 1) void k_row_gate(RowGateArgs A) {
   // gather (window x frame t) -> forward transform -> split in place: v[e] = 2 X[bin_of_entry(c, e)]; lane 0 keeps its two
   // unpaired registers raw: v[0] = Zc[0] (bins 0 / 512), v[31] = Zc[256] (bin 256).  Returns 2 (2 delta_t)^2.
   // The exchange slices lie behind the samples, so the transforms of one quad do not disturb the gather of the other.
-  cf wlo, whi;
   auto forward = [&](cf* v, int t) -> float {
+    cf wlo, whi;
     // fresh (opaque) lane arithmetic per call: shared between the calls (CSE), the 32 swizzled exchange addresses and the
     // gather addresses would stay live across everything in between
     int c = lane & 15, zo = 0;
@@ -717,11 +717,17 @@ __global__ __launch_bounds__(RG_WAVES * 64, 1) void k_row_gate(RowGateArgs A) {
   __syncthreads();
   RG_STAMP(8);   // smoothing along t
   if (A.mask_out) {
+    // four bins per thread and store (the K tile keeps 4 adjacent bins in one 8-byte word: column(f) = f + 4 (f / 32)); bin 512
+    // of every row by the first T threads
     float* mo = A.mask_out + (int64_t)blockIdx.x * T * G.FS;
-    for (int i = tid; i < T * 513; i += RG_THREADS) {
-      const int r = i / 513, f = i - 513 * r;
-      mo[(int64_t)r * G.FS + f] = (float)cfp[(size_t)r * RG_FP + f + ((f >> 5) << 2)] * A.inv_ktot;
+    for (int i = tid; i < T * 128; i += RG_THREADS) {
+      const int r = i >> 7, f = (i & 127) * 4;
+      const uint2 k4 = *reinterpret_cast<const uint2*>(&cfp[(size_t)r * RG_FP + f + ((f >> 5) << 2)]);
+      *reinterpret_cast<float4*>(&mo[(int64_t)r * G.FS + f]) =
+          make_float4((float)(k4.x & 0xffffu) * A.inv_ktot, (float)(k4.x >> 16) * A.inv_ktot, (float)(k4.y & 0xffffu) * A.inv_ktot,
+                      (float)(k4.y >> 16) * A.inv_ktot);
     }
+    if (tid < T) mo[(int64_t)tid * G.FS + 512] = (float)cfp[(size_t)tid * RG_FP + 576] * A.inv_ktot;
   }
 
   // ---- x mask -> merge (second half of pair_mask), in place, both quads ------------------------------------------------
@@ -740,6 +746,14 @@ __global__ __launch_bounds__(RG_WAVES * 64, 1) void k_row_gate(RowGateArgs A) {
     };
     const float k512 = (float)krow[512 + 64] * A.kscale;
     const float ks = A.kscale * 0.25f;
+    // (the split's twiddles again from LDS -- not the forward transform's copies kept alive across the smoothing phases)
+    cf wlo = s_tw1024[c];
+    asm volatile("" : "+v"(wlo.x), "+v"(wlo.y));
+    cf whi = wlo;
+    {
+      const cf w16 = s_tw1024[16];
+      if (l0) whi = {-w16.y, w16.x};  // i * w_1024^16
+    }
     {
       // slot 0: lanes >= 1 merge the pair (v[0], v[31]); lane 0: bins 0 / 512 from v[0], bin 256 = v[31] scaled
       const cf r0 = vq[0], r31 = vq[31];
@@ -764,7 +778,6 @@ __global__ __launch_bounds__(RG_WAVES * 64, 1) void k_row_gate(RowGateArgs A) {
       for (int i = 0; i < 32; ++i) vq[i] = {0.f, 0.f};
     }
   }
-  const float4 n4 = *reinterpret_cast<const float4*>(&A.invn[(tid & 63) * 4]);
   __syncthreads();   // every lane has read its K values: the region is reused by the inverse transforms
   RG_STAMP(9);   // mask + merge
 
@@ -773,7 +786,10 @@ __global__ __launch_bounds__(RG_WAVES * 64, 1) void k_row_gate(RowGateArgs A) {
   // their partial sums wait in `carry` (the dead compare-constant tables).  Quad 1 = frames 32..63 -> hops 32..66.
   float* carry = s_t2;    // [3][256]
   static_assert(2 * T2_FLOATS >= 3 * 256, "carry buffer");
-  const int s4 = (tid & 63) * 4;
+  // (the lane index from v_mbcnt, not from threadIdx.x: the workitem id need not survive -- in a spill slot -- from the
+  // entry block to the epilogue of a kernel at its 128-VGPR cap)
+  const int lane_e = (int)__builtin_amdgcn_mbcnt_hi(~0u, __builtin_amdgcn_mbcnt_lo(~0u, 0u));
+  const int s4 = lane_e * 4;
   const int64_t h_begin = (A.om.p0 + G.padL) / 256, h_end = (A.om.p1 - 1 + G.padL) / 256 + 1;
 #pragma unroll
   for (int q = 0; q < RG_QUADS; ++q) {
@@ -788,20 +804,26 @@ __global__ __launch_bounds__(RG_WAVES * 64, 1) void k_row_gate(RowGateArgs A) {
       const float2* wsrc2 = reinterpret_cast<const float2*>(swin + 2 * c);
 #pragma unroll
       for (int j = 0; j < 4; ++j) {
-        const bool first = (j == 0) || (g == 3);
+        // (first contribution to hop g + j -- j == 0, or frame g == 3 -- is a plain store; sel_s: fastpath.hpp)
 #pragma unroll
         for (int rr = 0; rr < 8; ++rr) {
           const int r = 8 * j + rr;
           float2* dst = reinterpret_cast<float2*>(acc + (g + j) * HPITCH + 2 * c + 32 * rr);
-          const float2 old = *dst;
           const float2 ws = wsrc2[16 * r];
           float2 nw = {vq[r].x * ws.x, vq[r].y * ws.y};
-          if (!first) { nw.x += old.x; nw.y += old.y; }
+          if (j != 0) {
+            const float2 old = *dst;
+            nw.x = sel_s(OLA_KEEP, nw.x + old.x, nw.x);
+            nw.y = sel_s(OLA_KEEP, nw.y + old.y, nw.y);
+          }
           *dst = nw;
         }
         wave_lds_sync();
       }
     }
+    // (1 / envelope of this lane's four sample phases: loaded HERE, behind the transforms -- four registers that do not
+    // stay live across the inverse transform of a kernel at its 128-VGPR cap)
+    const float4 n4 = *reinterpret_cast<const float4*>(&A.invn[s4]);
     __syncthreads();
     // combine: local hop lj = 0..34 of this quad (ext hop jj = 32 q + lj): wave lj / 4 (hop lj % 4) + wave lj / 4 - 1 (hop lj % 4 + 4)
     const float* fr = reinterpret_cast<const float*>(slices);

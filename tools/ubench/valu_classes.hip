@@ -18,10 +18,10 @@
                "+v"(d[9]), "+v"(d[10]), "+v"(d[11]), "+v"(d[12]), "+v"(d[13]), "+v"(d[14]), "+v"(d[15])
 
 enum { M_FMA32, M_ADD32, M_CNDMASK, M_MOV_DPP, M_ADD_DPP, M_LOG, M_EXP, M_RCP, M_SQRT, M_FMA64, M_ADD64, M_MUL64, M_CVT_F64_F32,
-       M_LSHL64, M_AND_OR, M_PERM, M_MAD_U32_U24, M_ADD3, N_MODES };
+       M_LSHL64, M_AND_OR, M_PERM, M_MAD_U32_U24, M_ADD3, M_CNDMASK_SGPR, M_CNDMASK_VCC_DST, M_MOV, N_MODES };
 static const char* names[N_MODES] = {"v_fma_f32", "v_add_f32", "v_cndmask_b32 (vcc)", "v_mov_b32_dpp row_shr:1", "v_add_f32_dpp row_shr:1",
                                      "v_log_f32", "v_exp_f32", "v_rcp_f32", "v_sqrt_f32", "v_fma_f64", "v_add_f64", "v_mul_f64",
-                                     "v_cvt_f64_f32", "v_lshlrev_b64", "v_and_or_b32", "v_perm_b32", "v_mad_u32_u24", "v_add3_u32"};
+                                     "v_cvt_f64_f32", "v_lshlrev_b64", "v_and_or_b32", "v_perm_b32", "v_mad_u32_u24", "v_add3_u32", "v_cndmask_b32_e64 (sgpr pair)", "v_cndmask_b32 (vcc, other sources)", "v_mov_b32"};
 constexpr int REPT = 32, PER_BODY = 16;
 
 template <int MODE>
@@ -61,6 +61,23 @@ __global__ __launch_bounds__(256) void k(float* out, int iters, float a, float b
     } else if constexpr (MODE == M_AND_OR) asm volatile(".rept 32\n" R16("v_and_or_b32", ", %16, %17") ".endr" : REGS32 : "v"(a), "v"(b));
     else if constexpr (MODE == M_PERM) asm volatile(".rept 32\n" R16("v_perm_b32", ", %16, %17") ".endr" : REGS32 : "v"(a), "v"(b));
     else if constexpr (MODE == M_MAD_U32_U24) asm volatile(".rept 32\n" R16("v_mad_u32_u24", ", %16, %17") ".endr" : REGS32 : "v"(a), "v"(b));
+    else if constexpr (MODE == M_CNDMASK_SGPR) {
+      unsigned long long msk;
+      asm volatile("v_cmp_gt_f32 %0, %1, %2" : "=s"(msk) : "v"(a), "v"(b));
+      asm volatile(".rept 32\n" R16("v_cndmask_b32_e64", ", %16, %17") ".endr" : REGS32 : "v"(a), "s"(msk));
+    } else if constexpr (MODE == M_CNDMASK_VCC_DST) {
+      asm volatile("v_cmp_gt_f32 vcc, %16, %17\n.rept 32\n"
+                   "v_cndmask_b32 %0, %16, %17, vcc\n v_cndmask_b32 %1, %16, %17, vcc\n v_cndmask_b32 %2, %16, %17, vcc\n v_cndmask_b32 %3, %16, %17, vcc\n"
+                   "v_cndmask_b32 %4, %16, %17, vcc\n v_cndmask_b32 %5, %16, %17, vcc\n v_cndmask_b32 %6, %16, %17, vcc\n v_cndmask_b32 %7, %16, %17, vcc\n"
+                   "v_cndmask_b32 %8, %16, %17, vcc\n v_cndmask_b32 %9, %16, %17, vcc\n v_cndmask_b32 %10, %16, %17, vcc\n v_cndmask_b32 %11, %16, %17, vcc\n"
+                   "v_cndmask_b32 %12, %16, %17, vcc\n v_cndmask_b32 %13, %16, %17, vcc\n v_cndmask_b32 %14, %16, %17, vcc\n v_cndmask_b32 %15, %16, %17, vcc\n"
+                   ".endr" : REGS32 : "v"(a), "v"(b) : "vcc");
+    } else if constexpr (MODE == M_MOV) {
+      asm volatile(".rept 32\n"
+                   "v_mov_b32 %0, %16\n v_mov_b32 %1, %16\n v_mov_b32 %2, %16\n v_mov_b32 %3, %16\n v_mov_b32 %4, %16\n v_mov_b32 %5, %16\n v_mov_b32 %6, %16\n v_mov_b32 %7, %16\n"
+                   "v_mov_b32 %8, %16\n v_mov_b32 %9, %16\n v_mov_b32 %10, %16\n v_mov_b32 %11, %16\n v_mov_b32 %12, %16\n v_mov_b32 %13, %16\n v_mov_b32 %14, %16\n v_mov_b32 %15, %16\n"
+                   ".endr" : REGS32 : "v"(a));
+    }
     else if constexpr (MODE == M_ADD3) asm volatile(".rept 32\n" R16("v_add3_u32", ", %16, %17") ".endr" : REGS32 : "v"(a), "v"(b));
   }
   float s = 0.f;
