@@ -815,6 +815,11 @@ def main():
         }
         line["kernel_ms_sum"] = round(sum(line["kernel_ms_per_step"].values()), 4)
         line["kernel_ms_sum_le_step"] = bool(line["kernel_ms_sum"] <= line["ms_per_step"])
+        line["kernel_ms_note"] = ("event-bracketed kernel times (one stage at a time, empty-pair time subtracted) still include the "
+                                  "launch / drain bubble a kernel has when events fence it (~3-5 % of a 0.25 ms kernel: the gate reads "
+                                  "0.262-0.265 ms here, 0.252 ms in rocprofv3's kernel trace, profiles/); back to back in a step the bubbles "
+                                  "overlap, so the sum may exceed ms_per_step by a few percent.  The roofline uses the dominant kernel's "
+                                  "time from the TIMED region; rocprofv3 averages are committed under profiles/")
         line["roofline"]["avg_launch_ms_corrected"] = round(max(0.0, avg_ms - ev_oh), 4)
         line["gpu_state"] = {"before_settle": state_before_settle, "before_timed": state_before, "after_timed": state_after,
                              "source": "librocm_smi64 in-process (sclk / mclk of the current DPM level, socket power, cap, "

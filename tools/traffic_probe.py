@@ -26,3 +26,12 @@ tg = TorchGate(sr=16000).to(dev)
 for _ in range(4):
     out = tg(x)                                                  # configs[4] forward
 torch.cuda.synchronize()
+xg = x.clone().requires_grad_()
+for _ in range(4):
+    xg.grad = None
+    tg(xg).sum().backward()                                      # configs[4] forward (mask saved) + backward (k_row_backward)
+torch.cuda.synchronize()
+y16 = (y * 20000).to(torch.int16)
+for _ in range(4):
+    out = nr.reduce_noise(y=y16, sr=48000, stationary=True)      # int16 recording: bit path + k_apply_fast64
+torch.cuda.synchronize()
