@@ -74,7 +74,7 @@ __device__ __forceinline__ void fft512_inv_half_d(cd* v, cd* fb, const cd* tw512
   wave_lds_sync();
   __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
-  for (int k1 = 0; k1 < 16; ++k1) {
+  for (int k1 = 0; k1 < 16; ++k1) {   // (four at a time: see fft512_fwd_half_d)
     const cd e = fb[k1 * 16 + (c ^ k1)];
     if (k1 == 0) {
       w[brev<32>(k1)] = e;
@@ -83,6 +83,7 @@ __device__ __forceinline__ void fft512_inv_half_d(cd* v, cd* fb, const cd* tw512
       t.y = -t.y;
       w[brev<32>(k1)] = cmul(e, t);
     }
+    if ((k1 & 3) == 3) __builtin_amdgcn_sched_barrier(0);
   }
   wave_lds_sync();
   __builtin_amdgcn_sched_barrier(0);
@@ -103,6 +104,7 @@ __device__ __forceinline__ void fft512_inv_half_d(cd* v, cd* fb, const cd* tw512
     cd t = tw512[k1 * 16 + c];
     t.y = -t.y;
     w[brev<32>(k1)] = cmul(e, t);
+    if ((k1 & 3) == 3) __builtin_amdgcn_sched_barrier(0);
   }
   wave_lds_sync();
   __builtin_amdgcn_sched_barrier(0);
@@ -208,7 +210,23 @@ __global__ __launch_bounds__(WAVES * 64, 2) void k_apply_fast64(Apply64Args A) {
   double* xs = reinterpret_cast<double*>(regions);
   {
     const int64_t s0b = tf_tile * 256 - G.padL;
-    for (int i = tid; i < SPAN; i += WAVES * 64) xs[(i >> 8) * A64_XP + (i & 255)] = view_sample(A.view, row, chunk, s0b + i);
+    const int64_t gb = chunk * A.view.cs - A.view.pad + s0b;
+    if (s0b >= 0 && s0b + SPAN <= A.view.Lp && gb >= A.view.lo && gb + SPAN <= A.view.hi) {
+      // interior tile: every sample of the span is readable -- one unchecked load per sample, the type switch outside the loop
+      const int64_t b0 = row * A.view.stride + gb;
+      auto fill = [&](auto* p) {
+#pragma unroll 4
+        for (int i = tid; i < SPAN; i += WAVES * 64) xs[(i >> 8) * A64_XP + (i & 255)] = (double)p[b0 + i];
+      };
+      switch (A.view.dtype) {
+        case 0: fill((const float*)A.view.x); break;
+        case 1: fill((const double*)A.view.x); break;
+        case 2: fill((const int16_t*)A.view.x); break;
+        default: fill((const int32_t*)A.view.x); break;
+      }
+    } else {
+      for (int i = tid; i < SPAN; i += WAVES * 64) xs[(i >> 8) * A64_XP + (i & 255)] = view_sample(A.view, row, chunk, s0b + i);
+    }
   }
   __syncthreads();
   cd v[32];
@@ -280,7 +298,14 @@ __global__ __launch_bounds__(WAVES * 64, 2) void k_apply_fast64(Apply64Args A) {
       __builtin_amdgcn_sched_barrier(0);
     }
     lane0_from_entries_d(v, l0);
-    fft512_inv_half_d(v, fb, tw512, c);
+    {
+      // fresh (opaque) lane arithmetic for the inverse exchange: shared with the forward transform (CSE), the 32 swizzled
+      // exchange addresses stay live across the pair stage -- and were spilled (68 VGPRs, 1 GB of scratch traffic per ten
+      // minutes of audio: profiles/r05_v1_traffic_detail.json)
+      int zi = 0, ci = c;
+      asm volatile("" : "+v"(zi), "+v"(ci));
+      fft512_inv_half_d(v, fb + zi, tw512 + zi, ci);
+    }
   }
   // synthesis window, wave-private overlap-add of this wave's 4 frames into 7 hop accumulators (k_apply_fast<LEAN>):
   // step j: frame g adds its quarter j to hop g + j -- the four lane groups never collide within a step and a hop receives

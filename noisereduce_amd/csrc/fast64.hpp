@@ -88,11 +88,16 @@ __device__ __forceinline__ void fft512_fwd_half_d(cd* v, cd* fb, const cd* tw512
   __builtin_amdgcn_sched_barrier(0);
   dft_inplace_d<32>(v);
   __builtin_amdgcn_sched_barrier(0);
-#pragma unroll
-  for (int k1 = 1; k1 < 32; ++k1) v[k1] = cmul(v[k1], tw512[k1 * 16 + c]);
+  // twiddle and store FOUR rows at a time (sched_barriers): left alone, the scheduler issues all 31 twiddle loads up
+  // front -- 124 more registers beside the 128 of the spectra -- and the kernels spill (k_apply_fast64: 64 VGPRs, a GB of
+  // scratch traffic per ten minutes of audio, round 5).  Same arithmetic in the same order: bit-identical results.
   // element (row k1, column c) lives in slot k1 * 16 + (c ^ (k1 & 15)): a row is one 256-byte bank line
 #pragma unroll
-  for (int k1 = 0; k1 < 16; ++k1) fb[k1 * 16 + (c ^ k1)] = v[k1];
+  for (int k1 = 0; k1 < 16; ++k1) {
+    if (k1 != 0) v[k1] = cmul(v[k1], tw512[k1 * 16 + c]);
+    fb[k1 * 16 + (c ^ k1)] = v[k1];
+    if ((k1 & 3) == 3) __builtin_amdgcn_sched_barrier(0);
+  }
   wave_lds_sync();
   {
     const int row = row1(c);
@@ -101,7 +106,11 @@ __device__ __forceinline__ void fft512_fwd_half_d(cd* v, cd* fb, const cd* tw512
   }
   wave_lds_sync();
 #pragma unroll
-  for (int k1 = 16; k1 < 32; ++k1) fb[(k1 - 16) * 16 + (c ^ (k1 - 16))] = v[k1];
+  for (int k1 = 16; k1 < 32; ++k1) {
+    v[k1] = cmul(v[k1], tw512[k1 * 16 + c]);
+    fb[(k1 - 16) * 16 + (c ^ (k1 - 16))] = v[k1];
+    if ((k1 & 3) == 3) __builtin_amdgcn_sched_barrier(0);
+  }
   wave_lds_sync();
   {
     const int row = row2(c) - 16;
