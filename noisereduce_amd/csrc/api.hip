@@ -1567,8 +1567,10 @@ static int stage_smooth(sg_handle* h, const Geom& g, int64_t ub, hipStream_t st)
     const int nf = h->p.n_grad_freq, nt = h->p.n_grad_time;
     const int rows = SMF_TT + 2 * nt, cols = SMF_FB + 2 * nf;
     // +3: the sliding windows read up to 3 entries past the last tap
-    size_t lds = ((size_t)(rows + 3) * (cols | 1) + (size_t)(rows + 3) * (SMF_FB + 1) + 8 + 128 + SMF_FB + SMF_TT) * sizeof(float);
-    if (lds <= 150 * 1024 && ub <= 65535 && nf <= 30 && nt <= 30 && SMF_FB + 2 * nf <= 192) {
+    size_t lds = ((size_t)(rows + 3) * (cols | 1) + (size_t)(rows + 3) * (SMF_FB + 1) + 8 + 64 + SMF_KT + SMF_FB + SMF_TT) * sizeof(float);
+    // (time half-widths up to 94: short frames have long smoothing windows in frames -- n_fft = 256 at 48 kHz: nt = 37 --
+    // and used to fall through to the two direct global-memory convolutions below: 0.73 ms of a 1.09 ms call)
+    if (lds <= 150 * 1024 && ub <= 65535 && nf <= 30 && 2 * nt + 4 <= SMF_KT && SMF_FB + 2 * nf <= 192) {
       auto kern = k_smooth_tiled;
       if (lds > 65536)
         HIPCHK(h, set_lds(reinterpret_cast<const void*>(kern), lds));

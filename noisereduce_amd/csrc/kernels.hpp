@@ -1033,7 +1033,7 @@ __global__ void k_smooth_t(const float* __restrict__ tmp, Geom g, const float* _
 // The kernel is latency-bound (one global round trip per block, then LDS work): the tile is sized
 // for occupancy -- 64 x 64 outputs = 46 KB of LDS at the 48 kHz default (3 blocks/CU); 32 x 128
 // (54 KB, 2 blocks/CU) was 1.6x slower, smaller tiles pay too much halo.
-constexpr int SMF_TT = 64, SMF_FB = 64;
+constexpr int SMF_TT = 64, SMF_FB = 64, SMF_KT = 192;
 
 __global__ __launch_bounds__(256) void k_smooth_tiled(const float* __restrict__ raw, Geom g,
                                                       const float* __restrict__ kf, int nf,
@@ -1047,15 +1047,13 @@ __global__ __launch_bounds__(256) void k_smooth_tiled(const float* __restrict__ 
   // taps first (16-byte aligned, padded to multiples of 4): broadcast LDS reads instead of one
   // scalar-cache round trip per tap inside the filter loops
   float* skf = reinterpret_cast<float*>(smem);       // [64]
-  float* skt = skf + 64;                             // [64]
-  float* sef = skt + 64;                             // [SMF_FB] conv(1) along f under zero padding
+  float* skt = skf + 64;                             // [SMF_KT]: time half-widths up to 95 (n_fft = 256 at 48 kHz: nt = 37)
+  float* sef = skt + SMF_KT;                         // [SMF_FB] conv(1) along f under zero padding
   float* set_ = sef + SMF_FB;                        // [SMF_TT] conv(1) along t
   float* tile = set_ + SMF_TT;                       // [rows][tp]  raw, zero outside the field
   float* buf = tile + (size_t)rows * tp;             // [rows][BP]  after the f-pass
-  if (threadIdx.x < 64) {
-    skf[threadIdx.x] = (int)threadIdx.x <= 2 * nf ? kf[threadIdx.x] : 0.f;
-    skt[threadIdx.x] = (int)threadIdx.x <= 2 * nt ? kt[threadIdx.x] : 0.f;
-  }
+  if (threadIdx.x < 64) skf[threadIdx.x] = (int)threadIdx.x <= 2 * nf ? kf[threadIdx.x] : 0.f;
+  if (threadIdx.x < SMF_KT) skt[threadIdx.x] = (int)threadIdx.x <= 2 * nt ? kt[threadIdx.x] : 0.f;
   const int64_t u = blockIdx.z;
   const int64_t t0 = (int64_t)blockIdx.y * SMF_TT;
   const int f0 = blockIdx.x * SMF_FB;

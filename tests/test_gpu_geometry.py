@@ -198,3 +198,16 @@ def test_torchgate_nfft2048(nr):
         yc = torch.istft(X * m, 2048, 512, 2048, window=win, center=True)
         (yc * w).sum().backward()
         assert O.rel_err(xt.grad.cpu().numpy(), xc.grad.numpy()) < TOL
+
+
+@pytest.mark.parametrize("stationary", [True, False])
+@pytest.mark.parametrize("n_fft,sr,extra", [(256, 48000, {}), (128, 44100, dict(freq_mask_smooth_hz=1000))])
+def test_short_frames_long_smoothing_window(nr, n_fft, sr, extra, stationary):
+    """Short frames at a high sample rate: time_mask_smooth_ms = 50 is 37 frames of n_fft = 256 at 48 kHz (68 at n_fft = 128,
+    44.1 kHz) -- beyond the register-tile mask kernels (nt <= 20); round 5 routes them through the LDS-tiled smoothing kernel
+    (nt <= 94) instead of two direct global-memory convolutions.  Against the oracle."""
+    y = O.synth_signal(60000, sr=sr, seed=33, tone_hz=1500.0).astype(np.float64)
+    kw = dict(n_fft=n_fft, chunk_size=25000, padding=4000, **extra)
+    got = nr.reduce_noise(y=y, sr=sr, stationary=stationary, **kw)
+    want = O.reduce_noise_S(y, sr, stationary=stationary, **kw)
+    assert O.rel_err(got, want) < TOL
