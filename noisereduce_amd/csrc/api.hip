@@ -632,10 +632,10 @@ static hipError_t stft_any(const sg_handle* h, const View& v, const Geom& g, int
     return rc == SG_OK ? hipSuccess : (rc == SG_E_NOMEM ? hipErrorOutOfMemory : hipErrorUnknown);
   }
   const void* wfull = sizeof(TC) == 8 ? h->wfull64.p : h->wa32.p;
-  if (sizeof(TC) == 8 && h->fast_ok && !h->force_nofast && P && !mag && !z && v.dtype == SG_F32 &&
-      units * ((g.T + 15) / 16) >= 512) {
-    // default geometry, float32 samples, float64 powers only, enough 16-frame blocks for two per CU: register FFT
+  if (sizeof(TC) == 8 && h->fast_ok && !h->force_nofast && P && !mag && !z && units * ((g.T + 15) / 16) >= 512) {
+    // default geometry, float64 powers only, enough 16-frame blocks for two per CU: register FFT
     // core (fast64.hpp).  (A single noise clip is faster on k_stft's one-frame-per-wave grid: 13.7 vs 18 us.)
+    // Samples staged as float32 where that is exact (float32 / int16 recordings), as float64 otherwise.
     constexpr int WAVES = 4;
     fast::Pow64Args A{v, g, (const double*)h->wfull64.p, (const fast::cd*)h->tw64.p, P, pmax_bits};
     const size_t lds = (size_t)(fast::FN + WAVES * 4 * fast::FSLOTS_D + 32) * sizeof(fast::cd);
@@ -646,7 +646,9 @@ static hipError_t stft_any(const sg_handle* h, const View& v, const Geom& g, int
       hipLaunchKernelGGL(kern, grid, dim3(WAVES * 64), lds, st, A);
       return hipGetLastError();
     };
-    return pmax_bits ? go(fast::k_power_fast64<WAVES, true>) : go(fast::k_power_fast64<WAVES, false>);
+    if (v.dtype == SG_F32 || v.dtype == SG_I16)
+      return pmax_bits ? go(fast::k_power_fast64<WAVES, true>) : go(fast::k_power_fast64<WAVES, false>);
+    return pmax_bits ? go(fast::k_power_fast64<WAVES, true, double>) : go(fast::k_power_fast64<WAVES, false, double>);
   }
   if (!h->czt_M) {
     const void* tw = sizeof(TC) == 8 ? h->tw64.p : h->tw32.p;
@@ -1485,7 +1487,7 @@ static int stage_nonstat_mask2(sg_handle* h, const View& v, const Geom& g, int64
       hipLaunchKernelGGL(k_iir_part, dim3((unsigned)((nk * (g.FS / 4) + 255) / 256), (unsigned)ub), dim3(256), 0,
                          st, mag, g, tl, h->p.iir_b, (double*)h->nsp.p);
     HIPCHK(h, hipGetLastError());
-    hipLaunchKernelGGL(k_iir_chain, dim3((unsigned)((ub * g.FS + 63) / 64)), dim3(64), 0, st, mag,
+    hipLaunchKernelGGL((k_iir_chain<float, false>), dim3((unsigned)((ub * g.FS + 63) / 64)), dim3(64), 0, st, mag,
                        (const double*)h->nsp.p, g, tl, h->p.iir_b, (double*)h->nsc.p, ub);
     HIPCHK(h, hipGetLastError());
   }
@@ -2102,26 +2104,29 @@ static int stage_onepass(sg_handle* h, const View& v, const View& vx, const Geom
 }
 
 // float64 fused apply (apply64.hpp): K counts of stage_fused_mask -> output samples, everything in double
-template <int WAVES>
+template <int WAVES, bool KMASK>
 static hipError_t launch_apply_fast64(fast::Apply64Args& A, int64_t nh, int64_t ub, hipStream_t st) {
   constexpr int NH = 4 * WAVES - 3;
   const size_t lds = (size_t)(fast::FN + WAVES * 4 * fast::FSLOTS_D + 17) * sizeof(fast::cd);
-  auto kern = fast::k_apply_fast64<WAVES>;
+  auto kern = fast::k_apply_fast64<WAVES, KMASK>;
   hipError_t e = set_lds(reinterpret_cast<const void*>(kern), lds);
   if (e != hipSuccess) return e;
   hipLaunchKernelGGL(kern, dim3((unsigned)((nh + NH - 1) / NH), (unsigned)ub), dim3(WAVES * 64), lds, st, A);
   return hipGetLastError();
 }
 
-static int stage_apply_fast64(sg_handle* h, const View& v, const Geom& g, int64_t ub, const OutMap& om, hipStream_t st) {
+// mask_f64 == nullptr: the uint16 counts in h->K16 (stationary gate); else a float64 mask field [units][T][FS]
+static int stage_apply_fast64(sg_handle* h, const View& v, const Geom& g, int64_t ub, const OutMap& om, hipStream_t st,
+                              const double* mask_f64 = nullptr) {
   ProfScope ps(h, SG_STAGE_APPLY_FAST, st);
   fast::Apply64Args A;
   A.view = v; A.g = g; A.om = om;
   A.K = (const unsigned short*)h->K16.p;
+  A.Mf = mask_f64;
   A.win = (const double*)h->wfull64.p;
   A.norm = (const double*)h->norm64.p;
   A.tw1024 = (const fast::cd*)h->tw64.p;
-  A.kscale = 1.0 / ((double)h->ktot * 512.0);
+  A.kscale = mask_f64 ? 1.0 / 512.0 : 1.0 / ((double)h->ktot * 512.0);
   A.h_begin = (om.p0 + g.padL) / 256;
   A.h_end = (om.p1 - 1 + g.padL) / 256 + 1;
   const int64_t nh = A.h_end - A.h_begin;
@@ -2130,8 +2135,13 @@ static int stage_apply_fast64(sg_handle* h, const View& v, const Geom& g, int64_
   // short; either way two wavefronts per SIMD (256 VGPRs) and one (8) or two (4) workgroups per CU
   static const int waves_env = getenv("SG_APPLY64_WAVES") ? atoi(getenv("SG_APPLY64_WAVES")) : 0;
   const bool wide = waves_env ? waves_env == 8 : nh >= 64;
-  if (wide) HIPCHK(h, launch_apply_fast64<8>(A, nh, ub, st));
-  else HIPCHK(h, launch_apply_fast64<4>(A, nh, ub, st));
+  if (mask_f64) {
+    if (wide) HIPCHK(h, (launch_apply_fast64<8, false>(A, nh, ub, st)));
+    else HIPCHK(h, (launch_apply_fast64<4, false>(A, nh, ub, st)));
+  } else {
+    if (wide) HIPCHK(h, (launch_apply_fast64<8, true>(A, nh, ub, st)));
+    else HIPCHK(h, (launch_apply_fast64<4, true>(A, nh, ub, st)));
+  }
   return SG_OK;
 }
 
@@ -2230,7 +2240,8 @@ static hipError_t xapply_any(sg_handle* h, const View& v, const Geom& g, int64_t
 // float64 pipeline (exact.hpp): bytes per unit -- P, raw, M, tmp (8 B per cell each) + frames (8 B per sample of every
 // frame) + the statistics rows -- and units per batch.  Shared with sg_workspace_bytes.
 static size_t exact_unit_bytes(const Geom& g) {
-  return (size_t)g.T * g.FS * 32 + (size_t)g.T * g.n * 8 + (size_t)g.FS * 16;
+  // (+ the non-stationary gate's tile partials and carries: 2 x 2 doubles per band and 32-frame tile, one tile more than T / 32)
+  return (size_t)g.T * g.FS * 32 + (size_t)g.T * g.n * 8 + (size_t)g.FS * 16 + (size_t)(g.T / 32 + 2) * g.FS * 32;
 }
 static int64_t exact_units_per_batch(const sg_handle* h, const Geom& g, int64_t total_units) {
   return std::max<int64_t>(1, std::min<int64_t>(std::min<int64_t>(ws_budget(h) / (int64_t)exact_unit_bytes(g), 32768), total_units));
@@ -2246,7 +2257,9 @@ static int run_S_exact(sg_handle* h, View v, int64_t total_units, const OutMap& 
   if ((rc = ensure(h, h->xraw, cells * 8))) return rc;
   if ((rc = ensure(h, h->xM, cells * 8))) return rc;
   if ((rc = ensure(h, h->xtmp, cells * 8))) return rc;
-  if ((rc = ensure(h, h->xseg, (size_t)ub * g.T * g.n * 8))) return rc;
+  // default geometry: k_apply_fast64 reads the float64 mask field and writes samples (no masked frames through HBM)
+  const bool apply64 = h->fast_ok && !h->force_nofast && g.F == 513 && h->norm64.p && !h->exact_materialised;
+  if (!apply64 && (rc = ensure(h, h->xseg, (size_t)ub * g.T * g.n * 8))) return rc;
   if ((rc = ensure(h, h->pmax, (size_t)ub * g.FS * 8))) return rc;
   const int nf = h->p.n_grad_freq, nt = h->p.n_grad_time;
   const double p = h->p.prop_decrease;
@@ -2268,6 +2281,24 @@ static int run_S_exact(sg_handle* h, View v, int64_t total_units, const OutMap& 
                          (const double*)h->pmax.p, (const double*)h->thresh.p, (int64_t)0, h->mag_scale, h->p.top_db,
                          (float*)h->xraw.p, nb);
       HIPCHK(h, hipGetLastError());
+    } else if (g.T >= 4 * exact::XIIR_TT && nb <= 65535) {
+      // (round 5) tile-parallel: partials of 32-frame tiles -> chain -> both sweeps per tile from the entering states
+      ProfScope ps(h, SG_STAGE_NONSTAT_MASK, st);
+      NsTiling tl{g.T, 0};
+      tl.tt = exact::XIIR_TT;
+      const int64_t nk = tl.n_tiles();
+      const size_t bytes = (size_t)nb * nk * 2 * g.FS * sizeof(double);
+      if ((rc = ensure(h, h->nsp, bytes))) return rc;
+      if ((rc = ensure(h, h->nsc, bytes))) return rc;
+      const dim3 gp((unsigned)((nk * g.FS + 255) / 256), (unsigned)nb);
+      hipLaunchKernelGGL(exact::kx_iir_part, gp, dim3(256), 0, st, (const double*)P, g, tl, h->p.iir_b, (double*)h->nsp.p);
+      HIPCHK(h, hipGetLastError());
+      hipLaunchKernelGGL((k_iir_chain<double, true>), dim3((unsigned)((nb * g.FS + 63) / 64)), dim3(64), 0, st, (const double*)P,
+                         (const double*)h->nsp.p, g, tl, h->p.iir_b, (double*)h->nsc.p, nb);
+      HIPCHK(h, hipGetLastError());
+      hipLaunchKernelGGL(exact::kx_iir_apply, gp, dim3(256), 0, st, (const double*)P, (const double*)h->nsc.p, g, tl, h->p.iir_b,
+                         h->p.nonstat_thresh, h->p.nonstat_slope, (double*)h->xraw.p);
+      HIPCHK(h, hipGetLastError());
     } else {
       ProfScope ps(h, SG_STAGE_NONSTAT_MASK, st);
       hipLaunchKernelGGL(exact::kx_iir_sigmoid, dim3((unsigned)((g.F + 63) / 64), (unsigned)nb), dim3(64), 0, st,
@@ -2282,6 +2313,20 @@ static int run_S_exact(sg_handle* h, View v, int64_t total_units, const OutMap& 
           hipLaunchKernelGGL(exact::kx_prop_only<float>, gr, dim3(256), 0, st, (const float*)h->xraw.p, g, p, (double*)h->xM.p, nb);
         else
           hipLaunchKernelGGL(exact::kx_prop_only<double>, gr, dim3(256), 0, st, (const double*)h->xraw.p, g, p, (double*)h->xM.p, nb);
+      } else if (exact::xsm_lds_bytes(nf, nt) <= 150 * 1024 && 2 * nf < exact::XSM_KMAX && 2 * nt < exact::XSM_KMAX && nb <= 65535 &&
+                 (g.T + exact::XSM_TT - 1) / exact::XSM_TT <= 65535) {
+        // (round 5) both passes in one LDS-tiled kernel, taps computed once per block
+        const size_t lds = exact::xsm_lds_bytes(nf, nt);
+        const dim3 gt((unsigned)((g.F + exact::XSM_FB - 1) / exact::XSM_FB), (unsigned)((g.T + exact::XSM_TT - 1) / exact::XSM_TT), (unsigned)nb);
+        if (h->p.stationary) {
+          auto kern = exact::kx_smooth_tiled<float>;
+          HIPCHK(h, set_lds(reinterpret_cast<const void*>(kern), lds));
+          hipLaunchKernelGGL(kern, gt, dim3(256), lds, st, (const float*)h->xraw.p, g, nf, nt, p, prop_before, (double*)h->xM.p);
+        } else {
+          auto kern = exact::kx_smooth_tiled<double>;
+          HIPCHK(h, set_lds(reinterpret_cast<const void*>(kern), lds));
+          hipLaunchKernelGGL(kern, gt, dim3(256), lds, st, (const double*)h->xraw.p, g, nf, nt, p, prop_before, (double*)h->xM.p);
+        }
       } else {
         if (h->p.stationary)
           hipLaunchKernelGGL(exact::kx_smooth_f<float>, gr, dim3(256), 0, st, (const float*)h->xraw.p, g, nf, (double*)h->xtmp.p, nb);
@@ -2292,6 +2337,13 @@ static int run_S_exact(sg_handle* h, View v, int64_t total_units, const OutMap& 
                            (double*)h->xM.p, nb);
       }
       HIPCHK(h, hipGetLastError());
+    }
+    // default geometry: transforms, mask multiply and overlap-add in ONE float64 kernel reading the mask field (round 5)
+    // instead of masked frames through HBM + a gather
+    if (apply64) {
+      if ((rc = stage_apply_fast64(h, v, g, nb, om, st, (const double*)h->xM.p))) return rc;
+      h->dbg_units = 0;
+      continue;
     }
     {
       ProfScope ps(h, SG_STAGE_APPLY_ISTFT, st);

@@ -159,17 +159,18 @@ struct Apply64Args {
   View view;
   Geom g;
   OutMap om;
-  const unsigned short* K;   // permuted mask counts [units][T][FSK] (k_smooth_bits2's layout for k_apply_fast<KMASK>)
+  const unsigned short* K;   // KMASK: permuted mask counts [units][T][FSK] (k_smooth_bits2's layout for k_apply_fast<KMASK>)
+  const double* Mf;          // !KMASK: float64 mask field [units][T][FS], natural bin order (exact.hpp's xM: the non-stationary gate)
   const double* win;         // analysis == synthesis window, double[1024]
   const double* norm;        // sum_q win^2[256 q + s], s < 256 (interior hops)
   const cd* tw1024;          // w_1024^k, k = 0..511
-  double kscale;             // 1 / (ktot * 512)
+  double kscale;             // KMASK: 1 / (ktot * 512); !KMASK: 1 / 512
   int64_t h_begin, h_end;    // ext hops (256-sample blocks, ext = unit sample + 512) to produce
 };
 
 constexpr int A64_XP = 264;   // doubles between the staged hop rows / the hop accumulators of a wave
 
-template <int WAVES>
+template <int WAVES, bool KMASK = true>
 __global__ __launch_bounds__(WAVES * 64, 2) void k_apply_fast64(Apply64Args A) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
   cd* tw512 = reinterpret_cast<cd*>(smem);   // [32][16]: w_512^(k1 c)
@@ -246,21 +247,30 @@ __global__ __launch_bounds__(WAVES * 64, 2) void k_apply_fast64(Apply64Args A) {
   const bool wave_live = tf_tile + 4 * wave + 3 >= 0 && tf_tile + 4 * wave < G.T;
   if (wave_live) {
     fft512_fwd_half_d(v, fb, tw512, c);
-    // mask counts of this lane's 32 entries (+ bin 512)
-    const unsigned short* Krow = A.K + ((u * G.T + (fvalid ? t : 0)) * (int64_t)FSK);
-    unsigned kw[16];
-    {
+    // KMASK: mask counts of this lane's 32 entries (+ bin 512), 16 registers; !KMASK: the float64 mask row, read where used
+    unsigned kw[KMASK ? 16 : 1];
+    const double* Mrow = nullptr;
+    double k512;
+    if constexpr (KMASK) {
+      const unsigned short* Krow = A.K + ((u * G.T + (fvalid ? t : 0)) * (int64_t)FSK);
       const uint4* p4 = reinterpret_cast<const uint4*>(Krow + c * 32);
 #pragma unroll
       for (int q = 0; q < 4; ++q) {
         const uint4 w4 = p4[q];
         kw[4 * q] = w4.x; kw[4 * q + 1] = w4.y; kw[4 * q + 2] = w4.z; kw[4 * q + 3] = w4.w;
       }
+      k512 = (double)Krow[512] * A.kscale;
+    } else {
+      Mrow = A.Mf + (u * G.T + (fvalid ? t : 0)) * (int64_t)G.FS;
+      k512 = Mrow[512] * A.kscale;
     }
-    const double k512 = (double)Krow[512] * A.kscale;
     auto mval = [&](int e, double scale) -> double {
-      const unsigned wv = kw[e >> 1];
-      return (double)((e & 1) ? (wv >> 16) : (wv & 0xffffu)) * scale;
+      if constexpr (KMASK) {
+        const unsigned wv = kw[e >> 1];
+        return (double)((e & 1) ? (wv >> 16) : (wv & 0xffffu)) * scale;
+      } else {
+        return Mrow[bin_of_entry(c, e)] * scale;
+      }
     };
     const bool l0 = c == 0;
     const cd wlo = tw_lo[c];

@@ -11,6 +11,7 @@
 #pragma once
 #include "kernels.hpp"
 #include "czt.hpp"
+#include "nonstat_mask.hpp"   // NsTiling
 
 namespace sg {
 namespace exact {
@@ -44,6 +45,82 @@ __global__ void kx_iir_sigmoid(const double* __restrict__ P, Geom g, double b, d
     const double a = sqrt(p[t * g.FS]);
     r[t * g.FS] = 1.0 / (1.0 + exp(-((a - s) / s - nthresh) * slope));
   }
+}
+
+// The same mask tile-parallel (round 5; nonstat.hpp's scheme in double): kx_iir_sigmoid walks a band's 2579 frames
+// serially with one thread per (unit, band) -- 24 k threads on 256 CUs, 2.85 ms of a 6.7 ms call.  The recurrence is
+// linear: a tile of XIIR_TT frames contributes two numbers per band (kx_iir_part), k_iir_chain<double, true> turns them
+// into the states entering every tile, and kx_iir_apply runs both sweeps of a tile from those states with the tile's
+// magnitudes and forward values in registers -- the operations of kx_iir_sigmoid on every frame, in the same order within
+// a tile; what differs is how the state ENTERING a tile was formed (closed-form combination instead of the running
+// value: a few 1e-16 relative).
+constexpr int XIIR_TT = 32;
+__global__ __launch_bounds__(256) void kx_iir_part(const double* __restrict__ P, Geom g, NsTiling tl, double b,
+                                                   double* __restrict__ part) {
+  const unsigned FSu = (unsigned)g.FS;
+  const unsigned idx = blockIdx.x * 256u + threadIdx.x;
+  const int64_t nk = tl.n_tiles();
+  if (idx >= (unsigned)nk * FSu) return;
+  const int64_t k = idx / FSu;
+  const int f = (int)(idx % FSu);
+  if (f >= g.F) return;
+  const int64_t u = blockIdx.y;
+  const double c = 1.0 - b;
+  const double* a = P + u * g.T * g.FS + f;
+  const int64_t ts = k * XIIR_TT, te = ts + XIIR_TT < g.T ? ts + XIIR_TT : g.T;
+  double x[XIIR_TT];
+#pragma unroll
+  for (int q = 0; q < XIIR_TT; ++q) x[q] = a[(ts + q < te ? ts + q : te - 1) * g.FS];   // all loads in flight
+  double e = 0.0, E0 = 0.0, pw = b;
+#pragma unroll
+  for (int q = 0; q < XIIR_TT; ++q)
+    if (ts + q < te) {
+      e = b * sqrt(x[q]) + c * e;
+      E0 += pw * e;
+      pw *= c;
+    }
+  double* o = part + ((u * nk + k) * 2) * (int64_t)g.FS + f;
+  o[0] = e;
+  o[g.FS] = E0;
+}
+
+// carries [unit][tile][2][FS] of k_iir_chain: [0] forward state before the tile (s_f[ts - 1]), [1] backward state at its
+// end (S[te]; S[T] = s_f[T - 1])
+__global__ __launch_bounds__(256) void kx_iir_apply(const double* __restrict__ P, const double* __restrict__ carry, Geom g,
+                                                    NsTiling tl, double b, double nthresh, double slope,
+                                                    double* __restrict__ raw) {
+  const unsigned FSu = (unsigned)g.FS;
+  const unsigned idx = blockIdx.x * 256u + threadIdx.x;
+  const int64_t nk = tl.n_tiles();
+  if (idx >= (unsigned)nk * FSu) return;
+  const int64_t k = idx / FSu;
+  const int f = (int)(idx % FSu);
+  if (f >= g.F) return;
+  const int64_t u = blockIdx.y;
+  const double c = 1.0 - b;
+  const int64_t ts = k * XIIR_TT, te = ts + XIIR_TT < g.T ? ts + XIIR_TT : g.T;
+  const double* a = P + (u * g.T + ts) * g.FS + f;
+  double* r = raw + (u * g.T + ts) * g.FS + f;
+  const int n = (int)(te - ts);
+  const double* cb = carry + ((u * nk + k) * 2) * (int64_t)g.FS + f;
+  double s = cb[0];
+  double S = cb[g.FS];
+  double x[XIIR_TT], sf[XIIR_TT];
+#pragma unroll
+  for (int q = 0; q < XIIR_TT; ++q) x[q] = a[(int64_t)(q < n ? q : n - 1) * g.FS];
+#pragma unroll
+  for (int q = 0; q < XIIR_TT; ++q) {
+    x[q] = sqrt(x[q]);
+    if (q < n) s = b * x[q] + c * s;
+    sf[q] = s;
+  }
+  if (te == g.T) S = s;   // the backward pass's seed: the forward pass's last value, exactly
+#pragma unroll
+  for (int q = XIIR_TT - 1; q >= 0; --q)
+    if (q < n) {
+      S = b * sf[q] + c * S;
+      r[(int64_t)q * g.FS] = 1.0 / (1.0 + exp(-((x[q] - S) / S - nthresh) * slope));
+    }
 }
 
 // separable triangle smoothing, zero padded ("same"), float64.  TIN: float (0/1 decisions) or double (sigmoid).
@@ -87,6 +164,101 @@ __global__ void kx_smooth_t(const double* __restrict__ tmp, Geom g, int nt, int 
       edge = ef * et;
     }
     M[i] = p * acc + (1.0 - p) * edge;
+  }
+}
+
+// LDS-tiled kx_smooth_f + kx_smooth_t (k_smooth_tiled of kernels.hpp in double; round 5): one block = XT frames x XB bins of
+// one unit; raw tile (+ halo) -> LDS, f-pass LDS -> LDS, t-pass LDS -> global.  The taps are computed once per block
+// (kx_smooth_f / kx_smooth_t divide per tap and cell: 2.0 ms of a 6.7 ms non-stationary call on ten minutes of int16 audio).
+// Same sums in the same order as the two direct kernels (a = -nf .. nf, then b = -nt .. nt; taps outside the field skipped =
+// zero in the tile): identical results.
+constexpr int XSM_TT = 32, XSM_FB = 64, XSM_KMAX = 192;
+__host__ __device__ inline size_t xsm_lds_bytes(int nf, int nt) {
+  const int rows = XSM_TT + 2 * nt + 3, cols = XSM_FB + 2 * nf + 3;   // + 3: the sliding windows read 3 entries past the last tap
+  return ((size_t)rows * (cols | 1) + (size_t)rows * (XSM_FB + 1) + 2 * XSM_KMAX + XSM_FB + XSM_TT) * sizeof(double);
+}
+template <typename TIN>
+__global__ __launch_bounds__(256) void kx_smooth_tiled(const TIN* __restrict__ raw, Geom g, int nf, int nt, double p, int prop_before,
+                                                       double* __restrict__ M) {
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  const int rows = XSM_TT + 2 * nt, cols = XSM_FB + 2 * nf;
+  const int tp = (cols + 3) | 1;
+  constexpr int BP = XSM_FB + 1;
+  double* skf = reinterpret_cast<double*>(smem);   // [XSM_KMAX]
+  double* skt = skf + XSM_KMAX;                    // [XSM_KMAX]
+  double* sef = skt + XSM_KMAX;                    // [XSM_FB] conv(1) along f under zero padding
+  double* set_ = sef + XSM_FB;                     // [XSM_TT] conv(1) along t
+  double* tile = set_ + XSM_TT;                    // [rows + 3][tp]
+  double* buf = tile + (size_t)(rows + 3) * tp;    // [rows + 3][BP]
+  const int64_t u = blockIdx.z;
+  const int64_t t0 = (int64_t)blockIdx.y * XSM_TT;
+  const int f0 = blockIdx.x * XSM_FB;
+  for (int i = threadIdx.x; i < XSM_KMAX; i += 256) {
+    skf[i] = i <= 2 * nf ? tap(nf, i - nf) : 0.0;
+    skt[i] = i <= 2 * nt ? tap(nt, i - nt) : 0.0;
+  }
+  if (threadIdx.x < XSM_FB + XSM_TT) {
+    const int j = threadIdx.x;
+    double e = 0.0;
+    if (j < XSM_FB) {
+      const int f = f0 + j;
+      for (int a = -nf; a <= nf; ++a)
+        if (f + a >= 0 && f + a < g.F) e += tap(nf, a);
+      sef[j] = e;
+    } else {
+      const int64_t t = t0 + (j - XSM_FB);
+      for (int b = -nt; b <= nt; ++b)
+        if (t + b >= 0 && t + b < g.T) e += tap(nt, b);
+      set_[j - XSM_FB] = e;
+    }
+  }
+  for (int i = threadIdx.x; i < (rows + 3) * tp; i += 256) {
+    const int r = i / tp, cidx = i - r * tp;
+    const int64_t t = t0 - nt + r;
+    const int f = f0 - nf + cidx;
+    tile[i] = (r < rows && cidx < cols && t >= 0 && t < g.T && f >= 0 && f < g.F) ? (double)raw[(u * g.T + t) * g.FS + f] : 0.0;
+  }
+  __syncthreads();
+  // f-pass: item = (row, group of 4 bins), consecutive lanes take consecutive rows; FOUR adjacent outputs from a sliding
+  // register window (one LDS read per tap per four outputs); every output sums its taps in the order a = -nf .. nf
+  for (int it = threadIdx.x; it < (rows + 3) * (XSM_FB / 4); it += 256) {
+    const int r = it % (rows + 3), c0 = (it / (rows + 3)) * 4;
+    const double* src = tile + (size_t)r * tp + c0;   // src[a] = raw at bin f0 + c0 - nf + a
+    double w0 = src[0], w1 = src[1], w2 = src[2];
+    double a0 = 0.0, a1 = 0.0, a2 = 0.0, a3 = 0.0;
+    for (int a = 0; a <= 2 * nf; ++a) {
+      const double w3 = src[a + 3];
+      const double k = skf[a];
+      a0 += k * w0; a1 += k * w1; a2 += k * w2; a3 += k * w3;
+      w0 = w1; w1 = w2; w2 = w3;
+    }
+    double* dst = buf + (size_t)r * BP + c0;
+    dst[0] = a0; dst[1] = a1; dst[2] = a2; dst[3] = a3;
+  }
+  __syncthreads();
+  // t-pass: item = (group of 4 frames, bin), consecutive lanes take consecutive bins
+  for (int it = threadIdx.x; it < (XSM_TT / 4) * XSM_FB; it += 256) {
+    const int cidx = it % XSM_FB, r0 = (it / XSM_FB) * 4;
+    const int f = f0 + cidx;
+    const double* src = buf + (size_t)r0 * BP + cidx;   // src[b * BP] = frame t0 + r0 - nt + b
+    double w0 = src[0], w1 = src[BP], w2 = src[2 * BP];
+    double a0 = 0.0, a1 = 0.0, a2 = 0.0, a3 = 0.0;
+    for (int b = 0; b <= 2 * nt; ++b) {
+      const double w3 = src[(size_t)(b + 3) * BP];
+      const double k = skt[b];
+      a0 += k * w0; a1 += k * w1; a2 += k * w2; a3 += k * w3;
+      w0 = w1; w1 = w2; w2 = w3;
+    }
+    if (f >= g.F) continue;
+    const double accs[4] = {a0, a1, a2, a3};
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {
+      const int64_t t = t0 + r0 + e;
+      if (t >= g.T) break;
+      double edge = 1.0;
+      if (prop_before) edge = sef[cidx] * set_[r0 + e];
+      M[(u * g.T + t) * g.FS + f] = p * accs[e] + (1.0 - p) * edge;
+    }
   }
 }
 

@@ -133,7 +133,9 @@ struct Pow64Args {
   unsigned long long* pmax_bits;      // optional: per-(unit, band) maximum (atomic max on the bit pattern)
 };
 
-template <int WAVES, bool PMAX>
+// TS: type of the staged samples -- float (float32 / int16 recordings: exact) or double (int32 / float64 recordings: the
+// float64 pipeline of a recording whose samples have no exact float32 copy; round 5)
+template <int WAVES, bool PMAX, typename TS = float>
 __global__ __launch_bounds__(WAVES * 64, 2) void k_power_fast64(Pow64Args A) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
   cd* tw512 = reinterpret_cast<cd*>(smem);   // [32][16]: w_512^(k1 c)
@@ -168,10 +170,12 @@ __global__ __launch_bounds__(WAVES * 64, 2) void k_power_fast64(Pow64Args A) {
   // Stage the workgroup's sample span (16 frames = 19 hops) and the float64 window in the exchange region: ONE
   // global round trip for everything the gather needs; samples outside the readable range are zero
   // (view_sample), so ragged frames take the same path.  float32 samples only (the host checks): staging is float32.
-  constexpr int NFB = 4 * WAVES, SPAN = (NFB - 1) * 256 + 1024, XPITCH = 288;
-  static_assert((SPAN / 256) * XPITCH * 4 <= 24576 && 24576 + 8192 <= WAVES * 4 * FSLOTS_D * 16, "staging fits");
-  float* xs = reinterpret_cast<float*>(regions);
-  double* wl = reinterpret_cast<double*>(reinterpret_cast<char*>(regions) + 24576);
+  constexpr bool DS = sizeof(TS) == 8;
+  constexpr int NFB = 4 * WAVES, SPAN = (NFB - 1) * 256 + 1024, XPITCH = DS ? 264 : 288;
+  constexpr int WOFF = DS ? 40960 : 24576;   // the float64 window behind the staged span
+  static_assert((SPAN / 256) * XPITCH * (int)sizeof(TS) <= WOFF && WOFF + 8192 <= WAVES * 4 * FSLOTS_D * 16, "staging fits");
+  TS* xs = reinterpret_cast<TS*>(regions);
+  double* wl = reinterpret_cast<double*>(reinterpret_cast<char*>(regions) + WOFF);
   const int64_t tqb = (int64_t)blockIdx.x * NFB;
   {
     const int64_t s0b = tqb * 256 - G.padL;
@@ -184,11 +188,16 @@ __global__ __launch_bounds__(WAVES * 64, 2) void k_power_fast64(Pow64Args A) {
       double2 w2[KW];
 #pragma unroll
       for (int k = 0; k < KW; ++k) w2[k] = reinterpret_cast<const double2*>(A.win)[min(tid + k * WAVES * 64, 511)];
-      if (blk_in && (reinterpret_cast<uintptr_t>(sp) & 15) == 0) {
-        stage_span_vec<WAVES * 64, SPAN, XPITCH>(xs, sp, tid);
+      if constexpr (!DS) {
+        if (blk_in && (reinterpret_cast<uintptr_t>(sp) & 15) == 0) {
+          stage_span_vec<WAVES * 64, SPAN, XPITCH>(xs, sp, tid);
+        } else {
+          for (int i = tid; i < SPAN; i += WAVES * 64)
+            xs[(i >> 8) * XPITCH + (i & 255)] = (float)view_sample(A.view, row, chunk, s0b + i);
+        }
       } else {
         for (int i = tid; i < SPAN; i += WAVES * 64)
-          xs[(i >> 8) * XPITCH + (i & 255)] = (float)view_sample(A.view, row, chunk, s0b + i);
+          xs[(i >> 8) * XPITCH + (i & 255)] = view_sample(A.view, row, chunk, s0b + i);
       }
 #pragma unroll
       for (int k = 0; k < KW; ++k) {
@@ -206,13 +215,13 @@ __global__ __launch_bounds__(WAVES * 64, 2) void k_power_fast64(Pow64Args A) {
   // gather: v[brev(r)] = (x[2c + 32r], x[2c + 32r + 1]) * window
   cd v[32];
   {
-    const float* xl = xs + (4 * wave + g) * XPITCH + 2 * c;
+    const TS* xl = xs + (4 * wave + g) * XPITCH + 2 * c;
     const double2* wsrc = reinterpret_cast<const double2*>(wl + 2 * c);
 #pragma unroll
     for (int r = 0; r < 32; ++r) {
-      const float2 x2 = *reinterpret_cast<const float2*>(xl + (r >> 3) * XPITCH + 32 * (r & 7));
+      const TS* xp = xl + (r >> 3) * XPITCH + 32 * (r & 7);
       const double2 w2 = wsrc[16 * r];
-      v[brev<32>(r)] = {(double)x2.x * w2.x, (double)x2.y * w2.y};
+      v[brev<32>(r)] = {(double)xp[0] * w2.x, (double)xp[1] * w2.y};
     }
   }
   __syncthreads();   // every lane has its samples: the staging area becomes the exchange slices

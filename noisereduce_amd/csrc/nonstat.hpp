@@ -121,15 +121,18 @@ __global__ __launch_bounds__(256) void k_iir_comb(const double* __restrict__ sub
 
 // carries [unit][tile][2][FS]: [0] forward state before the tile's first frame (s_f[ts - 1]; s_f[-1] := A[0], the
 // lfilter_zi steady state), [1] backward state at its end (S[te]; S[T] := s_f[T - 1], the seed of the backward pass)
-__global__ __launch_bounds__(64) void k_iir_chain(const float* __restrict__ A, const double* __restrict__ part,
+// TA / SQ: the first frame's magnitude as it lies in memory -- float |X| (the fused pipeline) or double |X|^2 (SQ: the
+// float64 pipeline's power field; its tiles are tl.tt = 32 frames)
+template <typename TA, bool SQ>
+__global__ __launch_bounds__(64) void k_iir_chain(const TA* __restrict__ A, const double* __restrict__ part,
                                                   Geom g, NsTiling tl, double b, double* __restrict__ carry,
                                                   int64_t n_units) {
   const int64_t nk = tl.n_tiles();
   const int nj = (int)nk;
   const double c = 1.0 - b;
   // c^len and 1 - c^(2 len): every tile has NS_TT frames but the last (no table: an hour in one window has 10 k tiles)
-  const double len_last = (double)(g.T - (nk - 1) * NS_TT);
-  const double pf1 = pow(c, (double)NS_TT), pf2 = 1.0 - pow(c, 2.0 * NS_TT);
+  const double len_last = (double)(g.T - (nk - 1) * tl.tt);
+  const double pf1 = pow(c, (double)tl.tt), pf2 = 1.0 - pow(c, 2.0 * tl.tt);
   const double pl1 = pow(c, len_last), pl2 = 1.0 - pow(c, 2.0 * len_last);
   auto pw1 = [&](int j) { return j == nj - 1 ? pl1 : pf1; };
   auto pw2 = [&](int j) { return j == nj - 1 ? pl2 : pf2; };
@@ -141,6 +144,7 @@ __global__ __launch_bounds__(64) void k_iir_chain(const float* __restrict__ A, c
   const double* pb = part + (u * nk * 2) * (int64_t)g.FS + f;
   double* cb = carry + (u * nk * 2) * (int64_t)g.FS + f;
   double s = (double)A[u * g.T * g.FS + f];  // s[-1] = A[0]  (lfilter_zi steady state)
+  if constexpr (SQ) s = sqrt(s);
   // the chain is serial, its operands are not: the partials of the NEXT 16 tiles are in flight while this batch's
   // recurrence runs (double-buffered by hand; a batch is one dependent round trip to memory otherwise)
   const int64_t st2 = 2 * (int64_t)g.FS;

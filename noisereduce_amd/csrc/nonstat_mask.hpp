@@ -16,7 +16,8 @@ struct NsTiling {
   int64_t T;
   int nt;
   int64_t k0 = 0;   // first tile of this launch (grid.y <= 65535: very long windows take several launches)
-  __host__ __device__ int64_t n_tiles() const { return (T + NS_TT - 1) / NS_TT; }
+  int tt = NS_TT;   // frames per tile (the float64 pipeline of exact.hpp chains tiles of 32: two register rows per frame)
+  __host__ __device__ int64_t n_tiles() const { return (T + tt - 1) / tt; }
 };
 
 // sigmoid_ratio (kernels.hpp) with v_rcp_f32 in place of the two IEEE divisions (10 instructions each; the mask is a
