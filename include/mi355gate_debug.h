@@ -58,9 +58,10 @@ SG_API int sg_debug_fetch(sg_handle* h, int32_t what, void* host, int64_t bytes,
                                    * atomic on every tile's critical path (gate kernel -4.4 %), at the price of assuming that the dispatcher
                                    * starts workgroups in index order (it does on gfx950; HIP does not promise it).  Waits stay bounded and
                                    * reported either way */
-#define SG_OPT_EXACT_MATERIALISED 16 /* value != 0: the float64 pipeline (integer outputs, SG_OPT_FORCE_EXACT) always runs exact.hpp's
-                                      * materialised float64 fields, also where the fused float64 apply (k_apply_fast64: stationary gate,
-                                      * default geometry, full reduction) would do: A/B and parity of the two */
+#define SG_OPT_EXACT_MATERIALISED 16 /* value != 0: the float64 pipeline (integer outputs, SG_OPT_FORCE_EXACT) as it was before round 5 -- every
+                                      * field materialised, the recurrence serial per band, two direct smoothing passes, masked frames + gather --
+                                      * also where the fused float64 apply (k_apply_fast64), the tile-parallel recurrence and the LDS-tiled
+                                      * smoothing would do: A/B and parity of the two */
 #define SG_OPT_FORCE_NOFAST 2  /* value != 0: keep the bit-mask stages but use the general apply kernels */
 
 /* ---- per-kernel timing (bench.py's roofline leg) ------------------------------------- */

@@ -2281,7 +2281,7 @@ static int run_S_exact(sg_handle* h, View v, int64_t total_units, const OutMap& 
                          (const double*)h->pmax.p, (const double*)h->thresh.p, (int64_t)0, h->mag_scale, h->p.top_db,
                          (float*)h->xraw.p, nb);
       HIPCHK(h, hipGetLastError());
-    } else if (g.T >= 4 * exact::XIIR_TT && nb <= 65535) {
+    } else if (g.T >= 4 * exact::XIIR_TT && nb <= 65535 && !h->exact_materialised) {
       // (round 5) tile-parallel: partials of 32-frame tiles -> chain -> both sweeps per tile from the entering states
       ProfScope ps(h, SG_STAGE_NONSTAT_MASK, st);
       NsTiling tl{g.T, 0};
@@ -2313,7 +2313,7 @@ static int run_S_exact(sg_handle* h, View v, int64_t total_units, const OutMap& 
           hipLaunchKernelGGL(exact::kx_prop_only<float>, gr, dim3(256), 0, st, (const float*)h->xraw.p, g, p, (double*)h->xM.p, nb);
         else
           hipLaunchKernelGGL(exact::kx_prop_only<double>, gr, dim3(256), 0, st, (const double*)h->xraw.p, g, p, (double*)h->xM.p, nb);
-      } else if (exact::xsm_lds_bytes(nf, nt) <= 150 * 1024 && 2 * nf < exact::XSM_KMAX && 2 * nt < exact::XSM_KMAX && nb <= 65535 &&
+      } else if (!h->exact_materialised && exact::xsm_lds_bytes(nf, nt) <= 150 * 1024 && 2 * nf < exact::XSM_KMAX && 2 * nt < exact::XSM_KMAX && nb <= 65535 &&
                  (g.T + exact::XSM_TT - 1) / exact::XSM_TT <= 65535) {
         // (round 5) both passes in one LDS-tiled kernel, taps computed once per block
         const size_t lds = exact::xsm_lds_bytes(nf, nt);

@@ -169,3 +169,44 @@ def test_fused_float64_apply_sub_range(nr):
     decided = np.abs(want64 - np.round(want64)) > 1e-9
     d = part.astype(np.int64) - want64.astype(np.int16).astype(np.int64)
     assert np.abs(d).max() <= 1 and np.count_nonzero(d[decided]) == 0
+
+
+@pytest.mark.parametrize("dtype", [np.int16, np.float64])
+@pytest.mark.parametrize("kw", [dict(), dict(chunk_size=30000, padding=3000, prop_decrease=0.8),
+                                dict(stationary=True, prop_decrease=0.7, chunk_size=25000, padding=4000)])
+def test_float64_pipeline_equals_its_round4_form(nr, kw, dtype):
+    """The float64 pipeline of round 5 (tile-parallel recurrence, LDS-tiled smoothing, register float64 transform, k_apply_fast64
+    on the float64 mask field) against the materialised one it replaces (SG_OPT_EXACT_MATERIALISED: serial recurrence, two direct
+    smoothing passes, masked frames + gather): non-stationary gate, and the stationary gate with prop_decrease < 1 (which keeps
+    float64 mask fields).  float64 outputs equal to 1e-13 of peak, integer outputs equal wherever the value is not within 1e-9
+    of an integer; both against the oracle."""
+    from noisereduce_amd import _ffi
+    from noisereduce_amd.spectralgate.nonstationary import SpectralGateNonStationary
+    from noisereduce_amd.spectralgate.stationary import SpectralGateStationary
+    kw = dict(kw)
+    stationary = kw.pop("stationary", False)
+    n = 70000
+    scale = 20000 if dtype == np.int16 else 1.0
+    y = np.stack([O.synth_signal(n, seed=91 + c, tone_hz=600.0 * (c + 1)).astype(np.float64) * scale for c in range(2)])
+    y = (np.round(y) if dtype == np.int16 else y).astype(dtype)
+    base = dict(sr=48000, prop_decrease=1.0, chunk_size=600000, padding=30000, n_fft=1024, win_length=None, hop_length=None,
+                time_constant_s=2.0, freq_mask_smooth_hz=500, time_mask_smooth_ms=50, tmp_folder=None, use_tqdm=False, n_jobs=1)
+    base.update(kw)
+    if stationary:
+        sg = SpectralGateStationary(y=y, y_noise=None, n_std_thresh_stationary=1.5, clip_noise_stationary=True, precision="float64", **base)
+    else:
+        sg = SpectralGateNonStationary(y=y, thresh_n_mult_nonstationary=2, sigmoid_slope_nonstationary=10, precision="float64", **base)
+    new = sg.get_traces()
+    with sg._gate.with_options([(_ffi.SG_OPT_EXACT_MATERIALISED, 1)]):
+        old = sg.get_traces()
+    okw = {k: base[k] for k in ("chunk_size", "padding", "prop_decrease")}
+    want64 = O.reduce_noise_S(y.astype(np.float64), 48000, stationary=stationary, **okw)
+    if dtype == np.float64:
+        peak = np.abs(want64).max()
+        assert np.abs(new - old).max() <= 1e-13 * peak
+        assert np.abs(new - want64).max() <= 1e-12 * peak
+    else:
+        decided = np.abs(want64 - np.round(want64)) > 1e-9
+        for got in (new, old):
+            d = got.astype(np.int64) - want64.astype(dtype).astype(np.int64)
+            assert np.abs(d).max() <= 1 and np.count_nonzero(d[decided]) == 0
