@@ -1524,10 +1524,12 @@ __global__ __launch_bounds__(WAVES * 64, 3) void k_mag_fast(MagArgs A) {
   }
   auto sel = [&](cf a0, cf a1) -> cf { return {l0 ? a0.x : a1.x, l0 ? a0.y : a1.y}; };
   float* mrow = A.mag + (u * G.T + (fvalid ? t : 0)) * (int64_t)G.FS;
+  // (with_sub: the rows go to the block's LDS tile only and are written to the field from there, 16 bytes per lane and
+  // store, after the barrier below -- 2 stores per lane and frame row instead of 33 four-byte ones scattered over 64-byte runs)
   auto put = [&](int e, float P4) {  // |X| = sqrt(P4) / 2 at the bin of entry e
     const float m = half_sqrt(P4);
-    if (fvalid) mrow[bin_of_entry(c, e)] = m;
     if (with_sub) trow[bin_of_entry(c, e)] = m;   // (the wave's own exchange slice: its transform is done)
+    else if (fvalid) mrow[bin_of_entry(c, e)] = m;
   };
   auto pair_power = [&](cf a, cf b, cf w, float& Pk, float& Pn) {
     cf p, q;
@@ -1543,8 +1545,8 @@ __global__ __launch_bounds__(WAVES * 64, 3) void k_mag_fast(MagArgs A) {
     const float P256 = 4.f * (v[8].x * v[8].x + v[8].y * v[8].y);
     put(0, l0 ? x0 * x0 : Pk);
     put(31, l0 ? P256 : Pn);
-    if (l0 && fvalid) mrow[512] = 0.5f * fabsf(xN);
     if (l0 && with_sub) trow[512] = 0.5f * fabsf(xN);
+    else if (l0 && fvalid) mrow[512] = 0.5f * fabsf(xN);
   }
 #pragma unroll
   for (int sl = 1; sl < 16; ++sl) {
@@ -1562,6 +1564,19 @@ __global__ __launch_bounds__(WAVES * 64, 3) void k_mag_fast(MagArgs A) {
   __syncthreads();
   {
     const int n = (int)min<int64_t>((int64_t)NFB, G.T - tqb);   // frames of this block inside the unit
+    // the block's |X| rows: LDS tile -> field, coalesced (row r of the tile = frame tqb + r; 128 float4 + bin 512 per row)
+    {
+      float* mbase = A.mag + (u * G.T + tqb) * (int64_t)G.FS;
+      for (int i = tid; i < n * 128; i += WAVES * 64) {
+        const int r = i >> 7, q = i & 127;
+        const float* rowp = reinterpret_cast<const float*>(regions + (r >> 2) * WAVE_CX_H) + (r & 3) * MAG_TILE_PITCH;
+        *reinterpret_cast<float4*>(mbase + (int64_t)r * G.FS + 4 * q) = *reinterpret_cast<const float4*>(rowp + 4 * q);
+      }
+      if (tid < n) {
+        const float* rowp = reinterpret_cast<const float*>(regions + (tid >> 2) * WAVE_CX_H) + (tid & 3) * MAG_TILE_PITCH;
+        mbase[(int64_t)tid * G.FS + 512] = rowp[512];
+      }
+    }
     const double b = A.iir_b, cc = 1.0 - b;
     static_assert(WAVES * 64 == 256, "bins tid, tid + 256 and (thread 0) 512");
     // three independent chains per thread, interleaved (the recurrence is serial in t, float64 fma latency ~8 cycles)

@@ -427,6 +427,7 @@ class ChannelShardedStationary:
         self.backend = backend
         self.group = group
         self.ws = dist.get_world_size(group) if dist.is_initialized() else 1
+        self._last_count = None   # all-reduced channel count of the last run() (device tensor), for check_channel_total
 
     def run(self, y_local, c_total=None, timing=None):
         """y_local: this rank's (C_local, N) channels -- C_local may differ between ranks and may be 0 (more ranks than
@@ -475,6 +476,8 @@ class ChannelShardedStationary:
     def check_channel_total(self, c_total):
         """After run(): the all-reduced channel count of the last call equals `c_total` (synchronises; every rank reads
         the same number, so every rank raises -- or none does)."""
+        if self._last_count is None:
+            raise RuntimeError("check_channel_total: no run() with y_noise=None has taken place on this object yet")
         got = int(round(float(self._last_count.item())))
         if got != int(c_total):
             raise ValueError(f"channel-sharded gate: the ranks hold {got} channels in total, caller said {c_total}")
