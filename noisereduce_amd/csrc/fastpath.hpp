@@ -720,6 +720,35 @@ __global__ __launch_bounds__(WAVES * 64, LEAN ? 3 : 2) void k_apply_fast(ApplyAr
         }
       }
       k512 = (float)Krow[512] * A.kscale;
+    } else if constexpr (LEAN) {
+      // (round 5) natural bin order, through the wave's idle exchange slice: the four mask rows of a wave are ONE contiguous
+      // 8448-byte block of the field (frames tq .. tq + 3, pitch FSK) -- nine 16-byte loads per lane, then the 33 entries
+      // from LDS (pitch 528 floats: the four lane groups read disjoint banks) instead of 33 four-byte global loads per
+      // lane in 64-byte runs.  Called between the two transforms: the slice is free.
+      float* mt = reinterpret_cast<float*>(regions + wave * WAVE_CX_H);
+      static_assert(4 * FSK * 4 <= WAVE_CX_H * 8, "four mask rows fit the wave's exchange slice");
+      const int64_t tq0 = tf_tile + 4 * wave;
+      const float* Mu = A.Mf + (u * G.T) * (int64_t)FSK;
+      constexpr int R4 = FSK / 4;                    // float4 per row
+      auto ldrow = [&](int i) -> float4 {
+        const int r = i / R4, j = i - r * R4;
+        int64_t tr = tq0 + r;
+        tr = tr < 0 ? 0 : (tr >= G.T ? G.T - 1 : tr);   // frames outside the unit: any row (their spectra are zero)
+        return reinterpret_cast<const float4*>(Mu + tr * (int64_t)FSK)[j];
+      };
+      static_assert(4 * R4 == 8 * 64 + 16, "eight full passes of the wave + 16 lanes");
+      const float4 q0 = ldrow(lane), q1 = ldrow(lane + 64), q2 = ldrow(lane + 128), q3 = ldrow(lane + 192), q4 = ldrow(lane + 256),
+                   q5 = ldrow(lane + 320), q6 = ldrow(lane + 384), q7 = ldrow(lane + 448), q8 = ldrow(512 + (lane & 15));
+      float4* mt4 = reinterpret_cast<float4*>(mt);
+      mt4[lane] = q0; mt4[lane + 64] = q1; mt4[lane + 128] = q2; mt4[lane + 192] = q3; mt4[lane + 256] = q4;
+      mt4[lane + 320] = q5; mt4[lane + 384] = q6; mt4[lane + 448] = q7;
+      if (lane < 16) mt4[512 + lane] = q8;
+      wave_lds_sync();
+      const float* Mrow = mt + g * FSK;
+#pragma unroll
+      for (int e = 0; e < 32; ++e) mf[e] = Mrow[bin_of_entry(c, e)];
+      k512 = Mrow[512] * A.kscale;
+      wave_lds_sync();   // every lane has its entries: the inverse transform may overwrite the slice
     } else {
       // natural bin order: the 16 lanes of a frame read one 64-byte run per slot
       const float* Mrow = A.Mf + ((u * G.T + (fvalid ? t : 0)) * (int64_t)FSK);
