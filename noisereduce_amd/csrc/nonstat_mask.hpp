@@ -132,6 +132,7 @@ __device__ __forceinline__ void ns_mask_tile(const float* __restrict__ A, const 
     }
   }
   // ---- smoothing along t: triangle = boxcar(NT+1) * boxcar(NT+1); y[i] = sum_{e<=NT} B[i+e], B[r] = sum_{d<=NT} x[r+d]
+#ifndef NS_ABLATE_TSMOOTH   // (development: -DNS_ABLATE_TSMOOTH removes this stage to measure what it costs; results are wrong)
   {
     constexpr int W = NT + 1, NB = NS_TT + NT;
     double acc = 0.0;
@@ -156,6 +157,7 @@ __device__ __forceinline__ void ns_mask_tile(const float* __restrict__ A, const 
       acc += bn - bo;
     }
   }
+#endif
   // ---- smoothing along f through the wave + prop_decrease (applied AFTER smoothing, nonstationary.py:78-84).
   // The normalised triangle of half-width nf is boxcar(nf+1) * boxcar(nf+1) / (nf+1)^2 (utils.py:45-60: linspace
   // ramps k / (nf+1), divided by their sum nf+1), and a full-wave lane shift by one is a DPP modifier of the VALU add
