@@ -2127,6 +2127,9 @@ static int stage_apply_fast64(sg_handle* h, const View& v, const Geom& g, int64_
   A.norm = (const double*)h->norm64.p;
   A.tw1024 = (const fast::cd*)h->tw64.p;
   A.kscale = mask_f64 ? 1.0 / 512.0 : 1.0 / ((double)h->ktot * 512.0);
+  A.prop = h->p.prop_decrease;
+  A.nf = h->p.smooth_mask ? h->p.n_grad_freq : 0;
+  A.nt = h->p.smooth_mask ? h->p.n_grad_time : 0;
   A.h_begin = (om.p0 + g.padL) / 256;
   A.h_end = (om.p1 - 1 + g.padL) / 256 + 1;
   const int64_t nh = A.h_end - A.h_begin;
@@ -2152,7 +2155,7 @@ static int stage_apply_fast64(sg_handle* h, const View& v, const Geom& g, int64_
 // precision="float64" take it; everything else of the float64 contract stays on run_S_exact.
 static bool exact_fused_ok(const sg_handle* h, const Geom& g) {
   return h->p.stationary && h->fused_ok && !h->force_unfused && h->fast_ok && !h->force_nofast && !h->force_f64_decide &&
-         h->p.prop_decrease == 1.0 && g.F == 513 && h->norm64.p != nullptr && !h->exact_materialised;
+         g.F == 513 && h->norm64.p != nullptr && !h->exact_materialised;   // (any prop_decrease: k_apply_fast64 forms p K + (1 - p) edge)
 }
 
 static int run_S_exact_fused(sg_handle* h, View v, int64_t total_units, const OutMap& om, hipStream_t st) {

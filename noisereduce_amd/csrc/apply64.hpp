@@ -165,6 +165,11 @@ struct Apply64Args {
   const double* norm;        // sum_q win^2[256 q + s], s < 256 (interior hops)
   const cd* tw1024;          // w_1024^k, k = 0..511
   double kscale;             // KMASK: 1 / (ktot * 512); !KMASK: 1 / 512
+  // KMASK, prop_decrease < 1 (stationary.py:108-114 applies it BEFORE the zero-padded smoothing): mask = (p K + (1 - p) edge) / ktot,
+  // edge = the smoothing filter's integer weight inside the spectrogram, ef(f) * et(t) -- (nf+1)^2 (nt+1)^2 = ktot except within
+  // nf bins / nt frames of its borders.  prop = 1: mask = K / ktot.
+  double prop;
+  int nf, nt;
   int64_t h_begin, h_end;    // ext hops (256-sample blocks, ext = unit sample + 512) to produce
 };
 
@@ -264,10 +269,22 @@ __global__ __launch_bounds__(WAVES * 64, 2) void k_apply_fast64(Apply64Args A) {
       Mrow = A.Mf + (u * G.T + (fvalid ? t : 0)) * (int64_t)G.FS;
       k512 = Mrow[512] * A.kscale;
     }
+    // integer weight of the valid taps along one axis at position i of n (closed form of the triangle's tails)
+    auto edge1 = [](int m, int64_t i, int64_t n) -> double {
+      const int64_t l = i < m ? m - i : 0, r = (n - 1 - i) < m ? m - (n - 1 - i) : 0;
+      return (double)((int64_t)(m + 1) * (m + 1) - l * (l + 1) / 2 - r * (r + 1) / 2);
+    };
+    const bool with_prop = KMASK && A.prop != 1.0;
+    const double q_et = with_prop ? (1.0 - A.prop) * edge1(A.nt, fvalid ? t : 0, G.T) : 0.0;
+    if constexpr (KMASK) {
+      if (with_prop) k512 = (A.prop * (double)(A.K + ((u * G.T + (fvalid ? t : 0)) * (int64_t)FSK))[512] + q_et * edge1(A.nf, 512, G.F)) * A.kscale;
+    }
     auto mval = [&](int e, double scale) -> double {
       if constexpr (KMASK) {
         const unsigned wv = kw[e >> 1];
-        return (double)((e & 1) ? (wv >> 16) : (wv & 0xffffu)) * scale;
+        const double kv = (double)((e & 1) ? (wv >> 16) : (wv & 0xffffu));
+        if (with_prop) return (A.prop * kv + q_et * edge1(A.nf, bin_of_entry(c, e), G.F)) * scale;
+        return kv * scale;
       } else {
         return Mrow[bin_of_entry(c, e)] * scale;
       }
