@@ -1032,8 +1032,19 @@ def extras(device, wl, out, y2d, gate, O):
     medh = float(np.median(ts[2:]))
     oc["config2_numpy_to_numpy_pcie_inclusive"] = {
         "ms_median": round(medh * 1e3, 3), "Msamples_s": round(yh.size / medh / 1e6, 1),
-        "what": "host float32 array in, host array out (63 GB/s PCIe each way bounds this at 7.9 Gsamples/s); "
-                "never the headline value"}
+        "what": "host float32 array in, host array out: the recording goes up in pieces while the previous piece is gated "
+                "with its output stored straight into the page-locked result (spectralgate/base.py _get_traces_pipelined; "
+                "profiles/r05_pcie_overlap.txt: 56 GB/s one way alone, ~40 GB/s each way at once); never the headline value"}
+    os.environ["NOISEREDUCE_AMD_PIPELINE"] = "0"
+    try:
+        ts = []
+        for i in range(7):
+            t0 = time.perf_counter()
+            nr.reduce_noise(y=yh, sr=SR, stationary=True)
+            ts.append(time.perf_counter() - t0)
+        oc["config2_numpy_to_numpy_pcie_inclusive"]["ms_median_one_upload"] = round(float(np.median(ts[2:])) * 1e3, 3)
+    finally:
+        del os.environ["NOISEREDUCE_AMD_PIPELINE"]
     res["other_configs"] = oc
     return res
 

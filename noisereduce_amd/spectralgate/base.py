@@ -26,6 +26,18 @@ def _smoothing_filter(n_grad_freq, n_grad_time):
     return f / np.sum(f)
 
 
+_PIPE_STREAMS = {}
+
+
+def _pipe_stream(dev):
+    """The upload side stream of a device, created once."""
+    key = (dev.type, dev.index)
+    st = _PIPE_STREAMS.get(key)
+    if st is None:
+        st = _PIPE_STREAMS[key] = torch.cuda.Stream(dev)
+    return st
+
+
 _DEVICE_DTYPES = {
     np.dtype(np.float32): torch.float32, np.dtype(np.float64): torch.float64,
     np.dtype(np.int16): torch.int16, np.dtype(np.int32): torch.int32,
@@ -77,6 +89,7 @@ class SpectralGate:
 
         self.device = _ffi.resolve_device(device)
         self._y_dev = None
+        self._pipe = None      # state of a pipelined upload in progress (_pipeline_begin)
         self._gate = None
 
     # -- filter design (base.py:99-128) ---------------------------------------------------
@@ -125,6 +138,8 @@ class SpectralGate:
         return torch.from_numpy(np.ascontiguousarray(a)).to(self.device)
 
     def _device_y(self):
+        if self._pipe is not None:
+            self._pipeline_finish()
         if self._y_dev is None:
             self._y_dev = self._to_device(self.y)
         return self._y_dev
@@ -190,10 +205,122 @@ class SpectralGate:
         """Load per-object state into the shared engine handle (stationary gate: its threshold)."""
 
 
+    # -- host arrays: upload / compute / download in pieces, overlapped (SURVEY.md 8 row f2) ----------
+    # The reference streams chunks through a memmap (base.py:180-216).  Here a host recording crosses PCIe twice, and done one
+    # after the other -- upload everything, gate, download everything -- a ten-minute float32 recording takes 4.5 ms of which
+    # 0.3 is compute.  PCIe is full duplex, so the recording goes up in chunk-aligned pieces on a side stream while, on the
+    # caller's stream, the previous piece is gated (a start_frame / end_frame range of the one device copy: the chunk grid is
+    # the reference's, every output bit that of the one-upload path) with the kernels STORING STRAIGHT INTO THE PAGE-LOCKED
+    # RESULT ARRAY.  Measured (tools/ubench/pcie_*.py, profiles/r05_pcie_overlap.txt): a runtime device-to-host copy next to
+    # an upload halves the upload's rate whatever the streams, piece size or synchronisation (the two copies serialise);
+    # stores issued by a kernel do overlap it.  The first and last pieces are short: they are the two that run alone.
+    _PIPE_PIECE_BYTES = 24 << 20
+    _PIPE_MIN_PIECES = 3
+
+    def _pipeline_pieces(self):
+        """[(p0, p1), ...] chunk-aligned pieces of a host recording worth pipelining, else None."""
+        import os
+        if self._tensor_io or os.environ.get("NOISEREDUCE_AMD_PIPELINE", "1") == "0":
+            return None
+        if self._chunk_size is None or np.dtype(self._dtype) not in _DEVICE_DTYPES or not isinstance(self.y, np.ndarray):
+            return None
+        cs, N = int(self._chunk_size), int(self.n_frames)
+        n_chunks = -(-N // cs)
+        piece_bytes = int(os.environ.get("NOISEREDUCE_AMD_PIPELINE_PIECE_BYTES", self._PIPE_PIECE_BYTES))
+        k = max(1, piece_bytes // (self.n_channels * cs * np.dtype(self._dtype).itemsize))
+        short = max(1, k // 4)
+        sizes, left = [short], n_chunks - short
+        while left > k + short:
+            sizes.append(k)
+            left -= k
+        if left > short:
+            sizes.append(left - short)
+            left = short
+        if left > 0:
+            sizes.append(left)
+        if len(sizes) < self._PIPE_MIN_PIECES:
+            return None
+        pieces, p0 = [], 0
+        for n in sizes:
+            pieces.append((p0, min(p0 + n * cs, N)))
+            p0 += n * cs
+        return pieces
+
+    def _pipeline_begin(self):
+        """Allocate the device copy and send up the first piece (with its right halo); the stationary gate takes its noise
+        statistics from it.  None when the recording is not worth pipelining."""
+        pieces = self._pipeline_pieces()
+        if pieces is None:
+            return None
+        dev, N, C = self.device, int(self.n_frames), int(self.n_channels)
+        with torch.cuda.device(dev):
+            cur, up = torch.cuda.current_stream(dev), _pipe_stream(dev)
+            x_dev = torch.empty((C, N), dtype=_DEVICE_DTYPES[np.dtype(self._dtype)], device=dev)
+            up.wait_stream(cur)     # (the allocator may have handed back memory that work queued on `cur` still reads)
+        self._pipe = dict(pieces=pieces, x_dev=x_dev, sent=0)
+        self._pipeline_upload(0)
+        return x_dev
+
+    def _pipeline_upload(self, i):
+        """Piece i's samples and right halo (its left halo came with piece i - 1).  Blocks this thread until they are up."""
+        st = self._pipe
+        N, pad = int(self.n_frames), int(self.padding)
+        b = min(N, st["pieces"][i][1] + pad)
+        a = st["sent"]
+        if b > a:
+            up = _pipe_stream(self.device)
+            with torch.cuda.device(self.device), torch.cuda.stream(up):
+                st["x_dev"][:, a:b].copy_(torch.from_numpy(self.y[:, a:b]), non_blocking=True)
+            up.synchronize()
+            st["sent"] = b
+
+    def _get_traces_pipelined(self):
+        """None if the result array could not be page-locked (then the one-upload path is the faster one)."""
+        st = self._pipe
+        pieces, x_dev = st["pieces"], st["x_dev"]
+        out, out_t = _hostbuf.result_array((int(self.n_channels), int(self.n_frames)), self._dtype)
+        if not out_t.is_pinned():
+            return None
+        with torch.cuda.device(self.device), self._gate.lock:
+            try:    # an error left by an earlier unchecked call on this shared handle is that call's (Gate.run_checked)
+                self._gate.check_errors()
+            except _ffi.HandoffTimeout as e:
+                raise RuntimeError("an earlier, unchecked call on this engine handle lost a tile hand-off (its output "
+                                   "is invalid); this call has not run: " + str(e)) from None
+            for i, (p0, p1) in enumerate(pieces):
+                self._bind()
+                # out: the page-locked host array itself (device-visible at the same address)
+                self._gate.process_chunks(x_dev, out=out_t[:, p0:p1], start_frame=p0, end_frame=p1, chunked=True)
+                if i + 1 < len(pieces):
+                    self._pipeline_upload(i + 1)       # piece i is being gated and stored to the host meanwhile
+            self._gate.check_errors()   # synchronises; HandoffTimeout -> the caller re-runs on the plain path
+        return out.reshape(-1) if self.flat else out
+
+    def _pipeline_finish(self):
+        """Whatever happened, leave the object with a complete device copy (later calls and the plain path use it)."""
+        st = self._pipe
+        if st is not None:
+            self._pipeline_upload(len(st["pieces"]) - 1)     # sends whatever has not gone up yet
+            self._pipe = None
+            self._y_dev = st["x_dev"]
+
     def get_traces(self, start_frame=None, end_frame=None):
         """Grab filtered data iterating over chunks (base.py:167-226) -- on the device."""
         if self._gate is None:
             raise NotImplementedError
+        if self._pipe is None and self._y_dev is None and start_frame is None and end_frame is None:
+            self._pipeline_begin()
+        if self._pipe is not None:
+            try:
+                if start_frame is None and end_frame is None:
+                    try:
+                        out = self._get_traces_pipelined()
+                        if out is not None:
+                            return out
+                    except _ffi.HandoffTimeout:
+                        pass    # (rare: a fused kernel's bounded wait timed out) the plain path below checks and re-runs
+            finally:
+                self._pipeline_finish()
         if start_frame is None:
             start_frame = 0
         if end_frame is None:

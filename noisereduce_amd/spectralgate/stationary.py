@@ -23,7 +23,10 @@ class SpectralGateStationary(SpectralGate):
 
         # noise clip, (channels, frames)  (stationary.py:47-58)
         if y_noise is None:
-            noise_dev = self._device_y()
+            # a host recording that get_traces will stream in pieces: the statistics only need its first chunk_size samples,
+            # which arrive with the first piece
+            x_dev = self._pipeline_begin() if clip_noise_stationary and chunk_size is not None else None
+            noise_dev = x_dev if x_dev is not None else self._device_y()
         else:
             if not isinstance(y_noise, torch.Tensor):
                 y_noise = np.asarray(y_noise)

@@ -1,0 +1,82 @@
+"""Host arrays in / out: the recording crosses PCIe in chunk-aligned pieces, overlapped with the gate
+(noisereduce_amd/spectralgate/base.py: _get_traces_pipelined; SURVEY.md 8 row f2 -- the reference's chunk loop over a
+memmap, base.py:180-216).  Each piece is gated as a start_frame / end_frame range of the one device copy, so the chunk grid
+-- and every output bit -- is that of the one-upload path."""
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+
+def _rec(n, c, dtype, seed):
+    rng = np.random.default_rng(seed)
+    t = np.arange(n) / 48000.0
+    y = 0.1 * rng.standard_normal((c, n)) + 0.4 * np.sin(2 * np.pi * 700.0 * t)[None, :]
+    if np.dtype(dtype).kind == "i":
+        return (y * 12000).astype(dtype)
+    return y.astype(dtype)
+
+
+@pytest.mark.parametrize("stationary", [True, False])
+@pytest.mark.parametrize("dtype,c,n", [
+    (np.float32, 1, 600000 * 7 + 12345),     # ragged last piece
+    (np.float32, 2, 600000 * 10),            # two channels (strided host slices), exact multiple
+    (np.int16, 1, 600000 * 9 + 1),           # integer recording (float64 pipeline), one-sample tail
+    (np.float64, 1, 600000 * 9 + 777),
+])
+def test_pipelined_host_path_is_the_one_upload_path_bit_for_bit(monkeypatch, stationary, dtype, c, n):
+    import noisereduce_amd as nr
+    from noisereduce_amd.spectralgate import base
+    y = _rec(n, c, dtype, 5)
+    y = y[0] if c == 1 else y
+    monkeypatch.setenv("NOISEREDUCE_AMD_PIPELINE", "0")
+    ref = nr.reduce_noise(y=y, sr=48000, stationary=stationary)
+    monkeypatch.setenv("NOISEREDUCE_AMD_PIPELINE", "1")
+    # small pieces: one, two and three chunks per piece
+    for piece_chunks in (1, 2, 3):
+        monkeypatch.setenv("NOISEREDUCE_AMD_PIPELINE_PIECE_BYTES", str(piece_chunks * 600000 * c * np.dtype(dtype).itemsize))
+        calls = []
+        orig = base.SpectralGate._get_traces_pipelined
+        def counted(self):
+            out = orig(self)
+            calls.append((len(self._pipe["pieces"]), out is not None))
+            return out
+        monkeypatch.setattr(base.SpectralGate, "_get_traces_pipelined", counted)
+        got = nr.reduce_noise(y=y, sr=48000, stationary=stationary)
+        monkeypatch.setattr(base.SpectralGate, "_get_traces_pipelined", orig)
+        assert calls and calls[0][0] >= 3 and calls[0][1], "the pipelined path did not run"
+        assert got.dtype == ref.dtype and got.shape == ref.shape
+        assert np.array_equal(got, ref), (piece_chunks, int(np.argmax(got != ref)))
+
+
+def test_pipelined_path_default_piece_size_and_fallbacks(monkeypatch):
+    import noisereduce_amd as nr
+    from noisereduce_amd.spectralgate.stationary import SpectralGateStationary
+    y = _rec(600000 * 40, 1, np.float32, 9)[0]
+    kw = dict(y=y, sr=48000, y_noise=None, prop_decrease=1.0, time_constant_s=2.0, freq_mask_smooth_hz=500,
+              time_mask_smooth_ms=50, n_std_thresh_stationary=1.5, tmp_folder=None, chunk_size=600000, padding=30000,
+              n_fft=1024, win_length=None, hop_length=None, clip_noise_stationary=True, use_tqdm=False, n_jobs=1)
+    sg = SpectralGateStationary(**kw)
+    pieces = sg._pipeline_pieces()
+    assert sg._pipe is not None and sg._pipe["sent"] == 1200000 + 30000, "the constructor sends up the first piece only"
+    assert [(b - a) // 600000 for a, b in pieces] == [2, 10, 10, 10, 6, 2] and pieces[0][0] == 0 and pieces[-1][1] == y.size
+    assert sg._y_dev is None, "the constructor uploaded the whole recording"
+    a = sg.get_traces()
+    assert sg._pipe is None and sg._y_dev is not None and sg._y_dev.shape == (1, y.size)
+    assert np.array_equal(sg._y_dev.cpu().numpy()[0], y)
+    # a sub-range request, a short recording and clip_noise_stationary=False all take the one-upload path
+    sub = sg.get_traces(start_frame=600000, end_frame=1800000)
+    assert np.array_equal(sub, a[600000:1800000])
+    assert SpectralGateStationary(**dict(kw, y=y[:1500000]))._pipeline_pieces() is None
+    sg2 = SpectralGateStationary(**dict(kw, clip_noise_stationary=False))
+    assert sg2._y_dev is not None and sg2._pipe is None
+    # a sub-range asked of an object whose upload is in flight: the rest goes up, then the one-upload path
+    sg3 = SpectralGateStationary(**kw)
+    assert np.array_equal(sg3.get_traces(start_frame=600000, end_frame=1800000), a[600000:1800000]) and sg3._pipe is None
+    # the operator seam on such an object
+    sg4 = SpectralGateStationary(**kw)
+    ch = sg4.filter_chunk(600000, 1200000)
+    assert np.allclose(ch[0], a[600000:1200000], atol=2e-6)
+    assert np.array_equal(sg4._device_y().cpu().numpy()[0], y) and sg4._pipe is None    # (the device copy on demand: the rest goes up)
+    monkeypatch.setenv("NOISEREDUCE_AMD_PIPELINE", "0")
+    assert np.array_equal(SpectralGateStationary(**kw).get_traces(), a)
