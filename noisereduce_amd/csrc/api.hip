@@ -2324,11 +2324,11 @@ static int run_S_exact(sg_handle* h, View v, int64_t total_units, const OutMap& 
         if (h->p.stationary) {
           auto kern = exact::kx_smooth_tiled<float>;
           HIPCHK(h, set_lds(reinterpret_cast<const void*>(kern), lds));
-          hipLaunchKernelGGL(kern, gt, dim3(256), lds, st, (const float*)h->xraw.p, g, nf, nt, p, prop_before, (double*)h->xM.p);
+          hipLaunchKernelGGL(kern, gt, dim3(exact::XSM_THREADS), lds, st, (const float*)h->xraw.p, g, nf, nt, p, prop_before, (double*)h->xM.p);
         } else {
           auto kern = exact::kx_smooth_tiled<double>;
           HIPCHK(h, set_lds(reinterpret_cast<const void*>(kern), lds));
-          hipLaunchKernelGGL(kern, gt, dim3(256), lds, st, (const double*)h->xraw.p, g, nf, nt, p, prop_before, (double*)h->xM.p);
+          hipLaunchKernelGGL(kern, gt, dim3(exact::XSM_THREADS), lds, st, (const double*)h->xraw.p, g, nf, nt, p, prop_before, (double*)h->xM.p);
         }
       } else {
         if (h->p.stationary)

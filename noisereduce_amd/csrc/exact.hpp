@@ -172,15 +172,28 @@ __global__ void kx_smooth_t(const double* __restrict__ tmp, Geom g, int nt, int 
 // (kx_smooth_f / kx_smooth_t divide per tap and cell: 2.0 ms of a 6.7 ms non-stationary call on ten minutes of int16 audio).
 // Same sums in the same order as the two direct kernels (a = -nf .. nf, then b = -nt .. nt; taps outside the field skipped =
 // zero in the tile): identical results.
+// The kernel is latency-bound (three barrier-separated phases, 64 KB of LDS: two blocks per CU), so it runs 1024 threads per
+// block (1.01 ms with 256 threads and one dependent LDS read per tap -> 0.73 with four taps per step at 512 threads -> 0.55 at
+// 1024 -> 0.50 with one t-pass item per thread and the row loads of the tile issued together; ten minutes of 48 kHz).
 constexpr int XSM_TT = 32, XSM_FB = 64, XSM_KMAX = 192;
 __host__ __device__ inline size_t xsm_lds_bytes(int nf, int nt) {
   const int rows = XSM_TT + 2 * nt + 3, cols = XSM_FB + 2 * nf + 3;   // + 3: the sliding windows read 3 entries past the last tap
   return ((size_t)rows * (cols | 1) + (size_t)rows * (XSM_FB + 1) + 2 * XSM_KMAX + XSM_FB + XSM_TT) * sizeof(double);
 }
+// One sliding step of FOUR adjacent outputs over FOUR consecutive taps (k[0..3]; inputs w0..w2 carried in, w3..w6 fresh):
+// every output still sums its taps in ascending order, one fused multiply-add per tap -- the sums of the one-tap loop, without
+// its register rotation (three 64-bit moves per tap) and with four LDS reads in flight instead of one dependent read per tap.
+#define XSM_STEP4(k, w0, w1, w2, w3, w4, w5, w6) \
+  a0 += k[0] * w0; a1 += k[0] * w1; a2 += k[0] * w2; a3 += k[0] * w3; \
+  a0 += k[1] * w1; a1 += k[1] * w2; a2 += k[1] * w3; a3 += k[1] * w4; \
+  a0 += k[2] * w2; a1 += k[2] * w3; a2 += k[2] * w4; a3 += k[2] * w5; \
+  a0 += k[3] * w3; a1 += k[3] * w4; a2 += k[3] * w5; a3 += k[3] * w6;
+constexpr int XSM_THREADS = 1024;
 template <typename TIN>
-__global__ __launch_bounds__(256) void kx_smooth_tiled(const TIN* __restrict__ raw, Geom g, int nf, int nt, double p, int prop_before,
-                                                       double* __restrict__ M) {
+__global__ __launch_bounds__(XSM_THREADS) void kx_smooth_tiled(const TIN* __restrict__ raw, Geom g, int nf, int nt, double p, int prop_before,
+                                                               double* __restrict__ M) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
+  constexpr int NTHR = XSM_THREADS;
   const int rows = XSM_TT + 2 * nt, cols = XSM_FB + 2 * nf;
   const int tp = (cols + 3) | 1;
   constexpr int BP = XSM_FB + 1;
@@ -193,11 +206,27 @@ __global__ __launch_bounds__(256) void kx_smooth_tiled(const TIN* __restrict__ r
   const int64_t u = blockIdx.z;
   const int64_t t0 = (int64_t)blockIdx.y * XSM_TT;
   const int f0 = blockIdx.x * XSM_FB;
-  for (int i = threadIdx.x; i < XSM_KMAX; i += 256) {
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  // raw tile: a wave per row, lanes along the bins (coalesced 512-byte reads; no division per element)
+  for (int r = wave; r < rows + 3; r += NTHR / 64) {
+    const int64_t t = t0 - nt + r;
+    const bool rv = r < rows && t >= 0 && t < g.T;
+    const TIN* src = raw + (u * g.T + (rv ? t : 0)) * g.FS;
+    // (clamped loads issued together, selected afterwards: the row's two column passes are in flight at once)
+    const int fa = f0 - nf + lane, fb = fa + 64;
+    const TIN va = src[min(max(fa, 0), g.F - 1)], vb = src[min(max(fb, 0), g.F - 1)];
+    tile[r * tp + lane] = (rv && lane < cols && fa >= 0 && fa < g.F) ? (double)va : 0.0;
+    if (lane + 64 < tp) tile[r * tp + lane + 64] = (rv && lane + 64 < cols && fb >= 0 && fb < g.F) ? (double)vb : 0.0;
+    for (int cidx = lane + 128; cidx < tp; cidx += 64) {
+      const int f = f0 - nf + cidx;
+      tile[r * tp + cidx] = (rv && cidx < cols && f >= 0 && f < g.F) ? (double)src[f] : 0.0;
+    }
+  }
+  for (int i = threadIdx.x; i < XSM_KMAX; i += NTHR) {
     skf[i] = i <= 2 * nf ? tap(nf, i - nf) : 0.0;
     skt[i] = i <= 2 * nt ? tap(nt, i - nt) : 0.0;
   }
-  if (threadIdx.x < XSM_FB + XSM_TT) {
+  if (prop_before && threadIdx.x < XSM_FB + XSM_TT) {
     const int j = threadIdx.x;
     double e = 0.0;
     if (j < XSM_FB) {
@@ -212,21 +241,23 @@ __global__ __launch_bounds__(256) void kx_smooth_tiled(const TIN* __restrict__ r
       set_[j - XSM_FB] = e;
     }
   }
-  for (int i = threadIdx.x; i < (rows + 3) * tp; i += 256) {
-    const int r = i / tp, cidx = i - r * tp;
-    const int64_t t = t0 - nt + r;
-    const int f = f0 - nf + cidx;
-    tile[i] = (r < rows && cidx < cols && t >= 0 && t < g.T && f >= 0 && f < g.F) ? (double)raw[(u * g.T + t) * g.FS + f] : 0.0;
-  }
   __syncthreads();
   // f-pass: item = (row, group of 4 bins), consecutive lanes take consecutive rows; FOUR adjacent outputs from a sliding
-  // register window (one LDS read per tap per four outputs); every output sums its taps in the order a = -nf .. nf
-  for (int it = threadIdx.x; it < (rows + 3) * (XSM_FB / 4); it += 256) {
-    const int r = it % (rows + 3), c0 = (it / (rows + 3)) * 4;
+  // register window; every output sums its taps in the order a = -nf .. nf
+  const int kf_n = 2 * nf + 1, kt_n = 2 * nt + 1;
+  for (int it = threadIdx.x; it < (rows + 3) * (XSM_FB / 4); it += NTHR) {
+    const int q = it / (rows + 3), r = it - q * (rows + 3), c0 = q * 4;
     const double* src = tile + (size_t)r * tp + c0;   // src[a] = raw at bin f0 + c0 - nf + a
     double w0 = src[0], w1 = src[1], w2 = src[2];
     double a0 = 0.0, a1 = 0.0, a2 = 0.0, a3 = 0.0;
-    for (int a = 0; a <= 2 * nf; ++a) {
+    int a = 0;
+    for (; a + 4 <= kf_n; a += 4) {
+      const double w3 = src[a + 3], w4 = src[a + 4], w5 = src[a + 5], w6 = src[a + 6];
+      const double k[4] = {skf[a], skf[a + 1], skf[a + 2], skf[a + 3]};
+      XSM_STEP4(k, w0, w1, w2, w3, w4, w5, w6)
+      w0 = w4; w1 = w5; w2 = w6;
+    }
+    for (; a < kf_n; ++a) {
       const double w3 = src[a + 3];
       const double k = skf[a];
       a0 += k * w0; a1 += k * w1; a2 += k * w2; a3 += k * w3;
@@ -236,23 +267,34 @@ __global__ __launch_bounds__(256) void kx_smooth_tiled(const TIN* __restrict__ r
     dst[0] = a0; dst[1] = a1; dst[2] = a2; dst[3] = a3;
   }
   __syncthreads();
-  // t-pass: item = (group of 4 frames, bin), consecutive lanes take consecutive bins
-  for (int it = threadIdx.x; it < (XSM_TT / 4) * XSM_FB; it += 256) {
-    const int cidx = it % XSM_FB, r0 = (it / XSM_FB) * 4;
+  // t-pass: item = (pair of frames, bin), consecutive lanes take consecutive bins (a block's 1024 items: one per thread)
+  for (int it = threadIdx.x; it < (XSM_TT / 2) * XSM_FB; it += NTHR) {
+    const int cidx = it % XSM_FB, r0 = (it / XSM_FB) * 2;
     const int f = f0 + cidx;
     const double* src = buf + (size_t)r0 * BP + cidx;   // src[b * BP] = frame t0 + r0 - nt + b
-    double w0 = src[0], w1 = src[BP], w2 = src[2 * BP];
-    double a0 = 0.0, a1 = 0.0, a2 = 0.0, a3 = 0.0;
-    for (int b = 0; b <= 2 * nt; ++b) {
-      const double w3 = src[(size_t)(b + 3) * BP];
+    double w0 = src[0];
+    double a0 = 0.0, a1 = 0.0;
+    int b = 0;
+    for (; b + 4 <= kt_n; b += 4) {
+      const double* s1 = src + (size_t)(b + 1) * BP;
+      const double w1 = s1[0], w2 = s1[BP], w3 = s1[2 * BP], w4 = s1[3 * BP];
+      const double k0 = skt[b], k1 = skt[b + 1], k2 = skt[b + 2], k3 = skt[b + 3];
+      a0 += k0 * w0; a1 += k0 * w1;
+      a0 += k1 * w1; a1 += k1 * w2;
+      a0 += k2 * w2; a1 += k2 * w3;
+      a0 += k3 * w3; a1 += k3 * w4;
+      w0 = w4;
+    }
+    for (; b < kt_n; ++b) {
+      const double w1 = src[(size_t)(b + 1) * BP];
       const double k = skt[b];
-      a0 += k * w0; a1 += k * w1; a2 += k * w2; a3 += k * w3;
-      w0 = w1; w1 = w2; w2 = w3;
+      a0 += k * w0; a1 += k * w1;
+      w0 = w1;
     }
     if (f >= g.F) continue;
-    const double accs[4] = {a0, a1, a2, a3};
+    const double accs[2] = {a0, a1};
 #pragma unroll
-    for (int e = 0; e < 4; ++e) {
+    for (int e = 0; e < 2; ++e) {
       const int64_t t = t0 + r0 + e;
       if (t >= g.T) break;
       double edge = 1.0;
@@ -261,6 +303,7 @@ __global__ __launch_bounds__(256) void kx_smooth_tiled(const TIN* __restrict__ r
     }
   }
 }
+#undef XSM_STEP4
 
 template <typename TIN>
 __global__ void kx_prop_only(const TIN* __restrict__ raw, Geom g, double p, double* __restrict__ M, int64_t n_units) {
