@@ -1,7 +1,7 @@
 """Host arrays in / out: the recording crosses PCIe in chunk-aligned pieces, overlapped with the gate
 (noisereduce_amd/spectralgate/base.py: _get_traces_pipelined; SURVEY.md 8 row f2 -- the reference's chunk loop over a
 memmap, base.py:180-216).  Each piece is gated as a start_frame / end_frame range of the one device copy, so the chunk grid
--- and every output bit -- is that of the one-upload path."""
+-- and, on the float32 kernels and for integer outputs, every output bit -- is that of the one-upload path."""
 import numpy as np
 import pytest
 
@@ -80,3 +80,39 @@ def test_pipelined_path_default_piece_size_and_fallbacks(monkeypatch):
     assert np.array_equal(sg4._device_y().cpu().numpy()[0], y) and sg4._pipe is None    # (the device copy on demand: the rest goes up)
     monkeypatch.setenv("NOISEREDUCE_AMD_PIPELINE", "0")
     assert np.array_equal(SpectralGateStationary(**kw).get_traces(), a)
+
+
+@pytest.mark.parametrize("kw", [dict(n_fft=512), dict(n_fft=256), dict(n_fft=400, freq_mask_smooth_hz=1000), dict(n_fft=2048),
+                                dict(prop_decrease=0.6), dict(chunk_size=100000, padding=9000), dict(freq_mask_smooth_hz=None, time_mask_smooth_ms=None),
+                                dict(precision="float64")])
+@pytest.mark.parametrize("stationary", [True, False])
+def test_pipelined_host_path_other_geometries(monkeypatch, stationary, kw):
+    """Every kernel family behind get_traces stores its output once and never reads it back: the page-locked result array
+    works as its destination for the generic frame lengths, the chirp-z sizes, prop_decrease < 1, unsmoothed masks and the
+    float64 pipeline too."""
+    import noisereduce_amd as nr
+    from noisereduce_amd.spectralgate import base
+    cs = kw.get("chunk_size", 600000)
+    y = _rec(cs * 8 + 4321, 1, np.float32, 12)[0]
+    yn = y[5000:90000].copy()
+    monkeypatch.setenv("NOISEREDUCE_AMD_PIPELINE", "0")
+    ref = nr.reduce_noise(y=y, sr=48000, stationary=stationary, **kw)
+    refn = nr.reduce_noise(y=y, sr=48000, stationary=True, y_noise=yn, **kw) if stationary else None
+    monkeypatch.setenv("NOISEREDUCE_AMD_PIPELINE", "1")
+    monkeypatch.setenv("NOISEREDUCE_AMD_PIPELINE_PIECE_BYTES", str(2 * cs * 4))
+    calls = []
+    orig = base.SpectralGate._get_traces_pipelined
+    monkeypatch.setattr(base.SpectralGate, "_get_traces_pipelined", lambda self: (calls.append(1), orig(self))[1])
+    def same(a, b):
+        if "precision" not in kw:
+            return np.array_equal(a, b)
+        # the float64 kernels add the four overlapping frames of a hop in an order that depends on where the request's
+        # tiles start: float64 rounding (1e-16), which the float32 container shows as a last-place flip in a few samples
+        # (the same holds for get_traces(start, end) on a device-resident recording)
+        d = np.abs(a.astype(np.float64) - b.astype(np.float64))
+        return d.max() <= 1.2e-7 * np.abs(b).max() and np.count_nonzero(d) <= 1e-4 * d.size
+    got = nr.reduce_noise(y=y, sr=48000, stationary=stationary, **kw)
+    assert calls and same(got, ref)
+    if stationary:   # an explicit noise clip: the constructor uploads the clip, the recording still streams
+        gotn = nr.reduce_noise(y=y, sr=48000, stationary=True, y_noise=yn, **kw)
+        assert len(calls) == 2 and same(gotn, refn)
