@@ -44,26 +44,32 @@ class SpectralGateStationary(SpectralGate):
         # channel mean -> STFT -> dB -> per-band mean/std -> threshold (stationary.py:61-81),
         # all on the device; the result stays there.  The engine handle is shared by every object with
         # the same settings, the threshold is NOT: like the reference (self.noise_thresh,
-        # stationary.py:79-81) it belongs to this object -- a float64 device tensor copied out of the
-        # handle here and loaded back by _bind() whenever another object used the handle in between.
-        self._token = object()   # identity of this object's threshold (no reference cycle through the handle)
+        # stationary.py:79-81) it belongs to this object.  It stays IN the handle while this object is the last one to
+        # have put one there; whoever overwrites it first saves a float64 device copy into _thr_dev (Gate.evict_threshold),
+        # and _bind() loads that copy back when this object gates again.
+        self._token = object()   # identity of this object's threshold
+        self._thr_dev = None
         with self._gate.lock:
             self._gate.noise_stats(noise_dev)
-            self._thr_dev = self._gate.noise_threshold_tensor()
-            self._gate.thresh_owner = self._token
+            self._gate.claim_threshold(self, self._token)
         self._noise_thresh = None
 
     def _bind(self):
         """Make the shared handle hold THIS object's threshold (caller holds self._gate.lock)."""
         if self._gate.thresh_owner is not self._token:
+            if self._thr_dev is None:
+                raise RuntimeError("the engine handle lost this object's noise threshold (it was overwritten without "
+                                   "Gate.evict_threshold)")
             self._gate.set_noise_threshold_tensor(self._thr_dev)
-            self._gate.thresh_owner = self._token
+            self._gate.claim_threshold(self, self._token)
 
     @property
     def noise_thresh(self):
         """Per-band threshold in dB (stationary.py:79-81), fetched from the device on demand."""
         if self._noise_thresh is None:
-            self._noise_thresh = self._thr_dev.cpu().numpy()
+            with self._gate.lock:
+                t = self._thr_dev if self._thr_dev is not None else self._gate.noise_threshold_tensor()
+            self._noise_thresh = t.cpu().numpy()
         return self._noise_thresh
 
     def spectral_gating_stationary(self, chunk):
