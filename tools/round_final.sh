@@ -23,7 +23,8 @@ python tools/time_dtypes.py > "$OUT/time_dtypes.txt" 2>&1
 python tools/prof_torchgate.py > "$OUT/prof_torchgate.txt" 2>&1
 (cd /tmp; export TMPDIR=/tmp; rocprofv3 --kernel-trace --stats -d $REPO/gpurun_out/prof_${TAG}_fb -o fb --output-format csv -- python $REPO/tools/prof_fwdbwd.py > /dev/null 2>&1; F=$(find $REPO/gpurun_out/prof_${TAG}_fb -name '*kernel_stats.csv' | head -1); [ -n "$F" ] && (head -1 "$F"; grep "sg::" "$F") > "$OUT/fwdbwd_kernel_stats.csv")
 (cd /tmp; export TMPDIR=/tmp; rocprofv3 --kernel-trace --stats -d $REPO/gpurun_out/prof_${TAG}_i16 -o i16 --output-format csv -- python $REPO/tools/prof_int16.py > /dev/null 2>&1; F=$(find $REPO/gpurun_out/prof_${TAG}_i16 -name '*kernel_stats.csv' | head -1); [ -n "$F" ] && (head -1 "$F"; grep "sg::" "$F") > "$OUT/int16_kernel_stats.csv")
-tools/valu_calibrate.sh > "$OUT/valu_calibrate.log" 2>&1
+(cd /tmp; export TMPDIR=/tmp; rocprofv3 --kernel-trace --stats -d $REPO/gpurun_out/prof_${TAG}_x -o x --output-format csv -- python $REPO/tools/prof_exact.py > /dev/null 2>&1; F=$(find $REPO/gpurun_out/prof_${TAG}_x -name '*kernel_stats.csv' | head -1); [ -n "$F" ] && (head -1 "$F"; grep "sg::" "$F") > "$OUT/float64_pipeline_kernel_stats.csv")
+python tools/time_host_path.py > "$OUT/time_host_path.txt" 2>&1
 cat "$OUT/pytest_gpu.txt"; head -c 300 "$OUT/bench.json"; echo; tail -3 "$OUT/traffic.log"
 python tools/rowgate_scale.py > "$OUT/rowgate_scale.txt" 2>&1; cp gpurun_out/rowgate_scale.json "$OUT/" 2>/dev/null
 python tools/rowgate_probe.py > "$OUT/rowgate_probe.txt" 2>&1; cp gpurun_out/rowgate_probe.json "$OUT/" 2>/dev/null
