@@ -116,3 +116,29 @@ def test_pipelined_host_path_other_geometries(monkeypatch, stationary, kw):
     if stationary:   # an explicit noise clip: the constructor uploads the clip, the recording still streams
         gotn = nr.reduce_noise(y=y, sr=48000, stationary=True, y_noise=yn, **kw)
         assert len(calls) == 2 and same(gotn, refn)
+
+
+def test_pipelined_host_path_from_two_threads(monkeypatch):
+    """Two threads gate different host recordings through the same cached engine handle at once: the uploads share the side
+    stream, the gates serialise on the handle's lock, each thread gets its own result."""
+    import threading
+    import noisereduce_amd as nr
+    monkeypatch.setenv("NOISEREDUCE_AMD_PIPELINE_PIECE_BYTES", str(2 * 600000 * 4))
+    ys = [_rec(600000 * 9 + 100 * i, 1, np.float32, 30 + i)[0] for i in range(2)]
+    monkeypatch.setenv("NOISEREDUCE_AMD_PIPELINE", "0")
+    refs = [nr.reduce_noise(y=y, sr=48000, stationary=True) for y in ys]
+    monkeypatch.setenv("NOISEREDUCE_AMD_PIPELINE", "1")
+    out, errs = [None, None], []
+
+    def work(i):
+        try:
+            for _ in range(4):
+                out[i] = nr.reduce_noise(y=ys[i], sr=48000, stationary=True)
+        except Exception as e:      # noqa: BLE001
+            errs.append(e)
+    th = [threading.Thread(target=work, args=(i,)) for i in range(2)]
+    for t in th: t.start()
+    for t in th: t.join()
+    assert not errs, errs
+    for i in range(2):
+        assert np.array_equal(out[i], refs[i])
