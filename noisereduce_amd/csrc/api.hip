@@ -41,6 +41,22 @@
 #ifndef SG_TEAM_N
 #define SG_TEAM_N 2048
 #endif
+// (round 5) threads that share one frame in the LDS-Stockham kernels (fft_wave.hpp): the whole workgroup from N = SG_TEAM_N
+// on, one wavefront for 512 <= N < SG_TEAM_N, and SUB-wavefront teams for short frames -- a radix-8 pass over N complex
+// points has N / 8 butterflies, so a 64-lane team on N = 128 (n_fft = 256) idles 48 lanes in two of its three passes.
+// SG_SHORT_TEAMS=0 at build time restores one wavefront per frame (A/B).
+#ifndef SG_SHORT_TEAMS
+#define SG_SHORT_TEAMS 1
+#endif
+template <int N>
+constexpr int team_threads() {
+  return N >= SG_TEAM_N ? 256 : (!SG_SHORT_TEAMS ? 64 : (N <= 128 ? 16 : (N == 256 ? 32 : 64)));
+}
+// teams per workgroup: 256 threads unless the transform buffers (`elem` bytes per complex point) would not fit
+template <int N>
+constexpr int team_count(size_t elem) {
+  return N >= SG_TEAM_N ? 1 : (team_threads<N>() < 64 ? 256 / team_threads<N>() : ((N * elem > 16384) ? 2 : 4));
+}
 #ifndef SG_APPLY_WAVES
 #define SG_APPLY_WAVES 4  // wavefronts per workgroup of k_apply_fast: tile = 4*W frames -> 4*W-3 hops
 #endif
@@ -139,6 +155,8 @@ struct sg_handle {
   bool dbg_has_raw = true;           // the unsmoothed mask field exists (not when k_iir_mask / k_box_mask produced the mask in one kernel)
   bool dbg_fused = false;
   bool dbg_fast = false;
+  bool dbg_k16_only = false;         // the last fused general-geometry batch left K counts only (no float mask field): dbg_g
+  Geom dbg_g{};
   int64_t dbg_db = 0, dbg_de = 0;  // frames whose mask bits were decided in the last batch
   bool force_unfused = false;  // sg_set_option(SG_OPT_FORCE_UNFUSED): materialised v1 path
   // per-kernel timing with HIP events on the launch stream (sg_profile_*)
@@ -315,8 +333,8 @@ static hipError_t launch_stft_n(const View& v, const Geom& g, int64_t units, con
                                 double* P, float* mag, double* z, double zscale, hipStream_t st,
                                 unsigned long long* pmax_bits) {
   // n_fft = 8192 (N = 4096): the whole workgroup cooperates on one frame
-  constexpr int NT = N >= SG_TEAM_N ? 256 : 64;
-  constexpr int WAVES = N >= SG_TEAM_N ? 1 : ((N * sizeof(cx<TC>) > 16384) ? 2 : 4);
+  constexpr int NT = team_threads<N>();
+  constexpr int WAVES = team_count<N>(sizeof(cx<TC>));
   size_t lds = (size_t)(N + WAVES * lpn<TC>(N)) * sizeof(cx<TC>);
   // few units (the noise clip): one frame per wave so that the grid still covers the chip
   const bool small = units * ((g.T + WAVES * 4 - 1) / (WAVES * 4)) < 1024;
@@ -392,16 +410,17 @@ static hipError_t launch_bits(int N, const View& v, const Geom& g, int64_t units
 template <int N>
 static hipError_t launch_decide_lds_n(const sg_handle* h, const View& v, const Geom& g, int64_t units,
                                       const ThreshConsts& tc, unsigned long long* bits, int wpr, hipStream_t st) {
-  constexpr int WAVES = (N * sizeof(cx<float>) > 8192) ? 2 : 4;
+  constexpr int NT = team_threads<N>() > 64 ? 64 : team_threads<N>();   // (a frame never spans wavefronts here)
+  constexpr int WAVES = NT < 64 ? 256 / NT : ((N * sizeof(cx<float>) > 8192) ? 2 : 4);
   constexpr int FPW = 4;
   const size_t lds = (size_t)(N + WAVES * N) * sizeof(cx<float>) + (size_t)(N + 1) * sizeof(float);
-  auto kern = k_decide_lds<N, WAVES, FPW>;
+  auto kern = k_decide_lds<N, WAVES, FPW, NT>;
   if (lds > 65536) {
     hipError_t e = set_lds(reinterpret_cast<const void*>(kern), lds);
     if (e != hipSuccess) return e;
   }
   dim3 grid((unsigned)((g.T + WAVES * FPW - 1) / (WAVES * FPW)), (unsigned)units);
-  hipLaunchKernelGGL(kern, grid, dim3(WAVES * 64), lds, st, v, g, (const cx<float>*)h->tw32.p,
+  hipLaunchKernelGGL(kern, grid, dim3(WAVES * NT), lds, st, v, g, (const cx<float>*)h->tw32.p,
                      (const float*)h->wa32.p, (const cx<double>*)h->tw64.p, (const double*)h->wfull64.p, tc,
                      h->mag_scale, h->p.top_db, bits, wpr);
   return hipGetLastError();
@@ -423,9 +442,10 @@ static hipError_t launch_decide_lds(const sg_handle* h, const View& v, const Geo
 
 template <int N>
 static hipError_t launch_apply_n(const View& v, const Geom& g, int64_t units, const void* tw, const float* wa,
-                                 const float* ws, const float* M, float* seg, hipStream_t st) {
-  constexpr int NT = N >= SG_TEAM_N ? 256 : 64;
-  constexpr int WAVES = N >= SG_TEAM_N ? 1 : ((N * sizeof(cx<float>) > 16384) ? 2 : 4);
+                                 const float* ws, const float* M, float* seg, hipStream_t st,
+                                 const unsigned short* K16, float kscale) {
+  constexpr int NT = team_threads<N>();
+  constexpr int WAVES = team_count<N>(sizeof(cx<float>));
   constexpr int FPW = 4;
   size_t lds = (size_t)(N + WAVES * lpn<float>(N)) * sizeof(cx<float>);
   auto kern = k_apply_istft<N, WAVES, FPW, NT>;
@@ -434,21 +454,22 @@ static hipError_t launch_apply_n(const View& v, const Geom& g, int64_t units, co
     if (e != hipSuccess) return e;
   }
   dim3 grid((unsigned)((g.T + WAVES * FPW - 1) / (WAVES * FPW)), (unsigned)units);
-  hipLaunchKernelGGL(kern, grid, dim3(WAVES * NT), lds, st, v, g, (const cx<float>*)tw, wa, ws, M, seg);
+  hipLaunchKernelGGL(kern, grid, dim3(WAVES * NT), lds, st, v, g, (const cx<float>*)tw, wa, ws, M, seg, K16, kscale);
   return hipGetLastError();
 }
 
 static hipError_t launch_apply(int N, const View& v, const Geom& g, int64_t units, const void* tw,
-                               const float* wa, const float* ws, const float* M, float* seg, hipStream_t st) {
+                               const float* wa, const float* ws, const float* M, float* seg, hipStream_t st,
+                               const unsigned short* K16 = nullptr, float kscale = 0.f) {
   switch (N) {
-    case 32: return launch_apply_n<32>(v, g, units, tw, wa, ws, M, seg, st);
-    case 64: return launch_apply_n<64>(v, g, units, tw, wa, ws, M, seg, st);
-    case 128: return launch_apply_n<128>(v, g, units, tw, wa, ws, M, seg, st);
-    case 256: return launch_apply_n<256>(v, g, units, tw, wa, ws, M, seg, st);
-    case 512: return launch_apply_n<512>(v, g, units, tw, wa, ws, M, seg, st);
-    case 1024: return launch_apply_n<1024>(v, g, units, tw, wa, ws, M, seg, st);
-    case 2048: return launch_apply_n<2048>(v, g, units, tw, wa, ws, M, seg, st);
-    case 4096: return launch_apply_n<4096>(v, g, units, tw, wa, ws, M, seg, st);
+    case 32: return launch_apply_n<32>(v, g, units, tw, wa, ws, M, seg, st, K16, kscale);
+    case 64: return launch_apply_n<64>(v, g, units, tw, wa, ws, M, seg, st, K16, kscale);
+    case 128: return launch_apply_n<128>(v, g, units, tw, wa, ws, M, seg, st, K16, kscale);
+    case 256: return launch_apply_n<256>(v, g, units, tw, wa, ws, M, seg, st, K16, kscale);
+    case 512: return launch_apply_n<512>(v, g, units, tw, wa, ws, M, seg, st, K16, kscale);
+    case 1024: return launch_apply_n<1024>(v, g, units, tw, wa, ws, M, seg, st, K16, kscale);
+    case 2048: return launch_apply_n<2048>(v, g, units, tw, wa, ws, M, seg, st, K16, kscale);
+    case 4096: return launch_apply_n<4096>(v, g, units, tw, wa, ws, M, seg, st, K16, kscale);
   }
   return hipErrorInvalidValue;
 }
@@ -660,15 +681,18 @@ static hipError_t stft_any(const sg_handle* h, const View& v, const Geom& g, int
 #undef SG_CALL
 }
 
+// the general apply kernel that can read the K counts of the fused bit-mask stages directly (k16_apply_ok)
+static bool k16_apply_geom(const sg_handle* h) { return !h->big_M && !h->czt_M; }
+
 static hipError_t apply_any(const sg_handle* h, const View& v, const Geom& g, int64_t units, const float* Mk,
-                            float* seg, hipStream_t st) {
+                            float* seg, hipStream_t st, const unsigned short* K16 = nullptr, float kscale = 0.f) {
   if (h->big_M) {
     const int rc = big_apply(const_cast<sg_handle*>(h), v, g, units, Mk, seg, st);
     return rc == SG_OK ? hipSuccess : (rc == SG_E_NOMEM ? hipErrorOutOfMemory : hipErrorUnknown);
   }
   const float* wa = (const float*)h->wa32.p;
   const float* ws = (const float*)h->ws32.p;
-  if (!h->czt_M) return launch_apply(h->N, v, g, units, h->tw32.p, wa, ws, Mk, seg, st);
+  if (!h->czt_M) return launch_apply(h->N, v, g, units, h->tw32.p, wa, ws, Mk, seg, st, K16, kscale);
   const CztTabs<float> tb = czt_tabs<float>(h);
 #define SG_CALL(M) launch_apply_czt_m<M>(v, g, units, tb, wa, ws, Mk, seg, st)
   SG_CZT_SWITCH(h->czt_M, SG_CALL);
@@ -1598,10 +1622,11 @@ static int stage_smooth(sg_handle* h, const Geom& g, int64_t ub, hipStream_t st)
 }
 
 static int stage_apply_ola(sg_handle* h, const View& v, const Geom& g, int64_t ub, const float* M,
-                           const OutMap& om, int normalize, hipStream_t st) {
+                           const OutMap& om, int normalize, hipStream_t st, const unsigned short* K16 = nullptr,
+                           float kscale = 0.f) {
   {
     ProfScope ps(h, SG_STAGE_APPLY_ISTFT, st);
-    HIPCHK(h, apply_any(h, v, g, ub, M, (float*)h->seg.p, st));
+    HIPCHK(h, apply_any(h, v, g, ub, M, (float*)h->seg.p, st, K16, kscale));
   }
   int64_t np = om.p1 - om.p0;
   if (np > 0) {
@@ -1763,7 +1788,12 @@ static int stage_fused_mask(sg_handle* h, const View& v, const Geom& g, int64_t 
   int64_t cells = ub * g.T * g.FS;
   if (fast) return SG_OK;  // the fused apply kernel reads K directly
   if ((h->fast5_ok || h->fast20_ok) && !h->force_nofast && h->p.prop_decrease == 1.0) return SG_OK;   // so do k_apply_fast512 / 2048<K>
-  hipLaunchKernelGGL(k_k16_to_mask, dim3(grid_1d(cells, 256)), dim3(256), 0, st, (const unsigned short*)h->K16.p,
+  // (round 5) ... and k_apply_istft (power-of-two frames on the LDS transform): the float mask field is only written when
+  // somebody asks for it (sg_debug_fetch field 1 expands the K counts of the last batch then)
+  h->dbg_k16_only = k16_apply_geom(h) && h->p.prop_decrease == 1.0;
+  h->dbg_g = g;
+  if (h->dbg_k16_only) return SG_OK;
+  hipLaunchKernelGGL(k_k16_to_mask, dim3(grid_1d(cells / 8, 256)), dim3(256), 0, st, (const unsigned short*)h->K16.p,
                      g, nf, nt, 1.0f / (float)h->ktot, (float)h->p.prop_decrease, 1, h->p.smooth_mask ? 1 : 0,
                      (float*)h->M.p, ub);
   HIPCHK(h, hipGetLastError());
@@ -2448,6 +2478,8 @@ static int run_S(sg_handle* h, View v, int64_t total_units, const OutMap& om, hi
     } else if (h->fast20_ok && !h->force_nofast) {
       const bool kmask = fused && h->p.prop_decrease == 1.0;
       if ((rc = stage_apply2048(h, v, g, nb, om, kmask ? nullptr : (const float*)h->M.p, 1, st))) return rc;
+    } else if (fused && h->dbg_k16_only) {
+      if ((rc = stage_apply_ola(h, v, g, nb, nullptr, om, 1, st, (const unsigned short*)h->K16.p, 1.0f / (float)h->ktot))) return rc;
     } else {
       if ((rc = stage_apply_ola(h, v, g, nb, (const float*)h->M.p, om, 1, st))) return rc;
     }
@@ -3116,6 +3148,13 @@ extern "C" int sg_debug_fetch(sg_handle* h, int32_t what, void* host, int64_t by
     case 1:
       if (h->dbg_fast && h->dbg_fused)
         FAIL(h, SG_E_STATE, "fast path keeps the smoothed mask as uint16 counts in the apply kernel's lane order");
+      if (h->dbg_fused && h->dbg_k16_only) {
+        // the apply kernel read the K counts directly: expand them now (same kernel, same arithmetic as the materialising path)
+        hipLaunchKernelGGL(k_k16_to_mask, dim3(grid_1d((int64_t)cells / 8, 256)), dim3(256), 0, (hipStream_t)stream,
+                           (const unsigned short*)h->K16.p, h->dbg_g, h->p.n_grad_freq, h->p.n_grad_time, 1.0f / (float)h->ktot,
+                           (float)h->p.prop_decrease, 1, h->p.smooth_mask ? 1 : 0, (float*)h->M.p, (int64_t)h->dbg_units);
+        HIPCHK(h, hipGetLastError());
+      }
       src = h->M.p; need = cells * 4; break;
     case 2:
       if (!h->dbg_has_P) FAIL(h, SG_E_STATE, "power field only exists for stationary gates");

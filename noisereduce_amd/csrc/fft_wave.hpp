@@ -40,6 +40,20 @@ __device__ __forceinline__ cx<T> rot90(cx<T> a) {
 // sequence, so a block barrier is always legal here.
 #define SG_PASS_SYNC() __syncthreads()
 
+// (round 5) Sync between the passes of ONE team's transform.  A team of fewer than 64 lanes lies inside one wavefront, whose
+// LDS operations execute in order: its buffer needs no barrier at all, only the compiler pinned (the idiom of
+// fast::wave_lds_sync).  Teams of 64 / 256 threads keep the workgroup barrier their kernels were written around.
+template <int NT>
+__device__ __forceinline__ void team_sync() {
+  if constexpr (NT < 64) {
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+  } else {
+    __syncthreads();
+  }
+}
+
 template <bool INV, typename T>
 __device__ __forceinline__ void dft2(cx<T>* v) {
   cx<T> a = v[0], b = v[1];
@@ -137,7 +151,7 @@ struct FftPass {
         for (int j = 0; j < R; ++j) v[c][j] = buf[lp<T>(i + j * NB)];
       }
     }
-    SG_PASS_SYNC();
+    team_sync<NT>();
 #pragma unroll
     for (int c = 0; c < PER; ++c) {
       int i = lane + NT * c;
@@ -154,7 +168,7 @@ struct FftPass {
         for (int k = 0; k < R; ++k) buf[lp<T>(o + S * k)] = v[c][k];
       }
     }
-    SG_PASS_SYNC();
+    team_sync<NT>();
     if constexpr (NR / R > 1) FftPass<T, N, S * R, INV, NT>::run(buf, tw, lane);
   }
 };

@@ -294,20 +294,28 @@ __global__ __launch_bounds__(WAVES * NT) void k_stft_bits(View view, Geom g, con
 // whole wavefront sums the n-term float64 DFT of that bin.  The bits are therefore identical to those
 // of the float64 kernel k_stft_bits<MODE 1> (checked by tests/test_gpu_parity.py).
 // ---------------------------------------------------------------------------------------
-template <int N, int WAVES, int FPW>
-__global__ __launch_bounds__(WAVES * 64) void k_decide_lds(View view, Geom g, const cx<float>* __restrict__ tw_g,
+// (round 5) NT = lanes that share one frame (a TEAM; WAVES = teams per workgroup).  A 64-lane wavefront on a 128-point
+// transform leaves 48 lanes idle in two of the three Stockham passes; 16-lane teams run four frames per wavefront with the
+// same butterflies in the same order (bit-identical spectra).  Ballots stay wavefront-wide: a team takes its NT bits of
+// each ballot, and the exact re-evaluation of an ambiguous cell is done by the whole wavefront for whichever team owns it.
+template <int N, int WAVES, int FPW, int NT = 64>
+__global__ __launch_bounds__(WAVES * NT) void k_decide_lds(View view, Geom g, const cx<float>* __restrict__ tw_g,
                                                            const float* __restrict__ win32,
                                                            const cx<double>* __restrict__ tw64,
                                                            const double* __restrict__ win64, ThreshConsts tc,
                                                            double mag_scale, double top_db,
                                                            unsigned long long* __restrict__ bits, int wpr) {
+  static_assert(NT == 64 || NT == 32 || NT == 16, "team = a power-of-two part of a wavefront");
   extern __shared__ __attribute__((aligned(16))) char smem[];
   cx<float>* tw = reinterpret_cast<cx<float>*>(smem);
   cx<float>* bufs = tw + N;
   float* sT2 = reinterpret_cast<float*>(bufs + WAVES * N);  // [N+1] compare constants (float32)
-  const int lane = threadIdx.x & 63;
-  const int wave = threadIdx.x >> 6;
-  cx<float>* buf = bufs + wave * N;
+  constexpr int TPW = 64 / NT;                // teams per wavefront
+  const int lane64 = threadIdx.x & 63;
+  const int lane = threadIdx.x % NT;          // lane within the team
+  const int team = threadIdx.x / NT;          // team within the workgroup
+  const int tq = lane64 / NT;                 // team within the wavefront
+  cx<float>* buf = bufs + team * N;
   const int64_t u = blockIdx.y;
   const int need = tc.need_floor[u];
   const bool floor_live = need == 1;
@@ -320,8 +328,8 @@ __global__ __launch_bounds__(WAVES * 64) void k_decide_lds(View view, Geom g, co
     if (need == 2) t2 = T2_NEVER;
     return t2;
   };
-  for (int i = threadIdx.x; i < N; i += WAVES * 64) tw[i] = tw_g[i];
-  for (int i = threadIdx.x; i <= N; i += WAVES * 64) {
+  for (int i = threadIdx.x; i < N; i += WAVES * NT) tw[i] = tw_g[i];
+  for (int i = threadIdx.x; i <= N; i += WAVES * NT) {
     const double t2 = t2eff(i);
     // "every cell passes" as a huge negative constant: P - T > 0 and the ambiguity test fails by itself
     sT2[i] = t2_to_f32(t2, 1.0);
@@ -330,19 +338,19 @@ __global__ __launch_bounds__(WAVES * 64) void k_decide_lds(View view, Geom g, co
   const int64_t chunk = view.c0 + (view.unit0 + u) % view.n_chunks;
   __syncthreads();
   for (int fi = 0; fi < FPW; ++fi) {
-    const int64_t t = ((int64_t)blockIdx.x * FPW + fi) * WAVES + wave;
+    const int64_t t = ((int64_t)blockIdx.x * FPW + fi) * WAVES + team;
     const bool valid = t < g.T;
     const int64_t s0 = t * g.H - g.padL;
     float nrm2 = 0.f;
-    const float* fp = valid ? frame_ptr_f32(view, row, chunk, s0, 2 * N) : nullptr;  // wave-uniform
+    const float* fp = valid ? frame_ptr_f32(view, row, chunk, s0, 2 * N) : nullptr;  // team-uniform
     if (fp) {
-      for (int j = lane; j < N; j += 64) {
+      for (int j = lane; j < N; j += NT) {
         const cx<float> z = {fp[2 * j] * win32[2 * j], fp[2 * j + 1] * win32[2 * j + 1]};
         nrm2 += z.x * z.x + z.y * z.y;
         buf[j] = z;
       }
     } else {
-      for (int j = lane; j < N; j += 64) {
+      for (int j = lane; j < N; j += NT) {
         cx<float> z = {0.f, 0.f};
         if (valid) {
           z.x = (float)view_sample(view, row, chunk, s0 + 2 * j) * win32[2 * j];
@@ -352,15 +360,19 @@ __global__ __launch_bounds__(WAVES * 64) void k_decide_lds(View view, Geom g, co
         buf[j] = z;
       }
     }
-    for (int off = 32; off > 0; off >>= 1) nrm2 += __shfl_xor(nrm2, off);
+    for (int off = NT / 2; off > 0; off >>= 1) nrm2 += __shfl_xor(nrm2, off);
     // 2 delta^2 = 2 * 2^-32 * nrm2; a silent frame (nrm2 == 0) has no ambiguous cells
     const float d2 = nrm2 > 0.f ? 2.0f * 2.3283064e-10f * nrm2 : -1.0f;
-    SG_PASS_SYNC();
-    wave_fft<float, N, false>(buf, tw, lane);
+    team_sync<NT>();
+    wave_fft<float, N, false, NT>(buf, tw, lane);
     unsigned long long* brow = bits + ((u * g.T + t) * (int64_t)wpr);
+    constexpr int NW = N / 64 + 1;            // words per frame (F = N + 1 bins)
+    unsigned long long acc[NW];
 #pragma unroll
-    for (int m = 0; m <= N / 64; ++m) {
-      const int k = lane + 64 * m;
+    for (int w = 0; w < NW; ++w) acc[w] = 0ull;
+#pragma unroll
+    for (int m = 0; m <= N / NT; ++m) {
+      const int k = lane + NT * m;
       bool pred = false, amb = false;
       if (k <= N) {
         const cx<float> a = buf[k == N ? 0 : k];
@@ -378,10 +390,12 @@ __global__ __launch_bounds__(WAVES * 64) void k_decide_lds(View view, Geom g, co
       while (pending) {
         const int src = __ffsll((long long)pending) - 1;
         pending &= pending - 1;
-        const int ks = src + 64 * m;
+        const int ks = (src % NT) + NT * m;
+        // the frame of the team that owns the cell (the wavefront's teams are consecutive frames)
+        const int64_t s0s = (t - tq + src / NT) * g.H - g.padL;
         double re = 0.0, im = 0.0;
-        for (int i = lane; i < 2 * N; i += 64) {
-          const double xv = view_sample(view, row, chunk, s0 + i) * win64[i];
+        for (int i = lane64; i < 2 * N; i += 64) {
+          const double xv = view_sample(view, row, chunk, s0s + i) * win64[i];
           const int j = (int)(((int64_t)ks * i) & (2 * N - 1));
           cx<double> w = tw64[j & (N - 1)];
           if (j >= N) { w.x = -w.x; w.y = -w.y; }
@@ -393,12 +407,21 @@ __global__ __launch_bounds__(WAVES * 64) void k_decide_lds(View view, Geom g, co
           im += __shfl_xor(im, off);
         }
         const bool pass = re * re + im * im > t2eff(ks);
-        if (lane == src) pred = pass;
+        if (lane64 == src) pred = pass;
       }
       const unsigned long long word = __ballot(pred);
-      if (valid && lane == 0) brow[m] = word;
+      if constexpr (NT == 64) {
+        acc[m < NW ? m : 0] = word;           // (m < NW always: N / 64 + 1 ballots)
+      } else {
+        const unsigned long long seg = (word >> (NT * tq)) & ((1ull << NT) - 1ull);
+        acc[(NT * m) >> 6] |= seg << ((NT * m) & 63);
+      }
     }
-    SG_PASS_SYNC();
+    if (valid && lane == 0) {
+#pragma unroll
+      for (int w = 0; w < NW; ++w) brow[w] = acc[w];
+    }
+    team_sync<NT>();
   }
 }
 
@@ -643,27 +666,62 @@ __global__ void k_bits_to_k16(const unsigned long long* __restrict__ bits, Geom 
 // M[t][f] from K:  p * K/ktot + (1-p) * edge(f, t)  (edge = valid-tap weight fraction when the
 // reference applies prop_decrease before smoothing, else 1).  Written as float for the v1
 // apply kernel (general geometries); the fast apply kernel evaluates this on the fly.
+// (round 5) eight cells per thread -- FS is a multiple of 16, so a group of eight never straddles a frame: one 16-byte load,
+// two 16-byte stores and ONE division per group (the first version divided twice per cell in 64 bits and took 194 us for two
+// minutes of audio at n_fft = 256: 15 M cells, the longest kernel of that call).
 __global__ void k_k16_to_mask(const unsigned short* __restrict__ K, Geom g, int nf, int nt, float inv_ktot,
                               float p, int prop_before, int smooth, float* __restrict__ M, int64_t n_units) {
-  const int64_t cells = n_units * g.T * g.FS;
-  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < cells;
-       i += (int64_t)gridDim.x * blockDim.x) {
-    const int f = (int)(i % g.FS);
-    if (f >= g.F) continue;
-    const int64_t t = (i / g.FS) % g.T;
-    float edge = 1.0f;
-    if (prop_before && smooth) {
-      // integer triangle sums over the valid taps
-      auto tri = [](int m, int lo, int hi) {  // sum_{a=lo..hi} (m+1-|a|), -m <= lo <= hi <= m
-        int s = 0;
-        for (int a = lo; a <= hi; ++a) s += m + 1 - (a < 0 ? -a : a);
-        return s;
-      };
-      int flo = max(-nf, -f), fhi = min(nf, g.F - 1 - f);
-      int64_t tlo = max<int64_t>(-nt, -t), thi = min<int64_t>(nt, g.T - 1 - t);
-      edge = (float)tri(nf, flo, fhi) * (float)tri(nt, (int)tlo, (int)thi) * inv_ktot;
+  const int gpr = g.FS >> 3;                              // groups per frame
+  const int64_t groups = n_units * g.T * gpr;
+  const bool edge_live = prop_before && smooth;
+  const float q = 1.0f - p;
+  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < groups; i += (int64_t)gridDim.x * blockDim.x) {
+    int64_t rowi;
+    int gi;
+    if (groups <= 0x7fffffffll) {                         // (uniform) 32-bit division
+      const unsigned r = (unsigned)i / (unsigned)gpr;
+      rowi = r;
+      gi = (int)((unsigned)i - r * (unsigned)gpr);
+    } else {
+      rowi = i / gpr;
+      gi = (int)(i - rowi * gpr);
     }
-    M[i] = p * ((float)K[i] * inv_ktot) + (1.0f - p) * edge;
+    const int f0 = gi * 8;
+    if (f0 >= g.F) continue;                              // padding group of the frame
+    const uint4 kk = *reinterpret_cast<const uint4*>(K + i * 8);
+    const unsigned kw[4] = {kk.x, kk.y, kk.z, kk.w};
+    float out[8];
+    float et = 1.0f;
+    if (edge_live) {
+      // integer triangle sums over the valid taps
+      const int64_t t = rowi % g.T;
+      const int64_t tlo = max<int64_t>(-nt, -t), thi = min<int64_t>(nt, g.T - 1 - t);
+      int s = 0;
+      for (int a = (int)tlo; a <= (int)thi; ++a) s += nt + 1 - (a < 0 ? -a : a);
+      et = (float)s;
+    }
+#pragma unroll
+    for (int e = 0; e < 8; ++e) {
+      const int f = f0 + e;
+      const float kv = (float)((kw[e >> 1] >> (16 * (e & 1))) & 0xffffu);
+      float edge = 1.0f;
+      if (edge_live) {
+        const int flo = max(-nf, -f), fhi = min(nf, g.F - 1 - f);
+        int s = 0;
+        for (int a = flo; a <= fhi; ++a) s += nf + 1 - (a < 0 ? -a : a);
+        edge = (float)s * et * inv_ktot;
+      }
+      out[e] = p * (kv * inv_ktot) + q * edge;
+    }
+    float* dst = M + i * 8;
+    if (f0 + 8 <= g.F) {
+      *reinterpret_cast<float4*>(dst) = make_float4(out[0], out[1], out[2], out[3]);
+      *reinterpret_cast<float4*>(dst + 4) = make_float4(out[4], out[5], out[6], out[7]);
+    } else {
+#pragma unroll
+      for (int e = 0; e < 8; ++e)
+        if (f0 + e < g.F) dst[e] = out[e];
+    }
   }
 }
 

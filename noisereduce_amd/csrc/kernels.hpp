@@ -116,7 +116,7 @@ __global__ __launch_bounds__(WAVES * NT) void k_stft(View view, Geom g, const cx
         buf[lp<TC>(j)] = z;
       }
     }
-    SG_PASS_SYNC();
+    team_sync<NT>();
     wave_fft<TC, N, false, NT>(buf, tw, lane);
     if (valid) {
       const int64_t rowoff = (u * g.T + t) * g.FS;
@@ -139,7 +139,7 @@ __global__ __launch_bounds__(WAVES * NT) void k_stft(View view, Geom g, const cx
         }
       }
     }
-    SG_PASS_SYNC();
+    team_sync<NT>();
   }
   // per-(unit, band) max power, order-independent (non-negative doubles order like their bits)
   if (pmax_bits) {
@@ -162,7 +162,11 @@ template <int N, int WAVES, int FPW, int NT = 64>
 __global__ __launch_bounds__(WAVES * NT) void k_apply_istft(View view, Geom g, const cx<float>* __restrict__ tw_g,
                                                             const float* __restrict__ win_a,  // analysis window (n)
                                                             const float* __restrict__ win_s,  // synthesis window (n), incl. 1/N
-                                                            const float* __restrict__ M, float* __restrict__ seg) {
+                                                            const float* __restrict__ M, float* __restrict__ seg,
+                                                            // (round 5) K16 != nullptr: the mask is K16 * kscale, the integer weight
+                                                            // sums of the smoothed bit mask read as they are (no float mask field)
+                                                            const unsigned short* __restrict__ K16 = nullptr,
+                                                            float kscale = 0.f) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
   cx<float>* tw = reinterpret_cast<cx<float>*>(smem);
   cx<float>* bufs = tw + N;
@@ -192,16 +196,18 @@ __global__ __launch_bounds__(WAVES * NT) void k_apply_istft(View view, Geom g, c
         buf[lp<float>(j)] = z;
       }
     }
-    SG_PASS_SYNC();
+    team_sync<NT>();
     wave_fft<float, N, false, NT>(buf, tw, lane);
     // split -> mask -> merge, pairwise in place: task k handles bins k and N-k.
     if (valid) {
       const float* Mrow = M + (u * g.T + t) * g.FS;
+      const unsigned short* Krow = K16 + (u * g.T + t) * g.FS;
+      auto mask_at = [&](int k) -> float { return K16 ? (float)Krow[k] * kscale : Mrow[k]; };
       for (int k = lane; k <= N / 2; k += NT) {
         if (k == 0) {
           cx<float> a = buf[lp<float>(0)];
-          float y0 = (a.x + a.y) * Mrow[0];
-          float yN = (a.x - a.y) * Mrow[N];
+          float y0 = (a.x + a.y) * mask_at(0);
+          float yN = (a.x - a.y) * mask_at(N);
           buf[lp<float>(0)] = {0.5f * (y0 + yN), 0.5f * (y0 - yN)};
         } else {
           cx<float> a = buf[lp<float>(k)], b = buf[lp<float>(N - k)];
@@ -210,7 +216,7 @@ __global__ __launch_bounds__(WAVES * NT) void k_apply_istft(View view, Geom g, c
           cx<float> E = {(a.x + b.x) * 0.5f, (a.y - b.y) * 0.5f};
           cx<float> O = {(a.y + b.y) * 0.5f, (b.x - a.x) * 0.5f};
           cx<float> wO = cmul(w, O);
-          float mk = Mrow[k], mn = Mrow[N - k];
+          float mk = mask_at(k), mn = mask_at(N - k);
           cx<float> Yk = {(E.x + wO.x) * mk, (E.y + wO.y) * mk};
           cx<float> Yn = {(E.x - wO.x) * mn, (-E.y + wO.y) * mn};  // X[N-k] * mn
           // merge: E' = (Yk + conj Yn)/2 ; O' = (Yk - conj Yn)/2 * conj(w) ; Zc'[k] = E' + i O'
@@ -226,7 +232,7 @@ __global__ __launch_bounds__(WAVES * NT) void k_apply_istft(View view, Geom g, c
         }
       }
     }
-    SG_PASS_SYNC();
+    team_sync<NT>();
     wave_fft<float, N, true, NT>(buf, tw, lane);
     if (valid) {
       float2* srow = reinterpret_cast<float2*>(seg + (u * g.T + t) * (int64_t)g.n);
@@ -235,7 +241,7 @@ __global__ __launch_bounds__(WAVES * NT) void k_apply_istft(View view, Geom g, c
         srow[j] = make_float2(z.x * win_s[2 * j], z.y * win_s[2 * j + 1]);
       }
     }
-    SG_PASS_SYNC();
+    team_sync<NT>();
   }
 }
 

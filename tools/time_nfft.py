@@ -17,11 +17,11 @@ NFFTS = [int(a) for a in os.environ["NFFT"].split(",")] if os.environ.get("NFFT"
 for n_fft in NFFTS:
     for stationary in (True, False):
         kw = dict(stationary=stationary, n_fft=n_fft, time_mask_smooth_ms=(400 if n_fft > 16384 else 200) if n_fft > 2048 else 50)
-        for _ in range(2):
+        for _ in range(int(os.environ.get("WARM", "2"))):
             nr.reduce_noise(y=yd, sr=sr, **kw)
         torch.cuda.synchronize()
         a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-        reps = 5
+        reps = int(os.environ.get("REPS", "5"))
         a.record()
         for _ in range(reps):
             nr.reduce_noise(y=yd, sr=sr, **kw)
