@@ -28,6 +28,7 @@
 #include "rowgate.hpp"
 #include "rowbwd.hpp"
 #include "fast512.hpp"
+#include "fast256.hpp"
 #include "fast2048.hpp"
 #include "nonstat.hpp"
 #include "fast64.hpp"
@@ -143,6 +144,8 @@ struct sg_handle {
   bool fast_ok = false;              // default geometry: fused apply kernel available
   bool fast5_ok = false;             // n_fft = win = 512, hop = 128: register-transform kernels of fast512.hpp
   DevBuf invn5;                      // 1 / window envelope per hop phase (128) of that geometry
+  bool fast25_ok = false;            // n_fft = win = 256, hop = 64: register-transform kernels of fast256.hpp (round 5)
+  DevBuf invn25;                     // 1 / window envelope per hop phase (64)
   bool fast20_ok = false;            // n_fft = win = 2048, hop = 512: register-transform kernels of fast2048.hpp
   DevBuf invn20;                     // 1 / window envelope per hop phase (512)
   bool force_nofast = false;
@@ -1038,6 +1041,23 @@ extern "C" int sg_create(const sg_params* p, const double* window_host, sg_handl
     if (!rc) rc = upload(h, h->invn5, invn.data(), invn.size() * sizeof(float));
     h->fast5_ok = true;
   }
+  if (!rc && n == 256 && W == 256 && h->H == 64) {
+    // fast256.hpp: the same 512-point register transform carries FOUR real frames of 256 samples
+    std::vector<cx<float>> t512(512);
+    for (int j = 0; j < 512; ++j) {
+      long double a = -2.0L * 3.14159265358979323846264338327950288L * (long double)j / 512.0L;
+      t512[j] = {(float)cosl(a), (float)sinl(a)};
+    }
+    std::vector<float> invn(64);
+    for (int s2 = 0; s2 < 64; ++s2) {
+      double acc = 0.0;
+      for (int q = 0; q < 4; ++q) acc += wfull[64 * q + s2] * wfull[64 * q + s2];
+      invn[s2] = (float)(acc > 1e-10 ? 1.0 / acc : 1.0);
+    }
+    rc = upload(h, h->tw512, t512.data(), t512.size() * sizeof(cx<float>));
+    if (!rc) rc = upload(h, h->invn25, invn.data(), invn.size() * sizeof(float));
+    h->fast25_ok = true;
+  }
   if (!rc && n == 2048 && W == 2048 && h->H == 512) {
     std::vector<float> invn(512);
     for (int s2 = 0; s2 < 512; ++s2) {
@@ -1130,7 +1150,7 @@ extern "C" int sg_destroy(sg_handle* h) {
                     &h->need, &h->T2, &h->part, &h->tw512, &h->invn, &h->seam, &h->ftab, &h->xbits, &h->xpart,
                     &h->xticket, &h->xtick2, &h->ftab3, &h->xexp, &h->optab, &h->nsp, &h->nsc, &h->xin, &h->czt_tw64, &h->czt_ch64,
                     &h->czt_bh64, &h->czt_tw32, &h->czt_ch32, &h->czt_bh32, &h->logtab, &h->big_twM, &h->big_tw2,
-                    &h->big_ch, &h->big_bh, &h->big_W, &h->big_W2, &h->xP, &h->xraw, &h->xM, &h->xtmp, &h->xseg, &h->invn5, &h->invn20, &h->rg_count, &h->alim, &h->nss})
+                    &h->big_ch, &h->big_bh, &h->big_W, &h->big_W2, &h->xP, &h->xraw, &h->xM, &h->xtmp, &h->xseg, &h->invn5, &h->invn25, &h->invn20, &h->rg_count, &h->alim, &h->nss})
     free_buf(*b);
   delete h;
   return SG_OK;
@@ -1359,6 +1379,75 @@ static int stage_apply512(sg_handle* h, const View& v, const Geom& g, int64_t ub
 }
 
 // ------------------------------------------------------------------------------------------
+// n_fft = 256 / hop 64 on the register transform (fast256.hpp, round 5): four frames per lane group
+// ------------------------------------------------------------------------------------------
+static fast::Fast25Args fast25_args(const sg_handle* h, const View& v, const Geom& g) {
+  fast::Fast25Args A{};
+  A.view = v; A.g = g;
+  A.win = (const float*)h->wa32.p;
+  A.win64 = (const double*)h->wfull64.p;
+  A.tw512 = (const fast::cf*)h->tw512.p;
+  A.tw64 = (const cx<double>*)h->tw64.p;
+  A.mag_scale = h->mag_scale; A.top_db = h->p.top_db;
+  A.wsq = (const float*)h->wsq32.p;
+  A.invn = (const float*)h->invn25.p;
+  return A;
+}
+constexpr size_t FAST25_LDS = (size_t)(fast::FN + 4 * fast::WAVE_CX_H) * sizeof(fast::cf) + (256 + fast::F25_T2) * sizeof(float);
+
+static int stage_decide256(sg_handle* h, const View& v, const Geom& g, int64_t ub, const ThreshConsts& tc,
+                           unsigned long long* bits, hipStream_t st) {
+  ProfScope ps(h, SG_STAGE_DECIDE_FAST, st);
+  fast::Fast25Args A = fast25_args(h, v, g);
+  A.tc = tc;
+  A.bits = bits;
+  auto kern = fast::k_decide_fast256<4>;
+  HIPCHK(h, set_lds(reinterpret_cast<const void*>(kern), FAST25_LDS));
+  hipLaunchKernelGGL(kern, dim3((unsigned)((g.T + 63) / 64), (unsigned)ub), dim3(256), FAST25_LDS, st, A);
+  HIPCHK(h, hipGetLastError());
+  return SG_OK;
+}
+
+static int stage_mag256(sg_handle* h, const View& v, const Geom& g, int64_t ub, float* mag, hipStream_t st) {
+  ProfScope ps(h, SG_STAGE_STFT_MAG, st);
+  fast::Fast25Args A = fast25_args(h, v, g);
+  A.mag = mag;
+  auto kern = fast::k_mag_fast256<4>;
+  HIPCHK(h, set_lds(reinterpret_cast<const void*>(kern), FAST25_LDS));
+  hipLaunchKernelGGL(kern, dim3((unsigned)((g.T + 63) / 64), (unsigned)ub), dim3(256), FAST25_LDS, st, A);
+  HIPCHK(h, hipGetLastError());
+  return SG_OK;
+}
+
+static int stage_apply256(sg_handle* h, const View& v, const Geom& g, int64_t ub, const OutMap& om,
+                          const float* mask_f /* nullptr: uint16 weight sums in h->K16 (natural bin order) */,
+                          int normalize, hipStream_t st) {
+  ProfScope ps(h, SG_STAGE_APPLY_FAST, st);
+  fast::Fast25Args A = fast25_args(h, v, g);
+  A.Mf = mask_f;
+  A.K = (const unsigned short*)h->K16.p;
+  A.inv_ktot = (float)(1.0 / (double)h->ktot);
+  A.om = om;
+  A.normalize = normalize;
+  A.h_begin = (om.p0 + g.padL) / 64;
+  A.h_end = (om.p1 - 1 + g.padL) / 64 + 1;
+  const int64_t nh = A.h_end - A.h_begin;
+  if (nh <= 0) return SG_OK;
+  const dim3 grid((unsigned)((nh + 60) / 61), (unsigned)ub);
+  if (mask_f) {
+    auto kern = fast::k_apply_fast256<4, false>;
+    HIPCHK(h, set_lds(reinterpret_cast<const void*>(kern), FAST25_LDS));
+    hipLaunchKernelGGL(kern, grid, dim3(256), FAST25_LDS, st, A);
+  } else {
+    auto kern = fast::k_apply_fast256<4, true>;
+    HIPCHK(h, set_lds(reinterpret_cast<const void*>(kern), FAST25_LDS));
+    hipLaunchKernelGGL(kern, grid, dim3(256), FAST25_LDS, st, A);
+  }
+  HIPCHK(h, hipGetLastError());
+  return SG_OK;
+}
+
+// ------------------------------------------------------------------------------------------
 // n_fft = 2048 / hop 512 on the register transform (fast2048.hpp)
 // ------------------------------------------------------------------------------------------
 static fast::Fast20Args fast20_args(const sg_handle* h, const View& v, const Geom& g) {
@@ -1444,6 +1533,7 @@ static int stage_mag(sg_handle* h, const View& v, const Geom& g, int64_t ub, hip
                      double* sub = nullptr /* default geometry only: recurrence partials per 16-frame block (k_mag_fast) */) {
   float* mag = (float*)h->P.p;
   if (h->fast5_ok && !h->force_nofast) return stage_mag512(h, v, g, ub, mag, st);
+  if (h->fast25_ok && !h->force_nofast) return stage_mag256(h, v, g, ub, mag, st);
   if (h->fast20_ok && !h->force_nofast) return stage_mag2048(h, v, g, ub, mag, st);
   if (h->fast_ok && !h->force_nofast) {
     ProfScope ps(h, SG_STAGE_STFT_MAG, st);
@@ -1770,6 +1860,10 @@ static int stage_fused_mask(sg_handle* h, const View& v, const Geom& g, int64_t 
   } else if (!h->force_f64_decide && h->fast20_ok && !h->force_nofast) {
     int rc20 = stage_decide2048(h, v, g, ub, tc, (unsigned long long*)h->bits.p, st);
     if (rc20) return rc20;
+  } else if (!h->force_f64_decide && h->fast25_ok && !h->force_nofast) {
+    // n_fft = 256: register transform, four frames per lane group
+    int rc25 = stage_decide256(h, v, g, ub, tc, (unsigned long long*)h->bits.p, st);
+    if (rc25) return rc25;
   } else if (!h->force_f64_decide && h->fast5_ok && !h->force_nofast) {
     // n_fft = 512: register transform, two frames per lane group
     int rc5 = stage_decide512(h, v, g, ub, tc, (unsigned long long*)h->bits.p, st);
@@ -1787,7 +1881,7 @@ static int stage_fused_mask(sg_handle* h, const View& v, const Geom& g, int64_t 
   const int nf = h->p.n_grad_freq, nt = h->p.n_grad_time;
   int64_t cells = ub * g.T * g.FS;
   if (fast) return SG_OK;  // the fused apply kernel reads K directly
-  if ((h->fast5_ok || h->fast20_ok) && !h->force_nofast && h->p.prop_decrease == 1.0) return SG_OK;   // so do k_apply_fast512 / 2048<K>
+  if ((h->fast5_ok || h->fast20_ok || h->fast25_ok) && !h->force_nofast && h->p.prop_decrease == 1.0) return SG_OK;   // so do k_apply_fast512 / 2048 / 256<K>
   // (round 5) ... and k_apply_istft (power-of-two frames on the LDS transform): the float mask field is only written when
   // somebody asks for it (sg_debug_fetch field 1 expands the K counts of the last batch then)
   h->dbg_k16_only = k16_apply_geom(h) && h->p.prop_decrease == 1.0;
@@ -2453,7 +2547,7 @@ static int run_S(sg_handle* h, View v, int64_t total_units, const OutMap& om, hi
       continue;
     }
     // float mask field (natural bin order for the general apply kernels, lane order for the fused one)
-    h->dbg_fast = geom_fast || (fused && (h->fast5_ok || h->fast20_ok) && !h->force_nofast && h->p.prop_decrease == 1.0);
+    h->dbg_fast = geom_fast || (fused && (h->fast5_ok || h->fast20_ok || h->fast25_ok) && !h->force_nofast && h->p.prop_decrease == 1.0);
     if (fused) {
       if ((rc = stage_fused_mask(h, v, g, nb, false, 0, g.T, st))) return rc;
     } else {
@@ -2472,6 +2566,9 @@ static int run_S(sg_handle* h, View v, int64_t total_units, const OutMap& om, hi
     }
     if (geom_fast) {
       if ((rc = stage_apply_fast(h, v, g, nb, om, (const float*)h->M.p, 1, st))) return rc;
+    } else if (h->fast25_ok && !h->force_nofast) {
+      const bool kmask = fused && h->p.prop_decrease == 1.0;   // the bit-mask stages left uint16 sums, no float mask
+      if ((rc = stage_apply256(h, v, g, nb, om, kmask ? nullptr : (const float*)h->M.p, 1, st))) return rc;
     } else if (h->fast5_ok && !h->force_nofast) {
       const bool kmask = fused && h->p.prop_decrease == 1.0;   // the bit-mask stages left uint16 sums, no float mask
       if ((rc = stage_apply512(h, v, g, nb, om, kmask ? nullptr : (const float*)h->M.p, 1, st))) return rc;
@@ -2888,6 +2985,8 @@ extern "C" int sg_process_batch(sg_handle* h, const void* x_dev, int dtype, int6
                                hipMemcpyDeviceToDevice, st));
     if (geom_fast) {
       if ((rc = stage_apply_fast(h, v, g, nb, om, (const float*)h->M.p, 1, st))) return rc;
+    } else if (h->fast25_ok && !h->force_nofast) {
+      if ((rc = stage_apply256(h, v, g, nb, om, (const float*)h->M.p, 1, st))) return rc;
     } else if (h->fast5_ok && !h->force_nofast) {
       if ((rc = stage_apply512(h, v, g, nb, om, (const float*)h->M.p, 1, st))) return rc;
     } else if (h->fast20_ok && !h->force_nofast) {
@@ -2973,6 +3072,8 @@ extern "C" int sg_process_batch_backward(sg_handle* h, const void* grad_out_dev,
     const float* mk = mask_dev + (size_t)u0 * g.T * g.FS;
     if (h->fast_ok && !h->force_nofast) {
       if ((rc = stage_apply_fast(h, v, gb, nb, om, mk, 0, st))) return rc;
+    } else if (h->fast25_ok && !h->force_nofast) {
+      if ((rc = stage_apply256(h, v, gb, nb, om, mk, 0, st))) return rc;
     } else if (h->fast5_ok && !h->force_nofast) {
       if ((rc = stage_apply512(h, v, gb, nb, om, mk, 0, st))) return rc;
     } else if (h->fast20_ok && !h->force_nofast) {

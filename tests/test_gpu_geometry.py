@@ -140,6 +140,97 @@ def test_torchgate_nfft512(nr):
 
 
 @pytest.mark.parametrize("sr,n,kw", [
+    (8000, 30000, dict()),                                                   # one chunk (telephony)
+    (48000, 200000, dict(chunk_size=40000, padding=5000)),                   # chunk grid, partial last chunk, 37-frame smoothing
+    (16000, 51234, dict(chunk_size=9000, padding=1000, prop_decrease=0.6)),  # ragged: tiles at both unit edges
+    (16000, 259, dict()),                                                    # barely longer than a frame
+    (8000, 20000, dict(freq_mask_smooth_hz=None, time_mask_smooth_ms=None)),
+    (44100, 70000, dict(time_mask_smooth_ms=None)),
+    (16000, 64 * 61 * 3 + 17, dict(chunk_size=64 * 61, padding=64 * 4)),     # chunk = one tile's hops: tile seams on chunk seams
+])
+@pytest.mark.parametrize("stationary", [True, False])
+def test_nfft256_fast_path_matches_the_oracle(nr, sr, n, kw, stationary):
+    """fast256.hpp (round 5): four real frames of 256 samples per 512-point register transform."""
+    from noisereduce_amd import _ffi
+    y = np.stack([O.synth_signal(n, sr=sr, seed=31 + c, tone_hz=300.0 * (c + 1)) for c in range(2)]).astype(np.float32)
+    args = dict(stationary=stationary, n_fft=256, **kw)
+    got = nr.reduce_noise(y=y, sr=sr, **args)
+    want = O.reduce_noise_S(y.astype(np.float64), sr, **args)
+    assert got.shape == y.shape and got.dtype == y.dtype
+    assert O.rel_err(got, want) < TOL
+    # the general LDS kernels on the same input (SG_OPT_FORCE_NOFAST): same result to float32 rounding
+    from noisereduce_amd.spectralgate.stationary import SpectralGateStationary
+    from noisereduce_amd.spectralgate.nonstationary import SpectralGateNonStationary
+    y1 = torch.from_numpy(y).cuda()
+
+    def make():
+        base = dict(y=y1, sr=sr, chunk_size=kw.get("chunk_size", 600000), padding=kw.get("padding", 30000),
+                    prop_decrease=kw.get("prop_decrease", 1.0), n_fft=256, win_length=None, hop_length=None, time_constant_s=2.0,
+                    freq_mask_smooth_hz=kw.get("freq_mask_smooth_hz", 500), time_mask_smooth_ms=kw.get("time_mask_smooth_ms", 50),
+                    tmp_folder=None, use_tqdm=False, n_jobs=1)
+        if stationary:
+            return SpectralGateStationary(y_noise=None, n_std_thresh_stationary=1.5, clip_noise_stationary=True, **base)
+        return SpectralGateNonStationary(thresh_n_mult_nonstationary=2, sigmoid_slope_nonstationary=10, **base)
+
+    sg = make()
+    a = sg.get_traces().cpu().numpy()
+    with sg._gate.with_options([(_ffi.SG_OPT_FORCE_NOFAST, 1)]):
+        b = make().get_traces().cpu().numpy()
+    assert O.rel_err(a, want) < TOL and O.rel_err(b, want) < TOL
+    assert O.rel_err(a, b) < 2e-6
+
+
+def test_nfft256_decisions_equal_the_float64_decisions(nr):
+    """Mask bits of k_decide_fast256 (float32 + exact refinement, FOUR frames per transform) == the all-float64 decision
+    kernel, bit for bit -- incl. a loud frame next to quiet ones (they share one transform) and a steady tone."""
+    from noisereduce_amd import _ffi
+    from noisereduce_amd.spectralgate.stationary import SpectralGateStationary
+    sr, n = 16000, 120000
+    y = O.synth_signal(n, sr=sr, seed=6, tone_hz=440.0).astype(np.float32)
+    y[30000:30200] *= 200.0          # a burst: frames with loud and quiet partners
+    y[60000:] = (0.3 * np.sin(2 * np.pi * 1000.0 * np.arange(n - 60000) / sr)).astype(np.float32)   # steady tone
+    kw = dict(sr=sr, y_noise=None, prop_decrease=1.0, n_std_thresh_stationary=1.5, chunk_size=50000, clip_noise_stationary=True,
+              padding=4000, n_fft=256, win_length=None, hop_length=None, time_constant_s=2.0, freq_mask_smooth_hz=500,
+              time_mask_smooth_ms=50, tmp_folder=None, use_tqdm=False, n_jobs=1)
+    sg = SpectralGateStationary(y=torch.from_numpy(y).cuda(), **kw)
+    out_fast = sg.get_traces().clone()
+    bits_fast = sg._gate.debug_field(3)
+    sg._gate.set_option(_ffi.SG_OPT_FORCE_F64_DECIDE, 1)
+    try:
+        out_64 = sg.get_traces().clone()
+        bits_64 = sg._gate.debug_field(3)
+    finally:
+        sg._gate.set_option(_ffi.SG_OPT_FORCE_F64_DECIDE, 0)
+    assert bits_fast.shape == bits_64.shape and np.array_equal(bits_fast, bits_64)
+    assert torch.equal(out_fast, out_64)
+    want = O.reduce_noise_S(y.astype(np.float64), sr, stationary=True, n_fft=256, chunk_size=50000, padding=4000)
+    assert O.rel_err(out_fast.cpu().numpy(), want) < TOL
+
+
+def test_torchgate_nfft256(nr):
+    from noisereduce_amd.torchgate import TorchGate
+    for kw in (dict(), dict(nonstationary=True)):
+        x = np.stack([O.synth_signal(8000, sr=8000, seed=s, tone_hz=440.0) for s in range(5)]).astype(np.float64)
+        tg = TorchGate(sr=8000, n_fft=256, **kw).cuda()
+        xt = torch.from_numpy(x).cuda().requires_grad_()
+        y = tg(xt)
+        want = O.torchgate_T(x, 8000, n_fft=256, window=torch.hann_window(256).double().numpy(), **kw)
+        assert O.rel_err(y.detach().cpu().numpy(), want) < TOL
+        # backward: the adjoint with the mask fixed against autograd through torch.stft / istft on the CPU
+        w = torch.linspace(0.5, 1.5, y.shape[1], dtype=torch.float64)
+        (y * w.cuda()).sum().backward()
+        got_g = xt.grad.cpu()
+        _, st = O.torchgate_T(x, 8000, n_fft=256, window=torch.hann_window(256).double().numpy(), return_stages=True, **kw)
+        m = torch.from_numpy(st["mask"])
+        xc = torch.from_numpy(x).requires_grad_()
+        win = torch.hann_window(256, dtype=torch.float64)
+        X = torch.stft(xc, 256, 64, 256, window=win, center=True, pad_mode="constant", return_complex=True)
+        yc = torch.istft(X * m, 256, 64, 256, window=win, center=True)
+        (yc * w).sum().backward()
+        assert O.rel_err(got_g.numpy(), xc.grad.numpy()) < TOL
+
+
+@pytest.mark.parametrize("sr,n,kw", [
     (44100, 50000, dict()),                                                   # one chunk
     (48000, 300000, dict(chunk_size=70000, padding=9000)),                    # chunk grid, partial last chunk
     (48000, 123457, dict(chunk_size=30000, padding=4100, prop_decrease=0.6)), # ragged: tiles at both unit edges
