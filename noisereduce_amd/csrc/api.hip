@@ -49,6 +49,9 @@
 #ifndef SG_SHORT_TEAMS
 #define SG_SHORT_TEAMS 1
 #endif
+#ifndef SG_STATS_TEAM
+#define SG_STATS_TEAM 1   // float64 noise-clip transform of 1024 points (n_fft = 2048) by a whole workgroup (launch_stft_n); 0: A/B
+#endif
 template <int N>
 constexpr int team_threads() {
   return N >= SG_TEAM_N ? 256 : (!SG_SHORT_TEAMS ? 64 : (N <= 128 ? 16 : (N == 256 ? 32 : 64)));
@@ -351,6 +354,22 @@ static hipError_t launch_stft_n(const View& v, const Geom& g, int64_t units, con
                        z, zscale, pmax_bits);
     return hipGetLastError();
   };
+  if constexpr (sizeof(TC) == 8 && N >= 1024 && N < SG_TEAM_N && SG_STATS_TEAM) {
+    // (round 5) the noise clip in float64 at n_fft = 2048: 293 workgroups of four one-frame wavefronts are one
+    // latency-bound round of 32 us.  The whole workgroup on one frame (the N >= SG_TEAM_N shape): four times the
+    // workgroups, each transform split over 256 threads: 16.5 us.  (n_fft = 1024 measured too: 14.0 -> 15.9 us, so not there.)
+    if (small && units * g.T <= 16384) {
+      const size_t lds1 = (size_t)(N + lpn<TC>(N)) * sizeof(cx<TC>);
+      auto kern = k_stft<TC, N, 1, 1, 256>;
+      if (lds1 > 65536) {
+        hipError_t e = set_lds(reinterpret_cast<const void*>(kern), lds1);
+        if (e != hipSuccess) return e;
+      }
+      hipLaunchKernelGGL(kern, dim3((unsigned)g.T, (unsigned)units), dim3(256), lds1, st, v, g, (const cx<TC>*)tw,
+                         (const TC*)wfull, P, mag, z, zscale, pmax_bits);
+      return hipGetLastError();
+    }
+  }
   if (small) return launch(k_stft<TC, N, WAVES, 1, NT>, 1);
   return launch(k_stft<TC, N, WAVES, 4, NT>, 4);
 }
@@ -1572,7 +1591,8 @@ static bool nonstat2_chain_ok(const sg_handle* h, const Geom& g) {
 static bool nonstat2_ok(const sg_handle* h, const Geom& g) {
   if (!nonstat2_chain_ok(h, g) || !h->p.smooth_mask) return false;
   const int nf = h->p.n_grad_freq, nt = h->p.n_grad_time;
-  return nf <= NS_MAX_NF && nt >= 1 && nt <= NS_IIR_MAX_NT;   // instantiated time half-widths (the tile column lives in registers)
+  if (nt > NS_IIR_MAX_NT && !(std::pow(1.0 - h->p.iir_b, (double)(NS_TT + 2 * nt)) >= 1e-3)) return false;   // (as above, for the longer column)
+  return nf <= NS_MAX_NF && ns_iir_nt_ok(nt);   // instantiated time half-widths (the tile column lives in registers)
 }
 
 // smooth: IIR + sigmoid + smoothing + prop_decrease -> M;  !smooth: the raw sigmoid field -> raw (smoothing follows),

@@ -14,6 +14,7 @@ hipError_t launch_iir_mask(int nt, dim3 grid, hipStream_t st, const float* mag, 
     SG_NS_CASE(0) SG_NS_CASE(1) SG_NS_CASE(2) SG_NS_CASE(3) SG_NS_CASE(4) SG_NS_CASE(5) SG_NS_CASE(6) SG_NS_CASE(7)
     SG_NS_CASE(8) SG_NS_CASE(9) SG_NS_CASE(10) SG_NS_CASE(11) SG_NS_CASE(12) SG_NS_CASE(13) SG_NS_CASE(14)
     SG_NS_CASE(15) SG_NS_CASE(16) SG_NS_CASE(17) SG_NS_CASE(18) SG_NS_CASE(19) SG_NS_CASE(20)
+    SG_NS_CASE(25) SG_NS_CASE(34) SG_NS_CASE(37)   // ns_iir_nt_ok
 #undef SG_NS_CASE
     default: return hipErrorInvalidValue;
   }

@@ -353,6 +353,10 @@ hipError_t launch_iir_mask(int nt, dim3 grid, hipStream_t st, const float* mag, 
 hipError_t launch_box_mask(int nt, int kbox, dim3 grid, hipStream_t st, const float* mag, Geom g, double nthresh,
                            double slope, int nf, float p, float* M, int64_t k0);
 constexpr int NS_IIR_MAX_NT = 20;   // k_iir_mask<0 .. 20>
+// (round 5) ... plus the half-widths of the default 50 ms at a hop of 64 samples (n_fft = 256) and 32 / 44.1 / 48 kHz -- the
+// same at a hop of 128 and twice the rate: 138 register rows per bin column, two waves per SIMD.  Anything else beyond 20
+// takes k_iir_mask<0> + k_smooth_tiled (the raw field through HBM, the smoothing through LDS: 63 + 254 us where this takes ~150).
+__host__ __device__ constexpr bool ns_iir_nt_ok(int nt) { return (nt >= 1 && nt <= NS_IIR_MAX_NT) || nt == 25 || nt == 34 || nt == 37; }
 constexpr int NS_BOX_MAX_NT = 12;   // k_box_mask<0 .. 12, 20>
 constexpr int NS_BOX_KB = 20;       // the moving-mean length k_box_mask is built for (TorchGate's default)
 
