@@ -1022,6 +1022,23 @@ def extras(device, wl, out, y2d, gate, O):
     oc["config5_torchgate_forward_backward"] = {"ms_median": round(med, 4), "ms_mean": round(mean, 4),
                                                 "ms_max": max(reps5b),
                                                 "Msamples_s": round(x.numel() / (med * 1e-3) / 1e6, 1), **_time_events.last}
+    # other STFT geometries, the first two minutes of the same recording, device-resident
+    try:
+        y2 = y[:SR * 120].contiguous()
+        og = {}
+        for n_fft in (256, 512, 2048):
+            for stat in (True, False):
+                med, mean, blocks = _time_events(lambda: nr.reduce_noise(y=y2, sr=SR, stationary=stat, n_fft=n_fft), 5, 20)
+                og["n_fft=%d,%s" % (n_fft, "stationary" if stat else "non-stationary")] = {
+                    "ms_median": round(med, 4), "ms_per_call_blocks": blocks,
+                    "Msamples_s": round(y2.numel() / (med * 1e-3) / 1e6, 1),
+                    "settle_ms_per_call_blocks": _time_events.last.get("settle_ms_per_call_blocks")}
+        og["what"] = ("reduce_noise(n_fft=...) on 2 minutes (5.76 M samples, 10 chunks) of the benchmark recording: n_fft = 256 on "
+                      "fast256.hpp (four frames per register transform, round 5), 512 / 2048 on fast512.hpp / fast2048.hpp; "
+                      "5 blocks of 4 back-to-back calls after the adaptive settle, median of the blocks")
+        oc["other_geometries_2min"] = og
+    except Exception as e:
+        oc["other_geometries_2min"] = {"error": repr(e)}
     # PCIe-inclusive: numpy in -> numpy out (H2D + compute + D2H), wall clock
     yh = y.cpu().numpy()
     ts = []

@@ -328,7 +328,7 @@ __global__ __launch_bounds__(WAVES * NT) void kx_apply_istft(View view, Geom g, 
   const int lane = threadIdx.x % NT;
   const int wave = threadIdx.x / NT;
   cd* buf = bufs + wave * lpn<double>(N);
-  for (int i = threadIdx.x; i < N; i += WAVES * NT) tw[i] = tw_g[i];
+  stage_twiddles<WAVES * NT, N>(tw, tw_g, (int)threadIdx.x);
   const int64_t u = blockIdx.y;
   const int64_t row = (view.unit0 + u) / view.n_chunks;
   const int64_t chunk = view.c0 + (view.unit0 + u) % view.n_chunks;

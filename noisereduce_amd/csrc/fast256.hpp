@@ -241,7 +241,7 @@ __global__ __launch_bounds__(WAVES * 64, 3) void k_decide_fast256(Fast25Args A) 
     if (need == 2) v = T2_NEVER;
     return v;
   };
-  for (int i = tid; i < F25_F; i += WAVES * 64) s_t2[i] = t2_to_f32(t2eff(i), 4.0);
+  stage_t2_plain<WAVES * 64, F25_F>(s_t2, A.tc.T2, need, 4.0, tid, t2eff);
   constexpr int NF = F25_FPW * WAVES;
   const int64_t tf0 = (int64_t)blockIdx.x * NF;
   cf v[32];

@@ -55,6 +55,29 @@ __device__ __forceinline__ float t2_to_f32(double v, double scale) {
   return v < 0.0 ? -3.0e38f : (v > 1e37 ? 3.0e38f : (float)(scale * v));
 }
 
+// (round 5) The float32 compare constants of a decision kernel into LDS, COUNT bands by NTHR threads.  The common unit (no
+// live floor, no non-finite sample: need == 0) takes its constants straight from T2: every load of a thread is issued before
+// the first conversion -- the rolled form `for (i = tid; ...) s[i] = f(T2[i])` waits for each load in turn (the prologue-load
+// story of stage_tables): five dependent round trips per 8-frame tile at n_fft = 2048, nine / seventeen at 4096 / 8192.
+// `slow(i)`: the exact constant of band i for the other units.
+template <int NTHR, int COUNT, typename SLOW>
+__device__ __forceinline__ void stage_t2_plain(float* s_t2, const double* __restrict__ T2, int need, double scale, int tid,
+                                               SLOW slow) {
+  if (need == 0) {   // (workgroup-uniform)
+    constexpr int K = (COUNT + NTHR - 1) / NTHR;
+    double t[K];
+#pragma unroll
+    for (int k = 0; k < K; ++k) t[k] = T2[min(tid + k * NTHR, COUNT - 1)];
+#pragma unroll
+    for (int k = 0; k < K; ++k) {
+      const int i = tid + k * NTHR;
+      if ((k + 1) * NTHR <= COUNT || i < COUNT) s_t2[i] = t2_to_f32(t[k], scale);
+    }
+  } else {
+    for (int i = tid; i < COUNT; i += NTHR) s_t2[i] = t2_to_f32(slow(i), scale);
+  }
+}
+
 namespace fast {
 
 constexpr int FN = 512;           // complex points per frame

@@ -173,6 +173,28 @@ struct FftPass {
   }
 };
 
+// (round 5) The workgroup's twiddle table into LDS with every load of a thread in flight before its first store: the rolled
+// `for (i = tid; i < N; i += threads) tw[i] = tw_g[i]` waits for each load in turn -- sixteen dependent round trips per
+// workgroup at n_fft = 4096 (N = 2048, 128 threads), per EIGHT frames of work.  At most 8 entries per thread at a time.
+template <int NTHR, int N, typename T>
+__device__ __forceinline__ void stage_twiddles(cx<T>* tw, const cx<T>* __restrict__ tw_g, int tid) {
+  constexpr int K = (N + NTHR - 1) / NTHR, KB = K < 8 ? K : 8;
+#pragma unroll
+  for (int k0 = 0; k0 < K; k0 += KB) {
+    cx<T> t[KB];
+#pragma unroll
+    for (int k = 0; k < KB; ++k) {
+      const int i = tid + (k0 + k) * NTHR;
+      t[k] = tw_g[i < N ? i : N - 1];
+    }
+#pragma unroll
+    for (int k = 0; k < KB; ++k) {
+      const int i = tid + (k0 + k) * NTHR;
+      if (k0 + k < K && i < N) tw[i] = t[k];
+    }
+  }
+}
+
 // In-place complex FFT of buf[0..N) (unnormalised; INV uses exp(+i...)).
 template <typename T, int N, bool INV, int NT = 64>
 __device__ __forceinline__ void wave_fft(cx<T>* buf, const cx<T>* tw, int lane) {

@@ -220,7 +220,7 @@ __global__ __launch_bounds__(WAVES * NT) void k_stft_bits(View view, Geom g, con
   const int need = need_of(tc, u);
   const bool floor_live = need == 1;
   if (MODE == 0 && !floor_live) return;  // whole block: uniform
-  for (int i = threadIdx.x; i < N; i += WAVES * NT) tw[i] = tw_g[i];
+  stage_twiddles<WAVES * NT, N>(tw, tw_g, (int)threadIdx.x);
   if (MODE == 1) {
     for (int i = threadIdx.x; i <= N; i += WAVES * NT) {
       double t2 = tc.T2[i];
@@ -328,12 +328,9 @@ __global__ __launch_bounds__(WAVES * NT) void k_decide_lds(View view, Geom g, co
     if (need == 2) t2 = T2_NEVER;
     return t2;
   };
-  for (int i = threadIdx.x; i < N; i += WAVES * NT) tw[i] = tw_g[i];
-  for (int i = threadIdx.x; i <= N; i += WAVES * NT) {
-    const double t2 = t2eff(i);
-    // "every cell passes" as a huge negative constant: P - T > 0 and the ambiguity test fails by itself
-    sT2[i] = t2_to_f32(t2, 1.0);
-  }
+  stage_twiddles<WAVES * NT, N>(tw, tw_g, (int)threadIdx.x);
+  // ("every cell passes" as a huge negative constant: P - T > 0 and the ambiguity test fails by itself)
+  stage_t2_plain<WAVES * NT, N + 1>(sT2, tc.T2, need, 1.0, (int)threadIdx.x, t2eff);
   const int64_t row = (view.unit0 + u) / view.n_chunks;
   const int64_t chunk = view.c0 + (view.unit0 + u) % view.n_chunks;
   __syncthreads();

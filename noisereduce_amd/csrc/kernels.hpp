@@ -89,7 +89,7 @@ __global__ __launch_bounds__(WAVES * NT) void k_stft(View view, Geom g, const cx
   const int lane = threadIdx.x % NT;  // thread within the frame's team (NT = 64: one wavefront)
   const int wave = threadIdx.x / NT;
   cx<TC>* buf = bufs + wave * lpn<TC>(N);
-  for (int i = threadIdx.x; i < N; i += WAVES * NT) tw[i] = tw_g[i];
+  stage_twiddles<WAVES * NT, N>(tw, tw_g, (int)threadIdx.x);
   const int64_t u = blockIdx.y;
   const int64_t row = (view.unit0 + u) / view.n_chunks;
   const int64_t chunk = view.c0 + (view.unit0 + u) % view.n_chunks;
@@ -173,7 +173,7 @@ __global__ __launch_bounds__(WAVES * NT) void k_apply_istft(View view, Geom g, c
   const int lane = threadIdx.x % NT;  // thread within the frame's team (NT = 64: one wavefront)
   const int wave = threadIdx.x / NT;
   cx<float>* buf = bufs + wave * lpn<float>(N);
-  for (int i = threadIdx.x; i < N; i += WAVES * NT) tw[i] = tw_g[i];
+  stage_twiddles<WAVES * NT, N>(tw, tw_g, (int)threadIdx.x);
   const int64_t u = blockIdx.y;
   const int64_t row = (view.unit0 + u) / view.n_chunks;
   const int64_t chunk = view.c0 + (view.unit0 + u) % view.n_chunks;
@@ -514,7 +514,6 @@ __global__ __launch_bounds__(64 * STAT_TG) void k_colstats1_final(const double* 
                                                                   int ddof, double* __restrict__ pmax,
                                                                   double* __restrict__ thresh, GateConsts gc) {
   __shared__ double r[3][STAT_TG][64];
-  __shared__ int r_exact[STAT_TG][64];
   const int l = threadIdx.x & 63, tg = threadIdx.x >> 6;
   const int f = blockIdx.x * 64 + l;
   const int64_t u = blockIdx.y;
@@ -542,7 +541,6 @@ __global__ __launch_bounds__(64 * STAT_TG) void k_colstats1_final(const double* 
   for (int k = 0; k < STAT_TG; ++k) mx = fmax(mx, r[0][k][l]);
   const double mdb = cell_db(mx, mag_scale);
   const double pivot = live ? cell_db(p0, mag_scale) : 0.0;
-  bool exact = false;
   {
     // cells below the floor: replace d by the floored value (both about the pivot).
     // dB < mdb - top_db  <=>  P < Pfl (cell_db is monotone; at the boundary both forms of the cell give the
@@ -555,42 +553,76 @@ __global__ __launch_bounds__(64 * STAT_TG) void k_colstats1_final(const double* 
     bool any = false;
 #pragma unroll
     for (int k = 0; k < STAT1_MAXS; ++k) any = any || (m1[k] < Pfl);
-    if (any) {
+    if (__ballot(any) != 0ull) {   // (wave-uniform: the rescans below are done by the whole wavefront)
 #pragma unroll 1
       for (int k = 0; k < STAT1_MAXS; ++k) {
-        const int ts = tg + STAT_TG * k;
-        if (!(live && ts < nts)) continue;
-        const double* o = part + ((u * nts + ts) * STAT1_NP) * (int64_t)g.FS + f;
-        const double a1 = o[g.FS], a2 = o[2 * g.FS];
-        if (a1 < Pfl) {
-          const double d = cell_db(a1, mag_scale) - pivot;
-          if (d < dfl) {
-            s1 += dfl - d;
-            s2 += dfl * dfl - d * d;
-          }
-          if (a2 < Pfl) {
-            const double d2 = cell_db(a2, mag_scale) - pivot;
-            if (d2 < dfl) {
-              s1 += dfl - d2;
-              s2 += dfl * dfl - d2 * d2;
+        const int ts = tg + STAT_TG * k;     // wave-uniform
+        if (ts >= nts) break;
+        bool both = false;
+        if (live && any) {
+          const double* o = part + ((u * nts + ts) * STAT1_NP) * (int64_t)g.FS + f;
+          const double a1 = o[g.FS], a2 = o[2 * g.FS];
+          both = a1 < Pfl && a2 < Pfl;     // a third floored cell of this slice would go unseen: rescan the slice
+          if (a1 < Pfl && !both) {
+            const double d = cell_db(a1, mag_scale) - pivot;
+            if (d < dfl) {
+              s1 += dfl - d;
+              s2 += dfl * dfl - d * d;
             }
-            exact = true;  // a third floored cell of this slice would have gone unseen
+          }
+        }
+        // (round 5) rare: a slice whose two tracked minima are both under the floor.  The wavefront scans that slice of
+        // that band for EVERY cell under the floor (compares; a logarithm per floored cell) and the band's lane takes the
+        // correction -- until round 5 such a band was recomputed whole, one logarithm per cell of all T frames by one
+        // wavefront: 40 us of a 12 us kernel whenever a recording's DC / Nyquist band had such a slice (the benchmark
+        // recording at n_fft = 256: 0.234 instead of 0.157 ms per call).
+        unsigned long long todo = __ballot(both);
+        while (todo) {
+          const int src = __ffsll((long long)todo) - 1;
+          todo &= todo - 1;
+          const int fb = blockIdx.x * 64 + src;
+          const double Pfl_s = __shfl(Pfl, src), piv_s = __shfl(pivot, src), dfl_s = __shfl(dfl, src);
+          const int64_t tb = g.T * ts / nts, te = g.T * (ts + 1) / nts;
+          double c1 = 0.0, c2 = 0.0;
+          for (int64_t t0 = tb + l; t0 < te; t0 += 64 * 4) {
+            double pv[4];
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+              const int64_t t = t0 + 64 * q;
+              pv[q] = t < te ? P[(u * g.T + t) * g.FS + fb] : 1e300;
+            }
+#pragma unroll
+            for (int q = 0; q < 4; ++q)
+              if (pv[q] < Pfl_s) {
+                const double d = cell_db(pv[q], mag_scale) - piv_s;
+                if (d < dfl_s) {
+                  c1 += dfl_s - d;
+                  c2 += dfl_s * dfl_s - d * d;
+                }
+              }
+          }
+          for (int off = 32; off > 0; off >>= 1) {
+            c1 += __shfl_xor(c1, off);
+            c2 += __shfl_xor(c2, off);
+          }
+          if (l == src) {
+            s1 += c1;
+            s2 += c2;
           }
         }
       }
     }
   }
   __syncthreads();
-  r[1][tg][l] = s1; r[2][tg][l] = s2; r_exact[tg][l] = exact ? 1 : 0;
+  r[1][tg][l] = s1; r[2][tg][l] = s2;
   __syncthreads();
   if (tg != 0) return;
   double thr_out = (double)NAN;
-  s1 = 0.0; s2 = 0.0; exact = false;
+  s1 = 0.0; s2 = 0.0;
 #pragma unroll
   for (int k = 0; k < STAT_TG; ++k) {  // fixed order: deterministic
     s1 += r[1][k][l];
     s2 += r[2][k][l];
-    exact = exact || r_exact[k][l] != 0;
   }
   if (live) {
     pmax[i] = mx;
@@ -600,31 +632,6 @@ __global__ __launch_bounds__(64 * STAT_TG) void k_colstats1_final(const double* 
     thresh[i] = thr_out;
   } else if (f < g.FS) {
     pmax[i] = 0.0;
-  }
-  // rare: bands whose slices may hide more floored cells -- the wave recomputes them like k_colstats
-  unsigned long long todo = __ballot(exact && live);
-  while (todo) {
-    const int src = __ffsll((long long)todo) - 1;
-    todo &= todo - 1;
-    const int fb = blockIdx.x * 64 + src;
-    const double mb = __shfl(mdb, src);
-    double a1 = 0.0, a2 = 0.0;
-    for (int64_t t = l; t < g.T; t += 64) {
-      double d = cell_db(P[(u * g.T + t) * g.FS + fb], mag_scale) - mb;
-      d = (d != d) ? d : fmax(d, -top_db);   // (fmax would drop a NaN; numpy / torch keep it)
-      a1 += d;
-      a2 += d * d;
-    }
-    for (int off = 32; off > 0; off >>= 1) {
-      a1 += __shfl_xor(a1, off);
-      a2 += __shfl_xor(a2, off);
-    }
-    if (l == src) {
-      double var = (a2 - a1 * a1 / Tn) / (Tn - (double)ddof);
-      if (var < 0.0) var = 0.0;
-      thr_out = (mb + a1 / Tn) + sqrt(var) * n_std;
-      thresh[i] = thr_out;
-    }
   }
   if (gc.T2 == nullptr || u != 0) return;
   // ---- the gate's compare constants for these 64 bands (wave 0 holds their thresholds) ----

@@ -10,6 +10,6 @@ for n in $NFFTS; do
   D=/tmp/prof_nfft_$n
   rocprofv3 --kernel-trace --stats -d $D -o p --output-format csv -- python $REPO/tools/prof_nfft_loop.py $n $KIND > /dev/null 2>&1
   F=$(find $D -name '*kernel_stats.csv' | head -1)
-  [ -n "$F" ] && (head -1 "$F"; grep "sg::" "$F") > "$OUT/nfft${n}_${KIND}_kernel_stats.csv"
+  [ -n "$F" ] && (head -1 "$F"; grep "sg::" "$F") > "$OUT/nfft${n}_${KIND}_kernel_stats.csv"; [ -n "$F" ] && grep -v "sg::" "$F" | head -8 > "$OUT/nfft${n}_${KIND}_other_kernels.csv"
   echo "== n_fft $n $KIND"; cut -d, -f1-4 "$OUT/nfft${n}_${KIND}_kernel_stats.csv" | cut -c1-160
 done
