@@ -135,7 +135,9 @@ __device__ __forceinline__ cx<T> twN(const cx<T>* tw, int t) {
 
 // NT = threads that cooperate on one transform (64: one wavefront per frame; 256: a whole
 // workgroup per frame, for the sizes whose butterflies would not fit one wave's registers).
-template <typename T, int N, int S, bool INV, int NT = 64>
+// SY: what team_sync synchronises (default: the team size).  A kernel whose 64-lane teams ARE wavefronts and whose transform
+// buffers are team-private passes SY = 1 (wave-level ordering, no workgroup barrier): k_stft, k_apply_istft, k_decide_lds.
+template <typename T, int N, int S, bool INV, int NT = 64, int SY = NT>
 struct FftPass {
   static __device__ __forceinline__ void run(cx<T>* buf, const cx<T>* tw, int lane) {
     constexpr int NR = N / S;  // current sub-transform length
@@ -151,7 +153,7 @@ struct FftPass {
         for (int j = 0; j < R; ++j) v[c][j] = buf[lp<T>(i + j * NB)];
       }
     }
-    team_sync<NT>();
+    team_sync<SY>();
 #pragma unroll
     for (int c = 0; c < PER; ++c) {
       int i = lane + NT * c;
@@ -168,8 +170,8 @@ struct FftPass {
         for (int k = 0; k < R; ++k) buf[lp<T>(o + S * k)] = v[c][k];
       }
     }
-    team_sync<NT>();
-    if constexpr (NR / R > 1) FftPass<T, N, S * R, INV, NT>::run(buf, tw, lane);
+    team_sync<SY>();
+    if constexpr (NR / R > 1) FftPass<T, N, S * R, INV, NT, SY>::run(buf, tw, lane);
   }
 };
 
@@ -196,9 +198,9 @@ __device__ __forceinline__ void stage_twiddles(cx<T>* tw, const cx<T>* __restric
 }
 
 // In-place complex FFT of buf[0..N) (unnormalised; INV uses exp(+i...)).
-template <typename T, int N, bool INV, int NT = 64>
+template <typename T, int N, bool INV, int NT = 64, int SY = NT>
 __device__ __forceinline__ void wave_fft(cx<T>* buf, const cx<T>* tw, int lane) {
-  FftPass<T, N, 1, INV, NT>::run(buf, tw, lane);
+  FftPass<T, N, 1, INV, NT, SY>::run(buf, tw, lane);
 }
 
 // Real-FFT split: from Zc = FFT_N(x_even + i x_odd) compute bin k of the length-2N real

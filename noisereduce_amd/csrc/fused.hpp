@@ -306,6 +306,7 @@ __global__ __launch_bounds__(WAVES * NT) void k_decide_lds(View view, Geom g, co
                                                            double mag_scale, double top_db,
                                                            unsigned long long* __restrict__ bits, int wpr) {
   static_assert(NT == 64 || NT == 32 || NT == 16, "team = a power-of-two part of a wavefront");
+  constexpr int SY = 1;                     // teams are (parts of) wavefronts, buffers team-private: wave-level pass syncs
   extern __shared__ __attribute__((aligned(16))) char smem[];
   cx<float>* tw = reinterpret_cast<cx<float>*>(smem);
   cx<float>* bufs = tw + N;
@@ -360,8 +361,8 @@ __global__ __launch_bounds__(WAVES * NT) void k_decide_lds(View view, Geom g, co
     for (int off = NT / 2; off > 0; off >>= 1) nrm2 += __shfl_xor(nrm2, off);
     // 2 delta^2 = 2 * 2^-32 * nrm2; a silent frame (nrm2 == 0) has no ambiguous cells
     const float d2 = nrm2 > 0.f ? 2.0f * 2.3283064e-10f * nrm2 : -1.0f;
-    team_sync<NT>();
-    wave_fft<float, N, false, NT>(buf, tw, lane);
+    team_sync<SY>();
+    wave_fft<float, N, false, NT, SY>(buf, tw, lane);
     unsigned long long* brow = bits + ((u * g.T + t) * (int64_t)wpr);
     constexpr int NW = N / 64 + 1;            // words per frame (F = N + 1 bins)
     unsigned long long acc[NW];
@@ -418,7 +419,7 @@ __global__ __launch_bounds__(WAVES * NT) void k_decide_lds(View view, Geom g, co
 #pragma unroll
       for (int w = 0; w < NW; ++w) brow[w] = acc[w];
     }
-    team_sync<NT>();
+    team_sync<SY>();
   }
 }
 

@@ -83,6 +83,7 @@ __global__ __launch_bounds__(WAVES * NT) void k_stft(View view, Geom g, const cx
                                                      double* __restrict__ P_out, float* __restrict__ mag_out,
                                                      double* __restrict__ z_out, double z_scale,
                                                      unsigned long long* __restrict__ pmax_bits) {
+  constexpr int SY = NT <= 64 ? 1 : NT;   // a team of <= 64 lanes is (part of) one wavefront and its buffer is its own
   extern __shared__ __attribute__((aligned(16))) char smem[];
   cx<TC>* tw = reinterpret_cast<cx<TC>*>(smem);
   cx<TC>* bufs = tw + N;
@@ -116,8 +117,8 @@ __global__ __launch_bounds__(WAVES * NT) void k_stft(View view, Geom g, const cx
         buf[lp<TC>(j)] = z;
       }
     }
-    team_sync<NT>();
-    wave_fft<TC, N, false, NT>(buf, tw, lane);
+    team_sync<SY>();
+    wave_fft<TC, N, false, NT, SY>(buf, tw, lane);
     if (valid) {
       const int64_t rowoff = (u * g.T + t) * g.FS;
 #pragma unroll
@@ -139,7 +140,7 @@ __global__ __launch_bounds__(WAVES * NT) void k_stft(View view, Geom g, const cx
         }
       }
     }
-    team_sync<NT>();
+    team_sync<SY>();
   }
   // per-(unit, band) max power, order-independent (non-negative doubles order like their bits)
   if (pmax_bits) {
@@ -167,6 +168,7 @@ __global__ __launch_bounds__(WAVES * NT) void k_apply_istft(View view, Geom g, c
                                                             // sums of the smoothed bit mask read as they are (no float mask field)
                                                             const unsigned short* __restrict__ K16 = nullptr,
                                                             float kscale = 0.f) {
+  constexpr int SY = NT <= 64 ? 1 : NT;   // (as in k_stft)
   extern __shared__ __attribute__((aligned(16))) char smem[];
   cx<float>* tw = reinterpret_cast<cx<float>*>(smem);
   cx<float>* bufs = tw + N;
@@ -196,8 +198,8 @@ __global__ __launch_bounds__(WAVES * NT) void k_apply_istft(View view, Geom g, c
         buf[lp<float>(j)] = z;
       }
     }
-    team_sync<NT>();
-    wave_fft<float, N, false, NT>(buf, tw, lane);
+    team_sync<SY>();
+    wave_fft<float, N, false, NT, SY>(buf, tw, lane);
     // split -> mask -> merge, pairwise in place: task k handles bins k and N-k.
     if (valid) {
       const float* Mrow = M + (u * g.T + t) * g.FS;
@@ -232,8 +234,8 @@ __global__ __launch_bounds__(WAVES * NT) void k_apply_istft(View view, Geom g, c
         }
       }
     }
-    team_sync<NT>();
-    wave_fft<float, N, true, NT>(buf, tw, lane);
+    team_sync<SY>();
+    wave_fft<float, N, true, NT, SY>(buf, tw, lane);
     if (valid) {
       float2* srow = reinterpret_cast<float2*>(seg + (u * g.T + t) * (int64_t)g.n);
       for (int j = lane; j < N; j += NT) {
@@ -241,7 +243,7 @@ __global__ __launch_bounds__(WAVES * NT) void k_apply_istft(View view, Geom g, c
         srow[j] = make_float2(z.x * win_s[2 * j], z.y * win_s[2 * j + 1]);
       }
     }
-    team_sync<NT>();
+    team_sync<SY>();
   }
 }
 
@@ -550,16 +552,22 @@ __global__ __launch_bounds__(64 * STAT_TG) void k_colstats1_final(const double* 
     const double Pfl = am > 0.0 ? am * am : 0.0;
     // (hot path: compares only.  The corrections sit in a ROLLED loop that re-reads the two minima -- unrolled with
     // its two inlined logarithms per slice the kernel was 40 KB of straight-line code, fetched cold on every call)
-    bool any = false;
+    // (round 5) Which of the thread's slices have a floored minimum: a bit per slice, OR-ed over the wavefront; the loop
+    // below only visits those (typically one or two slices of the DC / Nyquist bands; it used to walk all sixteen with a
+    // dependent load each whenever any lane of the wavefront had one -- the two workgroups that hold those bands set the
+    // kernel's duration)
+    unsigned km = 0u;
 #pragma unroll
-    for (int k = 0; k < STAT1_MAXS; ++k) any = any || (m1[k] < Pfl);
-    if (__ballot(any) != 0ull) {   // (wave-uniform: the rescans below are done by the whole wavefront)
-#pragma unroll 1
-      for (int k = 0; k < STAT1_MAXS; ++k) {
-        const int ts = tg + STAT_TG * k;     // wave-uniform
-        if (ts >= nts) break;
+    for (int k = 0; k < STAT1_MAXS; ++k) km |= (m1[k] < Pfl ? 1u : 0u) << k;
+    unsigned wor = km;
+    for (int off = 32; off > 0; off >>= 1) wor |= (unsigned)__shfl_xor((int)wor, off);
+    {
+      while (wor) {                            // wave-uniform
+        const int k = __ffs((int)wor) - 1;
+        wor &= wor - 1u;
+        const int ts = tg + STAT_TG * k;     // (< nts: slices beyond it never set a bit)
         bool both = false;
-        if (live && any) {
+        if ((km >> k) & 1u) {
           const double* o = part + ((u * nts + ts) * STAT1_NP) * (int64_t)g.FS + f;
           const double a1 = o[g.FS], a2 = o[2 * g.FS];
           both = a1 < Pfl && a2 < Pfl;     // a third floored cell of this slice would go unseen: rescan the slice
