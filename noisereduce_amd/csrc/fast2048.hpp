@@ -289,8 +289,15 @@ __global__ __launch_bounds__(WAVES * 64, 3) void k_decide_fast2048(Fast20Args A)
     const int q = amb_s ? (__ffs((int)amb_s) - 1) : 32;
     const int cs = src & 31, gs = src >> 5;
     const int f = q < 32 ? cs + 32 * q : 1024;
-    const double P = f20_exact_power(A, row, chunk, tq + gs, f, lane);
-    const bool pass = P > t2eff(f);
+    const Fast20Args& L = *late_args<Fast20Args>();     // (cold path: arguments re-read here, not kept live from the entry)
+    const double P = f20_exact_power(L, row, chunk, tq + gs, f, lane);
+    double t2 = L.tc.T2[f];
+    if (floor_live) {
+      const double fl = cell_db(L.tc.pmax[u * (int64_t)L.g.FS + f], L.mag_scale) - L.top_db;
+      if (fl > L.tc.thresh[f]) t2 = -1.0;
+    }
+    if (need == 2) t2 = T2_NEVER;
+    const bool pass = P > t2;
     if (lane == src) {
       if (q < 32) {
         pred = (pred & ~(1u << q)) | ((pass ? 1u : 0u) << q);

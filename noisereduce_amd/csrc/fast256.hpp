@@ -309,8 +309,15 @@ __global__ __launch_bounds__(WAVES * 64, 3) void k_decide_fast256(Fast25Args A) 
     if (sam) { q = __ffs((int)sam) - 1; fr = q >> 3; f = bin6(cs, q & 7); }
     else { q = -1; fr = __ffs((int)s128) - 1; f = 128; }
     const int64_t t = tq + 4 * gs + fr;
-    const double Pe = f25_exact_power(A, row, chunk, t, f, lane);
-    const bool pass = Pe > t2eff(f);
+    const Fast25Args& L = *late_args<Fast25Args>();     // (cold path: arguments re-read here, not kept live from the entry)
+    const double Pe = f25_exact_power(L, row, chunk, t, f, lane);
+    double t2 = L.tc.T2[f];
+    if (floor_live) {
+      const double fl = cell_db(L.tc.pmax[u * (int64_t)L.g.FS + f], L.mag_scale) - L.top_db;
+      if (fl > L.tc.thresh[f]) t2 = -1.0;
+    }
+    if (need == 2) t2 = T2_NEVER;
+    const bool pass = Pe > t2;
     if (lane == src) {
       if (q >= 0) { pr = (pr & ~(1u << q)) | ((pass ? 1u : 0u) << q); am &= ~(1u << q); }
       else { p128 = (p128 & ~(1u << fr)) | ((pass ? 1u : 0u) << fr); a128 &= ~(1u << fr); }

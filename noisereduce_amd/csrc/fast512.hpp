@@ -218,8 +218,15 @@ __global__ __launch_bounds__(WAVES * 64, 3) void k_decide_fast512(Fast5Args A) {
     else if (s256A) { which = 2; f = 256; }
     else { which = 3; f = 256; }
     const int64_t t = tq + 2 * gs + (which & 1);
-    const double P = f5_exact_power(A, row, chunk, t, f, lane);
-    const bool pass = P > t2eff(f);
+    const Fast5Args& L = *late_args<Fast5Args>();       // (cold path: arguments re-read here, not kept live from the entry)
+    const double P = f5_exact_power(L, row, chunk, t, f, lane);
+    double t2 = L.tc.T2[f];
+    if (floor_live) {
+      const double fl = cell_db(L.tc.pmax[u * (int64_t)L.g.FS + f], L.mag_scale) - L.top_db;
+      if (fl > L.tc.thresh[f]) t2 = -1.0;
+    }
+    if (need == 2) t2 = T2_NEVER;
+    const bool pass = P > t2;
     if (lane == src) {
       if (which == 0) { pA = (pA & ~(1u << q)) | ((pass ? 1u : 0u) << q); aA &= ~(1u << q); }
       else if (which == 1) { pB = (pB & ~(1u << q)) | ((pass ? 1u : 0u) << q); aB &= ~(1u << q); }

@@ -78,6 +78,18 @@ __device__ __forceinline__ void stage_t2_plain(float* s_t2, const double* __rest
   }
 }
 
+// (round 5) The kernel's own argument struct re-read from the kernel-argument segment through an OPAQUE pointer, for the COLD
+// parts of a long kernel (the exact re-evaluation of an ambiguous cell needs the view's dozen fields, the float64 tables and
+// the threshold pointers).  Taken from the by-value argument they stay live in SGPRs from the kernel's entry through every
+// phase (k_decide_fast512 / 2048 / 256: 83 - 92 spilled SGPRs); read through this pointer they are loaded where they are
+// used.  ARGS must be the kernel's FIRST (only) parameter.  (k_gate_onepass does the same per field, onepass.hpp.)
+template <typename ARGS>
+__device__ __forceinline__ const ARGS* late_args() {
+  const __attribute__((address_space(4))) char* kp = (const __attribute__((address_space(4))) char*)__builtin_amdgcn_kernarg_segment_ptr();
+  asm volatile("" : "+s"(kp));
+  return reinterpret_cast<const ARGS*>((const char*)kp);
+}
+
 namespace fast {
 
 constexpr int FN = 512;           // complex points per frame

@@ -1,0 +1,27 @@
+#!/bin/bash
+# Final measurements of round 5's second session (the code paths that changed: short frames, fast256, statistics): GPU test
+# suite, bench lines (configs[1], [2], [3]-share), rocprofv3 kernel stats of the bench command, PMC traffic, throughput over
+# n_fft and sample dtypes, per-kernel tables of n_fft 256 / 512 / 2048, step timeline.  One gpurun call.
+# usage (on the GPU box): tools/round_final_v5.sh <tag>      -> gpurun_out/<tag>/
+set -u
+TAG=${1:-r05_v5}
+REPO=${GRAFT_REPO_ROOT:-/root/repo}
+OUT=$REPO/gpurun_out/$TAG
+mkdir -p "$OUT"
+cd "$REPO"
+(python -m pytest tests -m gpu -q 2>&1 | tail -5) > "$OUT/pytest_gpu.txt"
+python bench.py > "$OUT/bench.json" 2> "$OUT/bench.err"
+python bench.py --workload config3 --no-cpu-baseline > "$OUT/bench_config3.json" 2>> "$OUT/bench.err"
+python bench.py --workload config4 --no-cpu-baseline --steps 10 --warmup 3 > "$OUT/bench_config4.json" 2>> "$OUT/bench.err"
+tools/gpu_profile.sh ${TAG}k --no-extras > "$OUT/prof.log" 2>&1
+tools/gpu_profile.sh ${TAG}k3 --no-extras --workload config3 > "$OUT/prof3.log" 2>&1
+for t in ${TAG}k ${TAG}k3; do F=$(find gpurun_out/prof_$t -name '*kernel_stats.csv' | head -1); [ -n "$F" ] && (head -1 "$F"; grep "sg::" "$F") > "$OUT/${t}_kernel_stats.csv"; done
+tools/gpu_traffic.sh > "$OUT/traffic.log" 2>&1
+cp gpurun_out/traffic/traffic.json gpurun_out/traffic/traffic_detail.json "$OUT/" 2>/dev/null
+WARM=20 REPS=20 python tools/time_nfft.py > "$OUT/time_nfft.txt" 2>&1
+python tools/time_dtypes.py > "$OUT/time_dtypes.txt" 2>&1
+tools/prof_nfft.sh ${TAG}_nfft "256 512 2048" stat > /dev/null 2>&1
+tools/prof_nfft.sh ${TAG}_nfft "256 512 2048" nonstat > /dev/null 2>&1
+cp gpurun_out/${TAG}_nfft/*kernel_stats.csv "$OUT/" 2>/dev/null
+tools/step_timeline.sh $TAG > "$OUT/step_timeline.log" 2>&1; cp gpurun_out/timeline_$TAG.txt "$OUT/" 2>/dev/null
+cat "$OUT/pytest_gpu.txt"; head -c 400 "$OUT/bench.json"; echo; tail -3 "$OUT/traffic.log" | cut -c1-300
