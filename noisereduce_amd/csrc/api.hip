@@ -957,7 +957,7 @@ extern "C" int sg_create(const sg_params* p, const double* window_host, sg_handl
       const int wpr = (h->F + 63) / 64;
       const bool small = (p->n_grad_freq + 1) * (p->n_grad_freq + 1) <= 255;
       size_t lds = 0;
-      for (h->sm2_tt = SM2_TT; h->sm2_tt >= 16; h->sm2_tt >>= 1) {
+      for (h->sm2_tt = smooth2_tt_max(h->F); h->sm2_tt >= 16; h->sm2_tt >>= 1) {
         const int rows = h->sm2_tt + 2 * p->n_grad_time;
         lds = smooth2_cf_bytes(rows + 2, h->F, small ? 1 : 2) + (size_t)rows * (wpr + 2) * 8 + 8192;
         if (lds <= 150 * 1024) break;
@@ -3270,7 +3270,9 @@ extern "C" int sg_debug_fetch(sg_handle* h, int32_t what, void* host, int64_t by
       if (h->dbg_fast && h->dbg_fused)
         FAIL(h, SG_E_STATE, "fast path keeps the smoothed mask as uint16 counts in the apply kernel's lane order");
       if (h->dbg_fused && h->dbg_k16_only) {
-        // the apply kernel read the K counts directly: expand them now (same kernel, same arithmetic as the materialising path)
+        // the apply kernel read the K counts directly: expand them now (same kernel, same arithmetic as the materialising path).
+        // (a debug entry point: whatever stream produced the counts has to be done first)
+        HIPCHK(h, hipDeviceSynchronize());
         hipLaunchKernelGGL(k_k16_to_mask, dim3(grid_1d((int64_t)cells / 8, 256)), dim3(256), 0, (hipStream_t)stream,
                            (const unsigned short*)h->K16.p, h->dbg_g, h->p.n_grad_freq, h->p.n_grad_time, 1.0f / (float)h->ktot,
                            (float)h->p.prop_decrease, 1, h->p.smooth_mask ? 1 : 0, (float*)h->M.p, (int64_t)h->dbg_units);

@@ -512,6 +512,10 @@ __global__ __launch_bounds__(256) void k_smooth_bits(const unsigned long long* _
 // launch parameter: long frames (n_fft = 4096: 2049 bins per row) take lower tiles so that the tile fits the LDS.
 constexpr int SM2_TT = 64;
 constexpr int SM2_THREADS = 576;
+// (round 5) tallest tile tried for a row of F bins: short rows take tall tiles (fewer halo rows per output -- the time
+// half-width of n_fft = 256 at 48 kHz is 37 frames: 64-frame tiles ran phase 1 over 2.2 x the rows) and split them into
+// segments for phase 2
+__host__ __device__ inline int smooth2_tt_max(int F) { return F <= 160 ? 256 : (F <= 320 ? 128 : SM2_TT); }
 
 __device__ __forceinline__ unsigned long long funnel_r(unsigned long long lo, unsigned long long hi, int sh) {
   // bits [sh, sh+64) of the 128-bit value hi:lo, 0 <= sh < 64
@@ -619,9 +623,17 @@ __global__ __launch_bounds__(SM2_THREADS) void k_smooth_bits2(const unsigned lon
   // The walk reads rows r - nt .. r + nt + 2 for r = nt .. nt + tt - 1: never below row 0, at most two
   // rows past the tile -- those two rows exist and are zero (cleared above), so no bounds checks
   // (they were scalar compares/selects per read: the CU's one scalar unit was the bottleneck).
-  for (int pos = threadIdx.x; pos < g.F; pos += SM2_THREADS) {
+  // (round 5) Short rows (F = 129 / 257: n_fft = 256 / 512) used to leave 447 / 319 of the 576 threads idle here: the tile's
+  // frames are split into nseg = 576 / F segments, one (segment, position) per thread, each segment with its own start-up sum
+  // (2 nt + 2 reads) -- integer arithmetic, so the counts do not depend on where a segment starts.
+  const int nseg = g.F < SM2_THREADS ? max(1, SM2_THREADS / g.F) : 1;
+  const int slen = (tt + nseg - 1) / nseg;
+  for (int item = threadIdx.x; item < nseg * g.F; item += SM2_THREADS) {
+    const int seg = nseg == 1 ? 0 : item / g.F;
+    const int pos = item - seg * g.F;
+    const int i0 = seg * slen;                           // first output frame of the segment (tile-local)
     const int f = perm ? fast::perm_inv(pos) : pos;
-    const CT* col = cf + f + ((f >> 5) << 2);
+    const CT* col = cf + f + ((f >> 5) << 2) + (size_t)i0 * FP;
     int c = 0, R = 0, L = 0;
     for (int b = -nt; b <= nt + 1; ++b) {
       const int x = (int)col[(size_t)(nt + b) * FP];
@@ -629,8 +641,9 @@ __global__ __launch_bounds__(SM2_THREADS) void k_smooth_bits2(const unsigned lon
       if (b >= 1) R += x;
       if (b <= 0) L += x;
     }
-    unsigned short* kout = K + (u * g.T + t0) * (int64_t)g.FS + pos;
-    const int n_out = (int)min<int64_t>(tt, min<int64_t>(t_end, g.T) - t0);
+    unsigned short* kout = K + (u * g.T + t0 + i0) * (int64_t)g.FS + pos;
+    const int n_tile = (int)min<int64_t>(tt, min<int64_t>(t_end, g.T) - t0);
+    const int n_out = min(slen, n_tile - i0);
     const CT* pa = col + (size_t)(2 * nt + 2) * FP;  // row r + nt + 2
     const CT* pb = col + (size_t)(nt + 1) * FP;      // row r + 1
     const CT* pc = col;                              // row r - nt
