@@ -36,7 +36,7 @@ SG_API int sg_debug_fetch(sg_handle* h, int32_t what, void* host, int64_t bytes,
 #define SG_OPT_FORCE_F64_DECIDE 3 /* value != 0: decide every mask cell from a float64 STFT */
 #define SG_OPT_FORCE_NOSEAM 4   /* value != 0: overlapping apply tiles instead of abutting tiles + seam kernel */
 #define SG_OPT_FORCE_NOLEAN 5   /* value != 0: apply kernel with full-size LDS slices and stored frames */
-#define SG_OPT_FORCE_SPLIT 6    /* value != 0: default geometry: decide / smooth / apply as three kernels instead of the one-pass kernel */
+#define SG_OPT_FORCE_SPLIT 6    /* value != 0: default geometry: decide / smooth / apply as three kernels instead of the one-pass kernel; non-stationary gate: the serial tile chain (k_iir_comb + k_iir_chain) instead of k_iir_chain_par */
 #define SG_OPT_INJECT_HANDOFF_FAULT 7 /* tests: the next launch with in-launch hand-offs reports `value` (bits 0..2) as lost hand-offs
                                        * (the output is fine); bits 3..5 make the KERNEL lose its hand-offs (3 or 4: the one-pass
                                        * gate, 5: the fused apply): the producers' tags are never accepted and the polls give up --

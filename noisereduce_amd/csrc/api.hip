@@ -49,6 +49,9 @@
 #ifndef SG_SHORT_TEAMS
 #define SG_SHORT_TEAMS 1
 #endif
+#ifndef SG_CHAIN_PAR
+#define SG_CHAIN_PAR 1    // the non-stationary gate's tile chain in 16 parallel runs per band (nonstat.hpp: k_iir_chain_par); 0: A/B
+#endif
 #ifndef SG_STATS_TEAM
 #define SG_STATS_TEAM 1   // float64 noise-clip transform of 1024 points (n_fft = 2048) by a whole workgroup (launch_stft_n); 0: A/B
 #endif
@@ -1614,16 +1617,30 @@ static int stage_nonstat_mask2(sg_handle* h, const View& v, const Geom& g, int64
   if ((rc = ensure(h, h->nsc, bytes))) return rc;
   {
     ProfScope ps(h, SG_STAGE_NONSTAT_MASK, st);
-    if (sub_ok)
-      hipLaunchKernelGGL(k_iir_comb, dim3((unsigned)((nk * g.FS + 255) / 256), (unsigned)ub), dim3(256), 0, st,
-                         (const double*)h->nss.p, g, tl, h->p.iir_b, (double*)h->nsp.p, (int)nsub);
-    else
-      hipLaunchKernelGGL(k_iir_part, dim3((unsigned)((nk * (g.FS / 4) + 255) / 256), (unsigned)ub), dim3(256), 0,
-                         st, mag, g, tl, h->p.iir_b, (double*)h->nsp.p);
-    HIPCHK(h, hipGetLastError());
-    hipLaunchKernelGGL((k_iir_chain<float, false>), dim3((unsigned)((ub * g.FS + 63) / 64)), dim3(64), 0, st, mag,
-                       (const double*)h->nsp.p, g, tl, h->p.iir_b, (double*)h->nsc.p, ub);
-    HIPCHK(h, hipGetLastError());
+    // (round 5) k_iir_chain_par: the chain in 16 runs per band, straight from the 16-frame sub-tile partials where
+    // k_mag_fast left them (no k_iir_comb); SG_OPT_FORCE_SPLIT keeps the serial kernels (A/B)
+    const bool par = SG_CHAIN_PAR && !h->force_split && ub <= 65535;
+    const dim3 pgrid((unsigned)((g.F + 63) / 64), (unsigned)ub);
+    if (sub_ok && par && nsp_ok(nk, 4)) {
+      hipLaunchKernelGGL(k_iir_chain_par<4>, pgrid, dim3(64 * NSP_WAVES), 0, st, mag, (const double*)h->nss.p, g, tl,
+                         h->p.iir_b, (double*)h->nsc.p, (int)nsub);
+      HIPCHK(h, hipGetLastError());
+    } else {
+      if (sub_ok)
+        hipLaunchKernelGGL(k_iir_comb, dim3((unsigned)((nk * g.FS + 255) / 256), (unsigned)ub), dim3(256), 0, st,
+                           (const double*)h->nss.p, g, tl, h->p.iir_b, (double*)h->nsp.p, (int)nsub);
+      else
+        hipLaunchKernelGGL(k_iir_part, dim3((unsigned)((nk * (g.FS / 4) + 255) / 256), (unsigned)ub), dim3(256), 0,
+                           st, mag, g, tl, h->p.iir_b, (double*)h->nsp.p);
+      HIPCHK(h, hipGetLastError());
+      if (par && nsp_ok(nk, 1))
+        hipLaunchKernelGGL(k_iir_chain_par<1>, pgrid, dim3(64 * NSP_WAVES), 0, st, mag, (const double*)h->nsp.p, g, tl,
+                           h->p.iir_b, (double*)h->nsc.p, (int)nk);
+      else
+        hipLaunchKernelGGL((k_iir_chain<float, false>), dim3((unsigned)((ub * g.FS + 63) / 64)), dim3(64), 0, st, mag,
+                           (const double*)h->nsp.p, g, tl, h->p.iir_b, (double*)h->nsc.p, ub);
+      HIPCHK(h, hipGetLastError());
+    }
   }
   {
     ProfScope ps(h, smooth ? SG_STAGE_SMOOTH : SG_STAGE_NONSTAT_MASK, st);

@@ -205,4 +205,108 @@ __global__ __launch_bounds__(64) void k_iir_chain(const TA* __restrict__ A, cons
   }
 }
 
+// (round 5) k_iir_comb + k_iir_chain in ONE kernel with the chain cut into 16 runs of tiles per band.  The serial form walks a
+// band's tiles one dependent multiply-add at a time, forward and back (41 tiles at the default geometry, 162 at a hop of 64
+// samples: 17 - 33 us of latency with a few hundred wavefronts on the chip), after k_iir_comb has already read the 16-frame
+// partials once (19 us).  The recurrences are affine maps (s' = e + c^len s;  S_start = E_b + c^len S_end), and maps compose:
+//   1. wavefront w of a workgroup (64 bands x 16 wavefronts) composes the forward maps of its run of pieces;
+//   2. through LDS every wavefront learns the state entering its run (at most 15 compositions from s[-1] = A[0]);
+//   3. it replays its run with that state: the forward carries of its tiles, the backward terms E_b of its pieces (they need
+//      the entering states) and the composed BACKWARD map of the run, accumulated in the same forward order;
+//   4. through LDS again: the state at the end of its run from the runs behind it and the seed S[T] = s_f[T - 1];
+//   5. it replays its run backwards: the backward carries.
+// PER: pieces per 64-frame tile -- 4 (k_mag_fast's 16-frame sub-tiles, no k_iir_comb) or 1 (k_iir_part's tile partials).
+// A run is at most NSP_MAXP pieces (they live in registers): longer windows keep the serial kernels (nsp_ok).
+// carry: [unit][tile][2][FS] exactly as k_iir_chain writes it.
+constexpr int NSP_WAVES = 16, NSP_MAXP = 16;
+__host__ __device__ inline bool nsp_ok(int64_t n_tiles, int per) {
+  const int64_t G = (n_tiles + NSP_WAVES - 1) / NSP_WAVES;
+  return n_tiles >= 1 && G * per <= NSP_MAXP;
+}
+
+template <int PER>
+__global__ __launch_bounds__(64 * NSP_WAVES) void k_iir_chain_par(const float* __restrict__ A, const double* __restrict__ pieces,
+                                                                   Geom g, NsTiling tl, double b, double* __restrict__ carry,
+                                                                   int np) {
+  __shared__ double sA[NSP_WAVES][64], sB[NSP_WAVES][64];   // forward maps of the runs, then their backward maps
+  __shared__ double sSeed[64];
+  const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+  const int f = blockIdx.x * 64 + lane;
+  const bool live = f < g.F;
+  const int fc = live ? f : g.F - 1;
+  const int64_t u = blockIdx.y;
+  const int nk = (int)tl.n_tiles();
+  constexpr int PLEN = NS_TT / PER;
+  const double c = 1.0 - b, gq = b * c / (1.0 - c * c);
+  const double len_last = (double)(g.T - (int64_t)(np - 1) * PLEN);
+  const double pf1 = pow(c, (double)PLEN), pf2 = 1.0 - pow(c, 2.0 * PLEN);
+  const double pl1 = pow(c, len_last), pl2 = 1.0 - pow(c, 2.0 * len_last);
+  const int G = (nk + NSP_WAVES - 1) / NSP_WAVES;          // tiles per run
+  const int k0 = w * G;
+  const int j0 = k0 * PER;
+  const int j1 = min(np, (k0 + G) * PER);
+  const int cnt = j1 > j0 ? j1 - j0 : 0;                    // pieces of this run (0: a wavefront beyond the last tile)
+  const int64_t st2 = 2 * (int64_t)g.FS;
+  const double* pb = pieces + (u * np * 2) * (int64_t)g.FS + fc;
+  double e[NSP_MAXP], E[NSP_MAXP];
+#pragma unroll
+  for (int q = 0; q < NSP_MAXP; ++q) {
+    const int j = q < cnt ? j0 + q : (np - 1);
+    e[q] = pb[j * st2];
+    E[q] = pb[j * st2 + g.FS];
+  }
+  double s = (double)A[u * g.T * g.FS + fc];               // s[-1] = A[0]  (lfilter_zi steady state)
+  // 1. forward map of the run: s_out = Bm + Am s_in
+  {
+    double Am = 1.0, Bm = 0.0;
+#pragma unroll
+    for (int q = 0; q < NSP_MAXP; ++q)
+      if (q < cnt) {
+        const double cl = (j0 + q == np - 1) ? pl1 : pf1;
+        Bm = e[q] + cl * Bm;
+        Am *= cl;
+      }
+    sA[w][lane] = Am;
+    sB[w][lane] = Bm;
+  }
+  __syncthreads();
+  // 2. the state entering the run
+  for (int v = 0; v < w; ++v) s = sB[v][lane] + sA[v][lane] * s;
+  __syncthreads();                                          // (sA / sB are reused for the backward maps)
+  // 3. forward replay: carries, backward terms, the run's backward map S_start = Qm + Pm S_end
+  double* cb = carry + (u * nk * 2) * (int64_t)g.FS + fc;
+  {
+    double Pm = 1.0, Qm = 0.0;
+#pragma unroll
+    for (int q = 0; q < NSP_MAXP; ++q)
+      if (q < cnt) {
+        const bool last = j0 + q == np - 1;
+        const double cl = last ? pl1 : pf1, ql = last ? pl2 : pf2;
+        if (q % PER == 0 && live) cb[(k0 + q / PER) * st2] = s;
+        const double Eb = E[q] + s * gq * ql;               // sum_t b c^(t - start) s_f[t] of the piece
+        E[q] = Eb;
+        Qm += Pm * Eb;
+        Pm *= cl;
+        s = e[q] + cl * s;
+      }
+    sA[w][lane] = Pm;
+    sB[w][lane] = Qm;
+    if (cnt > 0 && j1 == np) sSeed[lane] = s;               // the forward pass's last value seeds the backward pass
+  }
+  __syncthreads();
+  // 4. the state at the end of the run
+  double S = sSeed[lane];
+  for (int v = NSP_WAVES - 1; v > w; --v) S = sB[v][lane] + sA[v][lane] * S;
+  // 5. backward replay
+#pragma unroll
+  for (int q = NSP_MAXP - 1; q >= 0; --q)
+    if (q < cnt) {
+      const bool last = j0 + q == np - 1;
+      const double cl = last ? pl1 : pf1;
+      if ((q % PER == PER - 1 || last) && live) cb[(k0 + q / PER) * st2 + g.FS] = S;
+      S = E[q] + cl * S;
+    }
+}
+
+
 }  // namespace sg

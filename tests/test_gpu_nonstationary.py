@@ -175,3 +175,38 @@ def test_nonstationary_window_of_24_minutes(nr):
         sg._gate.set_option(_ffi.SG_OPT_FORCE_UNFUSED, 0)
     assert bool(torch.isfinite(a).all())
     assert float((a - b).abs().max()) < 1e-5 * float(b.abs().max())
+
+
+@pytest.mark.parametrize("n_fft,n,kw", [
+    (1024, 48000 * 20, dict()),                                             # 16-frame sub-tiles, 2 chunks, ragged last tile
+    (1024, 70001, dict(chunk_size=30000, padding=3000)),                    # short units: a few tiles, runs of one tile
+    (1024, 1500, dict()),                                                   # a single tile, fewer than four sub-tiles
+    (1024, 48000 * 30, dict(chunk_size=1300000, padding=40000)),            # 85 tiles per unit: six tiles of sub-tiles exceed a run -> k_iir_comb + the chain on tile partials
+    (512, 300000, dict()),                                                  # k_iir_part's tile partials (PER = 1)
+    (256, 200000, dict(chunk_size=90000, padding=5000)),
+    (2048, 250000, dict()),
+])
+def test_parallel_tile_chain_equals_the_serial_chain(nr, n_fft, n, kw):
+    """k_iir_chain_par (round 5: the non-stationary gate's tile chain in 16 composed runs per band, from the 16-frame sub-tile
+    partials at the default geometry) against k_iir_comb + k_iir_chain (SG_OPT_FORCE_SPLIT) and the oracle
+    (nonstationary.py:106-115: filtfilt along time)."""
+    from noisereduce_amd import _ffi
+    from noisereduce_amd.spectralgate.nonstationary import SpectralGateNonStationary
+    sr = 48000
+    y = np.stack([O.synth_signal(n, sr=sr, seed=11 + c, tone_hz=500.0 * (c + 1)) for c in range(2)]).astype(np.float32)
+    y[0, n // 3:n // 3 + 5000] *= 30.0
+    yd = torch.from_numpy(y).cuda()
+
+    def make():
+        return SpectralGateNonStationary(y=yd, sr=sr, chunk_size=kw.get("chunk_size", 600000), padding=kw.get("padding", 30000),
+                                         prop_decrease=1.0, n_fft=n_fft, win_length=None, hop_length=None, time_constant_s=2.0,
+                                         freq_mask_smooth_hz=500, time_mask_smooth_ms=50, thresh_n_mult_nonstationary=2,
+                                         sigmoid_slope_nonstationary=10, tmp_folder=None, use_tqdm=False, n_jobs=1)
+    sg = make()
+    a = sg.get_traces().cpu().numpy()
+    with sg._gate.with_options([(_ffi.SG_OPT_FORCE_SPLIT, 1)]):
+        b = make().get_traces().cpu().numpy()
+    assert O.rel_err(a, b) < 1e-6
+    if n <= 300000:
+        want = O.reduce_noise_S(y.astype(np.float64), sr, stationary=False, n_fft=n_fft, **kw)
+        assert O.rel_err(a, want) < 1e-4
