@@ -1633,7 +1633,9 @@ static int stage_nonstat_mask2(sg_handle* h, const View& v, const Geom& g, int64
         hipLaunchKernelGGL(k_iir_part, dim3((unsigned)((nk * (g.FS / 4) + 255) / 256), (unsigned)ub), dim3(256), 0,
                            st, mag, g, tl, h->p.iir_b, (double*)h->nsp.p);
       HIPCHK(h, hipGetLastError());
-      if (par && nsp_ok(nk, 1))
+      // (tile partials: the parallel form pays from ~64 tiles per unit on -- hops of 64 / 128 samples; at 41 tiles the default
+      // geometry measured 0.522 ms per ten minutes through k_iir_comb + k_iir_chain_par<1> against 0.514 on the serial chain)
+      if (par && nk >= 64 && nsp_ok(nk, 1))
         hipLaunchKernelGGL(k_iir_chain_par<1>, pgrid, dim3(64 * NSP_WAVES), 0, st, mag, (const double*)h->nsp.p, g, tl,
                            h->p.iir_b, (double*)h->nsc.p, (int)nk);
       else
