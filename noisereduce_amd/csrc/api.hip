@@ -1621,9 +1621,17 @@ static int stage_nonstat_mask2(sg_handle* h, const View& v, const Geom& g, int64
     // k_mag_fast left them (no k_iir_comb); SG_OPT_FORCE_SPLIT keeps the serial kernels (A/B)
     const bool par = SG_CHAIN_PAR && !h->force_split && ub <= 65535;
     const dim3 pgrid((unsigned)((g.F + 63) / 64), (unsigned)ub);
+    // c^len and 1 - c^(2 len) of a full piece and of the unit's last one (uniform: computed here, not per thread)
+    auto piece_pows = [&](int plen, int64_t np, double* o) {
+      const double c = 1.0 - h->p.iir_b, len_last = (double)(g.T - (np - 1) * plen);
+      o[0] = std::pow(c, (double)plen); o[1] = 1.0 - std::pow(c, 2.0 * plen);
+      o[2] = std::pow(c, len_last); o[3] = 1.0 - std::pow(c, 2.0 * len_last);
+    };
+    double pw[4];
     if (sub_ok && par && nsp_ok(nk, 4)) {
+      piece_pows(16, nsub, pw);
       hipLaunchKernelGGL(k_iir_chain_par<4>, pgrid, dim3(64 * NSP_WAVES), 0, st, mag, (const double*)h->nss.p, g, tl,
-                         h->p.iir_b, (double*)h->nsc.p, (int)nsub);
+                         h->p.iir_b, (double*)h->nsc.p, (int)nsub, pw[0], pw[1], pw[2], pw[3]);
       HIPCHK(h, hipGetLastError());
     } else {
       if (sub_ok)
@@ -1633,14 +1641,15 @@ static int stage_nonstat_mask2(sg_handle* h, const View& v, const Geom& g, int64
         hipLaunchKernelGGL(k_iir_part, dim3((unsigned)((nk * (g.FS / 4) + 255) / 256), (unsigned)ub), dim3(256), 0,
                            st, mag, g, tl, h->p.iir_b, (double*)h->nsp.p);
       HIPCHK(h, hipGetLastError());
-      // (tile partials: the parallel form pays from ~64 tiles per unit on -- hops of 64 / 128 samples; at 41 tiles the default
-      // geometry measured 0.522 ms per ten minutes through k_iir_comb + k_iir_chain_par<1> against 0.514 on the serial chain)
-      if (par && nk >= 64 && nsp_ok(nk, 1))
+      // (tile partials: n_fft = 256 / 512 / 2048 -- 162 / 81 / 21 tiles per unit -- measured 12 / 6 / 1.4 % of the call)
+      if (par && nk >= 8 && nsp_ok(nk, 1)) {
+        piece_pows(NS_TT, nk, pw);
         hipLaunchKernelGGL(k_iir_chain_par<1>, pgrid, dim3(64 * NSP_WAVES), 0, st, mag, (const double*)h->nsp.p, g, tl,
-                           h->p.iir_b, (double*)h->nsc.p, (int)nk);
-      else
+                           h->p.iir_b, (double*)h->nsc.p, (int)nk, pw[0], pw[1], pw[2], pw[3]);
+      } else {
         hipLaunchKernelGGL((k_iir_chain<float, false>), dim3((unsigned)((ub * g.FS + 63) / 64)), dim3(64), 0, st, mag,
                            (const double*)h->nsp.p, g, tl, h->p.iir_b, (double*)h->nsc.p, ub);
+      }
       HIPCHK(h, hipGetLastError());
     }
   }

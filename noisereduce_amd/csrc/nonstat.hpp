@@ -227,7 +227,7 @@ __host__ __device__ inline bool nsp_ok(int64_t n_tiles, int per) {
 template <int PER>
 __global__ __launch_bounds__(64 * NSP_WAVES) void k_iir_chain_par(const float* __restrict__ A, const double* __restrict__ pieces,
                                                                    Geom g, NsTiling tl, double b, double* __restrict__ carry,
-                                                                   int np) {
+                                                                   int np, double pf1, double pf2, double pl1, double pl2) {
   __shared__ double sA[NSP_WAVES][64], sB[NSP_WAVES][64];   // forward maps of the runs, then their backward maps
   __shared__ double sSeed[64];
   const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
@@ -236,11 +236,9 @@ __global__ __launch_bounds__(64 * NSP_WAVES) void k_iir_chain_par(const float* _
   const int fc = live ? f : g.F - 1;
   const int64_t u = blockIdx.y;
   const int nk = (int)tl.n_tiles();
-  constexpr int PLEN = NS_TT / PER;
   const double c = 1.0 - b, gq = b * c / (1.0 - c * c);
-  const double len_last = (double)(g.T - (int64_t)(np - 1) * PLEN);
-  const double pf1 = pow(c, (double)PLEN), pf2 = 1.0 - pow(c, 2.0 * PLEN);
-  const double pl1 = pow(c, len_last), pl2 = 1.0 - pow(c, 2.0 * len_last);
+  // pf1 = c^PLEN, pf2 = 1 - c^(2 PLEN) for full pieces, pl1 / pl2 the same for the unit's last piece: from the HOST (four
+  // float64 pow() per thread were most of this kernel's instructions: 442 k threads per ten minutes where k_iir_chain has 25 k)
   const int G = (nk + NSP_WAVES - 1) / NSP_WAVES;          // tiles per run
   const int k0 = w * G;
   const int j0 = k0 * PER;

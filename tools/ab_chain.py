@@ -8,7 +8,7 @@ from noisereduce_amd import _ffi
 from noisereduce_amd.spectralgate.nonstationary import SpectralGateNonStationary
 sr = 48000
 y = bench.synth_on_device(sr * 600, 1, torch.device("cuda", 0))
-for n_fft, secs in ((1024, 600), (256, 120), (512, 120)):
+for n_fft, secs in ((1024, 600), (256, 120), (512, 120), (2048, 120)):
     yy = y[:sr * secs].contiguous()
     def make():
         return SpectralGateNonStationary(y=yy, sr=sr, chunk_size=600000, padding=30000, prop_decrease=1.0, n_fft=n_fft, win_length=None,
