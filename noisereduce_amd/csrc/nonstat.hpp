@@ -249,6 +249,7 @@ __global__ __launch_bounds__(64 * NSP_WAVES) void k_iir_chain_par(const float* _
   double e[NSP_MAXP], E[NSP_MAXP];
 #pragma unroll
   for (int q = 0; q < NSP_MAXP; ++q) {
+    // (clamped, not predicated: with `if (q < cnt)` around the loads the call took 1.65 ms instead of 0.49 -- measured)
     const int j = q < cnt ? j0 + q : (np - 1);
     e[q] = pb[j * st2];
     E[q] = pb[j * st2 + g.FS];
