@@ -35,3 +35,9 @@ y16 = (y * 20000).to(torch.int16)
 for _ in range(4):
     out = nr.reduce_noise(y=y16, sr=48000, stationary=True)      # int16 recording: bit path + k_apply_fast64
 torch.cuda.synchronize()
+if os.environ.get("TRAFFIC_NFFT"):                                # other geometries, ten minutes each (r5: fast256.hpp)
+    for n_fft in [int(a) for a in os.environ["TRAFFIC_NFFT"].split(",")]:
+        for stat in (True, False):
+            for _ in range(4):
+                out = nr.reduce_noise(y=y, sr=48000, stationary=stat, n_fft=n_fft)
+            torch.cuda.synchronize()
