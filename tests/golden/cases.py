@@ -43,6 +43,12 @@ S_CASES = {
                           kwargs=dict(stationary=True, n_fft=2048, n_std_thresh_stationary=2.0)),
     "nonstat_nfft256": dict(sr=8000, n=20000, seed=19, tone_hz=300.0,
                             kwargs=dict(stationary=False, n_fft=256)),
+    # n_fft = 256 at 48 kHz (round 5: fast256.hpp -- four frames per register transform; the 50 ms smoothing is 37 frames here:
+    # k_iir_mask<37>, tall integer-smoothing tiles), chunk grid with a partial last chunk
+    "stat_nfft256_48k_chunks": dict(sr=48000, n=70000, seed=71,
+                                    kwargs=dict(stationary=True, n_fft=256, chunk_size=30000, padding=3000)),
+    "nonstat_nfft256_48k_chunks": dict(sr=48000, n=70000, seed=72,
+                                       kwargs=dict(stationary=False, n_fft=256, chunk_size=30000, padding=3000)),
     # no smoothing / one-axis smoothing
     "stat_nosmooth": dict(sr=48000, n=30000, seed=20,
                           kwargs=dict(stationary=True, freq_mask_smooth_hz=None,
