@@ -130,7 +130,9 @@ struct sg_handle {
   bool force_split = false;          // SG_OPT_FORCE_SPLIT: decide / smooth / apply as three kernels
   int rowgate_mode = 0;              // SG_OPT_FORCE_NOROWGATE: 0 = by batch size, 1 = never, 2 = whenever the shape is eligible
   int64_t n_floor_lazy = 0, n_floor_apriori = 0;   // sg_debug_counter 1 / 2
-  int tile_order = 0;                // SG_OPT_TILE_ORDER: 1 = the gate's tiles by block index instead of tickets
+  int tile_order = 0;                // SG_OPT_TILE_ORDER: 0 = persistent workgroups looping over tickets (round 6), 1 = tile = block
+                                     // index (no ticket), 2 = one ticket-drawn tile per workgroup (the kernel of rounds 2-5)
+  int n_cu = 0;                      // compute units of the handle's device (persistent grids)
   int floor_test = 0;                // SG_OPT_FLOOR_TEST: one-pass gate's floor test 0 = predicted, 1 = a priori, 2 = in the gate kernel
   int rg_shape = 16;                 // SG_OPT_ROWGATE_SHAPE: waves per workgroup of the row gate (16 x 1 quad, or 8 x 2 quads)
   bool rg_tap = false;               // SG_OPT_ROWGATE_TAP: keep the row gate's float32 power tile (stage tap 4)
@@ -2189,8 +2191,20 @@ static int stage_onepass(sg_handle* h, const View& v, const View& vx, const Geom
   P.epoch = h->epoch;
   P.err = h->err_dev;
   P.ticket_base = h->ticket_base;
+  // persistent workgroups (onepass.hpp "PERSIST"): the lazy first launch only -- its compare constants do not depend on the unit
+  const bool persist = lazy && h->tile_order == 0 && !(h->lose_now & 3u) && ub * ntt >= 2;
+  if (persist && h->n_cu == 0) {
+    int dev = 0, cus = 0;
+    HIPCHK(h, hipGetDevice(&dev));
+    HIPCHK(h, hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev));
+    h->n_cu = cus > 0 ? cus : 256;
+  }
+  // three workgroups per CU (LDS) is what is resident at once; every workgroup ends on one ticket past the last tile
+  static const int pg_per_cu = [] { const char* e = getenv("SG_ONEPASS_WG_PER_CU"); int v = e ? atoi(e) : 3; return v >= 1 && v <= 3 ? v : 3; }();   // (experiments: fewer resident workgroups)
+  const unsigned pgrid = persist ? (unsigned)std::min<int64_t>(ub * ntt, (int64_t)pg_per_cu * h->n_cu) : 0u;
+  P.total_tiles = (unsigned)(ub * ntt);
   if (h->tile_order == 1) P.ticket_base = 0xffffffffu;   // SG_OPT_TILE_ORDER 1: tile = block index (no ticket)
-  else h->ticket_base += (unsigned)(ub * ntt);
+  else h->ticket_base += (unsigned)(ub * ntt) + pgrid;
   P.nf = h->p.n_grad_freq; P.nt = h->p.n_grad_time;
   P.prop = (float)h->p.prop_decrease;
   P.inv_ktot = 1.0f / (float)h->ktot;
@@ -2233,14 +2247,16 @@ static int stage_onepass(sg_handle* h, const View& v, const View& vx, const Geom
   {
     ProfScope ps(h, SG_STAGE_ONEPASS, st);
     const size_t lds = (size_t)(fast::FN + WAVES * fast::WAVE_CX_H) * sizeof(fast::cf) + (1024 + T2_FLOATS) * sizeof(float) +
-                       256 * 8 + 514 * 8 + 16 + (prop ? 528 : 0);
+                       256 * 8 + 514 * 8 + 32 + (prop ? 528 : 0);
     auto go = [&](auto kern) -> hipError_t {
       hipError_t e = set_lds(reinterpret_cast<const void*>(kern), lds);
       if (e != hipSuccess) return e;
-      hipLaunchKernelGGL(kern, dim3((unsigned)(ub * ntt)), dim3(WAVES * 64), lds, st, P);
+      hipLaunchKernelGGL(kern, dim3(persist ? pgrid : (unsigned)(ub * ntt)), dim3(WAVES * 64), lds, st, P);
       return hipGetLastError();
     };
-    if (h->lose_now & 3u) HIPCHK(h, go(fast::k_gate_onepass<WAVES, false, true>));   // test hook (PROP-free shape only)
+    if (persist && prop) HIPCHK(h, go(fast::k_gate_onepass<WAVES, true, false, false, true>));
+    else if (persist) HIPCHK(h, go(fast::k_gate_onepass<WAVES, false, false, false, true>));
+    else if (h->lose_now & 3u) HIPCHK(h, go(fast::k_gate_onepass<WAVES, false, true>));   // test hook (PROP-free shape only)
     else if (prop) HIPCHK(h, go(fast::k_gate_onepass<WAVES, true>));
     else HIPCHK(h, go(fast::k_gate_onepass<WAVES, false>));
   }
@@ -2256,7 +2272,7 @@ static int stage_onepass(sg_handle* h, const View& v, const View& vx, const Geom
     P.ticket = (unsigned*)h->xticket.p + 8;   // its own counter (zeroed by the first launch's ticket-0 workgroup): it takes tickets only if a unit reported
     P.ticket_base = 0;
     const size_t lds = (size_t)(fast::FN + WAVES * fast::WAVE_CX_H) * sizeof(fast::cf) + (1024 + T2_FLOATS) * sizeof(float) +
-                       256 * 8 + 514 * 8 + 16 + (prop ? 528 : 0);
+                       256 * 8 + 514 * 8 + 32 + (prop ? 528 : 0);
     auto redo = [&](auto kern) -> hipError_t {
       hipError_t e = set_lds(reinterpret_cast<const void*>(kern), lds);
       if (e != hipSuccess) return e;
@@ -3168,7 +3184,10 @@ extern "C" int sg_set_option(sg_handle* h, int32_t option, int64_t value) {
       h->rg_shape = (int)value;
       return SG_OK;
     case SG_OPT_INJECT_HANDOFF_FAULT: h->inject_fault = (unsigned)value & 63u; return SG_OK;
-    case SG_OPT_TILE_ORDER: h->tile_order = value != 0; return SG_OK;
+    case SG_OPT_TILE_ORDER:
+      if (value < 0 || value > 2) FAIL(h, SG_E_INVALID, "SG_OPT_TILE_ORDER: 0 (persistent workgroups), 1 (block index) or 2 (one ticket per workgroup)");
+      h->tile_order = (int)value;
+      return SG_OK;
     case SG_OPT_EXACT_MATERIALISED: h->exact_materialised = value != 0; return SG_OK;
     case SG_OPT_FLOOR_TEST:
       if (value < 0 || value > 2) FAIL(h, SG_E_INVALID, "SG_OPT_FLOOR_TEST: 0 (predicted), 1 (a priori) or 2 (in the gate kernel)");

@@ -81,6 +81,7 @@ struct OnePassArgs {
   // tools/ubench/ticket_atomic.hip)
   unsigned* alim;
   int scan_q;                 // in-kernel floor test: samples of the unit window's unstaged part that each tile scans
+  unsigned total_tiles;       // units * (n_tiles + 2): PERSIST workgroups draw tickets until they get one >= this
 #if OP_TRACE
   unsigned* trace;                   // [workgroups][4 waves][16] shader cycles per phase (slot 15 = 1: tile completed): development builds
 #endif
@@ -160,9 +161,37 @@ __device__ __forceinline__ double op_exact_power(const OnePassArgs& P, int64_t r
 // REDO: the second launch of a call with the in-kernel floor test (its own instantiation: its launches are their own row in
 // a profile -- when no chunk reported they return at once, and would halve the gate's average duration -- and the first
 // launch carries no test for it).
-template <int WAVES, bool PROP, bool LOSE = false, bool REDO = false>
-__global__ __launch_bounds__(WAVES * 64, 3) void k_gate_onepass(OnePassArgs P) {
+// PERSIST (round 6): a workgroup LOOPS over tickets instead of handling one tile.  What that buys -- a tile's first two phases
+// (ticket atomic + constant tables: one memory round trip; span loads + compare constants: a second one) were 11.4 k of the
+// 58.7 k cycles a wave lives (profiles/r03_onepass_phase_trace.txt), pure memory latency that the other two workgroups of the
+// CU only partly cover (the kernel runs tiles x lifetime / 768 slots almost exactly):
+//   * twiddles, window, byte-expansion table, compare constants (a lazy first launch has need == 0 in every unit: they do not
+//     depend on the tile) and the floor test's bound are staged ONCE per workgroup;
+//   * the NEXT ticket is drawn by thread 0 right after the neighbours' bits have arrived (never earlier: a workgroup that
+//     held ticket j + 1 while waiting for tile j + 1's bits would wait for itself) and travels through LDS under the
+//     smoothing stage's closing barrier;
+//   * the next tile's span (five 16-byte loads per thread) and its slice of the floor test are issued after the inverse
+//     transform, when the 64 spectrum registers are about to die, and land under the overlap-add and the epilogue;
+//     the loop top only moves them from registers to LDS.
+// Round 4's attempt at this died of loop-carried kernel arguments (160 spilled SGPRs).  Here NOTHING of the argument struct
+// is loop-carried: every iteration reads `P` through late_args() -- an opaque pointer to the kernel-argument segment made
+// inside the loop body, so no load from it can be hoisted -- and thread / lane indices come from an opaque copy of
+// threadIdx.x.  Loop-carried: the parity of the ticket slot, the "prefetched" flag, one VGPR of floor-test bound and the 25
+// VGPRs of prefetched samples.
+// Deadlock freedom as before (tickets; publish before wait); a launch needs two resident workgroups, and draws
+// total_tiles + gridDim.x tickets (every workgroup ends on one ticket >= total_tiles).
+// Not for REDO / LOSE / a-priori floor flags (compare constants depend on the unit there) / SG_OPT_TILE_ORDER 1.
+#ifndef OP_LATE_P
+#define OP_LATE_P 1   // 1: every instantiation reads its arguments through late_args() (0 SGPR spills; 0: the by-value struct outside PERSIST)
+#endif
+#ifndef OP_OCC
+#define OP_OCC 3   // workgroups per CU the register budget is set for (development builds: 2 shows the unconstrained pressure)
+#endif
+#define OP_DONE { if (PERSIST) continue; return; }
+template <int WAVES, bool PROP, bool LOSE = false, bool REDO = false, bool PERSIST = false>
+__global__ __launch_bounds__(WAVES * 64, OP_OCC) void k_gate_onepass(OnePassArgs Pk) {
   static_assert(WAVES == 4, "tile = 16 frames");
+  static_assert(!PERSIST || (!LOSE && !REDO), "the persistent loop is the lazy first launch only");
   extern __shared__ __attribute__((aligned(16))) char smem[];
   cf* tw512 = reinterpret_cast<cf*>(smem);
   cf* regions = tw512 + FN;
@@ -170,60 +199,143 @@ __global__ __launch_bounds__(WAVES * 64, 3) void k_gate_onepass(OnePassArgs P) {
   float* s_t2 = swin + 1024;
   unsigned long long* s_exp = reinterpret_cast<unsigned long long*>(s_t2 + T2_FLOATS);
   double* s_t2d = reinterpret_cast<double*>(s_exp + 256);   // exact compare constants (refinement), same order
-  unsigned* s_misc = reinterpret_cast<unsigned*>(s_t2d + 514);
-  unsigned char* s_ef = reinterpret_cast<unsigned char*>(s_misc + 4);  // PROP: integer weight (<= 81) of the valid taps along f, per bin
+  unsigned* s_misc = reinterpret_cast<unsigned*>(s_t2d + 514);   // [0] ticket, [1] lost hand-off, [4], [5]: PERSIST ticket slots
+  unsigned char* s_ef = reinterpret_cast<unsigned char*>(s_misc + 8);  // PROP: integer weight (<= 81) of the valid taps along f, per bin
   constexpr int NF = 4 * WAVES;
-  const ApplyArgs& A = P.A;
-  const Geom& G = A.g;
-  const int tid = threadIdx.x;
-  const int lane = tid & 63, wave = tid >> 6;
-  const int g = lane >> 4, c = lane & 15;
-#if OP_TRACE
-  long long t_prev_ = clock64();
-  unsigned* t_slot_ = nullptr;   // known once the ticket is
-#endif
+  constexpr int SPAN = (NF - 1) * 256 + 1024, XPITCH = 288;
+  static_assert((SPAN / 256) * XPITCH <= WAVES * WAVE_CX_H * 2, "span must fit the exchange slices");
+  // span loads: one dword per thread and 256-sample row (lane-contiguous, 19 per thread).  16-byte loads (five per thread)
+  // need aligned register QUADS; held across the second half of a tile (PERSIST) the allocator could not place them next to
+  // the 64 spectrum registers and spilled all of them -- a scratch store that waits for the load it was meant to hide
+  constexpr int NQ = SPAN / 256;
+  static_assert(SPAN % 256 == 0 && WAVES * 64 == 256, "one sample per thread and row");
+  constexpr int SCAN_REG = 5;                     // floor-test slices up to 5 x 256 samples ride in registers
 
-  if (REDO && P.alim[1] != P.tc.need_tag) return;   // second launch of a call none of whose units reported (the common case)
+  if (REDO && Pk.alim[1] != Pk.tc.need_tag) return;   // second launch of a call none of whose units reported (the common case)
   double t2pre[3];   // compare constants of entries tid, tid + 256 and 512 (they do not depend on the ticket)
   unsigned alim_v = 0u;
   {
+    const int tid = threadIdx.x, lane = tid & 63;
     // table loads first, the ticket's atomic behind them in the same queue: one memory round trip, not two
     static_assert(FN == 2 * WAVES * 64 && WAVES * 64 == 256, "one pass of the prologue loads per thread");
-    const cf tw_a = reinterpret_cast<const cf*>(P.tab + OP_TAB_TW512)[(tid >> 4) * (tid & 15)];
-    const cf tw_b = reinterpret_cast<const cf*>(P.tab + OP_TAB_TW512)[((tid + 256) >> 4) * (tid & 15)];
-    const float4 w4 = reinterpret_cast<const float4*>(P.tab + OP_TAB_WIN)[tid];
-    const unsigned long long e8 = reinterpret_cast<const unsigned long long*>(P.tab + OP_TAB_EXP8)[tid];
-    t2pre[0] = P.tc.T2[perm_inv(tid)];
-    t2pre[1] = P.tc.T2[perm_inv(tid + 256)];
-    t2pre[2] = P.tc.T2[perm_inv(512)];
-    if (!REDO && P.alim != nullptr) {
+    const cf tw_a = reinterpret_cast<const cf*>(Pk.tab + OP_TAB_TW512)[(tid >> 4) * (tid & 15)];
+    const cf tw_b = reinterpret_cast<const cf*>(Pk.tab + OP_TAB_TW512)[((tid + 256) >> 4) * (tid & 15)];
+    const float4 w4 = reinterpret_cast<const float4*>(Pk.tab + OP_TAB_WIN)[tid];
+    const unsigned long long e8 = reinterpret_cast<const unsigned long long*>(Pk.tab + OP_TAB_EXP8)[tid];
+    t2pre[0] = Pk.tc.T2[perm_inv(tid)];
+    t2pre[1] = Pk.tc.T2[perm_inv(tid + 256)];
+    t2pre[2] = Pk.tc.T2[perm_inv(512)];
+    if (!REDO && Pk.alim != nullptr) {
       // the floor test's compare constant: a VECTOR load behind the table loads (as a scalar load the compiler places it
       // at its use, after the span has landed: one more exposed round trip per tile, 5 us of the kernel)
       int z = 2 + min(lane & 15, OP_ALIM_BLOCKS - 1);   // one bound per band block of the noise statistics: minimum below
       asm volatile("" : "+v"(z));
-      alim_v = P.alim[z];
+      alim_v = Pk.alim[z];
     }
     if (tid == 0) {
       // (ticket_base == 0xffffffff: SG_OPT_TILE_ORDER 1, the block index instead of a ticket)
-      s_misc[0] = P.ticket_base == 0xffffffffu ? blockIdx.x : atomicAdd(P.ticket, 1u) - P.ticket_base;
+      s_misc[PERSIST ? 4 : 0] = Pk.ticket_base == 0xffffffffu ? blockIdx.x : atomicAdd(Pk.ticket, 1u) - Pk.ticket_base;
       s_misc[1] = 0u;   // set when a hand-off of this tile is lost: its output hops are POISONED (NaN), never plausible garbage
     }
     tw512[tid] = tw_a;
     tw512[tid + 256] = tw_b;
     reinterpret_cast<float4*>(swin)[tid] = w4;
     s_exp[tid] = e8;
-  }
-  if constexpr (PROP) {
-    for (int f = tid; f <= 512; f += WAVES * 64) {
-      const int lo = max(-P.nf, -f), hi = min(P.nf, 512 - f);
-      int sum = 0;
-      for (int a = lo; a <= hi; ++a) sum += P.nf + 1 - (a < 0 ? -a : a);
-      s_ef[f] = (unsigned char)sum;
+    if constexpr (PROP) {
+      for (int f = tid; f <= 512; f += WAVES * 64) {
+        const int lo = max(-Pk.nf, -f), hi = min(Pk.nf, 512 - f);
+        int sum = 0;
+        for (int a = lo; a <= hi; ++a) sum += Pk.nf + 1 - (a < 0 ? -a : a);
+        s_ef[f] = (unsigned char)sum;
+      }
+    }
+    if constexpr (PERSIST) {
+      // need == 0 in every unit of a lazy first launch: one set of compare constants for all of the workgroup's tiles
+#pragma unroll
+      for (int k = 0; k < 3; ++k) {
+        const int i = tid + k * WAVES * 64;
+        if (i > 512) break;
+        s_t2[t2_pos(i)] = t2_to_f32(t2pre[k], 4.0);
+        s_t2d[i] = t2pre[k];
+      }
+      for (int off = 1; off < 16; off <<= 1) alim_v = min(alim_v, (unsigned)__shfl_xor((int)alim_v, off));
+      if (tid == 0) s_misc[2] = alim_v;   // (not a loop-carried register: it would live in scratch)
     }
   }
   __syncthreads();
+
+  // what one tile reads from the recording: its span, and its slice of the floor test's scan (see "floor test" below).
+  // A function of the ticket alone: the loop top evaluates it for the tile at hand, the prefetch for the next one.
+  struct TileSrc {
+    const float* sp;        // first sample of the span
+    bool blk_vec;           // interior tile of float32 input: five aligned 16-byte loads per thread
+    const float* sc_base;   // floor-test slice that rides in registers (null: none, or the slow loop)
+    int sc_n1;              // its length - 1
+    int64_t s0b, sc_lo, sc_last, sc_lenA, sc_c0, sc_c1;
+  };
+  auto tile_src = [](const OnePassArgs& P, int64_t row, int64_t chunk, int jt, bool test) -> TileSrc {
+    const ApplyArgs& A = P.A;
+    TileSrc S;
+    const int64_t tf_tile = A.h_begin - 3 + (int64_t)jt * NF;
+    S.s0b = tf_tile * 256 - A.g.padL;
+    const int64_t gb = chunk * A.view.cs - A.view.pad + S.s0b;
+    S.sp = (const float*)A.view.x + row * A.view.stride + gb;
+    S.blk_vec = A.view.dtype == 0 && tf_tile >= 0 && tf_tile + NF <= A.g.T && S.s0b >= 0 && S.s0b + SPAN <= A.view.Lp &&
+                gb >= A.view.lo && gb + SPAN <= A.view.hi && (reinterpret_cast<uintptr_t>(S.sp) & 15) == 0;
+    S.sc_base = nullptr;
+    S.sc_n1 = 0;
+    S.sc_lo = S.sc_last = S.sc_lenA = S.sc_c0 = S.sc_c1 = 0;
+    if (test) {
+      const int64_t g0 = chunk * A.view.cs - A.view.pad;
+      const int64_t s_lo = max<int64_t>(0, A.view.lo - g0), s_hi = min<int64_t>(A.view.Lp, A.view.hi - g0);
+      const int64_t sp0 = (A.h_begin - 3 - NF) * 256 - A.g.padL;                                   // tile -1's span begins
+      const int64_t sp1 = (A.h_begin - 3 + (int64_t)A.n_tiles * NF) * 256 - A.g.padL + SPAN;       // tile n_tiles' span ends
+      const int64_t first = min(s_hi, max(s_lo, sp0));
+      S.sc_lo = s_lo;
+      S.sc_last = max(s_lo, min(s_hi, sp1));
+      S.sc_lenA = first - s_lo;
+      S.sc_c0 = (int64_t)(jt + 1) * P.scan_q;
+      S.sc_c1 = min(S.sc_c0 + P.scan_q, S.sc_lenA + (s_hi - S.sc_last));
+      if (A.view.dtype == 0 && S.sc_c1 > S.sc_c0 && S.sc_c1 - S.sc_c0 <= SCAN_REG * WAVES * 64 &&
+          (S.sc_c1 <= S.sc_lenA || S.sc_c0 >= S.sc_lenA)) {
+        S.sc_base = (const float*)A.view.x + row * A.view.stride + g0 +
+                    (S.sc_c1 <= S.sc_lenA ? s_lo + S.sc_c0 : S.sc_last + (S.sc_c0 - S.sc_lenA));
+        S.sc_n1 = (int)(S.sc_c1 - S.sc_c0) - 1;
+      }
+    }
+    return S;
+  };
+  // loop-carried (PERSIST): the samples of the tile at hand, issued by the previous iteration
+  float q[NQ];
+  float sc[SCAN_REG];
+  bool pf = false;
+
+  for (unsigned iter = 0; iter == 0u || PERSIST; ++iter) {
+  // ---- PERSIST: nothing of the arguments or the thread's indices survives an iteration (see above) ----
+  const OnePassArgs& P = (PERSIST || OP_LATE_P) ? *late_args<OnePassArgs>() : Pk;
+  int tid = threadIdx.x;
+#if OP_TRACE
+  long long t_prev_ = clock64();   // (PERSIST: phase 0 = the wait at the loop-top barrier)
+  unsigned* t_slot_ = nullptr;   // known once the ticket is
+#endif
+  if constexpr (PERSIST) {
+    asm volatile("" : "+v"(tid));
+    if (iter != 0u) __syncthreads();   // the previous tile's epilogue has read every hop accumulator: the slices are free
+  }
+  const ApplyArgs& A = P.A;
+  const Geom& G = A.g;
+  const int lane = tid & 63, wave = tid >> 6;
+  const int g = lane >> 4, c = lane & 15;
+  const unsigned tk_slot = PERSIST ? 4u + (iter & 1u) : 0u;
   const int ntt = A.n_tiles + 2;                 // tiles per unit incl. one decide-only halo tile per side
-  const unsigned ticket = s_misc[0];
+  const unsigned ticket = PERSIST ? (unsigned)__builtin_amdgcn_readfirstlane((int)s_misc[tk_slot]) : s_misc[0];
+  if (PERSIST && ticket >= P.total_tiles) return;   // (workgroup-uniform)
+  if (PERSIST && tid == 0) {
+    s_misc[1] = 0u;
+#if OP_TK_LATE
+    s_misc[tk_slot ^ 1u] = 0xffffffffu;   // "the next ticket has not arrived yet"
+#endif
+  }
 #if OP_TRACE
   t_slot_ = P.trace + ((size_t)ticket * 4 + wave) * 16;
 #endif
@@ -237,7 +349,7 @@ __global__ __launch_bounds__(WAVES * 64, 3) void k_gate_onepass(OnePassArgs P) {
   const int64_t chunk = A.view.c0 + gu % nch;
   // Floor flags of the unit.  lazy (P.alim set): the first launch assumes "not live" and runs the floor test on the
   // samples it stages (below); the second launch (REDO) serves exactly the units whose test fired.
-  const bool lazy = P.alim != nullptr;
+  const bool lazy = PERSIST || P.alim != nullptr;
   const int need = (lazy && !REDO) ? 0 : need_of(P.tc, u);
   if (REDO && need == 0) return;   // whole workgroup
   // (first launch: the second launch's work counter -- it only counts when a unit reported -- starts from zero)
@@ -261,26 +373,8 @@ __global__ __launch_bounds__(WAVES * 64, 3) void k_gate_onepass(OnePassArgs P) {
 
   // ---- stage the tile's contiguous sample span: interior tiles of float32 input with 16-byte loads, the others
   // (unit edges, halo tiles) sample by sample through view_sample -- zero outside the readable range ------------
-  constexpr int SPAN = (NF - 1) * 256 + 1024, XPITCH = 288;
-  static_assert((SPAN / 256) * XPITCH <= WAVES * WAVE_CX_H * 2, "span must fit the exchange slices");
   bool blk_vec;
   {
-    const int64_t s0b = tf_tile * 256 - G.padL;
-    const int64_t gb = chunk * A.view.cs - A.view.pad + s0b;
-    const float* sp = (const float*)A.view.x + row * A.view.stride + gb;
-    blk_vec = A.view.dtype == 0 && tf_tile >= 0 && tf_tile + NF <= G.T && s0b >= 0 && s0b + SPAN <= A.view.Lp &&
-              gb >= A.view.lo && gb + SPAN <= A.view.hi && (reinterpret_cast<uintptr_t>(sp) & 15) == 0;
-    auto fill_t2 = [&]() {
-#pragma unroll
-      for (int k = 0; k < 3; ++k) {
-        const int i = tid + k * WAVES * 64;
-        if (i > 512) break;
-        const double v = t2eff(perm_inv(i), t2pre[k]);
-        s_t2[t2_pos(i)] = t2_to_f32(v, 4.0);
-        s_t2d[i] = v;   // the rare exact re-evaluation compares against this (no log10 in the hot kernel body)
-      }
-    };
-    float* xs = reinterpret_cast<float*>(regions);
     // ---- floor test (lazy, first launch).  k_unit_absmax + k_prep_thresh read the whole recording before the gate to
     // decide, per unit, whether _amp_to_db's floor max(dB, band max - top_db) (spectralgate/utils.py:16) can lift a band
     // over its threshold: max|x| sum|w| bounds every |X|.  The tiles of a unit stage nearly all of its window anyway:
@@ -291,57 +385,44 @@ __global__ __launch_bounds__(WAVES * 64, 3) void k_gate_onepass(OnePassArgs P) {
     // sample), the unit's band maxima cleared for the float64 pre-pass that follows.  This launch's result for a reported
     // unit is overwritten by the second (REDO).
     const bool test = !REDO && lazy;
-    unsigned mi = 0u;   // max |x| seen by this thread, as a bit pattern (sign cleared: NaN / Inf order above every finite value)
-    auto ab = [](float x) -> unsigned { return __float_as_uint(x) & 0x7fffffffu; };
-    constexpr int SCAN_REG = 5;                     // slices up to 5 x 256 samples ride in registers
-    int64_t sc_lo = 0, sc_last = 0, sc_lenA = 0, sc_c0 = 0, sc_c1 = 0;
-    const float* sc_base = nullptr;                 // float32 samples, slice inside A or inside B: its first sample
-    if (test) {
-      const int64_t g0 = chunk * A.view.cs - A.view.pad;
-      const int64_t s_lo = max<int64_t>(0, A.view.lo - g0), s_hi = min<int64_t>(A.view.Lp, A.view.hi - g0);
-      const int64_t sp0 = (A.h_begin - 3 - NF) * 256 - G.padL;                                   // tile -1's span begins
-      const int64_t sp1 = (A.h_begin - 3 + (int64_t)A.n_tiles * NF) * 256 - G.padL + SPAN;       // tile n_tiles' span ends
-      const int64_t first = min(s_hi, max(s_lo, sp0));
-      sc_lo = s_lo;
-      sc_last = max(s_lo, min(s_hi, sp1));
-      sc_lenA = first - s_lo;
-      sc_c0 = (int64_t)(jt + 1) * P.scan_q;
-      sc_c1 = min(sc_c0 + P.scan_q, sc_lenA + (s_hi - sc_last));
-      if (A.view.dtype == 0 && sc_c1 > sc_c0 && sc_c1 - sc_c0 <= SCAN_REG * WAVES * 64 && (sc_c1 <= sc_lenA || sc_c0 >= sc_lenA))
-        sc_base = (const float*)A.view.x + row * A.view.stride + g0 + (sc_c1 <= sc_lenA ? s_lo + sc_c0 : sc_last + (sc_c0 - sc_lenA));
-    }
-    float sc[SCAN_REG];
-    // issued BEHIND the span's loads (every later phase waits for the span), consumed after them.  One scalar base + a
-    // clamped lane offset: the slice's tail re-reads its last sample (a predicated load is a branch and a copy)
-    auto scan_issue = [&]() {
-      if (sc_base != nullptr) {
-        const int n1 = (int)(sc_c1 - sc_c0) - 1;
+    const TileSrc S = tile_src(P, row, chunk, jt, test);
+    blk_vec = S.blk_vec;
+    const int64_t s0b = S.s0b;
+    auto fill_t2 = [&]() {
+      if constexpr (!PERSIST) {
 #pragma unroll
-        for (int k = 0; k < SCAN_REG; ++k) sc[k] = sc_base[min(tid + k * WAVES * 64, n1)];
+        for (int k = 0; k < 3; ++k) {
+          const int i = tid + k * WAVES * 64;
+          if (i > 512) break;
+          const double v = t2eff(perm_inv(i), t2pre[k]);
+          s_t2[t2_pos(i)] = t2_to_f32(v, 4.0);
+          s_t2d[i] = v;   // the rare exact re-evaluation compares against this (no log10 in the hot kernel body)
+        }
       }
     };
-    if (blk_vec) {
-      // span loads in flight while the compare constants are built
-      constexpr int NQ = (SPAN / 4 + WAVES * 64 - 1) / (WAVES * 64);
-      float4 q[NQ];
+    float* xs = reinterpret_cast<float*>(regions);
+    unsigned mi = 0u;   // max |x| seen by this thread, as a bit pattern (sign cleared: NaN / Inf order above every finite value)
+    auto ab = [](float x) -> unsigned { return __float_as_uint(x) & 0x7fffffffu; };
+    // issued BEHIND the span's loads (every later phase waits for the span), consumed after them.  One scalar base + a
+    // clamped lane offset: the slice's tail re-reads its last sample (a predicated load is a branch and a copy)
+    if (!pf) {
+      if (S.blk_vec) {
 #pragma unroll
-      for (int k = 0; k < NQ; ++k) {
-        const int i = tid + k * WAVES * 64;
-        // (clamped, not predicated: a predicated load is a branch + a copy of its result, and that copy waited for every
-        // load in flight -- before the compare constants, which were meant to be built under the loads)
-        q[k] = reinterpret_cast<const float4*>(sp)[min(i, SPAN / 4 - 1)];
+        for (int k = 0; k < NQ; ++k) q[k] = S.sp[tid + k * 256];
       }
-      scan_issue();
-      fill_t2();
+      if (S.sc_base != nullptr) {
+#pragma unroll
+        for (int k = 0; k < SCAN_REG; ++k) sc[k] = S.sc_base[min(tid + k * WAVES * 64, S.sc_n1)];
+      }
+    }
+    fill_t2();   // (span loads in flight while the compare constants are built)
+    if (blk_vec) {
 #pragma unroll
       for (int k = 0; k < NQ; ++k) {
-        const int e = 4 * (tid + k * WAVES * 64);
-        if ((k + 1) * WAVES * 64 <= SPAN / 4 || e < SPAN) *reinterpret_cast<float4*>(&xs[(e >> 8) * XPITCH + (e & 255)]) = q[k];
-        mi = max(max(mi, max(ab(q[k].x), ab(q[k].y))), max(ab(q[k].z), ab(q[k].w)));
+        xs[k * XPITCH + tid] = q[k];
+        mi = max(mi, ab(q[k]));
       }
     } else {
-      scan_issue();
-      fill_t2();
       for (int i = tid; i < SPAN; i += WAVES * 64) {
         const float xv = (float)view_sample(A.view, row, chunk, s0b + i);
         xs[(i >> 8) * XPITCH + (i & 255)] = xv;
@@ -349,17 +430,19 @@ __global__ __launch_bounds__(WAVES * 64, 3) void k_gate_onepass(OnePassArgs P) {
       }
     }
     if (test) {
-      if (sc_base != nullptr) {
+      if (S.sc_base != nullptr) {
 #pragma unroll
         for (int k = 0; k < SCAN_REG; ++k) mi = max(mi, ab(sc[k]));
       } else {
         // the slice that straddles A | B, long slices (padding much longer than the kept part), other sample types: a
         // loop after the span
-        for (int64_t i = sc_c0 + tid; i < sc_c1; i += WAVES * 64)
-          mi = max(mi, ab((float)view_sample(A.view, row, chunk, i < sc_lenA ? sc_lo + i : sc_last + (i - sc_lenA))));
+        for (int64_t i = S.sc_c0 + tid; i < S.sc_c1; i += WAVES * 64)
+          mi = max(mi, ab((float)view_sample(A.view, row, chunk, i < S.sc_lenA ? S.sc_lo + i : S.sc_last + (i - S.sc_lenA))));
       }
-      for (int off = 1; off < 16; off <<= 1) alim_v = min(alim_v, (unsigned)__shfl_xor((int)alim_v, off));
-      const bool hit = mi >= alim_v;
+      unsigned alim_t = PERSIST ? s_misc[2] : alim_v;
+      if constexpr (!PERSIST)
+        for (int off = 1; off < 16; off <<= 1) alim_t = min(alim_t, (unsigned)__shfl_xor((int)alim_t, off));
+      const bool hit = mi >= alim_t;
       if (__any(hit)) {   // wave-uniform, rare
         const bool nonfinite = __any(mi >= 0x7f800000u);
         double* pm = const_cast<double*>(P.tc.pmax) + u * G.FS;
@@ -614,7 +697,7 @@ __global__ __launch_bounds__(WAVES * 64, 3) void k_gate_onepass(OnePassArgs P) {
   op_kpm_t kpm = (op_kpm_t)__builtin_amdgcn_kernarg_segment_ptr();
   asm volatile("" : "+s"(kpm));
 #define OP_MARG(type, member) (*(const __attribute__((address_space(4))) type*)(kpm + __builtin_offsetof(OnePassArgs, member)))
-  const unsigned m_ticket = (unsigned)__builtin_amdgcn_readfirstlane((int)s_misc[0]);
+  const unsigned m_ticket = (unsigned)__builtin_amdgcn_readfirstlane((int)s_misc[tk_slot]);
   const unsigned m_ntt = (unsigned)(OP_MARG(int, A.n_tiles) + 2);
   const int64_t m_u = m_ticket / m_ntt;
   const int m_jt = (int)(m_ticket % m_ntt) - 1;
@@ -640,7 +723,19 @@ __global__ __launch_bounds__(WAVES * 64, 3) void k_gate_onepass(OnePassArgs P) {
     op_st16_sc1(&xb_mine[((4 * wave + g) * OP_XW + c) * 2], gr);
   }
   __syncthreads();   // every wave is past its forward exchange: the slices are idle from here
-  if (halo_tile) return;
+  if (halo_tile) {
+    if constexpr (PERSIST) {
+      // a halo tile ends here: its next ticket is drawn on the spot (two tiles in 149 at the default chunking)
+      if (tid == 0) s_misc[tk_slot ^ 1u] = atomicAdd((unsigned*)(uintptr_t)OP_MARG(unsigned long long, ticket), 1u) - OP_MARG(unsigned, ticket_base);
+      pf = false;
+      // (defined on this path too: left alone, the registers of the samples staged at the loop top would stay live up to here)
+#pragma unroll
+      for (int k = 0; k < NQ; ++k) q[k] = 0.f;
+#pragma unroll
+      for (int k = 0; k < SCAN_REG; ++k) sc[k] = 0.f;
+    }
+    OP_DONE;
+  }
   OP_STAMP(6);   // publish + barrier
 
   // ---- smoothing on the matrix cores (exact integer arithmetic, v_mfma_i32_16x16x32_i8) ----------------
@@ -712,6 +807,12 @@ __global__ __launch_bounds__(WAVES * 64, 3) void k_gate_onepass(OnePassArgs P) {
   }
   __syncthreads();
   OP_STAMP(8);   // neighbours' bits (poll) + barrier
+  // PERSIST: the next ticket.  Drawn only now -- this tile no longer waits for a tile with a HIGHER ticket -- and consumed at
+  // the end of the smoothing stage: the atomic's round trip (~1.5 us) runs under the matrix-core work
+  [[maybe_unused]] unsigned nx_raw = 0u;
+  if constexpr (PERSIST) {
+    if (tid == 0) nx_raw = atomicAdd((unsigned*)(uintptr_t)OP_MARG(unsigned long long, ticket), 1u);
+  }
   {
     const unsigned char* rp1 = wbb + r1 * WPB + 7 + q4;
     const unsigned char* rp2 = wbb + r2 * WPB + 7 + q4;
@@ -739,6 +840,11 @@ __global__ __launch_bounds__(WAVES * 64, 3) void k_gate_onepass(OnePassArgs P) {
       }
     }
   }
+#if !OP_TK_LATE
+  if constexpr (PERSIST) {
+    if (tid == 0) s_misc[tk_slot ^ 1u] = nx_raw - OP_MARG(unsigned, ticket_base);
+  }
+#endif
   __syncthreads();  // K of all 16 frames complete; from here every wave touches only its own slice
   OP_STAMP(9);   // smoothing on the matrix cores + barrier
 
@@ -831,6 +937,12 @@ __global__ __launch_bounds__(WAVES * 64, 3) void k_gate_onepass(OnePassArgs P) {
 #endif
   wave_lds_sync();  // K tile consumed: the slice is reused by the inverse transform
   OP_STAMP(10);  // mask + merge
+#if OP_TK_LATE
+  if constexpr (PERSIST) {
+    // the next ticket, from thread 0 to the other waves through a polled LDS word (no barrier between here and the prefetch)
+    if (tid == 0) *(volatile unsigned*)&s_misc[tk_slot ^ 1u] = nx_raw - OP_MARG(unsigned, ticket_base);
+  }
+#endif
 
   // ---- inverse transform, synthesis window, wave-private overlap-add (k_apply_fast<LEAN>) -------------
   {
@@ -841,6 +953,54 @@ __global__ __launch_bounds__(WAVES * 64, 3) void k_gate_onepass(OnePassArgs P) {
     fft512_inv_half(v, fb + zi, tw512 + zi, ci);
   }
   OP_STAMP(11);  // inverse transform
+  float4 n4;   // 1 / window envelope of the lane's four samples of a hop
+  auto load_n4 = [&]() { n4 = *reinterpret_cast<const float4*>(&reinterpret_cast<const float*>(m_tab + OP_TAB_INVN)[(tid & 63) * 4]); };
+  if constexpr (PERSIST) load_n4();   // ahead of the prefetch: the epilogue's wait for it must not include the next tile's samples
+  auto prefetch_next = [&]() {
+    // ---- the NEXT tile's samples: loads issued here, consumed at the loop top (see PERSIST above) ----
+    const OnePassArgs& Pn = *late_args<OnePassArgs>();
+#if OP_TK_LATE
+    unsigned nx_v;
+    while ((nx_v = *(volatile unsigned*)&s_misc[tk_slot ^ 1u]) == 0xffffffffu) __builtin_amdgcn_s_sleep(1);
+    const unsigned nx = (unsigned)__builtin_amdgcn_readfirstlane((int)nx_v);
+#else
+    const unsigned nx = (unsigned)__builtin_amdgcn_readfirstlane((int)s_misc[tk_slot ^ 1u]);
+#endif
+    pf = true;
+    // (every path DEFINES q / sc: a conditional assignment would keep the previous tile's values alive -- 24 registers --
+    // through a whole iteration)
+    // q / sc are DEFINED on every path, each by one if / else (a conditional assignment -- or a flag the optimiser cannot
+    // thread -- keeps the previous tile's values alive through a whole iteration, and the allocator then parks all 24
+    // in scratch: a store that waits for the very load it was meant to hide)
+    const bool n_live = nx < Pn.total_tiles;
+    const unsigned n_ntt = (unsigned)(Pn.A.n_tiles + 2);
+    const unsigned n_tk = n_live ? nx : 0u;
+    const unsigned n_u = n_tk / n_ntt;
+    const int n_jt = (int)(n_tk % n_ntt) - 1;
+    const unsigned n_gu = (unsigned)(Pn.A.view.unit0 + n_u), n_nch = (unsigned)Pn.A.view.n_chunks;
+    const TileSrc N = tile_src(Pn, (int64_t)(n_gu / n_nch), Pn.A.view.c0 + n_gu % n_nch, n_jt, true);
+    if (n_live && N.blk_vec) {
+#pragma unroll
+      for (int k = 0; k < NQ; ++k) q[k] = N.sp[tid + k * 256];
+    } else {
+#pragma unroll
+      for (int k = 0; k < NQ; ++k) q[k] = 0.f;
+    }
+    if (n_live && N.sc_base != nullptr) {
+#pragma unroll
+      for (int k = 0; k < SCAN_REG; ++k) sc[k] = N.sc_base[min(tid + k * WAVES * 64, N.sc_n1)];
+    } else {
+#pragma unroll
+      for (int k = 0; k < SCAN_REG; ++k) sc[k] = 0.f;
+    }
+  };
+#ifndef OP_PF_AT
+#define OP_PF_AT 2   // where the prefetch is issued: 0 before the overlap-add, 1 / 2 / 3 after that many quarters of it, 4 after it, 5 at the end of the epilogue
+#endif
+#ifndef OP_TK_LATE
+#define OP_TK_LATE 0  // 1: the next ticket reaches the other waves through a polled LDS word after the mask stage, not under the smoothing stage's barrier
+#endif
+  if constexpr (PERSIST && OP_PF_AT == 0) prefetch_next();
   float* acc = reinterpret_cast<float*>(regions + wave * WAVE_CX_H);
   {
     const float2* wsrc2 = reinterpret_cast<const float2*>(swin + 2 * c);
@@ -861,9 +1021,10 @@ __global__ __launch_bounds__(WAVES * 64, 3) void k_gate_onepass(OnePassArgs P) {
         *dst = nw;
       }
       wave_lds_sync();
+      if constexpr (PERSIST) { if (j + 1 == OP_PF_AT) prefetch_next(); }
     }
   }
-  const float4 n4 = *reinterpret_cast<const float4*>(&reinterpret_cast<const float*>(m_tab + OP_TAB_INVN)[(tid & 63) * 4]);
+  if constexpr (!PERSIST) load_n4();
   __syncthreads();
   OP_STAMP(12);  // window + wave-private overlap-add + barrier
 #if OP_TRACE
@@ -900,7 +1061,7 @@ __global__ __launch_bounds__(WAVES * 64, 3) void k_gate_onepass(OnePassArgs P) {
   const int e_padL = OP_KARG(int32_t, A.g.padL);
   const int64_t e_T = OP_KARG(int64_t, A.g.T), e_Lout = OP_KARG(int64_t, A.g.Lout);
 #if OP_LATE_ARGS
-  const unsigned e_ticket = (unsigned)__builtin_amdgcn_readfirstlane((int)s_misc[0]);
+  const unsigned e_ticket = (unsigned)__builtin_amdgcn_readfirstlane((int)s_misc[tk_slot]);
   const unsigned e_ntt = (unsigned)(e_ntiles + 2);
   const int64_t e_u = e_ticket / e_ntt;
   const int e_jt = (int)(e_ticket % e_ntt) - 1;
@@ -944,7 +1105,8 @@ __global__ __launch_bounds__(WAVES * 64, 3) void k_gate_onepass(OnePassArgs P) {
 #pragma unroll
         for (int it = 0; it < 4; ++it) fin(ld4(it * R + 3 * HPITCH), 3 + 4 * it);
         OP_STAMP(13);
-        return;
+        if constexpr (PERSIST && OP_PF_AT == 5) prefetch_next();
+        OP_DONE;
       }
       {
         const float4 a4 = ld4((WAVES - 1) * R + (wave + 4) * HPITCH);
@@ -984,7 +1146,8 @@ __global__ __launch_bounds__(WAVES * 64, 3) void k_gate_onepass(OnePassArgs P) {
         fin(a4, wave);
       }
       OP_STAMP(13);  // cross-wave combine, hand-off of the straddling hops, stores
-      return;
+      if constexpr (PERSIST && OP_PF_AT == 5) prefetch_next();
+      OP_DONE;
     }
   }
   for (int it = 0; it < 5; ++it) {
@@ -1082,6 +1245,8 @@ __global__ __launch_bounds__(WAVES * 64, 3) void k_gate_onepass(OnePassArgs P) {
       store_sample(e_out, e_odtype, e_row * e_ostride + gi - e_g0, p < e_Lout ? vals[e] : 0.f);
     }
   }
+  if constexpr (PERSIST && OP_PF_AT == 5) prefetch_next();
+  }   // tile loop (one iteration unless PERSIST)
 }
 
 }  // namespace fast

@@ -285,7 +285,8 @@ def test_onepass_floor_test_prediction_follows_the_data():
 
 
 def test_onepass_tile_order_option_same_output():
-    """SG_OPT_TILE_ORDER 1 (tile = block index, no atomic ticket) is an ordering choice only: bit-identical output."""
+    """SG_OPT_TILE_ORDER is an ordering choice only -- 0 persistent workgroups looping over tickets (default, round 6),
+    1 tile = block index, 2 one ticket-drawn tile per workgroup: bit-identical output, and equal to the oracle."""
     from noisereduce_amd import _ffi
     from noisereduce_amd.spectralgate.stationary import SpectralGateStationary
     y, y_noise, cs, pad = _floor_inputs("benign")
@@ -294,12 +295,47 @@ def test_onepass_tile_order_option_same_output():
               time_constant_s=2.0, freq_mask_smooth_hz=500, time_mask_smooth_ms=50, tmp_folder=None, use_tqdm=False,
               n_jobs=1)
     sg = SpectralGateStationary(y=y, **kw)
+    assert sg._gate.get_option(_ffi.SG_OPT_TILE_ORDER) == 0
     a = sg.get_traces()
+    outs = []
     try:
-        sg._gate.set_option(_ffi.SG_OPT_TILE_ORDER, 1)
-        b = sg.get_traces()
-        c = sg.get_traces()
+        for mode in (1, 2, 0, 2, 0):
+            sg._gate.set_option(_ffi.SG_OPT_TILE_ORDER, mode)
+            outs.append(sg.get_traces())
+            outs.append(sg.get_traces())
     finally:
         sg._gate.set_option(_ffi.SG_OPT_TILE_ORDER, 0)
-    d = sg.get_traces()
-    assert np.array_equal(a, b) and np.array_equal(a, c) and np.array_equal(a, d)
+    for b in outs:
+        assert np.array_equal(a, b)
+    sg._gate.check_errors()
+
+
+@pytest.mark.parametrize("prop", [1.0, 0.8])
+@pytest.mark.parametrize("shape", [(1, 48000 * 40, 600000, 30000), (3, 48000 * 7 + 123, 100000, 5000),
+                                   (2, 48000 * 3, 40000, 6000), (1, 20000, 600000, 30000)])
+def test_onepass_persistent_equals_one_tile_per_workgroup(shape, prop):
+    """The persistent loop (tables once per workgroup, next ticket + next span prefetched) against the one-tile kernel and
+    the oracle: more tiles than resident workgroups (40 s), several units per channel, chunks of a few tiles, a call
+    with fewer tiles than the grid."""
+    from noisereduce_amd import _ffi
+    from noisereduce_amd.spectralgate.stationary import SpectralGateStationary
+    from oracle import spectralgate_oracle as O
+    C, n, cs, pad = shape
+    y = np.stack([O.synth_signal(n, seed=11 + c, tone_hz=700.0 + 300 * c) for c in range(C)]).astype(np.float32)
+    kw = dict(sr=48000, y_noise=None, prop_decrease=prop, n_std_thresh_stationary=1.5, chunk_size=cs,
+              clip_noise_stationary=True, padding=pad, n_fft=1024, win_length=None, hop_length=None,
+              time_constant_s=2.0, freq_mask_smooth_hz=500, time_mask_smooth_ms=50, tmp_folder=None, use_tqdm=False,
+              n_jobs=1)
+    sg = SpectralGateStationary(y=y, **kw)
+    a = sg.get_traces()
+    a2 = sg.get_traces()
+    try:
+        sg._gate.set_option(_ffi.SG_OPT_TILE_ORDER, 2)
+        b = sg.get_traces()
+    finally:
+        sg._gate.set_option(_ffi.SG_OPT_TILE_ORDER, 0)
+    assert np.array_equal(a, b) and np.array_equal(a, a2)
+    sg._gate.check_errors()
+    if n <= 48000 * 7 + 123:
+        want = O.reduce_noise_S(y.astype(np.float64), 48000, stationary=True, chunk_size=cs, padding=pad, prop_decrease=prop)
+        assert O.rel_err(a, want) < 1e-4
