@@ -183,6 +183,7 @@ class Gate:
         self.lock = threading.RLock()
         self.thresh_owner = None
         self._thresh_owner_ref = None    # weak reference to the owning object while its only copy is the handle's (claim_threshold)
+        self._thr_stream = None          # stream the handle's current threshold was written on (noise_stats / set_noise_threshold*)
         wptr = None
         if window is not None:
             w = np.ascontiguousarray(np.asarray(window, dtype=np.float64))
@@ -270,7 +271,18 @@ class Gate:
             ref, self._thresh_owner_ref = self._thresh_owner_ref, None
             obj = ref() if ref is not None else None
             if obj is not None and obj._thr_dev is None and self.thresh_owner is obj._token:
-                obj._thr_dev = self.noise_threshold_tensor()
+                # The copy runs on the EVICTING caller's stream; the threshold was written on the owner's.  One stream (the
+                # usual case): ordered by the stream, nothing to do.  Two: the copy waits for the writer's stream, the
+                # owner's stream -- which will read the copy later -- waits for the copy, and the caching allocator is told
+                # (costs nothing on the single-stream path)
+                with torch.cuda.device(self.device):
+                    cur, src = torch.cuda.current_stream(self.device), self._thr_stream
+                    if src is not None and src != cur:
+                        cur.wait_stream(src)
+                    obj._thr_dev = self.noise_threshold_tensor()
+                    if src is not None and src != cur:
+                        src.wait_stream(cur)
+                        obj._thr_dev.record_stream(src)
             self.thresh_owner = None
 
     def noise_stats(self, noise):
@@ -281,6 +293,7 @@ class Gate:
             self._check(self.lib.sg_noise_stats(self._h, noise.data_ptr(), _sg_dtype(noise),
                                                 noise.shape[0], noise.shape[1], stride,
                                                 self._stream()))
+            self._thr_stream = torch.cuda.current_stream(self.device)
 
     def get_noise_threshold(self):
         out = np.empty(self.n_bins, dtype=np.float64)
@@ -295,6 +308,7 @@ class Gate:
         with torch.cuda.device(self.device):
             self._check(self.lib.sg_set_noise_threshold(
                 self._h, t.ctypes.data_as(POINTER(c_double)), int(t.shape[0]), self._stream()))
+            self._thr_stream = torch.cuda.current_stream(self.device)
 
     def noise_threshold_tensor(self):
         """The threshold as a float64 device tensor (no host synchronisation)."""
@@ -311,6 +325,7 @@ class Gate:
         with torch.cuda.device(self.device):
             self._check(self.lib.sg_set_noise_threshold_dev(self._h, t.data_ptr(), int(t.numel()),
                                                             self._stream()))
+            self._thr_stream = torch.cuda.current_stream(self.device)
 
     def process_chunks(self, x, out_dtype=None, start_frame=0, end_frame=None, chunked=True,
                        out=None, halo_left=0, halo_right=0):
@@ -390,8 +405,8 @@ class Gate:
         the library's default if it was never set -- not every default is 0 (SG_OPT_ROWGATE_SHAPE: 16)."""
         v = c_int64(0)
         rc = self.lib.sg_get_option(self._h, int(option), byref(v))
-        if rc != 0:
-            raise ValueError(f"sg_get_option: unknown option {int(option)}")
+        if rc != 0:   # (the handle is const in sg_get_option: the library leaves no message of its own)
+            raise ValueError(f"sg_get_option: unknown option {int(option)} (rc {rc})")
         return int(v.value)
 
     @contextlib.contextmanager

@@ -26,7 +26,13 @@ def reduce_noise(y, sr, stationary=False, y_noise=None, prop_decrease=1.0, time_
 
     ``use_torch=False`` evaluates the numpy/scipy "spectralgate" algorithm,
     ``use_torch=True`` the "torchgate" algorithm (the two differ)."""
+    if precision not in (None, "float32", "float64"):
+        raise ValueError("precision must be None, 'float32' or 'float64'")
     if use_torch:
+        if precision == "float64":
+            # (the torchgate algorithm computes in float32 in the reference too, torchgate.py:200-264: asking for float64
+            # arithmetic there must not be silently ignored)
+            raise ValueError("precision='float64' applies to use_torch=False only (the torchgate algorithm is float32)")
         if n_jobs != 1:
             raise ValueError("n_jobs must be 1 when using torch version of spectral gating.")
         from noisereduce_amd.spectralgate.streamed_torch_gate import StreamedTorchGate

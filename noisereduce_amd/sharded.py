@@ -103,6 +103,12 @@ class HipStationaryBackend:
                        hop_length=None, time_constant_s=2.0, freq_mask_smooth_hz=500,
                        time_mask_smooth_ms=50, tmp_folder=None, prop_decrease=1.0,
                        use_tqdm=False, n_jobs=1)
+        # precision (reduce_noise's extension): "float64" selects the float64 pipeline on this rank's handle too -- a sharded
+        # call must not quietly come back float32-accurate; None defers to NOISEREDUCE_AMD_EXACT like cached_gate
+        precision = kw.pop("precision", None)
+        if precision not in (None, "float32", "float64"):
+            raise ValueError('precision must be None, "float32" or "float64"')
+        self.exact = None if precision is None else precision == "float64"
         self.kw.update(kw)
         self.chunk_size, self.padding = self.kw["chunk_size"], self.kw["padding"]
         self._g = None
@@ -126,7 +132,8 @@ class HipStationaryBackend:
                                        n_grad_freq=probe._n_grad_freq, n_grad_time=probe._n_grad_time,
                                        smooth_mask=probe.smooth_mask, chunk_size=k["chunk_size"],
                                        padding=k["padding"], prop_decrease=k["prop_decrease"],
-                                       n_std_thresh=k["n_std_thresh_stationary"], top_db=80.0, ddof=0)
+                                       n_std_thresh=k["n_std_thresh_stationary"], top_db=80.0, ddof=0,
+                                       exact=self.exact)
         return self._g
 
     def lock(self):

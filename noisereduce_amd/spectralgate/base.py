@@ -224,7 +224,14 @@ class SpectralGate:
             return None
         if self._chunk_size is None or np.dtype(self._dtype) not in _DEVICE_DTYPES or not isinstance(self.y, np.ndarray):
             return None
+        # torch.from_numpy (the per-piece upload) refuses views with a negative stride (y[::-1], np.flip) -- and there is
+        # nothing to pipeline in a recording without channels or samples: those take the one-upload path, which goes
+        # through np.ascontiguousarray
+        if self.y.ndim != 2 or self.n_channels <= 0 or self.n_frames <= 0 or any(st <= 0 for st in self.y.strides):
+            return None
         cs, N = int(self._chunk_size), int(self.n_frames)
+        if cs <= 0:
+            return None
         n_chunks = -(-N // cs)
         piece_bytes = int(os.environ.get("NOISEREDUCE_AMD_PIPELINE_PIECE_BYTES", self._PIPE_PIECE_BYTES))
         k = max(1, piece_bytes // (self.n_channels * cs * np.dtype(self._dtype).itemsize))

@@ -142,3 +142,34 @@ def test_pipelined_host_path_from_two_threads(monkeypatch):
     assert not errs, errs
     for i in range(2):
         assert np.array_equal(out[i], refs[i])
+
+
+@pytest.mark.parametrize("stationary", [True, False])
+def test_host_views_the_piecewise_upload_cannot_take(monkeypatch, stationary):
+    """a time-reversed view (negative stride) made the pipelined upload raise in torch.from_numpy once the
+    recording was long enough to pipeline; such views -- and Fortran-ordered / transposed multichannel inputs, whose rows
+    are strided but positive -- must give what their contiguous copies give."""
+    import noisereduce_amd as nr
+    from noisereduce_amd.spectralgate import base
+    n = 600000 * 7 + 4321
+    y = _rec(n, 1, np.float32, 21)[0]
+    monkeypatch.setenv("NOISEREDUCE_AMD_PIPELINE_PIECE_BYTES", str(600000 * 4))
+    rev = y[::-1]
+    assert rev.strides[0] < 0
+    got = nr.reduce_noise(y=rev, sr=48000, stationary=stationary)
+    want = nr.reduce_noise(y=np.ascontiguousarray(rev), sr=48000, stationary=stationary)
+    assert np.array_equal(got, want)
+    # two channels: Fortran order, a transposed (n, 2) array, and a channel-reversed view
+    y2 = _rec(n, 2, np.float32, 22)
+    want2 = nr.reduce_noise(y=y2, sr=48000, stationary=stationary)
+    for view in (np.asfortranarray(y2), np.ascontiguousarray(y2.T).T):
+        assert not view.flags["C_CONTIGUOUS"]
+        assert np.array_equal(nr.reduce_noise(y=view, sr=48000, stationary=stationary), want2)
+    got3 = nr.reduce_noise(y=y2[::-1], sr=48000, stationary=stationary)
+    assert np.array_equal(got3, nr.reduce_noise(y=np.ascontiguousarray(y2[::-1]), sr=48000, stationary=stationary))
+    # the guard itself
+    sg = base.SpectralGate.__new__(base.SpectralGate)
+    sg._tensor_io, sg._chunk_size, sg._dtype, sg.y, sg.n_channels, sg.n_frames = False, 600000, np.float32, y2[:, ::-1], 2, n
+    assert sg._pipeline_pieces() is None
+    sg.y = y2
+    assert sg._pipeline_pieces() is not None

@@ -217,3 +217,26 @@ def test_channel_bounds_cover_every_channel_once():
             assert all(x[1] == y[0] for x, y in zip(b, b[1:]))
             sizes = [e - s for s, e in b]
             assert max(sizes) - min(sizes) <= 1 and sizes == sorted(sizes, reverse=True)
+
+
+def test_pipeline_pieces_refuses_views_the_piecewise_upload_cannot_take():
+    """Host logic only (no GPU): the pipelined upload slices the caller's array per piece with torch.from_numpy, which
+    rejects negative strides; zero channels / samples have nothing to pipeline."""
+    from noisereduce_amd.spectralgate import base
+    n = 600000 * 8
+    y = np.zeros((2, n), dtype=np.float32)
+
+    def pieces(arr, c=2, frames=n, cs=600000):
+        sg = base.SpectralGate.__new__(base.SpectralGate)
+        sg._tensor_io, sg._chunk_size, sg._dtype, sg.y, sg.n_channels, sg.n_frames = False, cs, np.float32, arr, c, frames
+        return sg._pipeline_pieces()
+
+    ok = pieces(y)
+    assert ok is not None and ok[0][0] == 0 and ok[-1][1] == n and all(a < b for a, b in ok)
+    assert all(ok[i][1] == ok[i + 1][0] for i in range(len(ok) - 1))
+    assert pieces(y[:, ::-1]) is None          # time-reversed view
+    assert pieces(y[::-1]) is None             # channel-reversed view
+    assert pieces(np.asfortranarray(y)) is not None   # strided but positive: torch.from_numpy takes it
+    assert pieces(np.zeros((0, n), np.float32), c=0) is None
+    assert pieces(np.zeros((2, 0), np.float32), frames=0) is None
+    assert pieces(y, cs=None) is None
