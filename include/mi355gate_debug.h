@@ -85,7 +85,9 @@ SG_API int sg_debug_fetch(sg_handle* h, int32_t what, void* host, int64_t bytes,
 #define SG_STAGE_DECIDE_FAST 15
 #define SG_STAGE_ONEPASS 16
 #define SG_STAGE_ROW_GATE 17   /* k_row_gate: TorchGate.forward of a whole row (<= 64 frames) in one kernel */
-#define SG_N_STAGES 18
+#define SG_STAGE_IIR_CHAIN 18 /* non-stationary gate: carries of the time tiles (k_iir_chain_par; serial form k_iir_part / k_iir_comb + k_iir_chain) */
+#define SG_STAGE_IIR_MASK 19  /* non-stationary gate: k_iir_mask<nt> -- recurrence, sigmoid and both smoothing passes in one kernel */
+#define SG_N_STAGES 20
 /* When enabled, every kernel launch is bracketed by a hipEvent pair recorded on the launch
  * stream.  sg_profile_read synchronises those events and returns accumulated milliseconds
  * and launch counts per stage (arrays of SG_N_STAGES); reset != 0 clears the accumulators. */

@@ -23,7 +23,7 @@ LIB_PATH = os.path.join(_HERE, "libmi355gate.so")
 SG_F32, SG_F64, SG_I16, SG_I32 = 0, 1, 2, 3
 SG_VARIANT_S, SG_VARIANT_T = 0, 1
 SG_E_INVALID, SG_E_UNSUPPORTED, SG_E_HIP, SG_E_NOMEM, SG_E_STATE, SG_E_HANDOFF = -1, -2, -3, -4, -5, -6
-SG_N_STAGES = 18
+SG_N_STAGES = 20
 SG_OPT_FORCE_F64_DECIDE = 3
 SG_OPT_FORCE_NOSEAM = 4
 SG_OPT_FORCE_NOLEAN = 5

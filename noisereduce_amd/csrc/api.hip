@@ -1618,7 +1618,7 @@ static int stage_nonstat_mask2(sg_handle* h, const View& v, const Geom& g, int64
   if ((rc = ensure(h, h->nsp, bytes))) return rc;
   if ((rc = ensure(h, h->nsc, bytes))) return rc;
   {
-    ProfScope ps(h, SG_STAGE_NONSTAT_MASK, st);
+    ProfScope ps(h, SG_STAGE_IIR_CHAIN, st);
     // (round 5) k_iir_chain_par: the chain in 16 runs per band, straight from the 16-frame sub-tile partials where
     // k_mag_fast left them (no k_iir_comb); SG_OPT_FORCE_SPLIT keeps the serial kernels (A/B)
     const bool par = SG_CHAIN_PAR && !h->force_split && ub <= 65535;
@@ -1656,7 +1656,7 @@ static int stage_nonstat_mask2(sg_handle* h, const View& v, const Geom& g, int64
     }
   }
   {
-    ProfScope ps(h, smooth ? SG_STAGE_SMOOTH : SG_STAGE_NONSTAT_MASK, st);
+    ProfScope ps(h, SG_STAGE_IIR_MASK, st);
     const int BW = 64 - 2 * nf;
     const unsigned gx = (unsigned)(((g.F + BW - 1) / BW + 3) / 4);
     const bool to_raw = !smooth && h->p.smooth_mask;
@@ -3254,14 +3254,18 @@ extern "C" int sg_profile_read(sg_handle* h, double* ms, int64_t* counts, int32_
 
 extern "C" const char* sg_stage_name(int32_t stage) {
   static const char* names[SG_N_STAGES] = {"k_channel_mean", "k_stft<double> (power)", "k_colmax", "k_colstats",
-                                           "k_decide", "k_stft<float> (magnitude)", "nonstat mask (iir/boxcar)",
-                                           "k_smooth_f+k_smooth_t", "k_apply_istft", "k_ola",
+                                           "k_decide", "k_mag_fast* / k_stft<float> (magnitude)",
+                                           "k_box_mask / k_iir_sigmoid / k_boxcar_sigmoid (non-stationary mask, other paths)",
+                                           "mask smoothing (k_smooth_bits2 / k_smooth_tiled / k_smooth_f+k_smooth_t)",
+                                           "k_apply_istft", "k_ola",
                                            "noise statistics (all kernels)", "k_unit_absmax+k_prep_thresh",
                                            "k_stft_bits<max> (floor pre-pass)", "k_stft_bits<decide>",
                                            "k_apply_fast (fft+mask+ifft+ola)",
                                            "k_decide_fast (f32 stft + exact f64 refine)",
                                            "k_gate_onepass (fft+decide+smooth+mask+ifft+ola)",
-                                           "k_row_gate (fft+row stats+decide+smooth+mask+ifft+ola)"};
+                                           "k_row_gate (fft+row stats+decide+smooth+mask+ifft+ola)",
+                                           "k_iir_chain_par (tile carries; serial: k_iir_part / k_iir_comb + k_iir_chain)",
+                                           "k_iir_mask<nt> (recurrence+sigmoid+smoothing)"};
   return (stage >= 0 && stage < SG_N_STAGES) ? names[stage] : "?";
 }
 

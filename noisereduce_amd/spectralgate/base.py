@@ -227,7 +227,9 @@ class SpectralGate:
         # torch.from_numpy (the per-piece upload) refuses views with a negative stride (y[::-1], np.flip) -- and there is
         # nothing to pipeline in a recording without channels or samples: those take the one-upload path, which goes
         # through np.ascontiguousarray
-        if self.y.ndim != 2 or self.n_channels <= 0 or self.n_frames <= 0 or any(st <= 0 for st in self.y.strides):
+        # (the stride of a length-1 axis is arbitrary -- np.expand_dims leaves 0 or anything else there -- and never used)
+        if self.y.ndim != 2 or self.n_channels <= 0 or self.n_frames <= 0 or \
+                any(st <= 0 for st, n in zip(self.y.strides, self.y.shape) if n > 1):
             return None
         cs, N = int(self._chunk_size), int(self.n_frames)
         if cs <= 0:
@@ -278,7 +280,9 @@ class SpectralGate:
             up = _pipe_stream(self.device)
             with torch.cuda.device(self.device), torch.cuda.stream(up):
                 st["x_dev"][:, a:b].copy_(torch.from_numpy(self.y[:, a:b]), non_blocking=True)
-            up.synchronize()
+                done = torch.cuda.Event()
+                done.record(up)
+            done.synchronize()    # THIS upload only: the side stream is shared by every thread of the process
             st["sent"] = b
 
     def _get_traces_pipelined(self):

@@ -237,6 +237,10 @@ def test_pipeline_pieces_refuses_views_the_piecewise_upload_cannot_take():
     assert pieces(y[:, ::-1]) is None          # time-reversed view
     assert pieces(y[::-1]) is None             # channel-reversed view
     assert pieces(np.asfortranarray(y)) is not None   # strided but positive: torch.from_numpy takes it
+    one = np.zeros(n, np.float32)
+    assert pieces(np.expand_dims(one, 0), c=1) is not None                       # mono: whatever stride the unit axis got
+    assert pieces(np.lib.stride_tricks.as_strided(one, (1, n), (0, 4)), c=1) is not None
+    assert pieces(np.expand_dims(one[::-1], 0), c=1) is None
     assert pieces(np.zeros((0, n), np.float32), c=0) is None
     assert pieces(np.zeros((2, 0), np.float32), frames=0) is None
     assert pieces(y, cs=None) is None

@@ -157,3 +157,41 @@ def test_channel_sharded_hip_uneven_channels():
     mp.spawn(_worker_channels_uneven, args=(2, _free_port(), torch.from_numpy(y), torch.from_numpy(want), ret),
              nprocs=2, join=True)
     assert ret[0][0] < TOL and ret[1][0] < TOL and ret[0][1] == 1 and ret[1][1] == 1, dict(ret)
+
+
+@pytest.mark.parametrize("workload", ["config2", "config3", "config4"])
+def test_bench_two_ranks_end_to_end_over_gloo(workload):
+    """`python bench.py --gpus 2` exactly as the driver starts an N-GPU run (bare: it launches its own ranks through
+    torch.distributed.run on 127.0.0.1), with BENCH_BACKEND=gloo so that both ranks may share this box's one GPU: launcher,
+    rendezvous, sharded step, max-over-ranks timing, the weak-scaling line with its distributed parity verdict -- everything
+    but RCCL itself, so that the first 8-GPU lease cannot fail on plumbing."""
+    import json
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = dict(os.environ, BENCH_BACKEND="gloo", OMP_NUM_THREADS="1")
+    env.pop("WORLD_SIZE", None)
+    env.pop("RANK", None)
+    steps = "2"
+    cmd = [sys.executable, os.path.join(root, "bench.py"), "--gpus", "2", "--steps", steps, "--warmup", "1",
+           "--no-cpu-baseline", "--workload", workload]
+    pr = subprocess.run(cmd, env=env, cwd=root, capture_output=True, text=True, timeout=600)
+    assert pr.returncode == 0, pr.stderr[-2000:]
+    lines = [ln for ln in pr.stdout.splitlines() if ln.startswith("{")]
+    assert len(lines) == 1, pr.stdout[-2000:]
+    d = json.loads(lines[0])
+    assert d["n_gpus"] == 2 and d["steps"] == 2 and d["scaling"] == "weak" and d["unit"] == "Msamples/s"
+    assert d["value"] > 0 and d["higher_is_better"] is True and d["vs_baseline"] is None
+    per_gpu = d["config"]["samples_per_gpu"]
+    # whole-job aggregate: the samples of BOTH ranks over the slowest rank's time
+    assert abs(d["value"] - 2 * per_gpu / (d["ms_per_step"] * 1e-3) / 1e6) <= 0.01 * d["value"]
+    dd = d["distributed"]
+    assert dd["world_size"] == 2 and dd["parity_ok"] is True and len(dd["per_rank"]) == 2
+    assert len(dd["ms_per_step_per_rank"]) == 2 and all(t > 0 for t in dd["ms_per_step_per_rank"])
+    if workload == "config4":
+        sg = dd["single_gpu_same_share"]
+        assert sg["ms_per_step"] > 0 and sg["throughput_factor_vs_it"] > 0
+        assert all(g["rel_err_unit"] < 1e-4 for g in dd["per_rank"])
+    else:
+        assert all(g["halo_ok"] and g["rel_err_chunk0"] < 1e-4 for g in dd["per_rank"])
+        assert "roofline" in d and d["roofline"]["frac"] > 0
