@@ -24,6 +24,7 @@
 #include "kernels.hpp"
 #include "fused.hpp"
 #include "czt.hpp"
+#include "mixed.hpp"
 #include "onepass.hpp"
 #include "rowgate.hpp"
 #include "rowbwd.hpp"
@@ -146,6 +147,8 @@ struct sg_handle {
   int big_czt = 0;
   DevBuf big_twM, big_tw2, big_ch, big_bh, big_W, big_W2;
   int czt_M = 0;                     // > 0: n_fft is not a power of two -> chirp-z kernels (czt.hpp) of size M
+  bool mr_ok = false;                // n_fft even, n_fft / 2 <= 2048 with prime factors <= 13, not a power of two: the float32 and
+  MrPlan mr{};                       // float64 STFT / decision / apply kernels of mixed.hpp (run-time radix schedule) instead of chirp-z
   DevBuf czt_tw64, czt_ch64, czt_bh64, czt_tw32, czt_ch32, czt_bh32;
   bool force_noseam = false;
   bool force_nolean = false;         // SG_OPT_FORCE_NOLEAN: full-size slices + stored frames (2 waves/SIMD)
@@ -453,8 +456,11 @@ static hipError_t launch_decide_lds_n(const sg_handle* h, const View& v, const G
   return hipGetLastError();
 }
 
+static hipError_t launch_decide_mr(const sg_handle* h, const View& v, const Geom& g, int64_t units, const ThreshConsts& tc,
+                                   unsigned long long* bits, int wpr, hipStream_t st);
 static hipError_t launch_decide_lds(const sg_handle* h, const View& v, const Geom& g, int64_t units,
                                     const ThreshConsts& tc, unsigned long long* bits, int wpr, hipStream_t st) {
+  if (h->mr_ok) return launch_decide_mr(h, v, g, units, tc, bits, wpr, st);
   switch (h->N) {
     case 32: return launch_decide_lds_n<32>(h, v, g, units, tc, bits, wpr, st);
     case 64: return launch_decide_lds_n<64>(h, v, g, units, tc, bits, wpr, st);
@@ -499,6 +505,120 @@ static hipError_t launch_apply(int N, const View& v, const Geom& g, int64_t unit
     case 4096: return launch_apply_n<4096>(v, g, units, tw, wa, ws, M, seg, st, K16, kscale);
   }
   return hipErrorInvalidValue;
+}
+
+// ------------------------------------------------------------------------------------------
+// mixed-radix kernels (mixed.hpp): frame lengths 2 N with N = 2^a 3^b 5^c 7^d 11^e 13^f <= 2048 that are not powers of two
+// ------------------------------------------------------------------------------------------
+static bool mr_make_plan(int N, MrPlan* pl) {
+  if (N < 2 || N > 2048) return false;
+  pl->N = N;
+  pl->np = 0;
+  int r = N;
+  auto take = [&](int R) {
+    while (r % R == 0 && pl->np < MR_MAXP) { pl->R[pl->np++] = (unsigned char)R; r /= R; }
+  };
+  take(8); take(4); take(2); take(5); take(3); take(7); take(11); take(13);
+  return r == 1;
+}
+// threads per frame / frames in flight per workgroup: one wavefront per frame while a frame's two ping-pong buffers stay small,
+// the whole workgroup on one frame beyond (MR_MAXM sweeps of NT bins must cover N + 1 bins)
+static void mr_shape(int N, size_t cx_bytes, int* NT, int* teams) {
+  (void)cx_bytes;
+  const bool wide = N > 512;
+  *NT = wide ? 256 : 64;
+  *teams = wide ? 1 : 4;
+}
+template <typename TC>
+static hipError_t launch_stft_mr(const sg_handle* h, const View& v, const Geom& g, int64_t units, const void* wfull, double* P,
+                                 float* mag, double* z, double zscale, hipStream_t st, unsigned long long* pmax_bits) {
+  const int N = h->mr.N;
+  int NT, teams;
+  mr_shape(N, sizeof(cx<TC>), &NT, &teams);
+  const size_t lds = (size_t)(N + 2 * teams * lpn<TC>(N)) * sizeof(cx<TC>);
+  const void* tw = sizeof(TC) == 8 ? h->tw64.p : h->tw32.p;
+  // few units (the noise clip): one frame per team so that the grid still covers the chip
+  const int fpw = units * ((g.T + teams * 4 - 1) / (teams * 4)) < 1024 ? 1 : 4;
+  auto go = [&](auto kern) -> hipError_t {
+    if (lds > 65536) {
+      hipError_t e = set_lds(reinterpret_cast<const void*>(kern), lds);
+      if (e != hipSuccess) return e;
+    }
+    dim3 grid((unsigned)((g.T + teams * fpw - 1) / (teams * fpw)), (unsigned)units);
+    hipLaunchKernelGGL(kern, grid, dim3(teams * NT), lds, st, v, g, h->mr, (const cx<TC>*)tw, (const TC*)wfull, P, mag, z,
+                       zscale, pmax_bits, fpw);
+    return hipGetLastError();
+  };
+  return NT == 64 ? go(k_stft_mr<TC, 64>) : go(k_stft_mr<TC, 256>);
+}
+template <int MODE>
+static hipError_t launch_bits_mr(const sg_handle* h, const View& v, const Geom& g, int64_t units, const ThreshConsts& tc,
+                                 unsigned long long* pmax_bits, unsigned long long* bits, int wpr, hipStream_t st) {
+  const int N = h->mr.N;
+  int NT, teams;
+  mr_shape(N, sizeof(cx<double>), &NT, &teams);
+  const size_t lds = (size_t)(N + 2 * teams * lpn<double>(N)) * sizeof(cx<double>) + (size_t)(N + 1) * sizeof(double);
+  const int fpw = 4;
+  auto go = [&](auto kern) -> hipError_t {
+    if (lds > 65536) {
+      hipError_t e = set_lds(reinterpret_cast<const void*>(kern), lds);
+      if (e != hipSuccess) return e;
+    }
+    dim3 grid((unsigned)((g.T + teams * fpw - 1) / (teams * fpw)), (unsigned)units);
+    hipLaunchKernelGGL(kern, grid, dim3(teams * NT), lds, st, v, g, h->mr, (const cx<double>*)h->tw64.p,
+                       (const double*)h->wfull64.p, tc, h->mag_scale, h->p.top_db, pmax_bits, bits, wpr, fpw);
+    return hipGetLastError();
+  };
+  return NT == 64 ? go(k_stft_bits_mr<MODE, 64>) : go(k_stft_bits_mr<MODE, 256>);
+}
+static hipError_t launch_decide_mr(const sg_handle* h, const View& v, const Geom& g, int64_t units, const ThreshConsts& tc,
+                                   unsigned long long* bits, int wpr, hipStream_t st) {
+  const int N = h->mr.N;
+  int NT, teams;
+  mr_shape(N, sizeof(cx<float>), &NT, &teams);
+  const size_t lds = (size_t)(N + 2 * teams * N) * sizeof(cx<float>) + (size_t)(N + 1 + 4) * sizeof(float);
+  const int fpw = 4;
+  auto go = [&](auto kern) -> hipError_t {
+    if (lds > 65536) {
+      hipError_t e = set_lds(reinterpret_cast<const void*>(kern), lds);
+      if (e != hipSuccess) return e;
+    }
+    dim3 grid((unsigned)((g.T + teams * fpw - 1) / (teams * fpw)), (unsigned)units);
+    hipLaunchKernelGGL(kern, grid, dim3(teams * NT), lds, st, v, g, h->mr, (const cx<float>*)h->tw32.p, (const float*)h->wa32.p,
+                       (const cx<double>*)h->tw64.p, (const double*)h->wfull64.p, tc, h->mag_scale, h->p.top_db, bits, wpr, fpw);
+    return hipGetLastError();
+  };
+  return NT == 64 ? go(k_decide_mr<64>) : go(k_decide_mr<256>);
+}
+static hipError_t launch_apply_mr(const sg_handle* h, const View& v, const Geom& g, int64_t units, const float* wa, const float* ws,
+                                  const float* M, float* seg, hipStream_t st, const unsigned short* K16, float kscale) {
+  const int N = h->mr.N;
+  int NT, teams;
+  mr_shape(N, sizeof(cx<float>), &NT, &teams);
+  const size_t lds = (size_t)(N + 2 * teams * N) * sizeof(cx<float>);
+  const int fpw = 4;
+  auto go = [&](auto kern) -> hipError_t {
+    if (lds > 65536) {
+      hipError_t e = set_lds(reinterpret_cast<const void*>(kern), lds);
+      if (e != hipSuccess) return e;
+    }
+    dim3 grid((unsigned)((g.T + teams * fpw - 1) / (teams * fpw)), (unsigned)units);
+    hipLaunchKernelGGL(kern, grid, dim3(teams * NT), lds, st, v, g, h->mr, (const cx<float>*)h->tw32.p, wa, ws, M, seg, K16,
+                       kscale, fpw);
+    return hipGetLastError();
+  };
+  return NT == 64 ? go(k_apply_istft_mr<64>) : go(k_apply_istft_mr<256>);
+}
+template <int MODE>
+static hipError_t launch_bits(int N, const View& v, const Geom& g, int64_t units, const void* tw, const void* wfull,
+                              const ThreshConsts& tc, double mag_scale, double top_db, unsigned long long* pmax_bits,
+                              unsigned long long* bits, int wpr, hipStream_t st);
+// (the decision kernels of the fused path, whatever transform the frame length runs on)
+template <int MODE>
+static hipError_t launch_bits_any(const sg_handle* h, const View& v, const Geom& g, int64_t units, const ThreshConsts& tc,
+                                  unsigned long long* pmax_bits, unsigned long long* bits, int wpr, hipStream_t st) {
+  if (h->mr_ok) return launch_bits_mr<MODE>(h, v, g, units, tc, pmax_bits, bits, wpr, st);
+  return launch_bits<MODE>(h->N, v, g, units, h->tw64.p, h->wfull64.p, tc, h->mag_scale, h->p.top_db, pmax_bits, bits, wpr, st);
 }
 
 // ------------------------------------------------------------------------------------------
@@ -702,6 +822,7 @@ static hipError_t stft_any(const sg_handle* h, const View& v, const Geom& g, int
     const void* tw = sizeof(TC) == 8 ? h->tw64.p : h->tw32.p;
     return launch_stft<TC>(h->N, v, g, units, tw, wfull, P, mag, z, zscale, st, pmax_bits);
   }
+  if (h->mr_ok) return launch_stft_mr<TC>(h, v, g, units, wfull, P, mag, z, zscale, st, pmax_bits);
   const CztTabs<TC> tb = czt_tabs<TC>(h);
 #define SG_CALL(M) launch_stft_czt_m<TC, M>(v, g, units, tb, wfull, P, mag, z, zscale, st, pmax_bits)
   SG_CZT_SWITCH(h->czt_M, SG_CALL);
@@ -709,7 +830,7 @@ static hipError_t stft_any(const sg_handle* h, const View& v, const Geom& g, int
 }
 
 // the general apply kernel that can read the K counts of the fused bit-mask stages directly (k16_apply_ok)
-static bool k16_apply_geom(const sg_handle* h) { return !h->big_M && !h->czt_M; }
+static bool k16_apply_geom(const sg_handle* h) { return !h->big_M && (!h->czt_M || h->mr_ok); }
 
 static hipError_t apply_any(const sg_handle* h, const View& v, const Geom& g, int64_t units, const float* Mk,
                             float* seg, hipStream_t st, const unsigned short* K16 = nullptr, float kscale = 0.f) {
@@ -720,6 +841,7 @@ static hipError_t apply_any(const sg_handle* h, const View& v, const Geom& g, in
   const float* wa = (const float*)h->wa32.p;
   const float* ws = (const float*)h->ws32.p;
   if (!h->czt_M) return launch_apply(h->N, v, g, units, h->tw32.p, wa, ws, Mk, seg, st, K16, kscale);
+  if (h->mr_ok) return launch_apply_mr(h, v, g, units, wa, ws, Mk, seg, st, K16, kscale);
   const CztTabs<float> tb = czt_tabs<float>(h);
 #define SG_CALL(M) launch_apply_czt_m<M>(v, g, units, tb, wa, ws, Mk, seg, st)
   SG_CZT_SWITCH(h->czt_M, SG_CALL);
@@ -955,7 +1077,10 @@ extern "C" int sg_create(const sg_params* p, const double* window_host, sg_handl
     int64_t b = p->smooth_mask ? (int64_t)(p->n_grad_time + 1) * (p->n_grad_time + 1) : 1;
     h->ktot = a * b;
     // fused (bit-mask) path: variant-S stationary gate whose integer smoothing sums fit uint16
-    h->fused_ok = p->variant == SG_VARIANT_S && p->stationary && h->ktot <= 65535 && pow2 && n <= 4096 &&
+    // frame lengths 2 N, N a product of 2, 3, 5, 7, 11, 13: the mixed-radix kernels (mixed.hpp) -- and with them the fused
+    // (bit-mask) path -- instead of chirp-z
+    h->mr_ok = !pow2 && !bigf && n % 2 == 0 && n >= 8 && mr_make_plan(n / 2, &h->mr) && getenv("SG_NO_MIXED_RADIX") == nullptr;
+    h->fused_ok = p->variant == SG_VARIANT_S && p->stationary && h->ktot <= 65535 && (pow2 || h->mr_ok) && n <= 4096 &&
                   (!p->smooth_mask || p->n_grad_time <= 96);
     if (h->fused_ok && p->smooth_mask) {
       // the integer smoothing kernel holds (tt + 2 nt) rows of all F bins in LDS: 64-frame tiles, lower ones for long rows
@@ -991,7 +1116,7 @@ extern "C" int sg_create(const sg_params* p, const double* window_host, sg_handl
     wa32[k] = (float)wfull[k];
     // synthesis window incl. the inverse-transform normalisation: the half-size complex core leaves
     // a factor n/2, the chirp-z inverse a factor n
-    ws32[k] = (float)(wfull[k] / (pow2 ? (double)h->N : (double)n));
+    ws32[k] = (float)(wfull[k] / ((pow2 || h->mr_ok) ? (double)h->N : (double)n));
     wsq32[k] = (float)(wfull[k] * wfull[k]);
   }
   int rc = SG_OK;
@@ -1862,7 +1987,7 @@ static int stage_prep_floor(sg_handle* h, const View& v, const Geom& g, int64_t 
   {
     ProfScope ps(h, SG_STAGE_STFT_MAX, st);
     // (float64 transform of the ORIGINAL samples when `v` is a float32 copy)
-    HIPCHK(h, launch_bits<0>(h->N, v_exact ? *v_exact : v, g, ub, h->tw64.p, h->wfull64.p, tc, h->mag_scale, h->p.top_db,
+    HIPCHK(h, launch_bits_any<0>(h, v_exact ? *v_exact : v, g, ub, tc,
                              (unsigned long long*)h->pmax.p, (unsigned long long*)h->bits.p, wpr, st));
   }
   *tc_out = tc;
@@ -1924,7 +2049,7 @@ static int stage_fused_mask(sg_handle* h, const View& v, const Geom& g, int64_t 
     HIPCHK(h, launch_decide_lds(h, v, g, ub, tc, (unsigned long long*)h->bits.p, wpr, st));
   } else {
     ProfScope ps(h, SG_STAGE_STFT_BITS, st);
-    HIPCHK(h, launch_bits<1>(h->N, v, g, ub, h->tw64.p, h->wfull64.p, tc, h->mag_scale, h->p.top_db,
+    HIPCHK(h, launch_bits_any<1>(h, v, g, ub, tc,
                              (unsigned long long*)h->pmax.p, (unsigned long long*)h->bits.p, wpr, st));
   }
   { int rc2 = stage_smooth_bits(h, g, ub, fast, tb, te, st); if (rc2) return rc2; }
@@ -2265,7 +2390,7 @@ static int stage_onepass(sg_handle* h, const View& v, const View& vx, const Geom
     // when no unit reported (the common case)
     ProfScope ps(h, SG_STAGE_STFT_MAX, st);
     const int wpr = (g.F + 63) / 64;
-    HIPCHK(h, launch_bits<0>(h->N, vx, g, ub, h->tw64.p, h->wfull64.p, tc, h->mag_scale, h->p.top_db,
+    HIPCHK(h, launch_bits_any<0>(h, vx, g, ub, tc,
                              (unsigned long long*)h->pmax.p, (unsigned long long*)h->bits.p, wpr, st));
     if ((rc = handoff_next_epoch(h, st))) return rc;
     P.epoch = h->epoch;
