@@ -149,6 +149,7 @@ struct sg_handle {
   int czt_M = 0;                     // > 0: n_fft is not a power of two -> chirp-z kernels (czt.hpp) of size M
   bool mr_ok = false;                // n_fft even, n_fft / 2 <= 2048 with prime factors <= 13, not a power of two: the float32 and
   MrPlan mr{};                       // float64 STFT / decision / apply kernels of mixed.hpp (run-time radix schedule) instead of chirp-z
+  DevBuf mr_pt32, mr_pt64;           // the plan's per-pass twiddle tables (mr_pass_tables)
   DevBuf czt_tw64, czt_ch64, czt_bh64, czt_tw32, czt_ch32, czt_bh32;
   bool force_noseam = false;
   bool force_nolean = false;         // SG_OPT_FORCE_NOLEAN: full-size slices + stored frames (2 waves/SIMD)
@@ -510,104 +511,30 @@ static hipError_t launch_apply(int N, const View& v, const Geom& g, int64_t unit
 // ------------------------------------------------------------------------------------------
 // mixed-radix kernels (mixed.hpp): frame lengths 2 N with N = 2^a 3^b 5^c 7^d 11^e 13^f <= 2048 that are not powers of two
 // ------------------------------------------------------------------------------------------
-static bool mr_make_plan(int N, MrPlan* pl) {
-  if (N < 2 || N > 2048) return false;
-  pl->N = N;
-  pl->np = 0;
-  int r = N;
-  auto take = [&](int R) {
-    while (r % R == 0 && pl->np < MR_MAXP) { pl->R[pl->np++] = (unsigned char)R; r /= R; }
-  };
-  take(8); take(4); take(2); take(5); take(3); take(7); take(11); take(13);
-  return r == 1;
-}
-// threads per frame / frames in flight per workgroup: one wavefront per frame while a frame's two ping-pong buffers stay small,
-// the whole workgroup on one frame beyond (MR_MAXM sweeps of NT bins must cover N + 1 bins)
-static void mr_shape(int N, size_t cx_bytes, int* NT, int* teams) {
-  (void)cx_bytes;
-  const bool wide = N > 512;
-  *NT = wide ? 256 : 64;
-  *teams = wide ? 1 : 4;
-}
 template <typename TC>
 static hipError_t launch_stft_mr(const sg_handle* h, const View& v, const Geom& g, int64_t units, const void* wfull, double* P,
                                  float* mag, double* z, double zscale, hipStream_t st, unsigned long long* pmax_bits) {
-  const int N = h->mr.N;
-  int NT, teams;
-  mr_shape(N, sizeof(cx<TC>), &NT, &teams);
-  const size_t lds = (size_t)(N + 2 * teams * lpn<TC>(N)) * sizeof(cx<TC>);
-  const void* tw = sizeof(TC) == 8 ? h->tw64.p : h->tw32.p;
-  // few units (the noise clip): one frame per team so that the grid still covers the chip
-  const int fpw = units * ((g.T + teams * 4 - 1) / (teams * 4)) < 1024 ? 1 : 4;
-  auto go = [&](auto kern) -> hipError_t {
-    if (lds > 65536) {
-      hipError_t e = set_lds(reinterpret_cast<const void*>(kern), lds);
-      if (e != hipSuccess) return e;
-    }
-    dim3 grid((unsigned)((g.T + teams * fpw - 1) / (teams * fpw)), (unsigned)units);
-    hipLaunchKernelGGL(kern, grid, dim3(teams * NT), lds, st, v, g, h->mr, (const cx<TC>*)tw, (const TC*)wfull, P, mag, z,
-                       zscale, pmax_bits, fpw);
-    return hipGetLastError();
-  };
-  return NT == 64 ? go(k_stft_mr<TC, 64>) : go(k_stft_mr<TC, 256>);
+  if constexpr (sizeof(TC) == 8)
+    return mr_launch_stft64(h->mr, v, g, units, (const cx<double>*)h->tw64.p, (const cx<double>*)h->mr_pt64.p, (const double*)wfull, P, mag, z, zscale,
+                            pmax_bits, st);
+  else
+    return mr_launch_stft32(h->mr, v, g, units, (const cx<float>*)h->tw32.p, (const cx<float>*)h->mr_pt32.p, (const float*)wfull, P, mag, z, zscale,
+                            pmax_bits, st);
 }
 template <int MODE>
 static hipError_t launch_bits_mr(const sg_handle* h, const View& v, const Geom& g, int64_t units, const ThreshConsts& tc,
                                  unsigned long long* pmax_bits, unsigned long long* bits, int wpr, hipStream_t st) {
-  const int N = h->mr.N;
-  int NT, teams;
-  mr_shape(N, sizeof(cx<double>), &NT, &teams);
-  const size_t lds = (size_t)(N + 2 * teams * lpn<double>(N)) * sizeof(cx<double>) + (size_t)(N + 1) * sizeof(double);
-  const int fpw = 4;
-  auto go = [&](auto kern) -> hipError_t {
-    if (lds > 65536) {
-      hipError_t e = set_lds(reinterpret_cast<const void*>(kern), lds);
-      if (e != hipSuccess) return e;
-    }
-    dim3 grid((unsigned)((g.T + teams * fpw - 1) / (teams * fpw)), (unsigned)units);
-    hipLaunchKernelGGL(kern, grid, dim3(teams * NT), lds, st, v, g, h->mr, (const cx<double>*)h->tw64.p,
-                       (const double*)h->wfull64.p, tc, h->mag_scale, h->p.top_db, pmax_bits, bits, wpr, fpw);
-    return hipGetLastError();
-  };
-  return NT == 64 ? go(k_stft_bits_mr<MODE, 64>) : go(k_stft_bits_mr<MODE, 256>);
+  return mr_launch_bits(MODE, h->mr, v, g, units, (const cx<double>*)h->tw64.p, (const cx<double>*)h->mr_pt64.p, (const double*)h->wfull64.p, tc, h->mag_scale,
+                        h->p.top_db, pmax_bits, bits, wpr, st);
 }
 static hipError_t launch_decide_mr(const sg_handle* h, const View& v, const Geom& g, int64_t units, const ThreshConsts& tc,
                                    unsigned long long* bits, int wpr, hipStream_t st) {
-  const int N = h->mr.N;
-  int NT, teams;
-  mr_shape(N, sizeof(cx<float>), &NT, &teams);
-  const size_t lds = (size_t)(N + 2 * teams * N) * sizeof(cx<float>) + (size_t)(N + 1 + 4) * sizeof(float);
-  const int fpw = 4;
-  auto go = [&](auto kern) -> hipError_t {
-    if (lds > 65536) {
-      hipError_t e = set_lds(reinterpret_cast<const void*>(kern), lds);
-      if (e != hipSuccess) return e;
-    }
-    dim3 grid((unsigned)((g.T + teams * fpw - 1) / (teams * fpw)), (unsigned)units);
-    hipLaunchKernelGGL(kern, grid, dim3(teams * NT), lds, st, v, g, h->mr, (const cx<float>*)h->tw32.p, (const float*)h->wa32.p,
-                       (const cx<double>*)h->tw64.p, (const double*)h->wfull64.p, tc, h->mag_scale, h->p.top_db, bits, wpr, fpw);
-    return hipGetLastError();
-  };
-  return NT == 64 ? go(k_decide_mr<64>) : go(k_decide_mr<256>);
+  return mr_launch_decide(h->mr, v, g, units, (const cx<float>*)h->tw32.p, (const cx<float>*)h->mr_pt32.p, (const float*)h->wa32.p, (const cx<double>*)h->tw64.p,
+                          (const double*)h->wfull64.p, tc, h->mag_scale, h->p.top_db, bits, wpr, st);
 }
 static hipError_t launch_apply_mr(const sg_handle* h, const View& v, const Geom& g, int64_t units, const float* wa, const float* ws,
                                   const float* M, float* seg, hipStream_t st, const unsigned short* K16, float kscale) {
-  const int N = h->mr.N;
-  int NT, teams;
-  mr_shape(N, sizeof(cx<float>), &NT, &teams);
-  const size_t lds = (size_t)(N + 2 * teams * N) * sizeof(cx<float>);
-  const int fpw = 4;
-  auto go = [&](auto kern) -> hipError_t {
-    if (lds > 65536) {
-      hipError_t e = set_lds(reinterpret_cast<const void*>(kern), lds);
-      if (e != hipSuccess) return e;
-    }
-    dim3 grid((unsigned)((g.T + teams * fpw - 1) / (teams * fpw)), (unsigned)units);
-    hipLaunchKernelGGL(kern, grid, dim3(teams * NT), lds, st, v, g, h->mr, (const cx<float>*)h->tw32.p, wa, ws, M, seg, K16,
-                       kscale, fpw);
-    return hipGetLastError();
-  };
-  return NT == 64 ? go(k_apply_istft_mr<64>) : go(k_apply_istft_mr<256>);
+  return mr_launch_apply(h->mr, v, g, units, (const cx<float>*)h->tw32.p, (const cx<float>*)h->mr_pt32.p, wa, ws, M, seg, K16, kscale, st);
 }
 template <int MODE>
 static hipError_t launch_bits(int N, const View& v, const Geom& g, int64_t units, const void* tw, const void* wfull,
@@ -1121,6 +1048,13 @@ extern "C" int sg_create(const sg_params* p, const double* window_host, sg_handl
   }
   int rc = SG_OK;
   if (!rc) rc = upload(h, h->tw64, tw64.data(), tw64.size() * sizeof(cx<double>));
+  if (!rc && h->mr_ok) {
+    std::vector<double> pt((size_t)std::max(1, h->mr.ptotal) * 2, 0.0);
+    mr_pass_tables(h->mr, pt.data());
+    std::vector<float> pt32(pt.begin(), pt.end());
+    rc = upload(h, h->mr_pt64, pt.data(), pt.size() * sizeof(double));
+    if (!rc) rc = upload(h, h->mr_pt32, pt32.data(), pt32.size() * sizeof(float));
+  }
   {
     // db_fast: centre c_i = 1 + (i + 1/2) / 128 of the i-th mantissa slice; the logarithm is that of the ROUNDED
     // reciprocal, so that log2(m) = -log2(t_i) + log2(1 + (m t_i - 1)) holds exactly
@@ -1299,7 +1233,7 @@ extern "C" int sg_destroy(sg_handle* h) {
                     &h->need, &h->T2, &h->part, &h->tw512, &h->invn, &h->seam, &h->ftab, &h->xbits, &h->xpart,
                     &h->xticket, &h->xtick2, &h->ftab3, &h->xexp, &h->optab, &h->nsp, &h->nsc, &h->xin, &h->czt_tw64, &h->czt_ch64,
                     &h->czt_bh64, &h->czt_tw32, &h->czt_ch32, &h->czt_bh32, &h->logtab, &h->big_twM, &h->big_tw2,
-                    &h->big_ch, &h->big_bh, &h->big_W, &h->big_W2, &h->xP, &h->xraw, &h->xM, &h->xtmp, &h->xseg, &h->invn5, &h->invn25, &h->invn20, &h->rg_count, &h->alim, &h->nss})
+                    &h->big_ch, &h->big_bh, &h->big_W, &h->big_W2, &h->xP, &h->xraw, &h->xM, &h->xtmp, &h->xseg, &h->invn5, &h->invn25, &h->invn20, &h->rg_count, &h->alim, &h->nss, &h->mr_pt32, &h->mr_pt64})
     free_buf(*b);
   delete h;
   return SG_OK;

@@ -15,45 +15,9 @@
 // are skewed by 128 B so that every ds_write_b64 / ds_read_b128 is bank-conflict free.
 #pragma once
 #include "kernels.hpp"
+#include "thresh.hpp"
 
 namespace sg {
-
-struct ThreshConsts {
-  // all device pointers
-  const double* T2;        // [F]  compare constant on the RAW power |X|^2 (see k_prep_thresh)
-  const double* thresh;    // [F]  dB threshold (for the floor test)
-  const double* pmax;      // [units][FS] per-(unit, band) max raw power, 0 where not computed
-  const int* need_floor;   // [units] 1: this unit's -top_db floor may be live -> pmax is valid;
-                           //         2: the unit holds a non-finite sample -> no cell of it passes (T2_NEVER)
-  // need_tag != 0 (one-pass gate, in-kernel floor test): the words are TAGGED, (tag << 2) | flags, raised with atomicMax
-  // by the gate's tiles (2 beats 1) -- a word with another tag is a leftover of an earlier call and reads as 0, so
-  // nobody has to clear the array between calls
-  unsigned need_tag = 0;
-};
-// The one-pass gate's floor test reads its bound on max|x| as OP_ALIM_BLOCKS bit patterns (one per 64-band block of the
-// noise statistics' final kernel, which derives them without a cross-block reduction) and takes their minimum:
-// alim[2 .. 2 + OP_ALIM_BLOCKS); alim[1] is the tag of the last call in which a unit reported.
-constexpr int OP_ALIM_BLOCKS = 9;
-__device__ __forceinline__ int need_of(const ThreshConsts& tc, int64_t u) {
-  const unsigned w = (unsigned)tc.need_floor[u];
-  if (tc.need_tag == 0u) return (int)w;
-  return (w >> 2) == tc.need_tag ? (int)(w & 3u) : 0;
-}
-
-// Compare constant meaning "no cell passes".  A band with a NaN threshold (NaN in the noise clip: stationary.py:75-81
-// give mean(NaN) = NaN, and `dB > NaN` is False) and every band of a unit with a non-finite sample (np.max over a
-// band that holds a NaN is NaN: _amp_to_db makes the whole band NaN, stationary.py:96-106) gate everything.
-constexpr double T2_NEVER = 1e300;
-// LDS layout of the float32 compare constants of the decision stages: lane c's 32 entries start at c * 36 floats (a
-// pitch of 32 puts the lanes of equal parity on the same banks: every read was an 8-way conflict -- 45 % of the LDS
-// cycles of k_gate_onepass); 36 keeps 16-byte alignment and spreads the 16 lanes over all 64 banks.
-constexpr int T2_PITCH = 36, T2_POS512 = 16 * T2_PITCH, T2_FLOATS = 592;
-__host__ __device__ constexpr int t2_pos(int i) { return i >= 512 ? T2_POS512 : (i >> 5) * T2_PITCH + (i & 31); }
-// float32 copy of a (4x) compare constant for the float32 decision kernels: -1 ("all pass") and T2_NEVER map to
-// huge finite values of either sign -- P - T overflows when squared, so the ambiguity test fails by itself
-__device__ __forceinline__ float t2_to_f32(double v, double scale) {
-  return v < 0.0 ? -3.0e38f : (v > 1e37 ? 3.0e38f : (float)(scale * v));
-}
 
 // (round 5) The float32 compare constants of a decision kernel into LDS, COUNT bands by NTHR threads.  The common unit (no
 // live floor, no non-finite sample: need == 0) takes its constants straight from T2: every load of a thread is issued before

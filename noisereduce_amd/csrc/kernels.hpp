@@ -16,46 +16,8 @@
 
 namespace sg {
 
-__device__ __forceinline__ double load_sample(const void* p, int dtype, int64_t idx) {
-  switch (dtype) {
-    case 0: return (double)((const float*)p)[idx];
-    case 1: return ((const double*)p)[idx];
-    case 2: return (double)((const int16_t*)p)[idx];
-    default: return (double)((const int32_t*)p)[idx];
-  }
-}
-
-__device__ __forceinline__ double view_sample(const View& v, int64_t row, int64_t chunk, int64_t s) {
-  if (s < 0 || s >= v.Lp) return 0.0;
-  int64_t g = chunk * v.cs - v.pad + s;
-  if (g < v.lo || g >= v.hi) return 0.0;
-  return load_sample(v.x, v.dtype, row * v.stride + g);
-}
-
-// Maximum that KEEPS a NaN (numpy / torch maxima do; fmax drops it): a band that holds a NaN has a NaN maximum, and
-// the reference's `max(dB, rowmax - top_db) > thresh` is then False for the whole band.  The canonical positive NaN also
-// wins the bit-pattern atomicMax of the per-band maxima.
-__device__ __forceinline__ double nanmax(double a, double b) { return (a != a || b != b) ? (double)NAN : fmax(a, b); }
-
-// Start of the `len` samples [s0, s0 + len) of a unit window when they are all readable float32
-// samples (no zero padding, no conversion), else nullptr: frames take the direct-load path in the
-// interior and the checked per-sample path (view_sample) at the edges / for other dtypes.
-__device__ __forceinline__ const float* frame_ptr_f32(const View& v, int64_t row, int64_t chunk, int64_t s0,
-                                                      int64_t len) {
-  if (v.dtype != 0 || s0 < 0 || s0 + len > v.Lp) return nullptr;
-  const int64_t g = chunk * v.cs - v.pad + s0;
-  if (g < v.lo || g + len > v.hi) return nullptr;
-  return (const float*)v.x + row * v.stride + g;
-}
-
-__device__ __forceinline__ void store_sample(void* p, int dtype, int64_t idx, float val) {
-  switch (dtype) {
-    case 0: ((float*)p)[idx] = val; break;
-    case 1: ((double*)p)[idx] = (double)val; break;
-    case 2: ((int16_t*)p)[idx] = (int16_t)val; break;  // truncation, like ndarray.astype
-    default: ((int32_t*)p)[idx] = (int32_t)val; break;
-  }
-}
+// (load_sample, view_sample, nanmax, frame_ptr_f32, store_sample, cell_db: geom.hpp -- shared with the translation units that
+// hold kernel templates only)
 
 // The readable part [lo, hi) of every row as float32 -- what every float32 transform kernel makes of a sample
 // anyway ((float)sample): non-float32 recordings are converted ONCE instead of per frame and kernel on the
@@ -314,12 +276,6 @@ __global__ void k_env_scale(const void* __restrict__ gsrc, int dtype, int64_t st
 // Per-band statistics over time (lanes = bins).  block = 64 bins x TG time groups.
 // ---------------------------------------------------------------------------------------
 constexpr int STAT_TG = 4;
-
-// dB of one cell exactly as the reference writes it: 20*log10(|Z| + eps)
-// (spectralgate/utils.py:15; torchgate/utils.py:22), |Z| = sqrt(P) * mag_scale.
-__device__ __forceinline__ double cell_db(double P, double mag_scale) {
-  return 20.0 * log10(sqrt(P) * mag_scale + 2.220446049250313e-16);
-}
 
 // cell_db without the library logarithm and square root, for kernels whose time IS those two (k_row_decide: 8 M cells
 // x ~110 float64 operations).  With y = sqrt(P) s:  20 log10(y + eps) = 10 log10(2) log2(P) + 20 log10(s) +

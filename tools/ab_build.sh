@@ -7,5 +7,5 @@ cd "$(dirname "$0")/.."
 TAG=$1; shift
 mkdir -p noisereduce_amd/_ab
 cd noisereduce_amd/csrc && /opt/rocm/bin/hipcc --offload-arch=gfx950 -O3 -std=c++17 -fPIC -shared -fvisibility=hidden \
-  -Wl,--version-script=exports.map api.hip nonstat_mask.hip -o ../_ab/lib_$TAG.so -fno-slp-vectorize "$@" 2>/dev/null
+  -Wl,--version-script=exports.map api.hip nonstat_mask.hip mixed.hip -o ../_ab/lib_$TAG.so -fno-slp-vectorize "$@" 2>/dev/null
 ls -la ../_ab/lib_$TAG.so
