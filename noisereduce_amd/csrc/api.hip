@@ -1365,9 +1365,9 @@ static int stage_stats(sg_handle* h, const View& v, const Geom& g, int64_t ub, d
     // (for the stationary gate's noise statistics the final kernel also derives the gate's compare constants: no
     // k_prep_thresh_lazy launch in the calls that follow)
     GateConsts gc{};
-    if (gate_consts && ub == 1 && grid.x == OP_ALIM_BLOCKS) {
+    if (gate_consts && ub == 1 && grid.x <= 62) {   // (one bound per 64-band block: 9 at n_fft = 1024, 33 at 4096)
       if ((rc = ensure(h, h->T2, (size_t)g.FS * 8))) return rc;
-      if ((rc = ensure_zeroed(h, h->alim, 64, st))) return rc;
+      if ((rc = ensure_zeroed(h, h->alim, 256, st))) return rc;
       gc.T2 = (double*)h->T2.p; gc.alim_b = (unsigned*)h->alim.p + 2; gc.sum_abs_w = h->sum_abs_w;
     }
     hipLaunchKernelGGL(k_colstats1_final, dim3((unsigned)((g.FS + 63) / 64), (unsigned)ub), dim3(64 * STAT_TG), 0, st,
@@ -1410,15 +1410,20 @@ static fast::Fast5Args fast5_args(const sg_handle* h, const View& v, const Geom&
 constexpr size_t FAST5_LDS = (size_t)(fast::FN + 4 * fast::WAVE_CX_H) * sizeof(fast::cf) + (512 + 264) * sizeof(float);
 
 static int stage_decide512(sg_handle* h, const View& v, const Geom& g, int64_t ub, const ThreshConsts& tc,
-                           unsigned long long* bits, hipStream_t st) {
-  ProfScope ps(h, SG_STAGE_DECIDE_FAST, st);
+                           unsigned long long* bits, hipStream_t st, const FloorLazy& fl = FloorLazy{}, bool redo = false) {
+  ProfScope ps(h, redo ? SG_STAGE_STFT_MAX : SG_STAGE_DECIDE_FAST, st);   // (the early-exit second launch is booked with the pre-pass)
   fast::Fast5Args A = fast5_args(h, v, g);
   A.tc = tc;
   A.bits = bits;
-  auto kern = fast::k_decide_fast512<4>;
-  HIPCHK(h, set_lds(reinterpret_cast<const void*>(kern), FAST5_LDS));
-  hipLaunchKernelGGL(kern, dim3((unsigned)((g.T + 31) / 32), (unsigned)ub), dim3(256), FAST5_LDS, st, A);
-  HIPCHK(h, hipGetLastError());
+  A.fl = fl;
+  auto go = [&](auto kern) -> hipError_t {
+    hipError_t e = set_lds(reinterpret_cast<const void*>(kern), FAST5_LDS);
+    if (e != hipSuccess) return e;
+    hipLaunchKernelGGL(kern, dim3((unsigned)((g.T + 31) / 32), (unsigned)ub), dim3(256), FAST5_LDS, st, A);
+    return hipGetLastError();
+  };
+  if (redo) HIPCHK(h, go(fast::k_decide_fast512<4, true>));
+  else HIPCHK(h, go(fast::k_decide_fast512<4, false>));
   return SG_OK;
 }
 
@@ -1479,15 +1484,20 @@ static fast::Fast25Args fast25_args(const sg_handle* h, const View& v, const Geo
 constexpr size_t FAST25_LDS = (size_t)(fast::FN + 4 * fast::WAVE_CX_H) * sizeof(fast::cf) + (256 + fast::F25_T2) * sizeof(float);
 
 static int stage_decide256(sg_handle* h, const View& v, const Geom& g, int64_t ub, const ThreshConsts& tc,
-                           unsigned long long* bits, hipStream_t st) {
-  ProfScope ps(h, SG_STAGE_DECIDE_FAST, st);
+                           unsigned long long* bits, hipStream_t st, const FloorLazy& fl = FloorLazy{}, bool redo = false) {
+  ProfScope ps(h, redo ? SG_STAGE_STFT_MAX : SG_STAGE_DECIDE_FAST, st);
   fast::Fast25Args A = fast25_args(h, v, g);
   A.tc = tc;
   A.bits = bits;
-  auto kern = fast::k_decide_fast256<4>;
-  HIPCHK(h, set_lds(reinterpret_cast<const void*>(kern), FAST25_LDS));
-  hipLaunchKernelGGL(kern, dim3((unsigned)((g.T + 63) / 64), (unsigned)ub), dim3(256), FAST25_LDS, st, A);
-  HIPCHK(h, hipGetLastError());
+  A.fl = fl;
+  auto go = [&](auto kern) -> hipError_t {
+    hipError_t e = set_lds(reinterpret_cast<const void*>(kern), FAST25_LDS);
+    if (e != hipSuccess) return e;
+    hipLaunchKernelGGL(kern, dim3((unsigned)((g.T + 63) / 64), (unsigned)ub), dim3(256), FAST25_LDS, st, A);
+    return hipGetLastError();
+  };
+  if (redo) HIPCHK(h, go(fast::k_decide_fast256<4, true>));
+  else HIPCHK(h, go(fast::k_decide_fast256<4, false>));
   return SG_OK;
 }
 
@@ -1548,15 +1558,20 @@ static fast::Fast20Args fast20_args(const sg_handle* h, const View& v, const Geo
 constexpr size_t FAST20_LDS = (size_t)(1024 + 4 * fast::WAVE_CX_H) * sizeof(fast::cf) + 1028 * sizeof(float);
 
 static int stage_decide2048(sg_handle* h, const View& v, const Geom& g, int64_t ub, const ThreshConsts& tc,
-                            unsigned long long* bits, hipStream_t st) {
-  ProfScope ps(h, SG_STAGE_DECIDE_FAST, st);
+                            unsigned long long* bits, hipStream_t st, const FloorLazy& fl = FloorLazy{}, bool redo = false) {
+  ProfScope ps(h, redo ? SG_STAGE_STFT_MAX : SG_STAGE_DECIDE_FAST, st);
   fast::Fast20Args A = fast20_args(h, v, g);
   A.tc = tc;
   A.bits = bits;
-  auto kern = fast::k_decide_fast2048<4>;
-  HIPCHK(h, set_lds(reinterpret_cast<const void*>(kern), FAST20_LDS));
-  hipLaunchKernelGGL(kern, dim3((unsigned)((g.T + 7) / 8), (unsigned)ub), dim3(256), FAST20_LDS, st, A);
-  HIPCHK(h, hipGetLastError());
+  A.fl = fl;
+  auto go = [&](auto kern) -> hipError_t {
+    hipError_t e = set_lds(reinterpret_cast<const void*>(kern), FAST20_LDS);
+    if (e != hipSuccess) return e;
+    hipLaunchKernelGGL(kern, dim3((unsigned)((g.T + 7) / 8), (unsigned)ub), dim3(256), FAST20_LDS, st, A);
+    return hipGetLastError();
+  };
+  if (redo) HIPCHK(h, go(fast::k_decide_fast2048<4, true>));
+  else HIPCHK(h, go(fast::k_decide_fast2048<4, false>));
   return SG_OK;
 }
 
@@ -1928,6 +1943,7 @@ static int stage_prep_floor(sg_handle* h, const View& v, const Geom& g, int64_t 
   return SG_OK;
 }
 
+static int handoff_prepare(sg_handle* h, hipStream_t st);
 // Fused stationary mask (variant S): STFT(f64) -> bits -> integer smoothing -> K16 -> float mask.
 static int stage_fused_mask(sg_handle* h, const View& v, const Geom& g, int64_t ub, bool fast, int64_t tb,
                             int64_t te, hipStream_t st) {
@@ -1941,7 +1957,45 @@ static int stage_fused_mask(sg_handle* h, const View& v, const Geom& g, int64_t 
   int rc;
   if ((rc = ensure(h, h->K16, (size_t)ub * g.T * g.FS * 2))) return rc;
   ThreshConsts tc{};
-  if ((rc = stage_prep_floor(h, v, g, ub, &tc, st))) return rc;
+  // (round 6) The register-transform decision kernels of n_fft = 512 / 256 / 2048 stage every sample of a unit's window: they
+  // run the floor test themselves (thresh.hpp: FloorLazy -- the one-pass gate's protocol) instead of k_unit_absmax +
+  // k_prep_thresh reading the recording once more before the gate.  Same prediction as stage_onepass: a priori when a recent
+  // call on the handle reported (SG_OPT_FLOOR_TEST forces either); both end in exact band maxima.
+  const bool reg_path = !fast && !h->force_f64_decide && !h->force_nofast && (h->fast20_ok || h->fast25_ok || h->fast5_ok);
+  bool lazy = false;
+  FloorLazy fl{};
+  if (reg_path && h->floor_test != 1) {
+    if ((rc = handoff_prepare(h, st))) return rc;     // (a fresh epoch = the tag of this call's flags; the host-mapped stamp)
+    const unsigned live_stamp = h->err_host[1];
+    const unsigned need_tag = h->epoch & 0x3fffffffu;
+    const unsigned era = h->epoch >> 30;
+    if (era != h->need_era || need_tag == 0u) {   // (tags wrapped: flags of the previous era carry larger ones)
+      if (h->need.p) HIPCHK(h, hipMemsetAsync(h->need.p, 0, h->need.bytes, st));
+      if (h->alim.p) HIPCHK(h, hipMemsetAsync((char*)h->alim.p + 4, 0, 4, st));
+      h->need_era = era;
+    }
+    lazy = need_tag != 0u && (h->floor_test == 2 || !(live_stamp != 0u && h->epoch - live_stamp <= 16u));
+    if (lazy) {
+      const int nb = (g.FS + 63) / 64;
+      if ((rc = ensure(h, h->bits, (size_t)ub * g.T * wpr * 8))) return rc;
+      if ((rc = ensure_zeroed(h, h->need, (size_t)ub * 4, st))) return rc;
+      if ((rc = ensure(h, h->T2, (size_t)g.FS * 8))) return rc;
+      if ((rc = ensure_zeroed(h, h->alim, 256, st))) return rc;
+      if (!h->t2_ready) {   // the threshold did not come from sg_noise_stats (whose last kernel derives T2 / alim itself)
+        ProfScope ps(h, SG_STAGE_PREP, st);
+        hipLaunchKernelGGL(k_prep_thresh_lazy, dim3(1), dim3(256), 0, st, (const double*)h->thresh.p, g.F, h->mag_scale,
+                           h->sum_abs_w, h->p.top_db, (double*)h->T2.p, (unsigned*)h->alim.p, nb);
+        HIPCHK(h, hipGetLastError());
+        h->t2_ready = true;
+      }
+      tc = ThreshConsts{(const double*)h->T2.p, (const double*)h->thresh.p, (const double*)h->pmax.p, (const int*)h->need.p,
+                        need_tag};
+      fl = FloorLazy{(unsigned*)h->alim.p, nb, h->err_dev + 1, h->epoch};
+    }
+  }
+  if (reg_path) ++(lazy ? h->n_floor_lazy : h->n_floor_apriori);
+  if (!lazy && (rc = stage_prep_floor(h, v, g, ub, &tc, st, nullptr, reg_path && h->err_dev ? h->err_dev + 1 : nullptr, h->epoch)))
+    return rc;
   if (fast && !h->force_f64_decide) {
     ProfScope ps(h, SG_STAGE_DECIDE_FAST, st);
     constexpr int WAVES = 4;
@@ -1967,15 +2021,15 @@ static int stage_fused_mask(sg_handle* h, const View& v, const Geom& g, int64_t 
     hipLaunchKernelGGL(kern, grid, dim3(WAVES * 64), lds, st, D);
     HIPCHK(h, hipGetLastError());
   } else if (!h->force_f64_decide && h->fast20_ok && !h->force_nofast) {
-    int rc20 = stage_decide2048(h, v, g, ub, tc, (unsigned long long*)h->bits.p, st);
+    int rc20 = stage_decide2048(h, v, g, ub, tc, (unsigned long long*)h->bits.p, st, fl);
     if (rc20) return rc20;
   } else if (!h->force_f64_decide && h->fast25_ok && !h->force_nofast) {
     // n_fft = 256: register transform, four frames per lane group
-    int rc25 = stage_decide256(h, v, g, ub, tc, (unsigned long long*)h->bits.p, st);
+    int rc25 = stage_decide256(h, v, g, ub, tc, (unsigned long long*)h->bits.p, st, fl);
     if (rc25) return rc25;
   } else if (!h->force_f64_decide && h->fast5_ok && !h->force_nofast) {
     // n_fft = 512: register transform, two frames per lane group
-    int rc5 = stage_decide512(h, v, g, ub, tc, (unsigned long long*)h->bits.p, st);
+    int rc5 = stage_decide512(h, v, g, ub, tc, (unsigned long long*)h->bits.p, st, fl);
     if (rc5) return rc5;
   } else if (!h->force_f64_decide) {
     // other power-of-two frame lengths: float32 LDS transform + exact refinement
@@ -1985,6 +2039,18 @@ static int stage_fused_mask(sg_handle* h, const View& v, const Geom& g, int64_t 
     ProfScope ps(h, SG_STAGE_STFT_BITS, st);
     HIPCHK(h, launch_bits_any<1>(h, v, g, ub, tc,
                              (unsigned long long*)h->pmax.p, (unsigned long long*)h->bits.p, wpr, st));
+  }
+  if (lazy) {
+    // the units whose floor test fired: float64 band maxima, then their decisions again with them.  Both launches return at
+    // once when no unit reported (the common case)
+    {
+      ProfScope ps(h, SG_STAGE_STFT_MAX, st);
+      HIPCHK(h, launch_bits_any<0>(h, v, g, ub, tc, (unsigned long long*)h->pmax.p, (unsigned long long*)h->bits.p, wpr, st));
+    }
+    int rcr = h->fast20_ok ? stage_decide2048(h, v, g, ub, tc, (unsigned long long*)h->bits.p, st, fl, true)
+              : h->fast25_ok ? stage_decide256(h, v, g, ub, tc, (unsigned long long*)h->bits.p, st, fl, true)
+                             : stage_decide512(h, v, g, ub, tc, (unsigned long long*)h->bits.p, st, fl, true);
+    if (rcr) return rcr;
   }
   { int rc2 = stage_smooth_bits(h, g, ub, fast, tb, te, st); if (rc2) return rc2; }
   const int nf = h->p.n_grad_freq, nt = h->p.n_grad_time;
@@ -2193,7 +2259,7 @@ static int stage_onepass(sg_handle* h, const View& v, const View& vx, const Geom
     if ((rc = ensure(h, h->bits, (size_t)ub * g.T * wpr * 8))) return rc;
     if ((rc = ensure_zeroed(h, h->need, (size_t)ub * 4, st))) return rc;
     if ((rc = ensure(h, h->T2, (size_t)g.FS * 8))) return rc;
-    if ((rc = ensure_zeroed(h, h->alim, 64, st))) return rc;
+    if ((rc = ensure_zeroed(h, h->alim, 256, st))) return rc;
     if (!h->t2_ready) {
       // the threshold did not come from sg_noise_stats (whose last kernel derives T2 / alim itself): one small launch
       ProfScope ps(h, SG_STAGE_PREP, st);
@@ -2879,7 +2945,7 @@ extern "C" int sg_noise_stats(sg_handle* h, const void* noise_dev, int dtype, in
   Geom g = make_geom(h, n);
   if ((rc = ensure_ws(h, g, 1))) return rc;
   h->t2_ready = false;
-  if ((rc = stage_stats(h, v, g, 1, (double*)h->thresh.p, st, /*gate_consts=*/h->fast_ok))) return rc;
+  if ((rc = stage_stats(h, v, g, 1, (double*)h->thresh.p, st, /*gate_consts=*/h->fast_ok || h->fast5_ok || h->fast25_ok || h->fast20_ok))) return rc;
   h->has_thresh = true;
   return SG_OK;
 }

@@ -51,6 +51,7 @@ struct Fast20Args {
   int normalize;
   float* part;               // seam mode: [units][tiles][6][512] un-normalised partial hops (3 leading, 3 trailing), else nullptr
   int n_tiles;
+  FloorLazy fl;              // decide: in-kernel floor test (thresh.hpp), alim == nullptr: flags computed a priori
 };
 
 // w_1024^e from the w_2048 table
@@ -63,9 +64,10 @@ __device__ __forceinline__ cf f20_w1024(const cf* tw2048, int e) {
 
 // Stage the twiddle table T[k1][c] = w_1024^(k1 c) and the tile's sample span; gather v[r] = (x[2m], x[2m+1]) * w,
 // m = c + 32 r, of frame tf0 + 2 wave + g.
-template <int WAVES>
-__device__ __forceinline__ void f20_gather(const Fast20Args& A, cf* tw, cf* regions, int64_t row, int64_t chunk,
-                                           int64_t tf0, cf* v, bool& valid) {
+template <int WAVES, bool MX = false>
+__device__ __forceinline__ unsigned f20_gather(const Fast20Args& A, cf* tw, cf* regions, int64_t row, int64_t chunk,
+                                           int64_t tf0, cf* v, bool& valid) {   // returns (MX) the largest |sample| this thread staged, as a bit pattern
+  unsigned mx_ = 0u;
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, g = lane >> 5, c = lane & 31;
   constexpr int NF = 2 * WAVES, ROWS = NF - 1 + 4, SPAN = ROWS * F20_H;
   static_assert(ROWS * F20_XP * 4 <= WAVES * WAVE_CX_H * 8, "span must fit the exchange slices");
@@ -92,10 +94,16 @@ __device__ __forceinline__ void f20_gather(const Fast20Args& A, cf* tw, cf* regi
                    gb >= A.view.lo && gb + SPAN <= A.view.hi && (reinterpret_cast<uintptr_t>(sp) & 15) == 0;
   float* xs = reinterpret_cast<float*>(regions);
   if (vec) {
-    stage_span_vec<WAVES * 64, SPAN, F20_XP, 512>(xs, sp, tid);
+    const unsigned m = stage_span_vec<WAVES * 64, SPAN, F20_XP, 512, MX>(xs, sp, tid);
+    if constexpr (MX) mx_ = m;
   } else {
-    for (int i = tid; i < SPAN; i += WAVES * 64)
-      xs[(i >> 9) * F20_XP + (i & 511)] = (float)view_sample(A.view, row, chunk, s0b + i);
+    unsigned m = 0u;
+    for (int i = tid; i < SPAN; i += WAVES * 64) {
+      const float xv = (float)view_sample(A.view, row, chunk, s0b + i);
+      xs[(i >> 9) * F20_XP + (i & 511)] = xv;
+      m = max(m, __float_as_uint(xv) & 0x7fffffffu);
+    }
+    if constexpr (MX) mx_ = m;
   }
   __syncthreads();
   const int f = 2 * wave + g;
@@ -112,6 +120,7 @@ __device__ __forceinline__ void f20_gather(const Fast20Args& A, cf* tw, cf* regi
     v[r] = {x2.x * w2.x, x2.y * w2.y};
   }
   __syncthreads();
+  return mx_;
 }
 
 // forward: v[r] = z[c + 32 r]  ->  v[k2] = Zc[c + 32 k2]
@@ -198,8 +207,10 @@ __device__ __forceinline__ double f20_exact_power(const Fast20Args& A, int64_t r
 }
 
 // ---------------------------------------------------------------------------------------------------------------
-template <int WAVES>
+// REDO: the second launch of a call with the in-kernel floor test (thresh.hpp: FloorLazy): only the units whose test fired.
+template <int WAVES, bool REDO = false>
 __global__ __launch_bounds__(WAVES * 64, 3) void k_decide_fast2048(Fast20Args A) {
+  if (REDO && A.fl.alim[1] != A.tc.need_tag) return;   // no unit of this call reported (the common case)
   extern __shared__ __attribute__((aligned(16))) char smem[];
   cf* tw = reinterpret_cast<cf*>(smem);                 // [32][32] w_1024^(k1 c)
   cf* regions = tw + 1024;
@@ -209,7 +220,10 @@ __global__ __launch_bounds__(WAVES * 64, 3) void k_decide_fast2048(Fast20Args A)
   const int64_t u = blockIdx.y;
   const int64_t row = (A.view.unit0 + u) / A.view.n_chunks;
   const int64_t chunk = A.view.c0 + (A.view.unit0 + u) % A.view.n_chunks;
-  const int need = A.tc.need_floor[u];
+  const bool lazy = A.fl.alim != nullptr;
+  const int need = (lazy && !REDO) ? 0 : need_of(A.tc, u);
+  if (REDO && need == 0) return;   // whole workgroup
+  const unsigned fl_bound = REDO ? 0xffffffffu : floor_lazy_bound(A.fl, lane);
   const bool floor_live = need == 1;
   auto t2eff = [&](int f) -> double {
     double v = A.tc.T2[f];
@@ -225,7 +239,8 @@ __global__ __launch_bounds__(WAVES * 64, 3) void k_decide_fast2048(Fast20Args A)
   const int64_t tf0 = (int64_t)blockIdx.x * NF;
   cf v[32];
   bool valid;
-  f20_gather<WAVES>(A, tw, regions, row, chunk, tf0, v, valid);
+  const unsigned fl_mx = f20_gather<WAVES, true>(A, tw, regions, row, chunk, tf0, v, valid);
+  if (!REDO) floor_lazy_report(A.tc, A.fl, fl_bound, fl_mx, u, G.FS, lane);
   const int64_t tq = tf0 + 2 * wave;
   if (tq >= G.T) return;   // wave-uniform
   float nrm2 = 0.f;

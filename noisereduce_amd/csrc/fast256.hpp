@@ -57,6 +57,7 @@ struct Fast25Args {
   OutMap om;
   int64_t h_begin, h_end;    // apply: ext hops (64-sample blocks, ext = unit sample + padL) to produce
   int normalize;
+  FloorLazy fl;              // decide: in-kernel floor test (thresh.hpp), alim == nullptr: flags computed a priori
 };
 
 // second stage: two DFT8 per row (even columns = sequence 1, odd columns = sequence 2)
@@ -122,9 +123,10 @@ __device__ __forceinline__ void f25_inv_half(cf* v, cf* fb, const cf* tw512, int
 
 // stage tables + the tile's sample span, gather the lane's 32 complex points: v[r] = (x[m], y[m]) * w[m], m = cp + 8 r, of the
 // lane's frame pair X = tf0 + 16 wave + 4 g + 2 (c & 1), Y = X + 1.  Returns with the span consumed.
-template <int WAVES>
-__device__ __forceinline__ void f25_gather(const Fast25Args& A, cf* tw512, cf* regions, float* swin, int64_t row,
-                                           int64_t chunk, int64_t tf0, cf* v, bool& validX, bool& validY) {
+template <int WAVES, bool MX = false>
+__device__ __forceinline__ unsigned f25_gather(const Fast25Args& A, cf* tw512, cf* regions, float* swin, int64_t row,
+                                           int64_t chunk, int64_t tf0, cf* v, bool& validX, bool& validY) {   // returns (MX) the largest |sample| this thread staged, as a bit pattern
+  unsigned mx_ = 0u;
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, g = lane >> 4, c = lane & 15, cp = c >> 1;
   constexpr int NF = F25_FPW * WAVES, ROWS = NF - 1 + 4, SPAN = ROWS * F25_H;
   static_assert(ROWS * F25_XP * 4 <= WAVES * WAVE_CX_H * 8, "span must fit the exchange slices");
@@ -137,10 +139,16 @@ __device__ __forceinline__ void f25_gather(const Fast25Args& A, cf* tw512, cf* r
                    gb >= A.view.lo && gb + SPAN <= A.view.hi && (reinterpret_cast<uintptr_t>(sp) & 15) == 0;
   float* xs = reinterpret_cast<float*>(regions);
   if (vec) {
-    stage_span_vec<WAVES * 64, SPAN, F25_XP, 64>(xs, sp, tid);
+    const unsigned m = stage_span_vec<WAVES * 64, SPAN, F25_XP, 64, MX>(xs, sp, tid);
+    if constexpr (MX) mx_ = m;
   } else {
-    for (int i = tid; i < SPAN; i += WAVES * 64)
-      xs[(i >> 6) * F25_XP + (i & 63)] = (float)view_sample(A.view, row, chunk, s0b + i);
+    unsigned m = 0u;
+    for (int i = tid; i < SPAN; i += WAVES * 64) {
+      const float xv = (float)view_sample(A.view, row, chunk, s0b + i);
+      xs[(i >> 6) * F25_XP + (i & 63)] = xv;
+      m = max(m, __float_as_uint(xv) & 0x7fffffffu);
+    }
+    if constexpr (MX) mx_ = m;
   }
   __syncthreads();
   const int fx = F25_FPW * wave + 4 * g + 2 * (c & 1);         // tile-local index of frame X
@@ -158,6 +166,7 @@ __device__ __forceinline__ void f25_gather(const Fast25Args& A, cf* tw512, cf* r
     v[r] = {a * w, b * w};
   }
   __syncthreads();
+  return mx_;
 }
 
 // the conjugate pair of slot e of sequence `off` (0: frames A, B; 8: frames C, D): (a, b) = (Z[k], Z[256 - k]).  Slot 0 of
@@ -218,8 +227,10 @@ __device__ __forceinline__ void f25_powers(const cf* v, bool l0, float (&P)[4][8
 }
 
 // ---------------------------------------------------------------------------------------------------------------
-template <int WAVES>
+// REDO: the second launch of a call with the in-kernel floor test (thresh.hpp: FloorLazy): only the units whose test fired.
+template <int WAVES, bool REDO = false>
 __global__ __launch_bounds__(WAVES * 64, 3) void k_decide_fast256(Fast25Args A) {
+  if (REDO && A.fl.alim[1] != A.tc.need_tag) return;   // no unit of this call reported (the common case)
   extern __shared__ __attribute__((aligned(16))) char smem[];
   cf* tw512 = reinterpret_cast<cf*>(smem);
   cf* regions = tw512 + FN;
@@ -230,7 +241,10 @@ __global__ __launch_bounds__(WAVES * 64, 3) void k_decide_fast256(Fast25Args A) 
   const int64_t u = blockIdx.y;
   const int64_t row = (A.view.unit0 + u) / A.view.n_chunks;
   const int64_t chunk = A.view.c0 + (A.view.unit0 + u) % A.view.n_chunks;
-  const int need = A.tc.need_floor[u];
+  const bool lazy = A.fl.alim != nullptr;
+  const int need = (lazy && !REDO) ? 0 : need_of(A.tc, u);
+  if (REDO && need == 0) return;   // whole workgroup
+  const unsigned fl_bound = REDO ? 0xffffffffu : floor_lazy_bound(A.fl, lane);
   const bool floor_live = need == 1;
   auto t2eff = [&](int f) -> double {
     double v = A.tc.T2[f];
@@ -246,7 +260,8 @@ __global__ __launch_bounds__(WAVES * 64, 3) void k_decide_fast256(Fast25Args A) 
   const int64_t tf0 = (int64_t)blockIdx.x * NF;
   cf v[32];
   bool validX, validY;
-  f25_gather<WAVES>(A, tw512, regions, swin, row, chunk, tf0, v, validX, validY);
+  const unsigned fl_mx = f25_gather<WAVES, true>(A, tw512, regions, swin, row, chunk, tf0, v, validX, validY);
+  if (!REDO) floor_lazy_report(A.tc, A.fl, fl_bound, fl_mx, u, G.FS, lane);
   const int64_t tq = tf0 + F25_FPW * wave;
   if (tq >= G.T) return;   // wave-uniform; no barrier below
   // delta^2 = 2^-32 ||x w||^2 (see k_decide_fast): one sequence carries two frames, the rounding error in either spectrum

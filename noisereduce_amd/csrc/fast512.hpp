@@ -49,14 +49,16 @@ struct Fast5Args {
   OutMap om;
   int64_t h_begin, h_end;    // apply: ext hops (128-sample blocks, ext = unit sample + padL) to produce
   int normalize;
+  FloorLazy fl;              // decide: in-kernel floor test (thresh.hpp), alim == nullptr: flags computed a priori
 };
 
 // stage tables + the tile's sample span, gather the lane's 32 complex points of its frame pair:
 // v[r] = (a[m], b[m]) * w[m], m = c + 16 r; frame A = tq + 2 g, frame B = A + 1.  `tf0`: first frame of the tile.
 // Returns with the span consumed (the exchange slices may be overwritten).
-template <int WAVES>
-__device__ __forceinline__ void f5_gather(const Fast5Args& A, cf* tw512, cf* regions, float* swin, int64_t row,
-                                          int64_t chunk, int64_t tf0, int64_t t_lim, cf* v, bool& validA, bool& validB) {
+template <int WAVES, bool MX = false>
+__device__ __forceinline__ unsigned f5_gather(const Fast5Args& A, cf* tw512, cf* regions, float* swin, int64_t row,
+                                          int64_t chunk, int64_t tf0, int64_t t_lim, cf* v, bool& validA, bool& validB) {   // returns (MX) the largest |sample| this thread staged, as a bit pattern
+  unsigned mx_ = 0u;
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, g = lane >> 4, c = lane & 15;
   constexpr int NF = F5_FPW * WAVES, ROWS = NF - 1 + 4, SPAN = ROWS * F5_H;
   static_assert(ROWS * F5_XP * 4 <= WAVES * WAVE_CX_H * 8, "span must fit the exchange slices");
@@ -69,10 +71,16 @@ __device__ __forceinline__ void f5_gather(const Fast5Args& A, cf* tw512, cf* reg
                    gb >= A.view.lo && gb + SPAN <= A.view.hi && (reinterpret_cast<uintptr_t>(sp) & 15) == 0;
   float* xs = reinterpret_cast<float*>(regions);
   if (vec) {
-    stage_span_vec<WAVES * 64, SPAN, F5_XP, 128>(xs, sp, tid);
+    const unsigned m = stage_span_vec<WAVES * 64, SPAN, F5_XP, 128, MX>(xs, sp, tid);
+    if constexpr (MX) mx_ = m;
   } else {
-    for (int i = tid; i < SPAN; i += WAVES * 64)
-      xs[(i >> 7) * F5_XP + (i & 127)] = (float)view_sample(A.view, row, chunk, s0b + i);
+    unsigned m = 0u;
+    for (int i = tid; i < SPAN; i += WAVES * 64) {
+      const float xv = (float)view_sample(A.view, row, chunk, s0b + i);
+      xs[(i >> 7) * F5_XP + (i & 127)] = xv;
+      m = max(m, __float_as_uint(xv) & 0x7fffffffu);
+    }
+    if constexpr (MX) mx_ = m;
   }
   __syncthreads();
   const int fa = F5_FPW * wave + 2 * g;                       // tile-local index of frame A
@@ -90,6 +98,7 @@ __device__ __forceinline__ void f5_gather(const Fast5Args& A, cf* tw512, cf* reg
     v[r] = {a * w, b * w};
   }
   __syncthreads();
+  return mx_;
 }
 
 // the 16 conjugate pairs of a lane in slot order: (a, b) = (Z[k], Z[512 - k]); lane 0 pairs its self-conjugate rows
@@ -122,8 +131,10 @@ __device__ __forceinline__ double f5_exact_power(const Fast5Args& A, int64_t row
 }
 
 // ---------------------------------------------------------------------------------------------------------------
-template <int WAVES>
+// REDO: the second launch of a call with the in-kernel floor test (thresh.hpp: FloorLazy): only the units whose test fired.
+template <int WAVES, bool REDO = false>
 __global__ __launch_bounds__(WAVES * 64, 3) void k_decide_fast512(Fast5Args A) {
+  if (REDO && A.fl.alim[1] != A.tc.need_tag) return;   // no unit of this call reported (the common case)
   extern __shared__ __attribute__((aligned(16))) char smem[];
   cf* tw512 = reinterpret_cast<cf*>(smem);
   cf* regions = tw512 + FN;
@@ -134,7 +145,11 @@ __global__ __launch_bounds__(WAVES * 64, 3) void k_decide_fast512(Fast5Args A) {
   const int64_t u = blockIdx.y;
   const int64_t row = (A.view.unit0 + u) / A.view.n_chunks;
   const int64_t chunk = A.view.c0 + (A.view.unit0 + u) % A.view.n_chunks;
-  const int need = A.tc.need_floor[u];
+  // lazy (A.fl.alim set): the first launch assumes "no floor live" and tests the samples it stages; REDO serves the flagged units
+  const bool lazy = A.fl.alim != nullptr;
+  const int need = (lazy && !REDO) ? 0 : need_of(A.tc, u);
+  if (REDO && need == 0) return;   // whole workgroup
+  const unsigned fl_bound = REDO ? 0xffffffffu : floor_lazy_bound(A.fl, lane);
   const bool floor_live = need == 1;
   auto t2eff = [&](int f) -> double {
     double v = A.tc.T2[f];
@@ -150,7 +165,8 @@ __global__ __launch_bounds__(WAVES * 64, 3) void k_decide_fast512(Fast5Args A) {
   const int64_t tf0 = (int64_t)blockIdx.x * NF;
   cf v[32];
   bool validA, validB;
-  f5_gather<WAVES>(A, tw512, regions, swin, row, chunk, tf0, G.T, v, validA, validB);
+  const unsigned fl_mx = f5_gather<WAVES, true>(A, tw512, regions, swin, row, chunk, tf0, G.T, v, validA, validB);
+  if (!REDO) floor_lazy_report(A.tc, A.fl, fl_bound, fl_mx, u, G.FS, lane);
   const int64_t tq = tf0 + F5_FPW * wave;
   if (tq >= G.T) return;   // wave-uniform; no barrier below
   // delta^2 = 2^-32 ||x w||^2 per frame (see k_decide_fast): the two frames' norms from the real / imaginary parts

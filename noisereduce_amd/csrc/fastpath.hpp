@@ -99,18 +99,25 @@ __device__ __forceinline__ void stage_tables(cf* tw512, const cf* __restrict__ t
   }
 }
 // SPAN contiguous float32 samples at sp (16-byte aligned) -> xs, rows of ROW samples at a pitch of XPITCH floats
-template <int NTHR, int SPAN, int XPITCH, int ROW = 256>
-__device__ __forceinline__ void stage_span_vec(float* xs, const float* __restrict__ sp, int tid) {
+// (MX: also return the largest |sample| this thread staged, as a bit pattern with the sign cleared -- the in-kernel floor test)
+template <int NTHR, int SPAN, int XPITCH, int ROW = 256, bool MX = false>
+__device__ __forceinline__ unsigned stage_span_vec(float* xs, const float* __restrict__ sp, int tid) {
   static_assert(SPAN % 4 == 0, "16-byte loads");
   constexpr int N4 = SPAN / 4, NQ = (N4 + NTHR - 1) / NTHR;
   float4 q[NQ];
+  unsigned mi = 0u;
 #pragma unroll
   for (int k = 0; k < NQ; ++k) q[k] = reinterpret_cast<const float4*>(sp)[min(tid + k * NTHR, N4 - 1)];
 #pragma unroll
   for (int k = 0; k < NQ; ++k) {
     const int e = 4 * (tid + k * NTHR);
     if ((k + 1) * NTHR <= N4 || e < SPAN) *reinterpret_cast<float4*>(&xs[(e / ROW) * XPITCH + (e % ROW)]) = q[k];
+    if constexpr (MX) {
+      auto ab = [](float x) -> unsigned { return __float_as_uint(x) & 0x7fffffffu; };
+      mi = max(max(mi, max(ab(q[k].x), ab(q[k].y))), max(ab(q[k].z), ab(q[k].w)));
+    }
   }
+  return mi;
 }
 
 // The same from int16 samples (8-byte aligned): four samples per load, converted on the way into LDS.  Integer

@@ -156,7 +156,8 @@ __global__ void k_prep_thresh(const double* __restrict__ thresh, int F, double m
 // test that fires too often only costs time: a flagged unit takes the exact floor path).  Only needed when the threshold
 // did not come from sg_noise_stats, whose last kernel (k_colstats1, Colstats1Fin) derives the same constants itself.
 __global__ void k_prep_thresh_lazy(const double* __restrict__ thresh, int F, double mag_scale, double sum_abs_w,
-                                   double top_db, double* __restrict__ T2, unsigned* __restrict__ alim_bits) {
+                                   double top_db, double* __restrict__ T2, unsigned* __restrict__ alim_bits,
+                                   int nb = OP_ALIM_BLOCKS /* bounds to write: one per 64-band block, all equal here */) {
   const double eps = 2.220446049250313e-16;
   __shared__ double s_min[256];
   double mn = 1e300;
@@ -192,7 +193,7 @@ __global__ void k_prep_thresh_lazy(const double* __restrict__ thresh, int F, dou
       const float lf = __double2float_rd(lim * (1.0 - 1e-6));
       bits = __float_as_uint(lf);              // +Inf (limit beyond float): only non-finite samples report
     }
-    for (int b = 0; b < OP_ALIM_BLOCKS; ++b) alim_bits[2 + b] = bits;   // (the gate takes the minimum of the block bounds)
+    for (int b = 0; b < nb; ++b) alim_bits[2 + b] = bits;   // (the gate takes the minimum of the block bounds)
   }
 }
 

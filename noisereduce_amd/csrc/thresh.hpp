@@ -42,4 +42,41 @@ __device__ __forceinline__ float t2_to_f32(double v, double scale) {
   return v < 0.0 ? -3.0e38f : (v > 1e37 ? 3.0e38f : (float)(scale * v));
 }
 
+// In-kernel floor test of a decision kernel (the protocol of the one-pass gate, onepass.hpp "floor test"), for the kernels
+// whose tiles stage EVERY sample of a unit's window (k_decide_fast512 / 256 / 2048: their frames cover the window, padding
+// included): instead of reading the recording once more before the gate (k_unit_absmax + k_prep_thresh: 18 us of a 150 us
+// call on two minutes of audio) every tile compares the largest sample it staged with the bound a_lim under which no band's
+// -top_db floor can be live (alim[2 .. 2 + nb): one bit pattern per 64-band block of the statistics' last kernel, minimum
+// taken here).  A tile whose test fires reports its unit -- need_floor[u] = (tag << 2) | 1 (2: a non-finite sample) by
+// atomicMax, the unit's band maxima cleared for the float64 pre-pass -- and stamps alim[1] / the host-mapped word; the
+// call's follow-up launches (pre-pass, the decision kernel's REDO instantiation) return at once unless a unit reported.
+struct FloorLazy {
+  unsigned* alim;      // null: the flags in ThreshConsts::need_floor were computed a priori
+  int nb;              // bounds in alim[2 .. 2 + nb)
+  unsigned* live;      // host-mapped: "a unit of launch `epoch` reported"
+  unsigned epoch;
+};
+// the bound, loaded early (one vector load per lane, reduced over the wavefront); 0 when the test is off
+__device__ __forceinline__ unsigned floor_lazy_bound(const FloorLazy& L, int lane) {
+  if (L.alim == nullptr) return 0xffffffffu;
+  unsigned a = L.alim[2 + (lane % L.nb)];
+  for (int off = 32; off > 0; off >>= 1) a = min(a, (unsigned)__shfl_xor((int)a, off));
+  return a;
+}
+// mi: largest |sample| this thread staged, as a bit pattern (sign cleared: NaN / Inf order above every finite value)
+__device__ __forceinline__ void floor_lazy_report(const ThreshConsts& tc, const FloorLazy& L, unsigned bound, unsigned mi,
+                                                  int64_t u, int FS, int lane) {
+  if (L.alim == nullptr) return;
+  if (__any(mi >= bound)) {   // wave-uniform, rare
+    const bool nonfinite = __any(mi >= 0x7f800000u);
+    double* pm = const_cast<double*>(tc.pmax) + u * FS;
+    for (int f = lane; f < FS; f += 64) pm[f] = 0.0;
+    if (lane == 0) {
+      atomicMax(reinterpret_cast<unsigned*>(const_cast<int*>(tc.need_floor)) + u, (tc.need_tag << 2) | (nonfinite ? 2u : 1u));
+      L.alim[1] = tc.need_tag;
+      *L.live = L.epoch;
+    }
+  }
+}
+
 }  // namespace sg

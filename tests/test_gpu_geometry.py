@@ -302,3 +302,101 @@ def test_short_frames_long_smoothing_window(nr, n_fft, sr, extra, stationary):
     got = nr.reduce_noise(y=y, sr=sr, stationary=stationary, **kw)
     want = O.reduce_noise_S(y, sr, stationary=stationary, **kw)
     assert O.rel_err(got, want) < TOL
+
+
+def _floor_inputs_geom(kind, n_fft):
+    """Inputs of tests/test_gpu_onepass.py::_floor_inputs, sized for short chunks of any frame length."""
+    rng = np.random.default_rng(4321 + n_fft)
+    n, cs, pad = 150000, 40000, 6000
+    y = (0.05 * rng.standard_normal(n)).astype(np.float32)
+    y_noise = (0.05 * rng.standard_normal(30000)).astype(np.float32)
+    if kind == "live":                # loud half next to digital silence, very quiet noise clip: bands lifted by the floor
+        y[: n // 2] = 0.0
+        y[n // 2:] *= 10.0
+        y_noise = (1e-7 * rng.standard_normal(30000)).astype(np.float32)
+    elif kind == "loud_in_padding":   # the only loud samples of chunk 1's window sit in its left padding (chunk 0's tail)
+        y[:] = (1e-6 * rng.standard_normal(n)).astype(np.float32)
+        y[cs - pad + 200: cs - pad + 1500] = (0.9 * rng.standard_normal(1300)).astype(np.float32)
+        y_noise = (1e-7 * rng.standard_normal(30000)).astype(np.float32)
+    elif kind == "nan_in_padding":    # a NaN that only chunk 2's right padding sees (and chunk 3's body)
+        y[3 * cs + 4000] = np.nan
+    elif kind == "inf_far_padding":   # an Inf near the far end of chunk 0's right padding
+        y[cs + pad - 3] = np.inf
+    return y, y_noise, cs, pad
+
+
+@pytest.mark.parametrize("n_fft", [256, 512, 2048])
+@pytest.mark.parametrize("kind", ["benign", "live", "loud_in_padding", "nan_in_padding", "inf_far_padding"])
+def test_register_paths_floor_test_in_the_decision_kernel(n_fft, kind):
+    """Round 6: k_decide_fast256 / 512 / 2048 run the -top_db floor test on the samples they stage (SG_OPT_FLOOR_TEST 2;
+    flagged chunks: float64 band maxima + the decision kernel's REDO launch) instead of k_unit_absmax + k_prep_thresh
+    reading the recording before the gate (1).  Same bits, same output, whichever answers -- and the oracle's."""
+    from noisereduce_amd import _ffi
+    from noisereduce_amd.spectralgate.stationary import SpectralGateStationary
+    y, y_noise, cs, pad = _floor_inputs_geom(kind, n_fft)
+    sr = 48000
+    kw = dict(sr=sr, y_noise=y_noise, prop_decrease=1.0, n_std_thresh_stationary=1.5, chunk_size=cs,
+              clip_noise_stationary=True, padding=pad, n_fft=n_fft, win_length=None, hop_length=None,
+              time_constant_s=2.0, freq_mask_smooth_hz=500, time_mask_smooth_ms=50, tmp_folder=None, use_tqdm=False,
+              n_jobs=1)
+    sg = SpectralGateStationary(y=y, **kw)
+    gate = sg._gate
+    outs, how = {}, {}
+    try:
+        for mode in (1, 2, 2, 0, 0, 1):
+            gate.set_option(_ffi.SG_OPT_FLOOR_TEST, mode)
+            a0, b0 = gate.debug_counter(1), gate.debug_counter(2)
+            outs.setdefault(mode, []).append(sg.get_traces())
+            torch.cuda.synchronize()
+            how.setdefault(mode, []).append((gate.debug_counter(1) - a0, gate.debug_counter(2) - b0))
+    finally:
+        gate.set_option(_ffi.SG_OPT_FLOOR_TEST, 0)
+    assert how[1] == [(0, 1), (0, 1)] and how[2] == [(1, 0), (1, 0)]     # the path asked for is the one that ran
+    ref = outs[1][0]
+    for mode, lst in outs.items():
+        for o in lst:
+            assert np.array_equal(o, ref, equal_nan=True), (kind, mode)
+    gate.check_errors()
+    if kind in ("benign", "live", "loud_in_padding"):
+        want = O.reduce_noise_S(y.astype(np.float64), sr, stationary=True, y_noise=y_noise.astype(np.float64),
+                                chunk_size=cs, padding=pad, n_fft=n_fft)
+        assert O.rel_err(ref, want) < TOL
+    else:
+        assert np.isnan(ref).any()
+
+
+@pytest.mark.parametrize("n_fft", [512, 2048])
+def test_register_paths_floor_test_prediction_follows_the_data(n_fft):
+    """Default mode on the register paths: in the kernel while nothing reports, a priori after a call whose chunks did."""
+    from noisereduce_amd import _ffi
+    from noisereduce_amd.spectralgate.stationary import SpectralGateStationary
+    kw = dict(sr=48000, prop_decrease=1.0, n_std_thresh_stationary=1.5, clip_noise_stationary=True, n_fft=n_fft,
+              win_length=None, hop_length=None, time_constant_s=2.0, freq_mask_smooth_hz=500, time_mask_smooth_ms=50,
+              tmp_folder=None, use_tqdm=False, n_jobs=1)
+    yb, nb, cs, pad = _floor_inputs_geom("benign", n_fft)
+    yl, nl, _, _ = _floor_inputs_geom("live", n_fft)
+    sb = SpectralGateStationary(y=yb, y_noise=nb, chunk_size=cs, padding=pad, **kw)
+    sl = SpectralGateStationary(y=yl, y_noise=nl, chunk_size=cs, padding=pad, **kw)
+    gate = sb._gate
+    assert gate is sl._gate
+    gate.set_option(_ffi.SG_OPT_FLOOR_TEST, 0)
+
+    def run(sg):
+        a0, b0 = gate.debug_counter(1), gate.debug_counter(2)
+        out = sg.get_traces()
+        torch.cuda.synchronize()
+        return (gate.debug_counter(1) - a0, gate.debug_counter(2) - b0), out
+
+    for _ in range(20):
+        sb.get_traces()
+    torch.cuda.synchronize()
+    how, out_b = run(sb)
+    how1, out_l1 = run(sl)
+    how2, out_l2 = run(sl)
+    assert how == (1, 0) and how1 == (1, 0) and how2 == (0, 1)
+    assert np.array_equal(out_l1, out_l2, equal_nan=True)
+    for _ in range(20):
+        sb.get_traces()
+    torch.cuda.synchronize()
+    how3, out_b2 = run(sb)
+    assert how3 == (1, 0) and np.array_equal(out_b, out_b2)
