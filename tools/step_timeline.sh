@@ -17,7 +17,7 @@ rows = [r for r in csv.DictReader(open(sys.argv[1])) if "sg::" in r["Kernel_Name
 rows.sort(key=lambda r: int(r["Start_Timestamp"]))
 def short(k):
     m = re.search(r"sg::(?:fast::)?(k_[a-z0-9_]+)", k)
-    if m and m.group(1) == "k_gate_onepass" and re.search(r"k_gate_onepass<\d+, \w+, \w+, true>", k):
+    if m and m.group(1) == "k_gate_onepass" and re.search(r"k_gate_onepass<\d+, \w+, \w+, true[,>]", k):
         return "k_gate_onepass<redo>"    # second launch of the in-kernel floor test (returns at once when no chunk reported)
     return m.group(1) if m else k[:30]
 # a step starts at the first noise-statistics kernel (k_stft of the clip)
