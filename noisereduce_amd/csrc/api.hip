@@ -29,6 +29,7 @@
 #include "rowgate.hpp"
 #include "rowbwd.hpp"
 #include "fast512.hpp"
+#include "onepass512.hpp"
 #include "fast256.hpp"
 #include "fast2048.hpp"
 #include "nonstat.hpp"
@@ -140,6 +141,7 @@ struct sg_handle {
   bool dbg_rg = false;               // the last batch ran on the row gate
   DevBuf rg_count;                   // k_row_gate: number of (row, band) pairs that took the exact path (one counter, never reset)
   bool dbg_xbits = false;            // the last batch's mask bits live in xbits (tile-blocked)
+  int dbg_trows = 16, dbg_tstep = 16, dbg_twords = 0, dbg_txw = 9;   // ... in tiles of trows frames every tstep frames, twords granule halves, txw words per row
   int64_t dbg_tf0 = 0;               // first frame of tile 0 of that batch
   int dbg_ntt = 0;                   // tiles per unit incl. the two halo tiles
   int big_M = 0;                     // > 0: long frames (n_fft > 8192, or > 4096 and not a power of two): four-step
@@ -1466,6 +1468,116 @@ static int stage_apply512(sg_handle* h, const View& v, const Geom& g, int64_t ub
   return SG_OK;
 }
 
+// (round 6) one-pass gate for n_fft = 512 (onepass512.hpp): decide + smooth + apply in one kernel, tiles exchange their bits
+static int handoff_prepare(sg_handle* h, hipStream_t st);
+static int handoff_next_epoch(sg_handle* h, hipStream_t st);
+static int stage_prep_floor(sg_handle* h, const View& v, const Geom& g, int64_t ub, ThreshConsts* tc_out, hipStream_t st,
+                            const View* v_exact, unsigned* live_host, unsigned stamp);
+template <int MODE>
+static hipError_t launch_bits_any(const sg_handle* h, const View& v, const Geom& g, int64_t units, const ThreshConsts& tc,
+                                  unsigned long long* pmax_bits, unsigned long long* bits, int wpr, hipStream_t st);
+static bool onepass512_ok(const sg_handle* h, const Geom& g, const OutMap& om) {
+  if (!h->fast5_ok || h->force_nofast || h->force_split || h->force_f64_decide || h->force_unfused || !h->fused_ok) return false;
+  if (h->p.variant != SG_VARIANT_S || !h->p.stationary || !h->p.smooth_mask || h->p.prop_decrease != 1.0) return false;
+  if (h->p.n_grad_freq > fast::O5_MAX_NF || h->p.n_grad_time > fast::O5_MAX_NT || g.F != 257) return false;
+  if (h->tile_order == 1) return false;
+  const int64_t hb = (om.p0 + g.padL) / 128, he = (om.p1 - 1 + g.padL) / 128 + 1;
+  return he > hb;
+}
+static int stage_onepass512(sg_handle* h, const View& v, const View& vx, const Geom& g, int64_t ub, const OutMap& om,
+                            hipStream_t st) {
+  int rc;
+  if ((rc = handoff_prepare(h, st))) return rc;
+  const unsigned live_stamp = h->err_host[1];
+  const unsigned need_tag = h->epoch & 0x3fffffffu;
+  const unsigned era = h->epoch >> 30;
+  if (era != h->need_era || need_tag == 0u) {
+    if (h->need.p) HIPCHK(h, hipMemsetAsync(h->need.p, 0, h->need.bytes, st));
+    if (h->alim.p) HIPCHK(h, hipMemsetAsync((char*)h->alim.p + 4, 0, 4, st));
+    h->need_era = era;
+  }
+  const bool lazy = need_tag != 0u &&
+                    (h->floor_test == 2 || (h->floor_test == 0 && !(live_stamp != 0u && h->epoch - live_stamp <= 16u)));
+  ++(lazy ? h->n_floor_lazy : h->n_floor_apriori);
+  const int wpr = (g.F + 63) / 64;
+  ThreshConsts tc{};
+  FloorLazy fl{};
+  if (!lazy) {
+    if ((rc = stage_prep_floor(h, v, g, ub, &tc, st, &vx, h->err_dev + 1, h->epoch))) return rc;
+  } else {
+    const int nb = (g.FS + 63) / 64;
+    if ((rc = ensure(h, h->bits, (size_t)ub * g.T * wpr * 8))) return rc;
+    if ((rc = ensure_zeroed(h, h->need, (size_t)ub * 4, st))) return rc;
+    if ((rc = ensure(h, h->T2, (size_t)g.FS * 8))) return rc;
+    if ((rc = ensure_zeroed(h, h->alim, 256, st))) return rc;
+    if (!h->t2_ready) {
+      ProfScope ps(h, SG_STAGE_PREP, st);
+      hipLaunchKernelGGL(k_prep_thresh_lazy, dim3(1), dim3(256), 0, st, (const double*)h->thresh.p, g.F, h->mag_scale,
+                         h->sum_abs_w, h->p.top_db, (double*)h->T2.p, (unsigned*)h->alim.p, nb);
+      HIPCHK(h, hipGetLastError());
+      h->t2_ready = true;
+    }
+    tc = ThreshConsts{(const double*)h->T2.p, (const double*)h->thresh.p, (const double*)h->pmax.p, (const int*)h->need.p, need_tag};
+    fl = FloorLazy{(unsigned*)h->alim.p, nb, h->err_dev + 1, h->epoch};
+  }
+  fast::OnePass5Args P{};
+  P.A = fast5_args(h, v, g);
+  P.A.tc = tc;
+  P.A.fl = fl;
+  P.A.inv_ktot = (float)(1.0 / (double)h->ktot);
+  P.A.om = om;
+  P.A.normalize = 1;
+  P.A.h_begin = (om.p0 + g.padL) / 128;
+  P.A.h_end = (om.p1 - 1 + g.padL) / 128 + 1;
+  const int64_t nh = P.A.h_end - P.A.h_begin;
+  const int64_t n_tiles = (nh + fast::O5_NH - 1) / fast::O5_NH, ntt = n_tiles + 2;
+  if ((rc = ensure_zeroed(h, h->xbits, (size_t)ub * ntt * fast::O5_TILE_WORDS * 8, st))) return rc;
+  P.xbits = (unsigned long long*)h->xbits.p;
+  P.ticket = (unsigned*)h->xticket.p;
+  P.ticket_base = h->ticket_base;
+  h->ticket_base += (unsigned)(ub * ntt);
+  P.epoch = h->epoch;
+  P.err = h->err_dev;
+  P.nf = h->p.n_grad_freq; P.nt = h->p.n_grad_time; P.n_tiles = (int)n_tiles;
+  {
+    // the part of a unit's window outside its tiles' spans, dealt evenly to the unit's tiles (onepass512.hpp "floor test")
+    constexpr int64_t SPAN = (fast::O5_NF - 1 + 4) * 128;
+    const int64_t sp0 = (P.A.h_begin - 3 - fast::O5_NH) * 128 - g.padL, sp1 = (P.A.h_begin - 3 + n_tiles * fast::O5_NH) * 128 - g.padL + SPAN;
+    const int64_t inside = std::max<int64_t>(0, std::min<int64_t>(v.Lp, sp1) - std::max<int64_t>(0, sp0));
+    const int64_t q = (v.Lp - inside + ntt - 1) / ntt;
+    if (q > 0x7fffffff) FAIL(h, SG_E_UNSUPPORTED, "one-pass gate: window of %lld samples", (long long)v.Lp);
+    P.scan_q = (int)q;
+  }
+  const size_t lds = FAST5_LDS + 16;
+  {
+    ProfScope ps(h, SG_STAGE_ONEPASS, st);
+    auto kern = fast::k_gate_onepass512<4, false>;
+    HIPCHK(h, set_lds(reinterpret_cast<const void*>(kern), lds));
+    hipLaunchKernelGGL(kern, dim3((unsigned)(ub * ntt)), dim3(256), lds, st, P);
+    HIPCHK(h, hipGetLastError());
+  }
+  if (lazy) {
+    // the units whose floor test fired: float64 band maxima, then the gate again with them (both return at once otherwise)
+    ProfScope ps(h, SG_STAGE_STFT_MAX, st);
+    HIPCHK(h, launch_bits_any<0>(h, vx, g, ub, tc, (unsigned long long*)h->pmax.p, (unsigned long long*)h->bits.p, wpr, st));
+    if ((rc = handoff_next_epoch(h, st))) return rc;
+    P.epoch = h->epoch;
+    P.ticket = (unsigned*)h->xticket.p + 8;   // its own counter (zeroed by the first launch's ticket-0 workgroup)
+    P.ticket_base = 0;
+    auto kern = fast::k_gate_onepass512<4, true>;
+    HIPCHK(h, set_lds(reinterpret_cast<const void*>(kern), lds));
+    hipLaunchKernelGGL(kern, dim3((unsigned)(ub * ntt)), dim3(256), lds, st, P);
+    HIPCHK(h, hipGetLastError());
+  }
+  h->dbg_xbits = true;
+  h->dbg_trows = fast::O5_NF; h->dbg_tstep = fast::O5_NH; h->dbg_twords = fast::O5_TILE_WORDS; h->dbg_txw = fast::O5_XW;
+  h->dbg_tf0 = P.A.h_begin - 3;
+  h->dbg_ntt = (int)ntt;
+  h->dbg_db = std::max<int64_t>(0, P.A.h_begin - 3 - fast::O5_NH);
+  h->dbg_de = std::min<int64_t>(g.T, P.A.h_begin - 3 + fast::O5_NH * (n_tiles + 1) + 3);
+  return SG_OK;
+}
+
 // ------------------------------------------------------------------------------------------
 // n_fft = 256 / hop 64 on the register transform (fast256.hpp, round 5): four frames per lane group
 // ------------------------------------------------------------------------------------------
@@ -2409,6 +2521,7 @@ static int stage_onepass(sg_handle* h, const View& v, const View& vx, const Geom
     HIPCHK(h, hipGetLastError());
   }
   h->dbg_xbits = true;
+  h->dbg_trows = 16; h->dbg_tstep = 16; h->dbg_twords = fast::OP_TILE_WORDS; h->dbg_txw = fast::OP_XW;
   h->dbg_tf0 = A.h_begin - 3;
   h->dbg_ntt = (int)ntt;
   h->dbg_db = std::max<int64_t>(0, A.h_begin - 3 - NF);
@@ -2690,8 +2803,9 @@ static int run_S(sg_handle* h, View v, int64_t total_units, const OutMap& om, hi
   // one-pass gate (any prop_decrease) or, with prop_decrease == 1, the three-kernel bit-mask path: only bit /
   // count fields in the workspace
   const bool onepass = h->fused_ok && !h->force_unfused && h->fast_ok && !h->force_nofast && onepass_ok(h, g, om);
-  const bool lean = onepass || (h->fused_ok && !h->force_unfused && h->fast_ok && !h->force_nofast &&
-                                h->p.prop_decrease == 1.0);
+  const bool onepass5 = !onepass && onepass512_ok(h, g, om);
+  const bool lean = onepass || onepass5 || (h->fused_ok && !h->force_unfused && h->fast_ok && !h->force_nofast &&
+                                            h->p.prop_decrease == 1.0);
   int64_t ub = units_per_batch(h, g, total_units, lean);
   int rc = ensure_ws(h, g, ub, lean);
   if (rc) return rc;
@@ -2699,7 +2813,7 @@ static int run_S(sg_handle* h, View v, int64_t total_units, const OutMap& om, hi
   // frame (in every kernel).  Convert the readable part of the rows ONCE -- (float)sample is what those kernels
   // compute anyway -- and keep the original view for the float64 work (exact refinement, floor pre-pass).
   const View vx = v;
-  if (v.dtype != SG_F32 && h->fast_ok && !h->force_nofast && (onepass || (!h->p.stationary && nonstat2_ok(h, g)))) {
+  if (v.dtype != SG_F32 && ((h->fast_ok && !h->force_nofast && (onepass || (!h->p.stationary && nonstat2_ok(h, g)))) || onepass5)) {
     const int64_t rows = total_units / std::max<int64_t>(1, v.n_chunks), len = v.hi - v.lo;
     const size_t bytes = (size_t)rows * len * sizeof(float);
     if (len > 0 && bytes <= ((size_t)16 << 30)) {
@@ -2724,6 +2838,13 @@ static int run_S(sg_handle* h, View v, int64_t total_units, const OutMap& om, hi
       vxb.unit0 = u0;
       if ((rc = stage_onepass(h, v, vxb, g, nb, om, st))) return rc;
       h->dbg_units = nb; h->dbg_T = g.T; h->dbg_has_P = false; h->dbg_fused = true; h->dbg_fast = true;
+      continue;
+    }
+    if (onepass5) {
+      View vxb = vx;
+      vxb.unit0 = u0;
+      if ((rc = stage_onepass512(h, v, vxb, g, nb, om, st))) return rc;
+      h->dbg_units = nb; h->dbg_T = g.T; h->dbg_has_P = false; h->dbg_fused = true; h->dbg_fast = true; h->dbg_k16_only = false;
       continue;
     }
     if (fast) {
@@ -3470,19 +3591,20 @@ extern "C" int sg_debug_fetch(sg_handle* h, int32_t what, void* host, int64_t by
     // one-pass path: the bits live tile-blocked in the exchange buffer [unit][tile][16][9]; rearrange into
     // the natural [unit][T][wpr] layout (frames outside sg_debug_range stay zero)
     const int wpr = (h->F + 63) / 64;
-    const size_t words = (size_t)h->dbg_units * h->dbg_ntt * fast::OP_TILE_WORDS;
+    const int TW = h->dbg_twords ? h->dbg_twords : fast::OP_TILE_WORDS, XW = h->dbg_txw;
+    const size_t words = (size_t)h->dbg_units * h->dbg_ntt * TW;
     std::vector<unsigned long long> tmp(words);
     HIPCHK(h, hipMemcpy(tmp.data(), h->xbits.p, words * 8, hipMemcpyDeviceToHost));
     unsigned long long* dst = (unsigned long long*)host;
     std::memset(dst, 0, need);
     for (int64_t u = 0; u < h->dbg_units; ++u)
       for (int64_t j = 0; j < h->dbg_ntt; ++j)
-        for (int i = 0; i < 16; ++i) {
-          const int64_t t = h->dbg_tf0 + (j - 1) * 16 + i;
+        for (int i = 0; i < h->dbg_trows; ++i) {
+          const int64_t t = h->dbg_tf0 + (j - 1) * h->dbg_tstep + i;
           if (t < 0 || t >= h->dbg_T) continue;
           for (int w = 0; w < wpr; ++w)
           {
-            const unsigned long long* gr = &tmp[((size_t)u * h->dbg_ntt + j) * fast::OP_TILE_WORDS + (i * fast::OP_XW + w) * 2];
+            const unsigned long long* gr = &tmp[((size_t)u * h->dbg_ntt + j) * TW + (i * XW + w) * 2];
             dst[(u * h->dbg_T + t) * wpr + w] = (gr[0] & 0xffffffffull) | (gr[1] << 32);
           }
         }

@@ -1,0 +1,472 @@
+// One-pass stationary gate for n_fft = win = 512, hop = 128 (round 6; VERDICT r3 / r4 / r5 "one-pass gates for n_fft != 1024").
+//
+//   k_decide_fast512 + k_smooth_bits2 + k_apply_fast512<K>      (3 transforms per frame pair, bit field and K field in HBM)
+//     ->  k_gate_onepass512                                      (2 transforms per frame pair, neither field)
+//
+// The structure of k_gate_onepass (onepass.hpp) on the transforms of fast512.hpp.  A workgroup takes a TICKET and owns one tile
+// of 32 consecutive frames of one unit (4 wavefronts x 4 lane groups x one frame PAIR per 512-point register transform).  After
+// the forward transform it decides its 32 x 257 cells (float32 + exact float64 refinement: the bits of k_decide_fast512), keeps
+// the spectra in registers and
+//   1. publishes the tile's bits (32 rows x 5 words) to its neighbours as data-tagged granules {32 bits, launch epoch};
+//   2. polls the nt adjacent rows of tiles j - 1 and j + 1 (nt <= 24: the time half-width of the smoothing filter);
+//   3. smooths the (32 + 2 nt) x 257 bit tile in LDS with the exact integer separable triangle filter -- along f by a
+//      two-popcount recurrence on the bit rows (H, uint8: (nf + 1)^2 <= 255), along t by a two-boxcar recurrence per bin column
+//      (K, uint16), 16 output frames at a time so that bits + H + half of K fit the exchange slices, which are idle between the
+//      two transforms: no more LDS than k_apply_fast512 (3 workgroups per CU);
+// then x mask -> inverse transform -> window -> overlap-add -> store exactly as k_apply_fast512<K>.  Tiles OVERLAP by 3 frames
+// as there (29 complete hops per tile, 9 % redundant transforms): no partial hops travel between workgroups, the bits are the
+// only exchange.  Inter-workgroup protocol, deadlock freedom (tickets; publish before wait), bounded polls and NaN-poisoned
+// output of a tile that lost a hand-off: onepass.hpp.  The -top_db floor test runs on the staged samples (thresh.hpp:
+// FloorLazy); REDO = the second launch for the units whose test fired.  prop_decrease = 1 only (the caller keeps the
+// three-kernel path otherwise).
+#pragma once
+#include "fast512.hpp"
+
+namespace sg {
+namespace fast {
+
+constexpr int O5_NF = 32, O5_NH = 29;              // frames / complete hops per tile
+constexpr int O5_XW = 5;                           // 64-bit words per bit row (257 bins)
+constexpr int O5_TILE_WORDS = O5_NF * O5_XW * 2;   // payload of one tile: 320 tagged 8-byte halves = 2560 B
+constexpr int O5_BW = O5_XW + 2;                   // bit row pitch in LDS: one zero word on each side
+constexpr int O5_KP = 264;                         // H / K row pitch (entries)
+constexpr int O5_MAX_NT = 24;                      // (32 + 2 nt) (56 + 264) + 16 x 264 x 2 bytes <= the exchange slices
+constexpr int O5_MAX_NF = 14;                      // (nf + 1)^2 <= 255: H as bytes
+
+struct OnePass5Args {
+  Fast5Args A;                 // view, geometry, tables, compare constants, output map, hop range, floor test (FIRST: late_args)
+  unsigned long long* xbits;   // [units][n_tiles + 2][32][5][2] published mask bits: granules {32 bits, epoch}
+  unsigned* ticket;            // work counter: never reset, a launch takes exactly units * (n_tiles + 2) tickets
+  unsigned ticket_base;
+  unsigned epoch;
+  unsigned* err;               // host-mapped word: bit 0 = a bit hand-off timed out
+  int nf, nt, n_tiles;
+  int scan_q;                  // in-kernel floor test: samples of the unit window's unstaged part that each tile scans
+};
+
+template <int WAVES, bool REDO = false>
+__global__ __launch_bounds__(WAVES * 64, 3) void k_gate_onepass512(OnePass5Args P) {
+  static_assert(WAVES == 4, "tile = 32 frames");
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  cf* tw512 = reinterpret_cast<cf*>(smem);
+  cf* regions = tw512 + FN;
+  float* swin = reinterpret_cast<float*>(regions + WAVES * WAVE_CX_H);
+  float* s_t2 = swin + F5_N;                 // [257] float32 compare constants x4 (the split works on 2 X)
+  unsigned* s_misc = reinterpret_cast<unsigned*>(s_t2 + 264);   // [0] ticket, [1] lost hand-off
+  const Fast5Args& A = P.A;
+  if (REDO && A.fl.alim[1] != A.tc.need_tag) return;   // no unit of this call reported (the common case)
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, g = lane >> 4, c = lane & 15;
+  const Geom& G = A.g;
+  if (tid == 0) {
+    s_misc[0] = atomicAdd(P.ticket, 1u) - P.ticket_base;
+    s_misc[1] = 0u;
+  }
+  const unsigned fl_bound = REDO ? 0xffffffffu : floor_lazy_bound(A.fl, lane);
+  __syncthreads();
+  const int ntt = P.n_tiles + 2;                   // tiles per unit incl. one decide-only halo tile per side
+  const unsigned ticket = s_misc[0];
+  const int64_t u = ticket / (unsigned)ntt;
+  const int jt = (int)(ticket % (unsigned)ntt) - 1;
+  const bool halo_tile = jt < 0 || jt >= P.n_tiles;
+  const unsigned gu = (unsigned)(A.view.unit0 + u), nch = (unsigned)A.view.n_chunks;
+  const int64_t row = gu / nch;
+  const int64_t chunk = A.view.c0 + gu % nch;
+  const bool lazy = A.fl.alim != nullptr;
+  const int need = (lazy && !REDO) ? 0 : need_of(A.tc, u);
+  if (REDO && need == 0) return;   // whole workgroup
+  if (!REDO && lazy && ticket == 0u && tid == 0) P.ticket[8] = 0u;   // (the second launch's counter starts from zero)
+  const bool floor_live = need == 1;
+  auto t2eff = [&](int f) -> double {
+    double v = A.tc.T2[f];
+    if (floor_live) {
+      const double fl = cell_db(A.tc.pmax[u * G.FS + f], A.mag_scale) - A.top_db;
+      if (fl > A.tc.thresh[f]) v = -1.0;
+    }
+    if (need == 2) v = T2_NEVER;
+    return v;
+  };
+  stage_t2_plain<WAVES * 64, F5_F>(s_t2, A.tc.T2, need, 4.0, tid, t2eff);
+  constexpr int NF = O5_NF, NH = O5_NH;
+  const int64_t tf0 = A.h_begin - 3 + (int64_t)jt * NH;   // first frame of the tile
+  cf v[32];
+  bool validA, validB;
+  unsigned fl_mx = f5_gather<WAVES, true>(A, tw512, regions, swin, row, chunk, tf0, G.T, v, validA, validB);
+  if (!REDO && lazy) {
+    // The tiles of a unit stage the frames its kept hops need (+- nt), not the whole window: the rest -- the chunk's padding
+    // beyond them, A = [s_lo, first span) and B = [last span's end, s_hi) -- is dealt to the unit's tiles in slices of scan_q
+    // samples of A ++ B (onepass.hpp "floor test"; a few hundred samples per tile at the default chunking)
+    constexpr int SPAN = (NF - 1 + 4) * F5_H;
+    const int64_t g0 = chunk * A.view.cs - A.view.pad;
+    const int64_t s_lo = max<int64_t>(0, A.view.lo - g0), s_hi = min<int64_t>(A.view.Lp, A.view.hi - g0);
+    const int64_t sp0 = (A.h_begin - 3 - NH) * F5_H - G.padL;
+    const int64_t sp1 = (A.h_begin - 3 + (int64_t)P.n_tiles * NH) * F5_H - G.padL + SPAN;
+    const int64_t first = min(s_hi, max(s_lo, sp0)), last = max(s_lo, min(s_hi, sp1));
+    const int64_t lenA = first - s_lo;
+    const int64_t c0 = (int64_t)(jt + 1) * P.scan_q, c1 = min(c0 + P.scan_q, lenA + (s_hi - last));
+    for (int64_t i = c0 + tid; i < c1; i += WAVES * 64)
+      fl_mx = max(fl_mx, __float_as_uint((float)view_sample(A.view, row, chunk, i < lenA ? s_lo + i : last + (i - lenA))) & 0x7fffffffu);
+  }
+  if (!REDO) floor_lazy_report(A.tc, A.fl, fl_bound, fl_mx, u, G.FS, lane);
+  const int64_t tq = tf0 + F5_FPW * wave;
+  // ---- forward transform + decisions (k_decide_fast512) -------------------------------------------------------
+  float nA = 0.f, nB = 0.f;
+#pragma unroll
+  for (int r = 0; r < 32; ++r) { nA += v[r].x * v[r].x; nB += v[r].y * v[r].y; }
+#pragma unroll
+  for (int o = 1; o < 16; o <<= 1) { nA += __shfl_xor(nA, o); nB += __shfl_xor(nB, o); }
+  cf* fb = regions + wave * WAVE_CX_H + frame_base_h(g);
+  {
+    int z0 = 0;
+    asm volatile("" : "+v"(z0));
+    fft512_fwd_half(v, fb, tw512 + z0, c);
+  }
+  const bool l0 = c == 0;
+  unsigned long long wA = 0ull, wB = 0ull;   // lane c < 5 of group g: word c of frames tq + 2 g, tq + 2 g + 1
+  {
+    const float nAB = nA + nB;
+    const float dA = nAB > 0.f ? 8.0f * 2.3283064e-10f * nAB : -1.0f;
+    const float dB = dA;
+    unsigned pA = 0, pB = 0, aA = 0, aB = 0;
+    bool p256A = false, p256B = false, a256A = false, a256B = false;
+    auto decide = [&](float Pw, float T, float d2, unsigned& pr, unsigned& am, int q) {
+      const float diff = Pw - T;
+      pr |= (diff > 0.f ? 1u : 0u) << q;
+      am |= ((diff * diff <= d2 * (Pw + T)) ? 1u : 0u) << q;
+    };
+#pragma unroll
+    for (int sl = 0; sl < 16; ++sl) {
+      cf a, b;
+      f5_pair(v, sl, l0, a, b);
+      const cf E = {a.x + b.x, a.y - b.y}, O = {a.y + b.y, b.x - a.x};   // 2 A[k], 2 B[k]
+      float PA = E.x * E.x + E.y * E.y, PB = O.x * O.x + O.y * O.y;
+      if (sl == 0) {
+        const float xa = 2.f * v[0].x, xb = 2.f * v[0].y;
+        PA = l0 ? xa * xa : PA;
+        PB = l0 ? xb * xb : PB;
+      }
+      const float T = s_t2[bin5(c, sl)];
+      decide(PA, T, dA, pA, aA, sl);
+      decide(PB, T, dB, pB, aB, sl);
+    }
+    {
+      const float xa = 2.f * v[8].x, xb = 2.f * v[8].y, T = s_t2[256];
+      const float da = xa * xa - T, db = xb * xb - T;
+      p256A = l0 && da > 0.f;
+      p256B = l0 && db > 0.f;
+      a256A = l0 && da * da <= dA * (xa * xa + T);
+      a256B = l0 && db * db <= dB * (xb * xb + T);
+    }
+    if (need == 2) { pA = pB = 0; aA = aB = 0; p256A = p256B = a256A = a256B = false; }
+    if (!validA) { pA = 0; aA = 0; p256A = a256A = false; }
+    if (!validB) { pB = 0; aB = 0; p256B = a256B = false; }
+    while (true) {   // exact re-evaluation of ambiguous cells, one at a time, whole wave cooperating
+      const unsigned long long pending = __ballot(aA != 0 || aB != 0 || a256A || a256B);
+      if (pending == 0) break;
+      const int src = __ffsll((long long)pending) - 1;
+      const unsigned sA = (unsigned)__shfl((int)aA, src), sB = (unsigned)__shfl((int)aB, src);
+      const int s256A = __shfl((int)a256A, src);
+      const int cs = src & 15, gs = src >> 4;
+      int which, f;
+      int q = 0;
+      if (sA) { which = 0; q = __ffs((int)sA) - 1; f = bin5(cs, q); }
+      else if (sB) { which = 1; q = __ffs((int)sB) - 1; f = bin5(cs, q); }
+      else if (s256A) { which = 2; f = 256; }
+      else { which = 3; f = 256; }
+      const int64_t t = tq + 2 * gs + (which & 1);
+      const Fast5Args& L = *late_args<Fast5Args>();       // (cold path: arguments re-read here; A is the FIRST member)
+      const double Pe = f5_exact_power(L, row, chunk, t, f, lane);
+      double t2 = L.tc.T2[f];
+      if (floor_live) {
+        const double fl = cell_db(L.tc.pmax[u * (int64_t)L.g.FS + f], L.mag_scale) - L.top_db;
+        if (fl > L.tc.thresh[f]) t2 = -1.0;
+      }
+      if (need == 2) t2 = T2_NEVER;
+      const bool pass = Pe > t2;
+      if (lane == src) {
+        if (which == 0) { pA = (pA & ~(1u << q)) | ((pass ? 1u : 0u) << q); aA &= ~(1u << q); }
+        else if (which == 1) { pB = (pB & ~(1u << q)) | ((pass ? 1u : 0u) << q); aB &= ~(1u << q); }
+        else if (which == 2) { p256A = pass; a256A = false; }
+        else { p256B = pass; a256B = false; }
+      }
+    }
+    // pack (k_decide_fast512): 16 x 16 bit transpose across the lane group, then lane c < 4 assembles word c, lane 4 bin 256
+    unsigned tr = (pA & 0xffffu) | (pB << 16);
+    auto tstep = [&](int sft, unsigned msk) {
+      const unsigned y = (unsigned)__shfl_xor((int)tr, sft);
+      const bool up = (c & sft) != 0;
+      const unsigned ysh = up ? (y >> sft) : (y << sft);
+      const unsigned mk = up ? msk : ~msk;
+      tr = (tr & ~mk) | (ysh & mk);
+    };
+    tstep(8, 0x00ff00ffu);
+    tstep(4, 0x0f0f0f0fu);
+    tstep(2, 0x33333333u);
+    tstep(1, 0x55555555u);
+    const int gl = lane & 48, w = c & 3;
+#pragma unroll
+    for (int h2 = 0; h2 < 2; ++h2) {
+      const int j = 2 * w + h2;
+      const unsigned lo = (unsigned)__shfl((int)tr, gl | j);
+      const unsigned up = (unsigned)__shfl((int)tr, gl | (15 - j));
+      const unsigned z0 = (unsigned)__shfl((int)tr, gl | (8 + j));
+      const unsigned upA = up & 0xfffeu, upB = (up >> 16) & 0xfffeu;
+      const unsigned hiA = (((__brev(upA) >> 16) << 1) & 0xffffu) | (z0 & 1u);
+      const unsigned hiB = (((__brev(upB) >> 16) << 1) & 0xffffu) | ((z0 >> 16) & 1u);
+      wA |= (unsigned long long)((lo & 0xffffu) | (hiA << 16)) << (32 * h2);
+      wB |= (unsigned long long)((lo >> 16) | (hiB << 16)) << (32 * h2);
+    }
+    {
+      const int sh = 16 * g;
+      const unsigned long long bA = __ballot(p256A), bB = __ballot(p256B);
+      if (c == 4) { wA = (bA >> sh) & 1ull; wB = (bB >> sh) & 1ull; }
+    }
+  }
+  // ---- publish this tile's bits; the spectra stay in v[] --------------------------------------------------------
+  const int fa = F5_FPW * wave + 2 * g;      // tile row of frame A (B: fa + 1)
+  unsigned long long* xb_mine = P.xbits + ((size_t)u * ntt + (jt + 1)) * O5_TILE_WORDS;
+  if (c < O5_XW) {
+    const op_v4u ga = {(unsigned)wA, P.epoch, (unsigned)(wA >> 32), P.epoch};
+    const op_v4u gb = {(unsigned)wB, P.epoch, (unsigned)(wB >> 32), P.epoch};
+    op_st16_sc1(&xb_mine[((fa)*O5_XW + c) * 2], ga);
+    op_st16_sc1(&xb_mine[((fa + 1) * O5_XW + c) * 2], gb);
+  }
+  __syncthreads();   // every wave is past its forward exchange: the slices are idle from here
+  if (halo_tile) return;
+
+  // ---- integer smoothing in LDS (exchange slices) -----------------------------------------------------------------
+  const int nt = P.nt, nf = P.nf;
+  const int R = NF + 2 * nt;                 // bit rows: nt of tile j - 1, the tile's 32, nt of tile j + 1
+  char* arena = reinterpret_cast<char*>(regions);
+  unsigned long long* brow = reinterpret_cast<unsigned long long*>(arena);                  // [R][O5_BW]
+  unsigned char* Hs = reinterpret_cast<unsigned char*>(arena) + (size_t)R * O5_BW * 8;      // [R][O5_KP]
+  unsigned short* Ks = reinterpret_cast<unsigned short*>(Hs + (size_t)R * O5_KP);           // [16][O5_KP]
+  if (c < O5_XW) {
+    brow[(nt + fa) * O5_BW + 1 + c] = wA;
+    brow[(nt + fa + 1) * O5_BW + 1 + c] = wB;
+  }
+  for (int r = tid; r < R; r += WAVES * 64) {
+    brow[r * O5_BW] = 0ull;
+    brow[r * O5_BW + O5_BW - 1] = 0ull;
+  }
+  // neighbour rows: one 16-byte load per 64-bit word (2 nt x 5 words <= 240: one per thread), polled until both tags are current
+  for (int i = tid; i < 2 * nt * O5_XW; i += WAVES * 64) {
+    const int side = i >= nt * O5_XW;
+    const int rem = i - side * nt * O5_XW;
+    const int rr = rem / O5_XW, w = rem - rr * O5_XW;
+    // tile j - 1 holds frames tf0 - 29 ..: frame tf0 - nt + rr is its row 29 - nt + rr; tile j + 1: frame tf0 + 32 + rr is its row 3 + rr
+    const unsigned long long* src = side ? xb_mine + O5_TILE_WORDS + ((3 + rr) * O5_XW + w) * 2
+                                         : xb_mine - O5_TILE_WORDS + ((NH - nt + rr) * O5_XW + w) * 2;
+    op_v4u gr = op_ld16_sc1(src);
+    for (int spin = 0; gr[1] != P.epoch || gr[3] != P.epoch; ++spin) {
+      if (spin >= OP_SPIN_MAX) {   // bounded: report instead of hanging the device
+        atomicOr_system(P.err, 1u);
+        s_misc[1] = 1u;            // the tile's mask is unknown: every hop it finalises becomes NaN
+        break;
+      }
+      __builtin_amdgcn_s_sleep(1);
+      gr = op_ld16_sc1(src);
+    }
+    brow[(side ? nt + NF + rr : rr) * O5_BW + 1 + w] = (unsigned long long)gr[0] | ((unsigned long long)gr[2] << 32);
+  }
+  __syncthreads();
+  // along f: H[r][f] = sum_a (nf + 1 - |a|) bit[r][f + a].  The triangle is a stack of nf + 1 centred windows (direct value at
+  // the start of a segment); H[f + 1] - H[f] = popcount(bits f + 1 .. f + nf + 1) - popcount(bits f - nf .. f).
+  {
+    auto win = [](const unsigned long long* rp, int lo, int len) -> int {   // bits [lo, lo + len) of a row, lo >= -64, len <= 31
+      const int b = lo + 64, k = b >> 6, s = b & 63;
+      unsigned long long x = rp[k] >> s;
+      if (s) x |= rp[k + 1] << (64 - s);
+      return __popcll(x & ((1ull << len) - 1ull));
+    };
+    constexpr int SEG = 33, NSEG = 8;     // 8 x 33 = 264 >= 257 bins
+    for (int task = tid; task < R * NSEG; task += WAVES * 64) {
+      const int r = task / NSEG, seg = task - r * NSEG;
+      const int f0 = seg * SEG, f1 = min(f0 + SEG, F5_F);
+      if (f0 >= F5_F) continue;
+      const unsigned long long* rp = brow + r * O5_BW;
+      int hcur = 0;
+      for (int m = 0; m <= nf; ++m) hcur += win(rp, f0 - nf + m, 2 * (nf - m) + 1);
+      unsigned char* hp = Hs + r * O5_KP;
+      hp[f0] = (unsigned char)hcur;
+      for (int f = f0; f + 1 < f1; ++f) {
+        hcur += win(rp, f + 1, nf + 1) - win(rp, f - nf, nf + 1);
+        hp[f + 1] = (unsigned char)hcur;
+      }
+    }
+  }
+  __syncthreads();
+  // along t, 16 output frames at a time: K[t][f] = sum_b (nt + 1 - |b|) H[nt + t + b][f];
+  // K[t + 1] - K[t] = sum_{b = 1 .. nt + 1} H[nt + t + b] - sum_{b = 0 .. nt} H[nt + t - b]  (two running boxcar sums)
+  float ma[16], mb[16], m256a = 0.f, m256b = 0.f;
+  const float ks = A.inv_ktot * (0.5f / 512.0f);   // K / ktot, the 1/2 of the split and the 1/512 of the inverse transform
+#pragma unroll 1
+  for (int hh = 0; hh < 2; ++hh) {
+    for (int f = tid; f < F5_F; f += WAVES * 64) {
+      const unsigned char* hc = Hs + f;
+      const int t0 = 16 * hh, r0 = nt + t0;
+      int k = 0, sup = 0, sdn = 0;
+      for (int b = -nt; b <= nt; ++b) {
+        const int hv = hc[(r0 + b) * O5_KP];
+        k += (nt + 1 - (b < 0 ? -b : b)) * hv;
+        if (b >= 1) sup += hv;
+        if (b <= 0) sdn += hv;
+      }
+      sup += hc[(r0 + nt + 1) * O5_KP];     // (r0 + nt + 1 <= R - 1 for t0 <= 16)
+      Ks[f] = (unsigned short)k;
+      for (int t = t0; t < t0 + 15; ++t) {
+        k += sup - sdn;
+        Ks[(t + 1 - t0) * O5_KP + f] = (unsigned short)k;
+        const int ra = nt + t + nt + 2, rm = nt + t + 1;
+        const int hm = hc[rm * O5_KP];
+        sup += (ra < R ? (int)hc[ra * O5_KP] : 0) - hm;
+        sdn += hm - (int)hc[t * O5_KP];
+      }
+    }
+    __syncthreads();
+    if ((wave >> 1) == hh) {     // the wavefronts whose 8 frames lie in this half take their mask entries
+      const unsigned short* KA = Ks + (fa - 16 * hh) * O5_KP;
+      const unsigned short* KB = KA + O5_KP;
+#pragma unroll
+      for (int sl = 0; sl < 16; ++sl) {
+        const int f = bin5(c, sl);
+        ma[sl] = (float)KA[f] * ks;
+        mb[sl] = (float)KB[f] * ks;
+      }
+      m256a = (float)KA[256] * (2.f * ks);
+      m256b = (float)KB[256] * (2.f * ks);
+    }
+    __syncthreads();
+  }
+
+  // ---- x mask, merge, inverse transform, window, overlap-add, store (k_apply_fast512<K>) --------------------------
+  const bool wave_live = tf0 + F5_FPW * wave + F5_FPW - 1 >= 0 && tf0 + F5_FPW * wave < G.T;
+  if (wave_live) {
+    cf na[16], nb[16];
+#pragma unroll
+    for (int sl = 0; sl < 16; ++sl) {
+      cf a, b;
+      f5_pair(v, sl, l0, a, b);
+      const cf E = {a.x + b.x, a.y - b.y}, O = {a.y + b.y, b.x - a.x};
+      const cf Ya = {E.x * ma[sl], E.y * ma[sl]}, Yb = {O.x * mb[sl], O.y * mb[sl]};
+      na[sl] = {Ya.x - Yb.y, Ya.y + Yb.x};
+      nb[sl] = {Ya.x + Yb.y, Yb.x - Ya.y};
+    }
+    auto sel = [&](cf a0, cf a1) -> cf { return {l0 ? a0.x : a1.x, l0 ? a0.y : a1.y}; };
+    cf nv[32];
+    {
+      const cf z0 = {v[0].x * (2.f * ma[0]), v[0].y * (2.f * mb[0])};
+      const cf z8 = {v[8].x * m256a, v[8].y * m256b};
+      nv[0] = sel(z0, na[0]);
+      nv[8] = z8;
+      nv[31] = nb[0];
+    }
+#pragma unroll
+    for (int i = 1; i < 8; ++i) nv[i] = na[i];
+    {
+      const cf keep8 = nv[8];
+      nv[8] = sel(keep8, na[8]);
+    }
+#pragma unroll
+    for (int i = 9; i < 16; ++i) nv[i] = sel(nb[16 - i], na[i]);
+#pragma unroll
+    for (int i = 16; i < 24; ++i) nv[i] = sel(na[i - 8], nb[31 - i]);
+#pragma unroll
+    for (int i = 24; i < 31; ++i) nv[i] = sel(nb[39 - i], nb[31 - i]);
+    {
+      const cf keep31 = nv[31];
+      nv[31] = sel(nb[8], keep31);
+    }
+#pragma unroll
+    for (int i = 0; i < 32; ++i) v[i] = nv[i];
+    {
+      int zi = 0, ci = c;
+      asm volatile("" : "+v"(zi), "+v"(ci));
+      fft512_inv_half(v, fb + zi, tw512 + zi, ci);
+    }
+  }
+  float* acc = reinterpret_cast<float*>(regions + wave * WAVE_CX_H);
+  static_assert((F5_FPW + 3) * F5_HP * 4 <= WAVE_CX_H * 8, "hop accumulators must fit the wave's slice");
+#pragma unroll
+  for (int j = 0; j < 4; ++j) {
+    const int fA = 2 * g, fB = 2 * g + 1;
+    const bool firstA = j == 0, firstB = (j == 0) || (g == 3);
+#pragma unroll
+    for (int rr = 0; rr < 8; ++rr) {
+      const int r = 8 * j + rr;
+      const float ws = swin[c + 16 * r];
+      float* dA = acc + (fA + j) * F5_HP + c + 16 * rr;
+      float* dB = acc + (fB + j) * F5_HP + c + 16 * rr;
+      float ya = wave_live ? v[r].x * ws : 0.f, yb = wave_live ? v[r].y * ws : 0.f;
+      if (!firstA) ya += *dA;
+      *dA = ya;
+      if (!firstB) yb += *dB;
+      *dB = yb;
+    }
+    wave_lds_sync();
+  }
+  __syncthreads();
+  const float poison = s_misc[1] != 0u ? __uint_as_float(0x7fc00000u) : 0.f;
+  const float* fr = reinterpret_cast<const float*>(regions);
+  const int s4 = (tid & 31) * 4;
+  for (int jj = 3 + (tid >> 5); jj < NF; jj += (WAVES * 64) >> 5) {
+    const int64_t h = tf0 + jj;
+    if (h < A.h_begin || h >= A.h_end) continue;
+    const int wv = jj >> 3, lh = jj & 7;
+    float4 a4 = make_float4(0.f, 0.f, 0.f, 0.f);
+    if (wv >= 1 && lh <= 2) a4 = *reinterpret_cast<const float4*>(&fr[(wv - 1) * WAVE_CX_H * 2 + (lh + 8) * F5_HP + s4]);
+    {
+      const float4 f4 = *reinterpret_cast<const float4*>(&fr[wv * WAVE_CX_H * 2 + lh * F5_HP + s4]);
+      a4.x += f4.x; a4.y += f4.y; a4.z += f4.z; a4.w += f4.w;
+    }
+    a4.x += poison; a4.y += poison; a4.z += poison; a4.w += poison;
+    bool all_valid = true;
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+      const int64_t ti = h - q;
+      if (ti < 0 || ti >= G.T) all_valid = false;
+    }
+    if (!A.normalize) {
+    } else if (all_valid) {
+      const float4 n4 = *reinterpret_cast<const float4*>(&A.invn[s4]);
+      a4.x *= n4.x; a4.y *= n4.y; a4.z *= n4.z; a4.w *= n4.w;
+    } else {
+      float4 nrm = make_float4(0.f, 0.f, 0.f, 0.f);
+#pragma unroll
+      for (int q = 0; q < 4; ++q) {
+        const int64_t ti = h - q;
+        if (ti >= 0 && ti < G.T) {
+          const float4 w4 = *reinterpret_cast<const float4*>(&A.wsq[F5_H * q + s4]);
+          nrm.x += w4.x; nrm.y += w4.y; nrm.z += w4.z; nrm.w += w4.w;
+        }
+      }
+      a4.x /= (nrm.x > 1e-10f ? nrm.x : 1.f);
+      a4.y /= (nrm.y > 1e-10f ? nrm.y : 1.f);
+      a4.z /= (nrm.z > 1e-10f ? nrm.z : 1.f);
+      a4.w /= (nrm.w > 1e-10f ? nrm.w : 1.f);
+    }
+    {
+      const int64_t pb = h * F5_H - G.padL;
+      const int64_t gi0 = chunk * A.om.g_step + (pb - A.om.p0);
+      if (A.om.dtype == 0 && pb >= A.om.p0 && pb + F5_H <= A.om.p1 && pb + F5_H <= G.Lout && gi0 >= A.om.g_lo &&
+          gi0 + F5_H <= A.om.g_hi) {
+        float* dst = (float*)A.om.out + (row * A.om.stride + gi0 - A.om.g0 + s4);
+        if ((reinterpret_cast<uintptr_t>(dst) & 15) == 0) {
+          *reinterpret_cast<float4*>(dst) = a4;
+          continue;
+        }
+      }
+    }
+    const float vals[4] = {a4.x, a4.y, a4.z, a4.w};
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {
+      const int64_t p = h * F5_H + s4 + e - G.padL;
+      if (p < A.om.p0 || p >= A.om.p1) continue;
+      const int64_t gi = chunk * A.om.g_step + (p - A.om.p0);
+      if (gi < A.om.g_lo || gi >= A.om.g_hi) continue;
+      store_sample(A.om.out, A.om.dtype, row * A.om.stride + gi - A.om.g0, p < G.Lout ? vals[e] : 0.f);
+    }
+  }
+}
+
+}  // namespace fast
+}  // namespace sg
