@@ -152,6 +152,7 @@ struct sg_handle {
   bool mr_ok = false;                // n_fft even, n_fft / 2 <= 2048 with prime factors <= 13, not a power of two: the float32 and
   MrPlan mr{};                       // float64 STFT / decision / apply kernels of mixed.hpp (run-time radix schedule) instead of chirp-z
   DevBuf mr_pt32, mr_pt64;           // the plan's per-pass twiddle tables (mr_pass_tables)
+  DevBuf o5tab;                      // k_gate_onepass512: MFMA operands + byte expansion (onepass512.hpp)
   DevBuf czt_tw64, czt_ch64, czt_bh64, czt_tw32, czt_ch32, czt_bh32;
   bool force_noseam = false;
   bool force_nolean = false;         // SG_OPT_FORCE_NOLEAN: full-size slices + stored frames (2 waves/SIMD)
@@ -1214,6 +1215,27 @@ extern "C" int sg_create(const sg_params* p, const double* window_host, sg_handl
       }
     }
   }
+  if (!rc && h->fast5_ok && p->smooth_mask && p->n_grad_freq <= fast::O5_MAX_NF && p->n_grad_time <= fast::O5_MAX_NT) {
+    // operands of k_gate_onepass512's MFMA smoothing (onepass512.hpp), v_mfma_i32_16x16x32_i8 layout: lane l = (q = l / 16,
+    // j = l % 16) supplies bytes e = 0..7 = k slots 8 q + e of row / column j
+    const int nf = p->n_grad_freq, nt = p->n_grad_time;
+    std::vector<unsigned long long> tb(448, 0ull);
+    auto wt = [&](int d) { const int ad = d < 0 ? -d : d; return ad <= nt ? nt + 1 - ad : 0; };
+    for (int l = 0; l < 64; ++l) {
+      const int q = l / 16, j = l % 16;
+      for (int e = 0; e < 8; ++e) {
+        const int a = 8 * q + e - 8 - j, aa = a < 0 ? -a : a;
+        tb[l] |= (unsigned long long)(aa <= nf ? nf + 1 - aa : 0) << (8 * e);
+        // k slot 8 q + e: row 4 q + e of the first block (e < 4) / 16 + 4 q + (e - 4) of the second; output frame j at row nt + j
+        const int r1 = e < 4 ? 4 * q + e : 16 + 4 * q + (e - 4);
+        tb[64 + l] |= (unsigned long long)wt(r1 - nt - j) << (8 * e);
+        tb[128 + l] |= (unsigned long long)wt(32 + r1 - nt - j) << (8 * e);
+      }
+    }
+    for (int v = 0; v < 256; ++v)
+      for (int e = 0; e < 8; ++e) tb[192 + v] |= (unsigned long long)((v >> e) & 1) << (8 * e);
+    rc = upload(h, h->o5tab, tb.data(), tb.size() * 8);
+  }
   if (!rc) rc = ensure(h, h->thresh, (size_t)h->FS * sizeof(double));
   if (rc) {
     g_create_error = h->err;
@@ -1235,7 +1257,7 @@ extern "C" int sg_destroy(sg_handle* h) {
                     &h->need, &h->T2, &h->part, &h->tw512, &h->invn, &h->seam, &h->ftab, &h->xbits, &h->xpart,
                     &h->xticket, &h->xtick2, &h->ftab3, &h->xexp, &h->optab, &h->nsp, &h->nsc, &h->xin, &h->czt_tw64, &h->czt_ch64,
                     &h->czt_bh64, &h->czt_tw32, &h->czt_ch32, &h->czt_bh32, &h->logtab, &h->big_twM, &h->big_tw2,
-                    &h->big_ch, &h->big_bh, &h->big_W, &h->big_W2, &h->xP, &h->xraw, &h->xM, &h->xtmp, &h->xseg, &h->invn5, &h->invn25, &h->invn20, &h->rg_count, &h->alim, &h->nss, &h->mr_pt32, &h->mr_pt64})
+                    &h->big_ch, &h->big_bh, &h->big_W, &h->big_W2, &h->xP, &h->xraw, &h->xM, &h->xtmp, &h->xseg, &h->invn5, &h->invn25, &h->invn20, &h->rg_count, &h->alim, &h->nss, &h->mr_pt32, &h->mr_pt64, &h->o5tab})
     free_buf(*b);
   delete h;
   return SG_OK;
@@ -1479,7 +1501,7 @@ static hipError_t launch_bits_any(const sg_handle* h, const View& v, const Geom&
 static bool onepass512_ok(const sg_handle* h, const Geom& g, const OutMap& om) {
   if (!h->fast5_ok || h->force_nofast || h->force_split || h->force_f64_decide || h->force_unfused || !h->fused_ok) return false;
   if (h->p.variant != SG_VARIANT_S || !h->p.stationary || !h->p.smooth_mask || h->p.prop_decrease != 1.0) return false;
-  if (h->p.n_grad_freq > fast::O5_MAX_NF || h->p.n_grad_time > fast::O5_MAX_NT || g.F != 257) return false;
+  if (h->p.n_grad_freq > fast::O5_MAX_NF || h->p.n_grad_time > fast::O5_MAX_NT || g.F != 257 || !h->o5tab.p) return false;
   if (h->tile_order == 1) return false;
   const int64_t hb = (om.p0 + g.padL) / 128, he = (om.p1 - 1 + g.padL) / 128 + 1;
   return he > hb;
@@ -1539,6 +1561,7 @@ static int stage_onepass512(sg_handle* h, const View& v, const View& vx, const G
   P.epoch = h->epoch;
   P.err = h->err_dev;
   P.nf = h->p.n_grad_freq; P.nt = h->p.n_grad_time; P.n_tiles = (int)n_tiles;
+  P.tab = (const unsigned long long*)h->o5tab.p;
   {
     // the part of a unit's window outside its tiles' spans, dealt evenly to the unit's tiles (onepass512.hpp "floor test")
     constexpr int64_t SPAN = (fast::O5_NF - 1 + 4) * 128;
@@ -1548,7 +1571,7 @@ static int stage_onepass512(sg_handle* h, const View& v, const View& vx, const G
     if (q > 0x7fffffff) FAIL(h, SG_E_UNSUPPORTED, "one-pass gate: window of %lld samples", (long long)v.Lp);
     P.scan_q = (int)q;
   }
-  const size_t lds = FAST5_LDS + 16;
+  const size_t lds = FAST5_LDS + 16 + 2048;
   {
     ProfScope ps(h, SG_STAGE_ONEPASS, st);
     auto kern = fast::k_gate_onepass512<4, false>;

@@ -103,8 +103,13 @@ __device__ __forceinline__ unsigned f5_gather(const Fast5Args& A, cf* tw512, cf*
 
 // the 16 conjugate pairs of a lane in slot order: (a, b) = (Z[k], Z[512 - k]); lane 0 pairs its self-conjugate rows
 // differently (fastpath.hpp).  Slot 0 of lane 0 is NOT a pair: v[0] = Z[0], v[8] = Z[256] are handled by the callers.
+// (round 6: the selects are v_cndmask_b32_e64 on a constant SGPR-pair lane mask -- sel_s, fastpath.hpp -- instead of `l0 ? :`
+// next to its compare: 4 cycles of the vector pipe instead of 20 each, and opaque to the SLP vectoriser, which turned the select
+// chains of the one-pass kernel into <7 x i32> operations on a stack copy of five spectrum values)
+constexpr unsigned long long F5_L0 = 0x0001000100010001ull;   // lanes with c == 0
 __device__ __forceinline__ void f5_pair(const cf* v, int sl, bool l0, cf& a, cf& b) {
-  auto sel = [&](cf a0, cf a1) -> cf { return {l0 ? a0.x : a1.x, l0 ? a0.y : a1.y}; };
+  (void)l0;
+  auto sel = [&](cf a0, cf a1) -> cf { return {sel_s(F5_L0, a0.x, a1.x), sel_s(F5_L0, a0.y, a1.y)}; };
   if (sl == 0) { a = v[0]; b = v[31]; return; }
   a = sl < 8 ? v[sl] : sel(v[8 + sl], v[sl]);
   b = sl < 8 ? sel(v[16 - sl], v[31 - sl]) : sel(v[39 - sl], v[31 - sl]);
@@ -406,7 +411,7 @@ __global__ __launch_bounds__(WAVES * 64, 3) void k_apply_fast512(Fast5Args A) {
       nb[sl] = {Ya.x + Yb.y, Yb.x - Ya.y};
     }
     // scatter back (the inverse of f5_pair): lanes >= 1: register sl <- na[sl], register 31 - sl <- nb[sl]
-    auto sel = [&](cf a0, cf a1) -> cf { return {l0 ? a0.x : a1.x, l0 ? a0.y : a1.y}; };
+    auto sel = [&](cf a0, cf a1) -> cf { return {sel_s(F5_L0, a0.x, a1.x), sel_s(F5_L0, a0.y, a1.y)}; };
     cf nv[32];
     {
       // lane 0, slot 0: Z[0] and Z[256] are their own partners: Z' = (Re Z ma, Im Z mb) with the masks of bins 0 / 256

@@ -9,10 +9,13 @@
 // the spectra in registers and
 //   1. publishes the tile's bits (32 rows x 5 words) to its neighbours as data-tagged granules {32 bits, launch epoch};
 //   2. polls the nt adjacent rows of tiles j - 1 and j + 1 (nt <= 24: the time half-width of the smoothing filter);
-//   3. smooths the (32 + 2 nt) x 257 bit tile in LDS with the exact integer separable triangle filter -- along f by a
-//      two-popcount recurrence on the bit rows (H, uint8: (nf + 1)^2 <= 255), along t by a two-boxcar recurrence per bin column
-//      (K, uint16), 16 output frames at a time so that bits + H + half of K fit the exchange slices, which are idle between the
-//      two transforms: no more LDS than k_apply_fast512 (3 workgroups per CU);
+//   3. smooths the (32 + 2 nt) x 257 bit tile with the exact integer separable triangle filter ON THE MATRIX CORES
+//      (v_mfma_i32_16x16x32_i8, the formulation of onepass.hpp): per 16-bin block, H = bits x band matrix for the five 16-row
+//      blocks of the tile (nf <= 8), then K = time weights x H for the two 16-frame halves (two 32-row k-blocks each:
+//      16 + 2 nt <= 64 rows); H never leaves the registers, bits and the K tile (uint16) live in the exchange slices, which are
+//      idle between the two transforms: 3 workgroups per CU as k_apply_fast512.  (A first build ran both directions as
+//      sliding-window recurrences in LDS -- popcounts along f, two running boxcars along t: 203 us per two minutes where the three
+//      kernels it replaces take 103.)
 // then x mask -> inverse transform -> window -> overlap-add -> store exactly as k_apply_fast512<K>.  Tiles OVERLAP by 3 frames
 // as there (29 complete hops per tile, 9 % redundant transforms): no partial hops travel between workgroups, the bits are the
 // only exchange.  Inter-workgroup protocol, deadlock freedom (tickets; publish before wait), bounded polls and NaN-poisoned
@@ -29,10 +32,16 @@ constexpr int O5_NF = 32, O5_NH = 29;              // frames / complete hops per
 constexpr int O5_XW = 5;                           // 64-bit words per bit row (257 bins)
 constexpr int O5_TILE_WORDS = O5_NF * O5_XW * 2;   // payload of one tile: 320 tagged 8-byte halves = 2560 B
 constexpr int O5_BW = O5_XW + 2;                   // bit row pitch in LDS: one zero word on each side
-constexpr int O5_KP = 264;                         // H / K row pitch (entries)
-constexpr int O5_MAX_NT = 24;                      // (32 + 2 nt) (56 + 264) + 16 x 264 x 2 bytes <= the exchange slices
-constexpr int O5_MAX_NF = 14;                      // (nf + 1)^2 <= 255: H as bytes
+constexpr int O5_ROWS = 80;                        // bit rows in LDS: five 16-row blocks (32 + 2 nt <= 80)
+constexpr int O5_KP = 272;                         // K row pitch (entries): 17 blocks of 16 bins
+constexpr int O5_MAX_NT = 24;                      // 16 + 2 nt <= 64 rows = two k-blocks of the time product
+constexpr int O5_MAX_NF = 8;                       // the 32 x 16 band matrix of the frequency product
+// constant operands (device table `tab`, 64-bit entries): [0, 64) Bf (band matrix, per lane), [64, 128) At1, [128, 192) At2 (time
+// weights of the two k-blocks), [192, 448) byte -> eight 0 / 1 bytes
 
+#ifndef O5_OCC
+#define O5_OCC 3   // workgroups per CU the register budget is set for
+#endif
 struct OnePass5Args {
   Fast5Args A;                 // view, geometry, tables, compare constants, output map, hop range, floor test (FIRST: late_args)
   unsigned long long* xbits;   // [units][n_tiles + 2][32][5][2] published mask bits: granules {32 bits, epoch}
@@ -42,10 +51,11 @@ struct OnePass5Args {
   unsigned* err;               // host-mapped word: bit 0 = a bit hand-off timed out
   int nf, nt, n_tiles;
   int scan_q;                  // in-kernel floor test: samples of the unit window's unstaged part that each tile scans
+  const unsigned long long* tab;   // MFMA operands + byte expansion (see above)
 };
 
 template <int WAVES, bool REDO = false>
-__global__ __launch_bounds__(WAVES * 64, 3) void k_gate_onepass512(OnePass5Args P) {
+__global__ __launch_bounds__(WAVES * 64, O5_OCC) void k_gate_onepass512(OnePass5Args P) {
   static_assert(WAVES == 4, "tile = 32 frames");
   extern __shared__ __attribute__((aligned(16))) char smem[];
   cf* tw512 = reinterpret_cast<cf*>(smem);
@@ -53,6 +63,7 @@ __global__ __launch_bounds__(WAVES * 64, 3) void k_gate_onepass512(OnePass5Args 
   float* swin = reinterpret_cast<float*>(regions + WAVES * WAVE_CX_H);
   float* s_t2 = swin + F5_N;                 // [257] float32 compare constants x4 (the split works on 2 X)
   unsigned* s_misc = reinterpret_cast<unsigned*>(s_t2 + 264);   // [0] ticket, [1] lost hand-off
+  unsigned long long* s_exp = reinterpret_cast<unsigned long long*>(s_misc + 4);   // [256] byte -> eight 0 / 1 bytes
   const Fast5Args& A = P.A;
   if (REDO && A.fl.alim[1] != A.tc.need_tag) return;   // no unit of this call reported (the common case)
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, g = lane >> 4, c = lane & 15;
@@ -61,6 +72,7 @@ __global__ __launch_bounds__(WAVES * 64, 3) void k_gate_onepass512(OnePass5Args 
     s_misc[0] = atomicAdd(P.ticket, 1u) - P.ticket_base;
     s_misc[1] = 0u;
   }
+  s_exp[tid] = P.tab[192 + tid];
   const unsigned fl_bound = REDO ? 0xffffffffu : floor_lazy_bound(A.fl, lane);
   __syncthreads();
   const int ntt = P.n_tiles + 2;                   // tiles per unit incl. one decide-only halo tile per side
@@ -159,35 +171,55 @@ __global__ __launch_bounds__(WAVES * 64, 3) void k_gate_onepass512(OnePass5Args 
     if (need == 2) { pA = pB = 0; aA = aB = 0; p256A = p256B = a256A = a256B = false; }
     if (!validA) { pA = 0; aA = 0; p256A = a256A = false; }
     if (!validB) { pB = 0; aB = 0; p256B = a256B = false; }
-    while (true) {   // exact re-evaluation of ambiguous cells, one at a time, whole wave cooperating
-      const unsigned long long pending = __ballot(aA != 0 || aB != 0 || a256A || a256B);
-      if (pending == 0) break;
-      const int src = __ffsll((long long)pending) - 1;
-      const unsigned sA = (unsigned)__shfl((int)aA, src), sB = (unsigned)__shfl((int)aB, src);
-      const int s256A = __shfl((int)a256A, src);
-      const int cs = src & 15, gs = src >> 4;
-      int which, f;
-      int q = 0;
-      if (sA) { which = 0; q = __ffs((int)sA) - 1; f = bin5(cs, q); }
-      else if (sB) { which = 1; q = __ffs((int)sB) - 1; f = bin5(cs, q); }
-      else if (s256A) { which = 2; f = 256; }
-      else { which = 3; f = 256; }
-      const int64_t t = tq + 2 * gs + (which & 1);
-      const Fast5Args& L = *late_args<Fast5Args>();       // (cold path: arguments re-read here; A is the FIRST member)
-      const double Pe = f5_exact_power(L, row, chunk, t, f, lane);
-      double t2 = L.tc.T2[f];
-      if (floor_live) {
-        const double fl = cell_db(L.tc.pmax[u * (int64_t)L.g.FS + f], L.mag_scale) - L.top_db;
-        if (fl > L.tc.thresh[f]) t2 = -1.0;
+    // exact re-evaluation of ambiguous cells, one at a time, whole wave cooperating.  Rare (about one wave in fifty has an
+    // ambiguous cell), but its float64 temporaries do not fit next to the 64 registers of the spectra at three waves per SIMD
+    // (the first build kept 29 of them in scratch through the hot path): the wave parks half of the spectra in its idle
+    // exchange slice for the duration (onepass.hpp does the same).
+    if (__ballot(aA != 0 || aB != 0 || a256A || a256B) != 0ull) {
+      float* park = reinterpret_cast<float*>(regions + wave * WAVE_CX_H) + lane;
+      static_assert(64 * 32 * 4 <= WAVE_CX_H * 8, "parked registers must fit the wave's slice");
+#pragma unroll
+      for (int i = 0; i < 16; ++i) {
+        park[(2 * i) * 64] = v[16 + i].x;
+        park[(2 * i + 1) * 64] = v[16 + i].y;
       }
-      if (need == 2) t2 = T2_NEVER;
-      const bool pass = Pe > t2;
-      if (lane == src) {
-        if (which == 0) { pA = (pA & ~(1u << q)) | ((pass ? 1u : 0u) << q); aA &= ~(1u << q); }
-        else if (which == 1) { pB = (pB & ~(1u << q)) | ((pass ? 1u : 0u) << q); aB &= ~(1u << q); }
-        else if (which == 2) { p256A = pass; a256A = false; }
-        else { p256B = pass; a256B = false; }
+      while (true) {   // exact re-evaluation of ambiguous cells, one at a time, whole wave cooperating
+        const unsigned long long pending = __ballot(aA != 0 || aB != 0 || a256A || a256B);
+        if (pending == 0) break;
+        const int src = __ffsll((long long)pending) - 1;
+        const unsigned sA = (unsigned)__shfl((int)aA, src), sB = (unsigned)__shfl((int)aB, src);
+        const int s256A = __shfl((int)a256A, src);
+        const int cs = src & 15, gs = src >> 4;
+        int which, f;
+        int q = 0;
+        if (sA) { which = 0; q = __ffs((int)sA) - 1; f = bin5(cs, q); }
+        else if (sB) { which = 1; q = __ffs((int)sB) - 1; f = bin5(cs, q); }
+        else if (s256A) { which = 2; f = 256; }
+        else { which = 3; f = 256; }
+        const int64_t t = tq + 2 * gs + (which & 1);
+        const Fast5Args& L = *late_args<Fast5Args>();       // (cold path: arguments re-read here; A is the FIRST member)
+        const double Pe = f5_exact_power(L, row, chunk, t, f, lane);
+        double t2 = L.tc.T2[f];
+        if (floor_live) {
+          const double fl = cell_db(L.tc.pmax[u * (int64_t)L.g.FS + f], L.mag_scale) - L.top_db;
+          if (fl > L.tc.thresh[f]) t2 = -1.0;
+        }
+        if (need == 2) t2 = T2_NEVER;
+        const bool pass = Pe > t2;
+        if (lane == src) {
+          if (which == 0) { pA = (pA & ~(1u << q)) | ((pass ? 1u : 0u) << q); aA &= ~(1u << q); }
+          else if (which == 1) { pB = (pB & ~(1u << q)) | ((pass ? 1u : 0u) << q); aB &= ~(1u << q); }
+          else if (which == 2) { p256A = pass; a256A = false; }
+          else { p256B = pass; a256B = false; }
+        }
       }
+      wave_lds_sync();
+#pragma unroll
+      for (int i = 0; i < 16; ++i) {
+        v[16 + i].x = park[(2 * i) * 64];
+        v[16 + i].y = park[(2 * i + 1) * 64];
+      }
+      wave_lds_sync();
     }
     // pack (k_decide_fast512): 16 x 16 bit transpose across the lane group, then lane c < 4 assembles word c, lane 4 bin 256
     unsigned tr = (pA & 0xffffu) | (pB << 16);
@@ -233,20 +265,23 @@ __global__ __launch_bounds__(WAVES * 64, 3) void k_gate_onepass512(OnePass5Args 
   __syncthreads();   // every wave is past its forward exchange: the slices are idle from here
   if (halo_tile) return;
 
-  // ---- integer smoothing in LDS (exchange slices) -----------------------------------------------------------------
-  const int nt = P.nt, nf = P.nf;
-  const int R = NF + 2 * nt;                 // bit rows: nt of tile j - 1, the tile's 32, nt of tile j + 1
+  // ---- integer smoothing on the matrix cores (onepass.hpp) ----------------------------------------------------------
+  const int nt = P.nt;
   char* arena = reinterpret_cast<char*>(regions);
-  unsigned long long* brow = reinterpret_cast<unsigned long long*>(arena);                  // [R][O5_BW]
-  unsigned char* Hs = reinterpret_cast<unsigned char*>(arena) + (size_t)R * O5_BW * 8;      // [R][O5_KP]
-  unsigned short* Ks = reinterpret_cast<unsigned short*>(Hs + (size_t)R * O5_KP);           // [16][O5_KP]
+  unsigned long long* brow = reinterpret_cast<unsigned long long*>(arena);                           // [O5_ROWS][O5_BW]
+  unsigned short* Ks = reinterpret_cast<unsigned short*>(arena + (size_t)O5_ROWS * O5_BW * 8);       // [32][O5_KP]
+  static_assert(O5_ROWS * O5_BW * 8 + O5_NF * O5_KP * 2 <= WAVES * WAVE_CX_H * 8, "bits + K tile must fit the exchange slices");
   if (c < O5_XW) {
     brow[(nt + fa) * O5_BW + 1 + c] = wA;
     brow[(nt + fa + 1) * O5_BW + 1 + c] = wB;
   }
-  for (int r = tid; r < R; r += WAVES * 64) {
+  for (int r = tid; r < O5_ROWS; r += WAVES * 64) {
     brow[r * O5_BW] = 0ull;
     brow[r * O5_BW + O5_BW - 1] = 0ull;
+    if (r >= NF + 2 * nt) {       // rows past the neighbours': zero (the last k-block reads them)
+#pragma unroll
+      for (int w = 1; w <= O5_XW; ++w) brow[r * O5_BW + w] = 0ull;
+    }
   }
   // neighbour rows: one 16-byte load per 64-bit word (2 nt x 5 words <= 240: one per thread), polled until both tags are current
   for (int i = tid; i < 2 * nt * O5_XW; i += WAVES * 64) {
@@ -268,75 +303,58 @@ __global__ __launch_bounds__(WAVES * 64, 3) void k_gate_onepass512(OnePass5Args 
     }
     brow[(side ? nt + NF + rr : rr) * O5_BW + 1 + w] = (unsigned long long)gr[0] | ((unsigned long long)gr[2] << 32);
   }
+  const int q4 = lane >> 4, j16 = lane & 15;
+  const long Bf = (long)P.tab[lane], At1 = (long)P.tab[64 + lane], At2 = (long)P.tab[128 + lane];
   __syncthreads();
-  // along f: H[r][f] = sum_a (nf + 1 - |a|) bit[r][f + a].  The triangle is a stack of nf + 1 centred windows (direct value at
-  // the start of a segment); H[f + 1] - H[f] = popcount(bits f + 1 .. f + nf + 1) - popcount(bits f - nf .. f).
   {
-    auto win = [](const unsigned long long* rp, int lo, int len) -> int {   // bits [lo, lo + len) of a row, lo >= -64, len <= 31
-      const int b = lo + 64, k = b >> 6, s = b & 63;
-      unsigned long long x = rp[k] >> s;
-      if (s) x |= rp[k + 1] << (64 - s);
-      return __popcll(x & ((1ull << len) - 1ull));
-    };
-    constexpr int SEG = 33, NSEG = 8;     // 8 x 33 = 264 >= 257 bins
-    for (int task = tid; task < R * NSEG; task += WAVES * 64) {
-      const int r = task / NSEG, seg = task - r * NSEG;
-      const int f0 = seg * SEG, f1 = min(f0 + SEG, F5_F);
-      if (f0 >= F5_F) continue;
-      const unsigned long long* rp = brow + r * O5_BW;
-      int hcur = 0;
-      for (int m = 0; m <= nf; ++m) hcur += win(rp, f0 - nf + m, 2 * (nf - m) + 1);
-      unsigned char* hp = Hs + r * O5_KP;
-      hp[f0] = (unsigned char)hcur;
-      for (int f = f0; f + 1 < f1; ++f) {
-        hcur += win(rp, f + 1, nf + 1) - win(rp, f - nf, nf + 1);
-        hp[f + 1] = (unsigned char)hcur;
+    // Per 16-bin block b:  H[row][bin] = sum_k bit[row][16 b - 8 + k] vf[k - 8 - j]   (A = 16 rows x 32 bins of 0 / 1 bytes, B = Bf)
+    // for the five row blocks; the result layout (lane = bin column, 4 consecutive rows per lane group) IS the B layout of
+    //   K[frame][bin] = sum_slot vt[row(slot) - nt - frame] H[row(slot)][bin]       (A = At1 / At2, B = two packed H blocks)
+    // Output frames 16 hh + j (hh = 0, 1) sit at bit row nt + 16 hh + j and reach rows 16 hh + j .. 16 hh + j + 2 nt: row blocks
+    // hh .. hh + 3; k-slot 8 q + e of the first product = row 4 q + e of block hh (e < 4) / block hh + 1 (e >= 4), of the second
+    // = blocks hh + 2 / hh + 3 -- the same weights for both halves.
+    typedef int o5_v4i __attribute__((ext_vector_type(4)));
+    const o5_v4i zero4 = {0, 0, 0, 0};
+    const unsigned char* wbb = reinterpret_cast<const unsigned char*>(brow);
+    constexpr int WPB = O5_BW * 8;
+    for (int b = wave; b < 17; b += WAVES) {
+      unsigned hp[5];
+#pragma unroll
+      for (int m = 0; m < 5; ++m) {
+        const long a = (long)s_exp[wbb[(16 * m + j16) * WPB + 7 + q4 + 2 * b]];
+        const o5_v4i hv = __builtin_amdgcn_mfma_i32_16x16x32_i8(a, Bf, zero4, 0, 0, 0);
+        hp[m] = (unsigned)hv[0] | ((unsigned)hv[1] << 8) | ((unsigned)hv[2] << 16) | ((unsigned)hv[3] << 24);
+      }
+#pragma unroll
+      for (int hh = 0; hh < 2; ++hh) {
+        const long bt1 = (long)(((unsigned long long)hp[hh + 1] << 32) | (unsigned long long)hp[hh]);
+        const long bt2 = (long)(((unsigned long long)hp[hh + 3] << 32) | (unsigned long long)hp[hh + 2]);
+        o5_v4i d = __builtin_amdgcn_mfma_i32_16x16x32_i8(At1, bt1, zero4, 0, 0, 0);
+        d = __builtin_amdgcn_mfma_i32_16x16x32_i8(At2, bt2, d, 0, 0, 0);
+        unsigned short* kd = Ks + (16 * hh + 4 * q4) * O5_KP + 16 * b + j16;   // lane group q4: output frames 4 q4 .. 4 q4 + 3
+        kd[0] = (unsigned short)d[0];
+        kd[O5_KP] = (unsigned short)d[1];
+        kd[2 * O5_KP] = (unsigned short)d[2];
+        kd[3 * O5_KP] = (unsigned short)d[3];
       }
     }
   }
   __syncthreads();
-  // along t, 16 output frames at a time: K[t][f] = sum_b (nt + 1 - |b|) H[nt + t + b][f];
-  // K[t + 1] - K[t] = sum_{b = 1 .. nt + 1} H[nt + t + b] - sum_{b = 0 .. nt} H[nt + t - b]  (two running boxcar sums)
-  float ma[16], mb[16], m256a = 0.f, m256b = 0.f;
-  const float ks = A.inv_ktot * (0.5f / 512.0f);   // K / ktot, the 1/2 of the split and the 1/512 of the inverse transform
-#pragma unroll 1
-  for (int hh = 0; hh < 2; ++hh) {
-    for (int f = tid; f < F5_F; f += WAVES * 64) {
-      const unsigned char* hc = Hs + f;
-      const int t0 = 16 * hh, r0 = nt + t0;
-      int k = 0, sup = 0, sdn = 0;
-      for (int b = -nt; b <= nt; ++b) {
-        const int hv = hc[(r0 + b) * O5_KP];
-        k += (nt + 1 - (b < 0 ? -b : b)) * hv;
-        if (b >= 1) sup += hv;
-        if (b <= 0) sdn += hv;
-      }
-      sup += hc[(r0 + nt + 1) * O5_KP];     // (r0 + nt + 1 <= R - 1 for t0 <= 16)
-      Ks[f] = (unsigned short)k;
-      for (int t = t0; t < t0 + 15; ++t) {
-        k += sup - sdn;
-        Ks[(t + 1 - t0) * O5_KP + f] = (unsigned short)k;
-        const int ra = nt + t + nt + 2, rm = nt + t + 1;
-        const int hm = hc[rm * O5_KP];
-        sup += (ra < R ? (int)hc[ra * O5_KP] : 0) - hm;
-        sdn += hm - (int)hc[t * O5_KP];
-      }
-    }
-    __syncthreads();
-    if ((wave >> 1) == hh) {     // the wavefronts whose 8 frames lie in this half take their mask entries
-      const unsigned short* KA = Ks + (fa - 16 * hh) * O5_KP;
-      const unsigned short* KB = KA + O5_KP;
+  float ma[16], mb[16], m256a, m256b;
+  {
+    const float ks = A.inv_ktot * (0.5f / 512.0f);   // K / ktot, the 1/2 of the split and the 1/512 of the inverse transform
+    const unsigned short* KA = Ks + fa * O5_KP;
+    const unsigned short* KB = KA + O5_KP;
 #pragma unroll
-      for (int sl = 0; sl < 16; ++sl) {
-        const int f = bin5(c, sl);
-        ma[sl] = (float)KA[f] * ks;
-        mb[sl] = (float)KB[f] * ks;
-      }
-      m256a = (float)KA[256] * (2.f * ks);
-      m256b = (float)KB[256] * (2.f * ks);
+    for (int sl = 0; sl < 16; ++sl) {
+      const int f = bin5(c, sl);
+      ma[sl] = (float)KA[f] * ks;
+      mb[sl] = (float)KB[f] * ks;
     }
-    __syncthreads();
+    m256a = (float)KA[256] * (2.f * ks);
+    m256b = (float)KB[256] * (2.f * ks);
   }
+  __syncthreads();   // every lane has its mask entries: the slices are free for the inverse transform
 
   // ---- x mask, merge, inverse transform, window, overlap-add, store (k_apply_fast512<K>) --------------------------
   const bool wave_live = tf0 + F5_FPW * wave + F5_FPW - 1 >= 0 && tf0 + F5_FPW * wave < G.T;
@@ -351,7 +369,7 @@ __global__ __launch_bounds__(WAVES * 64, 3) void k_gate_onepass512(OnePass5Args 
       na[sl] = {Ya.x - Yb.y, Ya.y + Yb.x};
       nb[sl] = {Ya.x + Yb.y, Yb.x - Ya.y};
     }
-    auto sel = [&](cf a0, cf a1) -> cf { return {l0 ? a0.x : a1.x, l0 ? a0.y : a1.y}; };
+    auto sel = [&](cf a0, cf a1) -> cf { return {sel_s(F5_L0, a0.x, a1.x), sel_s(F5_L0, a0.y, a1.y)}; };
     cf nv[32];
     {
       const cf z0 = {v[0].x * (2.f * ma[0]), v[0].y * (2.f * mb[0])};
