@@ -31,6 +31,7 @@
 #include "fast512.hpp"
 #include "onepass512.hpp"
 #include "fast256.hpp"
+#include "onepass256.hpp"
 #include "fast2048.hpp"
 #include "nonstat.hpp"
 #include "fast64.hpp"
@@ -152,7 +153,7 @@ struct sg_handle {
   bool mr_ok = false;                // n_fft even, n_fft / 2 <= 2048 with prime factors <= 13, not a power of two: the float32 and
   MrPlan mr{};                       // float64 STFT / decision / apply kernels of mixed.hpp (run-time radix schedule) instead of chirp-z
   DevBuf mr_pt32, mr_pt64;           // the plan's per-pass twiddle tables (mr_pass_tables)
-  DevBuf o5tab;                      // k_gate_onepass512: MFMA operands + byte expansion (onepass512.hpp)
+  DevBuf o5tab, o25tab;              // k_gate_onepass512 / 256: MFMA operands + byte expansion (onepass512.hpp, onepass256.hpp)
   DevBuf czt_tw64, czt_ch64, czt_bh64, czt_tw32, czt_ch32, czt_bh32;
   bool force_noseam = false;
   bool force_nolean = false;         // SG_OPT_FORCE_NOLEAN: full-size slices + stored frames (2 waves/SIMD)
@@ -1236,6 +1237,26 @@ extern "C" int sg_create(const sg_params* p, const double* window_host, sg_handl
       for (int e = 0; e < 8; ++e) tb[192 + v] |= (unsigned long long)((v >> e) & 1) << (8 * e);
     rc = upload(h, h->o5tab, tb.data(), tb.size() * 8);
   }
+  if (!rc && h->fast25_ok && p->smooth_mask && p->n_grad_freq <= fast::O25_MAX_NF && p->n_grad_time <= fast::O25_MAX_NT) {
+    // k_gate_onepass256 (onepass256.hpp): the same operands with THREE k-blocks of time weights
+    const int nf = p->n_grad_freq, nt = p->n_grad_time;
+    std::vector<unsigned long long> tb(512, 0ull);
+    auto wt = [&](int d) { const int ad = d < 0 ? -d : d; return ad <= nt ? nt + 1 - ad : 0; };
+    for (int l = 0; l < 64; ++l) {
+      const int q = l / 16, j = l % 16;
+      for (int e = 0; e < 8; ++e) {
+        const int a = 8 * q + e - 8 - j, aa = a < 0 ? -a : a;
+        tb[l] |= (unsigned long long)(aa <= nf ? nf + 1 - aa : 0) << (8 * e);
+        const int r1 = e < 4 ? 4 * q + e : 16 + 4 * q + (e - 4);
+        tb[64 + l] |= (unsigned long long)wt(r1 - nt - j) << (8 * e);
+        tb[128 + l] |= (unsigned long long)wt(32 + r1 - nt - j) << (8 * e);
+        tb[192 + l] |= (unsigned long long)wt(64 + r1 - nt - j) << (8 * e);
+      }
+    }
+    for (int v = 0; v < 256; ++v)
+      for (int e = 0; e < 8; ++e) tb[256 + v] |= (unsigned long long)((v >> e) & 1) << (8 * e);
+    rc = upload(h, h->o25tab, tb.data(), tb.size() * 8);
+  }
   if (!rc) rc = ensure(h, h->thresh, (size_t)h->FS * sizeof(double));
   if (rc) {
     g_create_error = h->err;
@@ -1257,7 +1278,7 @@ extern "C" int sg_destroy(sg_handle* h) {
                     &h->need, &h->T2, &h->part, &h->tw512, &h->invn, &h->seam, &h->ftab, &h->xbits, &h->xpart,
                     &h->xticket, &h->xtick2, &h->ftab3, &h->xexp, &h->optab, &h->nsp, &h->nsc, &h->xin, &h->czt_tw64, &h->czt_ch64,
                     &h->czt_bh64, &h->czt_tw32, &h->czt_ch32, &h->czt_bh32, &h->logtab, &h->big_twM, &h->big_tw2,
-                    &h->big_ch, &h->big_bh, &h->big_W, &h->big_W2, &h->xP, &h->xraw, &h->xM, &h->xtmp, &h->xseg, &h->invn5, &h->invn25, &h->invn20, &h->rg_count, &h->alim, &h->nss, &h->mr_pt32, &h->mr_pt64, &h->o5tab})
+                    &h->big_ch, &h->big_bh, &h->big_W, &h->big_W2, &h->xP, &h->xraw, &h->xM, &h->xtmp, &h->xseg, &h->invn5, &h->invn25, &h->invn20, &h->rg_count, &h->alim, &h->nss, &h->mr_pt32, &h->mr_pt64, &h->o5tab, &h->o25tab})
     free_buf(*b);
   delete h;
   return SG_OK;
@@ -1498,16 +1519,23 @@ static int stage_prep_floor(sg_handle* h, const View& v, const Geom& g, int64_t 
 template <int MODE>
 static hipError_t launch_bits_any(const sg_handle* h, const View& v, const Geom& g, int64_t units, const ThreshConsts& tc,
                                   unsigned long long* pmax_bits, unsigned long long* bits, int wpr, hipStream_t st);
-static bool onepass512_ok(const sg_handle* h, const Geom& g, const OutMap& om) {
-  if (!h->fast5_ok || h->force_nofast || h->force_split || h->force_f64_decide || h->force_unfused || !h->fused_ok) return false;
+// geometry constants of a small one-pass gate (onepass512.hpp / onepass256.hpp)
+struct OnePassSmall {
+  int hop, NF, NH, tile_words, xw, max_nf, max_nt, F;
+  size_t lds;
+};
+static bool onepass_small_ok(const sg_handle* h, const Geom& g, const OutMap& om, const OnePassSmall& S, const DevBuf& tab) {
+  if (h->force_nofast || h->force_split || h->force_f64_decide || h->force_unfused || !h->fused_ok) return false;
   if (h->p.variant != SG_VARIANT_S || !h->p.stationary || !h->p.smooth_mask || h->p.prop_decrease != 1.0) return false;
-  if (h->p.n_grad_freq > fast::O5_MAX_NF || h->p.n_grad_time > fast::O5_MAX_NT || g.F != 257 || !h->o5tab.p) return false;
+  if (h->p.n_grad_freq > S.max_nf || h->p.n_grad_time > S.max_nt || g.F != S.F || !tab.p) return false;
   if (h->tile_order == 1) return false;
-  const int64_t hb = (om.p0 + g.padL) / 128, he = (om.p1 - 1 + g.padL) / 128 + 1;
+  const int64_t hb = (om.p0 + g.padL) / S.hop, he = (om.p1 - 1 + g.padL) / S.hop + 1;
   return he > hb;
 }
-static int stage_onepass512(sg_handle* h, const View& v, const View& vx, const Geom& g, int64_t ub, const OutMap& om,
-                            hipStream_t st) {
+// PARGS: the kernel's argument struct (its member A already filled with the geometry's tables); launch(P, redo) enqueues it
+template <typename PARGS, typename LAUNCH>
+static int stage_onepass_small(sg_handle* h, const View& v, const View& vx, const Geom& g, int64_t ub, const OutMap& om,
+                               hipStream_t st, const OnePassSmall& S, PARGS P, const DevBuf& tab, LAUNCH launch) {
   int rc;
   if ((rc = handoff_prepare(h, st))) return rc;
   const unsigned live_stamp = h->err_host[1];
@@ -1542,18 +1570,16 @@ static int stage_onepass512(sg_handle* h, const View& v, const View& vx, const G
     tc = ThreshConsts{(const double*)h->T2.p, (const double*)h->thresh.p, (const double*)h->pmax.p, (const int*)h->need.p, need_tag};
     fl = FloorLazy{(unsigned*)h->alim.p, nb, h->err_dev + 1, h->epoch};
   }
-  fast::OnePass5Args P{};
-  P.A = fast5_args(h, v, g);
   P.A.tc = tc;
   P.A.fl = fl;
   P.A.inv_ktot = (float)(1.0 / (double)h->ktot);
   P.A.om = om;
   P.A.normalize = 1;
-  P.A.h_begin = (om.p0 + g.padL) / 128;
-  P.A.h_end = (om.p1 - 1 + g.padL) / 128 + 1;
+  P.A.h_begin = (om.p0 + g.padL) / S.hop;
+  P.A.h_end = (om.p1 - 1 + g.padL) / S.hop + 1;
   const int64_t nh = P.A.h_end - P.A.h_begin;
-  const int64_t n_tiles = (nh + fast::O5_NH - 1) / fast::O5_NH, ntt = n_tiles + 2;
-  if ((rc = ensure_zeroed(h, h->xbits, (size_t)ub * ntt * fast::O5_TILE_WORDS * 8, st))) return rc;
+  const int64_t n_tiles = (nh + S.NH - 1) / S.NH, ntt = n_tiles + 2;
+  if ((rc = ensure_zeroed(h, h->xbits, (size_t)ub * ntt * S.tile_words * 8, st))) return rc;
   P.xbits = (unsigned long long*)h->xbits.p;
   P.ticket = (unsigned*)h->xticket.p;
   P.ticket_base = h->ticket_base;
@@ -1561,23 +1587,20 @@ static int stage_onepass512(sg_handle* h, const View& v, const View& vx, const G
   P.epoch = h->epoch;
   P.err = h->err_dev;
   P.nf = h->p.n_grad_freq; P.nt = h->p.n_grad_time; P.n_tiles = (int)n_tiles;
-  P.tab = (const unsigned long long*)h->o5tab.p;
+  P.tab = (const unsigned long long*)tab.p;
   {
-    // the part of a unit's window outside its tiles' spans, dealt evenly to the unit's tiles (onepass512.hpp "floor test")
-    constexpr int64_t SPAN = (fast::O5_NF - 1 + 4) * 128;
-    const int64_t sp0 = (P.A.h_begin - 3 - fast::O5_NH) * 128 - g.padL, sp1 = (P.A.h_begin - 3 + n_tiles * fast::O5_NH) * 128 - g.padL + SPAN;
+    // the part of a unit's window outside its tiles' spans, dealt evenly to the unit's tiles ("floor test" in the kernels)
+    const int64_t SPAN = (int64_t)(S.NF - 1 + 4) * S.hop;
+    const int64_t sp0 = (P.A.h_begin - 3 - S.NH) * S.hop - g.padL, sp1 = (P.A.h_begin - 3 + n_tiles * S.NH) * S.hop - g.padL + SPAN;
     const int64_t inside = std::max<int64_t>(0, std::min<int64_t>(v.Lp, sp1) - std::max<int64_t>(0, sp0));
     const int64_t q = (v.Lp - inside + ntt - 1) / ntt;
     if (q > 0x7fffffff) FAIL(h, SG_E_UNSUPPORTED, "one-pass gate: window of %lld samples", (long long)v.Lp);
     P.scan_q = (int)q;
   }
-  const size_t lds = FAST5_LDS + 16 + 2048;
+  const dim3 grid((unsigned)(ub * ntt));
   {
     ProfScope ps(h, SG_STAGE_ONEPASS, st);
-    auto kern = fast::k_gate_onepass512<4, false>;
-    HIPCHK(h, set_lds(reinterpret_cast<const void*>(kern), lds));
-    hipLaunchKernelGGL(kern, dim3((unsigned)(ub * ntt)), dim3(256), lds, st, P);
-    HIPCHK(h, hipGetLastError());
+    HIPCHK(h, launch(P, false, grid));
   }
   if (lazy) {
     // the units whose floor test fired: float64 band maxima, then the gate again with them (both return at once otherwise)
@@ -1587,18 +1610,36 @@ static int stage_onepass512(sg_handle* h, const View& v, const View& vx, const G
     P.epoch = h->epoch;
     P.ticket = (unsigned*)h->xticket.p + 8;   // its own counter (zeroed by the first launch's ticket-0 workgroup)
     P.ticket_base = 0;
-    auto kern = fast::k_gate_onepass512<4, true>;
-    HIPCHK(h, set_lds(reinterpret_cast<const void*>(kern), lds));
-    hipLaunchKernelGGL(kern, dim3((unsigned)(ub * ntt)), dim3(256), lds, st, P);
-    HIPCHK(h, hipGetLastError());
+    HIPCHK(h, launch(P, true, grid));
   }
   h->dbg_xbits = true;
-  h->dbg_trows = fast::O5_NF; h->dbg_tstep = fast::O5_NH; h->dbg_twords = fast::O5_TILE_WORDS; h->dbg_txw = fast::O5_XW;
+  h->dbg_trows = S.NF; h->dbg_tstep = S.NH; h->dbg_twords = S.tile_words; h->dbg_txw = S.xw;
   h->dbg_tf0 = P.A.h_begin - 3;
   h->dbg_ntt = (int)ntt;
-  h->dbg_db = std::max<int64_t>(0, P.A.h_begin - 3 - fast::O5_NH);
-  h->dbg_de = std::min<int64_t>(g.T, P.A.h_begin - 3 + fast::O5_NH * (n_tiles + 1) + 3);
+  h->dbg_db = std::max<int64_t>(0, P.A.h_begin - 3 - S.NH);
+  h->dbg_de = std::min<int64_t>(g.T, P.A.h_begin - 3 + (int64_t)S.NH * (n_tiles + 1) + 3);
   return SG_OK;
+}
+
+static const OnePassSmall O5_GEOM{128, fast::O5_NF, fast::O5_NH, fast::O5_TILE_WORDS, fast::O5_XW, fast::O5_MAX_NF, fast::O5_MAX_NT, 257,
+                                  FAST5_LDS + 16 + 2048};
+static bool onepass512_ok(const sg_handle* h, const Geom& g, const OutMap& om) {
+  return h->fast5_ok && onepass_small_ok(h, g, om, O5_GEOM, h->o5tab);
+}
+static int stage_onepass512(sg_handle* h, const View& v, const View& vx, const Geom& g, int64_t ub, const OutMap& om,
+                            hipStream_t st) {
+  fast::OnePass5Args P{};
+  P.A = fast5_args(h, v, g);
+  auto launch = [&](const fast::OnePass5Args& Q, bool redo, dim3 grid) -> hipError_t {
+    auto go = [&](auto kern) -> hipError_t {
+      hipError_t e = set_lds(reinterpret_cast<const void*>(kern), O5_GEOM.lds);
+      if (e != hipSuccess) return e;
+      hipLaunchKernelGGL(kern, grid, dim3(256), O5_GEOM.lds, st, Q);
+      return hipGetLastError();
+    };
+    return redo ? go(fast::k_gate_onepass512<4, true>) : go(fast::k_gate_onepass512<4, false>);
+  };
+  return stage_onepass_small(h, v, vx, g, ub, om, st, O5_GEOM, P, h->o5tab, launch);
 }
 
 // ------------------------------------------------------------------------------------------
@@ -1673,6 +1714,28 @@ static int stage_apply256(sg_handle* h, const View& v, const Geom& g, int64_t ub
   }
   HIPCHK(h, hipGetLastError());
   return SG_OK;
+}
+
+// (round 6) one-pass gate for n_fft = 256 (onepass256.hpp)
+static const OnePassSmall O25_GEOM{64, fast::O25_NF, fast::O25_NH, fast::O25_TILE_WORDS, fast::O25_XW, fast::O25_MAX_NF, fast::O25_MAX_NT,
+                                   129, FAST25_LDS + 16 + 2048};
+static bool onepass256_ok(const sg_handle* h, const Geom& g, const OutMap& om) {
+  return h->fast25_ok && onepass_small_ok(h, g, om, O25_GEOM, h->o25tab);
+}
+static int stage_onepass256(sg_handle* h, const View& v, const View& vx, const Geom& g, int64_t ub, const OutMap& om,
+                            hipStream_t st) {
+  fast::OnePass25Args P{};
+  P.A = fast25_args(h, v, g);
+  auto launch = [&](const fast::OnePass25Args& Q, bool redo, dim3 grid) -> hipError_t {
+    auto go = [&](auto kern) -> hipError_t {
+      hipError_t e = set_lds(reinterpret_cast<const void*>(kern), O25_GEOM.lds);
+      if (e != hipSuccess) return e;
+      hipLaunchKernelGGL(kern, grid, dim3(256), O25_GEOM.lds, st, Q);
+      return hipGetLastError();
+    };
+    return redo ? go(fast::k_gate_onepass256<4, true>) : go(fast::k_gate_onepass256<4, false>);
+  };
+  return stage_onepass_small(h, v, vx, g, ub, om, st, O25_GEOM, P, h->o25tab, launch);
 }
 
 // ------------------------------------------------------------------------------------------
@@ -2827,7 +2890,8 @@ static int run_S(sg_handle* h, View v, int64_t total_units, const OutMap& om, hi
   // count fields in the workspace
   const bool onepass = h->fused_ok && !h->force_unfused && h->fast_ok && !h->force_nofast && onepass_ok(h, g, om);
   const bool onepass5 = !onepass && onepass512_ok(h, g, om);
-  const bool lean = onepass || onepass5 || (h->fused_ok && !h->force_unfused && h->fast_ok && !h->force_nofast &&
+  const bool onepass25 = !onepass && !onepass5 && onepass256_ok(h, g, om);
+  const bool lean = onepass || onepass5 || onepass25 || (h->fused_ok && !h->force_unfused && h->fast_ok && !h->force_nofast &&
                                             h->p.prop_decrease == 1.0);
   int64_t ub = units_per_batch(h, g, total_units, lean);
   int rc = ensure_ws(h, g, ub, lean);
@@ -2836,7 +2900,7 @@ static int run_S(sg_handle* h, View v, int64_t total_units, const OutMap& om, hi
   // frame (in every kernel).  Convert the readable part of the rows ONCE -- (float)sample is what those kernels
   // compute anyway -- and keep the original view for the float64 work (exact refinement, floor pre-pass).
   const View vx = v;
-  if (v.dtype != SG_F32 && ((h->fast_ok && !h->force_nofast && (onepass || (!h->p.stationary && nonstat2_ok(h, g)))) || onepass5)) {
+  if (v.dtype != SG_F32 && ((h->fast_ok && !h->force_nofast && (onepass || (!h->p.stationary && nonstat2_ok(h, g)))) || onepass5 || onepass25)) {
     const int64_t rows = total_units / std::max<int64_t>(1, v.n_chunks), len = v.hi - v.lo;
     const size_t bytes = (size_t)rows * len * sizeof(float);
     if (len > 0 && bytes <= ((size_t)16 << 30)) {
@@ -2867,6 +2931,13 @@ static int run_S(sg_handle* h, View v, int64_t total_units, const OutMap& om, hi
       View vxb = vx;
       vxb.unit0 = u0;
       if ((rc = stage_onepass512(h, v, vxb, g, nb, om, st))) return rc;
+      h->dbg_units = nb; h->dbg_T = g.T; h->dbg_has_P = false; h->dbg_fused = true; h->dbg_fast = true; h->dbg_k16_only = false;
+      continue;
+    }
+    if (onepass25) {
+      View vxb = vx;
+      vxb.unit0 = u0;
+      if ((rc = stage_onepass256(h, v, vxb, g, nb, om, st))) return rc;
       h->dbg_units = nb; h->dbg_T = g.T; h->dbg_has_P = false; h->dbg_fused = true; h->dbg_fast = true; h->dbg_k16_only = false;
       continue;
     }

@@ -171,8 +171,10 @@ __device__ __forceinline__ unsigned f25_gather(const Fast25Args& A, cf* tw512, c
 
 // the conjugate pair of slot e of sequence `off` (0: frames A, B; 8: frames C, D): (a, b) = (Z[k], Z[256 - k]).  Slot 0 of
 // lane 0 is NOT a pair (callers handle DC and bin 128).
+constexpr unsigned long long F25_L0 = 0x0001000100010001ull;   // lanes with c == 0 (sel_s: fastpath.hpp; see fast512.hpp)
 __device__ __forceinline__ void f25_pair(const cf* v, int off, int e, bool l0, cf& a, cf& b) {
-  auto sel = [&](cf a0, cf a1) -> cf { return {l0 ? a0.x : a1.x, l0 ? a0.y : a1.y}; };
+  (void)l0;
+  auto sel = [&](cf a0, cf a1) -> cf { return {sel_s(F25_L0, a0.x, a1.x), sel_s(F25_L0, a0.y, a1.y)}; };
   const cf* pa = v + off;
   const cf* pb = v + 16 + off;
   a = e < 4 ? pa[e] : sel(pb[e - 4], pa[e]);
@@ -454,7 +456,7 @@ __global__ __launch_bounds__(WAVES * 64, 3) void k_apply_fast256(Fast25Args A) {
         m128[fr] = Mr[128] * (2.f * ks);
       }
     }
-    auto sel = [&](cf a0, cf a1) -> cf { return {l0 ? a0.x : a1.x, l0 ? a0.y : a1.y}; };
+    auto sel = [&](cf a0, cf a1) -> cf { return {sel_s(F25_L0, a0.x, a1.x), sel_s(F25_L0, a0.y, a1.y)}; };
 #pragma unroll
     for (int s = 0; s < 2; ++s) {
       const int off = 8 * s;
