@@ -33,6 +33,7 @@
 #include "fast256.hpp"
 #include "onepass256.hpp"
 #include "fast2048.hpp"
+#include "onepass2048.hpp"
 #include "nonstat.hpp"
 #include "fast64.hpp"
 #include "big.hpp"
@@ -153,7 +154,7 @@ struct sg_handle {
   bool mr_ok = false;                // n_fft even, n_fft / 2 <= 2048 with prime factors <= 13, not a power of two: the float32 and
   MrPlan mr{};                       // float64 STFT / decision / apply kernels of mixed.hpp (run-time radix schedule) instead of chirp-z
   DevBuf mr_pt32, mr_pt64;           // the plan's per-pass twiddle tables (mr_pass_tables)
-  DevBuf o5tab, o25tab;              // k_gate_onepass512 / 256: MFMA operands + byte expansion (onepass512.hpp, onepass256.hpp)
+  DevBuf o5tab, o25tab, o20tab;      // k_gate_onepass512 / 256 / 2048: MFMA operands + byte expansion (onepass512.hpp, onepass256.hpp, onepass2048.hpp)
   DevBuf czt_tw64, czt_ch64, czt_bh64, czt_tw32, czt_ch32, czt_bh32;
   bool force_noseam = false;
   bool force_nolean = false;         // SG_OPT_FORCE_NOLEAN: full-size slices + stored frames (2 waves/SIMD)
@@ -1257,6 +1258,27 @@ extern "C" int sg_create(const sg_params* p, const double* window_host, sg_handl
       for (int e = 0; e < 8; ++e) tb[256 + v] |= (unsigned long long)((v >> e) & 1) << (8 * e);
     rc = upload(h, h->o25tab, tb.data(), tb.size() * 8);
   }
+  if (!rc && h->fast20_ok && p->smooth_mask && p->n_grad_freq <= fast::O20_MAX_NF && p->n_grad_time <= fast::O20_MAX_NT) {
+    // k_gate_onepass2048 (onepass2048.hpp): TWO band matrices (bins 16 b - 24 + k and 16 b + 8 + k against output bin 16 b + j), one
+    // k-block of time weights
+    const int nf = p->n_grad_freq, nt = p->n_grad_time;
+    std::vector<unsigned long long> tb(448, 0ull);
+    auto wt = [&](int d) { const int ad = d < 0 ? -d : d; return ad <= nt ? nt + 1 - ad : 0; };
+    auto wf = [&](int d) { const int ad = d < 0 ? -d : d; return ad <= nf ? nf + 1 - ad : 0; };
+    for (int l = 0; l < 64; ++l) {
+      const int q = l / 16, j = l % 16;
+      for (int e = 0; e < 8; ++e) {
+        const int k = 8 * q + e;
+        tb[l] |= (unsigned long long)wf(k - 24 - j) << (8 * e);
+        tb[64 + l] |= (unsigned long long)wf(k + 8 - j) << (8 * e);
+        const int r1 = e < 4 ? 4 * q + e : 16 + 4 * q + (e - 4);
+        tb[128 + l] |= (unsigned long long)wt(r1 - nt - j) << (8 * e);
+      }
+    }
+    for (int v = 0; v < 256; ++v)
+      for (int e = 0; e < 8; ++e) tb[192 + v] |= (unsigned long long)((v >> e) & 1) << (8 * e);
+    rc = upload(h, h->o20tab, tb.data(), tb.size() * 8);
+  }
   if (!rc) rc = ensure(h, h->thresh, (size_t)h->FS * sizeof(double));
   if (rc) {
     g_create_error = h->err;
@@ -1278,7 +1300,7 @@ extern "C" int sg_destroy(sg_handle* h) {
                     &h->need, &h->T2, &h->part, &h->tw512, &h->invn, &h->seam, &h->ftab, &h->xbits, &h->xpart,
                     &h->xticket, &h->xtick2, &h->ftab3, &h->xexp, &h->optab, &h->nsp, &h->nsc, &h->xin, &h->czt_tw64, &h->czt_ch64,
                     &h->czt_bh64, &h->czt_tw32, &h->czt_ch32, &h->czt_bh32, &h->logtab, &h->big_twM, &h->big_tw2,
-                    &h->big_ch, &h->big_bh, &h->big_W, &h->big_W2, &h->xP, &h->xraw, &h->xM, &h->xtmp, &h->xseg, &h->invn5, &h->invn25, &h->invn20, &h->rg_count, &h->alim, &h->nss, &h->mr_pt32, &h->mr_pt64, &h->o5tab, &h->o25tab})
+                    &h->big_ch, &h->big_bh, &h->big_W, &h->big_W2, &h->xP, &h->xraw, &h->xM, &h->xtmp, &h->xseg, &h->invn5, &h->invn25, &h->invn20, &h->rg_count, &h->alim, &h->nss, &h->mr_pt32, &h->mr_pt64, &h->o5tab, &h->o25tab, &h->o20tab})
     free_buf(*b);
   delete h;
   return SG_OK;
@@ -1523,6 +1545,7 @@ static hipError_t launch_bits_any(const sg_handle* h, const View& v, const Geom&
 struct OnePassSmall {
   int hop, NF, NH, tile_words, xw, max_nf, max_nt, F;
   size_t lds;
+  int extra = 0;   // abutting tiles (NH == NF, n_fft = 2048): the last tile must reach 3 hops past the range (its leading partials)
 };
 static bool onepass_small_ok(const sg_handle* h, const Geom& g, const OutMap& om, const OnePassSmall& S, const DevBuf& tab) {
   if (h->force_nofast || h->force_split || h->force_f64_decide || h->force_unfused || !h->fused_ok) return false;
@@ -1578,7 +1601,7 @@ static int stage_onepass_small(sg_handle* h, const View& v, const View& vx, cons
   P.A.h_begin = (om.p0 + g.padL) / S.hop;
   P.A.h_end = (om.p1 - 1 + g.padL) / S.hop + 1;
   const int64_t nh = P.A.h_end - P.A.h_begin;
-  const int64_t n_tiles = (nh + S.NH - 1) / S.NH, ntt = n_tiles + 2;
+  const int64_t n_tiles = (nh + S.extra + S.NH - 1) / S.NH, ntt = n_tiles + 2;
   if ((rc = ensure_zeroed(h, h->xbits, (size_t)ub * ntt * S.tile_words * 8, st))) return rc;
   P.xbits = (unsigned long long*)h->xbits.p;
   P.ticket = (unsigned*)h->xticket.p;
@@ -1617,7 +1640,7 @@ static int stage_onepass_small(sg_handle* h, const View& v, const View& vx, cons
   h->dbg_tf0 = P.A.h_begin - 3;
   h->dbg_ntt = (int)ntt;
   h->dbg_db = std::max<int64_t>(0, P.A.h_begin - 3 - S.NH);
-  h->dbg_de = std::min<int64_t>(g.T, P.A.h_begin - 3 + (int64_t)S.NH * (n_tiles + 1) + 3);
+  h->dbg_de = std::min<int64_t>(g.T, P.A.h_begin - 3 + (int64_t)S.NH * (n_tiles + 1) + (S.NF - S.NH));
   return SG_OK;
 }
 
@@ -1820,6 +1843,42 @@ static int stage_apply2048(sg_handle* h, const View& v, const Geom& g, int64_t u
   HIPCHK(h, hipGetLastError());
   if (seam) {
     hipLaunchKernelGGL(fast::k_ola_seam2048<8>, dim3((unsigned)(tiles - 1), (unsigned)ub), dim3(512), 0, st, A);
+    HIPCHK(h, hipGetLastError());
+  }
+  return SG_OK;
+}
+
+// (round 6) one-pass gate for n_fft = 2048 (onepass2048.hpp): abutting tiles of 8 frames + k_ola_seam2048
+static const OnePassSmall O20_GEOM{512, fast::O20_NF, fast::O20_NF, fast::O20_TILE_WORDS, fast::O20_XW, fast::O20_MAX_NF, fast::O20_MAX_NT,
+                                   1025, FAST20_LDS + 16 + 2048, 3};
+static bool onepass2048_ok(const sg_handle* h, const Geom& g, const OutMap& om) {
+  return h->fast20_ok && !h->force_noseam && onepass_small_ok(h, g, om, O20_GEOM, h->o20tab);
+}
+static int stage_onepass2048(sg_handle* h, const View& v, const View& vx, const Geom& g, int64_t ub, const OutMap& om,
+                             hipStream_t st) {
+  fast::OnePass20Args P{};
+  P.A = fast20_args(h, v, g);
+  const int64_t hb = (om.p0 + g.padL) / 512, he = (om.p1 - 1 + g.padL) / 512 + 1;
+  const int64_t tiles = (he - hb + 3 + 7) / 8;
+  int rc = ensure(h, h->seam, (size_t)ub * tiles * 6 * 512 * sizeof(float));
+  if (rc) return rc;
+  P.A.part = (float*)h->seam.p;
+  P.A.n_tiles = (int)tiles;
+  fast::Fast20Args last{};
+  auto launch = [&](const fast::OnePass20Args& Q, bool redo, dim3 grid) -> hipError_t {
+    last = Q.A;
+    auto go = [&](auto kern) -> hipError_t {
+      hipError_t e = set_lds(reinterpret_cast<const void*>(kern), O20_GEOM.lds);
+      if (e != hipSuccess) return e;
+      hipLaunchKernelGGL(kern, grid, dim3(256), O20_GEOM.lds, st, Q);
+      return hipGetLastError();
+    };
+    return redo ? go(fast::k_gate_onepass2048<4, true>) : go(fast::k_gate_onepass2048<4, false>);
+  };
+  if ((rc = stage_onepass_small(h, v, vx, g, ub, om, st, O20_GEOM, P, h->o20tab, launch))) return rc;
+  if (tiles >= 2) {   // the hops that straddle two tiles (after the second launch, if any: a redone unit rewrote its partials)
+    ProfScope ps(h, SG_STAGE_APPLY_FAST, st);
+    hipLaunchKernelGGL(fast::k_ola_seam2048<8>, dim3((unsigned)(tiles - 1), (unsigned)ub), dim3(512), 0, st, last);
     HIPCHK(h, hipGetLastError());
   }
   return SG_OK;
@@ -2891,7 +2950,8 @@ static int run_S(sg_handle* h, View v, int64_t total_units, const OutMap& om, hi
   const bool onepass = h->fused_ok && !h->force_unfused && h->fast_ok && !h->force_nofast && onepass_ok(h, g, om);
   const bool onepass5 = !onepass && onepass512_ok(h, g, om);
   const bool onepass25 = !onepass && !onepass5 && onepass256_ok(h, g, om);
-  const bool lean = onepass || onepass5 || onepass25 || (h->fused_ok && !h->force_unfused && h->fast_ok && !h->force_nofast &&
+  const bool onepass20 = !onepass && !onepass5 && !onepass25 && onepass2048_ok(h, g, om);
+  const bool lean = onepass || onepass5 || onepass25 || onepass20 || (h->fused_ok && !h->force_unfused && h->fast_ok && !h->force_nofast &&
                                             h->p.prop_decrease == 1.0);
   int64_t ub = units_per_batch(h, g, total_units, lean);
   int rc = ensure_ws(h, g, ub, lean);
@@ -2900,7 +2960,7 @@ static int run_S(sg_handle* h, View v, int64_t total_units, const OutMap& om, hi
   // frame (in every kernel).  Convert the readable part of the rows ONCE -- (float)sample is what those kernels
   // compute anyway -- and keep the original view for the float64 work (exact refinement, floor pre-pass).
   const View vx = v;
-  if (v.dtype != SG_F32 && ((h->fast_ok && !h->force_nofast && (onepass || (!h->p.stationary && nonstat2_ok(h, g)))) || onepass5 || onepass25)) {
+  if (v.dtype != SG_F32 && ((h->fast_ok && !h->force_nofast && (onepass || (!h->p.stationary && nonstat2_ok(h, g)))) || onepass5 || onepass25 || onepass20)) {
     const int64_t rows = total_units / std::max<int64_t>(1, v.n_chunks), len = v.hi - v.lo;
     const size_t bytes = (size_t)rows * len * sizeof(float);
     if (len > 0 && bytes <= ((size_t)16 << 30)) {
@@ -2938,6 +2998,13 @@ static int run_S(sg_handle* h, View v, int64_t total_units, const OutMap& om, hi
       View vxb = vx;
       vxb.unit0 = u0;
       if ((rc = stage_onepass256(h, v, vxb, g, nb, om, st))) return rc;
+      h->dbg_units = nb; h->dbg_T = g.T; h->dbg_has_P = false; h->dbg_fused = true; h->dbg_fast = true; h->dbg_k16_only = false;
+      continue;
+    }
+    if (onepass20) {
+      View vxb = vx;
+      vxb.unit0 = u0;
+      if ((rc = stage_onepass2048(h, v, vxb, g, nb, om, st))) return rc;
       h->dbg_units = nb; h->dbg_T = g.T; h->dbg_has_P = false; h->dbg_fused = true; h->dbg_fast = true; h->dbg_k16_only = false;
       continue;
     }

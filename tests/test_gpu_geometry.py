@@ -279,14 +279,24 @@ def test_nfft2048_decisions_equal_the_float64_decisions(nr):
     sg = SpectralGateStationary(y=torch.from_numpy(y).cuda(), **kw)
     out_fast = sg.get_traces().clone()
     bits_fast = sg._gate.debug_field(3)
+    d0, d1 = sg._gate.debug_range()     # (round 6: the one-pass gate decides the frames its tiles reach, not every frame of the window)
     sg._gate.set_option(_ffi.SG_OPT_FORCE_F64_DECIDE, 1)
     try:
         out_64 = sg.get_traces().clone()
         bits_64 = sg._gate.debug_field(3)
     finally:
         sg._gate.set_option(_ffi.SG_OPT_FORCE_F64_DECIDE, 0)
-    assert bits_fast.shape == bits_64.shape and np.array_equal(bits_fast, bits_64)
+    assert bits_fast.shape == bits_64.shape and d1 - d0 > 300
+    assert np.array_equal(bits_fast[:, d0:d1], bits_64[:, d0:d1])
     assert torch.equal(out_fast, out_64)
+    # ... and the four-kernel path (k_decide_fast2048 + k_smooth_bits2 + k_apply_fast2048 + k_ola_seam2048): same bits, same samples
+    sg._gate.set_option(_ffi.SG_OPT_FORCE_SPLIT, 1)
+    try:
+        out_3k = sg.get_traces().clone()
+        bits_3k = sg._gate.debug_field(3)
+    finally:
+        sg._gate.set_option(_ffi.SG_OPT_FORCE_SPLIT, 0)
+    assert np.array_equal(bits_fast[:, d0:d1], bits_3k[:, d0:d1]) and torch.equal(out_fast, out_3k)
     want = O.reduce_noise_S(y.astype(np.float64), sr, stationary=True, n_fft=2048, chunk_size=150000, padding=12000)
     assert O.rel_err(out_fast.cpu().numpy(), want) < TOL
 
