@@ -1608,6 +1608,9 @@ static int stage_onepass_small(sg_handle* h, const View& v, const View& vx, cons
   P.ticket_base = h->ticket_base;
   h->ticket_base += (unsigned)(ub * ntt);
   P.epoch = h->epoch;
+  const bool lose = (h->lose_now & 3u) != 0;   // test hook: every poll of this launch gives up at once (the timeout path itself)
+  P.poll_epoch = lose ? ~h->epoch : h->epoch;
+  P.spin_max = lose ? 0 : fast::OP_SPIN_MAX;
   P.err = h->err_dev;
   P.nf = h->p.n_grad_freq; P.nt = h->p.n_grad_time; P.n_tiles = (int)n_tiles;
   P.tab = (const unsigned long long*)tab.p;
@@ -1631,6 +1634,8 @@ static int stage_onepass_small(sg_handle* h, const View& v, const View& vx, cons
     HIPCHK(h, launch_bits_any<0>(h, vx, g, ub, tc, (unsigned long long*)h->pmax.p, (unsigned long long*)h->bits.p, wpr, st));
     if ((rc = handoff_next_epoch(h, st))) return rc;
     P.epoch = h->epoch;
+    P.poll_epoch = h->epoch;
+    P.spin_max = fast::OP_SPIN_MAX;
     P.ticket = (unsigned*)h->xticket.p + 8;   // its own counter (zeroed by the first launch's ticket-0 workgroup)
     P.ticket_base = 0;
     HIPCHK(h, launch(P, true, grid));

@@ -41,6 +41,8 @@ struct OnePass20Args {
   unsigned* ticket;
   unsigned ticket_base;
   unsigned epoch;
+  unsigned poll_epoch;         // = epoch; tests (SG_OPT_INJECT_HANDOFF_FAULT bits 3..4): a tag no producer writes, with spin_max = 0
+  int spin_max;                // polls per hand-off before the tile gives up (OP_SPIN_MAX)
   unsigned* err;
   int nf, nt, n_tiles;
   int scan_q;
@@ -253,8 +255,8 @@ __global__ __launch_bounds__(WAVES * 64, O20_OCC) void k_gate_onepass2048(OnePas
     const unsigned long long* sp = side ? xb_mine + O20_TILE_WORDS + (rr * O20_XW + w) * 2
                                         : xb_mine - O20_TILE_WORDS + ((NF - nt + rr) * O20_XW + w) * 2;
     op_v4u gr = op_ld16_sc1(sp);
-    for (int spin = 0; gr[1] != P.epoch || gr[3] != P.epoch; ++spin) {
-      if (spin >= OP_SPIN_MAX) {   // bounded: report instead of hanging the device
+    for (int spin = 0; gr[1] != P.poll_epoch || gr[3] != P.poll_epoch; ++spin) {
+      if (spin >= P.spin_max) {   // bounded: report instead of hanging the device
         atomicOr_system(P.err, 1u);
         s_misc[1] = 1u;            // the tile's mask is unknown: every hop it touches becomes NaN
         break;
@@ -309,6 +311,10 @@ __global__ __launch_bounds__(WAVES * 64, O20_OCC) void k_gate_onepass2048(OnePas
     const float ks = A.inv_ktot * (0.25f / 1024.0f);
     const unsigned short* Kf = Ks + fr * O20_KP;
     auto mval = [&](int k) -> float { return (float)Kf[k] * ks; };
+    // (opaque copy: the 16 pair twiddles w_2048^c w_64^i are recomputed here -- kept from the decision stage they are 32 live
+    // registers across the smoothing, 14 of which went to scratch)
+    cf wl2 = wl;
+    asm volatile("" : "+v"(wl2.x), "+v"(wl2.y));
     const cf a0 = v[0], a16 = v[16];
     cf carry = v[0];
 #pragma unroll
@@ -320,7 +326,7 @@ __global__ __launch_bounds__(WAVES * 64, O20_OCC) void k_gate_onepass2048(OnePas
       carry = ob;
       const int ka = c + 32 * i;
       cf xa = oa;
-      pair_mask(xa, ba, f20_wk(wl, i), mval(ka), mval(1024 - ka));          // (ka = 0: the second mask is bin 1024's)
+      pair_mask(xa, ba, f20_wk(wl2, i), mval(ka), mval(1024 - ka));          // (ka = 0: the second mask is bin 1024's)
       v[i] = xa;
       v[31 - i].x = __shfl(ba.x, src);                          // the partner's merged value for OUR register 31 - i
       v[31 - i].y = __shfl(ba.y, src);

@@ -35,6 +35,8 @@ struct OnePass25Args {
   unsigned* ticket;
   unsigned ticket_base;
   unsigned epoch;
+  unsigned poll_epoch;         // = epoch; tests (SG_OPT_INJECT_HANDOFF_FAULT bits 3..4): a tag no producer writes, with spin_max = 0
+  int spin_max;                // polls per hand-off before the tile gives up (OP_SPIN_MAX)
   unsigned* err;
   int nf, nt, n_tiles;
   int scan_q;
@@ -251,8 +253,8 @@ __global__ __launch_bounds__(WAVES * 64, O25_OCC) void k_gate_onepass256(OnePass
     const unsigned long long* src = side ? xb_mine + O25_TILE_WORDS + ((3 + rr) * O25_XW + w) * 2
                                          : xb_mine - O25_TILE_WORDS + ((NH - nt + rr) * O25_XW + w) * 2;
     op_v4u gr = op_ld16_sc1(src);
-    for (int spin = 0; gr[1] != P.epoch || gr[3] != P.epoch; ++spin) {
-      if (spin >= OP_SPIN_MAX) {
+    for (int spin = 0; gr[1] != P.poll_epoch || gr[3] != P.poll_epoch; ++spin) {
+      if (spin >= P.spin_max) {
         atomicOr_system(P.err, 1u);
         s_misc[1] = 1u;
         break;

@@ -48,6 +48,8 @@ struct OnePass5Args {
   unsigned* ticket;            // work counter: never reset, a launch takes exactly units * (n_tiles + 2) tickets
   unsigned ticket_base;
   unsigned epoch;
+  unsigned poll_epoch;         // = epoch; tests (SG_OPT_INJECT_HANDOFF_FAULT bits 3..4): a tag no producer writes, with spin_max = 0
+  int spin_max;                // polls per hand-off before the tile gives up (OP_SPIN_MAX)
   unsigned* err;               // host-mapped word: bit 0 = a bit hand-off timed out
   int nf, nt, n_tiles;
   int scan_q;                  // in-kernel floor test: samples of the unit window's unstaged part that each tile scans
@@ -292,8 +294,8 @@ __global__ __launch_bounds__(WAVES * 64, O5_OCC) void k_gate_onepass512(OnePass5
     const unsigned long long* src = side ? xb_mine + O5_TILE_WORDS + ((3 + rr) * O5_XW + w) * 2
                                          : xb_mine - O5_TILE_WORDS + ((NH - nt + rr) * O5_XW + w) * 2;
     op_v4u gr = op_ld16_sc1(src);
-    for (int spin = 0; gr[1] != P.epoch || gr[3] != P.epoch; ++spin) {
-      if (spin >= OP_SPIN_MAX) {   // bounded: report instead of hanging the device
+    for (int spin = 0; gr[1] != P.poll_epoch || gr[3] != P.poll_epoch; ++spin) {
+      if (spin >= P.spin_max) {   // bounded: report instead of hanging the device
         atomicOr_system(P.err, 1u);
         s_misc[1] = 1u;            // the tile's mask is unknown: every hop it finalises becomes NaN
         break;

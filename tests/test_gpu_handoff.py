@@ -252,6 +252,32 @@ def test_lost_handoff_poisons_the_output(nr, stationary, bits, what):
     assert torch.equal(sg.get_traces(), good)
 
 
+@pytest.mark.parametrize("n_fft", [256, 512, 2048])
+def test_lost_handoff_poisons_the_small_onepass_gates(nr, n_fft):
+    """The same for k_gate_onepass256 / 512 / 2048 (round 6): a tile whose neighbours' bits never arrive poisons every hop it
+    touches (2048: complete hops AND the partial sums k_ola_seam2048 combines), sets the error word itself, and the next
+    call on the handle is clean."""
+    from noisereduce_amd import _ffi
+    from noisereduce_amd.spectralgate.stationary import SpectralGateStationary
+    y = O.synth_signal(300000, sr=48000, seed=9).astype(np.float32)
+    kw = dict(NS_KW)
+    for k in ("thresh_n_mult_nonstationary", "sigmoid_slope_nonstationary"):
+        kw.pop(k)
+    kw.update(y_noise=None, n_std_thresh_stationary=1.5, clip_noise_stationary=True, n_fft=n_fft)
+    sg = SpectralGateStationary(y=torch.from_numpy(y).cuda(), **kw)
+    good = sg.get_traces().clone()
+    sg._gate.check_errors()
+    assert torch.isfinite(good).all()
+    sg._gate.set_option(_ffi.SG_OPT_INJECT_HANDOFF_FAULT, 8)
+    bad = sg.get_traces().clone()
+    torch.cuda.synchronize()
+    assert int(torch.isnan(bad).sum()) > 0.9 * bad.numel()
+    with pytest.raises(_ffi.HandoffTimeout):
+        sg._gate.check_errors()
+    sg._gate.check_errors()
+    assert torch.equal(sg.get_traces(), good)
+
+
 def test_lost_handoff_poisons_torchgate_forward(nr):
     """The same for TorchGate.forward in a training loop (device tensors, asynchronous): NaN, not garbage."""
     from noisereduce_amd import _ffi

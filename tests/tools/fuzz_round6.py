@@ -8,7 +8,11 @@
      SG_OPT_TILE_ORDER 0 against 2 (one ticket-drawn tile per workgroup) bit for bit, every 6th case against the oracle;
   C. the floor test inside the decision kernels of n_fft = 512 / 256 / 2048 (thresh.hpp FloorLazy): SG_OPT_FLOOR_TEST 1
      (a priori) against 2 (in the kernel + REDO launch) on recordings with loud bursts, digital silence, NaN / Inf at random
-     places, quiet or loud noise clips: bit for bit (NaN for NaN).
+     places, quiet or loud noise clips: bit for bit (NaN for NaN);
+  D. the one-pass gates of n_fft = 512 / 256 / 2048 (onepass512.hpp, onepass256.hpp, onepass2048.hpp) against the kernels they
+     replace (SG_OPT_FORCE_SPLIT: decide + smooth + apply): random sample rate (so: smoothing half-widths on both sides of the
+     kernels' limits), channels, length, chunk grid, padding, sub-range, input dtype, bursts / silence / NaN: bit for bit, every
+     6th case against the oracle.
 
   python tests/tools/fuzz_round6.py [first_seed] [count]   -> gpurun_out/fuzz_round6.json
 """
@@ -176,18 +180,72 @@ def run_c(seed, res):
             res["c_fail"].append((seed, n_fft, e))
 
 
+def run_d(seed, res):
+    rng = np.random.default_rng(90000 + seed)
+    n_fft = int(rng.choice([256, 512, 2048]))
+    C = int(rng.choice([1, 1, 2, 3]))
+    sr = int(rng.choice([48000, 48000, 44100, 32000, 22050, 96000]))
+    n = int(rng.integers(12 * n_fft, int(rng.choice([60000, 300000, 1500000]))))
+    cs = int(rng.choice([600000, int(rng.integers(6 * n_fft, 200000))]))
+    pad = int(rng.integers(0, min(cs, 30000) + 1))
+    y = np.stack([O.synth_signal(n, sr=sr, seed=seed * 7 + c, tone_hz=250.0 * (c + 1)) for c in range(C)]).astype(np.float32)
+    kind = rng.integers(0, 5)
+    if kind == 0:
+        a = int(rng.integers(0, n - 100)); y[:, a:a + int(rng.integers(50, 20000))] = 0.0
+        a = int(rng.integers(0, n - 100)); y[int(rng.integers(0, C)), a:a + int(rng.integers(50, 3000))] *= 300.0
+    elif kind == 1:
+        y[int(rng.integers(0, C)), int(rng.integers(0, n))] = np.nan
+    dtype = str(rng.choice(["float32", "float32", "float64"]))
+    kw = dict(sr=sr, y_noise=None, prop_decrease=1.0, n_std_thresh_stationary=float(rng.choice([1.5, 1.5, 0.5, 3.0])), chunk_size=cs,
+              clip_noise_stationary=True, padding=pad, n_fft=n_fft, win_length=None, hop_length=None, time_constant_s=2.0,
+              freq_mask_smooth_hz=float(rng.choice([500, 500, 200, 100])), time_mask_smooth_ms=float(rng.choice([50, 50, 20, 90])),
+              tmp_folder=None, use_tqdm=False, n_jobs=1)
+    yy = y.astype(dtype)
+    try:
+        sg = SpectralGateStationary(y=yy if C > 1 else yy[0], **kw)
+    except ValueError:
+        return
+    g = sg._gate
+    args = {}
+    if rng.integers(0, 4) == 0 and n > 40000:
+        a = int(rng.integers(0, n // 2)); args = dict(start_frame=a, end_frame=int(rng.integers(a + 3000, n)))
+    try:
+        a0 = sg.get_traces(**args)
+        a1 = sg.get_traces(**args)
+        g.set_option(_ffi.SG_OPT_FORCE_SPLIT, 1)
+        b = sg.get_traces(**args)
+    finally:
+        g.set_option(_ffi.SG_OPT_FORCE_SPLIT, 0)
+    g.check_errors()
+    res["d_cases"] += 1
+    res["d_by_nfft"][str(n_fft)] = res["d_by_nfft"].get(str(n_fft), 0) + 1
+    if not (np.array_equal(a0, b, equal_nan=True) and np.array_equal(a0, a1, equal_nan=True)):
+        res["d_fail"].append((seed, n_fft))
+    if seed % 6 == 0 and not args and n <= 300000 and np.isfinite(y).all():
+        want = O.reduce_noise_S(yy.astype(np.float64) if C > 1 else yy[0].astype(np.float64), sr, stationary=True, chunk_size=cs,
+                                padding=pad, n_fft=n_fft, n_std_thresh_stationary=kw["n_std_thresh_stationary"],
+                                freq_mask_smooth_hz=kw["freq_mask_smooth_hz"], time_mask_smooth_ms=kw["time_mask_smooth_ms"])
+        e = float(O.rel_err(a0, want))
+        res["d_oracle"] += 1
+        res["d_worst"] = max(res["d_worst"], e)
+        if not e < 1e-4:
+            res["d_fail"].append((seed, n_fft, e))
+
+
 def main():
     first = int(sys.argv[1]) if len(sys.argv) > 1 else 0
     count = int(sys.argv[2]) if len(sys.argv) > 2 else 150
     res = {"seeds": [first, first + count], "a_cases": 0, "a_sizes": set(), "a_fail": [], "a_worst": 0.0,
-           "b_cases": 0, "b_fail": [], "b_oracle": 0, "b_worst": 0.0, "c_cases": 0, "c_fail": [], "c_reported": 0, "c_worst": 0.0}
+           "b_cases": 0, "b_fail": [], "b_oracle": 0, "b_worst": 0.0, "c_cases": 0, "c_fail": [], "c_reported": 0, "c_worst": 0.0,
+           "d_cases": 0, "d_by_nfft": {}, "d_fail": [], "d_oracle": 0, "d_worst": 0.0}
     for seed in range(first, first + count):
         run_a(seed, res)
         run_b(seed, res)
         run_c(seed, res)
+        run_d(seed, res)
     torch.cuda.synchronize()
     res["a_sizes"] = sorted(res["a_sizes"])
-    res["failures"] = len(res["a_fail"]) + len(res["b_fail"]) + len(res["c_fail"])
+    res["failures"] = len(res["a_fail"]) + len(res["b_fail"]) + len(res["c_fail"]) + len(res["d_fail"])
     os.makedirs(os.path.join(ROOT, "gpurun_out"), exist_ok=True)
     json.dump(res, open(os.path.join(ROOT, "gpurun_out", "fuzz_round6.json"), "w"), indent=1)
     print(json.dumps({k: v for k, v in res.items() if k != "a_sizes"}), "distinct n_fft:", len(res["a_sizes"]))
