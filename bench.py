@@ -60,7 +60,7 @@ ALGO_BYTES_PER_SAMPLE = 8           # 4 B float32 read + 4 B float32 written (SU
 HBM_PEAK_GBS = 8000.0               # MI355X_MICROARCH.md: 8 TB/s spec
 VALU_PEAK_TFLOPS = 157.3            # MI355X_MICROARCH.md: float32 vector peak (2.4 GHz)
 ALGO_FLOPS_PER_SAMPLE = 450         # two 1024-point real transforms per 256-sample hop, smoothing, log / compare / window / overlap-add
-TRAFFIC_DETAIL = "profiles/r06_v1_traffic_detail.json"   # rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes (tools/gpu_traffic.sh), committed
+TRAFFIC_DETAIL = "profiles/r06_v2_traffic_detail.json"   # rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes (tools/gpu_traffic.sh), committed
 C4_CHANNELS, C4_SAMPLES = 8, SR * 1800   # configs[3]: one GPU's share
 
 
@@ -1058,7 +1058,7 @@ def extras(device, wl, out, y2d, gate, O):
                     "Msamples_s": round(y2.numel() / (med * 1e-3) / 1e6, 1),
                     "settle_ms_per_call_blocks": _time_events.last.get("settle_ms_per_call_blocks")}
         og["what"] = ("reduce_noise(n_fft=...) on 2 minutes (5.76 M samples, 10 chunks) of the benchmark recording: n_fft = 256 on "
-                      "fast256.hpp (four frames per register transform, round 5), 512 / 2048 on fast512.hpp / fast2048.hpp; "
+                      "fast256.hpp (four frames per register transform), 512 / 2048 on fast512.hpp / fast2048.hpp; stationary: the one-pass gates of round 6 (onepass256 / 512 / 2048.hpp); "
                       "5 blocks of 4 back-to-back calls after the adaptive settle, median of the blocks")
         oc["other_geometries_2min"] = og
     except Exception as e:
