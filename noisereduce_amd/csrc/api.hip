@@ -1549,7 +1549,7 @@ struct OnePassSmall {
 };
 static bool onepass_small_ok(const sg_handle* h, const Geom& g, const OutMap& om, const OnePassSmall& S, const DevBuf& tab) {
   if (h->force_nofast || h->force_split || h->force_f64_decide || h->force_unfused || !h->fused_ok) return false;
-  if (h->p.variant != SG_VARIANT_S || !h->p.stationary || !h->p.smooth_mask || h->p.prop_decrease != 1.0) return false;
+  if (h->p.variant != SG_VARIANT_S || !h->p.stationary || !h->p.smooth_mask) return false;
   if (h->p.n_grad_freq > S.max_nf || h->p.n_grad_time > S.max_nt || g.F != S.F || !tab.p) return false;
   if (h->tile_order == 1) return false;
   const int64_t hb = (om.p0 + g.padL) / S.hop, he = (om.p1 - 1 + g.padL) / S.hop + 1;
@@ -1614,6 +1614,7 @@ static int stage_onepass_small(sg_handle* h, const View& v, const View& vx, cons
   P.err = h->err_dev;
   P.nf = h->p.n_grad_freq; P.nt = h->p.n_grad_time; P.n_tiles = (int)n_tiles;
   P.tab = (const unsigned long long*)tab.p;
+  P.prop = (float)h->p.prop_decrease;
   {
     // the part of a unit's window outside its tiles' spans, dealt evenly to the unit's tiles ("floor test" in the kernels)
     const int64_t SPAN = (int64_t)(S.NF - 1 + 4) * S.hop;

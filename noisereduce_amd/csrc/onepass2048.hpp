@@ -46,6 +46,7 @@ struct OnePass20Args {
   unsigned* err;
   int nf, nt, n_tiles;
   int scan_q;
+  float prop;                  // prop_decrease (onepass512.hpp)
   const unsigned long long* tab;
 };
 
@@ -308,9 +309,16 @@ __global__ __launch_bounds__(WAVES * 64, O20_OCC) void k_gate_onepass2048(OnePas
   const bool wave_live = tf0 + 2 * wave + 1 >= 0 && tf0 + 2 * wave < G.T;
   if (wave_live) {
     // pair_mask leaves out four 1/2 factors; the inverse transform a factor 1024; K / ktot for the integer sums
-    const float ks = A.inv_ktot * (0.25f / 1024.0f);
+    const float ks = A.inv_ktot * (0.25f / 1024.0f) * P.prop;
+    const bool propn = P.prop != 1.0f;   // + (1 - p) E / ktot (thresh.hpp: tri_valid)
+    const float tq_ = propn ? (1.0f - P.prop) * A.inv_ktot * (0.25f / 1024.0f) * tri_valid(nt, tf0 + fr, G.T) : 0.f;
+    const int nfw = P.nf;
     const unsigned short* Kf = Ks + fr * O20_KP;
-    auto mval = [&](int k) -> float { return (float)Kf[k] * ks; };
+    auto mval = [&](int k) -> float {
+      float m = (float)Kf[k] * ks;
+      if (propn) m = fmaf(tri_valid(nfw, k, F20_F), tq_, m);
+      return m;
+    };
     // (opaque copy: the 16 pair twiddles w_2048^c w_64^i are recomputed here -- kept from the decision stage they are 32 live
     // registers across the smoothing, 14 of which went to scratch)
     cf wl2 = wl;

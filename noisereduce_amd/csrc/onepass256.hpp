@@ -40,6 +40,7 @@ struct OnePass25Args {
   unsigned* err;
   int nf, nt, n_tiles;
   int scan_q;
+  float prop;                  // prop_decrease (onepass512.hpp)
   const unsigned long long* tab;
 };
 
@@ -303,13 +304,23 @@ __global__ __launch_bounds__(WAVES * 64, O25_OCC) void k_gate_onepass256(OnePass
   __syncthreads();
   float mk[4][8], m128[4];
   {
-    const float ks = A.inv_ktot * (0.5f / 256.0f);
+    const float ks = A.inv_ktot * (0.5f / 256.0f) * P.prop;
 #pragma unroll
     for (int fr = 0; fr < 4; ++fr) {
       const unsigned short* Kr = Ks + (fq + fr) * O25_KP;
 #pragma unroll
       for (int e = 0; e < 8; ++e) mk[fr][e] = (float)Kr[bin6(c, e)] * ks;
       m128[fr] = (float)Kr[128] * (2.f * ks);
+    }
+    if (P.prop != 1.0f) {   // + (1 - p) E / ktot (thresh.hpp: tri_valid)
+      const float kq = (1.0f - P.prop) * A.inv_ktot * (0.5f / 256.0f);
+#pragma unroll
+      for (int fr = 0; fr < 4; ++fr) {
+        const float tt = kq * tri_valid(nt, tf0 + fq + fr, G.T);
+#pragma unroll
+        for (int e = 0; e < 8; ++e) mk[fr][e] = fmaf(tri_valid(P.nf, bin6(c, e), F25_F), tt, mk[fr][e]);
+        m128[fr] = fmaf(2.f * tri_valid(P.nf, 128, F25_F), tt, m128[fr]);
+      }
     }
   }
   __syncthreads();   // every lane has its mask entries: the slices are free for the inverse transform

@@ -20,8 +20,8 @@
 // as there (29 complete hops per tile, 9 % redundant transforms): no partial hops travel between workgroups, the bits are the
 // only exchange.  Inter-workgroup protocol, deadlock freedom (tickets; publish before wait), bounded polls and NaN-poisoned
 // output of a tile that lost a hand-off: onepass.hpp.  The -top_db floor test runs on the staged samples (thresh.hpp:
-// FloorLazy); REDO = the second launch for the units whose test fired.  prop_decrease = 1 only (the caller keeps the
-// three-kernel path otherwise).
+// FloorLazy); REDO = the second launch for the units whose test fired.  Any prop_decrease (a scale and an offset on the
+// mask entries).
 #pragma once
 #include "fast512.hpp"
 
@@ -53,6 +53,7 @@ struct OnePass5Args {
   unsigned* err;               // host-mapped word: bit 0 = a bit hand-off timed out
   int nf, nt, n_tiles;
   int scan_q;                  // in-kernel floor test: samples of the unit window's unstaged part that each tile scans
+  float prop;                  // prop_decrease: mask = prop K / ktot + (1 - prop)   (stationary.py:116-119: after the smoothing)
   const unsigned long long* tab;   // MFMA operands + byte expansion (see above)
 };
 
@@ -344,7 +345,7 @@ __global__ __launch_bounds__(WAVES * 64, O5_OCC) void k_gate_onepass512(OnePass5
   __syncthreads();
   float ma[16], mb[16], m256a, m256b;
   {
-    const float ks = A.inv_ktot * (0.5f / 512.0f);   // K / ktot, the 1/2 of the split and the 1/512 of the inverse transform
+    const float ks = A.inv_ktot * (0.5f / 512.0f) * P.prop;   // p K / ktot, the 1/2 of the split and the 1/512 of the inverse transform
     const unsigned short* KA = Ks + fa * O5_KP;
     const unsigned short* KB = KA + O5_KP;
 #pragma unroll
@@ -355,6 +356,19 @@ __global__ __launch_bounds__(WAVES * 64, O5_OCC) void k_gate_onepass512(OnePass5
     }
     m256a = (float)KA[256] * (2.f * ks);
     m256b = (float)KB[256] * (2.f * ks);
+    if (P.prop != 1.0f) {   // + (1 - p) E / ktot (thresh.hpp: tri_valid)
+      const float kq = (1.0f - P.prop) * A.inv_ktot * (0.5f / 512.0f);
+      const float tA = kq * tri_valid(nt, tf0 + fa, G.T), tB = kq * tri_valid(nt, tf0 + fa + 1, G.T);
+#pragma unroll
+      for (int sl = 0; sl < 16; ++sl) {
+        const float wf = tri_valid(P.nf, bin5(c, sl), F5_F);
+        ma[sl] = fmaf(wf, tA, ma[sl]);
+        mb[sl] = fmaf(wf, tB, mb[sl]);
+      }
+      const float w256 = 2.f * tri_valid(P.nf, 256, F5_F);
+      m256a = fmaf(w256, tA, m256a);
+      m256b = fmaf(w256, tB, m256b);
+    }
   }
   __syncthreads();   // every lane has its mask entries: the slices are free for the inverse transform
 

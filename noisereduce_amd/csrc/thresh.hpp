@@ -79,4 +79,12 @@ __device__ __forceinline__ void floor_lazy_report(const ThreshConsts& tc, const 
   }
 }
 
+// prop_decrease < 1 (stationary.py:108-114 applies it BEFORE the zero-padded smoothing): mask = (p K + (1 - p) E) / ktot with
+// E[t][f] = tri_valid(nt, t, T) tri_valid(nf, f, F), the triangle's weight over the taps that fall inside the field
+// (closed form of its tails; half-width w, index i of [0, n)).
+__device__ __forceinline__ float tri_valid(int w, int64_t i, int64_t n) {
+  const int64_t l = i < w ? w - i : 0, r = (n - 1 - i) < w ? w - (n - 1 - i) : 0;
+  return (float)((int64_t)(w + 1) * (w + 1) - l * (l + 1) / 2 - r * (r + 1) / 2);
+}
+
 }  // namespace sg

@@ -430,3 +430,28 @@ def test_register_paths_floor_test_prediction_follows_the_data(n_fft):
     torch.cuda.synchronize()
     how3, out_b2 = run(sb)
     assert how3 == (1, 0) and np.array_equal(out_b, out_b2)
+
+
+@pytest.mark.parametrize("n_fft", [256, 512, 2048])
+def test_small_onepass_gates_with_prop_decrease(nr, n_fft):
+    """k_gate_onepass256 / 512 / 2048 with prop_decrease != 1 (mask = p K / ktot + (1 - p) formed on the K tile in LDS):
+    the oracle to the 1e-4 bar, the split kernels (float mask field through HBM) to a few float32 ulps of the peak."""
+    from noisereduce_amd import _ffi
+    from noisereduce_amd.spectralgate.stationary import SpectralGateStationary
+    sr, n = 48000, 260000
+    y = np.stack([O.synth_signal(n, sr=sr, seed=31 + c, tone_hz=350.0 * (c + 1)) for c in range(2)]).astype(np.float32)
+    for prop in (0.7, 0.25):
+        kw = dict(sr=sr, y_noise=None, prop_decrease=prop, n_std_thresh_stationary=1.5, chunk_size=90000, clip_noise_stationary=True,
+                  padding=7000, n_fft=n_fft, win_length=None, hop_length=None, time_constant_s=2.0, freq_mask_smooth_hz=500,
+                  time_mask_smooth_ms=50, tmp_folder=None, use_tqdm=False, n_jobs=1)
+        sg = SpectralGateStationary(y=torch.from_numpy(y).cuda(), **kw)
+        got = sg.get_traces().clone()
+        sg._gate.set_option(_ffi.SG_OPT_FORCE_SPLIT, 1)
+        try:
+            split = sg.get_traces().clone()
+        finally:
+            sg._gate.set_option(_ffi.SG_OPT_FORCE_SPLIT, 0)
+        sg._gate.check_errors()
+        want = O.reduce_noise_S(y.astype(np.float64), sr, stationary=True, n_fft=n_fft, chunk_size=90000, padding=7000, prop_decrease=prop)
+        assert O.rel_err(got.cpu().numpy(), want) < TOL
+        assert float((got - split).abs().max()) <= 2e-6 * float(split.abs().max())

@@ -196,7 +196,8 @@ def run_d(seed, res):
     elif kind == 1:
         y[int(rng.integers(0, C)), int(rng.integers(0, n))] = np.nan
     dtype = str(rng.choice(["float32", "float32", "float64"]))
-    kw = dict(sr=sr, y_noise=None, prop_decrease=1.0, n_std_thresh_stationary=float(rng.choice([1.5, 1.5, 0.5, 3.0])), chunk_size=cs,
+    prop = float(rng.choice([1.0, 1.0, 0.8, 0.35]))
+    kw = dict(sr=sr, y_noise=None, prop_decrease=prop, n_std_thresh_stationary=float(rng.choice([1.5, 1.5, 0.5, 3.0])), chunk_size=cs,
               clip_noise_stationary=True, padding=pad, n_fft=n_fft, win_length=None, hop_length=None, time_constant_s=2.0,
               freq_mask_smooth_hz=float(rng.choice([500, 500, 200, 100])), time_mask_smooth_ms=float(rng.choice([50, 50, 20, 90])),
               tmp_folder=None, use_tqdm=False, n_jobs=1)
@@ -219,11 +220,16 @@ def run_d(seed, res):
     g.check_errors()
     res["d_cases"] += 1
     res["d_by_nfft"][str(n_fft)] = res["d_by_nfft"].get(str(n_fft), 0) + 1
-    if not (np.array_equal(a0, b, equal_nan=True) and np.array_equal(a0, a1, equal_nan=True)):
-        res["d_fail"].append((seed, n_fft))
+    if prop == 1.0:
+        same = np.array_equal(a0, b, equal_nan=True)
+    else:   # (the split kernels form p K / ktot + (1 - p) as a float mask field: last-bit differences)
+        fin = np.isfinite(a0)
+        same = np.array_equal(fin, np.isfinite(b)) and (not fin.any() or float(np.max(np.abs(a0[fin] - b[fin]))) <= 2e-6 * max(1e-30, float(np.max(np.abs(b[fin])))))
+    if not (same and np.array_equal(a0, a1, equal_nan=True)):
+        res["d_fail"].append((seed, n_fft, prop))
     if seed % 6 == 0 and not args and n <= 300000 and np.isfinite(y).all():
         want = O.reduce_noise_S(yy.astype(np.float64) if C > 1 else yy[0].astype(np.float64), sr, stationary=True, chunk_size=cs,
-                                padding=pad, n_fft=n_fft, n_std_thresh_stationary=kw["n_std_thresh_stationary"],
+                                padding=pad, n_fft=n_fft, n_std_thresh_stationary=kw["n_std_thresh_stationary"], prop_decrease=prop,
                                 freq_mask_smooth_hz=kw["freq_mask_smooth_hz"], time_mask_smooth_ms=kw["time_mask_smooth_ms"])
         e = float(O.rel_err(a0, want))
         res["d_oracle"] += 1
