@@ -6,10 +6,10 @@
 // Tiles ABUT, as k_apply_fast2048's (overlapping by 3 frames would redo 3 of every 8 transforms): the 3 hops that straddle two
 // tiles leave as partial sums and k_ola_seam2048 combines them -- the bits are the only exchange inside the launch.
 // Integer smoothing on the matrix cores, with two differences from the 512 / 256 kernels:
-//   * the frequency half-width is 21 bins at 48 kHz (500 Hz / 23.4 Hz): a 16-bin output block reads 16 + 2 nf <= 64 bins = TWO
-//     32-bin k-blocks (band matrices Bf_lo: bins 16 b - 24 .., Bf_hi: bins 16 b + 8 ..), nf <= 24;
-//   * H = bits x band reaches (nf + 1)^2 = 484 > 127: it enters the time product as two base-128 digits,
-//     K = At x (H & 127) + 128 At x (H >> 7)   (exact: integers).
+//   * the frequency half-width is 10 bins at 48 kHz, 23 at 22.05 kHz (base.py:100: 500 Hz / (sr / 1024)): a 16-bin output block
+//     reads 16 + 2 nf <= 64 bins = TWO 32-bin k-blocks (band matrices Bf_lo: bins 16 b - 24 .., Bf_hi: bins 16 b + 8 ..), nf <= 24;
+//   * H = bits x band reaches (nf + 1)^2 = 576 > 127 (the int8 range of the second product's operand): it enters the time
+//     product as two base-128 digits, K = At x (H & 127) + 128 At x (H >> 7)   (exact: integers).
 // 8 + 2 nt <= 32 bit rows (nt <= 8) = two 16-row blocks = ONE k-block of the time product.  Six MFMAs per bin block, 65 blocks.
 // The K tile (8 x 1025 uint16) and the bits live in the exchange slices, idle between the transforms; the pair stage reads its
 // mask entries straight from there (k_apply_fast2048<K> reads them from HBM), one barrier before the inverse exchange.

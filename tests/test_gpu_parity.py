@@ -325,15 +325,17 @@ def test_torchgate_backward_matches_autograd(kw, dtype):
     assert x.grad.dtype == dtype and x.grad.shape == x.shape
 
 
-def test_unit_batching_is_invisible(nr):
+@pytest.mark.parametrize("n_fft,nf,nt", [(1024, 5, 9), (512, 2, 18), (256, 1, 37), (2048, 10, 4)])
+def test_unit_batching_is_invisible(nr, n_fft, nf, nt):
     """A workspace budget that forces the (channel, chunk) units through several batches must give
-    bit-identical output (config 4 has 9216 units; the workspace is bounded)."""
+    bit-identical output (config 4 has 9216 units; the workspace is bounded).  Every geometry with a one-pass gate:
+    each batch is a launch of its own with its own tickets, epoch and exchange buffers."""
     from noisereduce_amd import _ffi
     C, n = 6, 130000
     y = np.stack([O.synth_signal(n, seed=40 + c, tone_hz=200.0 * (c + 1)) for c in range(C)])
     yd = torch.from_numpy(y).cuda()
-    kw = dict(variant=_ffi.SG_VARIANT_S, stationary=True, n_fft=1024, win_length=1024, hop_length=256,
-              n_grad_freq=5, n_grad_time=9, smooth_mask=True, chunk_size=20000, padding=3000,
+    kw = dict(variant=_ffi.SG_VARIANT_S, stationary=True, n_fft=n_fft, win_length=n_fft, hop_length=n_fft // 4,
+              n_grad_freq=nf, n_grad_time=nt, smooth_mask=True, chunk_size=20000, padding=3000,
               n_std_thresh=1.5, top_db=80.0, ddof=0)
     big = _ffi.Gate("cuda", **kw)
     small = _ffi.Gate("cuda", max_workspace_bytes=3 << 20, **kw)   # a couple of units per batch
@@ -341,8 +343,9 @@ def test_unit_batching_is_invisible(nr):
     for gate in (big, small):
         gate.noise_stats(yd[:, :20000])
         outs.append(gate.process_chunks(yd, chunked=True).cpu().numpy())
+        gate.check_errors()
     assert np.array_equal(outs[0], outs[1])
-    want = O.reduce_noise_S(y.astype(np.float64), 48000, stationary=True, chunk_size=20000, padding=3000)
+    want = O.reduce_noise_S(y.astype(np.float64), 48000, stationary=True, chunk_size=20000, padding=3000, n_fft=n_fft)
     assert O.rel_err(outs[0], want) < TOL
     big.close(); small.close()
 
