@@ -455,3 +455,37 @@ def test_small_onepass_gates_with_prop_decrease(nr, n_fft):
         want = O.reduce_noise_S(y.astype(np.float64), sr, stationary=True, n_fft=n_fft, chunk_size=90000, padding=7000, prop_decrease=prop)
         assert O.rel_err(got.cpu().numpy(), want) < TOL
         assert float((got - split).abs().max()) <= 2e-6 * float(split.abs().max())
+
+
+@pytest.mark.parametrize("n_fft", [256, 512, 2048])
+def test_small_onepass_gates_short_recordings(nr, n_fft):
+    """Recordings of one frame ... a few tiles (a single tile with two halo tiles, no seam at n_fft = 2048, chunks shorter
+    than a tile, a last chunk of a few samples): the oracle to the 1e-4 bar and the split kernels bit for bit (padding of at
+    least three hops) or to an ulp."""
+    from noisereduce_amd import _ffi
+    from noisereduce_amd.spectralgate.stationary import SpectralGateStationary
+    sr = 48000
+    for n, cs, pad in ((n_fft, 600000, 30000), (n_fft + 1, 600000, 30000), (3 * n_fft // 2, 600000, 0), (4 * n_fft, 600000, 30000),
+                       (9 * n_fft + 17, 600000, 30000), (9 * n_fft + 17, 3 * n_fft, n_fft), (20 * n_fft + 5, 5 * n_fft + 3, 2 * n_fft + 1)):
+        y = O.synth_signal(n, sr=sr, seed=n % 97, tone_hz=900.0).astype(np.float32)
+        kw = dict(sr=sr, y_noise=None, prop_decrease=1.0, n_std_thresh_stationary=1.5, chunk_size=cs, clip_noise_stationary=True,
+                  padding=pad, n_fft=n_fft, win_length=None, hop_length=None, time_constant_s=2.0, freq_mask_smooth_hz=500,
+                  time_mask_smooth_ms=50, tmp_folder=None, use_tqdm=False, n_jobs=1)
+        sg = SpectralGateStationary(y=torch.from_numpy(y).cuda(), **kw)
+        got = sg.get_traces().clone()
+        sg._gate.set_option(_ffi.SG_OPT_FORCE_SPLIT, 1)
+        try:
+            split = sg.get_traces().clone()
+        finally:
+            sg._gate.set_option(_ffi.SG_OPT_FORCE_SPLIT, 0)
+        sg._gate.check_errors()
+        if pad >= 3 * (n_fft // 4):
+            assert torch.equal(got, split), (n, cs, pad)
+        else:
+            # Without padding the first tile holds frames t < 0.  Such a frame shares a packed transform with a real one; its
+            # spectrum comes out of the split as rounding residue (1e-8 of the partner's), gets multiplied by whatever mask row
+            # the kernel has for it (the split kernels read frame 0's row, the one-pass gates smooth a row of their own for
+            # t = -1 ...) and lands in the first hops: differences of an ulp (1.2e-7 of the peak) between the two paths, both 2e-7 from the oracle.
+            assert float((got - split).abs().max()) <= 3e-7 * float(split.abs().max()), (n, cs, pad)
+        want = O.reduce_noise_S(y.astype(np.float64), sr, stationary=True, n_fft=n_fft, chunk_size=cs, padding=pad)
+        assert O.rel_err(got.cpu().numpy(), want) < TOL, (n, cs, pad)
