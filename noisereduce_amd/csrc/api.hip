@@ -3212,6 +3212,9 @@ extern "C" int sg_noise_stats(sg_handle* h, const void* noise_dev, int dtype, in
   if (!noise_dev || !dtype_ok(dtype) || C < 1 || n < 1) FAIL(h, SG_E_INVALID, "sg_noise_stats: bad argument");
   if (h->p.variant != SG_VARIANT_S) FAIL(h, SG_E_INVALID, "sg_noise_stats is a variant-S entry point");
   if (n < h->W) FAIL(h, SG_E_INVALID, "noise clip of %lld samples is shorter than win_length=%d", (long long)n, h->W);
+#ifdef SG_EXP_SKIP_STATS   // development experiment (tools/experiments/stats_in_launch.sh): the step without its statistics launches
+  if (h->has_thresh && h->t2_ready) return SG_OK;
+#endif
   hipStream_t st = (hipStream_t)stream;
   struct Tag {
     sg_handle* h;

@@ -48,6 +48,9 @@ constexpr int OP_TAB_WIN = 0, OP_TAB_WSQ = 4096, OP_TAB_INVN = 8192, OP_TAB_TW51
 #ifndef OP_TRACE
 #define OP_TRACE 0
 #endif
+#ifndef OP_EXP_STALL_NS
+#define OP_EXP_STALL_NS 0   // development experiment (see OP_STAMP(4))
+#endif
 #ifndef OP_INPLACE
 #define OP_INPLACE 0   // 1: split / merge in place after a one-off permutation of lane 0's registers (k_row_gate's formulation)
                        // instead of operand selects per pair.  Round 4: same instruction count (96 + 8 v_cndmask either way),
@@ -310,6 +313,9 @@ __global__ __launch_bounds__(WAVES * 64, OP_OCC) void k_gate_onepass(OnePassArgs
   float sc[SCAN_REG];
   bool pf = false;
 
+#if OP_EXP_STALL_NS
+  const unsigned long long op_exp_t0_ = wall_clock64();
+#endif
   for (unsigned iter = 0; iter == 0u || PERSIST; ++iter) {
   // ---- PERSIST: nothing of the arguments or the thread's indices survives an iteration (see above) ----
   const OnePassArgs& P = (PERSIST || OP_LATE_P) ? *late_args<OnePassArgs>() : Pk;
@@ -566,6 +572,12 @@ __global__ __launch_bounds__(WAVES * 64, OP_OCC) void k_gate_onepass(OnePassArgs
 #define OP_PB(sl) pb[sl]
 #endif
   OP_STAMP(4);   // split
+#if OP_EXP_STALL_NS
+  // (experiment, tools/experiments/stats_in_launch.sh: what a first-round tile would lose waiting at its decision stage for
+  // thresholds that an in-launch statistics chain publishes OP_EXP_STALL_NS after the launch starts; results unchanged)
+  if (PERSIST && iter == 0u)
+    while ((long long)(wall_clock64() - op_exp_t0_) * 10 < (long long)OP_EXP_STALL_NS) __builtin_amdgcn_s_sleep(2);
+#endif
   // ---- decide (k_decide_fast): mask bits of this lane's 32 entries -----------------------------------
   unsigned long long myword;  // lane c < 9 of group g: word c of frame tq + g
   {
