@@ -1332,7 +1332,7 @@ static size_t unit_bytes(const sg_handle* h, const Geom& g, bool lean) {
            (size_t)(g.T / 16 + 2) * 6 * 256 * 4;
   return cells * (8 + 4 + 4 + 2) + (size_t)g.T * g.n * 4 + (size_t)g.FS * 16 +
          (size_t)(g.T / NS_TT + 1) * 2 * g.FS * 8 * 2 +  // + partials and carries of the two-pass non-stationary mask
-         (size_t)(g.T / 16 + 1) * 2 * g.FS * 8;          // + k_mag_fast's per-block partials
+         (size_t)(g.T / 8 + 1) * 2 * g.FS * 8;           // + the magnitude kernels' per-tile partials (tiles of 8 frames at n_fft = 2048)
 }
 
 static int64_t units_per_batch(const sg_handle* h, const Geom& g, int64_t total, bool lean = false) {
@@ -1494,10 +1494,13 @@ static int stage_decide512(sg_handle* h, const View& v, const Geom& g, int64_t u
   return SG_OK;
 }
 
-static int stage_mag512(sg_handle* h, const View& v, const Geom& g, int64_t ub, float* mag, hipStream_t st) {
+static int stage_mag512(sg_handle* h, const View& v, const Geom& g, int64_t ub, float* mag, hipStream_t st, double iir_b = 0.0,
+                        double* sub = nullptr /* per-tile recurrence partials (mag_sub_partials) */) {
   ProfScope ps(h, SG_STAGE_STFT_MAG, st);
   fast::Fast5Args A = fast5_args(h, v, g);
   A.mag = mag;
+  A.iir_b = iir_b;
+  A.sub = sub;
   auto kern = fast::k_mag_fast512<4>;
   HIPCHK(h, set_lds(reinterpret_cast<const void*>(kern), FAST5_LDS));
   hipLaunchKernelGGL(kern, dim3((unsigned)((g.T + 31) / 32), (unsigned)ub), dim3(256), FAST5_LDS, st, A);
@@ -1706,10 +1709,13 @@ static int stage_decide256(sg_handle* h, const View& v, const Geom& g, int64_t u
   return SG_OK;
 }
 
-static int stage_mag256(sg_handle* h, const View& v, const Geom& g, int64_t ub, float* mag, hipStream_t st) {
+static int stage_mag256(sg_handle* h, const View& v, const Geom& g, int64_t ub, float* mag, hipStream_t st, double iir_b = 0.0,
+                        double* sub = nullptr /* per-tile recurrence partials (mag_sub_partials) */) {
   ProfScope ps(h, SG_STAGE_STFT_MAG, st);
   fast::Fast25Args A = fast25_args(h, v, g);
   A.mag = mag;
+  A.iir_b = iir_b;
+  A.sub = sub;
   auto kern = fast::k_mag_fast256<4>;
   HIPCHK(h, set_lds(reinterpret_cast<const void*>(kern), FAST25_LDS));
   hipLaunchKernelGGL(kern, dim3((unsigned)((g.T + 63) / 64), (unsigned)ub), dim3(256), FAST25_LDS, st, A);
@@ -1802,10 +1808,13 @@ static int stage_decide2048(sg_handle* h, const View& v, const Geom& g, int64_t 
   return SG_OK;
 }
 
-static int stage_mag2048(sg_handle* h, const View& v, const Geom& g, int64_t ub, float* mag, hipStream_t st) {
+static int stage_mag2048(sg_handle* h, const View& v, const Geom& g, int64_t ub, float* mag, hipStream_t st, double iir_b = 0.0,
+                        double* sub = nullptr /* per-tile recurrence partials (mag_sub_partials) */) {
   ProfScope ps(h, SG_STAGE_STFT_MAG, st);
   fast::Fast20Args A = fast20_args(h, v, g);
   A.mag = mag;
+  A.iir_b = iir_b;
+  A.sub = sub;
   auto kern = fast::k_mag_fast2048<4>;
   HIPCHK(h, set_lds(reinterpret_cast<const void*>(kern), FAST20_LDS));
   hipLaunchKernelGGL(kern, dim3((unsigned)((g.T + 7) / 8), (unsigned)ub), dim3(256), FAST20_LDS, st, A);
@@ -1891,11 +1900,11 @@ static int stage_onepass2048(sg_handle* h, const View& v, const View& vx, const 
 }
 
 static int stage_mag(sg_handle* h, const View& v, const Geom& g, int64_t ub, hipStream_t st, double iir_b = 0.0,
-                     double* sub = nullptr /* default geometry only: recurrence partials per 16-frame block (k_mag_fast) */) {
+                     double* sub = nullptr /* register geometries: recurrence partials per magnitude tile (16 / 32 / 64 / 8 frames) */) {
   float* mag = (float*)h->P.p;
-  if (h->fast5_ok && !h->force_nofast) return stage_mag512(h, v, g, ub, mag, st);
-  if (h->fast25_ok && !h->force_nofast) return stage_mag256(h, v, g, ub, mag, st);
-  if (h->fast20_ok && !h->force_nofast) return stage_mag2048(h, v, g, ub, mag, st);
+  if (h->fast5_ok && !h->force_nofast) return stage_mag512(h, v, g, ub, mag, st, iir_b, sub);
+  if (h->fast25_ok && !h->force_nofast) return stage_mag256(h, v, g, ub, mag, st, iir_b, sub);
+  if (h->fast20_ok && !h->force_nofast) return stage_mag2048(h, v, g, ub, mag, st, iir_b, sub);
   if (h->fast_ok && !h->force_nofast) {
     ProfScope ps(h, SG_STAGE_STFT_MAG, st);
     constexpr int WAVES = 4;
@@ -1940,9 +1949,13 @@ static bool nonstat2_ok(const sg_handle* h, const Geom& g) {
 // smooth: IIR + sigmoid + smoothing + prop_decrease -> M;  !smooth: the raw sigmoid field -> raw (smoothing follows),
 // or, without a smoothing filter, p * sigmoid + (1 - p) -> M
 static int stage_nonstat_mask2(sg_handle* h, const View& v, const Geom& g, int64_t ub, bool smooth, hipStream_t st) {
-  // default geometry: k_mag_fast also leaves the recurrence partials of its 16-frame blocks (no second pass over |X|)
-  const bool sub_ok = h->fast_ok && !h->force_nofast && !(h->fast5_ok || h->fast20_ok);
-  const int64_t nsub = (g.T + 15) / 16;
+  // register geometries: the magnitude kernel also leaves the recurrence partials of its tiles -- 16 frames at n_fft = 1024,
+  // (round 6) 32 / 64 / 8 at 512 / 256 / 2048 -- no second pass over |X| (k_iir_part); PER pieces per 64-frame tile of the chain
+  const int plen = h->fast5_ok ? 32 : h->fast25_ok ? 64 : h->fast20_ok ? 8 : 16, per = NS_TT / plen;
+  const int64_t nsub = (g.T + plen - 1) / plen;
+  const bool sub_small = (h->fast5_ok || h->fast25_ok || h->fast20_ok) && !h->force_nofast && SG_CHAIN_PAR && !h->force_split &&
+                         ub <= 65535 && nsp_ok((g.T + NS_TT - 1) / NS_TT, per);   // (the serial chain kernels know 16-frame pieces only)
+  const bool sub_ok = (h->fast_ok && !h->force_nofast && !(h->fast5_ok || h->fast20_ok || h->fast25_ok)) || sub_small;
   int rc;
   if (sub_ok && (rc = ensure(h, h->nss, (size_t)ub * nsub * 2 * g.FS * sizeof(double)))) return rc;
   rc = stage_mag(h, v, g, ub, st, h->p.iir_b, sub_ok ? (double*)h->nss.p : nullptr);
@@ -1967,10 +1980,16 @@ static int stage_nonstat_mask2(sg_handle* h, const View& v, const Geom& g, int64
       o[2] = std::pow(c, len_last); o[3] = 1.0 - std::pow(c, 2.0 * len_last);
     };
     double pw[4];
-    if (sub_ok && par && nsp_ok(nk, 4)) {
-      piece_pows(16, nsub, pw);
-      hipLaunchKernelGGL(k_iir_chain_par<4>, pgrid, dim3(64 * NSP_WAVES), 0, st, mag, (const double*)h->nss.p, g, tl,
-                         h->p.iir_b, (double*)h->nsc.p, (int)nsub, pw[0], pw[1], pw[2], pw[3]);
+    if (sub_ok && par && nsp_ok(nk, per)) {
+      piece_pows(plen, nsub, pw);
+      auto go = [&](auto kern) {
+        hipLaunchKernelGGL(kern, pgrid, dim3(64 * NSP_WAVES), 0, st, mag, (const double*)h->nss.p, g, tl, h->p.iir_b,
+                           (double*)h->nsc.p, (int)nsub, pw[0], pw[1], pw[2], pw[3]);
+      };
+      if (per == 4) go(k_iir_chain_par<4>);
+      else if (per == 2) go(k_iir_chain_par<2>);
+      else if (per == 1) go(k_iir_chain_par<1>);
+      else go(k_iir_chain_par<8>);
       HIPCHK(h, hipGetLastError());
     } else {
       if (sub_ok)

@@ -52,6 +52,8 @@ struct Fast20Args {
   float* part;               // seam mode: [units][tiles][6][512] un-normalised partial hops (3 leading, 3 trailing), else nullptr
   int n_tiles;
   FloorLazy fl;              // decide: in-kernel floor test (thresh.hpp), alim == nullptr: flags computed a priori
+  double iir_b;              // magnitude: the recurrence's b (non-stationary gate) ...
+  double* sub;               // ... and its per-tile partials [units][tiles][2][FS] (fastpath.hpp: mag_sub_partials), or nullptr
 };
 
 // w_1024^e from the w_2048 table
@@ -357,33 +359,47 @@ __global__ __launch_bounds__(WAVES * 64, 3) void k_mag_fast2048(Fast20Args A) {
   bool valid;
   f20_gather<WAVES>(A, tw, regions, row, chunk, tf0, v, valid);
   const int64_t tq = tf0 + 2 * wave;
-  if (tq >= G.T) return;
-  cf* fb = regions + wave * WAVE_CX_H + g * F20_FSL;
-  fft1k_fwd(v, fb, tw, c);
-  const cf wl = A.tw2048[c];
-  float* mrow = A.mag + (u * G.T + (valid ? tq + g : 0)) * (int64_t)G.FS;
-  const int src = (lane & 32) | ((32 - c) & 31);
-  const bool l0 = c == 0;
-  float Pp[16];
+  const bool with_sub = A.sub != nullptr;
+  constexpr int TP = 1028;   // floats between the rows of the |X| tile (with_sub): 2 rows per wave in its own exchange slice
+  static_assert(2 * TP * 4 <= WAVE_CX_H * 8, "a wave's |X| rows fit its exchange slice");
+  if (tq < G.T) {   // (wave-uniform)
+    cf* fb = regions + wave * WAVE_CX_H + g * F20_FSL;
+    fft1k_fwd(v, fb, tw, c);
+    const cf wl = A.tw2048[c];
+    float* mrow = A.mag + (u * G.T + (valid ? tq + g : 0)) * (int64_t)G.FS;
+    float* trow = reinterpret_cast<float*>(regions + wave * WAVE_CX_H) + g * TP;
+    const int src = (lane & 32) | ((32 - c) & 31);
+    const bool l0 = c == 0;
+    if (with_sub) wave_lds_sync();   // both lane groups are past their exchange reads: the slice becomes the wave's two |X| rows
+    auto put = [&](int k, float m) {
+      if (valid) mrow[k] = m;
+      if (with_sub) trow[k] = m;
+    };
+    float Pp[16];
 #pragma unroll
-  for (int i = 0; i < 16; ++i) {   // one pair per iteration, the partner's power handed over (see k_decide_fast2048)
-    const cf ob = v[31 - i], own = v[(32 - i) & 31];
-    cf ta;
-    ta.x = __shfl(ob.x, src); ta.y = __shfl(ob.y, src);
-    const cf ba = {l0 ? own.x : ta.x, l0 ? own.y : ta.y};
-    cf xa, xb;
-    split_pair(v[i], ba, f20_wk(wl, i), xa, xb);
-    if (valid) mrow[c + 32 * i] = half_sqrt(xa.x * xa.x + xa.y * xa.y);
-    Pp[i] = xb.x * xb.x + xb.y * xb.y;
-  }
-  if (l0 && valid) mrow[1024] = half_sqrt(Pp[0]);
-  const float P512 = 4.f * (v[16].x * v[16].x + v[16].y * v[16].y);
+    for (int i = 0; i < 16; ++i) {   // one pair per iteration, the partner's power handed over (see k_decide_fast2048)
+      const cf ob = v[31 - i], own = v[(32 - i) & 31];
+      cf ta;
+      ta.x = __shfl(ob.x, src); ta.y = __shfl(ob.y, src);
+      const cf ba = {l0 ? own.x : ta.x, l0 ? own.y : ta.y};
+      cf xa, xb;
+      split_pair(v[i], ba, f20_wk(wl, i), xa, xb);
+      put(c + 32 * i, half_sqrt(xa.x * xa.x + xa.y * xa.y));
+      Pp[i] = xb.x * xb.x + xb.y * xb.y;
+    }
+    if (l0) put(1024, half_sqrt(Pp[0]));
+    const float P512 = 4.f * (v[16].x * v[16].x + v[16].y * v[16].y);
 #pragma unroll
-  for (int i = 0; i < 16; ++i) {
-    const float pu = __shfl(Pp[i], src);
-    const float p0 = i < 15 ? Pp[i + 1] : P512;
-    if (valid) mrow[c + 32 * (31 - i)] = half_sqrt(l0 ? p0 : pu);
+    for (int i = 0; i < 16; ++i) {
+      const float pu = __shfl(Pp[i], src);
+      const float p0 = i < 15 ? Pp[i + 1] : P512;
+      put(c + 32 * (31 - i), half_sqrt(l0 ? p0 : pu));
+    }
   }
+  if (!with_sub) return;
+  __syncthreads();
+  mag_sub_partials<WAVES * 64, NF, 2, TP, F20_F>(regions, (int)min<int64_t>((int64_t)NF, G.T - tf0), A.iir_b,
+                                                A.sub + ((u * gridDim.x + blockIdx.x) * 2) * (int64_t)G.FS, G.FS, tid);
 }
 
 // ---------------------------------------------------------------------------------------------------------------

@@ -58,6 +58,8 @@ struct Fast25Args {
   int64_t h_begin, h_end;    // apply: ext hops (64-sample blocks, ext = unit sample + padL) to produce
   int normalize;
   FloorLazy fl;              // decide: in-kernel floor test (thresh.hpp), alim == nullptr: flags computed a priori
+  double iir_b;              // magnitude: the recurrence's b (non-stationary gate) ...
+  double* sub;               // ... and its per-tile partials [units][tiles][2][FS] (fastpath.hpp: mag_sub_partials), or nullptr
 };
 
 // second stage: two DFT8 per row (even columns = sequence 1, odd columns = sequence 2)
@@ -388,22 +390,39 @@ __global__ __launch_bounds__(WAVES * 64, 3) void k_mag_fast256(Fast25Args A) {
   bool validX, validY;
   f25_gather<WAVES>(A, tw512, regions, swin, row, chunk, tf0, v, validX, validY);
   const int64_t tq = tf0 + F25_FPW * wave;
-  if (tq >= G.T) return;
-  cf* fb = regions + wave * WAVE_CX_H + frame_base_h(g);
-  f25_fwd_half(v, fb, tw512, c);
-  const bool l0 = c == 0;
-  const int64_t tg = tq + 4 * g;
-  float P[4][8], P128[4];
-  f25_powers(v, l0, P, P128);
+  const bool with_sub = A.sub != nullptr;
+  constexpr int TP = 132;   // floats between the rows of the |X| tile (with_sub): 16 rows per wave in its own exchange slice
+  static_assert(F25_FPW * TP * 4 <= WAVE_CX_H * 8, "a wave's |X| rows fit its exchange slice");
+  if (tq < G.T) {   // (wave-uniform)
+    cf* fb = regions + wave * WAVE_CX_H + frame_base_h(g);
+    f25_fwd_half(v, fb, tw512, c);
+    const bool l0 = c == 0;
+    const int64_t tg = tq + 4 * g;
+    float P[4][8], P128[4];
+    f25_powers(v, l0, P, P128);
+    float* trow = reinterpret_cast<float*>(regions + wave * WAVE_CX_H) + (4 * g) * TP;   // (the wave's transform is done)
 #pragma unroll
-  for (int fr = 0; fr < 4; ++fr) {
-    const int64_t t = tg + fr;
-    if (t < 0 || t >= G.T) continue;
-    float* m = A.mag + (u * G.T + t) * (int64_t)G.FS;
+    for (int fr = 0; fr < 4; ++fr) {
+      const int64_t t = tg + fr;
+      const bool ok = t >= 0 && t < G.T;
+      float* m = A.mag + (u * G.T + (ok ? t : 0)) * (int64_t)G.FS;
 #pragma unroll
-    for (int e = 0; e < 8; ++e) m[bin6(c, e)] = half_sqrt(P[fr][e]);
-    if (l0) m[128] = half_sqrt(P128[fr]);
+      for (int e = 0; e < 8; ++e) {
+        const float mv = half_sqrt(P[fr][e]);
+        if (ok) m[bin6(c, e)] = mv;
+        if (with_sub) trow[fr * TP + bin6(c, e)] = mv;
+      }
+      if (l0) {
+        const float mv = half_sqrt(P128[fr]);
+        if (ok) m[128] = mv;
+        if (with_sub) trow[fr * TP + 128] = mv;
+      }
+    }
   }
+  if (!with_sub) return;
+  __syncthreads();
+  mag_sub_partials<WAVES * 64, NF, F25_FPW, TP, F25_F>(regions, (int)min<int64_t>((int64_t)NF, G.T - tf0), A.iir_b,
+                                                      A.sub + ((u * gridDim.x + blockIdx.x) * 2) * (int64_t)G.FS, G.FS, tid);
 }
 
 // ---------------------------------------------------------------------------------------------------------------

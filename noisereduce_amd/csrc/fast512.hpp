@@ -50,6 +50,8 @@ struct Fast5Args {
   int64_t h_begin, h_end;    // apply: ext hops (128-sample blocks, ext = unit sample + padL) to produce
   int normalize;
   FloorLazy fl;              // decide: in-kernel floor test (thresh.hpp), alim == nullptr: flags computed a priori
+  double iir_b;              // magnitude: the recurrence's b (non-stationary gate) ...
+  double* sub;               // ... and its per-tile partials [units][tiles][2][FS] (fastpath.hpp: mag_sub_partials), or nullptr
 };
 
 // stage tables + the tile's sample span, gather the lane's 32 complex points of its frame pair:
@@ -316,32 +318,45 @@ __global__ __launch_bounds__(WAVES * 64, 3) void k_mag_fast512(Fast5Args A) {
   bool validA, validB;
   f5_gather<WAVES>(A, tw512, regions, swin, row, chunk, tf0, G.T, v, validA, validB);
   const int64_t tq = tf0 + F5_FPW * wave;
-  if (tq >= G.T) return;
-  cf* fb = regions + wave * WAVE_CX_H + frame_base_h(g);
-  fft512_fwd_half(v, fb, tw512, c);
-  const bool l0 = c == 0;
-  const int64_t tA = tq + 2 * g;
-  float* mA = A.mag + (u * G.T + (validA ? tA : 0)) * (int64_t)G.FS;
-  float* mB = A.mag + (u * G.T + (validB ? tA + 1 : 0)) * (int64_t)G.FS;
+  const bool with_sub = A.sub != nullptr;
+  constexpr int TP = 260;   // floats between the rows of the |X| tile (with_sub): 8 rows per wave in its own exchange slice
+  static_assert(F5_FPW * TP * 4 <= WAVE_CX_H * 8, "a wave's |X| rows fit its exchange slice");
+  if (tq < G.T) {   // (wave-uniform)
+    cf* fb = regions + wave * WAVE_CX_H + frame_base_h(g);
+    fft512_fwd_half(v, fb, tw512, c);
+    const bool l0 = c == 0;
+    const int64_t tA = tq + 2 * g;
+    float* mA = A.mag + (u * G.T + (validA ? tA : 0)) * (int64_t)G.FS;
+    float* mB = A.mag + (u * G.T + (validB ? tA + 1 : 0)) * (int64_t)G.FS;
+    float* tA_ = reinterpret_cast<float*>(regions + wave * WAVE_CX_H) + (2 * g) * TP;   // (the wave's transform is done)
+    float* tB_ = tA_ + TP;
 #pragma unroll
-  for (int sl = 0; sl < 16; ++sl) {
-    cf a, b;
-    f5_pair(v, sl, l0, a, b);
-    const cf E = {a.x + b.x, a.y - b.y}, O = {a.y + b.y, b.x - a.x};
-    float PA = E.x * E.x + E.y * E.y, PB = O.x * O.x + O.y * O.y;
-    if (sl == 0) {
-      const float xa = 2.f * v[0].x, xb = 2.f * v[0].y;
-      PA = l0 ? xa * xa : PA;
-      PB = l0 ? xb * xb : PB;
+    for (int sl = 0; sl < 16; ++sl) {
+      cf a, b;
+      f5_pair(v, sl, l0, a, b);
+      const cf E = {a.x + b.x, a.y - b.y}, O = {a.y + b.y, b.x - a.x};
+      float PA = E.x * E.x + E.y * E.y, PB = O.x * O.x + O.y * O.y;
+      if (sl == 0) {
+        const float xa = 2.f * v[0].x, xb = 2.f * v[0].y;
+        PA = l0 ? xa * xa : PA;
+        PB = l0 ? xb * xb : PB;
+      }
+      const int f = bin5(c, sl);
+      const float ma = half_sqrt(PA), mb = half_sqrt(PB);
+      if (validA) mA[f] = ma;
+      if (validB) mB[f] = mb;
+      if (with_sub) { tA_[f] = ma; tB_[f] = mb; }
     }
-    const int f = bin5(c, sl);
-    if (validA) mA[f] = half_sqrt(PA);
-    if (validB) mB[f] = half_sqrt(PB);
+    if (l0) {
+      if (validA) mA[256] = fabsf(v[8].x);
+      if (validB) mB[256] = fabsf(v[8].y);
+      if (with_sub) { tA_[256] = fabsf(v[8].x); tB_[256] = fabsf(v[8].y); }
+    }
   }
-  if (l0) {
-    if (validA) mA[256] = fabsf(v[8].x);
-    if (validB) mB[256] = fabsf(v[8].y);
-  }
+  if (!with_sub) return;
+  __syncthreads();
+  mag_sub_partials<WAVES * 64, NF, F5_FPW, TP, F5_F>(regions, (int)min<int64_t>((int64_t)NF, G.T - tf0), A.iir_b,
+                                                    A.sub + ((u * gridDim.x + blockIdx.x) * 2) * (int64_t)G.FS, G.FS, tid);
 }
 
 // ---------------------------------------------------------------------------------------------------------------

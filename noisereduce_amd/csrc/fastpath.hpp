@@ -475,6 +475,34 @@ __device__ __forceinline__ void fft512_inv(cf* v, cf* fb, const cf* tw512, int c
 // not need the slice afterwards (decision and magnitude kernels).
 constexpr int FPITCH_H = 256 + 16;
 constexpr int WAVE_CX_H = 4 * FPITCH_H;
+
+// (round 6) The |X| tile of a magnitude kernel as ONE piece of the non-stationary gate's time recurrence (nonstat.hpp: what
+// k_iir_part computes from the field in a pass of its own): per band  e = sum_t b c^(end-1-t) A[t]  and  E0 = sum_t b c^(t-start) s0[t]
+// (s0: zero-state forward response), float64, over the tile's first n frames.  Row r of the tile lives in the exchange slice of the
+// wave that transformed it: slice r / FPW, row r % FPW, PITCH floats apart.  o: [2][FS] of this (unit, tile).
+template <int NTHR, int NFR, int FPW, int PITCH, int F>
+__device__ __forceinline__ void mag_sub_partials(const void* regions_, int n, double b, double* __restrict__ o, int FS, int tid) {
+  const char* base = reinterpret_cast<const char*>(regions_);
+  constexpr size_t SLICE = (size_t)WAVE_CX_H * 8;
+  const double cc = 1.0 - b;
+  for (int f = tid; f < F; f += NTHR) {
+    double e = 0.0, E0 = 0.0, pw = b;
+    auto step = [&](int r) {
+      const double a = (double)reinterpret_cast<const float*>(base + (size_t)(r / FPW) * SLICE)[(r % FPW) * PITCH + f];
+      e = b * a + cc * e;
+      E0 += pw * e;
+      pw *= cc;
+    };
+    if (n == NFR) {   // every tile but a unit's last: straight-line (the LDS reads up front)
+#pragma unroll
+      for (int r = 0; r < NFR; ++r) step(r);
+    } else {
+      for (int r = 0; r < n; ++r) step(r);
+    }
+    o[f] = e;
+    o[FS + f] = E0;
+  }
+}
 constexpr int HPITCH = 288;  // floats between the hop accumulators of a wave (k_apply_fast<LEAN>)
 __device__ __forceinline__ int frame_base_h(int g) { return g * FPITCH_H; }
 
