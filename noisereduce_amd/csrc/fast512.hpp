@@ -394,26 +394,30 @@ __global__ __launch_bounds__(WAVES * 64, 3) void k_apply_fast512(Fast5Args A) {
     const int64_t offA = (u * G.T + (validA ? tA : 0)) * (int64_t)G.FS, offB = (u * G.T + (validB ? tA + 1 : 0)) * (int64_t)G.FS;
     float ma[16], mb[16];
     float m256a, m256b;
+    // (round 6) A frame outside [0, T) shares its transform with a real one: its spectrum comes out of the split as rounding
+    // residue of the partner's (1e-8), and its mask is ZERO -- not whatever row the address clamp lands on (a NaN in frame 0's
+    // float mask would otherwise travel through the packed inverse transform into frame T - 1 of an odd-length unit).
     if constexpr (KMASK) {
       const unsigned short *KA = A.K + offA, *KB = A.K + offB;
+      const float ksA = validA ? ks : 0.f, ksB = validB ? ks : 0.f;   // (integers: a zero scale is a zero mask)
 #pragma unroll
       for (int sl = 0; sl < 16; ++sl) {
         const int f = bin5(c, sl);
-        ma[sl] = (float)KA[f] * ks;
-        mb[sl] = (float)KB[f] * ks;
+        ma[sl] = (float)KA[f] * ksA;
+        mb[sl] = (float)KB[f] * ksB;
       }
-      m256a = (float)KA[256] * (2.f * ks);
-      m256b = (float)KB[256] * (2.f * ks);
+      m256a = (float)KA[256] * (2.f * ksA);
+      m256b = (float)KB[256] * (2.f * ksB);
     } else {
       const float *MA = A.Mf + offA, *MB = A.Mf + offB;
 #pragma unroll
       for (int sl = 0; sl < 16; ++sl) {
         const int f = bin5(c, sl);
-        ma[sl] = MA[f] * ks;
-        mb[sl] = MB[f] * ks;
+        ma[sl] = validA ? MA[f] * ks : 0.f;
+        mb[sl] = validB ? MB[f] * ks : 0.f;
       }
-      m256a = MA[256] * (2.f * ks);
-      m256b = MB[256] * (2.f * ks);
+      m256a = validA ? MA[256] * (2.f * ks) : 0.f;
+      m256b = validB ? MB[256] * (2.f * ks) : 0.f;
     }
     cf na[16], nb[16];
 #pragma unroll

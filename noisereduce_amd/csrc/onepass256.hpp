@@ -308,15 +308,18 @@ __global__ __launch_bounds__(WAVES * 64, O25_OCC) void k_gate_onepass256(OnePass
 #pragma unroll
     for (int fr = 0; fr < 4; ++fr) {
       const unsigned short* Kr = Ks + (fq + fr) * O25_KP;
+      const int64_t t = tf0 + fq + fr;
+      const float kf = (t >= 0 && t < G.T) ? ks : 0.f;   // frames outside [0, T): mask zero (k_apply_fast256)
 #pragma unroll
-      for (int e = 0; e < 8; ++e) mk[fr][e] = (float)Kr[bin6(c, e)] * ks;
-      m128[fr] = (float)Kr[128] * (2.f * ks);
+      for (int e = 0; e < 8; ++e) mk[fr][e] = (float)Kr[bin6(c, e)] * kf;
+      m128[fr] = (float)Kr[128] * (2.f * kf);
     }
     if (P.prop != 1.0f) {   // + (1 - p) E / ktot (thresh.hpp: tri_valid)
       const float kq = (1.0f - P.prop) * A.inv_ktot * (0.5f / 256.0f);
 #pragma unroll
       for (int fr = 0; fr < 4; ++fr) {
-        const float tt = kq * tri_valid(nt, tf0 + fq + fr, G.T);
+        const int64_t t = tf0 + fq + fr;
+        const float tt = (t >= 0 && t < G.T) ? kq * tri_valid(nt, t, G.T) : 0.f;
 #pragma unroll
         for (int e = 0; e < 8; ++e) mk[fr][e] = fmaf(tri_valid(P.nf, bin6(c, e), F25_F), tt, mk[fr][e]);
         m128[fr] = fmaf(2.f * tri_valid(P.nf, 128, F25_F), tt, m128[fr]);

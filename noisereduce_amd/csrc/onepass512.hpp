@@ -348,17 +348,18 @@ __global__ __launch_bounds__(WAVES * 64, O5_OCC) void k_gate_onepass512(OnePass5
     const float ks = A.inv_ktot * (0.5f / 512.0f) * P.prop;   // p K / ktot, the 1/2 of the split and the 1/512 of the inverse transform
     const unsigned short* KA = Ks + fa * O5_KP;
     const unsigned short* KB = KA + O5_KP;
+    const float ksA = validA ? ks : 0.f, ksB = validB ? ks : 0.f;   // frames outside [0, T): mask zero (k_apply_fast512)
 #pragma unroll
     for (int sl = 0; sl < 16; ++sl) {
       const int f = bin5(c, sl);
-      ma[sl] = (float)KA[f] * ks;
-      mb[sl] = (float)KB[f] * ks;
+      ma[sl] = (float)KA[f] * ksA;
+      mb[sl] = (float)KB[f] * ksB;
     }
-    m256a = (float)KA[256] * (2.f * ks);
-    m256b = (float)KB[256] * (2.f * ks);
+    m256a = (float)KA[256] * (2.f * ksA);
+    m256b = (float)KB[256] * (2.f * ksB);
     if (P.prop != 1.0f) {   // + (1 - p) E / ktot (thresh.hpp: tri_valid)
       const float kq = (1.0f - P.prop) * A.inv_ktot * (0.5f / 512.0f);
-      const float tA = kq * tri_valid(nt, tf0 + fa, G.T), tB = kq * tri_valid(nt, tf0 + fa + 1, G.T);
+      const float tA = validA ? kq * tri_valid(nt, tf0 + fa, G.T) : 0.f, tB = validB ? kq * tri_valid(nt, tf0 + fa + 1, G.T) : 0.f;
 #pragma unroll
       for (int sl = 0; sl < 16; ++sl) {
         const float wf = tri_valid(P.nf, bin5(c, sl), F5_F);
