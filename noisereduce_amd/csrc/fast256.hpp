@@ -463,18 +463,18 @@ __global__ __launch_bounds__(WAVES * 64, 3) void k_apply_fast256(Fast25Args A) {
       const int64_t t = tg + fr;
       const bool ok = t >= 0 && t < G.T;
       const int64_t off = (u * G.T + (ok ? t : 0)) * (int64_t)G.FS;
-      // (round 6) frames outside [0, T): mask ZERO (fast512.hpp: k_apply_fast512)
+      // (round 6) frames outside [0, T): a zero mask SCALE (fast512.hpp: k_apply_fast512)
+      const float kf = ok ? ks : 0.f;
       if constexpr (KMASK) {
         const unsigned short* Kr = A.K + off;
-        const float kf = ok ? ks : 0.f;
 #pragma unroll
         for (int e = 0; e < 8; ++e) mk[fr][e] = (float)Kr[bin6(c, e)] * kf;
         m128[fr] = (float)Kr[128] * (2.f * kf);
       } else {
         const float* Mr = A.Mf + off;
 #pragma unroll
-        for (int e = 0; e < 8; ++e) mk[fr][e] = ok ? Mr[bin6(c, e)] * ks : 0.f;
-        m128[fr] = ok ? Mr[128] * (2.f * ks) : 0.f;
+        for (int e = 0; e < 8; ++e) mk[fr][e] = Mr[bin6(c, e)] * kf;
+        m128[fr] = Mr[128] * (2.f * kf);
       }
     }
     auto sel = [&](cf a0, cf a1) -> cf { return {sel_s(F25_L0, a0.x, a1.x), sel_s(F25_L0, a0.y, a1.y)}; };

@@ -395,11 +395,11 @@ __global__ __launch_bounds__(WAVES * 64, 3) void k_apply_fast512(Fast5Args A) {
     float ma[16], mb[16];
     float m256a, m256b;
     // (round 6) A frame outside [0, T) shares its transform with a real one: its spectrum comes out of the split as rounding
-    // residue of the partner's (1e-8), and its mask is ZERO -- not whatever row the address clamp lands on (a NaN in frame 0's
-    // float mask would otherwise travel through the packed inverse transform into frame T - 1 of an odd-length unit).
+    // residue of the partner's (1e-8), and its mask is ZERO (a zero SCALE: one select per frame -- a select per entry made the
+    // compiler branch around the mask loads, 52 -> 75 us) -- not whatever row the address clamp lands on.
+    const float ksA = validA ? ks : 0.f, ksB = validB ? ks : 0.f;
     if constexpr (KMASK) {
       const unsigned short *KA = A.K + offA, *KB = A.K + offB;
-      const float ksA = validA ? ks : 0.f, ksB = validB ? ks : 0.f;   // (integers: a zero scale is a zero mask)
 #pragma unroll
       for (int sl = 0; sl < 16; ++sl) {
         const int f = bin5(c, sl);
@@ -413,11 +413,11 @@ __global__ __launch_bounds__(WAVES * 64, 3) void k_apply_fast512(Fast5Args A) {
 #pragma unroll
       for (int sl = 0; sl < 16; ++sl) {
         const int f = bin5(c, sl);
-        ma[sl] = validA ? MA[f] * ks : 0.f;
-        mb[sl] = validB ? MB[f] * ks : 0.f;
+        ma[sl] = MA[f] * ksA;
+        mb[sl] = MB[f] * ksB;
       }
-      m256a = validA ? MA[256] * (2.f * ks) : 0.f;
-      m256b = validB ? MB[256] * (2.f * ks) : 0.f;
+      m256a = MA[256] * (2.f * ksA);
+      m256b = MB[256] * (2.f * ksB);
     }
     cf na[16], nb[16];
 #pragma unroll
