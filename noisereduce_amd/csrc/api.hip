@@ -1359,10 +1359,13 @@ static int ensure_ws(sg_handle* h, const Geom& g, int64_t ub, bool lean = false)
 // pipeline pieces (all enqueue on `st`)
 // ------------------------------------------------------------------------------------------
 // time slices for the column statistics: enough blocks to fill 256 CUs even for one unit
+#ifndef SG_STAT_SLICES_MAX
+#define SG_STAT_SLICES_MAX 64
+#endif
 static int stat_slices(const Geom& g, int64_t ub) {
   int64_t blocks = (int64_t)((g.F + 63) / 64) * ub;
   int64_t nts = (2048 + blocks - 1) / blocks;
-  nts = std::max<int64_t>(1, std::min<int64_t>(nts, std::min<int64_t>(64, std::max<int64_t>(1, g.T / 16))));
+  nts = std::max<int64_t>(1, std::min<int64_t>(nts, std::min<int64_t>(SG_STAT_SLICES_MAX, std::max<int64_t>(1, g.T / 16))));
   return (int)nts;
 }
 

@@ -456,7 +456,8 @@ __global__ __launch_bounds__(64 * STAT_TG) void k_colstats1(const double* __rest
 }
 
 // one workgroup = 64 bands of one unit; the STAT_TG thread groups split the slices
-constexpr int STAT1_MAXS = 16;  // slices per thread group (nts <= STAT_TG * STAT1_MAXS)
+constexpr int STAT1_MAXS = 16;  // slices per thread group (nts <= STAT_TG * STAT1_MAXS).  (round 6: 32 -- 128 slices -- measured: k_colstats1
+                                // 13.7 -> 10.1 us at n_fft = 256, 8.4 -> 7.5 at 1024, but k_colstats1_final 11 - 13 -> 16.6 us everywhere: reverted)
 // gc (variant S noise statistics, unit 0 only): the stationary gate's compare constants ride along instead of taking
 // a launch of their own (k_prep_thresh_lazy, fused.hpp: same arithmetic) -- T2[f] per band, and per BAND BLOCK the floor
 // test's bound on max|x| from that block's minimum threshold: alim_b[block].  The gate takes the minimum of the blocks'
