@@ -1425,7 +1425,10 @@ static int stage_stats(sg_handle* h, const View& v, const Geom& g, int64_t ub, d
       HIPCHK(h, stft_any<double>(h, v, g, ub, (double*)h->P.p, nullptr, nullptr, 1.0, st));
     }
     ProfScope ps(h, SG_STAGE_COLSTATS, st);
-    const int nts = std::min(stat_slices(g, ub), STAT_TG * STAT1_MAXS);
+    // (round 6) about 72 frames per slice: k_colstats1_final's time grows with the slice count faster than k_colstats1's falls
+    // (n_fft = 1024, T = 2345: 64 slices 8.4 + 13.2 us, 32 slices 9.8 + 9.2; n_fft = 256, T = 9375: 64 slices 13.7 + 11.1, 128 slices
+    // 10.1 + 16.6, 32 slices 22.9 + 8.8)
+    const int nts = (int)std::max<int64_t>(1, std::min<int64_t>(std::min(stat_slices(g, ub), STAT_TG * STAT1_MAXS), g.T / 72));
     int rc = ensure(h, h->part, (size_t)ub * nts * STAT1_NP * g.FS * 8);
     if (rc) return rc;
     dim3 grid((g.F + 63) / 64, (unsigned)ub, nts);
