@@ -1514,6 +1514,18 @@ static int stage_mag512(sg_handle* h, const View& v, const Geom& g, int64_t ub, 
   return SG_OK;
 }
 
+// seam hops of abutting apply / one-pass tiles at n_fft = 512 / 256 (fastpath.hpp: k_ola_seam); ARGS = Fast5Args / Fast25Args
+template <int HOP, int NF, typename ARGS>
+static int launch_seam_small(sg_handle* h, const ARGS& A, int64_t ub, hipStream_t st) {
+  if (A.n_tiles < 2) return SG_OK;
+  fast::SeamArgs S{};
+  S.view = A.view; S.g = A.g; S.om = A.om; S.h_begin = A.h_begin; S.h_end = A.h_end; S.normalize = A.normalize;
+  S.invn = A.invn; S.wsq = A.wsq; S.part = A.part; S.n_tiles = A.n_tiles;
+  hipLaunchKernelGGL((fast::k_ola_seam<HOP, NF>), dim3((unsigned)(A.n_tiles - 1), (unsigned)ub), dim3(HOP), 0, st, S);
+  HIPCHK(h, hipGetLastError());
+  return SG_OK;
+}
+
 static int stage_apply512(sg_handle* h, const View& v, const Geom& g, int64_t ub, const OutMap& om,
                           const float* mask_f /* nullptr: uint16 weight sums in h->K16 (natural bin order) */,
                           int normalize, hipStream_t st) {
@@ -1528,7 +1540,17 @@ static int stage_apply512(sg_handle* h, const View& v, const Geom& g, int64_t ub
   A.h_end = (om.p1 - 1 + g.padL) / 128 + 1;
   const int64_t nh = A.h_end - A.h_begin;
   if (nh <= 0) return SG_OK;
-  const dim3 grid((unsigned)((nh + 28) / 29), (unsigned)ub);
+  // (round 6) abutting tiles of 32 frames; the 3 hops that straddle two tiles as partial sums + k_ola_seam (fastpath.hpp)
+  const int64_t tiles = (nh + 3 + 31) / 32;
+  const bool seam = tiles >= 2 && !h->force_noseam;
+  A.part = nullptr;
+  A.n_tiles = (int)tiles;
+  if (seam) {
+    int rc = ensure(h, h->seam, (size_t)ub * tiles * 6 * 128 * sizeof(float));
+    if (rc) return rc;
+    A.part = (float*)h->seam.p;
+  }
+  const dim3 grid((unsigned)(seam ? tiles : (nh + 28) / 29), (unsigned)ub);
   if (mask_f) {
     auto kern = fast::k_apply_fast512<4, false>;
     HIPCHK(h, set_lds(reinterpret_cast<const void*>(kern), FAST5_LDS));
@@ -1539,6 +1561,7 @@ static int stage_apply512(sg_handle* h, const View& v, const Geom& g, int64_t ub
     hipLaunchKernelGGL(kern, grid, dim3(256), FAST5_LDS, st, A);
   }
   HIPCHK(h, hipGetLastError());
+  if (seam) return launch_seam_small<128, 32>(h, A, ub, st);
   return SG_OK;
 }
 
@@ -1661,6 +1684,9 @@ static int stage_onepass_small(sg_handle* h, const View& v, const View& vx, cons
 
 static const OnePassSmall O5_GEOM{128, fast::O5_NF, fast::O5_NH, fast::O5_TILE_WORDS, fast::O5_XW, fast::O5_MAX_NF, fast::O5_MAX_NT, 257,
                                   FAST5_LDS + 16 + 2048};
+// (abutting tiles + k_ola_seam: the default; SG_OPT_FORCE_NOSEAM keeps the overlapping tiles above)
+static const OnePassSmall O5_GEOM_SEAM{128, fast::O5_NF, fast::O5_NF, fast::O5_TILE_WORDS, fast::O5_XW, fast::O5_MAX_NF, fast::O5_MAX_NT, 257,
+                                       FAST5_LDS + 16 + 2048, 3};
 static bool onepass512_ok(const sg_handle* h, const Geom& g, const OutMap& om) {
   return h->fast5_ok && onepass_small_ok(h, g, om, O5_GEOM, h->o5tab);
 }
@@ -1668,7 +1694,18 @@ static int stage_onepass512(sg_handle* h, const View& v, const View& vx, const G
                             hipStream_t st) {
   fast::OnePass5Args P{};
   P.A = fast5_args(h, v, g);
+  const bool seam = !h->force_noseam;
+  if (seam) {
+    const int64_t hb = (om.p0 + g.padL) / 128, he = (om.p1 - 1 + g.padL) / 128 + 1;
+    const int64_t tiles = (he - hb + 3 + 31) / 32;
+    int rc = ensure(h, h->seam, (size_t)ub * tiles * 6 * 128 * sizeof(float));
+    if (rc) return rc;
+    P.A.part = (float*)h->seam.p;
+    P.A.n_tiles = (int)tiles;
+  }
+  fast::Fast5Args last{};
   auto launch = [&](const fast::OnePass5Args& Q, bool redo, dim3 grid) -> hipError_t {
+    last = Q.A;
     auto go = [&](auto kern) -> hipError_t {
       hipError_t e = set_lds(reinterpret_cast<const void*>(kern), O5_GEOM.lds);
       if (e != hipSuccess) return e;
@@ -1677,7 +1714,10 @@ static int stage_onepass512(sg_handle* h, const View& v, const View& vx, const G
     };
     return redo ? go(fast::k_gate_onepass512<4, true>) : go(fast::k_gate_onepass512<4, false>);
   };
-  return stage_onepass_small(h, v, vx, g, ub, om, st, O5_GEOM, P, h->o5tab, launch);
+  int rc = stage_onepass_small(h, v, vx, g, ub, om, st, seam ? O5_GEOM_SEAM : O5_GEOM, P, h->o5tab, launch);
+  if (rc || !seam) return rc;
+  ProfScope ps(h, SG_STAGE_APPLY_FAST, st);   // (after the second launch, if any: a redone unit rewrote its partials)
+  return launch_seam_small<128, 32>(h, last, ub, st);
 }
 
 // ------------------------------------------------------------------------------------------
@@ -1743,7 +1783,17 @@ static int stage_apply256(sg_handle* h, const View& v, const Geom& g, int64_t ub
   A.h_end = (om.p1 - 1 + g.padL) / 64 + 1;
   const int64_t nh = A.h_end - A.h_begin;
   if (nh <= 0) return SG_OK;
-  const dim3 grid((unsigned)((nh + 60) / 61), (unsigned)ub);
+  // (round 6) abutting tiles of 64 frames + k_ola_seam (see stage_apply512)
+  const int64_t tiles = (nh + 3 + 63) / 64;
+  const bool seam = tiles >= 2 && !h->force_noseam;
+  A.part = nullptr;
+  A.n_tiles = (int)tiles;
+  if (seam) {
+    int rc = ensure(h, h->seam, (size_t)ub * tiles * 6 * 64 * sizeof(float));
+    if (rc) return rc;
+    A.part = (float*)h->seam.p;
+  }
+  const dim3 grid((unsigned)(seam ? tiles : (nh + 60) / 61), (unsigned)ub);
   if (mask_f) {
     auto kern = fast::k_apply_fast256<4, false>;
     HIPCHK(h, set_lds(reinterpret_cast<const void*>(kern), FAST25_LDS));
@@ -1754,12 +1804,15 @@ static int stage_apply256(sg_handle* h, const View& v, const Geom& g, int64_t ub
     hipLaunchKernelGGL(kern, grid, dim3(256), FAST25_LDS, st, A);
   }
   HIPCHK(h, hipGetLastError());
+  if (seam) return launch_seam_small<64, 64>(h, A, ub, st);
   return SG_OK;
 }
 
 // (round 6) one-pass gate for n_fft = 256 (onepass256.hpp)
 static const OnePassSmall O25_GEOM{64, fast::O25_NF, fast::O25_NH, fast::O25_TILE_WORDS, fast::O25_XW, fast::O25_MAX_NF, fast::O25_MAX_NT,
                                    129, FAST25_LDS + 16 + 2048};
+static const OnePassSmall O25_GEOM_SEAM{64, fast::O25_NF, fast::O25_NF, fast::O25_TILE_WORDS, fast::O25_XW, fast::O25_MAX_NF, fast::O25_MAX_NT,
+                                        129, FAST25_LDS + 16 + 2048, 3};
 static bool onepass256_ok(const sg_handle* h, const Geom& g, const OutMap& om) {
   return h->fast25_ok && onepass_small_ok(h, g, om, O25_GEOM, h->o25tab);
 }
@@ -1767,7 +1820,18 @@ static int stage_onepass256(sg_handle* h, const View& v, const View& vx, const G
                             hipStream_t st) {
   fast::OnePass25Args P{};
   P.A = fast25_args(h, v, g);
+  const bool seam = !h->force_noseam;
+  if (seam) {
+    const int64_t hb = (om.p0 + g.padL) / 64, he = (om.p1 - 1 + g.padL) / 64 + 1;
+    const int64_t tiles = (he - hb + 3 + 63) / 64;
+    int rc = ensure(h, h->seam, (size_t)ub * tiles * 6 * 64 * sizeof(float));
+    if (rc) return rc;
+    P.A.part = (float*)h->seam.p;
+    P.A.n_tiles = (int)tiles;
+  }
+  fast::Fast25Args last{};
   auto launch = [&](const fast::OnePass25Args& Q, bool redo, dim3 grid) -> hipError_t {
+    last = Q.A;
     auto go = [&](auto kern) -> hipError_t {
       hipError_t e = set_lds(reinterpret_cast<const void*>(kern), O25_GEOM.lds);
       if (e != hipSuccess) return e;
@@ -1776,7 +1840,10 @@ static int stage_onepass256(sg_handle* h, const View& v, const View& vx, const G
     };
     return redo ? go(fast::k_gate_onepass256<4, true>) : go(fast::k_gate_onepass256<4, false>);
   };
-  return stage_onepass_small(h, v, vx, g, ub, om, st, O25_GEOM, P, h->o25tab, launch);
+  int rc = stage_onepass_small(h, v, vx, g, ub, om, st, seam ? O25_GEOM_SEAM : O25_GEOM, P, h->o25tab, launch);
+  if (rc || !seam) return rc;
+  ProfScope ps(h, SG_STAGE_APPLY_FAST, st);
+  return launch_seam_small<64, 64>(h, last, ub, st);
 }
 
 // ------------------------------------------------------------------------------------------

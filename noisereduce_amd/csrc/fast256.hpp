@@ -58,6 +58,8 @@ struct Fast25Args {
   int64_t h_begin, h_end;    // apply: ext hops (64-sample blocks, ext = unit sample + padL) to produce
   int normalize;
   FloorLazy fl;              // decide: in-kernel floor test (thresh.hpp), alim == nullptr: flags computed a priori
+  float* part;               // apply / one-pass gate, seam mode: [units][tiles][6][hop] un-normalised partial hops (3 leading, 3 trailing: k_ola_seam), else nullptr
+  int n_tiles;
   double iir_b;              // magnitude: the recurrence's b (non-stationary gate) ...
   double* sub;               // ... and its per-tile partials [units][tiles][2][FS] (fastpath.hpp: mag_sub_partials), or nullptr
 };
@@ -440,7 +442,8 @@ __global__ __launch_bounds__(WAVES * 64, 3) void k_apply_fast256(Fast25Args A) {
   const int64_t row = (A.view.unit0 + u) / A.view.n_chunks;
   const int64_t chunk = A.view.c0 + (A.view.unit0 + u) % A.view.n_chunks;
   constexpr int NF = F25_FPW * WAVES, NH = NF - 3;
-  const int64_t tf0 = A.h_begin - 3 + (int64_t)blockIdx.x * NH;   // first frame of the tile
+  const bool seam = A.part != nullptr;        // abutting tiles + k_ola_seam (fastpath.hpp), else tiles that overlap by 3 frames
+  const int64_t tf0 = A.h_begin - 3 + (int64_t)blockIdx.x * (seam ? NF : NH);   // first frame of the tile
   cf v[32];
   bool validX, validY;
   f25_gather<WAVES>(A, tw512, regions, swin, row, chunk, tf0, v, validX, validY);
@@ -548,15 +551,20 @@ __global__ __launch_bounds__(WAVES * 64, 3) void k_apply_fast256(Fast25Args A) {
   // hop (jj & 15) + 16 (fixed order: earlier wave first); 16 threads x float4 per hop
   const float* fr = reinterpret_cast<const float*>(regions);
   const int s4 = (tid & 15) * 4;
-  for (int jj = 3 + (tid >> 4); jj < NF; jj += (WAVES * 64) >> 4) {
+  for (int jj = (seam ? 0 : 3) + (tid >> 4); jj < (seam ? NF + 3 : NF); jj += (WAVES * 64) >> 4) {
     const int64_t h = tf0 + jj;
     if (h < A.h_begin || h >= A.h_end) continue;
-    const int wv = jj >> 4, lh = jj & 15;
+    const int wv = jj < NF ? jj >> 4 : WAVES - 1, lh = jj < NF ? jj & 15 : 16 + (jj - NF);   // (jj >= NF: the last wave's overflow rows)
     float4 a4 = make_float4(0.f, 0.f, 0.f, 0.f);
     if (wv >= 1 && lh <= 2) a4 = *reinterpret_cast<const float4*>(&fr[(wv - 1) * WAVE_CX_H * 2 + (lh + 16) * F25_HP + s4]);
     {
       const float4 f4 = *reinterpret_cast<const float4*>(&fr[wv * WAVE_CX_H * 2 + lh * F25_HP + s4]);
       a4.x += f4.x; a4.y += f4.y; a4.z += f4.z; a4.w += f4.w;
+    }
+    if (seam && (jj < 3 || jj >= NF)) {   // straddling hop: partial sum only; slots 0..2 leading, 3..5 trailing
+      const int slot = jj < 3 ? jj : 3 + (jj - NF);
+      *reinterpret_cast<float4*>(A.part + ((((size_t)u * A.n_tiles + blockIdx.x) * 6 + slot) * F25_H + s4)) = a4;
+      continue;
     }
     bool all_valid = true;
 #pragma unroll

@@ -476,6 +476,61 @@ __device__ __forceinline__ void fft512_inv(cf* v, cf* fb, const cf* tw512, int c
 constexpr int FPITCH_H = 256 + 16;
 constexpr int WAVE_CX_H = 4 * FPITCH_H;
 
+// (round 6) Abutting tiles for the packed-transform geometries (n_fft = 512 / 256) as at n_fft = 2048 (fast2048.hpp): a tile of NF frames
+// completes NF - 3 hops; the 3 hops that straddle two tiles leave as partial sums -- part[unit][tile][6][HOP]: slots 0..2 the tile's
+// leading hops, 3..5 its trailing ones -- and k_ola_seam combines them: hop tf0(b + 1) + k = trailing k of tile b + leading k of tile
+// b + 1 (fixed order), normalised and stored.  Overlapping tiles redo 3 of every 32 / 64 transforms AND make 10 % more tiles: on two
+// minutes of audio 1640 / 1560 workgroups for 768 resident slots (a third round for 104 / 24 of them) against 1490.
+struct SeamArgs {
+  View view;
+  Geom g;
+  OutMap om;
+  int64_t h_begin, h_end;
+  int normalize;
+  const float* invn;   // 1 / sum_q wsq[HOP q + s]
+  const float* wsq;    // window squared
+  const float* part;
+  int n_tiles;
+};
+template <int HOP, int NF>
+__global__ __launch_bounds__(HOP) void k_ola_seam(SeamArgs A) {
+  const Geom& G = A.g;
+  const int64_t u = blockIdx.y, b = blockIdx.x;
+  const int64_t row = (A.view.unit0 + u) / A.view.n_chunks;
+  const int64_t chunk = A.view.c0 + (A.view.unit0 + u) % A.view.n_chunks;
+  const int s = threadIdx.x;
+  const float* pa = A.part + ((u * A.n_tiles + b) * 6 + 3) * HOP;
+  const float* pb = A.part + ((u * A.n_tiles + b + 1) * 6 + 0) * HOP;
+  float va[3], vb[3];
+#pragma unroll
+  for (int k = 0; k < 3; ++k) { va[k] = pa[k * HOP + s]; vb[k] = pb[k * HOP + s]; }
+  const float inv = A.invn[s];
+#pragma unroll
+  for (int k = 0; k < 3; ++k) {
+    const int64_t h = A.h_begin - 3 + (int64_t)NF * (b + 1) + k;
+    if (h < A.h_begin || h >= A.h_end) continue;
+    float val = va[k] + vb[k];
+    if (A.normalize) {
+      if (h - 3 >= 0 && h < G.T) {
+        val *= inv;
+      } else {
+        float nrm = 0.f;
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+          const int64_t ti = h - q;
+          if (ti >= 0 && ti < G.T) nrm += A.wsq[HOP * q + s];
+        }
+        val /= (nrm > 1e-10f ? nrm : 1.f);
+      }
+    }
+    const int64_t p = h * HOP + s - G.padL;
+    if (p < A.om.p0 || p >= A.om.p1) continue;
+    const int64_t gi = chunk * A.om.g_step + (p - A.om.p0);
+    if (gi < A.om.g_lo || gi >= A.om.g_hi) continue;
+    store_sample(A.om.out, A.om.dtype, row * A.om.stride + gi - A.om.g0, p < G.Lout ? val : 0.f);
+  }
+}
+
 // (round 6) The |X| tile of a magnitude kernel as ONE piece of the non-stationary gate's time recurrence (nonstat.hpp: what
 // k_iir_part computes from the field in a pass of its own): per band  e = sum_t b c^(end-1-t) A[t]  and  E0 = sum_t b c^(t-start) s0[t]
 // (s0: zero-state forward response), float64, over the tile's first n frames.  Row r of the tile lives in the exchange slice of the

@@ -1,6 +1,6 @@
 // One-pass stationary gate for n_fft = win = 256, hop = 64 (round 6): k_gate_onepass512 (onepass512.hpp) on the transforms of
-// fast256.hpp -- four real frames per 512-point register transform, a tile of 64 frames (61 complete hops: tiles overlap by 3
-// frames, as k_apply_fast256), 129 bins = 3 bit words per frame.
+// fast256.hpp -- four real frames per 512-point register transform, a tile of 64 frames (abutting tiles + k_ola_seam by default,
+// 61 complete hops per tile with SG_OPT_FORCE_NOSEAM: onepass512.hpp), 129 bins = 3 bit words per frame.
 //
 //   k_decide_fast256 + k_smooth_bits2 + k_apply_fast256<K>   ->   k_gate_onepass256   (no bit field, no K field in HBM)
 //
@@ -89,7 +89,9 @@ __global__ __launch_bounds__(WAVES * 64, O25_OCC) void k_gate_onepass256(OnePass
   };
   stage_t2_plain<WAVES * 64, F25_F>(s_t2, A.tc.T2, need, 4.0, tid, t2eff);
   constexpr int NF = O25_NF, NH = O25_NH;
-  const int64_t tf0 = A.h_begin - 3 + (int64_t)jt * NH;   // first frame of the tile
+  const bool seam = A.part != nullptr;   // abutting tiles + k_ola_seam (fastpath.hpp); else tiles that overlap by 3 frames
+  const int step = seam ? NF : NH;       // frames from one tile to the next
+  const int64_t tf0 = A.h_begin - 3 + (int64_t)jt * step;   // first frame of the tile
   cf v[32];
   bool validX, validY;
   unsigned fl_mx = f25_gather<WAVES, true>(A, tw512, regions, swin, row, chunk, tf0, v, validX, validY);
@@ -97,8 +99,8 @@ __global__ __launch_bounds__(WAVES * 64, O25_OCC) void k_gate_onepass256(OnePass
     constexpr int SPAN = (NF - 1 + 4) * F25_H;
     const int64_t g0 = chunk * A.view.cs - A.view.pad;
     const int64_t s_lo = max<int64_t>(0, A.view.lo - g0), s_hi = min<int64_t>(A.view.Lp, A.view.hi - g0);
-    const int64_t sp0 = (A.h_begin - 3 - NH) * F25_H - G.padL;
-    const int64_t sp1 = (A.h_begin - 3 + (int64_t)P.n_tiles * NH) * F25_H - G.padL + SPAN;
+    const int64_t sp0 = (A.h_begin - 3 - step) * F25_H - G.padL;
+    const int64_t sp1 = (A.h_begin - 3 + (int64_t)P.n_tiles * step) * F25_H - G.padL + SPAN;
     const int64_t first = min(s_hi, max(s_lo, sp0)), last = max(s_lo, min(s_hi, sp1));
     const int64_t lenA = first - s_lo;
     const int64_t c0 = (int64_t)(jt + 1) * P.scan_q, c1 = min(c0 + P.scan_q, lenA + (s_hi - last));
@@ -250,9 +252,9 @@ __global__ __launch_bounds__(WAVES * 64, O25_OCC) void k_gate_onepass256(OnePass
     const int side = i >= nt * O25_XW;
     const int rem = i - side * nt * O25_XW;
     const int rr = rem / O25_XW, w = rem - rr * O25_XW;
-    // tile j - 1 holds frames tf0 - 61 ..: frame tf0 - nt + rr is its row 61 - nt + rr; tile j + 1: frame tf0 + 64 + rr is its row 3 + rr
-    const unsigned long long* src = side ? xb_mine + O25_TILE_WORDS + ((3 + rr) * O25_XW + w) * 2
-                                         : xb_mine - O25_TILE_WORDS + ((NH - nt + rr) * O25_XW + w) * 2;
+    // tile j - 1 holds frames tf0 - step ..: frame tf0 - nt + rr is its row step - nt + rr; tile j + 1: frame tf0 + 64 + rr is its row 64 - step + rr
+    const unsigned long long* src = side ? xb_mine + O25_TILE_WORDS + ((NF - step + rr) * O25_XW + w) * 2
+                                         : xb_mine - O25_TILE_WORDS + ((step - nt + rr) * O25_XW + w) * 2;
     op_v4u gr = op_ld16_sc1(src);
     for (int spin = 0; gr[1] != P.poll_epoch || gr[3] != P.poll_epoch; ++spin) {
       if (spin >= P.spin_max) {
@@ -394,10 +396,10 @@ __global__ __launch_bounds__(WAVES * 64, O25_OCC) void k_gate_onepass256(OnePass
   const float poison = s_misc[1] != 0u ? __uint_as_float(0x7fc00000u) : 0.f;
   const float* fr = reinterpret_cast<const float*>(regions);
   const int s4 = (tid & 15) * 4;
-  for (int jj = 3 + (tid >> 4); jj < NF; jj += (WAVES * 64) >> 4) {
+  for (int jj = (seam ? 0 : 3) + (tid >> 4); jj < (seam ? NF + 3 : NF); jj += (WAVES * 64) >> 4) {
     const int64_t h = tf0 + jj;
     if (h < A.h_begin || h >= A.h_end) continue;
-    const int wv = jj >> 4, lh = jj & 15;
+    const int wv = jj < NF ? jj >> 4 : WAVES - 1, lh = jj < NF ? jj & 15 : 16 + (jj - NF);   // (jj >= NF: the last wave's overflow rows)
     float4 a4 = make_float4(0.f, 0.f, 0.f, 0.f);
     if (wv >= 1 && lh <= 2) a4 = *reinterpret_cast<const float4*>(&fr[(wv - 1) * WAVE_CX_H * 2 + (lh + 16) * F25_HP + s4]);
     {
@@ -405,6 +407,11 @@ __global__ __launch_bounds__(WAVES * 64, O25_OCC) void k_gate_onepass256(OnePass
       a4.x += f4.x; a4.y += f4.y; a4.z += f4.z; a4.w += f4.w;
     }
     a4.x += poison; a4.y += poison; a4.z += poison; a4.w += poison;
+    if (seam && (jj < 3 || jj >= NF)) {   // straddling hop: partial sum only (poisoned with the tile); slots 0..2 leading, 3..5 trailing
+      const int slot = jj < 3 ? jj : 3 + (jj - NF);
+      *reinterpret_cast<float4*>(A.part + ((((size_t)u * A.n_tiles + jt) * 6 + slot) * F25_H + s4)) = a4;
+      continue;
+    }
     bool all_valid = true;
 #pragma unroll
     for (int q = 0; q < 4; ++q) {

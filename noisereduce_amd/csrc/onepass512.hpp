@@ -16,9 +16,10 @@
 //      idle between the two transforms: 3 workgroups per CU as k_apply_fast512.  (A first build ran both directions as
 //      sliding-window recurrences in LDS -- popcounts along f, two running boxcars along t: 203 us per two minutes where the three
 //      kernels it replaces take 103.)
-// then x mask -> inverse transform -> window -> overlap-add -> store exactly as k_apply_fast512<K>.  Tiles OVERLAP by 3 frames
-// as there (29 complete hops per tile, 9 % redundant transforms): no partial hops travel between workgroups, the bits are the
-// only exchange.  Inter-workgroup protocol, deadlock freedom (tickets; publish before wait), bounded polls and NaN-poisoned
+// then x mask -> inverse transform -> window -> overlap-add -> store exactly as k_apply_fast512<K>.  Tiles ABUT by default (A.part
+// set: the 3 hops that straddle two tiles leave as partial sums, k_ola_seam -- fastpath.hpp -- combines them after the launch: 1490
+// workgroups per two minutes instead of 1640, no redundant transforms) or, SG_OPT_FORCE_NOSEAM, overlap by 3 frames (29 complete
+// hops per tile); either way the bits are the only exchange INSIDE the launch.  Inter-workgroup protocol, deadlock freedom (tickets; publish before wait), bounded polls and NaN-poisoned
 // output of a tile that lost a hand-off: onepass.hpp.  The -top_db floor test runs on the staged samples (thresh.hpp:
 // FloorLazy); REDO = the second launch for the units whose test fired.  Any prop_decrease (a scale and an offset on the
 // mask entries).
@@ -102,7 +103,9 @@ __global__ __launch_bounds__(WAVES * 64, O5_OCC) void k_gate_onepass512(OnePass5
   };
   stage_t2_plain<WAVES * 64, F5_F>(s_t2, A.tc.T2, need, 4.0, tid, t2eff);
   constexpr int NF = O5_NF, NH = O5_NH;
-  const int64_t tf0 = A.h_begin - 3 + (int64_t)jt * NH;   // first frame of the tile
+  const bool seam = A.part != nullptr;   // abutting tiles + k_ola_seam (fastpath.hpp); else tiles that overlap by 3 frames
+  const int step = seam ? NF : NH;       // frames from one tile to the next
+  const int64_t tf0 = A.h_begin - 3 + (int64_t)jt * step;   // first frame of the tile
   cf v[32];
   bool validA, validB;
   unsigned fl_mx = f5_gather<WAVES, true>(A, tw512, regions, swin, row, chunk, tf0, G.T, v, validA, validB);
@@ -113,8 +116,8 @@ __global__ __launch_bounds__(WAVES * 64, O5_OCC) void k_gate_onepass512(OnePass5
     constexpr int SPAN = (NF - 1 + 4) * F5_H;
     const int64_t g0 = chunk * A.view.cs - A.view.pad;
     const int64_t s_lo = max<int64_t>(0, A.view.lo - g0), s_hi = min<int64_t>(A.view.Lp, A.view.hi - g0);
-    const int64_t sp0 = (A.h_begin - 3 - NH) * F5_H - G.padL;
-    const int64_t sp1 = (A.h_begin - 3 + (int64_t)P.n_tiles * NH) * F5_H - G.padL + SPAN;
+    const int64_t sp0 = (A.h_begin - 3 - step) * F5_H - G.padL;
+    const int64_t sp1 = (A.h_begin - 3 + (int64_t)P.n_tiles * step) * F5_H - G.padL + SPAN;
     const int64_t first = min(s_hi, max(s_lo, sp0)), last = max(s_lo, min(s_hi, sp1));
     const int64_t lenA = first - s_lo;
     const int64_t c0 = (int64_t)(jt + 1) * P.scan_q, c1 = min(c0 + P.scan_q, lenA + (s_hi - last));
@@ -291,9 +294,9 @@ __global__ __launch_bounds__(WAVES * 64, O5_OCC) void k_gate_onepass512(OnePass5
     const int side = i >= nt * O5_XW;
     const int rem = i - side * nt * O5_XW;
     const int rr = rem / O5_XW, w = rem - rr * O5_XW;
-    // tile j - 1 holds frames tf0 - 29 ..: frame tf0 - nt + rr is its row 29 - nt + rr; tile j + 1: frame tf0 + 32 + rr is its row 3 + rr
-    const unsigned long long* src = side ? xb_mine + O5_TILE_WORDS + ((3 + rr) * O5_XW + w) * 2
-                                         : xb_mine - O5_TILE_WORDS + ((NH - nt + rr) * O5_XW + w) * 2;
+    // tile j - 1 holds frames tf0 - step ..: frame tf0 - nt + rr is its row step - nt + rr; tile j + 1: frame tf0 + 32 + rr is its row 32 - step + rr
+    const unsigned long long* src = side ? xb_mine + O5_TILE_WORDS + ((NF - step + rr) * O5_XW + w) * 2
+                                         : xb_mine - O5_TILE_WORDS + ((step - nt + rr) * O5_XW + w) * 2;
     op_v4u gr = op_ld16_sc1(src);
     for (int spin = 0; gr[1] != P.poll_epoch || gr[3] != P.poll_epoch; ++spin) {
       if (spin >= P.spin_max) {   // bounded: report instead of hanging the device
@@ -443,10 +446,10 @@ __global__ __launch_bounds__(WAVES * 64, O5_OCC) void k_gate_onepass512(OnePass5
   const float poison = s_misc[1] != 0u ? __uint_as_float(0x7fc00000u) : 0.f;
   const float* fr = reinterpret_cast<const float*>(regions);
   const int s4 = (tid & 31) * 4;
-  for (int jj = 3 + (tid >> 5); jj < NF; jj += (WAVES * 64) >> 5) {
+  for (int jj = (seam ? 0 : 3) + (tid >> 5); jj < (seam ? NF + 3 : NF); jj += (WAVES * 64) >> 5) {
     const int64_t h = tf0 + jj;
     if (h < A.h_begin || h >= A.h_end) continue;
-    const int wv = jj >> 3, lh = jj & 7;
+    const int wv = jj < NF ? jj >> 3 : WAVES - 1, lh = jj < NF ? jj & 7 : 8 + (jj - NF);   // (jj >= NF: the last wave's overflow rows)
     float4 a4 = make_float4(0.f, 0.f, 0.f, 0.f);
     if (wv >= 1 && lh <= 2) a4 = *reinterpret_cast<const float4*>(&fr[(wv - 1) * WAVE_CX_H * 2 + (lh + 8) * F5_HP + s4]);
     {
@@ -454,6 +457,11 @@ __global__ __launch_bounds__(WAVES * 64, O5_OCC) void k_gate_onepass512(OnePass5
       a4.x += f4.x; a4.y += f4.y; a4.z += f4.z; a4.w += f4.w;
     }
     a4.x += poison; a4.y += poison; a4.z += poison; a4.w += poison;
+    if (seam && (jj < 3 || jj >= NF)) {   // straddling hop: partial sum only (poisoned with the tile); slots 0..2 leading, 3..5 trailing
+      const int slot = jj < 3 ? jj : 3 + (jj - NF);
+      *reinterpret_cast<float4*>(A.part + ((((size_t)u * A.n_tiles + jt) * 6 + slot) * F5_H + s4)) = a4;
+      continue;
+    }
     bool all_valid = true;
 #pragma unroll
     for (int q = 0; q < 4; ++q) {
