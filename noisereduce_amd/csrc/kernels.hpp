@@ -393,6 +393,9 @@ __global__ __launch_bounds__(64 * STAT_TG) void k_colstats(const double* __restr
 // recomputed exactly by its whole wave.
 // ---------------------------------------------------------------------------------------
 constexpr int STAT1_NP = 5;  // partials per (slice, band): max, min1, min2, s1, s2
+#ifndef STAT1_BATCH
+#define STAT1_BATCH 16
+#endif
 
 __device__ __forceinline__ void min2_push(double& m1, double& m2, double x) {  // keep the two smallest
   const double lo = fmin(m1, x), hi = fmax(m1, x);
@@ -420,16 +423,17 @@ __global__ __launch_bounds__(64 * STAT_TG) void k_colstats1(const double* __rest
     const double* col = P + (u * g.T) * g.FS + f;
     const double p0 = col[0];
     double pivot = 0.0;
-    for (int64_t t0 = tb + tg; t0 < te; t0 += 8 * STAT_TG) {
-      double pv[8];
+    constexpr int NB = STAT1_BATCH;   // cells in flight per thread
+    for (int64_t t0 = tb + tg; t0 < te; t0 += NB * STAT_TG) {
+      double pv[NB];
 #pragma unroll
-      for (int q = 0; q < 8; ++q) {
+      for (int q = 0; q < NB; ++q) {
         const int64_t t = t0 + q * STAT_TG;
         pv[q] = t < te ? col[t * g.FS] : 0.0;
       }
       if (t0 == tb + tg) pivot = cell_db(p0, mag_scale);   // (plain formula: k_colstats1_final recomputes it)
 #pragma unroll
-      for (int q = 0; q < 8; ++q) {
+      for (int q = 0; q < NB; ++q) {
         if (t0 + q * STAT_TG < te) {
           mx = fmax(mx, pv[q]);
           min2_push(m1, m2, pv[q]);
