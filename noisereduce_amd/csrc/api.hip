@@ -1362,6 +1362,9 @@ static int ensure_ws(sg_handle* h, const Geom& g, int64_t ub, bool lean = false)
 #ifndef SG_STAT_SLICES_MAX
 #define SG_STAT_SLICES_MAX 64
 #endif
+#ifndef SG_STAT_FRAMES_PER_SLICE
+#define SG_STAT_FRAMES_PER_SLICE 36   // k_colstats1 (stage_stats)
+#endif
 static int stat_slices(const Geom& g, int64_t ub) {
   int64_t blocks = (int64_t)((g.F + 63) / 64) * ub;
   int64_t nts = (2048 + blocks - 1) / blocks;
@@ -1425,10 +1428,10 @@ static int stage_stats(sg_handle* h, const View& v, const Geom& g, int64_t ub, d
       HIPCHK(h, stft_any<double>(h, v, g, ub, (double*)h->P.p, nullptr, nullptr, 1.0, st));
     }
     ProfScope ps(h, SG_STAGE_COLSTATS, st);
-    // (round 6) about 72 frames per slice: k_colstats1_final's time grows with the slice count faster than k_colstats1's falls
-    // (n_fft = 1024, T = 2345: 64 slices 8.4 + 13.2 us, 32 slices 9.8 + 9.2; n_fft = 256, T = 9375: 64 slices 13.7 + 11.1, 128 slices
-    // 10.1 + 16.6, 32 slices 22.9 + 8.8)
-    const int nts = (int)std::max<int64_t>(1, std::min<int64_t>(std::min(stat_slices(g, ub), STAT_TG * STAT1_MAXS), g.T / 72));
+    // (round 6) at least SG_STAT_FRAMES_PER_SLICE frames per slice, at most 64 slices.  Measured (k_colstats1 + k_colstats1_final, us):
+    // n_fft = 1024 (T = 2345): 64 slices 8.0 + 8.3, 32 slices 9.9 + 8.8; n_fft = 2048 (T = 1172): 32 slices 8.1 + 7.3, 16 slices 10.5 + 7.3,
+    // 64 slices 9.6 + 7.3.  (Before k_colstats1_final loaded its partials unconditionally it paid 0.08 us per slice: 13.2 us at 64.)
+    const int nts = (int)std::max<int64_t>(1, std::min<int64_t>(std::min(stat_slices(g, ub), STAT_TG * STAT1_MAXS), g.T / SG_STAT_FRAMES_PER_SLICE));
     int rc = ensure(h, h->part, (size_t)ub * nts * STAT1_NP * g.FS * 8);
     if (rc) return rc;
     dim3 grid((g.F + 63) / 64, (unsigned)ub, nts);

@@ -486,16 +486,30 @@ __global__ __launch_bounds__(64 * STAT_TG) void k_colstats1_final(const double* 
   double mx = 0.0, s1 = 0.0, s2 = 0.0;
   const double p0 = live ? P[(u * g.T) * g.FS + f] : 1.0;   // pivot cell: loaded with the partials, one round trip
   double m1[STAT1_MAXS];
+  {
+    // (round 6) every slice's four partials loaded UNCONDITIONALLY from a clamped address, selected afterwards: behind
+    // `if (live && ts < nts)` the loads of one slice waited for the previous slice's -- sixteen dependent round trips
+    const int fc = live ? f : g.F - 1;
+    double a0[STAT1_MAXS], a3[STAT1_MAXS], a4[STAT1_MAXS];
 #pragma unroll
-  for (int k = 0; k < STAT1_MAXS; ++k) {
-    const int ts = tg + STAT_TG * k;
-    m1[k] = 1e300;
-    if (live && ts < nts) {
-      const double* o = part + ((u * nts + ts) * STAT1_NP) * (int64_t)g.FS + f;
-      mx = fmax(mx, o[0]);
+    for (int k = 0; k < STAT1_MAXS; ++k) {
+      const int ts = tg + STAT_TG * k;
+      const double* o = part + ((u * nts + (ts < nts ? ts : nts - 1)) * STAT1_NP) * (int64_t)g.FS + fc;
+      a0[k] = o[0];
       m1[k] = o[g.FS];
-      s1 += o[3 * g.FS];
-      s2 += o[4 * g.FS];
+      a3[k] = o[3 * g.FS];
+      a4[k] = o[4 * g.FS];
+    }
+#pragma unroll
+    for (int k = 0; k < STAT1_MAXS; ++k) {
+      const bool on = live && tg + STAT_TG * k < nts;
+      if (on) {
+        mx = fmax(mx, a0[k]);
+        s1 += a3[k];
+        s2 += a4[k];
+      } else {
+        m1[k] = 1e300;
+      }
     }
   }
   r[0][tg][l] = mx;
