@@ -48,6 +48,9 @@ constexpr int OP_TAB_WIN = 0, OP_TAB_WSQ = 4096, OP_TAB_INVN = 8192, OP_TAB_TW51
 #ifndef OP_TRACE
 #define OP_TRACE 0
 #endif
+#ifndef OP_ARGCHECK
+#define OP_ARGCHECK 0
+#endif
 #ifndef OP_EXP_STALL_NS
 #define OP_EXP_STALL_NS 0   // development experiment (see OP_STAMP(4))
 #endif
@@ -320,6 +323,11 @@ __global__ __launch_bounds__(WAVES * 64, OP_OCC) void k_gate_onepass(OnePassArgs
   // ---- PERSIST: nothing of the arguments or the thread's indices survives an iteration (see above) ----
   const OnePassArgs& P = (PERSIST || OP_LATE_P) ? *late_args<OnePassArgs>() : Pk;
   int tid = threadIdx.x;
+#if OP_ARGCHECK
+  // (diagnosis) do the arguments re-read from the kernel-argument segment still equal the ones the kernel started with?
+  if (PERSIST && threadIdx.x == 0 && (P.total_tiles != Pk.total_tiles || P.epoch != Pk.epoch || P.xbits != Pk.xbits || P.A.view.x != Pk.A.view.x))
+    atomicOr_system(Pk.err, 0x80u);
+#endif
 #if OP_TRACE
   long long t_prev_ = clock64();   // (PERSIST: phase 0 = the wait at the loop-top barrier)
   unsigned* t_slot_ = nullptr;   // known once the ticket is
