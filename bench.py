@@ -60,7 +60,7 @@ ALGO_BYTES_PER_SAMPLE = 8           # 4 B float32 read + 4 B float32 written (SU
 HBM_PEAK_GBS = 8000.0               # MI355X_MICROARCH.md: 8 TB/s spec
 VALU_PEAK_TFLOPS = 157.3            # MI355X_MICROARCH.md: float32 vector peak (2.4 GHz)
 ALGO_FLOPS_PER_SAMPLE = 450         # two 1024-point real transforms per 256-sample hop, smoothing, log / compare / window / overlap-add
-TRAFFIC_DETAIL = "profiles/r06_v6_traffic_detail.json"   # rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes (tools/gpu_traffic.sh), committed
+TRAFFIC_DETAIL = "profiles/r06_v7_traffic_detail.json"   # rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes (tools/gpu_traffic.sh), committed
 C4_CHANNELS, C4_SAMPLES = 8, SR * 1800   # configs[3]: one GPU's share
 
 

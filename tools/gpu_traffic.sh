@@ -39,8 +39,9 @@ kf = GiB / (max(cal_f) * 1024) if cal_f else None
 kw = GiB / (max(cal_w) * 1024) if cal_w else None
 print("calibration factors (true bytes / (counter*1024)): fetch", kf, "write", kw)
 # (the gate's first launch; k_gate_onepass<4, false, false, true, false> is the second launch of the in-kernel floor test)
-# (round 6: <WAVES, PROP, LOSE, REDO, PERSIST> -- the persistent instantiation is the default first launch)
-names = {"k_gate_onepass<4, false, false, false, true>": "k_gate_onepass (fft+decide+smooth+mask+ifft+ola)",
+# (round 6: <WAVES, PROP, LOSE, REDO, PERSIST> -- the first launch is <..., false, false> by default, <..., false, true> with SG_OPT_TILE_ORDER 0)
+names = {"k_gate_onepass<4, false, false, false, false>": "k_gate_onepass (fft+decide+smooth+mask+ifft+ola)",
+         "k_gate_onepass<4, false, false, false, true>": "k_gate_onepass (fft+decide+smooth+mask+ifft+ola)",
          "k_unit_absmax": "k_unit_absmax+k_prep_thresh"}
 traffic = {}; detail = {}
 import re
