@@ -51,6 +51,9 @@ constexpr int OP_TAB_WIN = 0, OP_TAB_WSQ = 4096, OP_TAB_INVN = 8192, OP_TAB_TW51
 #ifndef OP_ARGCHECK
 #define OP_ARGCHECK 0
 #endif
+#ifndef OP_LATE_START_US
+#define OP_LATE_START_US 0
+#endif
 #ifndef OP_EXP_STALL_NS
 #define OP_EXP_STALL_NS 0   // development experiment (see OP_STAMP(4))
 #endif
@@ -218,6 +221,13 @@ __global__ __launch_bounds__(WAVES * 64, OP_OCC) void k_gate_onepass(OnePassArgs
   constexpr int SCAN_REG = 5;                     // floor-test slices up to 5 x 256 samples ride in registers
 
   if (REDO && Pk.alim[1] != Pk.tc.need_tag) return;   // second launch of a call none of whose units reported (the common case)
+#if OP_LATE_START_US
+  // (diagnosis) some workgroups of the persistent grid start late, as they do when another kernel holds their compute unit
+  if (PERSIST && (blockIdx.x % 5u) == 1u) {
+    const unsigned long long t0_ = wall_clock64();
+    while ((long long)(wall_clock64() - t0_) < (long long)OP_LATE_START_US * 100 * (1 + (blockIdx.x % 7u))) __builtin_amdgcn_s_sleep(8);
+  }
+#endif
   double t2pre[3];   // compare constants of entries tid, tid + 256 and 512 (they do not depend on the ticket)
   unsigned alim_v = 0u;
   {
