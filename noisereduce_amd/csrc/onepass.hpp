@@ -335,8 +335,18 @@ __global__ __launch_bounds__(WAVES * 64, OP_OCC) void k_gate_onepass(OnePassArgs
   int tid = threadIdx.x;
 #if OP_ARGCHECK
   // (diagnosis) do the arguments re-read from the kernel-argument segment still equal the ones the kernel started with?
+#if OP_ARGCHECK == 2
+  if (PERSIST && threadIdx.x == 1) {   // every word of the argument struct, by a thread that draws no ticket
+    const unsigned* a_ = reinterpret_cast<const unsigned*>(&P);
+    const unsigned* b_ = reinterpret_cast<const unsigned*>(&Pk);
+    bool same_ = true;
+    for (unsigned w_ = 0; w_ < sizeof(OnePassArgs) / 4; ++w_) same_ = same_ && a_[w_] == b_[w_];
+    if (!same_) atomicOr_system(Pk.err, 0x80u);
+  }
+#else
   if (PERSIST && threadIdx.x == 0 && (P.total_tiles != Pk.total_tiles || P.epoch != Pk.epoch || P.xbits != Pk.xbits || P.A.view.x != Pk.A.view.x))
     atomicOr_system(Pk.err, 0x80u);
+#endif
 #endif
 #if OP_TRACE
   long long t_prev_ = clock64();   // (PERSIST: phase 0 = the wait at the loop-top barrier)
