@@ -54,7 +54,17 @@ def b_n():
     out = sn.get_traces()
     if not torch.equal(out, ref_n): bad.append(("nonstationary", float((out - ref_n).abs().max())))
 xs = x.clone().requires_grad_()
+T_MODE = os.environ.get("T_MODE", "")   # (diagnosis) what the third thread runs: default TorchGate forward + backward; "fwd": forward only;
+mm = torch.randn(2048, 2048, device="cuda") if T_MODE == "matmul" else None      # "matmul": no kernel of this library at all
 def b_t():
+    if T_MODE == "fwd":
+        with torch.no_grad():
+            y = tg(x)
+        if not torch.equal(y, ref_y): bad.append(("torchgate fwd", float((y - ref_y).abs().max())))
+        return
+    if T_MODE == "matmul":
+        (mm @ mm).sum().item()
+        return
     xs.grad = None
     y = tg(xs); y.sum().backward()
     if not torch.equal(y.detach(), ref_y): bad.append(("torchgate fwd", float((y.detach() - ref_y).abs().max())))
