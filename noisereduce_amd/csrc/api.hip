@@ -55,6 +55,11 @@
 #endif
 #ifndef SG_CHAIN_PAR
 #define SG_CHAIN_PAR 1    // the non-stationary gate's tile chain in 16 parallel runs per band (nonstat.hpp: k_iir_chain_par); 0: A/B
+#if OP_TRACE
+static unsigned* g_trace_dev = nullptr;   // (development builds) the one-pass gate's phase trace of the last first launch: sg_debug_counter 8
+static size_t g_trace_tiles = 0;
+static int g_trace_ntt = 1;
+#endif
 #endif
 #ifndef SG_STATS_TEAM
 #define SG_STATS_TEAM 1   // float64 noise-clip transform of 1024 points (n_fft = 2048) by a whole workgroup (launch_stft_n); 0: A/B
@@ -106,6 +111,7 @@ struct sg_handle {
   DevBuf P, pmax, thr_rows, raw, M, seg, yn;
   DevBuf bits, K16, umax, need, T2;  // fused stationary path
   DevBuf nss;                        // non-stationary gate: recurrence partials of k_mag_fast's 16-frame blocks
+  DevBuf statdone;                   // k_colstats1 with the final stage inside: arrival counters [unit][band block], zero between launches
   DevBuf alim;                       // one-pass gate, in-kernel floor test: [1] tag of the last call that reported, [2..11) bounds on max|x| (k_colstats1_final / k_prep_thresh_lazy)
   bool t2_ready = false;             // T2 / alim hold the compare constants of the CURRENT threshold (any writer of thresh clears it)
   DevBuf logtab;                     // db_fast (kernels.hpp): {rd(1 / c_i), -log2 of it} for 128 mantissa centres
@@ -1302,7 +1308,7 @@ extern "C" int sg_destroy(sg_handle* h) {
                     &h->need, &h->T2, &h->part, &h->tw512, &h->invn, &h->seam, &h->ftab, &h->xbits, &h->xpart,
                     &h->xticket, &h->xtick2, &h->ftab3, &h->xexp, &h->optab, &h->nsp, &h->nsc, &h->xin, &h->czt_tw64, &h->czt_ch64,
                     &h->czt_bh64, &h->czt_tw32, &h->czt_ch32, &h->czt_bh32, &h->logtab, &h->big_twM, &h->big_tw2,
-                    &h->big_ch, &h->big_bh, &h->big_W, &h->big_W2, &h->xP, &h->xraw, &h->xM, &h->xtmp, &h->xseg, &h->invn5, &h->invn25, &h->invn20, &h->rg_count, &h->alim, &h->nss, &h->mr_pt32, &h->mr_pt64, &h->o5tab, &h->o25tab, &h->o20tab})
+                    &h->big_ch, &h->big_bh, &h->big_W, &h->big_W2, &h->xP, &h->xraw, &h->xM, &h->xtmp, &h->xseg, &h->invn5, &h->invn25, &h->invn20, &h->rg_count, &h->alim, &h->statdone, &h->nss, &h->mr_pt32, &h->mr_pt64, &h->o5tab, &h->o25tab, &h->o20tab})
     free_buf(*b);
   delete h;
   return SG_OK;
@@ -1437,10 +1443,7 @@ static int stage_stats(sg_handle* h, const View& v, const Geom& g, int64_t ub, d
     int rc = ensure(h, h->part, (size_t)ub * nts * STAT1_NP * g.FS * 8);
     if (rc) return rc;
     dim3 grid((g.F + 63) / 64, (unsigned)ub, nts);
-    hipLaunchKernelGGL(k_colstats1, grid, dim3(64 * STAT_TG), 0, st, (const double*)h->P.p, g, h->mag_scale,
-                       (double*)h->part.p, db_fast_consts(h));
-    HIPCHK(h, hipGetLastError());
-    // (for the stationary gate's noise statistics the final kernel also derives the gate's compare constants: no
+    // (for the stationary gate's noise statistics the final stage also derives the gate's compare constants: no
     // k_prep_thresh_lazy launch in the calls that follow)
     GateConsts gc{};
     if (gate_consts && ub == 1 && grid.x <= 62) {   // (one bound per 64-band block: 9 at n_fft = 1024, 33 at 4096)
@@ -1448,10 +1451,27 @@ static int stage_stats(sg_handle* h, const View& v, const Geom& g, int64_t ub, d
       if ((rc = ensure_zeroed(h, h->alim, 256, st))) return rc;
       gc.T2 = (double*)h->T2.p; gc.alim_b = (unsigned*)h->alim.p + 2; gc.sum_abs_w = h->sum_abs_w;
     }
-    hipLaunchKernelGGL(k_colstats1_final, dim3((unsigned)((g.FS + 63) / 64), (unsigned)ub), dim3(64 * STAT_TG), 0, st,
-                       (const double*)h->part.p, (const double*)h->P.p, g, nts, h->mag_scale, h->p.top_db,
-                       h->p.n_std_thresh, h->p.ddof, (double*)h->pmax.p, thresh_out, gc);
+    // (round 6) the final stage inside k_colstats1: the last workgroup of a (unit, band block) to finish its slice runs it --
+    // one dependent launch less (SG_STATS_FUSED=0 in the environment: the two-launch form, for A/B)
+    static const bool fused_final = [] { const char* e = getenv("SG_STATS_FUSED"); return !(e && e[0] == '0'); }();
+    const bool fin_on = fused_final && grid.x == (unsigned)((g.FS + 63) / 64) && !h->force_split;
+    Colstats1Fin fin{};
+    if (fin_on) {
+      if ((rc = ensure_zeroed(h, h->statdone, (size_t)ub * grid.x * 4, st))) return rc;
+      fin.done = (unsigned*)h->statdone.p;
+      fin.top_db = h->p.top_db; fin.n_std = h->p.n_std_thresh; fin.ddof = h->p.ddof;
+      fin.pmax = (double*)h->pmax.p; fin.thresh = thresh_out;
+      fin.T2 = gc.T2; fin.alim_b = gc.alim_b; fin.sum_abs_w = gc.sum_abs_w;
+    }
+    hipLaunchKernelGGL(k_colstats1, grid, dim3(64 * STAT_TG), 0, st, (const double*)h->P.p, g, h->mag_scale,
+                       (double*)h->part.p, db_fast_consts(h), fin);
     HIPCHK(h, hipGetLastError());
+    if (!fin_on) {
+      hipLaunchKernelGGL(k_colstats1_final, dim3((unsigned)((g.FS + 63) / 64), (unsigned)ub), dim3(64 * STAT_TG), 0, st,
+                         (const double*)h->part.p, (const double*)h->P.p, g, nts, h->mag_scale, h->p.top_db,
+                         h->p.n_std_thresh, h->p.ddof, (double*)h->pmax.p, thresh_out, gc);
+      HIPCHK(h, hipGetLastError());
+    }
     if (gc.T2 != nullptr) h->t2_ready = true;
     return SG_OK;
   }
@@ -2727,6 +2747,7 @@ static int stage_onepass(sg_handle* h, const View& v, const View& vx, const Geom
     }
     HIPCHK(h, hipMemsetAsync(tr, 0, slots * 64, st));
     P.trace = tr;
+    g_trace_dev = tr; g_trace_tiles = (size_t)ub * ntt; g_trace_ntt = (int)ntt;
   }
 #endif
   {
@@ -3803,6 +3824,38 @@ extern "C" int sg_debug_counter(sg_handle* h, int32_t which, int64_t* value, voi
   if (which == 3) {   // launch epoch of the last gate call in which a chunk's floor test fired / flag was set (0: never)
     HIPCHK(h, hipStreamSynchronize((hipStream_t)stream));
     *value = h->err_host ? (int64_t)h->err_host[1] : 0;
+    return SG_OK;
+  }
+#if OP_TRACE
+  if (which == 8) {
+    // (diagnosis) after a call that lost a hand-off: the tiles of the last first launch that did not run to the end -- who took
+    // their ticket (workgroup, iteration) and the last phase each of their four waves stamped -- on stderr; *value = their number
+    HIPCHK(h, hipStreamSynchronize((hipStream_t)stream));
+    std::vector<unsigned> t(g_trace_tiles * 64);
+    HIPCHK(h, hipMemcpy(t.data(), g_trace_dev, t.size() * 4, hipMemcpyDeviceToHost));
+    int64_t bad = 0;
+    auto last_phase = [&](size_t tk, int w) { int lp = -1; for (int k = 0; k < 14; ++k) if (t[(tk * 4 + w) * 16 + k]) lp = k; return lp; };
+    for (size_t tk = 0; tk < g_trace_tiles; ++tk) {
+      const int jt = (int)(tk % g_trace_ntt) - 1;
+      const bool halo = jt < 0 || jt >= g_trace_ntt - 2;
+      bool ok = true;
+      for (int w = 0; w < 4; ++w) ok = ok && (halo ? last_phase(tk, w) >= 5 : t[(tk * 4 + w) * 16 + 15] == 1u);
+      if (ok) continue;
+      if (++bad > 8) continue;
+      fprintf(stderr, "[trace] ticket %zu (unit %zu tile %d%s):", tk, tk / g_trace_ntt, jt, halo ? " halo" : "");
+      for (int w = 0; w < 4; ++w) {
+        const unsigned who = t[(tk * 4 + w) * 16 + 14];
+        fprintf(stderr, "  w%d wg %d iter %u last phase %d", w, (int)(who & 0xffffu) - 1, who >> 16, last_phase(tk, w));
+      }
+      fprintf(stderr, "\n");
+    }
+    *value = bad;
+    return SG_OK;
+  }
+#endif
+  if (which >= 4 && which <= 7) {   // development (-DOP_TILECOUNT=1 builds): tiles completed / sum of their tickets, persistent gate
+    HIPCHK(h, hipStreamSynchronize((hipStream_t)stream));
+    *value = h->err_host ? (int64_t)h->err_host[which] : 0;
     return SG_OK;
   }
   if (which != 0) FAIL(h, SG_E_INVALID, "sg_debug_counter: unknown counter %d", which);

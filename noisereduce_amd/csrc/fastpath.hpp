@@ -1587,6 +1587,8 @@ struct MagArgs {
 };
 constexpr int MAG_TILE_PITCH = 520;   // floats per frame row of the block's |X| tile in LDS (4 rows in each wave's exchange slice)
 
+// (round 6: a FOURTH workgroup per CU -- 128 registers: 10 spilled, and the window read from global memory / L1 instead of LDS to
+// get under 40 KB per workgroup -- measured 131 -> 151 us per ten minutes: DESIGN 8)
 template <int WAVES>
 __global__ __launch_bounds__(WAVES * 64, 3) void k_mag_fast(MagArgs A) {
   extern __shared__ __attribute__((aligned(16))) char smem[];

@@ -51,6 +51,9 @@ constexpr int OP_TAB_WIN = 0, OP_TAB_WSQ = 4096, OP_TAB_INVN = 8192, OP_TAB_TW51
 #ifndef OP_ARGCHECK
 #define OP_ARGCHECK 0
 #endif
+#ifndef OP_TILECOUNT
+#define OP_TILECOUNT 0
+#endif
 #ifndef OP_LATE_START_US
 #define OP_LATE_START_US 0
 #endif
@@ -276,6 +279,9 @@ __global__ __launch_bounds__(WAVES * 64, OP_OCC) void k_gate_onepass(OnePassArgs
       }
       for (int off = 1; off < 16; off <<= 1) alim_v = min(alim_v, (unsigned)__shfl_xor((int)alim_v, off));
       if (tid == 0) s_misc[2] = alim_v;   // (not a loop-carried register: it would live in scratch)
+#if OP_TILECOUNT == 2
+      if (tid == 0) { s_misc[3] = Pk.total_tiles; s_misc[6] = (unsigned)(uintptr_t)Pk.err; s_misc[7] = (unsigned)((uintptr_t)Pk.err >> 32); }
+#endif
     }
   }
   __syncthreads();
@@ -363,7 +369,21 @@ __global__ __launch_bounds__(WAVES * 64, OP_OCC) void k_gate_onepass(OnePassArgs
   const unsigned tk_slot = PERSIST ? 4u + (iter & 1u) : 0u;
   const int ntt = A.n_tiles + 2;                 // tiles per unit incl. one decide-only halo tile per side
   const unsigned ticket = PERSIST ? (unsigned)__builtin_amdgcn_readfirstlane((int)s_misc[tk_slot]) : s_misc[0];
+#if OP_TILECOUNT == 2
+  // (diagnosis) does the late read of total_tiles still equal what the workgroup saw when it started?  Reported through the err pointer
+  // stashed in LDS at the start (not a late read, and no by-value argument inside the loop)
+  if (PERSIST && threadIdx.x == 0 && P.total_tiles != s_misc[3]) {
+    unsigned* e_ = (unsigned*)(((uintptr_t)s_misc[7] << 32) | (uintptr_t)s_misc[6]);
+    atomicOr_system(e_, 0x40u);
+    atomicMax_system(e_ + 6, P.total_tiles);
+    atomicMax_system(e_ + 7, iter);
+  }
+  if (PERSIST && ticket >= s_misc[3]) return;
+#endif
   if (PERSIST && ticket >= P.total_tiles) return;   // (workgroup-uniform)
+#if OP_TILECOUNT == 1
+  if (PERSIST && threadIdx.x == 0) { atomicAdd_system(P.err + 4, 1u); atomicAdd_system(P.err + 5, ticket); }   // (diagnosis) every ticket taken up
+#endif
   if (PERSIST && tid == 0) {
     s_misc[1] = 0u;
 #if OP_TK_LATE
@@ -372,6 +392,7 @@ __global__ __launch_bounds__(WAVES * 64, OP_OCC) void k_gate_onepass(OnePassArgs
   }
 #if OP_TRACE
   t_slot_ = P.trace + ((size_t)ticket * 4 + wave) * 16;
+  if (lane == 0) t_slot_[14] = (blockIdx.x + 1u) | (iter << 16);   // who took the ticket up (sg_debug_counter 8 reads it after a lost hand-off)
 #endif
   OP_STAMP(0);   // tables + ticket
   const int64_t u = ticket / (unsigned)ntt;
