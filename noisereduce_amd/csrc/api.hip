@@ -111,7 +111,6 @@ struct sg_handle {
   DevBuf P, pmax, thr_rows, raw, M, seg, yn;
   DevBuf bits, K16, umax, need, T2;  // fused stationary path
   DevBuf nss;                        // non-stationary gate: recurrence partials of k_mag_fast's 16-frame blocks
-  DevBuf statdone;                   // k_colstats1 with the final stage inside: arrival counters [unit][band block], zero between launches
   DevBuf alim;                       // one-pass gate, in-kernel floor test: [1] tag of the last call that reported, [2..11) bounds on max|x| (k_colstats1_final / k_prep_thresh_lazy)
   bool t2_ready = false;             // T2 / alim hold the compare constants of the CURRENT threshold (any writer of thresh clears it)
   DevBuf logtab;                     // db_fast (kernels.hpp): {rd(1 / c_i), -log2 of it} for 128 mantissa centres
@@ -1308,7 +1307,7 @@ extern "C" int sg_destroy(sg_handle* h) {
                     &h->need, &h->T2, &h->part, &h->tw512, &h->invn, &h->seam, &h->ftab, &h->xbits, &h->xpart,
                     &h->xticket, &h->xtick2, &h->ftab3, &h->xexp, &h->optab, &h->nsp, &h->nsc, &h->xin, &h->czt_tw64, &h->czt_ch64,
                     &h->czt_bh64, &h->czt_tw32, &h->czt_ch32, &h->czt_bh32, &h->logtab, &h->big_twM, &h->big_tw2,
-                    &h->big_ch, &h->big_bh, &h->big_W, &h->big_W2, &h->xP, &h->xraw, &h->xM, &h->xtmp, &h->xseg, &h->invn5, &h->invn25, &h->invn20, &h->rg_count, &h->alim, &h->statdone, &h->nss, &h->mr_pt32, &h->mr_pt64, &h->o5tab, &h->o25tab, &h->o20tab})
+                    &h->big_ch, &h->big_bh, &h->big_W, &h->big_W2, &h->xP, &h->xraw, &h->xM, &h->xtmp, &h->xseg, &h->invn5, &h->invn25, &h->invn20, &h->rg_count, &h->alim, &h->nss, &h->mr_pt32, &h->mr_pt64, &h->o5tab, &h->o25tab, &h->o20tab})
     free_buf(*b);
   delete h;
   return SG_OK;
@@ -1443,35 +1442,25 @@ static int stage_stats(sg_handle* h, const View& v, const Geom& g, int64_t ub, d
     int rc = ensure(h, h->part, (size_t)ub * nts * STAT1_NP * g.FS * 8);
     if (rc) return rc;
     dim3 grid((g.F + 63) / 64, (unsigned)ub, nts);
-    // (for the stationary gate's noise statistics the final stage also derives the gate's compare constants: no
+    hipLaunchKernelGGL(k_colstats1, grid, dim3(64 * STAT_TG), 0, st, (const double*)h->P.p, g, h->mag_scale,
+                       (double*)h->part.p, db_fast_consts(h));
+    HIPCHK(h, hipGetLastError());
+    // (for the stationary gate's noise statistics the final kernel also derives the gate's compare constants: no
     // k_prep_thresh_lazy launch in the calls that follow)
+    // (round 6: the final stage INSIDE k_colstats1 -- run by the last workgroup of a band block to finish its slice -- measured:
+    // with __threadfence() around the arrival counter + 43 us per call, a device-scope release writes back the L2; fence-free
+    // (partials as sc1 stores, s_waitcnt vmcnt(0), counter, sc1 loads) + 2 / - 1 / + 0.5 / + 4 us at n_fft = 1024 / 256 / 512 /
+    // 2048: what the launch boundary costs the last arriver pays in memory round trips.  DESIGN 8, profiles/r06_stats_fused_ab.txt)
     GateConsts gc{};
     if (gate_consts && ub == 1 && grid.x <= 62) {   // (one bound per 64-band block: 9 at n_fft = 1024, 33 at 4096)
       if ((rc = ensure(h, h->T2, (size_t)g.FS * 8))) return rc;
       if ((rc = ensure_zeroed(h, h->alim, 256, st))) return rc;
       gc.T2 = (double*)h->T2.p; gc.alim_b = (unsigned*)h->alim.p + 2; gc.sum_abs_w = h->sum_abs_w;
     }
-    // (round 6) the final stage inside k_colstats1: the last workgroup of a (unit, band block) to finish its slice runs it --
-    // one dependent launch less (SG_STATS_FUSED=0 in the environment: the two-launch form, for A/B)
-    static const bool fused_final = [] { const char* e = getenv("SG_STATS_FUSED"); return !(e && e[0] == '0'); }();
-    const bool fin_on = fused_final && grid.x == (unsigned)((g.FS + 63) / 64) && !h->force_split;
-    Colstats1Fin fin{};
-    if (fin_on) {
-      if ((rc = ensure_zeroed(h, h->statdone, (size_t)ub * grid.x * 4, st))) return rc;
-      fin.done = (unsigned*)h->statdone.p;
-      fin.top_db = h->p.top_db; fin.n_std = h->p.n_std_thresh; fin.ddof = h->p.ddof;
-      fin.pmax = (double*)h->pmax.p; fin.thresh = thresh_out;
-      fin.T2 = gc.T2; fin.alim_b = gc.alim_b; fin.sum_abs_w = gc.sum_abs_w;
-    }
-    hipLaunchKernelGGL(k_colstats1, grid, dim3(64 * STAT_TG), 0, st, (const double*)h->P.p, g, h->mag_scale,
-                       (double*)h->part.p, db_fast_consts(h), fin);
+    hipLaunchKernelGGL(k_colstats1_final, dim3((unsigned)((g.FS + 63) / 64), (unsigned)ub), dim3(64 * STAT_TG), 0, st,
+                       (const double*)h->part.p, (const double*)h->P.p, g, nts, h->mag_scale, h->p.top_db,
+                       h->p.n_std_thresh, h->p.ddof, (double*)h->pmax.p, thresh_out, gc);
     HIPCHK(h, hipGetLastError());
-    if (!fin_on) {
-      hipLaunchKernelGGL(k_colstats1_final, dim3((unsigned)((g.FS + 63) / 64), (unsigned)ub), dim3(64 * STAT_TG), 0, st,
-                         (const double*)h->part.p, (const double*)h->P.p, g, nts, h->mag_scale, h->p.top_db,
-                         h->p.n_std_thresh, h->p.ddof, (double*)h->pmax.p, thresh_out, gc);
-      HIPCHK(h, hipGetLastError());
-    }
     if (gc.T2 != nullptr) h->t2_ready = true;
     return SG_OK;
   }

@@ -403,33 +403,9 @@ __device__ __forceinline__ void min2_push(double& m1, double& m2, double x) {  /
   m2 = fmin(m2, hi);
 }
 
-// (round 6, last session) FIN: k_colstats1_final's work done by the LAST workgroup of a (unit, band block) to finish its slice --
-// one dependent launch less per call (~4.7 us each on this device).  No fence: a device-scope release on this part
-// writes back the XCD's L2 (__threadfence() before the ticket and after it: + 43 us per call, measured).  Instead the partials
-// leave as device-scope relaxed atomic stores (write-through, sc1), wave 0 -- the only wave that stores them -- waits for
-// their acknowledgement (s_waitcnt vmcnt(0)) and then draws the workgroup's ticket on `fin.done[unit][band block]` (zero before
-// the launch; the last arriver resets it); the last arriver reads every slice's partials with device-scope relaxed atomic
-// loads (sc1: not a line its XCD's L2 may hold from an earlier launch).
-struct Colstats1Fin {
-  unsigned* done;       // nullptr: no finalisation in this launch (k_colstats1_final follows)
-  double top_db, n_std;
-  int ddof;
-  double* pmax;
-  double* thresh;
-  double* T2;           // GateConsts (below), flattened
-  unsigned* alim_b;
-  double sum_abs_w;
-};
-template <bool COH>
-__device__ __forceinline__ void colstats1_final_body(const double* part, const double* __restrict__ P, const Geom& g,
-                                                     int nts, double mag_scale, double top_db, double n_std, int ddof,
-                                                     double* __restrict__ pmax, double* __restrict__ thresh, double* gc_T2,
-                                                     unsigned* gc_alim_b, double gc_sum_abs_w, int bx, int64_t u,
-                                                     double (*r)[STAT_TG][64]);
-
 __global__ __launch_bounds__(64 * STAT_TG) void k_colstats1(const double* __restrict__ P, Geom g, double mag_scale,
                                                             double* __restrict__ part /* [u][nts][NP][FS] */,
-                                                            DbFast dbk, Colstats1Fin fin) {
+                                                            DbFast dbk) {
   __shared__ double r[STAT1_NP][STAT_TG][64];
   __shared__ __attribute__((aligned(16))) double s_tab[256];
   s_tab[threadIdx.x] = dbk.tab[threadIdx.x];   // 64 * STAT_TG = 256 threads
@@ -479,31 +455,8 @@ __global__ __launch_bounds__(64 * STAT_TG) void k_colstats1(const double* __rest
       s2 += r[4][i][l];
     }
     double* o = part + ((u * nts + ts) * STAT1_NP) * (int64_t)g.FS + f;
-    if (fin.done == nullptr) {
-      o[0] = mx; o[g.FS] = m1; o[2 * g.FS] = m2; o[3 * g.FS] = s1; o[4 * g.FS] = s2;
-    } else {
-      __hip_atomic_store(o, mx, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-      __hip_atomic_store(o + g.FS, m1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-      __hip_atomic_store(o + 2 * g.FS, m2, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-      __hip_atomic_store(o + 3 * g.FS, s1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-      __hip_atomic_store(o + 4 * g.FS, s2, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-    }
+    o[0] = mx; o[g.FS] = m1; o[2 * g.FS] = m2; o[3 * g.FS] = s1; o[4 * g.FS] = s2;
   }
-  if (fin.done == nullptr) return;   // (uniform)
-  __shared__ unsigned s_last;
-  if (tg == 0) {                     // (wave 0: the stores above are its own)
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-    if (threadIdx.x == 0) {
-      unsigned* d = fin.done + u * gridDim.x + blockIdx.x;
-      const unsigned n = __hip_atomic_fetch_add(d, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-      s_last = n == (unsigned)nts - 1u ? 1u : 0u;
-      if (n == (unsigned)nts - 1u) __hip_atomic_store(d, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);   // ready for the next launch
-    }
-  }
-  __syncthreads();
-  if (s_last == 0u) return;
-  colstats1_final_body<true>(part, P, g, nts, mag_scale, fin.top_db, fin.n_std, fin.ddof, fin.pmax, fin.thresh, fin.T2, fin.alim_b,
-                       fin.sum_abs_w, (int)blockIdx.x, u, r);
 }
 
 // one workgroup = 64 bands of one unit; the STAT_TG thread groups split the slices
@@ -518,20 +471,15 @@ struct GateConsts {
   unsigned* alim_b;     // [band blocks] bit patterns of the bounds
   double sum_abs_w;
 };
-// (r: three [STAT_TG][64] planes of shared memory; the caller's -- k_colstats1 lends the planes of its own reduction.
-// COH: the partials were written by other workgroups of THIS launch -- device-scope loads)
-template <bool COH>
-__device__ __forceinline__ void colstats1_final_body(const double* part, const double* __restrict__ P, const Geom& g,
-                                                     int nts, double mag_scale, double top_db, double n_std, int ddof,
-                                                     double* __restrict__ pmax, double* __restrict__ thresh, double* gc_T2,
-                                                     unsigned* gc_alim_b, double gc_sum_abs_w, int bx, int64_t u,
-                                                     double (*r)[STAT_TG][64]) {
-  auto ldp = [](const double* q) -> double {
-    if constexpr (COH) return __hip_atomic_load(q, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-    else return *q;
-  };
+__global__ __launch_bounds__(64 * STAT_TG) void k_colstats1_final(const double* __restrict__ part,
+                                                                  const double* __restrict__ P, Geom g, int nts,
+                                                                  double mag_scale, double top_db, double n_std,
+                                                                  int ddof, double* __restrict__ pmax,
+                                                                  double* __restrict__ thresh, GateConsts gc) {
+  __shared__ double r[3][STAT_TG][64];
   const int l = threadIdx.x & 63, tg = threadIdx.x >> 6;
-  const int f = bx * 64 + l;
+  const int f = blockIdx.x * 64 + l;
+  const int64_t u = blockIdx.y;
   const int64_t i = u * g.FS + f;
   const bool live = f < g.F;
   const double Tn = (double)g.T;
@@ -547,10 +495,10 @@ __device__ __forceinline__ void colstats1_final_body(const double* part, const d
     for (int k = 0; k < STAT1_MAXS; ++k) {
       const int ts = tg + STAT_TG * k;
       const double* o = part + ((u * nts + (ts < nts ? ts : nts - 1)) * STAT1_NP) * (int64_t)g.FS + fc;
-      a0[k] = ldp(o);
-      m1[k] = ldp(o + g.FS);
-      a3[k] = ldp(o + 3 * g.FS);
-      a4[k] = ldp(o + 4 * g.FS);
+      a0[k] = o[0];
+      m1[k] = o[g.FS];
+      a3[k] = o[3 * g.FS];
+      a4[k] = o[4 * g.FS];
     }
 #pragma unroll
     for (int k = 0; k < STAT1_MAXS; ++k) {
@@ -596,7 +544,7 @@ __device__ __forceinline__ void colstats1_final_body(const double* part, const d
         bool both = false;
         if ((km >> k) & 1u) {
           const double* o = part + ((u * nts + ts) * STAT1_NP) * (int64_t)g.FS + f;
-          const double a1 = ldp(o + g.FS), a2 = ldp(o + 2 * g.FS);
+          const double a1 = o[g.FS], a2 = o[2 * g.FS];
           both = a1 < Pfl && a2 < Pfl;     // a third floored cell of this slice would go unseen: rescan the slice
           if (a1 < Pfl && !both) {
             const double d = cell_db(a1, mag_scale) - pivot;
@@ -615,7 +563,7 @@ __device__ __forceinline__ void colstats1_final_body(const double* part, const d
         while (todo) {
           const int src = __ffsll((long long)todo) - 1;
           todo &= todo - 1;
-          const int fb = bx * 64 + src;
+          const int fb = blockIdx.x * 64 + src;
           const double Pfl_s = __shfl(Pfl, src), piv_s = __shfl(pivot, src), dfl_s = __shfl(dfl, src);
           const int64_t tb = g.T * ts / nts, te = g.T * (ts + 1) / nts;
           double c1 = 0.0, c2 = 0.0;
@@ -668,7 +616,7 @@ __device__ __forceinline__ void colstats1_final_body(const double* part, const d
   } else if (f < g.FS) {
     pmax[i] = 0.0;
   }
-  if (gc_T2 == nullptr || u != 0) return;
+  if (gc.T2 == nullptr || u != 0) return;
   // ---- the gate's compare constants for these 64 bands (wave 0 holds their thresholds) ----
   const double eps = 2.220446049250313e-16;
   double mn = 1e300;
@@ -683,27 +631,17 @@ __device__ __forceinline__ void colstats1_final_body(const double* part, const d
       const double tm = (exp10(thr_out / 20.0) - eps) / mag_scale;
       t2 = tm > 0.0 ? tm * tm : 0.0;
     }
-    gc_T2[f] = t2;
+    gc.T2[f] = t2;
     mn = fmin(mn, thr_out);
   }
   for (int off = 32; off > 0; off >>= 1) mn = fmin(mn, __shfl_xor(mn, off));
   if (l == 0) {
     // need  <=>  20 log10(max|x| sum|w| mag_scale + eps) + 1e-6 - top_db > min thresh   <=>   max|x| > lim
-    const double lim = (exp10((mn + top_db - 1e-6) / 20.0) - eps) / (gc_sum_abs_w * mag_scale);
+    const double lim = (exp10((mn + top_db - 1e-6) / 20.0) - eps) / (gc.sum_abs_w * mag_scale);
     unsigned bits = 0u;                        // lim <= 0 or NaN: every tile reports (the floor path is exact for every unit)
     if (lim > 0.0) bits = __float_as_uint(__double2float_rd(lim * (1.0 - 1e-6)));   // +Inf: only non-finite samples report
-    gc_alim_b[bx] = bits;
+    gc.alim_b[blockIdx.x] = bits;
   }
-}
-
-__global__ __launch_bounds__(64 * STAT_TG) void k_colstats1_final(const double* __restrict__ part,
-                                                                  const double* __restrict__ P, Geom g, int nts,
-                                                                  double mag_scale, double top_db, double n_std,
-                                                                  int ddof, double* __restrict__ pmax,
-                                                                  double* __restrict__ thresh, GateConsts gc) {
-  __shared__ double r[3][STAT_TG][64];
-  colstats1_final_body<false>(part, P, g, nts, mag_scale, top_db, n_std, ddof, pmax, thresh, gc.T2, gc.alim_b, gc.sum_abs_w,
-                       (int)blockIdx.x, (int64_t)blockIdx.y, r);
 }
 
 // thresh[u][f] = mean_t(dBfl) + n_std * std_t(dBfl)   (stationary.py:75-81; torchgate.py:158-160)
