@@ -2695,10 +2695,14 @@ static int stage_onepass(sg_handle* h, const View& v, const View& vx, const Geom
   }
   // three workgroups per CU (LDS) is what is resident at once; every workgroup ends on one ticket past the last tile
   static const int pg_per_cu = [] { const char* e = getenv("SG_ONEPASS_WG_PER_CU"); int v = e ? atoi(e) : 3; return v >= 1 && v <= 3 ? v : 3; }();   // (experiments: fewer resident workgroups)
+#if OP_MAX_ITERS == 1
+  const unsigned pgrid = persist ? (unsigned)(ub * ntt) : 0u;   // (diagnosis) one workgroup per tile, each draws its one ticket
+#else
   const unsigned pgrid = persist ? (unsigned)std::min<int64_t>(ub * ntt, (int64_t)pg_per_cu * h->n_cu) : 0u;
+#endif
   P.total_tiles = (unsigned)(ub * ntt);
   if (h->tile_order == 1) P.ticket_base = 0xffffffffu;   // SG_OPT_TILE_ORDER 1: tile = block index (no ticket)
-  else h->ticket_base += (unsigned)(ub * ntt) + pgrid;
+  else h->ticket_base += (unsigned)(ub * ntt) + (OP_MAX_ITERS == 1 ? 0u : pgrid);
   P.nf = h->p.n_grad_freq; P.nt = h->p.n_grad_time;
   P.prop = (float)h->p.prop_decrease;
   P.inv_ktot = 1.0f / (float)h->ktot;

@@ -54,6 +54,9 @@ constexpr int OP_TAB_WIN = 0, OP_TAB_WSQ = 4096, OP_TAB_INVN = 8192, OP_TAB_TW51
 #ifndef OP_TILECOUNT
 #define OP_TILECOUNT 0
 #endif
+#ifndef OP_MAX_ITERS
+#define OP_MAX_ITERS 0   // (diagnosis) 1: the persistent instantiation on a grid of one workgroup per tile, no second iteration -- is it the LOOP or the code?
+#endif
 #ifndef OP_LATE_START_US
 #define OP_LATE_START_US 0
 #endif
@@ -787,7 +790,11 @@ __global__ __launch_bounds__(WAVES * 64, OP_OCC) void k_gate_onepass(OnePassArgs
   if (halo_tile) {
     if constexpr (PERSIST) {
       // a halo tile ends here: its next ticket is drawn on the spot (two tiles in 149 at the default chunking)
+#if OP_MAX_ITERS == 1
+      if (tid == 0) s_misc[tk_slot ^ 1u] = 0xffffffffu;
+#else
       if (tid == 0) s_misc[tk_slot ^ 1u] = atomicAdd((unsigned*)(uintptr_t)OP_MARG(unsigned long long, ticket), 1u) - OP_MARG(unsigned, ticket_base);
+#endif
       pf = false;
       // (defined on this path too: left alone, the registers of the samples staged at the loop top would stay live up to here)
 #pragma unroll
@@ -872,7 +879,11 @@ __global__ __launch_bounds__(WAVES * 64, OP_OCC) void k_gate_onepass(OnePassArgs
   // the end of the smoothing stage: the atomic's round trip (~1.5 us) runs under the matrix-core work
   [[maybe_unused]] unsigned nx_raw = 0u;
   if constexpr (PERSIST) {
+#if OP_MAX_ITERS == 1
+    if (tid == 0) nx_raw = 0xffffffffu + OP_MARG(unsigned, ticket_base);   // "past the last tile": the workgroup leaves at the loop top
+#else
     if (tid == 0) nx_raw = atomicAdd((unsigned*)(uintptr_t)OP_MARG(unsigned long long, ticket), 1u);
+#endif
   }
   {
     const unsigned char* rp1 = wbb + r1 * WPB + 7 + q4;
