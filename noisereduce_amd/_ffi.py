@@ -490,11 +490,11 @@ class Gate:
         self._check(self.lib.sg_debug_range(self._h, r))
         return int(r[0]), int(r[1])
 
-    def debug_counter(self, which=0):
+    def debug_counter(self, which=0, value=0):
         """0: (row, band) pairs the row gate re-evaluated in float64 since the handle was created; 1 / 2: batches of the
         one-pass gate that took the in-kernel / the a-priori floor test (SG_OPT_FLOOR_TEST); 3: launch epoch of the last gate
         call in which a chunk's floor test fired."""
-        v = c_int64(0)
+        v = c_int64(int(value))   # (in: an argument of the development counters; 0 for the documented ones)
         with torch.cuda.device(self.device):
             self._check(self.lib.sg_debug_counter(self._h, int(which), ctypes.byref(v), self._stream()))
         return int(v.value)

@@ -55,6 +55,9 @@
 #endif
 #ifndef SG_CHAIN_PAR
 #define SG_CHAIN_PAR 1    // the non-stationary gate's tile chain in 16 parallel runs per band (nonstat.hpp: k_iir_chain_par); 0: A/B
+#if OP_WHO
+static unsigned* g_who_dev = nullptr;     // (development builds) per workgroup of the persistent gate: ticket started, iteration, ticket drawn next, stage
+#endif
 #if OP_TRACE
 static unsigned* g_trace_dev = nullptr;   // (development builds) the one-pass gate's phase trace of the last first launch: sg_debug_counter 8
 static size_t g_trace_tiles = 0;
@@ -2706,6 +2709,11 @@ static int stage_onepass(sg_handle* h, const View& v, const View& vx, const Geom
   P.nf = h->p.n_grad_freq; P.nt = h->p.n_grad_time;
   P.prop = (float)h->p.prop_decrease;
   P.inv_ktot = 1.0f / (float)h->ktot;
+#if OP_WHO
+  if (!g_who_dev) HIPCHK(h, hipMalloc((void**)&g_who_dev, 4096 * 16));
+  HIPCHK(h, hipMemsetAsync(g_who_dev, 0, 4096 * 16, st));
+  P.who = g_who_dev;
+#endif
 #if OP_TRACE
   {
     // development builds: one process-wide device trace [workgroup][wave][16], overwritten by every launch, averaged at exit
@@ -3846,7 +3854,25 @@ extern "C" int sg_debug_counter(sg_handle* h, int32_t which, int64_t* value, voi
     return SG_OK;
   }
 #endif
-  if (which >= 4 && which <= 7) {   // development (-DOP_TILECOUNT=1 builds): tiles completed / sum of their tickets, persistent gate
+#if OP_WHO
+  if (which == 16) {   // (diagnosis) the tickets around *value (in): who drew them while on which tile, who started them, on stderr
+    HIPCHK(h, hipStreamSynchronize((hipStream_t)stream));
+    std::vector<unsigned> w(4096 * 4);
+    HIPCHK(h, hipMemcpy(w.data(), g_who_dev, w.size() * 4, hipMemcpyDeviceToHost));
+    const long long T = *value;
+    if (T < 0) {   // everything, one line per ticket: ticket, drawer workgroup, its iteration, the tile it was on, starter workgroup, its iteration, past-bits flag
+      for (long long t = 0; t < 4096; ++t)
+        if (w[t * 4] | w[t * 4 + 2])
+          fprintf(stderr, "[whoall] %lld %d %u %u %d %u %u\n", t, (int)(w[t * 4] & 0xffffu) - 1, w[t * 4] >> 16, w[t * 4 + 1], (int)(w[t * 4 + 2] & 0xffffu) - 1, w[t * 4 + 2] >> 16, w[t * 4 + 3]);
+      return SG_OK;
+    }
+    for (long long t = std::max<long long>(0, T - 14); t <= std::min<long long>(4095, T + 3); ++t)
+      fprintf(stderr, "[who] ticket %lld: drawn by wg %d (iteration %u) while on tile %u; started by wg %d (iteration %u); past its bits poll: %u\n", t,
+              (int)(w[t * 4] & 0xffffu) - 1, w[t * 4] >> 16, w[t * 4 + 1], (int)(w[t * 4 + 2] & 0xffffu) - 1, w[t * 4 + 2] >> 16, w[t * 4 + 3]);
+    return SG_OK;
+  }
+#endif
+  if (which >= 4 && which <= 15) {   // development (-DOP_TILECOUNT=1 builds): tiles completed / sum of their tickets, persistent gate
     HIPCHK(h, hipStreamSynchronize((hipStream_t)stream));
     *value = h->err_host ? (int64_t)h->err_host[which] : 0;
     return SG_OK;

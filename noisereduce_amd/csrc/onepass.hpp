@@ -54,6 +54,23 @@ constexpr int OP_TAB_WIN = 0, OP_TAB_WSQ = 4096, OP_TAB_INVN = 8192, OP_TAB_TW51
 #ifndef OP_TILECOUNT
 #define OP_TILECOUNT 0
 #endif
+#ifndef OP_WHO
+#define OP_WHO 0   // (diagnosis) 1: a poll that gives up leaves its tile's ticket, what it waited for and the tag it saw in the error words 8..13
+#endif
+#ifndef OP_GLOBAL_DRAW
+#define OP_GLOBAL_DRAW 0   // (diagnosis) 1: the mid-tile ticket draws as GLOBAL atomics (the pointer re-read from the kernel-argument segment is a generic one: flat_atomic_add)
+#endif
+#if OP_GLOBAL_DRAW
+#define OP_DRAW_TICKET(p64) __hip_atomic_fetch_add((__attribute__((address_space(1))) unsigned*)(p64), 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)
+#else
+#define OP_DRAW_TICKET(p64) atomicAdd((unsigned*)(uintptr_t)(p64), 1u)
+#endif
+#ifndef OP_DRAW_TOP
+#define OP_DRAW_TOP 0   // (diagnosis, with -DOP_PF_AT=6) 1: the persistent loop draws its next ticket at the loop top -- no ticket is held while the previous tile is finished
+#endif
+#ifndef OP_RESTAGE
+#define OP_RESTAGE 0   // (diagnosis) 1: the persistent loop stages its LDS tables again in every iteration (is a table overwritten between tiles?)
+#endif
 #ifndef OP_MAX_ITERS
 #define OP_MAX_ITERS 0   // (diagnosis) 1: the persistent instantiation on a grid of one workgroup per tile, no second iteration -- is it the LOOP or the code?
 #endif
@@ -99,6 +116,9 @@ struct OnePassArgs {
   unsigned total_tiles;       // units * (n_tiles + 2): PERSIST workgroups draw tickets until they get one >= this
 #if OP_TRACE
   unsigned* trace;                   // [workgroups][4 waves][16] shader cycles per phase (slot 15 = 1: tile completed): development builds
+#endif
+#if OP_WHO
+  unsigned* who;                     // [ticket < 4096][4]: drawn by (workgroup + 1 | iteration << 16), while on tile, started by, past its bits poll -- development builds
 #endif
 };
 
@@ -364,6 +384,12 @@ __global__ __launch_bounds__(WAVES * 64, OP_OCC) void k_gate_onepass(OnePassArgs
   if constexpr (PERSIST) {
     asm volatile("" : "+v"(tid));
     if (iter != 0u) __syncthreads();   // the previous tile's epilogue has read every hop accumulator: the slices are free
+#if OP_DRAW_TOP
+    if (iter != 0u) {
+      if (threadIdx.x == 0) s_misc[4u + (iter & 1u)] = atomicAdd(P.ticket, 1u) - P.ticket_base;
+      __syncthreads();
+    }
+#endif
   }
   const ApplyArgs& A = P.A;
   const Geom& G = A.g;
@@ -383,9 +409,29 @@ __global__ __launch_bounds__(WAVES * 64, OP_OCC) void k_gate_onepass(OnePassArgs
   }
   if (PERSIST && ticket >= s_misc[3]) return;
 #endif
+#if OP_WHO
+  if (PERSIST && threadIdx.x == 0 && ticket < 4096u) P.who[ticket * 4 + 2] = (blockIdx.x + 1u) | (iter << 16);   // who started the tile
+#endif
   if (PERSIST && ticket >= P.total_tiles) return;   // (workgroup-uniform)
 #if OP_TILECOUNT == 1
   if (PERSIST && threadIdx.x == 0) { atomicAdd_system(P.err + 4, 1u); atomicAdd_system(P.err + 5, ticket); }   // (diagnosis) every ticket taken up
+#endif
+#if OP_RESTAGE
+  if (PERSIST && iter != 0u) {
+    const int t_ = threadIdx.x;
+    tw512[t_] = reinterpret_cast<const cf*>(P.tab + OP_TAB_TW512)[(t_ >> 4) * (t_ & 15)];
+    tw512[t_ + 256] = reinterpret_cast<const cf*>(P.tab + OP_TAB_TW512)[((t_ + 256) >> 4) * (t_ & 15)];
+    reinterpret_cast<float4*>(swin)[t_] = reinterpret_cast<const float4*>(P.tab + OP_TAB_WIN)[t_];
+    s_exp[t_] = reinterpret_cast<const unsigned long long*>(P.tab + OP_TAB_EXP8)[t_];
+#pragma unroll
+    for (int k = 0; k < 3; ++k) {
+      const int i = t_ + k * WAVES * 64;
+      if (i > 512) break;
+      const double v_ = P.tc.T2[perm_inv(i)];
+      s_t2[t2_pos(i)] = t2_to_f32(v_, 4.0);
+      s_t2d[i] = v_;
+    }
+  }
 #endif
   if (PERSIST && tid == 0) {
     s_misc[1] = 0u;
@@ -790,10 +836,10 @@ __global__ __launch_bounds__(WAVES * 64, OP_OCC) void k_gate_onepass(OnePassArgs
   if (halo_tile) {
     if constexpr (PERSIST) {
       // a halo tile ends here: its next ticket is drawn on the spot (two tiles in 149 at the default chunking)
-#if OP_MAX_ITERS == 1
+#if OP_MAX_ITERS == 1 || OP_DRAW_TOP
       if (tid == 0) s_misc[tk_slot ^ 1u] = 0xffffffffu;
 #else
-      if (tid == 0) s_misc[tk_slot ^ 1u] = atomicAdd((unsigned*)(uintptr_t)OP_MARG(unsigned long long, ticket), 1u) - OP_MARG(unsigned, ticket_base);
+      if (tid == 0) s_misc[tk_slot ^ 1u] = OP_DRAW_TICKET(OP_MARG(unsigned long long, ticket)) - OP_MARG(unsigned, ticket_base);
 #endif
       pf = false;
       // (defined on this path too: left alone, the registers of the samples staged at the loop top would stay live up to here)
@@ -865,6 +911,9 @@ __global__ __launch_bounds__(WAVES * 64, OP_OCC) void k_gate_onepass(OnePassArgs
     for (int spin = 0; !(OP_ABLATE & 2) && (LOSE || gr[1] != m_epoch || gr[3] != m_epoch); ++spin) {
       if (LOSE || spin >= OP_SPIN_MAX) {   // every spin is bounded: report instead of hanging the device
         atomicOr_system(m_err, 1u);
+#if OP_WHO
+        if (atomicAdd_system(m_err + 14, 1u) == 0u) { m_err[8] = m_ticket; m_err[9] = (unsigned)i; m_err[10] = gr[1]; m_err[11] = m_epoch; }
+#endif
         s_misc[1] = 1u;            // the tile's mask is unknown: every hop it finalises or hands on becomes NaN
         break;
       }
@@ -879,10 +928,10 @@ __global__ __launch_bounds__(WAVES * 64, OP_OCC) void k_gate_onepass(OnePassArgs
   // the end of the smoothing stage: the atomic's round trip (~1.5 us) runs under the matrix-core work
   [[maybe_unused]] unsigned nx_raw = 0u;
   if constexpr (PERSIST) {
-#if OP_MAX_ITERS == 1
+#if OP_MAX_ITERS == 1 || OP_DRAW_TOP
     if (tid == 0) nx_raw = 0xffffffffu + OP_MARG(unsigned, ticket_base);   // "past the last tile": the workgroup leaves at the loop top
 #else
-    if (tid == 0) nx_raw = atomicAdd((unsigned*)(uintptr_t)OP_MARG(unsigned long long, ticket), 1u);
+    if (tid == 0) nx_raw = OP_DRAW_TICKET(OP_MARG(unsigned long long, ticket));
 #endif
   }
   {
@@ -915,6 +964,14 @@ __global__ __launch_bounds__(WAVES * 64, OP_OCC) void k_gate_onepass(OnePassArgs
 #if !OP_TK_LATE
   if constexpr (PERSIST) {
     if (tid == 0) s_misc[tk_slot ^ 1u] = nx_raw - OP_MARG(unsigned, ticket_base);
+#if OP_WHO
+    if (tid == 0) {   // who drew the ticket, and while working on which tile
+      unsigned* w_ = (unsigned*)(uintptr_t)OP_MARG(unsigned long long, who);
+      const unsigned nx_ = nx_raw - OP_MARG(unsigned, ticket_base);
+      if (nx_ < 4096u) { w_[nx_ * 4] = (blockIdx.x + 1u) | (iter << 16); w_[nx_ * 4 + 1] = m_ticket; }
+      if (m_ticket < 4096u) w_[m_ticket * 4 + 3] = 1u;   // this tile is past its neighbours' bits
+    }
+#endif
   }
 #endif
   __syncthreads();  // K of all 16 frames complete; from here every wave touches only its own slice
@@ -1206,6 +1263,9 @@ __global__ __launch_bounds__(WAVES * 64, OP_OCC) void k_gate_onepass(OnePassArgs
           if ((OP_ABLATE & 16) || (!LOSE && ga[1] == e && ga[3] == e && gb[1] == e && gb[3] == e)) break;
           if (LOSE || spin >= OP_SPIN_MAX) {
             atomicOr_system(e_err, 2u);
+#if OP_WHO
+            if (atomicAdd_system(e_err + 15, 1u) == 0u) { e_err[12] = e_ticket; e_err[13] = ga[1]; }
+#endif
             ga[0] = ga[2] = gb[0] = gb[2] = 0x7fc00000u;   // the previous tile's share is unknown: NaN, not a partial sum
             break;
           }

@@ -19,9 +19,10 @@ def mm_loop():
         while not stop: (mm @ mm).sum().item()
 th = threading.Thread(target=mm_loop if not os.environ.get("NO_MM") else (lambda: None)); th.start()
 c0, s0 = g.debug_counter(4), g.debug_counter(5)
-per, bad = None, 0
+per, bad, slow = None, 0, 0.0
 for i in range(3000):
-    try: out = ss.get_traces()
+    t_call = time.perf_counter()
+    try: out = ss.get_traces(); torch.cuda.synchronize(); dt_ms = (time.perf_counter() - t_call) * 1e3; slow = max(slow, dt_ms) if i > 20 else slow
     except Exception as e:
         print("call", i, "raised", type(e).__name__); bad += 1
         try: g.check_errors()
@@ -35,12 +36,26 @@ for i in range(3000):
     ok = torch.equal(out, ref)
     if (dc, ds) != per or not ok:
         bad += 1
+        print("call", i, "took %.2f ms; slowest good call before it %.3f ms" % (dt_ms, slow), flush=True)
+        if os.environ.get("WHO") and bad == 1:   # (-DOP_WHO=1 library) the tickets around the first poll that gave up, before the next launch clears the record
+            t8 = g.debug_counter(8)
+            print("first bits poll that gave up: ticket", t8, "granule index", g.debug_counter(9), flush=True)
+            g.debug_counter(16, t8)
+            if os.environ.get("WHO") == "all": g.debug_counter(16, -1)
+            t12 = g.debug_counter(12)
+            print("first partial poll that gave up: ticket", t12, flush=True)
+            g.debug_counter(16, t12)
         if os.environ.get("TRACE_DUMP"):   # (-DOP_TRACE=1 library) the tiles that did not run to the end, before the next launch clears the trace
             try: print("incomplete tiles:", g.debug_counter(8), flush=True)
             except Exception as e: print("trace dump:", str(e)[:80])
         if bad <= 5: print("call", i, "tickets taken", dc, "sum", ds, "expected", per, "output equal", ok)
     if bad >= 5: break
 stop = True; th.join()
+if os.environ.get("WHO"):   # (-DOP_WHO=1 library) the first poll that gave up: its tile, what it waited for, the tag it saw
+    w = [g.debug_counter(k) for k in (9, 10, 11, 12, 13, 14, 15)]
+    try: w8 = g.debug_counter(8)
+    except Exception: w8 = -1
+    print("who: bits poll gave up in ticket", w8, "granule index", w[0], "tag seen", w[1], "epoch", w[2], "count", w[5], "| partial poll gave up in ticket", w[3], "tag seen", w[4], "count", w[6], flush=True)
 print("late total_tiles seen (max)", g.debug_counter(6), "at iteration (max)", g.debug_counter(7))
 try: g.check_errors(); print("no hand-off error")
 except Exception as e: print("ERR", str(e)[:80])

@@ -12,6 +12,7 @@ cd "$REPO"
 python bench.py > "$OUT/bench.json" 2> "$OUT/bench.err"
 python bench.py --workload config3 --no-cpu-baseline > "$OUT/bench_config3.json" 2>> "$OUT/bench.err"
 python bench.py --workload config4 --no-cpu-baseline --steps 10 --warmup 3 > "$OUT/bench_config4.json" 2>> "$OUT/bench.err"
+for S in 2 3; do python bench.py --streams $S --no-extras --no-cpu-baseline > "$OUT/bench_streams$S.json" 2>> "$OUT/bench.err"; done   # serving mode: S calls in flight (not the headline)
 tools/gpu_profile.sh ${TAG}k --no-extras > "$OUT/prof.log" 2>&1
 tools/gpu_profile.sh ${TAG}k3 --no-extras --workload config3 > "$OUT/prof3.log" 2>&1
 for t in ${TAG}k ${TAG}k3; do F=$(find gpurun_out/prof_$t -name '*kernel_stats.csv' | head -1); [ -n "$F" ] && (head -1 "$F"; grep "sg::" "$F") > "$OUT/${t}_kernel_stats.csv"; done
