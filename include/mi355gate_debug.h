@@ -27,7 +27,10 @@ SG_API int sg_debug_range(const sg_handle* h, int64_t range[2]);
  * re-evaluated in float64 since the handle was created (the float32 statistics could not decide them within their error
  * bound); divide by rows x 513 for the rate.  which = 1 / 2: batches of the one-pass gate that took the in-kernel / the a-priori
  * floor test (SG_OPT_FLOOR_TEST) since the handle was created (host counters, no synchronisation); which = 3: launch epoch of the
- * last gate call in which some chunk's floor test fired (0: never; synchronises). */
+ * last gate call in which some chunk's floor test fired (0: never; synchronises).  which = 4 .. 16: development builds of the
+ * persistent one-pass gate only (-DOP_TILECOUNT / -DOP_WHO / -DOP_TRACE libraries, tools/experiments/persist_*.py: words of the
+ * host-mapped error block; 8: unfinished tiles of the phase trace; 16: the per-ticket draw / start record around ticket *value,
+ * on stderr) -- they return 0 or SG_E_INVALID in the product library. */
 SG_API int sg_debug_counter(sg_handle* h, int32_t which, int64_t* value, void* stream);
 SG_API int sg_debug_fetch(sg_handle* h, int32_t what, void* host, int64_t bytes, void* stream);
 

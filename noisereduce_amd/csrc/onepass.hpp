@@ -54,6 +54,14 @@ constexpr int OP_TAB_WIN = 0, OP_TAB_WSQ = 4096, OP_TAB_INVN = 8192, OP_TAB_TW51
 #ifndef OP_TILECOUNT
 #define OP_TILECOUNT 0
 #endif
+#ifndef OP_BACKOFF
+#define OP_BACKOFF 0   // (diagnosis) 1: a poll that has missed 8 times sleeps ~3.5 us between tries instead of 64 cycles (is it the polls' own traffic?)
+#endif
+#if OP_BACKOFF
+#define OP_POLL_SLEEP(spin) do { if ((spin) >= 8) __builtin_amdgcn_s_sleep(127); else __builtin_amdgcn_s_sleep(1); } while (0)
+#else
+#define OP_POLL_SLEEP(spin) __builtin_amdgcn_s_sleep(1)
+#endif
 #ifndef OP_WHO
 #define OP_WHO 0   // (diagnosis) 1: a poll that gives up leaves its tile's ticket, what it waited for and the tag it saw in the error words 8..13
 #endif
@@ -917,7 +925,7 @@ __global__ __launch_bounds__(WAVES * 64, OP_OCC) void k_gate_onepass(OnePassArgs
         s_misc[1] = 1u;            // the tile's mask is unknown: every hop it finalises or hands on becomes NaN
         break;
       }
-      __builtin_amdgcn_s_sleep(1);
+      OP_POLL_SLEEP(spin);
       gr = op_ld16_sc1(src);
     }
     wb[(side ? m_nt + NF + rr : rr) * WP + 1 + w] = (unsigned long long)gr[0] | ((unsigned long long)gr[2] << 32);
@@ -1269,7 +1277,7 @@ __global__ __launch_bounds__(WAVES * 64, OP_OCC) void k_gate_onepass(OnePassArgs
             ga[0] = ga[2] = gb[0] = gb[2] = 0x7fc00000u;   // the previous tile's share is unknown: NaN, not a partial sum
             break;
           }
-          __builtin_amdgcn_s_sleep(1);
+          OP_POLL_SLEEP(spin);
         }
         a4.x = __uint_as_float(ga[0]) + a4.x;
         a4.y = __uint_as_float(ga[2]) + a4.y;
@@ -1328,7 +1336,7 @@ __global__ __launch_bounds__(WAVES * 64, OP_OCC) void k_gate_onepass(OnePassArgs
           ga[0] = ga[2] = gb[0] = gb[2] = 0x7fc00000u;
           break;
         }
-        __builtin_amdgcn_s_sleep(1);
+        OP_POLL_SLEEP(spin);
       }
       // trailing partial of the previous tile + leading partial of this one (the order k_ola_seam adds them in)
       a4.x = __uint_as_float(ga[0]) + a4.x;
