@@ -558,7 +558,9 @@ def main():
     gate = engine_gate()
     ev_oh = event_pair_overhead_ms()
     # untimed survey passes: one stage bracketed by HIP events at a time -> per-kernel table + dominant kernel
-    survey = per_stage_ms(gate, step, reps=4, ev_oh=ev_oh)
+    # (serving mode: steps rotate over the S handles; one survey call = S steps, of which exactly one runs on the profiled handle)
+    survey_fn = step if n_streams == 1 else (lambda: [step() for _ in range(n_streams)])
+    survey = per_stage_ms(gate, survey_fn, reps=4, ev_oh=ev_oh)
     dom = max(survey, key=lambda k: survey[k][0])
     # untimed settle loop on top of the W warm-up steps, DIRECTLY before the timed region: ~0.1 s of back-to-back steps
     # so that clock / power-state transitions of a GPU that was idle a moment ago happen BEFORE the timed steps.  (Up to
@@ -614,6 +616,7 @@ def main():
         # opening barrier the GPU queue is empty, so host time of the first step is exposed: one run showed 0.43 ms)
         for m in marks.values():
             m.record()
+    step_no[0] = 0   # (serving mode: the sampled steps i % E == 0 must land on the profiled handle, stream 0)
     sync()
     state_before = gpu_state()
     t0 = time.perf_counter()
