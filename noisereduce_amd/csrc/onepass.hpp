@@ -54,6 +54,9 @@ constexpr int OP_TAB_WIN = 0, OP_TAB_WSQ = 4096, OP_TAB_INVN = 8192, OP_TAB_TW51
 #ifndef OP_TILECOUNT
 #define OP_TILECOUNT 0
 #endif
+#ifndef OP_NO_LOOPTOP_WAIT
+#define OP_NO_LOOPTOP_WAIT 0   // (diagnosis) 1: without the explicit LDS wait before the persistent loop's top barrier (the state that lost hand-offs)
+#endif
 #ifndef OP_BACKOFF
 #define OP_BACKOFF 0   // (diagnosis) 1: a poll that has missed 8 times sleeps ~3.5 us between tries instead of 64 cycles (is it the polls' own traffic?)
 #endif
@@ -391,7 +394,18 @@ __global__ __launch_bounds__(WAVES * 64, OP_OCC) void k_gate_onepass(OnePassArgs
 #endif
   if constexpr (PERSIST) {
     asm volatile("" : "+v"(tid));
-    if (iter != 0u) __syncthreads();   // the previous tile's epilogue has read every hop accumulator: the slices are free
+    // (round 6, found with the builds listed in DESIGN 3: on the halo tiles' path to this barrier -- s_misc[next slot] = ticket;
+    // continue -- the compiler emits NO s_waitcnt lgkmcnt(0) between the ds_write and the s_barrier (gfx950 has no automatic
+    // wait before a barrier; the normal path's barrier has one).  Alone on the GPU the LDS write always landed before the other
+    // waves' read of the slot; next to a kernel that keeps the LDS queues busy a wave could read the slot's PREVIOUS content --
+    // the ticket of two tiles ago -- and the workgroup ran a tile with two different tickets: mis-gated tiles, lost hand-offs,
+    // wild addresses.  The wait is explicit now.)
+    if (iter != 0u) {
+#if !OP_NO_LOOPTOP_WAIT
+      asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+#endif
+      __syncthreads();   // the previous tile's epilogue has read every hop accumulator: the slices are free
+    }
 #if OP_DRAW_TOP
     if (iter != 0u) {
       if (threadIdx.x == 0) s_misc[4u + (iter & 1u)] = atomicAdd(P.ticket, 1u) - P.ticket_base;
