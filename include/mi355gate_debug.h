@@ -56,12 +56,11 @@ SG_API int sg_debug_fetch(sg_handle* h, int32_t what, void* host, int64_t bytes,
                                    * 2 = by the gate kernel on the samples it stages -- free unless a chunk reports, which is then gated a
                                    * second time with its float64 band maxima; 0 (default) = predicted from what recent calls on the handle
                                    * found (no synchronisation).  Same result either way: exact band maxima decide */
-#define SG_OPT_TILE_ORDER 15      /* one-pass gate (n_fft = 1024): how workgroups come by their tiles.  2 (default) = one ticket-drawn tile per
-                                   * workgroup (rounds 2-5).  0 = PERSISTENT workgroups (round 6): three per compute unit, each looping over
-                                   * atomic tickets -- constant tables staged once, the next ticket drawn and the next tile's samples
-                                   * prefetched under the current tile's second half: 1 % faster when the gate has the GPU to itself, opt-in
-                                   * because tests/tools/soak_handoff.py found it mis-gating a tile now and then (and losing hand-offs) while
-                                   * TorchGate's one-workgroup-per-CU row gate runs on a second stream; unresolved, see DESIGN.md section 3.
+#define SG_OPT_TILE_ORDER 15      /* one-pass gate (n_fft = 1024): how workgroups come by their tiles.  0 (default, round 6) = PERSISTENT
+                                   * workgroups: three per compute unit, each looping over atomic tickets -- constant tables staged once, the
+                                   * next ticket drawn and the next tile's samples prefetched under the current tile's second half (1 % faster
+                                   * than 2; bit-identical).  2 = one ticket-drawn tile per workgroup (rounds 2-5; REDO launches, a-priori floor
+                                   * flags and the fault-injection instantiation always run this form).
                                    * 1 = tile = block index -- no atomic at all, at the price of assuming that the dispatcher starts workgroups
                                    * in index order (it does on gfx950; HIP does not promise it).  Waits stay bounded and reported in every
                                    * mode; on an otherwise idle GPU the outputs are bit-identical */

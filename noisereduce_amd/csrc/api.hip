@@ -142,7 +142,7 @@ struct sg_handle {
   bool force_split = false;          // SG_OPT_FORCE_SPLIT: decide / smooth / apply as three kernels
   int rowgate_mode = 0;              // SG_OPT_FORCE_NOROWGATE: 0 = by batch size, 1 = never, 2 = whenever the shape is eligible
   int64_t n_floor_lazy = 0, n_floor_apriori = 0;   // sg_debug_counter 1 / 2
-  int tile_order = 2;                // SG_OPT_TILE_ORDER: 2 (default) = one ticket-drawn tile per workgroup (the kernel of rounds 2-5), 1 = tile =
+  int tile_order = 0;                // SG_OPT_TILE_ORDER: 0 (default, round 6) = persistent workgroups looping over tickets (onepass.hpp PERSIST), 2 = one ticket-drawn tile per workgroup (the kernel of rounds 2-5), 1 = tile = block index
                                      // block index (no ticket), 0 = persistent workgroups looping over tickets (round 6: 1 % faster alone on the
                                      // GPU, NOT the default -- next to TorchGate's row gate on a second stream it mis-gates a tile now and then:
                                      // tests/tools/soak_handoff.py)

@@ -308,8 +308,8 @@ def test_lost_handoff_poisons_torchgate_forward(nr):
 def test_gates_on_three_streams_at_once(n_fft):
     """tests/tools/soak_handoff.py for a few seconds: a stationary gate, a non-stationary gate and TorchGate forward + backward
     on three host threads / HIP streams; every result equals the same call run alone, bit for bit, no hand-off is lost.  (Round 6:
-    this is the test the persistent-workgroup form of k_gate_onepass -- SG_OPT_TILE_ORDER 0, opt-in -- fails next to TorchGate's
-    one-workgroup-per-CU row gate; the default kernels must not.)"""
+    this is the test the persistent-workgroup form of k_gate_onepass first failed next to TorchGate's one-workgroup-per-CU row
+    gate -- see test_persistent_gate_next_to_another_streams_kernels; it is the default kernel at n_fft = 1024 again.)"""
     import os
     import subprocess
     import sys
@@ -317,5 +317,24 @@ def test_gates_on_three_streams_at_once(n_fft):
     env = dict(os.environ, N_FFT=str(n_fft))
     env.pop("TILE_ORDER", None)
     r = subprocess.run([sys.executable, os.path.join(root, "tests", "tools", "soak_handoff.py"), "4"], env=env, cwd=root,
+                       capture_output=True, text=True, timeout=300)
+    assert r.returncode == 0 and "mismatches: none" in r.stdout, (r.stdout[-400:], r.stderr[-400:])
+
+
+@pytest.mark.parametrize("other", ["torchgate", "matmul"])
+def test_persistent_gate_next_to_another_streams_kernels(other):
+    """The persistent-workgroup form of k_gate_onepass (SG_OPT_TILE_ORDER 0) next to TorchGate forward + backward / a plain matmul
+    loop on a second stream: every output equals the one-tile kernel's, no hand-off is lost.  Round 6: this failed within a
+    second -- a missing wait for an LDS store before the barrier at the loop head, on the halo tiles' path (onepass.hpp,
+    DESIGN.md section 3; tests/test_isa_audit.py guards the ISA) -- and is the test that found it."""
+    import os
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = dict(os.environ, N_FFT="1024", TILE_ORDER="0", THREADS="s,t")
+    env.pop("T_MODE", None)
+    if other == "matmul":
+        env["T_MODE"] = "matmul"
+    r = subprocess.run([sys.executable, os.path.join(root, "tests", "tools", "soak_handoff.py"), "8"], env=env, cwd=root,
                        capture_output=True, text=True, timeout=300)
     assert r.returncode == 0 and "mismatches: none" in r.stdout, (r.stdout[-400:], r.stderr[-400:])

@@ -285,8 +285,8 @@ def test_onepass_floor_test_prediction_follows_the_data():
 
 
 def test_onepass_tile_order_option_same_output():
-    """SG_OPT_TILE_ORDER is an ordering choice only -- 2 one ticket-drawn tile per workgroup (default), 1 tile = block index,
-    0 persistent workgroups looping over tickets (round 6, opt-in): bit-identical output on an otherwise idle GPU."""
+    """SG_OPT_TILE_ORDER is an ordering choice only -- 0 persistent workgroups looping over tickets (round 6, default), 2 one
+    ticket-drawn tile per workgroup, 1 tile = block index: bit-identical output."""
     from noisereduce_amd import _ffi
     from noisereduce_amd.spectralgate.stationary import SpectralGateStationary
     y, y_noise, cs, pad = _floor_inputs("benign")
@@ -295,7 +295,7 @@ def test_onepass_tile_order_option_same_output():
               time_constant_s=2.0, freq_mask_smooth_hz=500, time_mask_smooth_ms=50, tmp_folder=None, use_tqdm=False,
               n_jobs=1)
     sg = SpectralGateStationary(y=y, **kw)
-    assert sg._gate.get_option(_ffi.SG_OPT_TILE_ORDER) == 2
+    assert sg._gate.get_option(_ffi.SG_OPT_TILE_ORDER) == 0
     a = sg.get_traces()
     outs = []
     try:
@@ -304,7 +304,7 @@ def test_onepass_tile_order_option_same_output():
             outs.append(sg.get_traces())
             outs.append(sg.get_traces())
     finally:
-        sg._gate.set_option(_ffi.SG_OPT_TILE_ORDER, 2)
+        sg._gate.set_option(_ffi.SG_OPT_TILE_ORDER, 0)
     for b in outs:
         assert np.array_equal(a, b)
     sg._gate.check_errors()
@@ -327,13 +327,13 @@ def test_onepass_persistent_equals_one_tile_per_workgroup(shape, prop):
               time_constant_s=2.0, freq_mask_smooth_hz=500, time_mask_smooth_ms=50, tmp_folder=None, use_tqdm=False,
               n_jobs=1)
     sg = SpectralGateStationary(y=y, **kw)
-    b = sg.get_traces()                     # default: one ticket-drawn tile per workgroup
     try:
-        sg._gate.set_option(_ffi.SG_OPT_TILE_ORDER, 0)
-        a = sg.get_traces()
-        a2 = sg.get_traces()
-    finally:
         sg._gate.set_option(_ffi.SG_OPT_TILE_ORDER, 2)
+        b = sg.get_traces()                 # one ticket-drawn tile per workgroup
+    finally:
+        sg._gate.set_option(_ffi.SG_OPT_TILE_ORDER, 0)
+    a = sg.get_traces()                     # default: persistent workgroups
+    a2 = sg.get_traces()
     assert np.array_equal(a, b) and np.array_equal(a, a2)
     sg._gate.check_errors()
     if n <= 48000 * 7 + 123:

@@ -113,7 +113,7 @@ def run_b(seed, res):
         g.set_option(_ffi.SG_OPT_TILE_ORDER, 2)
         b = sg.get_traces(**args)
     finally:
-        g.set_option(_ffi.SG_OPT_TILE_ORDER, 2)   # (the default)
+        g.set_option(_ffi.SG_OPT_TILE_ORDER, 0)   # (the default)
     g.check_errors()
     res["b_cases"] += 1
     if not (np.array_equal(a0, b, equal_nan=True) and np.array_equal(a0, a1, equal_nan=True)):

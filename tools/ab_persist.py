@@ -36,7 +36,7 @@ for m in MODES:
     prof = g.profile_read()
     kern[m] = {k: round(v[0] / 40, 4) for k, v in prof.items() if v[0] > 0}
 g.profile_enable(False)
-g.set_option(_ffi.SG_OPT_TILE_ORDER, 2)   # (the default)
+g.set_option(_ffi.SG_OPT_TILE_ORDER, 0)   # (the default)
 g.check_errors()
 print(json.dumps({"samples": int(y.numel()), "wall_ms_per_call": {m: [round(x, 4) for x in v] for m, v in wall.items()},
                   "wall_ms_median": {m: round(sorted(v)[len(v) // 2], 4) for m, v in wall.items()}, "event_ms": kern}))
