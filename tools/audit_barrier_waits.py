@@ -58,7 +58,9 @@ def audit(name, body):
             pass
         elif i + 1 < len(blocks):
             succ[i].append(i + 1)
-    is_write = lambda t: re.match(r'^ds_(write|add|sub|min|max|and|or|xor|inc|dec|cmpst|wrxchg|append|consume|swizzle)?', t) and t.startswith('ds_') and not t.startswith('ds_read') and not t.startswith('ds_bpermute') and not t.startswith('ds_permute') and not t.startswith('ds_swizzle')
+    reads_too = bool(__import__('os').environ.get('AUDIT_READS'))   # AUDIT_READS=1: LDS reads count as well (a later overwrite by another wave)
+    is_write0 = lambda t: re.match(r'^ds_(write|add|sub|min|max|and|or|xor|inc|dec|cmpst|wrxchg|append|consume|swizzle)?', t) and t.startswith('ds_') and not t.startswith('ds_read') and not t.startswith('ds_bpermute') and not t.startswith('ds_permute') and not t.startswith('ds_swizzle')
+    is_write = lambda t: is_write0(t) or (reads_too and t.startswith('ds_read'))
     clears = lambda t: t.startswith('s_waitcnt') and 'lgkmcnt(0)' in t
     pend_in = [False] * len(blocks)
     found = set()
