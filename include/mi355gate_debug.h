@@ -59,7 +59,9 @@ SG_API int sg_debug_fetch(sg_handle* h, int32_t what, void* host, int64_t bytes,
 #define SG_OPT_TILE_ORDER 15      /* one-pass gate (n_fft = 1024): how workgroups come by their tiles.  0 (default, round 6) = PERSISTENT
                                    * workgroups: three per compute unit, each looping over atomic tickets -- constant tables staged once, the
                                    * next ticket drawn and the next tile's samples prefetched under the current tile's second half (1 % faster
-                                   * than 2; bit-identical).  2 = one ticket-drawn tile per workgroup (rounds 2-5; REDO launches, a-priori floor
+                                   * than 2 for one call at a time; bit-identical).  2 = one ticket-drawn tile per workgroup (rounds 2-5: the better form when SEVERAL
+                                   * calls are in flight on their own handles and streams -- persistent workgroups hold every workgroup slot until their launch
+                                   * ends: 111 against 97 Gsamples/s at two calls in flight, bench.py --streams; REDO launches, a-priori floor
                                    * flags and the fault-injection instantiation always run this form).
                                    * 1 = tile = block index -- no atomic at all, at the price of assuming that the dispatcher starts workgroups
                                    * in index order (it does on gfx950; HIP does not promise it).  Waits stay bounded and reported in every
