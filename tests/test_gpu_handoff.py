@@ -304,7 +304,7 @@ def test_lost_handoff_poisons_torchgate_forward(nr):
     assert torch.equal(tg(x), good)
 
 
-@pytest.mark.parametrize("n_fft", [1024, 512, 2048])
+@pytest.mark.parametrize("n_fft", [1024, 512, 2048, -1024])
 def test_gates_on_three_streams_at_once(n_fft):
     """tests/tools/soak_handoff.py for a few seconds: a stationary gate, a non-stationary gate and TorchGate forward + backward
     on three host threads / HIP streams; every result equals the same call run alone, bit for bit, no hand-off is lost.  (Round 6:
@@ -314,8 +314,10 @@ def test_gates_on_three_streams_at_once(n_fft):
     import subprocess
     import sys
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-    env = dict(os.environ, N_FFT=str(n_fft))
+    env = dict(os.environ, N_FFT=str(abs(n_fft)))
     env.pop("TILE_ORDER", None)
+    if n_fft < 0:
+        env["TILE_ORDER"] = "2"   # (-1024: the one-tile-per-workgroup form of the n_fft = 1024 gate, what serving mode runs)
     r = subprocess.run([sys.executable, os.path.join(root, "tests", "tools", "soak_handoff.py"), "4"], env=env, cwd=root,
                        capture_output=True, text=True, timeout=300)
     assert r.returncode == 0 and "mismatches: none" in r.stdout, (r.stdout[-400:], r.stderr[-400:])
