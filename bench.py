@@ -800,7 +800,9 @@ def main():
                        "samples_per_gpu": samples_per_gpu,
                        "sharding": "channels (8 per GPU), all-reduce of the clip's channel sum" if wl == "config4"
                                    else "time (chunk-aligned), seam all-gather",
-                       "calls_in_flight": n_streams},
+                       "calls_in_flight": n_streams,
+                       **({"gate_form": "one ticket-drawn tile per workgroup (SG_OPT_TILE_ORDER 2: serving mode)"}
+                          if n_streams > 1 and wl == "config2" else {})},
             "roofline": {"bound": "hbm", "kernel": dom, "achieved": round(achieved, 2), "peak": HBM_PEAK_GBS,
                          "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBS, 5), "traffic": traffic,
                          "traffic_source": traffic_src,
